@@ -1,0 +1,220 @@
+/*
+ * omg_hip.h — C ABI of libomg_hip.so, the MI355X (gfx950) CHOMP trajectory-update engine.
+ *
+ * Drop-in boundary for the hot path of liruiw/OMG-Planner.  Every entry point
+ *   - takes plain device pointers + sizes (no torch types),
+ *   - is asynchronous on the hipStream_t passed as `stream` (void*, NULL = default stream),
+ *   - returns OMGX_OK or a negative error code and NEVER exits the process
+ *     (the reference does `exit(-1)` on a launch error: layers/sdf_matching_loss_kernel.cu:241-246).
+ *
+ * All pointers are DEVICE pointers unless the name starts with `h_`.
+ * Reference citations are file:line into liruiw/OMG-Planner.
+ */
+#ifndef OMG_HIP_H
+#define OMG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------------------------------------
+ * Error codes
+ * ------------------------------------------------------------------------------------------- */
+#define OMGX_OK 0
+#define OMGX_ERR_INVALID (-1)     /* null pointer / bad size / unsupported combination of sizes */
+#define OMGX_ERR_LAUNCH (-2)      /* HIP reported a launch error; text via omgx_last_error()      */
+#define OMGX_ERR_UNSUPPORTED (-3) /* a size beyond what this build supports (see limits below)    */
+
+/* Compile-time limits of this build. */
+#define OMGX_NUM_LINKS 10        /* Panda: 7 arm links + hand + 2 fingers (omg/core.py:166-190)   */
+#define OMGX_NUM_DOF 9           /* 7 arm joints + 2 finger joints                                 */
+#define OMGX_MAX_POINTS 16       /* collision points per link (cfg.collision_point_num = 15)       */
+#define OMGX_MAX_WAYPOINTS 64    /* cfg.timesteps (30 default, 50 in the PyBullet drivers)         */
+#define OMGX_MAX_CONSTRAINTS 8   /* cfg.reach_tail_length (5) or 1                                 */
+#define OMGX_INFO_STRIDE 16      /* doubles per trajectory in the info record                      */
+
+/* ---------------------------------------------------------------------------------------------
+ * Robot constants blob (double, device).  Raw tables of ycb_render/robotPose/robot_p3.pkl in the
+ * order used by robot_pykdl.py:148-215, followed by the sampled collision points and joint limits.
+ *   [  0,160)  pose_0        [10][4][4]
+ *   [160,320)  tip2joint     [10][4][4]
+ *   [320,480)  center_offset [10][4][4]
+ *   [480,510)  joint_axis    [10][3]
+ *   [510,519)  joint_lower_limit [9]   (omg/core.py:157-164, already padded by soft_joint_limit_padding)
+ *   [519,528)  joint_upper_limit [9]
+ *   [528,528+10*P*3) collision_points [10][P][3]  (Robot.collision_points, omg/core.py:166-190)
+ * ------------------------------------------------------------------------------------------- */
+#define OMGX_ROBOT_POSE0 0
+#define OMGX_ROBOT_TIP2JOINT 160
+#define OMGX_ROBOT_CENTER_OFFSET 320
+#define OMGX_ROBOT_JOINT_AXIS 480
+#define OMGX_ROBOT_LOWER 510
+#define OMGX_ROBOT_UPPER 519
+#define OMGX_ROBOT_POINTS 528
+
+/* ---------------------------------------------------------------------------------------------
+ * Scene object table.  One 128-byte record per obstacle/target object; replaces the five per-call
+ * host->device copies of Cost.compute_obstacle_cost_layer (omg/cost.py:303-335) and the
+ * pad-to-max `sdf_torch[O,X,Y,Z]` + `sdf_limits[O,10]` contract of Env.combine_sdfs
+ * (omg/core.py:366-411).  `grid_offset` lets grids live ragged in one float pool; the reference's
+ * padded layout is the special case grid_offset = o*X*Y*Z, dim = (X,Y,Z), hi = stretched max.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct omgx_object {
+    float pose_inv[12];  /* rows 0..2 of se3_inverse(obj.pose_mat), row-major [3][4] (omg/util.py:129-135) */
+    float lo[3];         /* sdf_limits[0:3]  min coords                                              */
+    float hi[3];         /* sdf_limits[3:6]  (stretched) max coords                                  */
+    int32_t dim[3];      /* sdf_limits[6:9]  grid dims, x-major storage x*dy*dz + y*dz + z           */
+    float delta;         /* sdf_limits[9]    voxel size                                              */
+    float epsilon;       /* cfg.epsilon / cfg.target_epsilon                                         */
+    float padding_scale; /* 1, or 0.5 for the table when the target is attached                     */
+    float clearance;     /* cfg.clearance / cfg.target_clearance                                     */
+    int32_t disabled;    /* 1 = skip (name == "floor" or in cfg.disable_collision_set)               */
+    int64_t grid_offset; /* element offset of this object's grid inside the sdf pool                 */
+    int32_t reserved[4];
+} omgx_object; /* sizeof == 128 */
+
+/* ---------------------------------------------------------------------------------------------
+ * CHOMP parameters for one optimiser step (a frozen snapshot of the reference's global mutable
+ * `cfg`, omg/config.py:30-131, after Optimizer.update() has applied the schedules,
+ * omg/optimizer.py:59-80).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct omgx_chomp_params {
+    int32_t n_waypoints;              /* cfg.timesteps                                              */
+    int32_t n_points;                 /* P = cfg.collision_point_num                                */
+    int32_t top_k;                    /* cfg.top_k_collision; 0 = clean sum branch (cost.py:380-388)*/
+    int32_t consider_finger;          /* cfg.consider_finger                                        */
+    int32_t goal_set_proj;            /* cfg.goal_set_proj                                          */
+    int32_t constraint_num;           /* reach_tail_length if cfg.use_standoff else 1               */
+    int32_t use_standoff;             /* cfg.use_standoff (only for info["standoff_idx"])           */
+    int32_t uncheck_finger_collision; /* cfg.uncheck_finger_collision (-1 softens fingers)          */
+    int32_t joint_limit_max_steps;    /* cfg.joint_limit_max_steps                                  */
+    int32_t allow_collision_point;    /* cfg.allow_collision_point                                  */
+    int32_t pre_terminate;            /* cfg.pre_terminate                                          */
+    int32_t do_update;                /* 0 = info_only (Optimizer.optimize(info_only=True))         */
+    double time_interval;             /* cfg.time_interval                                          */
+    double obstacle_weight;           /* cfg.obstacle_weight                                        */
+    double smoothness_weight;         /* cfg.smoothness_weight                                      */
+    double step_size;                 /* cfg.step_size                                              */
+    double clip_grad_scale;           /* cfg.clip_grad_scale                                        */
+    double terminate_smooth_loss;     /* cfg.terminate_smooth_loss                                  */
+    double link_smooth_weight[OMGX_NUM_DOF]; /* cfg.link_smooth_weight                              */
+} omgx_chomp_params;
+
+/* info record layout (doubles), one per trajectory: the numeric keys of Cost.compute_total_loss's
+ * `info` dict (omg/cost.py:509-530) + Optimizer.check_joint_limit (omg/optimizer.py:166-174). */
+#define OMGX_INFO_COST 0
+#define OMGX_INFO_OBS 1
+#define OMGX_INFO_SMOOTH 2
+#define OMGX_INFO_WEIGHTED_OBS 3
+#define OMGX_INFO_WEIGHTED_SMOOTH 4
+#define OMGX_INFO_WEIGHTED_OBS_GRAD 5
+#define OMGX_INFO_WEIGHTED_SMOOTH_GRAD 6
+#define OMGX_INFO_GRAD 7
+#define OMGX_INFO_COLLIDE 8
+#define OMGX_INFO_REACH 9
+#define OMGX_INFO_TERMINATE 10
+#define OMGX_INFO_FAILURE_TERMINATE 11
+#define OMGX_INFO_EXECUTE 12
+#define OMGX_INFO_STANDOFF_IDX 13
+#define OMGX_INFO_VIOLATE_LIMIT 14
+#define OMGX_INFO_LIMIT_STEPS 15 /* build-only: joint-limit projection iterations actually used     */
+
+/* ---------------------------------------------------------------------------------------------
+ * (1) omgx_sdf_loss_forward
+ * Replaces  omg_cuda.sdf_loss_forward  — layers/omg_layers.cpp:24-49 (binding),
+ *           sdf_loss_cuda_forward       — layers/sdf_matching_loss_kernel.cu:204-262 (4 launches + 2 syncs),
+ *           SDFdistanceForward / sum_gradients — .cu:96-181 / 185-195.
+ * Same eight inputs in the same order, float32 contiguous; outputs are the three reduced tensors
+ * the binding returns: potentials[N], potential_grads[N,3], collides[N].  One fused launch, the
+ * [N,O,*] intermediates and the atomicAdd reduction do not exist; objects are summed in index order.
+ * ------------------------------------------------------------------------------------------- */
+int omgx_sdf_loss_forward(const float* pose_init,       /* [O,4,4] inverse object poses            */
+                          const float* sdf_grids,       /* [O,X,Y,Z]                               */
+                          const float* sdf_limits,      /* [O,10]                                  */
+                          const float* points,          /* [N,3]                                   */
+                          const float* epsilons,        /* [O]                                     */
+                          const float* padding_scales,  /* [O]                                     */
+                          const float* clearances,      /* [O]                                     */
+                          const float* disables,        /* [O]                                     */
+                          int64_t num_points, int32_t num_objects,
+                          float* potentials,            /* [N]   out                               */
+                          float* potential_grads,       /* [N,3] out                               */
+                          float* collides,              /* [N]   out                               */
+                          void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * (2) omgx_fk_sdf
+ * Replaces the FK -> points -> SDF-layer chain of Cost.batch_obstacle_cost (omg/cost.py:192-232,
+ * arc_length <= 0) and of Cost.forward_kinematics_obstacle (omg/cost.py:124-143), i.e.
+ * robot_kinematics.forward_kinematics_parallel (robot_pykdl.py:148-215) + Cost.forward_points
+ * (cost.py:60-72) + Cost.compute_obstacle_cost_layer (cost.py:288-360), for S scenes x C robot
+ * configurations per scene, entirely on device.
+ *   joints      [S,C,9]  double, radians (9-dof; wrap_values' degree round trip is applied inside)
+ *   objects     table of omgx_object; scene s owns objects [scene_begin[s], scene_begin[s+1])
+ *   soften_fingers != 0  <=> uncheck_finger_collision == -1 (cost.py:350-353)
+ * Outputs (float32): potentials [S,C,10,P], grads [S,C,10,P,3], collides [S,C,10,P]; any may be NULL.
+ * ------------------------------------------------------------------------------------------- */
+int omgx_fk_sdf(const double* robot, int32_t n_points,
+                const omgx_object* objects, const int32_t* scene_begin, const float* sdf_pool,
+                const double* joints, int32_t num_scenes, int32_t configs_per_scene,
+                int32_t soften_fingers,
+                float* potentials, float* grads, float* collides, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * (3) omgx_goalset_cost
+ * Replaces Learner.cost_vector's device work (omg/online_learner.py:104-148):
+ * multi_interpolate_waypoints(..., "linear") (omg/util.py:261-290) -> Cost.batch_obstacle_cost with
+ * arc_length = n_remaining (omg/cost.py:192-286, incl. get_derivative_torch, config.py:162-187)
+ * -> sum over (link, point) and over the n_remaining waypoints, for S scenes x G goals.
+ *   traj_start [S,9]  the waypoint the interpolation starts from (traj.data[start])
+ *   goals      [S,G,9]
+ *   goal_cost  [S,G]  float32 out: sum_i sum_link sum_pt potential * ||velocity||
+ *   potentials [S,G,n_remaining,10,P] float32 out, optional (NULL to skip) — the weighted
+ *              potentials batch_obstacle_cost returns
+ *   collides   [S,G] float32 out, optional: number of (config, link, point, object) collisions
+ * ------------------------------------------------------------------------------------------- */
+int omgx_goalset_cost(const double* robot, int32_t n_points,
+                      const omgx_object* objects, const int32_t* scene_begin, const float* sdf_pool,
+                      const double* traj_start, const double* goals,
+                      int32_t num_scenes, int32_t num_goals, int32_t n_remaining,
+                      double time_interval, int32_t soften_fingers,
+                      float* goal_cost, float* potentials, float* collides, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * (4) omgx_chomp_optimize
+ * Replaces one Optimizer.optimize step (omg/optimizer.py:115-135) for S independent trajectories:
+ * Cost.compute_total_loss (omg/cost.py:451-532) = compute_smooth_loss (425-449) +
+ * compute_collision_loss (362-423, both the top-k quirk branch and the clean branch) on top of
+ * forward_kinematics_obstacle's Jacobians / velocities / accelerations (cost.py:112-190, 92-110,
+ * 24-43), then check_joint_limit (optimizer.py:166-174), goal_set_projection (88-113) or the plain
+ * -eta*Ainv*g step (132), Trajectory.update (omg/core.py:43-51) and handle_joint_limit (148-164).
+ * The SDF potentials/gradients of the S*n waypoint configurations must have been produced by
+ * omgx_fk_sdf on the same stream (configs_per_scene = n_waypoints).
+ *   traj   [S,n,9] double, in/out (updated in place when params.do_update)
+ *   start  [S,9], end [S,9] double   (traj.start, traj.end)
+ *   goal   [S,c,9] double  chosen goal rows (reach_grasps[goal_idx] or goal_set[goal_idx])
+ *   goal_point [S,9] double  traj.goal_set[traj.goal_idx], only for info["reach"] (cost.py:483-487)
+ *   potentials [S,n,10,P], grads [S,n,10,P,3], collides [S,n,10,P] float32 from omgx_fk_sdf
+ *   active [S] int32, optional: 0 = leave this trajectory untouched (terminated), NULL = all active
+ * Outputs: grad [S,n,9] double (info["gradient"]), cost_traj [S,n] double, info [S,16] double.
+ * ------------------------------------------------------------------------------------------- */
+int omgx_chomp_optimize(const double* robot, const omgx_chomp_params* h_params,
+                        double* traj, const double* start, const double* end, const double* goal,
+                        const double* goal_point,
+                        const float* potentials, const float* grads, const float* collides,
+                        const int32_t* active, int32_t num_scenes,
+                        double* grad, double* cost_traj, double* info, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Diagnostics
+ * ------------------------------------------------------------------------------------------- */
+const char* omgx_last_error(void); /* thread-local text of the last OMGX_ERR_LAUNCH               */
+int omgx_abi_version(void);        /* bumps when a signature or struct layout changes              */
+int omgx_device_arch(char* h_buf, int32_t h_len); /* writes gcnArchName of the current device      */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OMG_HIP_H */

@@ -1,0 +1,67 @@
+"""Panda robot model for the CHOMP engine: kinematic constants, joint limits, collision points.
+
+Host-side mirror of what the hot path reads from the reference's ``Robot`` / ``robot_kinematics``
+objects (omg/core.py:143-190, ycb_render/robotPose/robot_pykdl.py:96-113):
+
+* ``robot.robot_kinematics._pose_0 / _tip2joint / _joint_axis / center_offset``  -> ``PandaModel`` tables
+* ``robot.collision_points [10, P, 3]``                                          -> ``collision_points``
+* ``robot.joint_lower_limit / joint_upper_limit [1, 9]`` (URDF limits -/+ 0.2)    -> ``joint_lower_limit`` ...
+
+``blob()`` packs them into the flat float64 layout of ``include/omg_hip.h`` (OMGX_ROBOT_*).
+"""
+from __future__ import annotations
+
+from pathlib import Path
+
+import numpy as np
+
+NUM_LINKS = 10
+NUM_DOF = 9
+_DATA = Path(__file__).resolve().parent / "data" / "panda_fk.npz"
+
+# default start configuration of Trajectory (omg/core.py:38)
+HOME_CONFIG = np.array([0.0, -1.285, 0.0, -2.356, 0.0, 1.571, 0.785, 0.04, 0.04])
+
+
+class PandaModel:
+    """Kinematic constants + sampled collision points of the Franka Panda (7 arm dof + 2 fingers)."""
+
+    def __init__(self, collision_points: np.ndarray | None = None, soft_joint_limit_padding: float = 0.2,
+                 points_per_link: int = 15, seed: int = 0):
+        d = np.load(_DATA)
+        self.pose_0 = np.ascontiguousarray(d["pose_0"], dtype=np.float64)
+        self.tip2joint = np.ascontiguousarray(d["tip2joint"], dtype=np.float64)
+        self.center_offset = np.ascontiguousarray(d["center_offset"], dtype=np.float64)
+        self.joint_axis = np.ascontiguousarray(d["joint_axis"], dtype=np.float64)
+        limits = np.asarray(d["joint_limits"], dtype=np.float64)
+        # omg/core.py:157-164: arm joints padded inwards, fingers untouched
+        self.joint_lower_limit = limits[:, 0][None].copy()
+        self.joint_upper_limit = limits[:, 1][None].copy()
+        self.joint_lower_limit[:, :-2] += soft_joint_limit_padding
+        self.joint_upper_limit[:, :-2] -= soft_joint_limit_padding
+        if collision_points is None:
+            collision_points = synthetic_collision_points(points_per_link, seed)
+        self.collision_points = np.ascontiguousarray(collision_points, dtype=np.float64)
+        assert self.collision_points.shape[0] == NUM_LINKS and self.collision_points.shape[2] == 3
+
+    @property
+    def points_per_link(self) -> int:
+        return int(self.collision_points.shape[1])
+
+    def blob(self) -> np.ndarray:
+        """Flat float64 constants blob, layout = include/omg_hip.h OMGX_ROBOT_*."""
+        return np.concatenate([
+            self.pose_0.ravel(), self.tip2joint.ravel(), self.center_offset.ravel(), self.joint_axis.ravel(),
+            self.joint_lower_limit.ravel(), self.joint_upper_limit.ravel(), self.collision_points.ravel(),
+        ]).astype(np.float64)
+
+
+def synthetic_collision_points(points_per_link: int = 15, seed: int = 0) -> np.ndarray:
+    """Stand-in for Robot.load_collision_points (omg/core.py:166-190).
+
+    The reference samples ``points_per_link`` surface points per link from ``data/robots/*.xyz`` with
+    an unseeded ``random.sample``; that data set is not redistributable/available, so tests and the
+    benchmark use points uniform in a 10 cm cube around each (centred) link frame.
+    """
+    rng = np.random.RandomState(seed)
+    return rng.uniform(-0.05, 0.05, size=(NUM_LINKS, points_per_link, 3))

@@ -1,0 +1,313 @@
+"""Scene data for the CHOMP engine: SDF volumes, object tables, synthetic table-top scenes.
+
+Two HBM layouts of the same information:
+
+* the **reference boundary layout** of ``Env.combine_sdfs`` (omg/core.py:366-411): every grid padded
+  with 1.0 to the per-scene max shape, ``sdf_torch[O,X,Y,Z]`` float32 + ``sdf_limits[O,10]`` with the
+  max coordinate *stretched* to the padded shape -> :func:`pack_padded`;
+* the **engine layout** of ``include/omg_hip.h``: one ragged float32 pool holding every grid of every
+  scene back to back + a 128-byte ``omgx_object`` record per object + ``scene_begin[S+1]``
+  -> :func:`pack_table` / :class:`SceneBatch`.
+
+The reference's ``data/`` (YCB SDFs, scene .mat files) is a 600 MB download that is not available
+offline, so benchmark and test scenes are synthetic: analytic spheres / boxes sampled at
+voxel centres, a table slab, table-top poses.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+
+# numpy mirror of `omgx_object` (include/omg_hip.h), 128 bytes
+OBJECT_DTYPE = np.dtype([
+    ("pose_inv", np.float32, (12,)),
+    ("lo", np.float32, (3,)),
+    ("hi", np.float32, (3,)),
+    ("dim", np.int32, (3,)),
+    ("delta", np.float32),
+    ("epsilon", np.float32),
+    ("padding_scale", np.float32),
+    ("clearance", np.float32),
+    ("disabled", np.int32),
+    ("grid_offset", np.int64),
+    ("reserved", np.int32, (4,)),
+], align=True)
+assert OBJECT_DTYPE.itemsize == 128
+
+
+@dataclass
+class SdfGrid:
+    """What the path reads of SignedDensityField (omg/sdf_tools.py:17-35): data[x,y,z], origin, delta."""
+    data: np.ndarray  # [X,Y,Z] float32
+    origin: np.ndarray  # min_coords [3]
+    delta: float
+
+    @property
+    def min_coords(self) -> np.ndarray:
+        return np.asarray(self.origin, dtype=np.float64)
+
+    @property
+    def max_coords(self) -> np.ndarray:  # sdf_tools.py:30
+        return self.min_coords + self.delta * np.array(self.data.shape)
+
+
+@dataclass
+class SceneObject:
+    """What the path reads of Model (omg/core.py:83-141): name, pose_mat, sdf, attached."""
+    name: str
+    pose_mat: np.ndarray  # [4,4] object -> world
+    sdf: SdfGrid
+    attached: bool = False
+
+
+@dataclass
+class Scene:
+    objects: list = field(default_factory=list)
+    target_idx: int = 0
+
+
+def se3_inverse(pose: np.ndarray) -> np.ndarray:
+    """[R t]^-1 = [R^T, -R^T t] as float32 (omg/util.py:129-135)."""
+    out = np.eye(4, dtype=np.float32)
+    R = pose[:3, :3]
+    out[:3, :3] = R.T
+    out[:3, 3] = -(R.T @ pose[:3, 3])
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# analytic SDFs
+# ------------------------------------------------------------------------------------------------
+def _voxel_centres(shape, origin, delta):
+    ax = [origin[i] + (np.arange(shape[i]) + 0.5) * delta for i in range(3)]
+    return np.meshgrid(*ax, indexing="ij")
+
+
+def sphere_sdf(radius: float, shape=(64, 64, 64), delta: float = 0.6 / 64) -> SdfGrid:
+    origin = -0.5 * delta * np.array(shape, dtype=np.float64)
+    x, y, z = _voxel_centres(shape, origin, delta)
+    return SdfGrid((np.sqrt(x * x + y * y + z * z) - radius).astype(np.float32), origin, float(delta))
+
+
+def box_sdf(half_extents, shape=(64, 64, 64), delta: float = 0.6 / 64) -> SdfGrid:
+    origin = -0.5 * delta * np.array(shape, dtype=np.float64)
+    x, y, z = _voxel_centres(shape, origin, delta)
+    q = np.stack([np.abs(x) - half_extents[0], np.abs(y) - half_extents[1], np.abs(z) - half_extents[2]], -1)
+    outside = np.linalg.norm(np.maximum(q, 0.0), axis=-1)
+    inside = np.minimum(q.max(-1), 0.0)
+    return SdfGrid((outside + inside).astype(np.float32), origin, float(delta))
+
+
+def point_cloud_sdf(points: np.ndarray, grid_resolution: float = 0.02, margin: float = 0.24) -> SdfGrid:
+    """Unsigned nearest-point distance grid like PointEnv.compute_sdf_from_points (omg/core.py:426-457):
+    grid nodes at arange(min - margin, max + margin, res) per axis, value = distance to nearest point."""
+    from scipy.spatial import cKDTree
+
+    lo, hi = points.min(0), points.max(0)
+    ax = [np.arange(lo[i] - margin, hi[i] + margin, grid_resolution) for i in range(3)]
+    g = np.stack(np.meshgrid(*ax, indexing="ij"), 0)
+    d, _ = cKDTree(points).query(g.reshape(3, -1).T)
+    return SdfGrid(d.reshape(g.shape[1:]).astype(np.float32), (lo - margin).astype(np.float64), float(grid_resolution))
+
+
+# ------------------------------------------------------------------------------------------------
+# per-object SDF-layer parameters (Cost.compute_obstacle_cost_layer, omg/cost.py:303-328)
+# ------------------------------------------------------------------------------------------------
+def layer_params(scene: Scene, epsilon=0.2, target_epsilon=0.1, clearance=0.01, target_clearance=0.0,
+                 disable_collision_set=(), special_check_id=None):
+    """-> poses_inv [O,4,4] f32, epsilons, padding_scales, clearances, disables [O] f32.
+
+    ``special_check_id`` is accepted for signature parity; like the reference, the target is taken from
+    ``scene.target_idx`` (cost.py:321 compares against ``self.env.target_idx``).
+    """
+    O = len(scene.objects)
+    poses = np.zeros((O, 4, 4), np.float32)
+    eps = np.full(O, epsilon, np.float32)
+    pad = np.ones(O, np.float32)
+    clr = np.full(O, clearance, np.float32)
+    dis = np.zeros(O, np.float32)
+    for i, ob in enumerate(scene.objects):
+        if ob.name == "floor" or ob.name in disable_collision_set:
+            dis[i] = 1
+        poses[i] = se3_inverse(ob.pose_mat)
+        if i == scene.target_idx:
+            clr[i] = target_clearance
+            eps[i] = target_epsilon
+    if O > 0 and scene.objects[scene.target_idx].attached:  # cost.py:325-328 (table is last)
+        clr[-1] = 0.0
+        eps[-1] = 0.05
+        pad[-1] = 0.5
+    return poses, eps, pad, clr, dis
+
+
+# ------------------------------------------------------------------------------------------------
+# layouts
+# ------------------------------------------------------------------------------------------------
+def pack_padded(objects) -> tuple[np.ndarray, np.ndarray]:
+    """Env.combine_sdfs (omg/core.py:366-411): -> sdf [O,X,Y,Z] f32 (pad value 1.0), limits [O,10] f32."""
+    shapes = np.array([o.sdf.data.shape for o in objects])
+    mx = shapes.max(0)
+    sdf = np.ones((len(objects), mx[0], mx[1], mx[2]), np.float32)
+    lim = np.zeros((len(objects), 10), np.float32)
+    for i, o in enumerate(objects):
+        sz = o.sdf.data.shape
+        sdf[i, : sz[0], : sz[1], : sz[2]] = o.sdf.data.astype(np.float32)
+        mn, mxc = o.sdf.min_coords, o.sdf.max_coords
+        lim[i, 0:3] = mn
+        for a in range(3):
+            lim[i, 3 + a] = mn[a] + (mxc[a] - mn[a]) * mx[a] / sz[a]
+        lim[i, 6:9] = mx
+        lim[i, 9] = o.sdf.delta
+    return sdf, lim
+
+
+def table_from_padded(poses_inv, limits, eps, pad, clr, dis, grid_elems_per_object=None) -> np.ndarray:
+    """omgx_object records that address the reference's padded [O,X,Y,Z] tensor in place."""
+    O = limits.shape[0]
+    rec = np.zeros(O, OBJECT_DTYPE)
+    for o in range(O):
+        rec[o]["pose_inv"] = np.asarray(poses_inv[o], np.float32)[:3, :4].ravel()
+        rec[o]["lo"] = limits[o, 0:3]
+        rec[o]["hi"] = limits[o, 3:6]
+        rec[o]["dim"] = limits[o, 6:9].astype(np.int32)
+        rec[o]["delta"] = limits[o, 9]
+        rec[o]["epsilon"] = eps[o]
+        rec[o]["padding_scale"] = pad[o]
+        rec[o]["clearance"] = clr[o]
+        rec[o]["disabled"] = 1 if dis[o] > 0 else 0
+        d = rec[o]["dim"].astype(np.int64)
+        rec[o]["grid_offset"] = o * int(d[0] * d[1] * d[2]) if grid_elems_per_object is None else o * grid_elems_per_object
+    return rec
+
+
+@dataclass
+class SceneBatch:
+    """Engine layout for S scenes: object records, scene_begin[S+1], one ragged float32 pool."""
+    objects: np.ndarray  # OBJECT_DTYPE [sum O_s]
+    scene_begin: np.ndarray  # int32 [S+1]
+    pool: np.ndarray  # float32 [sum voxels]
+
+    @property
+    def num_scenes(self) -> int:
+        return len(self.scene_begin) - 1
+
+
+def pack_table(scenes, cfg_kwargs=None, ragged: bool = True, share_grids: bool = True) -> SceneBatch:
+    """Pack scenes into the engine layout.
+
+    ragged=True keeps every grid at its own shape (true limits); ragged=False reproduces the
+    reference's pad-to-max + stretched-limits layout per scene.  The two agree up to the float32
+    rounding of the grid coordinate (u-lo)/(hi-lo)*dim; inside the stretched box the padded layout reads
+    the 1.0 padding value where the ragged one returns the out-of-range 1.0 — the same number.
+    share_grids=True stores a grid referenced by several scenes once (same ndarray object).
+    """
+    cfg_kwargs = cfg_kwargs or {}
+    recs, begins, chunks, offset = [], [0], [], 0
+    seen = {}
+    for sc in scenes:
+        poses, eps, pad, clr, dis = layer_params(sc, **cfg_kwargs)
+        if ragged:
+            for i, ob in enumerate(sc.objects):
+                r = np.zeros((), OBJECT_DTYPE)
+                r["pose_inv"] = poses[i][:3, :4].ravel()
+                r["lo"] = ob.sdf.min_coords.astype(np.float32)
+                # same float32 arithmetic as combine_sdfs with max_shape == size
+                mn, mxc = ob.sdf.min_coords, ob.sdf.max_coords
+                r["hi"] = np.array([mn[a] + (mxc[a] - mn[a]) * 1.0 for a in range(3)], np.float32)
+                r["dim"] = ob.sdf.data.shape
+                r["delta"] = ob.sdf.delta
+                r["epsilon"], r["padding_scale"], r["clearance"] = eps[i], pad[i], clr[i]
+                r["disabled"] = 1 if dis[i] > 0 else 0
+                key = id(ob.sdf.data)
+                if share_grids and key in seen:
+                    r["grid_offset"] = seen[key]
+                else:
+                    r["grid_offset"] = offset
+                    seen[key] = offset
+                    chunks.append(np.ascontiguousarray(ob.sdf.data, np.float32).ravel())
+                    offset += chunks[-1].size
+                recs.append(r)
+        else:
+            sdf, lim = pack_padded(sc.objects)
+            t = table_from_padded(poses, lim, eps, pad, clr, dis)
+            t["grid_offset"] += offset
+            chunks.append(sdf.ravel())
+            offset += sdf.size
+            recs.extend(list(t))
+        begins.append(len(recs))
+    return SceneBatch(np.array(recs, OBJECT_DTYPE), np.array(begins, np.int32),
+                      np.concatenate(chunks) if chunks else np.zeros(0, np.float32))
+
+
+# ------------------------------------------------------------------------------------------------
+# synthetic table-top scenes
+# ------------------------------------------------------------------------------------------------
+_SHAPE_CACHE: dict = {}
+
+
+def _shape(kind: str, key, grid: int) -> SdfGrid:
+    k = (kind, key, grid)
+    if k not in _SHAPE_CACHE:
+        delta = 0.6 / grid
+        if kind == "sphere":
+            _SHAPE_CACHE[k] = sphere_sdf(key, (grid,) * 3, delta)
+        else:
+            _SHAPE_CACHE[k] = box_sdf(key, (grid,) * 3, delta)
+    return _SHAPE_CACHE[k]
+
+
+def _yaw_pose(x, y, z, yaw):
+    c, s = np.cos(yaw), np.sin(yaw)
+    T = np.eye(4)
+    T[:3, :3] = [[c, -s, 0], [s, c, 0], [0, 0, 1]]
+    T[:3, 3] = [x, y, z]
+    return T
+
+
+def make_tabletop_scene(seed: int, num_objects: int = 4, grid: int = 64, table_grid=(128, 96, 32)) -> Scene:
+    """`num_objects` YCB-like shapes (spheres r 6-9 cm, boxes 5-20 cm) on `grid`^3 volumes with
+    delta = 0.6/grid m, plus a table slab 1.2 x 0.8 x 0.04 m as the LAST object (cost.py:325-328 treats
+    objects[-1] as the table).  Object 0 is the grasp target.  A small palette of shapes is shared
+    between scenes (like the 21 YCB models are shared between the reference's 100 scenes)."""
+    rng = np.random.RandomState(seed)
+    radii = (0.06, 0.07, 0.08, 0.09)
+    boxes = ((0.025, 0.05, 0.10), (0.05, 0.05, 0.05), (0.04, 0.08, 0.03), (0.03, 0.03, 0.09))
+    objs = []
+    for i in range(num_objects):
+        if rng.rand() < 0.5:
+            sdf = _shape("sphere", radii[rng.randint(len(radii))], grid)
+        else:
+            sdf = _shape("box", boxes[rng.randint(len(boxes))], grid)
+        pose = _yaw_pose(rng.uniform(0.3, 0.7), rng.uniform(-0.3, 0.3), 0.15 + rng.uniform(-0.02, 0.02),
+                         rng.uniform(-np.pi, np.pi))
+        objs.append(SceneObject(f"obj_{i}", pose, sdf))
+    tk = ("table", tuple(table_grid))
+    if tk not in _SHAPE_CACHE:
+        tdelta = 1.5 / table_grid[0]
+        _SHAPE_CACHE[tk] = box_sdf((0.6, 0.4, 0.02), table_grid, tdelta)
+    objs.append(SceneObject("table", _yaw_pose(0.5, 0.0, 0.02, 0.0), _SHAPE_CACHE[tk]))
+    return Scene(objs, target_idx=0)
+
+
+def make_goal_set(seed: int, num_goals: int) -> np.ndarray:
+    """Reach configurations near a table-top pre-grasp + N(0, 0.05^2) on the arm joints."""
+    rng = np.random.RandomState(10_000 + seed)
+    base = np.array([0.3, 0.2, 0.1, -1.6, 0.1, 1.9, 1.0, 0.04, 0.04])
+    g = np.tile(base, (num_goals, 1))
+    g[:, :7] += rng.normal(0.0, 0.05, size=(num_goals, 7))
+    return g
+
+
+def linear_init(start: np.ndarray, end: np.ndarray, n: int) -> np.ndarray:
+    """Interior waypoints linspace(0,1,n+2)[1:-1] between start and end (util.py:238-258, "linear")."""
+    t = (np.arange(1, n + 1) / (n + 1.0))[:, None]
+    return start[None] + t * (end - start)[None]
+
+
+def cubic_init(start: np.ndarray, end: np.ndarray, n: int) -> np.ndarray:
+    """Clamped cubic spline through (0,start),(1,end) with zero end slopes = 3t^2-2t^3 blend
+    (closed form of scipy CubicSpline(bc_type="clamped") on two knots, util.py:252)."""
+    t = (np.arange(1, n + 1) / (n + 1.0))[:, None]
+    h = 3.0 * t * t - 2.0 * t * t * t
+    return start[None] + h * (end - start)[None]
