@@ -1,0 +1,84 @@
+"""ctypes loader of libomg_hip.so (the hand-written gfx950 kernels + C ABI of include/omg_hip.h).
+
+There is NO fallback: if the library is missing or a call fails, an exception is raised.  Nothing in
+this package computes the hot path on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+_CSRC = Path(__file__).resolve().parent / "csrc"
+LIB_PATH = _CSRC / "libomg_hip.so"
+
+OMGX_OK, OMGX_ERR_INVALID, OMGX_ERR_LAUNCH, OMGX_ERR_UNSUPPORTED = 0, -1, -2, -3
+NUM_DOF, INFO_STRIDE = 9, 16
+
+# every symbol include/omg_hip.h declares
+EXPORTS = ["omgx_sdf_loss_forward", "omgx_fk_sdf_workspace_bytes", "omgx_fk_sdf", "omgx_goalset_workspace_bytes",
+           "omgx_goalset_cost", "omgx_chomp_optimize", "omgx_last_error", "omgx_abi_version", "omgx_device_arch"]
+
+
+class OmgHipError(RuntimeError):
+    pass
+
+
+class ChompParams(C.Structure):
+    """Mirror of `omgx_chomp_params` (include/omg_hip.h)."""
+    _fields_ = [(n, C.c_int32) for n in (
+        "n_waypoints", "n_points", "top_k", "consider_finger", "goal_set_proj", "constraint_num",
+        "use_standoff", "uncheck_finger_collision", "joint_limit_max_steps", "allow_collision_point",
+        "pre_terminate", "do_update")] + [(n, C.c_double) for n in (
+        "time_interval", "obstacle_weight", "smoothness_weight", "step_size", "clip_grad_scale",
+        "terminate_smooth_loss")] + [("link_smooth_weight", C.c_double * NUM_DOF)]
+
+
+def build(force: bool = False) -> Path:
+    """Compile csrc/*.hip for gfx950 with hipcc (cross-compiles without a GPU)."""
+    args = ["make", "-C", str(_CSRC)] + (["-B"] if force else [])
+    subprocess.run(args, check=True, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise OmgHipError(f"{LIB_PATH} is missing: build it with `make -C {_CSRC}` "
+                              "(or __graft_entry__.build()); there is no CPU fallback")
+        l = C.CDLL(str(LIB_PATH))
+        vp, i32, i64, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+        l.omgx_sdf_loss_forward.argtypes = [vp] * 8 + [i64, i32] + [vp] * 3 + [vp]
+        l.omgx_fk_sdf_workspace_bytes.argtypes = [i32, i32, i32]
+        l.omgx_fk_sdf_workspace_bytes.restype = i64
+        l.omgx_fk_sdf.argtypes = [vp, i32, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]
+        l.omgx_goalset_workspace_bytes.argtypes = [i32, i32, i32, i32]
+        l.omgx_goalset_workspace_bytes.restype = i64
+        l.omgx_goalset_cost.argtypes = [vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, f64, i32, vp, vp, vp, vp, vp]
+        l.omgx_chomp_optimize.argtypes = [vp, C.POINTER(ChompParams)] + [vp] * 9 + [i32] + [vp] * 3 + [vp]
+        l.omgx_last_error.restype = C.c_char_p
+        l.omgx_device_arch.argtypes = [C.c_char_p, i32]
+        for name in ("omgx_sdf_loss_forward", "omgx_fk_sdf", "omgx_goalset_cost", "omgx_chomp_optimize",
+                     "omgx_abi_version", "omgx_device_arch"):
+            getattr(l, name).restype = C.c_int
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc == OMGX_OK:
+        return
+    if rc == OMGX_ERR_LAUNCH:
+        raise OmgHipError(f"{what}: {lib().omgx_last_error().decode()}")
+    names = {OMGX_ERR_INVALID: "invalid argument", OMGX_ERR_UNSUPPORTED: "size not supported by this build"}
+    raise OmgHipError(f"{what}: {names.get(rc, rc)}")
+
+
+def device_arch() -> str:
+    buf = C.create_string_buffer(64)
+    check(lib().omgx_device_arch(buf, 64), "omgx_device_arch")
+    return buf.value.decode()

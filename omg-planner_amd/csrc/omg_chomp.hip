@@ -1,0 +1,633 @@
+// omg_chomp.hip — k_chomp_optimize: one Optimizer.optimize step per trajectory, one workgroup each.
+//
+// Replaces (all float64, like the reference's numpy code):
+//   Cost.forward_kinematics_obstacle   omg/cost.py:112-190   FK + joint frames, x / v / a by finite differences
+//   Cost.compute_point_jacobian        omg/cost.py:92-110
+//   Cost.functional_grad               omg/cost.py:24-43
+//   Cost.compute_collision_loss        omg/cost.py:362-423   top-k "last write wins" branch AND the clean branch
+//   Cost.compute_smooth_loss           omg/cost.py:425-449
+//   Cost.compute_total_loss            omg/cost.py:451-532
+//   Optimizer.check_joint_limit        omg/optimizer.py:166-174
+//   Optimizer.goal_set_projection      omg/optimizer.py:88-113
+//   Trajectory.update                  omg/core.py:43-51
+//   Optimizer.handle_joint_limit       omg/optimizer.py:148-164
+//
+// The SDF potentials/gradients of the n waypoint configurations come from omgx_fk_sdf (float32,
+// [n][10][P] reference layout).  Everything else lives in LDS for the duration of the step:
+//   link poses of start, n waypoints, end (double [n+2][10][12]), joint axes/origins ([n][10][3] each),
+//   per-(waypoint,link) gradient slots ([n][10][8]), the trajectory and its gradient ([n][9]).
+//
+// A = D^T D is tridiagonal (-1,2,-1)/dt^2 with last diagonal 1/dt^2 (goal-set, free end) or 2/dt^2
+// (fixed end) — omg/config.py:208-220, util.py:165-178 — so A^-1 has the closed forms
+//   free end : Ainv[i][k] = dt^2 (min(i,k)+1)
+//   fixed end: Ainv[i][k] = dt^2 (min(i,k)+1)(n-max(i,k))/(n+1)
+// and the goal-set projector M = Ainv C^T (C Ainv C^T)^-1 (optimizer.py:107) with C = [0 I_c] is
+//   M[i][0] = (i+1)/(n-c+1) for i < n-c,  M[n-c+q][q] = 1, zero elsewhere
+// (inverse of a min(x_r,x_q) kernel is tridiagonal).  No matrix is stored or inverted on device.
+#include <hip/hip_runtime.h>
+
+#include <stdint.h>
+
+#include "omg_device.h"
+#include "omg_host.h"
+
+using namespace omg;
+
+#define CH_TPB 512
+#define CH_WAVES (CH_TPB / 64)
+
+namespace {
+
+struct ChompArgs {
+    const double* robot;
+    omgx_chomp_params prm;
+    double* traj;              // [S][n][9] in/out
+    const double* start;       // [S][9]
+    const double* end;         // [S][9]
+    const double* goal;        // [S][c][9]
+    const double* goal_point;  // [S][9]
+    const float* pot;          // [S][n][10][P]
+    const float* pgrad;        // [S][n][10][P][3]
+    const float* col;          // [S][n][10][P]
+    const int32_t* active;     // [S] or null
+    double* grad;              // [S][n][9]
+    double* cost_traj;         // [S][n]
+    double* info;              // [S][16]
+};
+
+// wrap_joint(l+1) (omg/util.py:213-220): k-th joint index (into the 10-joint tables) of link l; count via njoints().
+__device__ __forceinline__ int njoints(int l) { return l < 7 ? l + 1 : (l == 7 ? 7 : 8); }
+__device__ __forceinline__ int joint_of(int l, int k) { return k < 7 ? k : l; /* k==7: finger joint 8 or 9 == link index */ }
+// wrap_index(l+1) (omg/util.py:205-210): trajectory column of slot k of link l.
+__device__ __forceinline__ int column_of(int l, int k) { return k < 7 ? k : l - 1; /* 8->7, 9->8 */ }
+
+__device__ __forceinline__ uint32_t float_key(float f) {  // order-preserving float -> uint
+    const uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+struct Lds {
+    double* pose;    // [n+2][10][12]
+    double* jax;     // [n][10][3]
+    double* jog;     // [n][10][3]
+    double* gl;      // [n][10][8]
+    double* gcost;   // [n][10]
+    double* xi;      // [n][9]
+    double* g;       // [n][9]  total gradient
+    double* og;      // [n][9]  obstacle gradient -> clipped weighted obstacle gradient
+    double* sg;      // [n][9]  smoothness gradient -> weighted
+    double* tv;      // [n][9]
+    double* tvs;     // [n][9]
+    double* sml;     // [n+1]   smoothness loss
+    double* pts;     // [10][P][3] centred collision points
+    double* red;     // [64] scratch for reductions / scalars
+    int* gwin;       // [n][10] winner point of the group or -1
+    uint32_t* hist;  // [256]
+    uint32_t* tie;   // [(n*10*16+31)/32] tie bit mask
+    int* iscr;       // [16] int scalars
+};
+
+__device__ __forceinline__ Lds carve(unsigned char* base, int n, int P) {
+    Lds L;
+    double* d = reinterpret_cast<double*>(base);
+    L.pose = d; d += (size_t)(n + 2) * 120;
+    L.jax = d; d += (size_t)n * 30;
+    L.jog = d; d += (size_t)n * 30;
+    L.gl = d; d += (size_t)n * 80;
+    L.gcost = d; d += (size_t)n * 10;
+    L.xi = d; d += (size_t)n * 9;
+    L.g = d; d += (size_t)n * 9;
+    L.og = d; d += (size_t)n * 9;
+    L.sg = d; d += (size_t)n * 9;
+    L.tv = d; d += (size_t)n * 9;
+    L.tvs = d; d += (size_t)n * 9;
+    L.sml = d; d += (n + 1);
+    L.pts = d; d += 30 * P;
+    L.red = d; d += 64;
+    int* ip = reinterpret_cast<int*>(d);
+    L.gwin = ip; ip += n * 10;
+    L.hist = reinterpret_cast<uint32_t*>(ip); ip += 256;
+    L.tie = reinterpret_cast<uint32_t*>(ip); ip += (n * 160 + 31) / 32;
+    L.iscr = ip;
+    return L;
+}
+
+// x = out_l(cfg) . pts'(l,p)
+__device__ __forceinline__ void point_at(const Lds& L, int cfg, int l, int p, int P, double* x) {
+    const double* A = L.pose + ((size_t)cfg * 10 + l) * 12;
+    const double* q = L.pts + 3 * (l * P + p);
+    x[0] = A[0] * q[0] + A[1] * q[1] + A[2] * q[2] + A[9];
+    x[1] = A[3] * q[0] + A[4] * q[1] + A[5] * q[2] + A[10];
+    x[2] = A[6] * q[0] + A[7] * q[1] + A[8] * q[2] + A[11];
+}
+
+// Cost.functional_grad for one point (cost.py:24-43): returns c*||v||, g = ||v|| P grad_c - c P a / (||v||^2 + 1e-8)
+__device__ __forceinline__ double functional_g(const double* v, const double* a, double c, const double* dc, double* g) {
+    const double vn = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    double nv[3], Pa[3], Pg[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) nv[r] = v[r] / (vn + 1e-8);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        double pa = 0.0, pg = 0.0;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const double m = (r == q ? 1.0 : 0.0) - nv[r] * nv[q];
+            pa += m * a[q];
+            pg += m * dc[q];
+        }
+        Pa[r] = pa; Pg[r] = pg;
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) g[r] = vn * Pg[r] - c * (Pa[r] / (vn * vn + 1e-8));
+    return c * vn;
+}
+
+// J_k . g for the k-th joint of link l at waypoint i (cost.py:92-110)
+__device__ __forceinline__ double jacobian_dot(const Lds& L, int i, int l, int k, const double* x, const double* g) {
+    const int j = joint_of(l, k);
+    const double* ax = L.jax + ((size_t)i * 10 + j) * 3;
+    if (l >= 8 && k == 7) return ax[0] * g[0] + ax[1] * g[1] + ax[2] * g[2];  // "prsimatic" finger joint
+    const double* o = L.jog + ((size_t)i * 10 + j) * 3;
+    const double d0 = x[0] - o[0], d1 = x[1] - o[1], d2 = x[2] - o[2];
+    const double J0 = ax[1] * d2 - ax[2] * d1, J1 = ax[2] * d0 - ax[0] * d2, J2 = ax[0] * d1 - ax[1] * d0;
+    return J0 * g[0] + J1 * g[1] + J2 * g[2];
+}
+
+// v, a of point (i,l,p) by finite differences along the waypoint axis (config.py:134-159); cfg index = i+1
+__device__ __forceinline__ void point_kinematics(const Lds& L, int i, int l, int p, int P, double dt, double* x, double* v, double* a) {
+    double xm[3], xp[3];
+    point_at(L, i + 1, l, p, P, x);
+    point_at(L, i, l, p, P, xm);
+    point_at(L, i + 2, l, p, P, xp);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        v[r] = (x[r] - xm[r]) / dt;
+        a[r] = (xm[r] - 2.0 * x[r] + xp[r]) / (dt * dt);
+    }
+}
+
+// Sum of arr[0..count) by wave 0 in a fixed order; result broadcast through L.red[slot].  Call from ALL threads.
+__device__ __forceinline__ double block_sum(const Lds& L, const double* arr, int count, int slot) {
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        double s = 0.0;
+        for (int k = threadIdx.x; k < count; k += 64) s += arr[k];
+        s = wave_sum(s);
+        if (threadIdx.x == 0) L.red[slot] = s;
+    }
+    __syncthreads();
+    return L.red[slot];
+}
+
+__device__ __forceinline__ double ainv_entry(int i, int k, int n, bool free_end, double dt2) {
+    const int lo = i < k ? i : k, hi = i < k ? k : i;
+    return free_end ? dt2 * (double)(lo + 1) : dt2 * (double)(lo + 1) * (double)(n - hi) / (double)(n + 1);
+}
+
+// out[i][d] = sum_k Ainv[i][k] in[k][d]   (cfg.Ainv.dot(.), optimizer.py:109,132,156)
+__device__ __forceinline__ void apply_ainv(const double* in, double* out, int n, bool free_end, double dt2) {
+    for (int e = threadIdx.x; e < n * 9; e += blockDim.x) {
+        const int i = e / 9, d = e % 9;
+        double s = 0.0;
+        for (int k = 0; k < n; ++k) s += ainv_entry(i, k, n, free_end, dt2) * in[k * 9 + d];
+        out[e] = s;
+    }
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(CH_TPB) void k_chomp_optimize(ChompArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int s = blockIdx.x;
+    if (a.active && a.active[s] == 0) return;
+    const omgx_chomp_params& prm = a.prm;
+    const int n = prm.n_waypoints, P = prm.n_points, c = prm.constraint_num;
+    const double dt = prm.time_interval, dt2 = dt * dt;
+    const bool free_end = prm.goal_set_proj != 0;
+    const Lds L = carve(smem, n, P);
+    const RobotView rv(a.robot, P);
+    const int tid = threadIdx.x;
+    const int total = n * 10 * P;             // reference flat size of potentials [n][10][P]
+    const int nitems = n * 160;               // 16-lane groups: item = (i*10 + l)*16 + p
+    const float* pot = a.pot + (size_t)s * total;
+    const float* pgrad = a.pgrad + (size_t)s * total * 3;
+    const float* col = a.col + (size_t)s * total;
+    double* traj = a.traj + (size_t)s * n * 9;
+    const double* start = a.start + 9 * (size_t)s;
+    const double* end = a.end + 9 * (size_t)s;
+
+    // ---------------------------------------------------------------- phase 0: loads + FK
+    for (int e = tid; e < n * 9; e += blockDim.x) L.xi[e] = traj[e];
+    for (int e = tid; e < 30 * P; e += blockDim.x) L.pts[e] = rv.pts(0, 0)[e];
+    for (int e = tid; e < 256; e += blockDim.x) L.hist[e] = 0;
+    for (int e = tid; e < (nitems + 31) / 32; e += blockDim.x) L.tie[e] = 0;
+    __syncthreads();
+    if (tid < n + 2) {  // one lane per configuration: start, waypoints, end (cost.py:124-165)
+        double q[9];
+        const double* src = tid == 0 ? start : (tid == n + 1 ? end : L.xi + 9 * (tid - 1));
+#pragma unroll
+        for (int d = 0; d < 9; ++d) q[d] = src[d];
+        const bool wp = tid >= 1 && tid <= n;
+        fk_chain(rv, q, [&](int l, const Pose& pose) {
+            double* dst = L.pose + ((size_t)tid * 10 + l) * 12;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) dst[k] = pose.R[k];
+            dst[9] = pose.t[0]; dst[10] = pose.t[1]; dst[11] = pose.t[2];
+            if (wp) {  // joint frame = out_l . tip2joint_l (robot_pykdl.py:190-201); origin = its translation
+                const double* ax = rv.ax(l);
+                const double* og = rv.og(l);
+                double* ja = L.jax + ((size_t)(tid - 1) * 10 + l) * 3;
+                double* jo = L.jog + ((size_t)(tid - 1) * 10 + l) * 3;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    ja[r] = pose.R[3 * r] * ax[0] + pose.R[3 * r + 1] * ax[1] + pose.R[3 * r + 2] * ax[2];
+                    jo[r] = pose.R[3 * r] * og[0] + pose.R[3 * r + 1] * og[1] + pose.R[3 * r + 2] * og[2] + pose.t[r];
+                }
+            }
+        });
+    }
+
+    // ---------------------------------------------------------------- phase 1: top-k threshold (cost.py:392-398)
+    // Radix select of the K-th largest key over the `total` potentials, 4 passes of 8 bits.
+    const int K = prm.top_k;
+    const bool topk_mode = K > 0;
+    uint32_t tau = 0;      // key of the K-th largest potential; keys > tau are selected outright
+    int tie_take = 0;      // how many keys == tau are selected (those with the highest flat index)
+    bool tau_is_zero = false;
+    if (topk_mode && K < total) {
+        uint32_t prefix = 0, mask = 0;
+        int want = K;  // rank (from the top) still to locate inside the current prefix bucket
+        for (int pass = 0; pass < 4; ++pass) {
+            const int shift = 24 - 8 * pass;
+            __syncthreads();
+            for (int e = tid; e < 256; e += blockDim.x) L.hist[e] = 0;
+            __syncthreads();
+            for (int f = tid; f < total; f += blockDim.x) {
+                const uint32_t key = float_key(pot[f]);
+                if ((key & mask) == prefix) atomicAdd(&L.hist[(key >> shift) & 255u], 1u);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int acc = 0, b = 255;
+                for (; b > 0; --b) {
+                    if (acc + (int)L.hist[b] >= want) break;
+                    acc += (int)L.hist[b];
+                }
+                L.iscr[0] = b;
+                L.iscr[1] = want - acc;
+            }
+            __syncthreads();
+            prefix |= (uint32_t)L.iscr[0] << shift;
+            mask |= 255u << shift;
+            want = L.iscr[1];
+        }
+        tau = prefix;
+        tie_take = want;  // >= 1
+        tau_is_zero = (tau == float_key(0.0f));
+    }
+    __syncthreads();  // FK results visible
+    // Ties at a non-zero threshold: the reference keeps whichever numpy's unstable argsort placed last;
+    // this build (like the oracle) defines it as the highest flat indices.  Mark them in a bit mask.
+    if (topk_mode && K < total && !tau_is_zero) {
+        for (int f = tid; f < total; f += blockDim.x)
+            if (float_key(pot[f]) == tau) atomicOr(&L.tie[f >> 5], 1u << (f & 31));
+        __syncthreads();
+    }
+
+    // ---------------------------------------------------------------- phase 2: per point
+    const int mlinks = topk_mode ? (prm.consider_finger ? 10 : 8) : 10;  // cost.py:401-404
+    double colsum = 0.0;
+    for (int it0 = 0; it0 < nitems; it0 += blockDim.x) {
+        const int it = it0 + tid;
+        const bool inb = it < nitems;
+        const int p = it & 15, grp = it >> 4, l = grp % 10, i = grp / 10;
+        const bool valid = inb && p < P;
+        const int f = valid ? (i * 10 + l) * P + p : 0;
+        const float cf = valid ? pot[f] : 0.0f;
+        if (valid) colsum += (double)col[f];
+        double contrib = 0.0;
+        if (topk_mode) {
+            bool sel = false;
+            if (valid && l < mlinks && cf != 0.0f) {  // zero potentials add nothing to cost or gradient
+                if (K >= total) sel = true;
+                else {
+                    const uint32_t key = float_key(cf);
+                    if (key > tau) sel = true;
+                    else if (key == tau) {  // rank among ties counted from the highest index
+                        int above = 0;
+                        const int w0 = f >> 5;
+                        above += __popc(L.tie[w0] >> (f & 31)) - 1;
+                        for (int w = w0 + 1; w < (total + 31) / 32; ++w) above += __popc(L.tie[w]);
+                        sel = above < tie_take;
+                    }
+                }
+            }
+            double vn = 0.0;
+            if (sel) {
+                double x[3], xm[3];
+                point_at(L, i + 1, l, p, P, x);
+                point_at(L, i, l, p, P, xm);
+                const double v0 = (x[0] - xm[0]) / dt, v1 = (x[1] - xm[1]) / dt, v2 = (x[2] - xm[2]) / dt;
+                vn = sqrt(v0 * v0 + v1 * v1 + v2 * v2);
+                contrib = (double)cf * vn;
+            }
+            // group winner = selected point with the largest potential, ties -> largest p
+            // ("last write wins" of the buffered fancy-index +=, cost.py:421)
+            float bv = sel ? cf : -1.0f;
+            int bp = sel ? p : -1;
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) {
+                const float ov = __shfl_xor(bv, off, 16);
+                const int op = __shfl_xor(bp, off, 16);
+                if (ov > bv || (ov == bv && op > bp)) { bv = ov; bp = op; }
+            }
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) contrib += __shfl_xor(contrib, off, 16);
+            if (inb && p == 0) { L.gwin[grp] = bp; L.gcost[grp] = contrib; }
+        } else {
+            // clean branch (cost.py:380-388): every point of every link contributes J.g
+            double out[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (valid) {
+                double x[3], v[3], acc[3], g[3];
+                point_kinematics(L, i, l, p, P, dt, x, v, acc);
+                const double dc[3] = {(double)pgrad[3 * f], (double)pgrad[3 * f + 1], (double)pgrad[3 * f + 2]};
+                contrib = functional_g(v, acc, (double)cf, dc, g);
+                const int nk = njoints(l);
+                for (int k = 0; k < nk; ++k) out[k] = jacobian_dot(L, i, l, k, x, g);
+            }
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) {
+                contrib += __shfl_xor(contrib, off, 16);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) out[k] += __shfl_xor(out[k], off, 16);
+            }
+            if (inb && p == 0) {
+                L.gcost[grp] = contrib;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) L.gl[(size_t)grp * 8 + k] = out[k];
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---------------------------------------------------------------- phase 3: winners' gradients (top-k branch)
+    if (topk_mode) {
+        for (int grp = tid; grp < n * 10; grp += blockDim.x) {
+            const int l = grp % 10, i = grp / 10;
+            const int p = L.gwin[grp];
+            double out[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (p >= 0) {
+                const int f = (i * 10 + l) * P + p;
+                double x[3], v[3], acc[3], g[3];
+                point_kinematics(L, i, l, p, P, dt, x, v, acc);
+                const double dc[3] = {(double)pgrad[3 * f], (double)pgrad[3 * f + 1], (double)pgrad[3 * f + 2]};
+                functional_g(v, acc, (double)pot[f], dc, g);
+                const int nk = njoints(l);
+                for (int k = 0; k < nk; ++k) out[k] = jacobian_dot(L, i, l, k, x, g);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) L.gl[(size_t)grp * 8 + k] = out[k];
+        }
+        __syncthreads();
+    }
+
+    // ---------------------------------------------------------------- phase 4: obstacle gradient [n][9], smoothness
+    const double* w = prm.link_smooth_weight;
+    for (int e = tid; e < n * 9; e += blockDim.x) {
+        const int i = e / 9, d = e % 9;
+        double sgrad = 0.0;
+        for (int l = 0; l < mlinks; ++l) {  // ascending link order = the reference's += order
+            int k = -1;
+            if (d < 7) { if (d < njoints(l)) k = d; }
+            else if (l == d + 1) k = 7;  // column 7 <- link 8, column 8 <- link 9
+            if (k >= 0) sgrad += L.gl[((size_t)i * 10 + l) * 8 + k];
+        }
+        L.og[e] = sgrad;
+        // compute_smooth_loss gradient: A xi + D1^T ed (cost.py:447-448)
+        const double xc = L.xi[e];
+        const double xm = i > 0 ? L.xi[e - 9] : start[d];
+        double sm;
+        if (i < n - 1) sm = (2.0 * xc - xm - L.xi[e + 9]) / dt2;
+        else sm = free_end ? (xc - xm) / dt2 : (2.0 * xc - xm - end[d]) / dt2;
+        L.sg[e] = sm * w[d];
+    }
+    for (int i = tid; i <= n; i += blockDim.x) {  // smoothness loss rows 0..n (cost.py:430-445)
+        double s2 = 0.0;
+        for (int d = 0; d < 9; ++d) {
+            double vel;
+            if (i == 0) vel = L.xi[d] / dt + (-1.0 * start[d] / dt);
+            else if (i < n) vel = (L.xi[i * 9 + d] - L.xi[(i - 1) * 9 + d]) / dt;
+            else vel = free_end ? 0.0 : (-L.xi[(n - 1) * 9 + d] / dt + end[d] / dt);
+            const double ev = vel * w[d];
+            s2 += ev * ev;
+        }
+        const double nrm = sqrt(s2);
+        L.sml[i] = 0.5 * nrm * nrm;
+    }
+    __syncthreads();
+
+    // ---------------------------------------------------------------- phase 5: totals (cost.py:464-530)
+    // link costs: top-k branch broadcasts each link's summed cost to every waypoint (cost.py:416)
+    double obs_sum;
+    if (topk_mode) {
+        if (tid < 10) {
+            double cl = 0.0;
+            bool any = false;
+            for (int i = 0; i < n; ++i) { cl += L.gcost[i * 10 + tid]; any = any || (L.gwin[i * 10 + tid] >= 0); }
+            L.red[32 + tid] = (tid < mlinks && any) ? cl : 0.0;
+        }
+        __syncthreads();
+        double per_wp = 0.0;
+        for (int l = 0; l < 10; ++l) per_wp += L.red[32 + l];
+        obs_sum = per_wp * (double)n;
+        for (int i = tid; i < n; i += blockDim.x)
+            a.cost_traj[(size_t)s * n + i] = prm.obstacle_weight * per_wp + prm.smoothness_weight * L.sml[i];
+    } else {
+        obs_sum = block_sum(L, L.gcost, n * 10, 0);
+        for (int i = tid; i < n; i += blockDim.x) {
+            double r = 0.0;
+            for (int l = 0; l < 10; ++l) r += L.gcost[i * 10 + l];
+            a.cost_traj[(size_t)s * n + i] = prm.obstacle_weight * r + prm.smoothness_weight * L.sml[i];
+        }
+    }
+    const double smooth_sum = block_sum(L, L.sml, n + 1, 1);
+    for (int e = tid; e < n * 9; e += blockDim.x) {
+        double og = prm.obstacle_weight * L.og[e];
+        og = fmin(fmax(og, -prm.clip_grad_scale), prm.clip_grad_scale);
+        const double sgw = prm.smoothness_weight * L.sg[e];
+        const double gt = og + sgw;
+        L.og[e] = og * og; L.sg[e] = sgw * sgw; L.g[e] = gt; L.tv[e] = gt * gt;
+        a.grad[(size_t)s * n * 9 + e] = gt;
+    }
+    const double n_og = block_sum(L, L.og, n * 9, 2);
+    const double n_sg = block_sum(L, L.sg, n * 9, 3);
+    const double n_g = block_sum(L, L.tv, n * 9, 4);
+    // collide.sum() over the layer output (cost.py:187): per-thread partials -> fixed-order block sum
+    {
+        __syncthreads();
+        const double wsum = wave_sum(colsum);
+        if ((tid & 63) == 0) L.red[40 + (tid >> 6)] = wsum;
+        __syncthreads();
+    }
+    double collide = 0.0;
+    for (int wv = 0; wv < CH_WAVES; ++wv) collide += L.red[40 + wv];
+
+    // check_joint_limit (optimizer.py:166-174): flags only when a low AND a high violation exist
+    const double* lower = rv.lower();
+    const double* upper = rv.upper();
+    if (tid == 0) { L.red[50] = 0.0; L.red[51] = 0.0; }
+    __syncthreads();
+    {
+        bool lowv = false, highv = false;
+        for (int e = tid; e < n * 9; e += blockDim.x) {
+            const int d = e % 9;
+            lowv = lowv || (L.xi[e] < lower[d] - 5e-3);
+            highv = highv || (L.xi[e] > upper[d] + 5e-3);
+        }
+        if (lowv) L.red[50] = 1.0;   // benign same-value races
+        if (highv) L.red[51] = 1.0;
+    }
+    __syncthreads();
+
+    if (tid == 0) {
+        double goal_dist = 0.0;
+        if (prm.goal_set_proj) {
+            const double* gp = a.goal_point + 9 * (size_t)s;
+            for (int d = 0; d < 9; ++d) { const double e = L.xi[(n - 1) * 9 + d] - gp[d]; goal_dist += e * e; }
+            goal_dist = sqrt(goal_dist);
+        }
+        const bool violate = (L.red[50] > 0.0) && (L.red[51] > 0.0);
+        const double w_obs = prm.obstacle_weight * obs_sum, w_sm = prm.smoothness_weight * smooth_sum;
+        bool terminate = (collide <= prm.allow_collision_point) && prm.pre_terminate && (goal_dist < 0.01) &&
+                         (smooth_sum < prm.terminate_smooth_loss);
+        terminate = terminate && !violate;
+        const bool failure = (collide >= prm.allow_collision_point * 10) || (smooth_sum >= prm.terminate_smooth_loss * 2.5);
+        const bool execute = (collide <= prm.allow_collision_point) && (smooth_sum < prm.terminate_smooth_loss);
+        double* info = a.info + (size_t)s * OMGX_INFO_STRIDE;
+        info[OMGX_INFO_COST] = w_obs + w_sm;
+        info[OMGX_INFO_OBS] = obs_sum;
+        info[OMGX_INFO_SMOOTH] = smooth_sum;
+        info[OMGX_INFO_WEIGHTED_OBS] = w_obs;
+        info[OMGX_INFO_WEIGHTED_SMOOTH] = w_sm;
+        info[OMGX_INFO_WEIGHTED_OBS_GRAD] = sqrt(n_og);
+        info[OMGX_INFO_WEIGHTED_SMOOTH_GRAD] = sqrt(n_sg);
+        info[OMGX_INFO_GRAD] = sqrt(n_g);
+        info[OMGX_INFO_COLLIDE] = collide;
+        info[OMGX_INFO_REACH] = goal_dist;
+        info[OMGX_INFO_TERMINATE] = terminate ? 1.0 : 0.0;
+        info[OMGX_INFO_FAILURE_TERMINATE] = failure ? 1.0 : 0.0;
+        info[OMGX_INFO_EXECUTE] = execute ? 1.0 : 0.0;
+        info[OMGX_INFO_STANDOFF_IDX] = prm.use_standoff ? (double)(n - c) : (double)(n - 1);
+        info[OMGX_INFO_VIOLATE_LIMIT] = violate ? 1.0 : 0.0;
+        info[OMGX_INFO_LIMIT_STEPS] = 0.0;
+    }
+    if (!prm.do_update) return;
+
+    // ---------------------------------------------------------------- phase 6: covariant (projected) step
+    __syncthreads();
+    apply_ainv(L.g, L.tvs, n, free_end, dt2);  // Ag = Ainv g
+    __syncthreads();
+    const double eta = prm.step_size;
+    const double* goal = a.goal + (size_t)s * c * 9;
+    for (int e = tid; e < n * 9; e += blockDim.x) {
+        const int i = e / 9, d = e % 9;
+        double upd;
+        if (!free_end) {
+            upd = -eta * L.tvs[e];  // optimizer.py:132
+        } else {  // goal_set_projection, optimizer.py:101-112 with the closed-form M
+            const int first = n - c;
+            if (i >= first) {
+                const int q = i - first;
+                const double b = L.xi[e] - goal[q * 9 + d];
+                upd = -eta * L.tvs[e] + eta * L.tvs[e] - b;
+            } else {
+                const double m = (double)(i + 1) / (double)(first + 1);
+                const double b0 = L.xi[first * 9 + d] - goal[d];
+                upd = -eta * L.tvs[e] + eta * (m * L.tvs[first * 9 + d]) - m * b0;
+            }
+        }
+        // Trajectory.update (core.py:43-51): fingers frozen unless consider_finger, then clamped to [0, 0.04]
+        double xv = L.xi[e];
+        if (d < 7 || prm.consider_finger) xv += upd;
+        if (d >= 7) xv = fmin(fmax(xv, 0.0), 0.04);
+        L.g[e] = xv;  // new trajectory staged in L.g (L.xi still feeds neighbours' b0 reads)
+    }
+    __syncthreads();
+    for (int e = tid; e < n * 9; e += blockDim.x) L.xi[e] = L.g[e];
+
+    // ---------------------------------------------------------------- phase 7: handle_joint_limit (optimizer.py:148-164)
+    int cnt = 0;
+    for (;;) {
+        __syncthreads();
+        for (int e = tid; e < n * 9; e += blockDim.x) {  // compute_traj_v
+            const int d = e % 9;
+            const double x = L.xi[e];
+            const double t = (x < lower[d] ? lower[d] - x : 0.0) + (x > upper[d] ? upper[d] - x : 0.0);
+            L.tv[e] = t;
+            L.g[e] = t * t;
+        }
+        const double nrm2 = block_sum(L, L.g, n * 9, 5);
+        if (!(sqrt(nrm2) > 1e-2) || cnt >= prm.joint_limit_max_steps) break;
+        apply_ainv(L.tv, L.tvs, n, free_end, dt2);
+        __syncthreads();
+        if (tid < 64) {  // np.abs(traj_v).argmax(): first maximum in flat order
+            double best = -1.0;
+            int bi = 0x7fffffff;
+            for (int e = tid; e < n * 9; e += 64) {
+                const double v = fabs(L.tv[e]);
+                if (v > best) { best = v; bi = e; }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const double ov = __shfl_xor(best, off, 64);
+                const int oi = __shfl_xor(bi, off, 64);
+                if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+            }
+            if (tid == 0) L.red[6] = best / (fabs(L.tvs[bi]) + 1e-8);  // safe_div
+        }
+        __syncthreads();
+        const double scale = L.red[6];
+        for (int e = tid; e < n * 9; e += blockDim.x) L.xi[e] += scale * L.tvs[e];
+        ++cnt;
+    }
+    for (int e = tid; e < n * 9; e += blockDim.x) traj[e] = L.xi[e];
+    if (tid == 0) a.info[(size_t)s * OMGX_INFO_STRIDE + OMGX_INFO_LIMIT_STEPS] = (double)cnt;
+}
+
+static size_t host_lds_bytes(int n, int P) {
+    size_t d = (size_t)(n + 2) * 120 + (size_t)n * 30 * 2 + (size_t)n * 80 + (size_t)n * 10 + (size_t)n * 9 * 6 + (n + 1) + 30 * P + 64;
+    size_t i = (size_t)n * 10 + 256 + (n * 160 + 31) / 32 + 16;
+    return d * 8 + i * 4;
+}
+
+extern "C" int omgx_chomp_optimize(const double* robot, const omgx_chomp_params* h_params, double* traj,
+                                   const double* start, const double* end, const double* goal,
+                                   const double* goal_point, const float* potentials, const float* grads,
+                                   const float* collides, const int32_t* active, int32_t num_scenes, double* grad,
+                                   double* cost_traj, double* info, void* stream) {
+    if (!h_params || num_scenes < 0) return OMGX_ERR_INVALID;
+    if (num_scenes == 0) return OMGX_OK;
+    if (!robot || !traj || !start || !end || !goal || !goal_point || !potentials || !grads || !collides || !grad ||
+        !cost_traj || !info)
+        return OMGX_ERR_INVALID;
+    const omgx_chomp_params& p = *h_params;
+    if (p.n_waypoints < 1 || p.n_waypoints > OMGX_MAX_WAYPOINTS || p.n_points < 1 || p.n_points > OMGX_MAX_POINTS ||
+        p.constraint_num < 1 || p.constraint_num > OMGX_MAX_CONSTRAINTS || p.constraint_num > p.n_waypoints)
+        return OMGX_ERR_UNSUPPORTED;
+    if (!(p.time_interval > 0.0) || p.top_k < 0) return OMGX_ERR_INVALID;
+    ChompArgs a{};
+    a.robot = robot; a.prm = p; a.traj = traj; a.start = start; a.end = end; a.goal = goal; a.goal_point = goal_point;
+    a.pot = potentials; a.pgrad = grads; a.col = collides; a.active = active; a.grad = grad; a.cost_traj = cost_traj;
+    a.info = info;
+    const size_t lds = host_lds_bytes(p.n_waypoints, p.n_points);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_chomp_optimize, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return omgx_set_error("hipFuncSetAttribute(k_chomp_optimize)", e);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_chomp_optimize, dim3(num_scenes), dim3(CH_TPB), lds, (hipStream_t)stream, a);
+    OMGX_CHECK_LAUNCH("k_chomp_optimize");
+    return OMGX_OK;
+}

@@ -1,0 +1,317 @@
+// omg_device.h — device-side building blocks of the gfx950 CHOMP engine.
+//
+//   * SDF lookup: trilinear value + one-voxel central-difference gradient + hinge potential for one
+//     (point, object) pair — the body of SDFdistanceForward, layers/sdf_matching_loss_kernel.cu:96-181
+//     and its helpers (.cu:15-86).  The float32 arithmetic is written operation for operation like
+//     oracle/omg_oracle.c (explicit fmaf, -ffp-contract=off) so results are bit-identical to the oracle.
+//   * Panda forward kinematics in double — ycb_render/robotPose/robot_pykdl.py:148-215 re-associated
+//     around host-precomputed constants (see RobotView).
+//
+// gfx950 only: 64-wide wavefronts are assumed throughout.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/omg_hip.h"
+
+#define OMG_WAVE 64
+
+namespace omg {
+
+// -------------------------------------------------------------------------------------------------
+// SDF lookup
+// -------------------------------------------------------------------------------------------------
+struct __attribute__((packed, aligned(4))) F2 { float a, b; };        // dword-aligned 8-byte row piece
+struct __attribute__((packed, aligned(4))) F4 { float a, b, c, d; };  // dword-aligned 16-byte row piece
+
+__device__ __forceinline__ float lerpf(float a, float b, float t) { return __builtin_fmaf(t, b - a, a); }  // .cu:15-18
+
+// pGrid - 0.5 in double, truncation toward zero, fraction rounded to float (.cu:39-41).
+// `ok` is false for coordinates whose (int) cast would be undefined (the oracle returns 1.0 there).
+struct Axis { int i0; float f; bool ok; };
+__device__ __forceinline__ Axis axis_of(float g) {
+    Axis a;
+    a.ok = (g > -1.0e9f) && (g <= 1.0e9f);  // == (g-0.5 in (-1e9,1e9)) for float g; false for NaN
+    const double s = (double)g - 0.5;
+    a.i0 = (int)s;
+    a.f = (float)(s - (double)a.i0);
+    return a;
+}
+
+__device__ __forceinline__ float trilerp(float v000, float v001, float v010, float v011, float v100, float v101,
+                                         float v110, float v111, float fx, float fy, float fz) {
+    const float dx00 = lerpf(v000, v100, fx);
+    const float dx01 = lerpf(v001, v101, fx);
+    const float dx10 = lerpf(v010, v110, fx);
+    const float dx11 = lerpf(v011, v111, fx);
+    const float dxy0 = lerpf(dx00, dx10, fy);
+    const float dxy1 = lerpf(dx01, dx11, fy);
+    return lerpf(dxy0, dxy1, fz);
+}
+
+struct Grid {
+    const float* __restrict__ g;
+    int dx, dy, dz;
+    __device__ __forceinline__ int idx(int x, int y, int z) const { return (x * dy + y) * dz + z; }
+};
+
+// getValueInterpolated (.cu:36-64) from pre-split axes: generic path, own range test, 1.0 outside.
+__device__ __forceinline__ float sdf_value(const Grid& G, const Axis& ax, const Axis& ay, const Axis& az) {
+    const bool in = ax.ok && ay.ok && az.ok && ax.i0 >= 0 && ax.i0 < G.dx - 1 && ay.i0 >= 0 && ay.i0 < G.dy - 1 &&
+                    az.i0 >= 0 && az.i0 < G.dz - 1;
+    if (!in) return 1.0f;
+    const int b = G.idx(ax.i0, ay.i0, az.i0);
+    const int sy = G.dz, sx = G.dy * G.dz;
+    const F2 r00 = *reinterpret_cast<const F2*>(G.g + b);
+    const F2 r01 = *reinterpret_cast<const F2*>(G.g + b + sy);
+    const F2 r10 = *reinterpret_cast<const F2*>(G.g + b + sx);
+    const F2 r11 = *reinterpret_cast<const F2*>(G.g + b + sx + sy);
+    return trilerp(r00.a, r00.b, r01.a, r01.b, r10.a, r10.b, r11.a, r11.b, ax.f, ay.f, az.f);
+}
+
+struct ObjParams {  // wave-uniform (SGPR-resident) per-object parameters
+    float T[12];    // inverse pose rows
+    float lo[3], hi[3];
+    int dim[3];
+    float delta, eps, pad, clr;
+};
+
+struct Accum { float pot, gx, gy, gz, col; };
+
+// One (point, object) pair: body of SDFdistanceForward (.cu:111-180); adds into acc.
+// WANT_GRAD=false skips the world-frame gradient accumulation (potential/collides only need the
+// centre lookup unless the caller wants gradients).
+template <bool WANT_GRAD>
+__device__ __forceinline__ void sdf_pair(const ObjParams& o, const float* __restrict__ grid, float px, float py, float pz,
+                                         Accum& acc) {
+    const float* T = o.T;
+    // SE3(pose) * point (.cu:125-133)
+    const float ux = __builtin_fmaf(T[2], pz, __builtin_fmaf(T[1], py, __builtin_fmaf(T[0], px, T[3])));
+    const float uy = __builtin_fmaf(T[6], pz, __builtin_fmaf(T[5], py, __builtin_fmaf(T[4], px, T[7])));
+    const float uz = __builtin_fmaf(T[10], pz, __builtin_fmaf(T[9], py, __builtin_fmaf(T[8], px, T[11])));
+    // grid coordinates (.cu:137-142)
+    const float gx = (ux - o.lo[0]) / (o.hi[0] - o.lo[0]) * (float)o.dim[0];
+    const float gy = (uy - o.lo[1]) / (o.hi[1] - o.lo[1]) * (float)o.dim[1];
+    const float gz = (uz - o.lo[2]) / (o.hi[2] - o.lo[2]) * (float)o.dim[2];
+    Grid G{grid, o.dim[0], o.dim[1], o.dim[2]};
+    const Axis ax = axis_of(gx), ay = axis_of(gy), az = axis_of(gz);
+
+    const bool in_c = ax.ok && ay.ok && az.ok && ax.i0 >= 0 && ax.i0 < G.dx - 1 && ay.i0 >= 0 && ay.i0 < G.dy - 1 &&
+                      az.i0 >= 0 && az.i0 < G.dz - 1;
+    if (!in_c) {  // centre lookup is out of range -> 1.0 (.cu:49-50); almost always ends the pair here
+        if (1.0f < o.clr) acc.col += 1.0f;
+        if (!(1.0f <= o.eps)) return;
+    }
+    // Interior fast path: the whole 4x4x4-minus-corners stencil (32 voxels) is in range and the
+    // +-1 voxel shifted coordinates split regularly (i0 +- 1).  Then the 7 trilinear lookups share 12
+    // row loads (4 x 16 B + 8 x 8 B) instead of 7 x 8 scalar loads.
+    const Axis axp = axis_of(gx + 1.0f), axm = axis_of(gx - 1.0f);
+    const Axis ayp = axis_of(gy + 1.0f), aym = axis_of(gy - 1.0f);
+    const Axis azp = axis_of(gz + 1.0f), azm = axis_of(gz - 1.0f);
+    const bool regular = axp.i0 == ax.i0 + 1 && axm.i0 == ax.i0 - 1 && ayp.i0 == ay.i0 + 1 && aym.i0 == ay.i0 - 1 &&
+                         azp.i0 == az.i0 + 1 && azm.i0 == az.i0 - 1 && axp.ok && axm.ok && ayp.ok && aym.ok && azp.ok && azm.ok;
+    const bool interior = in_c && regular && ax.i0 >= 1 && ax.i0 < G.dx - 2 && ay.i0 >= 1 && ay.i0 < G.dy - 2 &&
+                          az.i0 >= 1 && az.i0 < G.dz - 2;
+
+    float value, fpx, fmx, fpy, fmy, fpz, fmz;
+    if (interior) {
+        const int sy = G.dz, sx = G.dy * G.dz;
+        const int b = G.idx(ax.i0, ay.i0, az.i0);
+        // centre rows, z0-1 .. z0+2
+        const F4 c00 = *reinterpret_cast<const F4*>(G.g + b - 1);
+        const F4 c01 = *reinterpret_cast<const F4*>(G.g + b + sy - 1);
+        const F4 c10 = *reinterpret_cast<const F4*>(G.g + b + sx - 1);
+        const F4 c11 = *reinterpret_cast<const F4*>(G.g + b + sx + sy - 1);
+        value = trilerp(c00.b, c00.c, c01.b, c01.c, c10.b, c10.c, c11.b, c11.c, ax.f, ay.f, az.f);
+        if (value < o.clr) acc.col += 1.0f;  // .cu:150-151
+        if (!(value <= o.eps)) return;       // .cu:170-171
+        // +-z: same rows shifted by one voxel
+        fpz = trilerp(c00.c, c00.d, c01.c, c01.d, c10.c, c10.d, c11.c, c11.d, ax.f, ay.f, azp.f);
+        fmz = trilerp(c00.a, c00.b, c01.a, c01.b, c10.a, c10.b, c11.a, c11.b, ax.f, ay.f, azm.f);
+        // +-x: planes x0+2 and x0-1
+        const F2 xp0 = *reinterpret_cast<const F2*>(G.g + b + 2 * sx);
+        const F2 xp1 = *reinterpret_cast<const F2*>(G.g + b + 2 * sx + sy);
+        const F2 xm0 = *reinterpret_cast<const F2*>(G.g + b - sx);
+        const F2 xm1 = *reinterpret_cast<const F2*>(G.g + b - sx + sy);
+        fpx = trilerp(c10.b, c10.c, c11.b, c11.c, xp0.a, xp0.b, xp1.a, xp1.b, axp.f, ay.f, az.f);
+        fmx = trilerp(xm0.a, xm0.b, xm1.a, xm1.b, c00.b, c00.c, c01.b, c01.c, axm.f, ay.f, az.f);
+        // +-y: rows y0+2 and y0-1
+        const F2 yp0 = *reinterpret_cast<const F2*>(G.g + b + 2 * sy);
+        const F2 yp1 = *reinterpret_cast<const F2*>(G.g + b + sx + 2 * sy);
+        const F2 ym0 = *reinterpret_cast<const F2*>(G.g + b - sy);
+        const F2 ym1 = *reinterpret_cast<const F2*>(G.g + b + sx - sy);
+        fpy = trilerp(c01.b, c01.c, yp0.a, yp0.b, c11.b, c11.c, yp1.a, yp1.b, ax.f, ayp.f, az.f);
+        fmy = trilerp(ym0.a, ym0.b, c00.b, c00.c, ym1.a, ym1.b, c10.b, c10.c, ax.f, aym.f, az.f);
+    } else {
+        if (in_c) {
+            value = sdf_value(G, ax, ay, az);
+            if (value < o.clr) acc.col += 1.0f;
+            if (!(value <= o.eps)) return;
+        } else {
+            value = 1.0f;  // only reachable when eps >= 1
+        }
+        fpx = sdf_value(G, axp, ay, az);
+        fpy = sdf_value(G, ax, ayp, az);
+        fpz = sdf_value(G, ax, ay, azp);
+        fmx = sdf_value(G, axm, ay, az);
+        fmy = sdf_value(G, ax, aym, az);
+        fmz = sdf_value(G, ax, ay, azm);
+    }
+    float v0, v1, v2;
+    if (value <= 0.0f) {  // .cu:158-164
+        acc.pot += (float)(-(double)value + 0.5 * (double)o.eps);
+        if (!WANT_GRAD) return;
+        const float g0 = (float)(0.5 * (double)(fpx - fmx) / (double)o.delta);  // .cu:82-84
+        const float g1 = (float)(0.5 * (double)(fpy - fmy) / (double)o.delta);
+        const float g2 = (float)(0.5 * (double)(fpz - fmz) / (double)o.delta);
+        v0 = -g0; v1 = -g1; v2 = -g2;
+    } else {  // 0 < value <= eps (.cu:165-171)
+        const float d = value - o.eps;
+        acc.pot += 1.0f / (2.0f * o.eps) * d * d * o.pad;
+        if (!WANT_GRAD) return;
+        const float g0 = (float)(0.5 * (double)(fpx - fmx) / (double)o.delta);
+        const float g1 = (float)(0.5 * (double)(fpy - fmy) / (double)o.delta);
+        const float g2 = (float)(0.5 * (double)(fpz - fmz) / (double)o.delta);
+        const float ie = 1.0f / o.eps;
+        v0 = ie * g0 * d * o.pad; v1 = ie * g1 * d * o.pad; v2 = ie * g2 * d * o.pad;
+    }
+    // rotationMatrix.transpose() * vgrad (.cu:176-179)
+    acc.gx += __builtin_fmaf(T[8], v2, __builtin_fmaf(T[4], v1, T[0] * v0));
+    acc.gy += __builtin_fmaf(T[9], v2, __builtin_fmaf(T[5], v1, T[1] * v0));
+    acc.gz += __builtin_fmaf(T[10], v2, __builtin_fmaf(T[6], v1, T[2] * v0));
+}
+
+__device__ __forceinline__ ObjParams load_object(const omgx_object* __restrict__ ob) {
+    ObjParams o;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) o.T[k] = ob->pose_inv[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { o.lo[k] = ob->lo[k]; o.hi[k] = ob->hi[k]; o.dim[k] = ob->dim[k]; }
+    o.delta = ob->delta; o.eps = ob->epsilon; o.pad = ob->padding_scale; o.clr = ob->clearance;
+    return o;
+}
+
+// All objects of one scene for one point (objects summed in index order; the reference's atomicAdd
+// order is unspecified, .cu:185-195).
+template <bool WANT_GRAD>
+__device__ __forceinline__ Accum sdf_point(const omgx_object* __restrict__ objs, int o_begin, int o_end,
+                                           const float* __restrict__ pool, float px, float py, float pz) {
+    Accum acc{0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    for (int o = o_begin; o < o_end; ++o) {  // wave-uniform trip count and addresses -> scalar loads
+        const omgx_object* ob = objs + o;
+        if (ob->disabled > 0) continue;  // .cu:115-116
+        const ObjParams op = load_object(ob);
+        sdf_pair<WANT_GRAD>(op, pool + ob->grid_offset, px, py, pz, acc);
+    }
+    return acc;
+}
+
+// -------------------------------------------------------------------------------------------------
+// Forward kinematics (double)
+// -------------------------------------------------------------------------------------------------
+// Derived constants appended to the robot blob by the host (omg-planner_amd/robot.py: PandaModel.blob):
+//   raw tables [0, 528 + 30 P)  as documented in include/omg_hip.h, then at D = 528 + 30 P:
+//   D+0    UVW  [7][3][9]   b_i(q) = pose_0[i] . Rz(q) . Rx(off_i) . N_i has rotation c*U_i + s*V_i + W_i
+//   D+189  TP   [7][3]      ... and translation pose_0[i][:3,3]
+//   D+210  H    [12]        pose_0[7] rows (hand)            (robot_pykdl.py:186)
+//   D+222  LF   [12]        pose_0[8] rows (left finger)     (:181-182)
+//   D+234  RF   [12]        pose_0[9] rows (right finger)    (:183-184)
+//   D+246  PTS  [10][P][3]  center_offset[l] applied to collision_points[l][p]  (:203-204 folded into cost.py:60-72)
+//   D+246+30P AX [10][3]    tip2joint[l][:3,:3] . joint_axis[l]                  (:190-197)
+//   D+276+30P OG [10][3]    tip2joint[l][:3,3]
+struct RobotView {
+    const double* __restrict__ raw;
+    const double* __restrict__ d;
+    int P;
+    __device__ __forceinline__ RobotView(const double* blob, int P_) : raw(blob), d(blob + OMGX_ROBOT_POINTS + 30 * P_), P(P_) {}
+    __device__ __forceinline__ const double* uvw(int i) const { return d + 27 * i; }
+    __device__ __forceinline__ const double* tp(int i) const { return d + 189 + 3 * i; }
+    __device__ __forceinline__ const double* hand() const { return d + 210; }
+    __device__ __forceinline__ const double* lf() const { return d + 222; }
+    __device__ __forceinline__ const double* rf() const { return d + 234; }
+    __device__ __forceinline__ const double* pts(int l, int p) const { return d + 246 + 3 * (l * P + p); }
+    __device__ __forceinline__ const double* ax(int l) const { return d + 246 + 30 * P + 3 * l; }
+    __device__ __forceinline__ const double* og(int l) const { return d + 276 + 30 * P + 3 * l; }
+    __device__ __forceinline__ const double* lower() const { return raw + OMGX_ROBOT_LOWER; }
+    __device__ __forceinline__ const double* upper() const { return raw + OMGX_ROBOT_UPPER; }
+};
+
+struct Pose { double R[9]; double t[3]; };  // link frame BEFORE center_offset (robot_pykdl output_pose)
+
+__device__ __forceinline__ void pose_mul(const Pose& A, const double* __restrict__ B /*rows [3][4]*/, Pose& C) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            C.R[3 * r + c] = A.R[3 * r] * B[c] + A.R[3 * r + 1] * B[4 + c] + A.R[3 * r + 2] * B[8 + c];
+        C.t[r] = A.R[3 * r] * B[3] + A.R[3 * r + 1] * B[7] + A.R[3 * r + 2] * B[11] + A.t[r];
+    }
+}
+
+// wrap_values' rad->deg and forward_kinematics_parallel's deg->rad (omg/util.py:194-202, robot_pykdl.py:164)
+__device__ __forceinline__ double deg_round_trip(double q) { return (q / M_PI * 180.0) / 180.0 * M_PI; }
+
+// Visits the 10 link poses of configuration q[9] (radians) in order; f(l, pose).
+template <class F>
+__device__ __forceinline__ void fk_chain(const RobotView& rv, const double* __restrict__ q, F&& f) {
+    Pose cur;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) cur.R[k] = (k % 4 == 0) ? 1.0 : 0.0;
+    cur.t[0] = cur.t[1] = cur.t[2] = 0.0;
+    for (int i = 0; i < 7; ++i) {
+        double s, c;
+        sincos(deg_round_trip(q[i]), &s, &c);
+        const double* uvw = rv.uvw(i);
+        const double* tp = rv.tp(i);
+        double B[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) B[k] = c * uvw[k] + s * uvw[9 + k] + uvw[18 + k];
+        Pose nxt;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc)
+                nxt.R[3 * r + cc] = cur.R[3 * r] * B[cc] + cur.R[3 * r + 1] * B[3 + cc] + cur.R[3 * r + 2] * B[6 + cc];
+            nxt.t[r] = cur.R[3 * r] * tp[0] + cur.R[3 * r + 1] * tp[1] + cur.R[3 * r + 2] * tp[2] + cur.t[r];
+        }
+        cur = nxt;
+        f(i, cur);
+    }
+    Pose hand;
+    pose_mul(cur, rv.hand(), hand);
+    f(7, hand);
+    {
+        double Fm[12];
+        const double* L = rv.lf();
+#pragma unroll
+        for (int k = 0; k < 12; ++k) Fm[k] = L[k];
+        Fm[7] += deg_round_trip(q[7]);  // left_finger_pose[:, 1, 3] += joints[:, -2]
+        Pose fp;
+        pose_mul(hand, Fm, fp);
+        f(8, fp);
+        const double* Rr = rv.rf();
+#pragma unroll
+        for (int k = 0; k < 12; ++k) Fm[k] = Rr[k];
+        Fm[7] -= deg_round_trip(q[8]);  // right_finger_pose[:, 1, 3] -= joints[:, -1]
+        pose_mul(hand, Fm, fp);
+        f(9, fp);
+    }
+}
+
+__device__ __forceinline__ void pose_apply(const Pose& A, const double* __restrict__ p, double& x, double& y, double& z) {
+    x = A.R[0] * p[0] + A.R[1] * p[1] + A.R[2] * p[2] + A.t[0];
+    y = A.R[3] * p[0] + A.R[4] * p[1] + A.R[5] * p[2] + A.t[1];
+    z = A.R[6] * p[0] + A.R[7] * p[1] + A.R[8] * p[2] + A.t[2];
+}
+
+// -------------------------------------------------------------------------------------------------
+// wave / block reductions with a fixed combination order (deterministic results)
+// -------------------------------------------------------------------------------------------------
+template <class T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, OMG_WAVE);
+    return v;  // valid in lane 0
+}
+
+}  // namespace omg

@@ -1,0 +1,134 @@
+"""Tensor-level wrappers over the C ABI.  torch owns device memory and streams; all compute is in
+libomg_hip.so.  Every function enqueues on torch's current stream and returns without syncing."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import ChompParams, check
+
+_ws_cache: dict = {}
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need(t: torch.Tensor, dtype, name: str):
+    if not t.is_cuda:
+        raise _lib.OmgHipError(f"{name} must be a device tensor (the reference asserts CHECK_CUDA, omg_layers.cpp:5)")
+    if not t.is_contiguous():
+        raise _lib.OmgHipError(f"{name} must be contiguous (CHECK_CONTIGUOUS, omg_layers.cpp:6)")
+    if t.dtype != dtype:
+        raise _lib.OmgHipError(f"{name} must be {dtype}, got {t.dtype}")
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    key = (device, torch.cuda.current_stream().cuda_stream)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+def sdf_loss_forward(pose_init, sdf_grids, sdf_limits, points, epsilons, padding_scales, clearances, disables):
+    """omg_cuda.sdf_loss_forward (layers/omg_layers.cpp:24-49): -> [potentials[N], potential_grads[N,3], collides[N]]."""
+    for n, t in (("pose_init", pose_init), ("sdf_grids", sdf_grids), ("sdf_limits", sdf_limits), ("points", points),
+                 ("epsilons", epsilons), ("padding_scales", padding_scales), ("clearances", clearances), ("disables", disables)):
+        _need(t, torch.float32, n)
+    N, O = points.shape[0], pose_init.shape[0]
+    pot = torch.empty(N, dtype=torch.float32, device=points.device)
+    grad = torch.empty((N, 3), dtype=torch.float32, device=points.device)
+    col = torch.empty(N, dtype=torch.float32, device=points.device)
+    with torch.cuda.device(points.device):
+        check(_lib.lib().omgx_sdf_loss_forward(_ptr(pose_init), _ptr(sdf_grids), _ptr(sdf_limits), _ptr(points),
+                                               _ptr(epsilons), _ptr(padding_scales), _ptr(clearances), _ptr(disables),
+                                               N, O, _ptr(pot), _ptr(grad), _ptr(col), _stream()), "omgx_sdf_loss_forward")
+    return [pot, grad, col]
+
+
+class DeviceScenes:
+    """Scene table resident in HBM: object records, scene_begin, SDF pool (see scenes.SceneBatch)."""
+
+    def __init__(self, batch, device="cuda:0"):
+        self.device = torch.device(device)
+        self.num_scenes = batch.num_scenes
+        self.objects = torch.from_numpy(np.ascontiguousarray(batch.objects).view(np.uint8).copy()).to(self.device)
+        self.scene_begin = torch.from_numpy(np.ascontiguousarray(batch.scene_begin, np.int32)).to(self.device)
+        self.pool = torch.from_numpy(np.ascontiguousarray(batch.pool, np.float32)).to(self.device)
+
+
+def robot_blob(model, device="cuda:0") -> torch.Tensor:
+    return torch.from_numpy(model.blob()).to(device)
+
+
+def fk_sdf(robot: torch.Tensor, P: int, scenes: DeviceScenes, joints: torch.Tensor, soften_fingers=False,
+           want_grad=True, want_col=True, out=None):
+    """joints [S,C,9] f64 -> potentials [S,C,10,P], grads [S,C,10,P,3] | None, collides [S,C,10,P] | None."""
+    _need(joints, torch.float64, "joints")
+    S, Cn = joints.shape[0], joints.shape[1]
+    dev = joints.device
+    if out is None:
+        pot = torch.empty((S, Cn, 10, P), dtype=torch.float32, device=dev)
+        grad = torch.empty((S, Cn, 10, P, 3), dtype=torch.float32, device=dev) if want_grad else None
+        col = torch.empty((S, Cn, 10, P), dtype=torch.float32, device=dev) if want_col else None
+    else:
+        pot, grad, col = out
+    l = _lib.lib()
+    with torch.cuda.device(dev):
+        ws = _workspace(l.omgx_fk_sdf_workspace_bytes(S, Cn, P), dev)
+        check(l.omgx_fk_sdf(_ptr(robot), P, _ptr(scenes.objects), _ptr(scenes.scene_begin), _ptr(scenes.pool),
+                            _ptr(joints), S, Cn, int(bool(soften_fingers)), _ptr(pot), _ptr(grad), _ptr(col), _ptr(ws),
+                            _stream()), "omgx_fk_sdf")
+    return pot, grad, col
+
+
+def goalset_cost(robot, P, scenes: DeviceScenes, traj_start, goals, n_remaining, dt, soften_fingers=False,
+                 want_potentials=False, out=None):
+    """traj_start [S,9], goals [S,G,9] f64 -> goal_cost [S,G] f32, collides [S,G] f32, potentials [S,G,n,10,P] | None."""
+    _need(traj_start, torch.float64, "traj_start")
+    _need(goals, torch.float64, "goals")
+    S, G = goals.shape[0], goals.shape[1]
+    dev = goals.device
+    if out is None:
+        cost = torch.empty((S, G), dtype=torch.float32, device=dev)
+        col = torch.empty((S, G), dtype=torch.float32, device=dev)
+    else:
+        cost, col = out
+    pots = torch.empty((S, G, n_remaining, 10, P), dtype=torch.float32, device=dev) if want_potentials else None
+    l = _lib.lib()
+    with torch.cuda.device(dev):
+        ws = _workspace(l.omgx_goalset_workspace_bytes(S, G, n_remaining, P), dev)
+        check(l.omgx_goalset_cost(_ptr(robot), P, _ptr(scenes.objects), _ptr(scenes.scene_begin), _ptr(scenes.pool),
+                                  _ptr(traj_start), _ptr(goals), S, G, n_remaining, float(dt), int(bool(soften_fingers)),
+                                  _ptr(cost), _ptr(pots), _ptr(col), _ptr(ws), _stream()), "omgx_goalset_cost")
+    return cost, col, pots
+
+
+def chomp_optimize(robot, params: ChompParams, traj, start, end, goal, goal_point, pot, pgrad, col, active=None, out=None):
+    """In-place step on traj [S,n,9] f64 -> grad [S,n,9], cost_traj [S,n], info [S,16] (f64)."""
+    for n_, t in (("traj", traj), ("start", start), ("end", end), ("goal", goal), ("goal_point", goal_point)):
+        _need(t, torch.float64, n_)
+    for n_, t in (("potentials", pot), ("grads", pgrad), ("collides", col)):
+        _need(t, torch.float32, n_)
+    S, n = traj.shape[0], traj.shape[1]
+    dev = traj.device
+    if out is None:
+        grad = torch.empty((S, n, 9), dtype=torch.float64, device=dev)
+        cost_traj = torch.empty((S, n), dtype=torch.float64, device=dev)
+        info = torch.zeros((S, _lib.INFO_STRIDE), dtype=torch.float64, device=dev)
+    else:
+        grad, cost_traj, info = out
+    with torch.cuda.device(dev):
+        check(_lib.lib().omgx_chomp_optimize(_ptr(robot), C.byref(params), _ptr(traj), _ptr(start), _ptr(end), _ptr(goal),
+                                             _ptr(goal_point), _ptr(pot), _ptr(pgrad), _ptr(col), _ptr(active), S,
+                                             _ptr(grad), _ptr(cost_traj), _ptr(info), _stream()), "omgx_chomp_optimize")
+    return grad, cost_traj, info

@@ -49,11 +49,44 @@ class PandaModel:
         return int(self.collision_points.shape[1])
 
     def blob(self) -> np.ndarray:
-        """Flat float64 constants blob, layout = include/omg_hip.h OMGX_ROBOT_*."""
-        return np.concatenate([
+        """Flat float64 constants blob: raw tables (include/omg_hip.h OMGX_ROBOT_*) followed by the
+        derived constants the device FK uses (same header, "followed, at D = 528+30P, by ...")."""
+        raw = np.concatenate([
             self.pose_0.ravel(), self.tip2joint.ravel(), self.center_offset.ravel(), self.joint_axis.ravel(),
             self.joint_lower_limit.ravel(), self.joint_upper_limit.ravel(), self.collision_points.ravel(),
         ]).astype(np.float64)
+        return np.concatenate([raw, self._derived()])
+
+    def _derived(self) -> np.ndarray:
+        """Re-association of forward_kinematics_parallel (robot_pykdl.py:148-215) into 3x3 pieces.
+
+        b_i(q) = pose_0[i] @ Rz(q) @ Rx(off_i), columns 1,2 negated for i > 0 (line 176).  With
+        Rz(q) = cos(q) E1 + sin(q) E2 + E3 its rotation part is cos(q) U_i + sin(q) V_i + W_i and its
+        translation is pose_0[i][:3,3].  center_offset is folded into the collision points and
+        tip2joint into the joint axis / origin, so the device never forms a 4x4 product.
+        """
+        offs = [0.0, -np.pi, np.pi, np.pi, -np.pi, np.pi, np.pi]
+        E1 = np.diag([1.0, 1.0, 0.0])
+        E2 = np.array([[0.0, -1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 0.0]])
+        E3 = np.diag([0.0, 0.0, 1.0])
+        uvw, tp = [], []
+        for i in range(7):
+            co, so = np.cos(offs[i]), np.sin(offs[i])
+            Rx = np.array([[1.0, 0.0, 0.0], [0.0, co, -so], [0.0, so, co]])
+            N = np.eye(3) if i == 0 else np.diag([1.0, -1.0, -1.0])
+            C = Rx @ N
+            Rp = self.pose_0[i][:3, :3]
+            uvw.append(np.stack([Rp @ E1 @ C, Rp @ E2 @ C, Rp @ E3 @ C]))
+            tp.append(self.pose_0[i][:3, 3])
+        rows = lambda T: T[:3, :4].ravel()
+        P = self.points_per_link
+        pts = np.einsum("lrc,lpc->lpr", self.center_offset[:, :3, :3], self.collision_points) + self.center_offset[:, None, :3, 3]
+        ax = np.einsum("lrc,lc->lr", self.tip2joint[:, :3, :3], self.joint_axis)
+        og = self.tip2joint[:, :3, 3]
+        out = np.concatenate([np.array(uvw).ravel(), np.array(tp).ravel(), rows(self.pose_0[7]), rows(self.pose_0[8]),
+                              rows(self.pose_0[9]), pts.ravel(), ax.ravel(), og.ravel()])
+        assert out.size == 306 + 30 * P
+        return out
 
 
 def synthetic_collision_points(points_per_link: int = 15, seed: int = 0) -> np.ndarray:

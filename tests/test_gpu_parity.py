@@ -1,0 +1,298 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP kernels, called through the C ABI of
+include/omg_hip.h, against (a) the CPU oracle on the same seeded inputs and (b) the golden fixtures
+produced by the reference itself.
+
+Tolerances: the float32 SDF arithmetic is bit-exact against the oracle; float64 stages are compared
+at 1e-9 (one step) / 1e-6 (free-running sequences); north_star's bar is 1e-4 on trajectory states
+and cost values."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU: torch.cuda.is_available() is False")
+    from omg_planner_amd import _lib
+    assert _lib.device_arch().startswith("gfx950"), _lib.device_arch()
+    return torch.device("cuda:0")
+
+
+def _t(a, dev, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(dev)
+
+
+def _padded_inputs(fx):
+    poses, eps, pad, clr, dis = H.layer_params_from(fx)
+    return poses, fx["sdf"], fx["limits"], eps, pad, clr, dis
+
+
+# ------------------------------------------------------------------------------------------------
+# (1) omgx_sdf_loss_forward
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", ["cost_topk300.npz", "cost_soft_finger.npz", "cost_attached.npz"])
+def test_sdf_loss_forward_bit_exact_vs_oracle(dev, case):
+    from omg_planner_amd import ops
+    from oracle import oracle as orc
+    fx = H.load(case)
+    poses, sdf, lim, eps, pad, clr, dis = _padded_inputs(fx)
+    rng = np.random.RandomState(0)
+    N = 200_000
+    pts = rng.uniform([-0.4, -0.8, -0.3], [1.2, 0.8, 1.2], size=(N, 3)).astype(np.float32)
+    # edge cases: far away, exactly on grid faces, huge, non-finite
+    pts[:8] = [[1e9, 0, 0], [-1e9, 0, 0], [3e9, 1, 1], [np.inf, 0, 0], [0, -np.inf, 0], [1e30, 1e30, 1e30],
+               [0.5, 0.0, 0.02], [-0.3, -0.3, -0.3]]
+    ref = orc.sdf_loss_forward(poses, sdf, lim, pts, eps, pad, clr, dis)
+    got = ops.sdf_loss_forward(*[_t(a, dev) for a in (poses, sdf, lim, pts, eps, pad, clr, dis)])
+    torch.cuda.synchronize()
+    for name, r, g in zip(("potentials", "grads", "collides"), ref, got):
+        np.testing.assert_array_equal(g.cpu().numpy(), r, err_msg=name)
+    assert (ref[0] > 0).mean() > 0.05 and ref[2].sum() > 100  # the case exercises both hinge branches
+
+
+def test_sdf_loss_forward_empty_and_disabled(dev):
+    from omg_planner_amd import ops
+    fx = H.load("cost_topk300.npz")
+    poses, sdf, lim, eps, pad, clr, dis = _padded_inputs(fx)
+    args = [_t(a, dev) for a in (poses, sdf, lim)]
+    tail = [_t(a, dev) for a in (eps, pad, clr)]
+    empty = torch.zeros((0, 3), dtype=torch.float32, device=dev)
+    out = ops.sdf_loss_forward(*args, empty, *tail, _t(dis, dev))
+    assert out[0].shape == (0,) and out[1].shape == (0, 3)
+    pts = _t(np.random.RandomState(1).uniform(0, 0.8, size=(1000, 3)).astype(np.float32), dev)
+    out = ops.sdf_loss_forward(*args, pts, *tail, torch.ones_like(_t(dis, dev)))
+    assert float(out[0].abs().sum()) == 0 and float(out[2].sum()) == 0 and float(out[1].abs().sum()) == 0
+
+
+def test_sdf_loss_forward_rejects_bad_inputs(dev):
+    from omg_planner_amd import _lib, ops
+    fx = H.load("cost_topk300.npz")
+    poses, sdf, lim, eps, pad, clr, dis = _padded_inputs(fx)
+    good = [_t(a, dev) for a in (poses, sdf, lim, np.zeros((4, 3), np.float32), eps, pad, clr, dis)]
+    with pytest.raises(_lib.OmgHipError):  # CHECK_CUDA
+        ops.sdf_loss_forward(*good[:3], torch.zeros((4, 3)), *good[4:])
+    with pytest.raises(_lib.OmgHipError):  # CHECK_CONTIGUOUS
+        ops.sdf_loss_forward(*good[:3], torch.zeros((3, 4), device=dev).t(), *good[4:])
+    with pytest.raises(_lib.OmgHipError):  # float64 is UB in the reference; an error here
+        ops.sdf_loss_forward(*good[:3], torch.zeros((4, 3), dtype=torch.float64, device=dev), *good[4:])
+    # raw C ABI: null pointers -> OMGX_ERR_INVALID, never a crash/exit
+    rc = _lib.lib().omgx_sdf_loss_forward(None, None, None, None, None, None, None, None, 10, 1, None, None, None, None)
+    assert rc == _lib.OMGX_ERR_INVALID
+
+
+def test_sdf_objects_sum_equals_single_object_runs_full_size(dev):
+    """Size-independent property at the C2 size (64 goals x 30 waypoints x 150 points = 288 000 points,
+    5 objects): the fused multi-object result equals the in-order float32 sum of single-object runs."""
+    from omg_planner_amd import ops, scenes as sc
+    scene = sc.make_tabletop_scene(0)
+    sdf, lim = sc.pack_padded(scene.objects)
+    poses, eps, pad, clr, dis = sc.layer_params(scene, **H.LAYER_CFG)
+    rng = np.random.RandomState(2)
+    pts = _t(rng.uniform([0.0, -0.6, 0.0], [1.0, 0.6, 0.9], size=(288_000, 3)).astype(np.float32), dev)
+    a = [_t(x, dev) for x in (poses, sdf, lim)]
+    b = [_t(x, dev) for x in (eps, pad, clr)]
+    full = ops.sdf_loss_forward(*a, pts, *b, _t(dis, dev))
+    acc = [torch.zeros_like(t) for t in full]
+    for o in range(len(scene.objects)):
+        only = np.ones_like(dis)
+        only[o] = 0
+        one = ops.sdf_loss_forward(*a, pts, *b, _t(only, dev))
+        acc = [x + y for x, y in zip(acc, one)]
+    for f, s in zip(full, acc):
+        assert torch.equal(f, s)
+    again = ops.sdf_loss_forward(*a, pts, *b, _t(dis, dev))
+    assert all(torch.equal(x, y) for x, y in zip(full, again))  # deterministic (no atomics)
+    assert float((full[0] > 0).float().mean()) > 0.2
+
+
+# ------------------------------------------------------------------------------------------------
+# (2) omgx_fk_sdf
+# ------------------------------------------------------------------------------------------------
+def _multi_scene_batch(num_scenes, grid=32):
+    from omg_planner_amd import scenes as sc
+    scenes = [sc.make_tabletop_scene(s, grid=grid, table_grid=(48, 32, 16)) for s in range(num_scenes)]
+    if num_scenes > 2:
+        scenes[1].objects[2].name = "floor"       # a disabled object
+        scenes[2].objects[0].attached = True      # table override (cost.py:325-328)
+    return scenes, sc.pack_table(scenes, H.LAYER_CFG)
+
+
+@pytest.mark.parametrize("S,Cn,soft", [(1, 30, False), (5, 70, True), (9, 1, False)])
+def test_fk_sdf_matches_oracle(dev, S, Cn, soft):
+    from omg_planner_amd import ops, robot as rb
+    from oracle import oracle as orc
+    m = rb.PandaModel(seed=3)
+    _, batch = _multi_scene_batch(S)
+    rng = np.random.RandomState(S * 100 + Cn)
+    lo, hi = m.joint_lower_limit[0], m.joint_upper_limit[0]
+    joints = rng.uniform(lo, hi, size=(S, Cn, 9))
+    ref = orc.fk_sdf(m.blob(), m.points_per_link, batch, joints, soften_fingers=soft)
+    ds = ops.DeviceScenes(batch, dev)
+    got = ops.fk_sdf(ops.robot_blob(m, dev), m.points_per_link, ds, _t(joints, dev), soften_fingers=soft)
+    torch.cuda.synchronize()
+    for name, r, g in zip(("potentials", "grads", "collides"), ref, got):
+        g = g.cpu().numpy()
+        # identical float32 op; inputs differ only where the float64 FK's last ulp flips a float32 point
+        assert (g == r).mean() > 0.999, name
+        np.testing.assert_allclose(g, r, rtol=0, atol=5e-6 if name != "grads" else 5e-4, err_msg=name)
+    assert ref[0].max() > 0
+
+
+@pytest.mark.parametrize("case", ["cost_topk1000.npz", "cost_topk300.npz", "cost_finger_n50.npz", "cost_soft_finger.npz"])
+def test_fk_sdf_matches_reference_fixture(dev, case):
+    from omg_planner_amd import ops
+    fx = H.load(case)
+    m = H.model_from(fx)
+    ds = ops.DeviceScenes(H.batch_from(fx), dev)
+    pot, grad, col = ops.fk_sdf(ops.robot_blob(m, dev), m.points_per_link, ds, _t(fx["xi"][None], dev),
+                                soften_fingers=int(fx["cfg_uncheck"]) == -1)
+    np.testing.assert_allclose(pot[0].cpu().numpy(), fx["potentials"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(grad[0].cpu().numpy(), fx["potential_grads"], rtol=0, atol=2e-4)
+    assert float(col.sum()) == float(fx["collide_sum"])
+
+
+# ------------------------------------------------------------------------------------------------
+# (3) omgx_goalset_cost
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", ["arc_g6_n30", "arc_g5_n7", "arc_attached_g4_n12"])
+def test_goalset_cost_matches_reference_fixture(dev, case):
+    from omg_planner_amd import ops
+    fx = H.load(f"batch_{case}.npz")
+    m = H.model_from(fx)
+    n, G = int(fx["n_remaining"]), fx["goals"].shape[0]
+    ds = ops.DeviceScenes(H.batch_from(fx), dev)
+    cost, col, pots = ops.goalset_cost(ops.robot_blob(m, dev), m.points_per_link, ds, _t(fx["traj_start"][None], dev),
+                                       _t(fx["goals"][None], dev), n, float(fx["cfg_dt"]), want_potentials=True)
+    ref = fx["potentials"].reshape(G, n, 10, -1)
+    np.testing.assert_allclose(pots[0].cpu().numpy(), ref, rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(cost[0].cpu().numpy(), fx["goal_cost"], rtol=1e-5, atol=1e-6)  # north_star: 1e-4
+    assert float(col.sum()) == float(fx["collides"].sum())
+
+
+@pytest.mark.parametrize("S,G,n", [(3, 7, 30), (10, 4, 1), (2, 33, 13)])
+def test_goalset_cost_matches_oracle(dev, S, G, n):
+    from omg_planner_amd import ops, robot as rb, scenes as sc
+    from oracle import oracle as orc
+    m = rb.PandaModel(seed=4)
+    _, batch = _multi_scene_batch(S)
+    starts = np.stack([sc.cubic_init(rb.HOME_CONFIG, sc.make_goal_set(s, 1)[0], 30)[30 - n] for s in range(S)])
+    goals = np.stack([sc.make_goal_set(s, G) for s in range(S)])
+    ref_cost, ref_col, ref_pots = orc.goalset_cost(m.blob(), m.points_per_link, batch, starts, goals, n, 0.1, want_potentials=True)
+    ds = ops.DeviceScenes(batch, dev)
+    cost, col, pots = ops.goalset_cost(ops.robot_blob(m, dev), m.points_per_link, ds, _t(starts, dev), _t(goals, dev), n, 0.1,
+                                       want_potentials=True)
+    g = pots.cpu().numpy()
+    assert (g == ref_pots).mean() > 0.999
+    np.testing.assert_allclose(g, ref_pots, rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(cost.cpu().numpy(), ref_cost, rtol=1e-5, atol=1e-6)
+    np.testing.assert_array_equal(col.cpu().numpy(), ref_col)
+
+
+# ------------------------------------------------------------------------------------------------
+# (4) omgx_chomp_optimize
+# ------------------------------------------------------------------------------------------------
+COST_CASES = ["topk1000", "topk300", "clean", "fixed_end", "soft_finger", "finger_n50", "attached", "short_n5"]
+OPT_CASES = ["standoff_20", "nostandoff_20", "fixed_end_5", "limits_5", "n50_dt006_5"]
+
+
+@pytest.mark.parametrize("case", COST_CASES)
+def test_total_loss_matches_reference_fixture(dev, case):
+    """Cost.compute_total_loss: cost, gradient and info of the reference (info_only step)."""
+    from omg_planner_amd import _lib, ops
+    fx = H.load(f"cost_{case}.npz")
+    m = H.model_from(fx)
+    n, P = fx["xi"].shape[0], m.points_per_link
+    robot = ops.robot_blob(m, dev)
+    ds = ops.DeviceScenes(H.batch_from(fx), dev)
+    traj = _t(fx["xi"][None], dev)
+    _, _, col = ops.fk_sdf(robot, P, ds, traj, soften_fingers=int(fx["cfg_uncheck"]) == -1)
+    prm = H.params_from(fx, _lib.ChompParams, n, P, 0, float(fx["cfg_obstacle_weight"]), float(fx["cfg_smoothness_weight"]))
+    goal = _t(np.tile(fx["end"], (1, prm.constraint_num, 1)), dev)
+    # the reference's own layer outputs as inputs (isolates the float64 stage)
+    grad, cost_traj, info = ops.chomp_optimize(robot, prm, traj, _t(fx["start"][None], dev), _t(fx["end"][None], dev), goal,
+                                               _t(fx["goal_point"][None], dev), _t(fx["potentials"][None], dev),
+                                               _t(fx["potential_grads"][None], dev), col)
+    np.testing.assert_array_equal(traj[0].cpu().numpy(), fx["xi"])  # info_only leaves the trajectory alone
+    np.testing.assert_allclose(grad[0].cpu().numpy(), fx["total_grad"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(cost_traj[0].cpu().numpy(), fx["info_cost_traj"], rtol=1e-9, atol=1e-9)
+    info = info[0].cpu().numpy()
+    for key in ["cost", "obs", "smooth", "weighted_obs", "weighted_smooth", "weighted_obs_grad", "weighted_smooth_grad",
+                "grad", "collide", "reach", "standoff_idx", "terminate", "failure_terminate", "execute"]:
+        np.testing.assert_allclose(info[H.INFO_IDX[key]], fx["info_" + key], rtol=1e-9, atol=1e-9, err_msg=key)
+
+
+@pytest.mark.parametrize("case", OPT_CASES)
+def test_optimizer_sequence_matches_reference_fixture(dev, case):
+    """Optimizer.optimize for k consecutive steps: teacher-forced 1e-9, free-running 1e-6 (bar: 1e-4)."""
+    from omg_planner_amd import _lib, ops
+    fx = H.load(f"opt_{case}.npz")
+    m = H.model_from(fx)
+    hist = fx["traj_history"]
+    steps, n, P = hist.shape[0] - 1, hist.shape[1], m.points_per_link
+    robot = ops.robot_blob(m, dev)
+    ds = ops.DeviceScenes(H.batch_from(fx), dev)
+    gi = int(fx["goal_idx"])
+    goal = _t((fx["reach_grasps"][gi] if int(fx["cfg_use_standoff"]) else fx["goal_set"][gi][None])[None], dev)
+    goal_point = _t(fx["goal_set"][gi][None], dev)
+    start, end = _t(fx["start"][None], dev), _t(fx["end"][None], dev)
+    free = _t(hist[0][None], dev)
+    for k in range(steps + 1):
+        w_obs, w_sm, eta = fx["schedule"][k]
+        upd = 1 if k < steps else 0
+        prm = H.params_from(fx, _lib.ChompParams, n, P, upd, w_obs, w_sm, eta, int(fx["cfg_reach_tail_length"]))
+        for mode in ("forced", "free"):
+            traj = _t(hist[k][None], dev) if mode == "forced" else free
+            pot, pg, col = ops.fk_sdf(robot, P, ds, traj)
+            grad, _, info = ops.chomp_optimize(robot, prm, traj, start, end, goal, goal_point, pot, pg, col)
+            if mode == "forced":
+                np.testing.assert_allclose(grad[0].cpu().numpy(), fx["info_gradient"][k], rtol=1e-7, atol=1e-7, err_msg=f"step {k}")
+                inf = info[0].cpu().numpy()
+                for key in ["cost", "obs", "smooth", "collide", "reach", "terminate", "violate_limit", "execute", "failure_terminate"]:
+                    np.testing.assert_allclose(inf[H.INFO_IDX[key]], fx["info_" + key][k], rtol=1e-7, atol=1e-7, err_msg=f"{key} step {k}")
+            if upd:
+                np.testing.assert_allclose(traj[0].cpu().numpy(), hist[k + 1], rtol=0, atol=1e-9 if mode == "forced" else 1e-6,
+                                           err_msg=f"{mode} step {k}")
+
+
+def test_chomp_optimize_batched_matches_oracle(dev):
+    """S scenes at once (mixed scenes, inactive mask) against the oracle, 3 consecutive steps."""
+    from omg_planner_amd import _lib, ops, robot as rb, scenes as sc
+    from oracle import oracle as orc
+    S, n = 12, 30
+    m = rb.PandaModel(seed=5)
+    P = m.points_per_link
+    _, batch = _multi_scene_batch(S)
+    goals = np.stack([sc.make_goal_set(s, 1)[0] for s in range(S)])
+    traj0 = np.stack([sc.cubic_init(rb.HOME_CONFIG, goals[s], n) for s in range(S)])
+    start = np.tile(rb.HOME_CONFIG, (S, 1))
+    active = np.ones(S, np.int32)
+    active[3] = 0
+    fx = dict(cfg_top_k=1000, cfg_goal_set_proj=1, cfg_use_standoff=0, cfg_dt=0.1)
+    robot, ds = ops.robot_blob(m, dev), ops.DeviceScenes(batch, dev)
+    t_dev = _t(traj0, dev)
+    t_ref = traj0.copy()
+    for step in range(1, 4):
+        w_sm = 0.1 * 1.02 ** step
+        po = H.params_from(fx, orc.ChompParams, n, P, 1, 1.0, w_sm)
+        pd = H.params_from(fx, _lib.ChompParams, n, P, 1, 1.0, w_sm)
+        rp, rg, rc = orc.fk_sdf(m.blob(), P, batch, t_ref)
+        t_ref, g_ref, ct_ref, info_ref = orc.chomp_optimize(m.blob(), po, t_ref, start, goals, goals[:, None], goals, rp, rg, rc, active)
+        pot, pg, col = ops.fk_sdf(robot, P, ds, t_dev)
+        g, ct, info = ops.chomp_optimize(robot, pd, t_dev, _t(start, dev), _t(goals, dev), _t(goals[:, None], dev), _t(goals, dev),
+                                         pot, pg, col, active=_t(active, dev))
+        act = active.astype(bool)
+        np.testing.assert_allclose(t_dev.cpu().numpy(), t_ref, rtol=0, atol=1e-7)
+        np.testing.assert_allclose(g.cpu().numpy()[act], g_ref[act], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(info.cpu().numpy()[act], info_ref[act], rtol=1e-6, atol=1e-6)
+    np.testing.assert_array_equal(t_dev[3].cpu().numpy(), traj0[3])  # inactive trajectory untouched
