@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""bench.py — CHOMP iterations/sec over batched scenes on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2], "100 generated table-top scenes batched, 30 waypoints, 1 MI355X with
+A^-1 covariant update on-device", with configs[1]'s 64-goal goal-set batch evaluated every iteration as
+the planner does, omg/planner.py:612-621): per GPU 100 synthetic table-top scenes (4 YCB-like 64^3 SDFs
++ a 128x96x32 table slab each, private copies per scene), Panda 9-dof, 30 waypoints, 15 collision
+points per link, 64 goal candidates per scene.
+
+One "step" = one planner-loop iteration for every scene of the rank:
+    Learner.cost_vector  -> omgx_goalset_cost  (S x 64 goals x 30 interpolated waypoints; window pinned
+                                               at the full 30 waypoints = the most expensive iteration)
+    goal selection (follow-the-leader, on device)
+    Optimizer.optimize   -> omgx_fk_sdf + omgx_chomp_optimize (loss, gradient, projected A^-1 step, limits)
+value = (scenes on all ranks) x K / (max over ranks of the timed region) in scene-iterations per second.
+Scenes are independent, so N GPUs hold N x 100 scenes (weak scaling); one all-gather of the final
+per-scene costs is inside the timed region.
+
+Prints ONE JSON line (rank 0) with the driver's contract keys + "roofline" and "cpu_baseline".
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
+
+
+def build_workload(num_scenes, num_goals, n, grid, seed0, share_grids):
+    from omg_planner_amd import robot as rb, scenes as sc
+    from omg_planner_amd.config import Config
+    cfg = Config(timesteps=n, use_standoff=False)  # omg.core -exp sets use_standoff=False (core.py:873)
+    model = rb.PandaModel(seed=0)
+    scenes = [sc.make_tabletop_scene(seed0 + s, grid=grid) for s in range(num_scenes)]
+    if not share_grids:  # every scene owns private SDF volumes, like the reference's per-scene sdf_torch
+        for scn in scenes:
+            for ob in scn.objects:
+                ob.sdf = sc.SdfGrid(ob.sdf.data.copy(), ob.sdf.origin, ob.sdf.delta)
+    batch = sc.pack_table(scenes, cfg.layer_kwargs(), ragged=True, share_grids=share_grids)
+    start = np.tile(rb.HOME_CONFIG, (num_scenes, 1))
+    goals = np.stack([sc.make_goal_set(seed0 + s, num_goals) for s in range(num_scenes)])
+    return cfg, model, batch, start, goals
+
+
+def cpu_baseline(cfg, model, batch, start, goals, n, budget_s=15.0):
+    """The oracle (CPU port, OpenMP over scenes/goals) timed on a bounded sample of the same step."""
+    from oracle import oracle as orc
+    from omg_planner_amd import scenes as sc
+    from omg_planner_amd._lib import ChompParams  # struct layout only
+    cores = os.cpu_count() or 1
+    orc.set_threads(cores)
+    P = model.points_per_link
+    blob = model.blob()
+
+    def sub_batch(k):
+        e = int(batch.scene_begin[k])
+        return sc.SceneBatch(batch.objects[:e], batch.scene_begin[: k + 1], batch.pool)
+
+    def one_step(k):
+        b = sub_batch(k)
+        traj = np.stack([sc.cubic_init(start[s], goals[s, 0], n) for s in range(k)])
+        t0 = time.perf_counter()
+        cost, _ = orc.goalset_cost(blob, P, b, traj[:, 0], goals[:k], n, cfg.time_interval)
+        gi = cost.argmin(-1)
+        end = goals[np.arange(k), gi]
+        pot, pg, col = orc.fk_sdf(blob, P, b, traj)
+        prm = orc.ChompParams()
+        prm.n_waypoints, prm.n_points, prm.top_k, prm.goal_set_proj, prm.constraint_num = n, P, cfg.top_k_collision, 1, 1
+        prm.joint_limit_max_steps, prm.allow_collision_point, prm.pre_terminate, prm.do_update = 10, 5, 1, 1
+        prm.time_interval, prm.obstacle_weight, prm.smoothness_weight, prm.step_size = cfg.time_interval, 1.0, 0.102, 0.1
+        prm.clip_grad_scale, prm.terminate_smooth_loss = 10.0, 35.0
+        for d in range(9):
+            prm.link_smooth_weight[d] = 1.0
+        orc.chomp_optimize(blob, prm, traj, start[:k], end, end[:, None], end, pot, pg, col)
+        return time.perf_counter() - t0
+
+    k = min(4, len(start))
+    per_scene = one_step(k) / k  # pilot
+    k2 = int(max(k, min(len(start), budget_s / max(per_scene, 1e-6))))
+    total, reps = 0.0, 0
+    while reps < 1 or (total < 10.0 and reps < 6):  # about 10-30 s of CPU work
+        total += one_step(k2)
+        reps += 1
+    t = total / reps
+    return {"value": k2 / t, "unit": "iterations/s", "cores": cores, "kind": "port",
+            "sample": f"{k2} scenes x 1 planner iteration (64-goal goal-set cost + optimize step), mean of {reps} run(s), "
+                      f"oracle/omg_oracle.c with OpenMP on {cores} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scenes", type=int, default=100, help="scenes per GPU")
+    ap.add_argument("--goals", type=int, default=64)
+    ap.add_argument("--waypoints", type=int, default=30)
+    ap.add_argument("--grid", type=int, default=64)
+    ap.add_argument("--share-grids", action="store_true", help="store identical SDF volumes once (model library)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--plan", action="store_true", help="also time a full 70-iteration plan (ms_per_plan)")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if args.gpus > 1 and world == 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from omg_planner_amd import _lib
+    from omg_planner_amd.engine import ChompEngine
+
+    S, G, n = args.scenes, args.goals, args.waypoints
+    cfg, model, batch, start, goals = build_workload(S, G, n, args.grid, seed0=rank * S, share_grids=args.share_grids)
+    eng = ChompEngine(model, batch, cfg, start, goals, device=dev, ol_alg="FTL")
+    lib = _lib.lib()
+
+    def step():
+        eng.t = 0  # pin the goal-set window at the full n waypoints (first-iteration workload)
+        eng.iterate(0)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    lib.omgx_timing_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    costs = eng.final_costs()
+    if world > 1:
+        import torch.distributed as dist
+        allc = torch.empty(world * S, dtype=costs.dtype, device=dev)
+        dist.all_gather_into_tensor(allc, costs)  # the job's one collective (RCCL over xGMI)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    buf = (C.c_float * 4096)()
+    nrec = lib.omgx_timing_collect(buf, 4096)
+    lib.omgx_timing_enable(0)
+    if world > 1:
+        import torch.distributed as dist
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    ms_per_plan = None
+    if args.plan and rank == 0:
+        eng2 = ChompEngine(model, batch, cfg, start, goals, device=dev, ol_alg="FTL")
+        torch.cuda.synchronize()
+        tp = time.perf_counter()
+        eng2.plan(early_stop=False)
+        torch.cuda.synchronize()
+        ms_per_plan = (time.perf_counter() - tp) * 1e3
+
+    if rank == 0:
+        durs = np.array([buf[i] for i in range(nrec)], dtype=np.float64)
+        # launches alternate: goal-set batch (dominant), waypoint batch
+        goal_ms = durs[0::2] if nrec >= 2 else durs
+        wp_ms = durs[1::2]
+        O_active = 5
+        pts_per_launch = S * G * n * 10 * model.points_per_link
+        alg_bytes = pts_per_launch * (32 + 128 * O_active)  # N (32 + 128 O_active)
+        avg_ms = float(goal_ms.mean()) if len(goal_ms) else float("nan")
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        tfile = ROOT / "profiles" / "traffic.json"
+        if tfile.exists():
+            traffic = json.loads(tfile.read_text()).get("k_sdf_chunks_goalset_bytes_per_launch")
+        out = {
+            "metric": "CHOMP iterations/sec (batched scenes)",
+            "value": world * S * args.steps / elapsed,
+            "unit": "iterations/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32 SDF / f64 kinematics+update",
+            "data": "synthetic",
+            "config": {"workload": "100 table-top scenes/GPU x (64-goal goal-set cost + CHOMP step), Panda 9-dof, 30 waypoints",
+                       "scenes_per_gpu": S, "goals": G, "waypoints": n, "objects_per_scene": O_active,
+                       "sdf_grid": f"4x{args.grid}^3 + 128x96x32 per scene, {'shared' if args.share_grids else 'private'}",
+                       "goal_selection": "FTL on device", "top_k_collision": cfg.top_k_collision},
+            "roofline": {"bound": "hbm", "kernel": "k_sdf_chunks<false> (goal-set batch)", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "avg_launch_ms": avg_ms, "launches": int(len(goal_ms)), "algorithmic_bytes_per_launch": alg_bytes,
+                         "waypoint_launch_avg_ms": float(wp_ms.mean()) if len(wp_ms) else None},
+        }
+        if ms_per_plan is not None:
+            out["ms_per_plan"] = ms_per_plan
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, model, batch, start, goals, n)
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

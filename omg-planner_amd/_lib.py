@@ -17,7 +17,8 @@ NUM_DOF, INFO_STRIDE = 9, 16
 
 # every symbol include/omg_hip.h declares
 EXPORTS = ["omgx_sdf_loss_forward", "omgx_fk_sdf_workspace_bytes", "omgx_fk_sdf", "omgx_goalset_workspace_bytes",
-           "omgx_goalset_cost", "omgx_chomp_optimize", "omgx_last_error", "omgx_abi_version", "omgx_device_arch"]
+           "omgx_goalset_cost", "omgx_chomp_optimize", "omgx_last_error", "omgx_abi_version", "omgx_device_arch",
+           "omgx_timing_enable", "omgx_timing_collect"]
 
 
 class OmgHipError(RuntimeError):
@@ -62,8 +63,10 @@ def lib() -> C.CDLL:
         l.omgx_chomp_optimize.argtypes = [vp, C.POINTER(ChompParams)] + [vp] * 9 + [i32] + [vp] * 3 + [vp]
         l.omgx_last_error.restype = C.c_char_p
         l.omgx_device_arch.argtypes = [C.c_char_p, i32]
+        l.omgx_timing_enable.argtypes = [i32]
+        l.omgx_timing_collect.argtypes = [C.POINTER(C.c_float), i32]
         for name in ("omgx_sdf_loss_forward", "omgx_fk_sdf", "omgx_goalset_cost", "omgx_chomp_optimize",
-                     "omgx_abi_version", "omgx_device_arch"):
+                     "omgx_abi_version", "omgx_device_arch", "omgx_timing_enable", "omgx_timing_collect"):
             getattr(l, name).restype = C.c_int
         _lib = l
     return _lib

@@ -198,6 +198,43 @@ int omgx_set_error(const char* what, hipError_t e) {
     return OMGX_ERR_LAUNCH;
 }
 extern "C" const char* omgx_last_error(void) { return g_err; }
+
+// ---- optional per-launch timing of the dominant kernel (k_sdf_chunks) with HIP events ----------
+// bench.py enables it around its timed region; events are recorded on the launch stream.
+#define OMGX_TIMING_CAP 4096
+static bool g_timing = false;
+static int g_timing_n = 0;
+static hipEvent_t g_ev[OMGX_TIMING_CAP][2];
+static bool g_ev_made[OMGX_TIMING_CAP];
+
+extern "C" int omgx_timing_enable(int32_t on) {
+    g_timing = on != 0;
+    g_timing_n = 0;
+    return OMGX_OK;
+}
+
+// Waits for the recorded launches and writes their durations in milliseconds; returns the count.
+extern "C" int omgx_timing_collect(float* h_ms, int32_t cap) {
+    int n = g_timing_n < cap ? g_timing_n : cap;
+    for (int i = 0; i < n; ++i) {
+        hipError_t e = hipEventSynchronize(g_ev[i][1]);
+        if (e != hipSuccess) return omgx_set_error("hipEventSynchronize", e);
+        e = hipEventElapsedTime(&h_ms[i], g_ev[i][0], g_ev[i][1]);
+        if (e != hipSuccess) return omgx_set_error("hipEventElapsedTime", e);
+    }
+    g_timing_n = 0;
+    return n;
+}
+
+static inline int timing_slot() {
+    if (!g_timing || g_timing_n >= OMGX_TIMING_CAP) return -1;
+    const int i = g_timing_n;
+    if (!g_ev_made[i]) {
+        if (hipEventCreate(&g_ev[i][0]) != hipSuccess || hipEventCreate(&g_ev[i][1]) != hipSuccess) return -1;
+        g_ev_made[i] = true;
+    }
+    return i;
+}
 extern "C" int omgx_abi_version(void) { return 1; }
 extern "C" int omgx_device_arch(char* h_buf, int32_t h_len) {
     if (!h_buf || h_len <= 0) return OMGX_ERR_INVALID;
@@ -252,10 +289,13 @@ static int launch_chunks(const ChunkArgs& ca, hipStream_t st) {
     const int scene_groups = (ca.S + 7) / 8;
     const int64_t grid = (int64_t)scene_groups * ca.NCH * 8;
     if (grid > 0x7fffffff) return OMGX_ERR_UNSUPPORTED;
+    const int slot = timing_slot();
+    if (slot >= 0) (void)hipEventRecord(g_ev[slot][0], st);
     if (ca.grad)
         hipLaunchKernelGGL(k_sdf_chunks<true>, dim3((unsigned)grid), dim3(256), 0, st, ca);
     else
         hipLaunchKernelGGL(k_sdf_chunks<false>, dim3((unsigned)grid), dim3(256), 0, st, ca);
+    if (slot >= 0) { (void)hipEventRecord(g_ev[slot][1], st); ++g_timing_n; }
     OMGX_CHECK_LAUNCH("k_sdf_chunks");
     return OMGX_OK;
 }

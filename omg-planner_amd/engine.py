@@ -1,0 +1,231 @@
+"""ChompEngine — device-resident batched CHOMP planning over S independent scenes.
+
+What the reference does per scene on the host (``Planner.plan``, omg/planner.py:600-653)::
+
+    for t in range(optim_steps + extra_smooth_steps):
+        if goal_set_proj and t < optim_steps: learner.update_goal()      # cost_vector -> batch_obstacle_cost
+        info = optim.optimize(traj, force_update=True)                   # compute_total_loss + update
+
+is run here for all scenes of this rank at once, with every tensor resident in HBM and no host round
+trip inside an iteration: per iteration three C-ABI calls on one stream
+
+    omgx_goalset_cost   (S x G goal candidates, arc-length weighted obstacle cost)   [t < optim_steps]
+    omgx_fk_sdf         (S x n waypoint configurations -> potentials / gradients)
+    omgx_chomp_optimize (S trajectories: loss, gradient, projected A^-1 step, joint limits)
+
+plus O(S*G) goal-selection arithmetic (torch elementwise ops; Learner.update_goal,
+omg/online_learner.py:162-249 — the follow-the-leader family runs on device, mirror descent is the
+"next" row of SURVEY.md §8f and is not part of this round).
+
+Multi-GPU: scenes are independent (omg/core.py:869-885 loops them), so rank r of R owns a contiguous block
+of the scene list; nothing is exchanged during planning and one all-gather of the final per-scene costs
+closes the job (``gather_costs``).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from .config import Config
+from .robot import PandaModel
+from .scenes import SceneBatch
+
+
+def shard_range(num_items: int, rank: int, world: int) -> range:
+    """Contiguous block partition of independent units over ranks (sizes differ by at most one)."""
+    base, rem = divmod(num_items, world)
+    lo = rank * base + min(rank, rem)
+    return range(lo, lo + base + (1 if rank < rem else 0))
+
+
+class ChompEngine:
+    def __init__(self, model: PandaModel, batch: SceneBatch, cfg: Config, start: np.ndarray, goal_set: np.ndarray,
+                 reach_grasps: np.ndarray | None = None, traj_init: np.ndarray | None = None, device="cuda:0",
+                 ol_alg: str = "FTL"):
+        """start [S,9]; goal_set [S,G,9]; reach_grasps [S,G,c,9] (needed when cfg.use_standoff)."""
+        self.cfg = cfg
+        self.model = model
+        self.device = torch.device(device)
+        self.S, self.G = goal_set.shape[0], goal_set.shape[1]
+        self.n = cfg.timesteps
+        self.P = model.points_per_link
+        self.ol_alg = ol_alg
+        if ol_alg not in ("FTL", "FTC", "Exp", "Proj", "Baseline"):
+            raise ValueError(f"ol_alg {ol_alg!r} is not available on device (MD is SURVEY.md §8f-1, a later round)")
+        assert batch.num_scenes == self.S
+        dev = self.device
+        f64 = dict(dtype=torch.float64, device=dev)
+        self.robot = ops.robot_blob(model, dev)
+        self.scenes = ops.DeviceScenes(batch, dev)
+        self.start = torch.as_tensor(start, **f64).contiguous()
+        self.goal_set = torch.as_tensor(goal_set, **f64).contiguous()
+        self.use_standoff = bool(cfg.use_standoff)
+        self.c = cfg.reach_tail_length if self.use_standoff else 1
+        if self.use_standoff:
+            if reach_grasps is None:
+                raise ValueError("cfg.use_standoff needs reach_grasps [S,G,c,9]")
+            self.reach = torch.as_tensor(reach_grasps, **f64).contiguous()
+            self.cv_goals = self.reach[:, :, -1, :].contiguous()  # online_learner.py:121-125
+        else:
+            self.reach = None
+            self.cv_goals = self.goal_set
+        self.goal_idx = torch.zeros(self.S, dtype=torch.int64, device=dev)
+        S, n, P, G = self.S, self.n, self.P, self.G
+        if traj_init is None:
+            from .scenes import cubic_init
+            traj_init = np.stack([cubic_init(start[s], goal_set[s, 0], n) for s in range(S)])
+        self.traj = torch.as_tensor(traj_init, **f64).contiguous().clone()
+        self.end = self.goal_set[:, 0].contiguous().clone()
+        self.goal_rows = torch.empty((S, self.c, 9), **f64)
+        self.goal_point = torch.empty((S, 9), **f64)
+        # preallocated outputs: nothing is allocated inside an iteration
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.pot = torch.empty((S, n, 10, P), **f32)
+        self.pgrad = torch.empty((S, n, 10, P, 3), **f32)
+        self.col = torch.empty((S, n, 10, P), **f32)
+        self.grad = torch.empty((S, n, 9), **f64)
+        self.cost_traj = torch.empty((S, n), **f64)
+        self.info = torch.zeros((S, _lib.INFO_STRIDE), **f64)
+        self.goal_cost = torch.empty((S, G), **f32)
+        self.goal_col = torch.empty((S, G), **f32)
+        self.sum_costs = torch.zeros((S, G), **f64)
+        self.p = torch.full((S, G), 1.0 / G, **f64)
+        self.eta = float(np.sqrt(np.log(G + 1) / cfg.optim_steps))  # online_learner.py:80
+        self.active = torch.ones(S, dtype=torch.int32, device=dev)
+        self.step_count = 0  # Optimizer.step
+        self.t = 0           # Learner.t
+        self._gather_goal()
+
+    # ---------------------------------------------------------------------------------------------
+    def _params(self, do_update: bool) -> _lib.ChompParams:
+        cfg = self.cfg
+        p = _lib.ChompParams()
+        p.n_waypoints, p.n_points = self.n, self.P
+        p.top_k = int(cfg.top_k_collision)
+        p.consider_finger = int(cfg.consider_finger)
+        p.goal_set_proj = int(cfg.goal_set_proj)
+        p.constraint_num = self.c
+        p.use_standoff = int(self.use_standoff)
+        p.uncheck_finger_collision = int(cfg.uncheck_finger_collision)
+        p.joint_limit_max_steps = int(cfg.joint_limit_max_steps)
+        p.allow_collision_point = int(cfg.allow_collision_point)
+        p.pre_terminate = int(cfg.pre_terminate)
+        p.do_update = int(do_update)
+        p.time_interval = float(cfg.time_interval)
+        p.obstacle_weight = float(cfg.obstacle_weight)
+        p.smoothness_weight = float(cfg.smoothness_weight)
+        p.step_size = float(cfg.step_size)
+        p.clip_grad_scale = float(cfg.clip_grad_scale)
+        p.terminate_smooth_loss = float(cfg.terminate_smooth_loss)
+        for d in range(9):
+            p.link_smooth_weight[d] = float(cfg.link_smooth_weight[d])
+        return p
+
+    def _schedule(self):
+        """Optimizer.update (omg/optimizer.py:59-80)."""
+        cfg = self.cfg
+        self.step_count += 1
+        k = self.step_count
+        cfg.obstacle_weight = cfg.base_obstacle_weight * cfg.cost_schedule_decay ** k
+        cfg.smoothness_weight = cfg.smoothness_base_weight * cfg.cost_schedule_boost ** k
+        cfg.grasp_weight = cfg.base_grasp_weight * cfg.cost_schedule_decay ** k
+        cfg.step_size = cfg.step_decay_rate ** k * cfg.base_step_size
+
+    def _gather_goal(self):
+        """traj.end / chosen goal rows for the current goal_idx (online_learner.py:243-245, optimizer.py:93-99)."""
+        idx = self.goal_idx
+        ar = torch.arange(self.S, device=self.device)
+        torch.index_select(self.goal_set.view(self.S * self.G, 9), 0, ar * self.G + idx, out=self.goal_point)
+        self.end.copy_(self.goal_point)
+        if self.use_standoff:
+            self.goal_rows.copy_(self.reach[ar, idx])
+        else:
+            self.goal_rows.copy_(self.goal_point[:, None, :])
+
+    # ---------------------------------------------------------------------------------------------
+    def cost_vector(self) -> torch.Tensor:
+        """Learner.cost_vector (omg/online_learner.py:104-160) for every scene: [S,G] float64 on device."""
+        cfg = self.cfg
+        start_idx = min(int((self.t / cfg.optim_steps) * cfg.timesteps), cfg.timesteps - 1)
+        n_rem = cfg.timesteps - start_idx
+        traj_start = self.traj[:, start_idx].contiguous()
+        ops.goalset_cost(self.robot, self.P, self.scenes, traj_start, self.cv_goals, n_rem, cfg.time_interval,
+                         soften_fingers=False, out=(self.goal_cost, self.goal_col))
+        d = traj_start[:, None, :] - self.goal_set  # np.diff(..., axis=-1): adjacent JOINT columns (sic)
+        smooth = (d[..., 1:] - d[..., :-1]).pow(2).sum(-1)
+        pot = cfg.base_obstacle_weight * self.goal_cost.double() + cfg.smoothness_base_weight * cfg.dist_eps * smooth
+        if cfg.normalize_cost:
+            pot = pot / torch.linalg.norm(pot, dim=-1, keepdim=True)
+        return pot
+
+    def update_goal(self):
+        """Learner.update_goal (online_learner.py:237-249) with the device-side policies."""
+        self.t += 1
+        alg = self.ol_alg
+        if alg == "Baseline":
+            return
+        if alg == "Proj":  # online_learner.py:196-206
+            dist = torch.linalg.norm(self.traj[:, -1][:, None, :] - self.goal_set, dim=-1)
+            self.goal_idx = torch.argmin(dist, dim=-1)
+        else:
+            cv = self.cost_vector()
+            if alg == "FTL":  # :175-181
+                self.sum_costs += cv
+                self.goal_idx = torch.argmin(self.sum_costs, dim=-1)
+            elif alg == "FTC":  # :183-189
+                self.goal_idx = torch.argmin(cv, dim=-1)
+            elif alg == "Exp":  # :208-217
+                self.sum_costs += cv
+                norm_sum = self.sum_costs / (self.sum_costs.sum(-1, keepdim=True) + 1e-8)
+                p = torch.exp(-self.eta * cv) * self.p * 0.999 + norm_sum * 0.001
+                self.p = p / (p.sum(-1, keepdim=True) + 1e-8)
+                self.goal_idx = torch.argmax(self.p, dim=-1)
+        self._gather_goal()
+
+    def optimize(self, do_update: bool = True):
+        """Optimizer.optimize(traj, force_update=True) (omg/optimizer.py:115-135) for all scenes."""
+        self._schedule()
+        ops.fk_sdf(self.robot, self.P, self.scenes, self.traj, soften_fingers=self.cfg.uncheck_finger_collision == -1,
+                   out=(self.pot, self.pgrad, self.col))
+        ops.chomp_optimize(self.robot, self._params(do_update), self.traj, self.start, self.end, self.goal_rows,
+                           self.goal_point, self.pot, self.pgrad, self.col, active=self.active,
+                           out=(self.grad, self.cost_traj, self.info))
+        return self.info
+
+    def iterate(self, t: int, early_stop: bool = False):
+        """One pass of the planner loop body (planner.py:612-621) over all scenes."""
+        cfg = self.cfg
+        if cfg.goal_set_proj and t < cfg.optim_steps:
+            self.update_goal()
+        self.optimize(True)
+        if early_stop and t > 0:  # planner.py:627: terminated scenes stop iterating
+            self.active = self.active * (self.info[:, 10] < 0.5).to(torch.int32)
+
+    def plan(self, early_stop: bool = True) -> torch.Tensor:
+        """Planner.plan (planner.py:600-653): up to optim_steps + extra_smooth_steps iterations, then one
+        info-only evaluation; returns the final info [S,16] (device)."""
+        cfg = self.cfg
+        for t in range(cfg.optim_steps + cfg.extra_smooth_steps):
+            self.iterate(t, early_stop)
+        return self.optimize(False)
+
+    def final_costs(self) -> torch.Tensor:
+        return self.info[:, 0].contiguous()
+
+
+def gather_costs(local_costs: torch.Tensor, world: int) -> torch.Tensor:
+    """The one collective of the job: all-gather of per-scene final costs over RCCL (backend "nccl")
+    or gloo.  Ragged shards are padded to the largest shard with NaN."""
+    if world == 1:
+        return local_costs
+    import torch.distributed as dist
+    n = torch.tensor([local_costs.numel()], device=local_costs.device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    mx = int(max(int(s.item()) for s in sizes))
+    pad = torch.full((mx,), float("nan"), dtype=local_costs.dtype, device=local_costs.device)
+    pad[: local_costs.numel()] = local_costs
+    out = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(out, pad)
+    return torch.cat([o[: int(s.item())] for o, s in zip(out, sizes)])
