@@ -52,7 +52,8 @@ def build_workload(num_scenes, num_goals, n, grid, seed0, share_grids):
                 ob.sdf = sc.SdfGrid(ob.sdf.data.copy(), ob.sdf.origin, ob.sdf.delta)
     batch = sc.pack_table(scenes, cfg.layer_kwargs(), ragged=True, share_grids=share_grids)
     start = np.tile(rb.HOME_CONFIG, (num_scenes, 1))
-    goals = np.stack([sc.make_goal_set(seed0 + s, num_goals) for s in range(num_scenes)])
+    # grasp-like goal sets: the hand ends 10-16 cm from the target, approach axis towards it
+    goals = np.stack([sc.make_reach_goals(scenes[s], model, num_goals, seed0 + s) for s in range(num_scenes)])
     return cfg, model, batch, start, goals
 
 

@@ -66,7 +66,7 @@ extern "C" {
 #define OMGX_ROBOT_POINTS 528
 
 /* ---------------------------------------------------------------------------------------------
- * Scene object table.  One 128-byte record per obstacle/target object; replaces the five per-call
+ * Scene object table.  One 160-byte record per obstacle/target object; replaces the five per-call
  * host->device copies of Cost.compute_obstacle_cost_layer (omg/cost.py:303-335) and the
  * pad-to-max `sdf_torch[O,X,Y,Z]` + `sdf_limits[O,10]` contract of Env.combine_sdfs
  * (omg/core.py:366-411).  `grid_offset` lets grids live ragged in one float pool; the reference's
@@ -83,8 +83,10 @@ typedef struct omgx_object {
     float clearance;     /* cfg.clearance / cfg.target_clearance                                     */
     int32_t disabled;    /* 1 = skip (name == "floor" or in cfg.disable_collision_set)               */
     int64_t grid_offset; /* element offset of this object's grid inside the sdf pool                 */
-    int32_t reserved[4];
-} omgx_object; /* sizeof == 128 */
+    double inv_extent[3]; /* derived: 1.0 / (double)((float)hi[a] - (float)lo[a])                     */
+    float far_lo[3];     /* derived: -1.5 voxels   } a point whose offset t = R p + t - lo lies outside  */
+    float far_hi[3];     /* derived: extent + 1.5 voxels } [far_lo, far_hi] is out of range for sure     */
+} omgx_object; /* sizeof == 160; derived fields: scenes.finish_records() is the reference derivation */
 
 /* ---------------------------------------------------------------------------------------------
  * CHOMP parameters for one optimiser step (a frozen snapshot of the reference's global mutable

@@ -33,6 +33,10 @@
 
 using namespace omg;
 
+// This translation unit holds float64 code only (the float32 SDF arithmetic that must stay
+// bit-identical to the oracle lives in omg_kernels.hip); let the compiler fuse multiply-adds here.
+#pragma clang fp contract(fast)
+
 #define CH_TPB 512
 #define CH_WAVES (CH_TPB / 64)
 
@@ -268,14 +272,27 @@ __global__ __launch_bounds__(CH_TPB) void k_chomp_optimize(ChompArgs a) {
                 if ((key & mask) == prefix) atomicAdd(&L.hist[(key >> shift) & 255u], 1u);
             }
             __syncthreads();
-            if (tid == 0) {
-                int acc = 0, b = 255;
-                for (; b > 0; --b) {
-                    if (acc + (int)L.hist[b] >= want) break;
-                    acc += (int)L.hist[b];
+            if (tid < 64) {  // wave 0: locate the bin holding the `want`-th largest key (suffix sums over 256 bins)
+                // lane j owns bins 4j..4j+3; `above` = number of keys in bins above lane j's bins
+                const uint32_t h0 = L.hist[4 * tid], h1 = L.hist[4 * tid + 1], h2 = L.hist[4 * tid + 2], h3 = L.hist[4 * tid + 3];
+                const int mine = (int)(h0 + h1 + h2 + h3);
+                int incl = mine;  // inclusive suffix sum over lanes tid..63
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int v = __shfl_down(incl, off, 64);
+                    if (tid + off < 64) incl += v;
                 }
-                L.iscr[0] = b;
-                L.iscr[1] = want - acc;
+                const int above = incl - mine;
+                if (above < want && want <= incl) {  // exactly one lane
+                    int acc = above, b = 4 * tid + 3;
+                    const uint32_t hh[4] = {h0, h1, h2, h3};
+                    for (; b > 4 * tid; --b) {
+                        if (acc + (int)hh[b - 4 * tid] >= want) break;
+                        acc += (int)hh[b - 4 * tid];
+                    }
+                    L.iscr[0] = b;
+                    L.iscr[1] = want - acc;
+                }
             }
             __syncthreads();
             prefix |= (uint32_t)L.iscr[0] << shift;

@@ -26,15 +26,25 @@ struct __attribute__((packed, aligned(4))) F4 { float a, b, c, d; };  // dword-a
 
 __device__ __forceinline__ float lerpf(float a, float b, float t) { return __builtin_fmaf(t, b - a, a); }  // .cu:15-18
 
-// pGrid - 0.5 in double, truncation toward zero, fraction rounded to float (.cu:39-41).
-// `ok` is false for coordinates whose (int) cast would be undefined (the oracle returns 1.0 there).
+// getValueInterpolated's split of one grid coordinate (.cu:39-41): the reference evaluates
+//   s = (double)g - 0.5;  i0 = (int)s (truncation toward zero);  f = (float)(s - i0)
+// The same result is obtained in float arithmetic for every g whose grid is smaller than 2^22 voxels
+// per axis (proof sketch: for g >= 0.25 the float subtraction g - 0.5f is exact; for 0 <= g < 0.25 both
+// give i0 = 0 and f = fl32(g - 0.5); for g <= -0.5 both are out of range; the single discrepancy is
+// g in (-0.5, -0.5 + 2^-25) where fl32(g - 0.5) rounds to -1.0 although the exact s > -1 truncates to 0
+// with f = fl32(s) = -1.0 — patched explicitly).  Checked exhaustively near the critical values in
+// tests/test_axis_split.py.  `ok` is false where the (int) cast would be undefined (|s| >= 1e9, NaN):
+// the oracle returns 1.0 there.
 struct Axis { int i0; float f; bool ok; };
 __device__ __forceinline__ Axis axis_of(float g) {
     Axis a;
     a.ok = (g > -1.0e9f) && (g <= 1.0e9f);  // == (g-0.5 in (-1e9,1e9)) for float g; false for NaN
-    const double s = (double)g - 0.5;
+    const float s = g - 0.5f;
     a.i0 = (int)s;
-    a.f = (float)(s - (double)a.i0);
+    a.f = s - (float)a.i0;
+    const bool edge = (s == -1.0f) && (g > -0.5f);
+    a.i0 = edge ? 0 : a.i0;
+    a.f = edge ? -1.0f : a.f;
     return a;
 }
 
@@ -74,34 +84,92 @@ struct ObjParams {  // wave-uniform (SGPR-resident) per-object parameters
     float lo[3], hi[3];
     int dim[3];
     float delta, eps, pad, clr;
+    double rw[3];   // 1 / (double)(float)(hi - lo): t / w == (float)((double)t * rw) exactly (see pair_exact)
+    float flo[3], fhi[3];  // far box in offset-from-lo coordinates (1.5 voxels of slack)
 };
+
+// far box of an object from its limits (used where the record does not carry it: the raw-tensor API)
+__device__ __forceinline__ void derive_far_box(ObjParams& o) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float w = o.hi[k] - o.lo[k];
+        const bool ok = w > 0.0f && o.dim[k] > 0;
+        const float vox = w / (float)(o.dim[k] > 0 ? o.dim[k] : 1);
+        o.flo[k] = ok ? -1.5f * vox : -__builtin_inff();
+        o.fhi[k] = ok ? w + 1.5f * vox : __builtin_inff();
+    }
+}
 
 struct Accum { float pot, gx, gy, gz, col; };
 
 // One (point, object) pair: body of SDFdistanceForward (.cu:111-180); adds into acc.
-// WANT_GRAD=false skips the world-frame gradient accumulation (potential/collides only need the
-// centre lookup unless the caller wants gradients).
-template <bool WANT_GRAD>
-__device__ __forceinline__ void sdf_pair(const ObjParams& o, const float* __restrict__ grid, float px, float py, float pz,
-                                         Accum& acc) {
+//
+// Work is ordered so that the common cases retire early (the kernel is VALU-bound, profiles/r01a_*):
+//   1. conservative far-reject in object space (1.5 voxels of slack on a half-voxel requirement): the
+//      centre lookup is provably out of range -> value 1.0 -> nothing to add (when eps < 1, clr <= 1);
+//   2. exact grid coordinates (IEEE division, double -0.5 split) and the centre trilinear value;
+//   3. only when a gradient is requested AND value <= eps: the six +-1-voxel lookups.
+// WANT_GRAD=false (goal-set cost: Learner.cost_vector never reads batch_obstacle_cost's gradient,
+// online_learner.py:134-148) therefore needs 4 row loads per in-range pair instead of the reference's 56.
+struct PairPrep { float tx, ty, tz; bool far; };
+
+// Step 1 of a pair: object-space offset from the grid's min corner + the conservative far test.
+__device__ __forceinline__ PairPrep pair_prepare(const ObjParams& o, float px, float py, float pz) {
     const float* T = o.T;
     // SE3(pose) * point (.cu:125-133)
     const float ux = __builtin_fmaf(T[2], pz, __builtin_fmaf(T[1], py, __builtin_fmaf(T[0], px, T[3])));
     const float uy = __builtin_fmaf(T[6], pz, __builtin_fmaf(T[5], py, __builtin_fmaf(T[4], px, T[7])));
     const float uz = __builtin_fmaf(T[10], pz, __builtin_fmaf(T[9], py, __builtin_fmaf(T[8], px, T[11])));
-    // grid coordinates (.cu:137-142)
-    const float gx = (ux - o.lo[0]) / (o.hi[0] - o.lo[0]) * (float)o.dim[0];
-    const float gy = (uy - o.lo[1]) / (o.hi[1] - o.lo[1]) * (float)o.dim[1];
-    const float gz = (uz - o.lo[2]) / (o.hi[2] - o.lo[2]) * (float)o.dim[2];
+    PairPrep r;
+    r.tx = ux - o.lo[0]; r.ty = uy - o.lo[1]; r.tz = uz - o.lo[2];
+    // an out-of-range lookup returns 1.0, which adds nothing when eps < 1 and clr <= 1 (wave-uniform);
+    // NaN offsets fail every comparison and are rejected too (the oracle returns 1.0 for them)
+    const bool inside = (r.tx >= o.flo[0]) & (r.tx <= o.fhi[0]) & (r.ty >= o.flo[1]) & (r.ty <= o.fhi[1]) &
+                        (r.tz >= o.flo[2]) & (r.tz <= o.fhi[2]);
+    r.far = (o.eps < 1.0f && o.clr <= 1.0f) ? !inside : false;
+    return r;
+}
+
+// Steps 2-3 of a pair that was not far-rejected.
+template <bool WANT_GRAD>
+__device__ __forceinline__ void pair_exact(const ObjParams& o, const float* __restrict__ grid, float tx, float ty, float tz,
+                                           Accum& acc) {
+    const float* T = o.T;
+    // grid coordinates (.cu:137-142): (u - lo) / (hi - lo) * dim.  The IEEE float quotient t / w is
+    // obtained as (float)((double)t * rw) with rw = fl64(1 / w): the double product is within 2^-52 of
+    // t / w while a quotient of two 24-bit floats is never closer than 2^-49 (relative) to a float
+    // rounding boundary, so the final rounding is the correct one — 3 instructions instead of the
+    // ~12-instruction v_div_scale/v_rcp/v_fma/v_div_fmas/v_div_fixup sequence.
+    const float gx = (float)((double)tx * o.rw[0]) * (float)o.dim[0];
+    const float gy = (float)((double)ty * o.rw[1]) * (float)o.dim[1];
+    const float gz = (float)((double)tz * o.rw[2]) * (float)o.dim[2];
     Grid G{grid, o.dim[0], o.dim[1], o.dim[2]};
     const Axis ax = axis_of(gx), ay = axis_of(gy), az = axis_of(gz);
-
     const bool in_c = ax.ok && ay.ok && az.ok && ax.i0 >= 0 && ax.i0 < G.dx - 1 && ay.i0 >= 0 && ay.i0 < G.dy - 1 &&
                       az.i0 >= 0 && az.i0 < G.dz - 1;
-    if (!in_c) {  // centre lookup is out of range -> 1.0 (.cu:49-50); almost always ends the pair here
+    if (!in_c) {  // centre lookup is out of range -> 1.0 (.cu:49-50)
         if (1.0f < o.clr) acc.col += 1.0f;
         if (!(1.0f <= o.eps)) return;
     }
+    const int sy = G.dz, sx = G.dy * G.dz;
+    const int b = G.idx(ax.i0, ay.i0, az.i0);
+
+    if (!WANT_GRAD) {  // branch-free: clamped (always valid) addresses + selects
+        const int bb = in_c ? b : 0;
+        const F2 r00 = *reinterpret_cast<const F2*>(G.g + bb);
+        const F2 r01 = *reinterpret_cast<const F2*>(G.g + bb + sy);
+        const F2 r10 = *reinterpret_cast<const F2*>(G.g + bb + sx);
+        const F2 r11 = *reinterpret_cast<const F2*>(G.g + bb + sx + sy);
+        const float tv = trilerp(r00.a, r00.b, r01.a, r01.b, r10.a, r10.b, r11.a, r11.b, ax.f, ay.f, az.f);
+        const float value = in_c ? tv : 1.0f;
+        acc.col += (in_c && value < o.clr) ? 1.0f : 0.0f;                       // .cu:150-151
+        const float p_in = (float)(-(double)value + 0.5 * (double)o.eps);        // .cu:158-160
+        const float d = value - o.eps;
+        const float p_band = 1.0f / (2.0f * o.eps) * d * d * o.pad;             // .cu:165-167
+        acc.pot += value <= 0.0f ? p_in : (value <= o.eps ? p_band : 0.0f);
+        return;
+    }
+
     // Interior fast path: the whole 4x4x4-minus-corners stencil (32 voxels) is in range and the
     // +-1 voxel shifted coordinates split regularly (i0 +- 1).  Then the 7 trilinear lookups share 12
     // row loads (4 x 16 B + 8 x 8 B) instead of 7 x 8 scalar loads.
@@ -115,8 +183,6 @@ __device__ __forceinline__ void sdf_pair(const ObjParams& o, const float* __rest
 
     float value, fpx, fmx, fpy, fmy, fpz, fmz;
     if (interior) {
-        const int sy = G.dz, sx = G.dy * G.dz;
-        const int b = G.idx(ax.i0, ay.i0, az.i0);
         // centre rows, z0-1 .. z0+2
         const F4 c00 = *reinterpret_cast<const F4*>(G.g + b - 1);
         const F4 c01 = *reinterpret_cast<const F4*>(G.g + b + sy - 1);
@@ -157,21 +223,16 @@ __device__ __forceinline__ void sdf_pair(const ObjParams& o, const float* __rest
         fmy = sdf_value(G, ax, aym, az);
         fmz = sdf_value(G, ax, ay, azm);
     }
+    const float g0 = (float)(0.5 * (double)(fpx - fmx) / (double)o.delta);  // .cu:82-84
+    const float g1 = (float)(0.5 * (double)(fpy - fmy) / (double)o.delta);
+    const float g2 = (float)(0.5 * (double)(fpz - fmz) / (double)o.delta);
     float v0, v1, v2;
     if (value <= 0.0f) {  // .cu:158-164
         acc.pot += (float)(-(double)value + 0.5 * (double)o.eps);
-        if (!WANT_GRAD) return;
-        const float g0 = (float)(0.5 * (double)(fpx - fmx) / (double)o.delta);  // .cu:82-84
-        const float g1 = (float)(0.5 * (double)(fpy - fmy) / (double)o.delta);
-        const float g2 = (float)(0.5 * (double)(fpz - fmz) / (double)o.delta);
         v0 = -g0; v1 = -g1; v2 = -g2;
     } else {  // 0 < value <= eps (.cu:165-171)
         const float d = value - o.eps;
         acc.pot += 1.0f / (2.0f * o.eps) * d * d * o.pad;
-        if (!WANT_GRAD) return;
-        const float g0 = (float)(0.5 * (double)(fpx - fmx) / (double)o.delta);
-        const float g1 = (float)(0.5 * (double)(fpy - fmy) / (double)o.delta);
-        const float g2 = (float)(0.5 * (double)(fpz - fmz) / (double)o.delta);
         const float ie = 1.0f / o.eps;
         v0 = ie * g0 * d * o.pad; v1 = ie * g1 * d * o.pad; v2 = ie * g2 * d * o.pad;
     }
@@ -181,13 +242,32 @@ __device__ __forceinline__ void sdf_pair(const ObjParams& o, const float* __rest
     acc.gz += __builtin_fmaf(T[10], v2, __builtin_fmaf(T[6], v1, T[2] * v0));
 }
 
-__device__ __forceinline__ ObjParams load_object(const omgx_object* __restrict__ ob) {
+template <bool WANT_GRAD>
+__device__ __forceinline__ void sdf_pair(const ObjParams& o, const float* __restrict__ grid, float px, float py, float pz,
+                                         Accum& acc) {
+    const PairPrep pp = pair_prepare(o, px, py, pz);
+    if (!pp.far) pair_exact<WANT_GRAD>(o, grid, pp.tx, pp.ty, pp.tz, acc);
+}
+
+// Wave-uniform tables (object records, scene_begin) are read through the CONSTANT address space: the
+// compiler then emits scalar loads (s_load -> SGPRs) even though the kernel also stores to global
+// memory it cannot prove disjoint; plain global pointers fell back to per-lane vector loads into
+// ~26 VGPRs per object.  The tables are never written by a kernel that reads them.
+#define OMG_CONST_AS __attribute__((address_space(4)))
+typedef const OMG_CONST_AS omgx_object* ObjTablePtr;
+typedef const OMG_CONST_AS int32_t* IntTablePtr;
+__device__ __forceinline__ ObjTablePtr as_const(const omgx_object* p) { return (ObjTablePtr)(uintptr_t)p; }
+__device__ __forceinline__ IntTablePtr as_const(const int32_t* p) { return (IntTablePtr)(uintptr_t)p; }
+
+__device__ __forceinline__ ObjParams load_object(ObjTablePtr ob) {
     ObjParams o;
 #pragma unroll
     for (int k = 0; k < 12; ++k) o.T[k] = ob->pose_inv[k];
 #pragma unroll
     for (int k = 0; k < 3; ++k) { o.lo[k] = ob->lo[k]; o.hi[k] = ob->hi[k]; o.dim[k] = ob->dim[k]; }
     o.delta = ob->delta; o.eps = ob->epsilon; o.pad = ob->padding_scale; o.clr = ob->clearance;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { o.rw[k] = ob->inv_extent[k]; o.flo[k] = ob->far_lo[k]; o.fhi[k] = ob->far_hi[k]; }
     return o;
 }
 
@@ -198,7 +278,7 @@ __device__ __forceinline__ Accum sdf_point(const omgx_object* __restrict__ objs,
                                            const float* __restrict__ pool, float px, float py, float pz) {
     Accum acc{0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     for (int o = o_begin; o < o_end; ++o) {  // wave-uniform trip count and addresses -> scalar loads
-        const omgx_object* ob = objs + o;
+        ObjTablePtr ob = as_const(objs) + o;
         if (ob->disabled > 0) continue;  // .cu:115-116
         const ObjParams op = load_object(ob);
         sdf_pair<WANT_GRAD>(op, pool + ob->grid_offset, px, py, pz, acc);
@@ -238,7 +318,10 @@ struct RobotView {
 
 struct Pose { double R[9]; double t[3]; };  // link frame BEFORE center_offset (robot_pykdl output_pose)
 
+// The double-precision kinematics may fuse multiply-adds (the file is compiled with -ffp-contract=off
+// for the float32 SDF arithmetic only; FK parity is checked at 1e-12, not bitwise).
 __device__ __forceinline__ void pose_mul(const Pose& A, const double* __restrict__ B /*rows [3][4]*/, Pose& C) {
+#pragma clang fp contract(fast)
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
 #pragma unroll
@@ -254,6 +337,7 @@ __device__ __forceinline__ double deg_round_trip(double q) { return (q / M_PI * 
 // Visits the 10 link poses of configuration q[9] (radians) in order; f(l, pose).
 template <class F>
 __device__ __forceinline__ void fk_chain(const RobotView& rv, const double* __restrict__ q, F&& f) {
+#pragma clang fp contract(fast)
     Pose cur;
 #pragma unroll
     for (int k = 0; k < 9; ++k) cur.R[k] = (k % 4 == 0) ? 1.0 : 0.0;
@@ -299,9 +383,19 @@ __device__ __forceinline__ void fk_chain(const RobotView& rv, const double* __re
 }
 
 __device__ __forceinline__ void pose_apply(const Pose& A, const double* __restrict__ p, double& x, double& y, double& z) {
+#pragma clang fp contract(fast)
     x = A.R[0] * p[0] + A.R[1] * p[1] + A.R[2] * p[2] + A.t[0];
     y = A.R[3] * p[0] + A.R[4] * p[1] + A.R[5] * p[2] + A.t[1];
     z = A.R[6] * p[0] + A.R[7] * p[1] + A.R[8] * p[2] + A.t[2];
+}
+
+// x = R p + t for a pose stored as 12 doubles (R row-major [9], t [3]); result rounded to float32 like
+// `torch.from_numpy(ws_positions).cuda().float()` (cost.py:136,218).
+__device__ __forceinline__ void pose12_apply(const double* __restrict__ A, const double* __restrict__ p, float& x, float& y, float& z) {
+#pragma clang fp contract(fast)
+    x = (float)(A[0] * p[0] + A[1] * p[1] + A[2] * p[2] + A[9]);
+    y = (float)(A[3] * p[0] + A[4] * p[1] + A[5] * p[2] + A[10]);
+    z = (float)(A[6] * p[0] + A[7] * p[1] + A[8] * p[2] + A[11]);
 }
 
 // -------------------------------------------------------------------------------------------------

@@ -2,20 +2,21 @@
 //
 // Kernels in this file
 //   k_sdf_loss        points x objects SDF potential/gradient/collides, one launch (API 1)
-//   k_fk_points       Panda FK, one lane per robot configuration -> float32 collision points
-//   k_sdf_chunks      the same SDF evaluation over FK-produced points, per (scene, chunk) workgroup,
-//                     optional arc-length weighting + per-chunk reduction (APIs 2 and 3)
+//   k_fk_poses        Panda FK, one lane per robot configuration -> float64 link poses
+//   k_sdf_chunks      the same SDF evaluation over the collision points of those poses, per (scene, chunk)
+//                     workgroup, optional arc-length weighting + per-chunk reduction (APIs 2 and 3)
 //
 // Hot-path data layout in HBM:
 //   objects[]  128-byte omgx_object records, wave-uniform reads -> SGPRs via scalar loads
 //   sdf pool   float32 grids, x-major, z fastest: a trilinear row (z0-1..z0+2) is one 16-byte load
-//   points ws  [scene][chunk][link][config-in-chunk][point][3] float32: consecutive lanes are the P
-//              points of one link at consecutive waypoints -> spatially coherent gathers, coalesced
-//              point reads
+//   pose ws    [scene][chunk][link][config-in-chunk][12] float64 link poses: the 16 lanes of a row (the P
+//              points of one link at one waypoint) share one 96-byte pose; a wave = 4 consecutive
+//              waypoints of one link -> spatially coherent gathers
 #include <hip/hip_runtime.h>
 
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "omg_device.h"
@@ -36,38 +37,64 @@ struct RawObjects {  // the eight tensors of omg_cuda.sdf_loss_forward
     const float* __restrict__ dis;
 };
 
+#define SDF_LOSS_TILE 32  // objects staged in LDS per pass
+
+// The raw tensors carry no derived constants, so each workgroup first turns (a tile of) the objects into
+// ObjParams records in LDS — including the double reciprocals of the grid extents — and then streams its
+// points (grid-stride) against them.
 __global__ __launch_bounds__(256) void k_sdf_loss(RawObjects R, const float* __restrict__ points, int64_t N, int O,
                                                    float* __restrict__ pot, float* __restrict__ grad,
                                                    float* __restrict__ col) {
+    __shared__ ObjParams objs[SDF_LOSS_TILE];
+    __shared__ int64_t goff[SDF_LOSS_TILE];
+    __shared__ int live[SDF_LOSS_TILE];
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += stride) {
-        const float px = points[3 * i], py = points[3 * i + 1], pz = points[3 * i + 2];
-        Accum acc{0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-        for (int o = 0; o < O; ++o) {  // uniform: parameters travel through scalar loads
-            if (R.dis[o] > 0.0f) continue;
+    const int64_t first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int o0 = 0; o0 < O; o0 += SDF_LOSS_TILE) {
+        const int cnt = min(SDF_LOSS_TILE, O - o0);
+        __syncthreads();
+        if (threadIdx.x < cnt) {
+            const int o = o0 + threadIdx.x;
             ObjParams op;
 #pragma unroll
             for (int k = 0; k < 12; ++k) op.T[k] = R.pose_init[16 * o + k];
             const float* L = R.sdf_limits + 10 * o;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) { op.lo[k] = L[k]; op.hi[k] = L[3 + k]; op.dim[k] = (int)L[6 + k]; }
+            for (int k = 0; k < 3; ++k) {
+                op.lo[k] = L[k]; op.hi[k] = L[3 + k]; op.dim[k] = (int)L[6 + k];
+                op.rw[k] = 1.0 / (double)(op.hi[k] - op.lo[k]);
+            }
             op.delta = L[9]; op.eps = R.eps[o]; op.pad = R.pad[o]; op.clr = R.clr[o];
-            const int64_t off = (int64_t)o * op.dim[0] * op.dim[1] * op.dim[2];  // .cu:147
-            sdf_pair<true>(op, R.sdf_grids + off, px, py, pz, acc);
+            derive_far_box(op);
+            objs[threadIdx.x] = op;
+            goff[threadIdx.x] = (int64_t)o * op.dim[0] * op.dim[1] * op.dim[2];  // .cu:147
+            live[threadIdx.x] = !(R.dis[o] > 0.0f);                               // .cu:115-116
         }
-        pot[i] = acc.pot;
-        col[i] = acc.col;
-        grad[3 * i] = acc.gx; grad[3 * i + 1] = acc.gy; grad[3 * i + 2] = acc.gz;
+        __syncthreads();
+        for (int64_t i = first; i < N; i += stride) {
+            const float px = points[3 * i], py = points[3 * i + 1], pz = points[3 * i + 2];
+            Accum acc{0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+            if (o0 > 0) { acc.pot = pot[i]; acc.col = col[i]; acc.gx = grad[3 * i]; acc.gy = grad[3 * i + 1]; acc.gz = grad[3 * i + 2]; }
+            for (int k = 0; k < cnt; ++k)
+                if (live[k]) sdf_pair<true>(objs[k], R.sdf_grids + goff[k], px, py, pz, acc);
+            pot[i] = acc.pot;
+            col[i] = acc.col;
+            grad[3 * i] = acc.gx; grad[3 * i + 1] = acc.gy; grad[3 * i + 2] = acc.gz;
+        }
     }
+    if (O == 0)
+        for (int64_t i = first; i < N; i += stride) { pot[i] = 0.0f; col[i] = 0.0f; grad[3 * i] = grad[3 * i + 1] = grad[3 * i + 2] = 0.0f; }
 }
 
 // =================================================================================================
-// (2) k_fk_points — one lane per configuration
+// (2) k_fk_poses — one lane per configuration -> link poses (double [12]: R row-major, t)
 // =================================================================================================
 // Config sources:
 //   mode 0: joints[S][C][9] given                                   (omgx_fk_sdf, chomp waypoints)
 //   mode 1: joints interpolated start + (i+1)/(n+1) (goal - start)  (omgx_goalset_cost; util.py:261-290 "linear")
-//           plus one extra "config n" per (scene) = traj_start itself, written to ws_start
+//           plus one extra configuration per scene = traj_start itself, written to ws_start
+// Output layout ws[S][NCH][10][CH][12]: for a fixed link the 64 configurations of a wave are contiguous
+// (6 KiB), so each link's poses are staged in LDS and stored cooperatively, fully coalesced.
 struct FkArgs {
     const double* robot;
     int P;
@@ -78,60 +105,75 @@ struct FkArgs {
     int S, C;                  // C configs per scene (mode 1: C = G * n)
     int n;                     // mode 1: waypoints per goal
     int CH;                    // configs per chunk
-    float* ws;                 // [S][NCH][10][CH][P][3]
-    float* ws_start;           // mode 1: [S][10][P][3]
+    double* ws;                // [S][NCH][10][CH][12]
+    double* ws_start;          // mode 1: [S][10][12]
 };
 
-__global__ __launch_bounds__(64) void k_fk_points(FkArgs a) {
+__global__ __launch_bounds__(64) void k_fk_poses(FkArgs a) {
+    __shared__ double stage[64 * 13];  // [64][12], row stride 13 doubles
+    __shared__ double* rowptr[64];
+    __shared__ int rowstride[64];
     const RobotView rv(a.robot, a.P);
     const int per_scene = a.C + (a.mode == 1 ? 1 : 0);
     const int64_t total = (int64_t)a.S * per_scene;
-    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= total) return;
-    const int s = (int)(id / per_scene), c = (int)(id % per_scene);
+    const int lane = threadIdx.x;
+    const int64_t id0 = (int64_t)blockIdx.x * 64;
+    const int64_t id = id0 + lane;
+    const int nlive = (int)((total - id0) < 64 ? (total - id0) : 64);
+    const int64_t idc = id < total ? id : total - 1;
+    const int s = (int)(idc / per_scene), c = (int)(idc % per_scene);
+    const int CH = a.CH;
+    const int NCH = (a.C + CH - 1) / CH;
     double q[9];
-    bool is_start = false;
     if (a.mode == 0) {
         const double* src = a.joints + ((int64_t)s * a.C + c) * 9;
 #pragma unroll
         for (int d = 0; d < 9; ++d) q[d] = src[d];
+        rowptr[lane] = a.ws + ((((int64_t)s * NCH + c / CH) * 10) * CH + c % CH) * 12;
+        rowstride[lane] = CH * 12;
     } else {
         const double* q0 = a.traj_start + 9 * (int64_t)s;
-        if (c == a.C) {
-            is_start = true;
+        if (c == a.C) {  // the start configuration of the scene (ws_positions_start, cost.py:240-251)
 #pragma unroll
             for (int d = 0; d < 9; ++d) q[d] = q0[d];
+            rowptr[lane] = a.ws_start + (int64_t)s * 120;
+            rowstride[lane] = 12;
         } else {
             const int g = c / a.n, i = c % a.n;
             const double* qg = a.goals + ((int64_t)s * (a.C / a.n) + g) * 9;
-            const double t = (double)(i + 1) / (double)(a.n + 1);
+            const double t = (double)(i + 1) / (double)(a.n + 1);  // linspace(0,1,n+2)[1:-1]
 #pragma unroll
             for (int d = 0; d < 9; ++d) q[d] = q0[d] + t * (qg[d] - q0[d]);
+            rowptr[lane] = a.ws + ((((int64_t)s * NCH + c / CH) * 10) * CH + c % CH) * 12;
+            rowstride[lane] = CH * 12;
         }
     }
-    const int P = a.P, CH = a.CH;
-    const int NCH = (a.C + CH - 1) / CH;
-    const int chunk = c / CH, ci = c % CH;
     fk_chain(rv, q, [&](int l, const Pose& pose) {
-        float* dst = is_start ? a.ws_start + ((int64_t)s * 10 + l) * P * 3
-                              : a.ws + ((((int64_t)s * NCH + chunk) * 10 + l) * CH + ci) * (int64_t)P * 3;
-        for (int p = 0; p < P; ++p) {
-            double x, y, z;
-            pose_apply(pose, rv.pts(l, p), x, y, z);
-            dst[3 * p] = (float)x; dst[3 * p + 1] = (float)y; dst[3 * p + 2] = (float)z;  // .cuda().float(), cost.py:136,218
+        double* mine = stage + lane * 13;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) mine[k] = pose.R[k];
+        mine[9] = pose.t[0]; mine[10] = pose.t[1]; mine[11] = pose.t[2];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+            const int idx = k * 64 + lane;
+            const int row = idx / 12, colm = idx - row * 12;
+            if (row < nlive) rowptr[row][(int64_t)l * rowstride[row] + colm] = stage[row * 13 + colm];
         }
+        __syncthreads();
     });
 }
 
 // =================================================================================================
-// (3) k_sdf_chunks — SDF over FK points, one workgroup per (scene, chunk)
+// (3) k_sdf_chunks — SDF over the collision points of FK-produced link poses, one workgroup per (scene, chunk)
 // =================================================================================================
 struct ChunkArgs {
+    const double* robot;
     const omgx_object* objects;
     const int32_t* scene_begin;
     const float* pool;
-    const float* ws;        // [S][NCH][10][CH][P][3]
-    const float* ws_start;  // [S][10][P][3] or null
+    const double* ws;        // [S][NCH][10][CH][12] link poses
+    const double* ws_start;  // [S][10][12] or null
     int S, C, CH, NCH, P;
     int soften;             // uncheck_finger_collision == -1 (cost.py:350-353)
     int arc;                // weight potentials by ||(x_i - x_{i-1}) / dt|| (cost.py:235-275)
@@ -143,37 +185,76 @@ struct ChunkArgs {
     float* chunk_col;       // [S][NCH] or null: sum of collides of the chunk
 };
 
-template <bool WANT_GRAD>
+// Thread layout: 256 threads = 16 rows x 16 lanes.  Lane = collision point p of a link (P <= 16), row =
+// configuration ci of the chunk (strided by 16); a wave therefore holds the points of ONE link at 4
+// consecutive waypoints — spatially coherent, so its SDF gathers share cache lines.  Each thread walks
+// the 10 links in batches of LB: the wave-uniform object record is fetched (scalar loads -> SGPRs) once
+// per (batch, object) and the LB far tests are straight-line code before any exact pair runs.
+// The point itself is x = R_link p' + t_link (double, rounded to float32) from the FK kernel's pose
+// (96 bytes shared by the 16 lanes of a row) and the centred collision point of the robot blob.
+// No integer division by run-time sizes anywhere.
+template <bool WANT_GRAD, int LB>
 __global__ __launch_bounds__(256) void k_sdf_chunks(ChunkArgs a) {
     __shared__ float red[2][4];
     // XCD-aware placement: workgroup b runs on XCD b % 8 (observed; used for L2 affinity only).
     // All chunks of a scene go to the same XCD so the scene's SDF volumes stay in one 4 MiB L2.
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    const int s = (j / a.NCH) * 8 + xcd, chunk = j % a.NCH;
+    const int sgrp = j / a.NCH;  // wave-uniform (one division per workgroup)
+    const int s = sgrp * 8 + xcd, chunk = j - sgrp * a.NCH;
     if (s >= a.S) return;
-    const int o_begin = a.scene_begin[s], o_end = a.scene_begin[s + 1];
+    const int o_begin = as_const(a.scene_begin)[s], o_end = as_const(a.scene_begin)[s + 1];
     const int P = a.P, CH = a.CH;
     const int nvalid = min(CH, a.C - chunk * CH);  // configs in this (possibly last, partial) chunk
-    const int items = 10 * CH * P;
-    const float* base = a.ws + ((int64_t)s * a.NCH + chunk) * (int64_t)items * 3;
+    const int p = threadIdx.x & 15, r = threadIdx.x >> 4;
+    const RobotView rv(a.robot, P);
+    const double* base = a.ws + ((int64_t)s * a.NCH + chunk) * (int64_t)(10 * CH) * 12;
+    const double* sbase = a.arc ? a.ws_start + (int64_t)s * 120 : nullptr;
     float tsum = 0.0f, tcol = 0.0f;
-    for (int it = threadIdx.x; it < items; it += blockDim.x) {
-        const int p = it % P, ci = (it / P) % CH, l = it / (P * CH);
-        if (ci >= nvalid) continue;
-        const float px = base[3 * it], py = base[3 * it + 1], pz = base[3 * it + 2];
-        Accum acc = sdf_point<WANT_GRAD>(a.objects, o_begin, o_end, a.pool, px, py, pz);
-        if (a.soften && l >= 8) { acc.pot *= 0.1f; acc.gx *= 0.1f; acc.gy *= 0.1f; acc.gz *= 0.1f; acc.col = 0.0f; }
-        if (a.arc) {
-            const float* prev = ci > 0 ? base + 3 * (it - P) : a.ws_start + (((int64_t)s * 10 + l) * P + p) * 3;
-            const float vx = (px - prev[0]) * a.inv_dt, vy = (py - prev[1]) * a.inv_dt, vz = (pz - prev[2]) * a.inv_dt;
-            acc.pot = acc.pot * sqrtf(vx * vx + vy * vy + vz * vz);
+    if (p < P) {
+        for (int ci = r; ci < nvalid; ci += 16) {
+            const int64_t out_cfg = ((int64_t)s * a.C + chunk * CH + ci) * 10;
+#pragma unroll 1
+            for (int l0 = 0; l0 < 10; l0 += LB) {
+                float px[LB], py[LB], pz[LB];
+                Accum acc[LB];
+#pragma unroll
+                for (int k = 0; k < LB; ++k) {
+                    pose12_apply(base + ((int64_t)(l0 + k) * CH + ci) * 12, rv.pts(l0 + k, p), px[k], py[k], pz[k]);
+                    acc[k] = Accum{0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+                }
+                for (int o = o_begin; o < o_end; ++o) {  // wave-uniform trip count and addresses
+                    ObjTablePtr ob = as_const(a.objects) + o;
+                    if (ob->disabled > 0) continue;  // .cu:115-116
+                    const ObjParams op = load_object(ob);
+                    const float* grid = a.pool + ob->grid_offset;
+                    PairPrep pp[LB];
+#pragma unroll
+                    for (int k = 0; k < LB; ++k) pp[k] = pair_prepare(op, px[k], py[k], pz[k]);
+#pragma unroll
+                    for (int k = 0; k < LB; ++k)
+                        if (!pp[k].far) pair_exact<WANT_GRAD>(op, grid, pp[k].tx, pp[k].ty, pp[k].tz, acc[k]);
+                }
+#pragma unroll
+                for (int k = 0; k < LB; ++k) {
+                    const int l = l0 + k;
+                    if (a.soften && l >= 8) {  // cost.py:350-353
+                        acc[k].pot *= 0.1f; acc[k].gx *= 0.1f; acc[k].gy *= 0.1f; acc[k].gz *= 0.1f; acc[k].col = 0.0f;
+                    }
+                    if (a.arc) {  // ||(x_i - x_{i-1}) / dt|| in float32 (config.py:162-187, cost.py:260-275)
+                        float qx, qy, qz;
+                        pose12_apply(ci > 0 ? base + ((int64_t)l * CH + ci - 1) * 12 : sbase + l * 12, rv.pts(l, p), qx, qy, qz);
+                        const float vx = (px[k] - qx) * a.inv_dt, vy = (py[k] - qy) * a.inv_dt, vz = (pz[k] - qz) * a.inv_dt;
+                        acc[k].pot = acc[k].pot * sqrtf(vx * vx + vy * vy + vz * vz);
+                    }
+                    const int64_t kk = (out_cfg + l) * P + p;
+                    if (a.pot) a.pot[kk] = acc[k].pot;
+                    if (a.col) a.col[kk] = acc[k].col;
+                    if (WANT_GRAD) { a.grad[3 * kk] = acc[k].gx; a.grad[3 * kk + 1] = acc[k].gy; a.grad[3 * kk + 2] = acc[k].gz; }
+                    tsum += acc[k].pot;
+                    tcol += acc[k].col;
+                }
+            }
         }
-        const int64_t k = (((int64_t)s * a.C + chunk * CH + ci) * 10 + l) * P + p;
-        if (a.pot) a.pot[k] = acc.pot;
-        if (a.col) a.col[k] = acc.col;
-        if (WANT_GRAD) { a.grad[3 * k] = acc.gx; a.grad[3 * k + 1] = acc.gy; a.grad[3 * k + 2] = acc.gz; }
-        tsum += acc.pot;
-        tcol += acc.col;
     }
     if (a.chunk_cost || a.chunk_col) {  // fixed-order block reduction: lanes -> waves -> thread 0
         const float ws_ = wave_sum(tsum), wc_ = wave_sum(tcol);
@@ -269,20 +350,23 @@ extern "C" int omgx_sdf_loss_forward(const float* pose_init, const float* sdf_gr
 }
 
 // ---- workspace sizing -------------------------------------------------------------------------
-static inline int chunk_configs_fk_sdf(int C) { return C < 32 ? C : 32; }
+// 16 configurations per workgroup: one row per configuration, more workgroups for small batches
+static inline int chunk_configs_fk_sdf(int C) { return C < 16 ? C : 16; }
 
 extern "C" int64_t omgx_fk_sdf_workspace_bytes(int32_t num_scenes, int32_t configs_per_scene, int32_t n_points) {
     if (num_scenes <= 0 || configs_per_scene <= 0 || n_points <= 0) return 0;
     const int CH = chunk_configs_fk_sdf(configs_per_scene);
     const int64_t NCH = (configs_per_scene + CH - 1) / CH;
-    return (int64_t)num_scenes * NCH * 10 * CH * n_points * 3 * sizeof(float);
+    (void)n_points;
+    return (int64_t)num_scenes * NCH * 10 * CH * 12 * sizeof(double);
 }
 
 extern "C" int64_t omgx_goalset_workspace_bytes(int32_t num_scenes, int32_t num_goals, int32_t n_remaining, int32_t n_points) {
     if (num_scenes <= 0 || num_goals <= 0 || n_remaining <= 0 || n_points <= 0) return 0;
-    const int64_t pts = (int64_t)num_scenes * num_goals * 10 * n_remaining * n_points * 3 * sizeof(float);
-    const int64_t start = (int64_t)num_scenes * 10 * n_points * 3 * sizeof(float);
-    return pts + start;
+    (void)n_points;
+    const int64_t poses = (int64_t)num_scenes * num_goals * 10 * n_remaining * 12 * sizeof(double);
+    const int64_t start = (int64_t)num_scenes * 10 * 12 * sizeof(double);
+    return poses + start;
 }
 
 static int launch_chunks(const ChunkArgs& ca, hipStream_t st) {
@@ -291,10 +375,17 @@ static int launch_chunks(const ChunkArgs& ca, hipStream_t st) {
     if (grid > 0x7fffffff) return OMGX_ERR_UNSUPPORTED;
     const int slot = timing_slot();
     if (slot >= 0) (void)hipEventRecord(g_ev[slot][0], st);
-    if (ca.grad)
-        hipLaunchKernelGGL(k_sdf_chunks<true>, dim3((unsigned)grid), dim3(256), 0, st, ca);
-    else
-        hipLaunchKernelGGL(k_sdf_chunks<false>, dim3((unsigned)grid), dim3(256), 0, st, ca);
+    static int lb = -1;  // links per batch; OMGX_LB overrides the tuned default (tuning aid)
+    if (lb < 0) { const char* e = getenv("OMGX_LB"); lb = e ? atoi(e) : 2; }
+#define OMGX_LAUNCH_CHUNKS(G_, LB_) hipLaunchKernelGGL((k_sdf_chunks<G_, LB_>), dim3((unsigned)grid), dim3(256), 0, st, ca)
+    if (ca.grad) {
+        if (lb == 1) OMGX_LAUNCH_CHUNKS(true, 1); else if (lb == 2) OMGX_LAUNCH_CHUNKS(true, 2);
+        else if (lb == 10) OMGX_LAUNCH_CHUNKS(true, 10); else OMGX_LAUNCH_CHUNKS(true, 5);
+    } else {
+        if (lb == 1) OMGX_LAUNCH_CHUNKS(false, 1); else if (lb == 2) OMGX_LAUNCH_CHUNKS(false, 2);
+        else if (lb == 10) OMGX_LAUNCH_CHUNKS(false, 10); else OMGX_LAUNCH_CHUNKS(false, 5);
+    }
+#undef OMGX_LAUNCH_CHUNKS
     if (slot >= 0) { (void)hipEventRecord(g_ev[slot][1], st); ++g_timing_n; }
     OMGX_CHECK_LAUNCH("k_sdf_chunks");
     return OMGX_OK;
@@ -313,12 +404,12 @@ extern "C" int omgx_fk_sdf(const double* robot, int32_t n_points, const omgx_obj
     const int NCH = (configs_per_scene + CH - 1) / CH;
     FkArgs fa{};
     fa.robot = robot; fa.P = n_points; fa.mode = 0; fa.joints = joints; fa.S = num_scenes; fa.C = configs_per_scene;
-    fa.CH = CH; fa.ws = (float*)workspace;
+    fa.CH = CH; fa.ws = (double*)workspace;
     const int64_t total = (int64_t)num_scenes * configs_per_scene;
-    hipLaunchKernelGGL(k_fk_points, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, st, fa);
-    OMGX_CHECK_LAUNCH("k_fk_points");
+    hipLaunchKernelGGL(k_fk_poses, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, st, fa);
+    OMGX_CHECK_LAUNCH("k_fk_poses");
     ChunkArgs ca{};
-    ca.objects = objects; ca.scene_begin = scene_begin; ca.pool = sdf_pool; ca.ws = (const float*)workspace;
+    ca.robot = robot; ca.objects = objects; ca.scene_begin = scene_begin; ca.pool = sdf_pool; ca.ws = (const double*)workspace;
     ca.S = num_scenes; ca.C = configs_per_scene; ca.CH = CH; ca.NCH = NCH; ca.P = n_points; ca.soften = soften_fingers != 0;
     ca.pot = potentials; ca.grad = grads; ca.col = collides;
     return launch_chunks(ca, st);
@@ -337,16 +428,16 @@ extern "C" int omgx_goalset_cost(const double* robot, int32_t n_points, const om
     if (!(time_interval > 0.0)) return OMGX_ERR_INVALID;
     hipStream_t st = (hipStream_t)stream;
     const int n = n_remaining, C = num_goals * n;
-    float* ws = (float*)workspace;
-    float* ws_start = ws + (int64_t)num_scenes * num_goals * 10 * n * n_points * 3;
+    double* ws = (double*)workspace;
+    double* ws_start = ws + (int64_t)num_scenes * num_goals * 10 * n * 12;
     FkArgs fa{};
     fa.robot = robot; fa.P = n_points; fa.mode = 1; fa.traj_start = traj_start; fa.goals = goals; fa.S = num_scenes;
     fa.C = C; fa.n = n; fa.CH = n; fa.ws = ws; fa.ws_start = ws_start;
     const int64_t total = (int64_t)num_scenes * (C + 1);
-    hipLaunchKernelGGL(k_fk_points, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, st, fa);
-    OMGX_CHECK_LAUNCH("k_fk_points");
+    hipLaunchKernelGGL(k_fk_poses, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, st, fa);
+    OMGX_CHECK_LAUNCH("k_fk_poses");
     ChunkArgs ca{};
-    ca.objects = objects; ca.scene_begin = scene_begin; ca.pool = sdf_pool; ca.ws = ws; ca.ws_start = ws_start;
+    ca.robot = robot; ca.objects = objects; ca.scene_begin = scene_begin; ca.pool = sdf_pool; ca.ws = ws; ca.ws_start = ws_start;
     ca.S = num_scenes; ca.C = C; ca.CH = n; ca.NCH = num_goals; ca.P = n_points; ca.soften = soften_fingers != 0;
     ca.arc = 1; ca.inv_dt = (float)(1.0 / time_interval);
     ca.pot = potentials; ca.grad = nullptr; ca.col = nullptr; ca.chunk_cost = goal_cost; ca.chunk_col = collides;

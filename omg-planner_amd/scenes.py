@@ -19,7 +19,7 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
-# numpy mirror of `omgx_object` (include/omg_hip.h), 128 bytes
+# numpy mirror of `omgx_object` (include/omg_hip.h), 160 bytes
 OBJECT_DTYPE = np.dtype([
     ("pose_inv", np.float32, (12,)),
     ("lo", np.float32, (3,)),
@@ -31,9 +31,26 @@ OBJECT_DTYPE = np.dtype([
     ("clearance", np.float32),
     ("disabled", np.int32),
     ("grid_offset", np.int64),
-    ("reserved", np.int32, (4,)),
+    ("inv_extent", np.float64, (3,)),
+    ("far_lo", np.float32, (3,)),
+    ("far_hi", np.float32, (3,)),
 ], align=True)
-assert OBJECT_DTYPE.itemsize == 128
+assert OBJECT_DTYPE.itemsize == 160
+
+
+def finish_records(rec: np.ndarray) -> np.ndarray:
+    """Fill the derived fields (include/omg_hip.h): inv_extent = 1 / float64(float32(hi) - float32(lo)) and the
+    conservative far box [-1.5 voxel, extent + 1.5 voxel] in offset-from-lo coordinates.  A lookup is in
+    range only for grid coordinates in (-0.5, dim - 0.5), so 1.5 voxels of slack absorb every rounding;
+    degenerate extents get an infinite box (never reject)."""
+    w = (rec["hi"].astype(np.float32) - rec["lo"].astype(np.float32)).astype(np.float32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        rec["inv_extent"] = 1.0 / w.astype(np.float64)
+        vox = w / np.maximum(rec["dim"], 1).astype(np.float32)
+    ok = (w > 0) & (rec["dim"] > 0)
+    rec["far_lo"] = np.where(ok, -1.5 * vox, -np.inf).astype(np.float32)
+    rec["far_hi"] = np.where(ok, w + 1.5 * vox, np.inf).astype(np.float32)
+    return rec
 
 
 @dataclass
@@ -178,7 +195,7 @@ def table_from_padded(poses_inv, limits, eps, pad, clr, dis, grid_elems_per_obje
         rec[o]["disabled"] = 1 if dis[o] > 0 else 0
         d = rec[o]["dim"].astype(np.int64)
         rec[o]["grid_offset"] = o * int(d[0] * d[1] * d[2]) if grid_elems_per_object is None else o * grid_elems_per_object
-    return rec
+    return finish_records(rec)
 
 
 @dataclass
@@ -236,7 +253,7 @@ def pack_table(scenes, cfg_kwargs=None, ragged: bool = True, share_grids: bool =
             offset += sdf.size
             recs.extend(list(t))
         begins.append(len(recs))
-    return SceneBatch(np.array(recs, OBJECT_DTYPE), np.array(begins, np.int32),
+    return SceneBatch(finish_records(np.array(recs, OBJECT_DTYPE)), np.array(begins, np.int32),
                       np.concatenate(chunks) if chunks else np.zeros(0, np.float32))
 
 
@@ -297,6 +314,69 @@ def make_goal_set(seed: int, num_goals: int) -> np.ndarray:
     g = np.tile(base, (num_goals, 1))
     g[:, :7] += rng.normal(0.0, 0.05, size=(num_goals, 7))
     return g
+
+
+_REACH_POOL: dict = {}
+
+
+def _reach_pool(model, count: int = 400_000, seed: int = 1234):
+    """Random arm configurations within the soft joint limits with their hand pose (numpy FK), cached."""
+    key = (count, seed)
+    if key not in _REACH_POOL:
+        from scipy.spatial import cKDTree
+        rng = np.random.RandomState(seed)
+        lo, hi = model.joint_lower_limit[0], model.joint_upper_limit[0]
+        q = rng.uniform(lo, hi, size=(count, 9))
+        q[:, 7:] = 0.04
+        pos, zax = hand_pose(model, q)
+        keep = pos[:, 2] > 0.10
+        q, pos, zax = q[keep], pos[keep], zax[keep]
+        _REACH_POOL[key] = (q, pos, zax, cKDTree(pos))
+    return _REACH_POOL[key]
+
+
+def hand_pose(model, q: np.ndarray):
+    """Position and approach (z) axis of the hand link for configurations q [B,9]: the first 8 frames of
+    robot_pykdl.py:148-215 in plain numpy (host-side scene synthesis only, not on the hot path)."""
+    offs = [0.0, -np.pi, np.pi, np.pi, -np.pi, np.pi, np.pi]
+    B = q.shape[0]
+    cur = np.tile(np.eye(4), (B, 1, 1))
+    for i in range(7):
+        c, s = np.cos(q[:, i]), np.sin(q[:, i])
+        Rz = np.tile(np.eye(4), (B, 1, 1))
+        Rz[:, 0, 0], Rz[:, 0, 1], Rz[:, 1, 0], Rz[:, 1, 1] = c, -s, s, c
+        co, so = np.cos(offs[i]), np.sin(offs[i])
+        Rx = np.array([[1, 0, 0, 0], [0, co, -so, 0], [0, so, co, 0], [0, 0, 0, 1.0]])
+        b = model.pose_0[i] @ (Rz @ Rx)
+        if i > 0:
+            b[..., [1, 2]] *= -1
+        cur = cur @ b
+    hand = cur @ model.pose_0[7]
+    return hand[:, :3, 3].copy(), hand[:, :3, 2].copy()
+
+
+def make_reach_goals(scene: "Scene", model, num_goals: int, seed: int = 0) -> np.ndarray:
+    """Grasp-like goal set for the scene's target: configurations whose hand sits 10-16 cm from the
+    target's centre, above it, with the approach axis pointing at it — a stand-in for the IK'd grasp
+    set of Planner.solve_goal_set_ik (omg/planner.py:296-455; IK itself is out of scope)."""
+    q, pos, zax, tree = _reach_pool(model)
+    ctr = scene.objects[scene.target_idx].pose_mat[:3, 3]
+    rng = np.random.RandomState(20_000 + seed)
+    radius = 0.16
+    while True:
+        idx = np.array(tree.query_ball_point(ctr, radius), dtype=np.int64)
+        if idx.size:
+            d = ctr[None] - pos[idx]
+            dist = np.linalg.norm(d, axis=1)
+            good = (dist > 0.10) & (np.einsum("ij,ij->i", d / dist[:, None], zax[idx]) > 0.8) & (pos[idx, 2] > ctr[2] + 0.02)
+            idx = idx[good]
+        if idx.size >= num_goals or radius > 0.4:
+            break
+        radius += 0.02
+    if idx.size == 0:
+        return make_goal_set(seed, num_goals)
+    pick = rng.choice(idx, size=num_goals, replace=idx.size < num_goals)
+    return q[pick].copy()
 
 
 def linear_init(start: np.ndarray, end: np.ndarray, n: int) -> np.ndarray:
