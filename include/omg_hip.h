@@ -105,7 +105,8 @@ typedef struct omgx_chomp_params {
     int32_t joint_limit_max_steps;    /* cfg.joint_limit_max_steps                                  */
     int32_t allow_collision_point;    /* cfg.allow_collision_point                                  */
     int32_t pre_terminate;            /* cfg.pre_terminate                                          */
-    int32_t do_update;                /* 0 = info_only (Optimizer.optimize(info_only=True))         */
+    int32_t do_update;                /* 0 = info_only; 1 = always update (force_update=True);
+                                         2 = update unless info["terminate"] (optimizer.py:124-125)   */
     double time_interval;             /* cfg.time_interval                                          */
     double obstacle_weight;           /* cfg.obstacle_weight                                        */
     double smoothness_weight;         /* cfg.smoothness_weight                                      */
@@ -167,15 +168,30 @@ int omgx_sdf_loss_forward(const float* pose_init,       /* [O,4,4] inverse objec
  *   joints      [S,C,9]  double, radians (9-dof; wrap_values' degree round trip is applied inside)
  *   objects     table of omgx_object; scene s owns objects [scene_begin[s], scene_begin[s+1])
  *   soften_fingers != 0  <=> uncheck_finger_collision == -1 (cost.py:350-353)
+ *   arc_length > 0: Cost.batch_obstacle_cost's arc-length branch (cost.py:235-275): the C configurations
+ *     of a scene are groups of `arc_length` consecutive waypoints; potentials are multiplied by
+ *     ||(x_i - x_{i-1}) / time_interval|| (float32), the first waypoint of every group differencing
+ *     against FK(arc_start[s]) (arc_start [S,9]).  C must be a multiple of arc_length <= 64.
  * Outputs (float32): potentials [S,C,10,P], grads [S,C,10,P,3], collides [S,C,10,P]; any may be NULL.
- *   workspace   device scratch of omgx_fk_sdf_workspace_bytes(S, C, P) bytes (FK-produced points)
+ *   workspace   device scratch of omgx_fk_sdf_workspace_bytes(S, C, P) bytes (FK-produced link poses)
  * ------------------------------------------------------------------------------------------- */
 int64_t omgx_fk_sdf_workspace_bytes(int32_t num_scenes, int32_t configs_per_scene, int32_t n_points);
 int omgx_fk_sdf(const double* robot, int32_t n_points,
                 const omgx_object* objects, const int32_t* scene_begin, const float* sdf_pool,
                 const double* joints, int32_t num_scenes, int32_t configs_per_scene,
-                int32_t soften_fingers,
+                int32_t soften_fingers, int32_t arc_length, const double* arc_start, double time_interval,
                 float* potentials, float* grads, float* collides, void* workspace, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * (2b) omgx_forward_kinematics
+ * Replaces robot_kinematics.forward_kinematics_parallel(..., return_joint_info=True)
+ * (ycb_render/robotPose/robot_pykdl.py:148-215) as used by Cost.forward_poses (omg/cost.py:45-58).
+ *   joints [B,9] double radians  ->  link_poses [B,10,4,4] (center_offset applied), joint_origins [B,10,3],
+ *   joint_axes [B,10,3] (double; origins/axes may be NULL).  joint_origins reproduces the reference's
+ *   `_joint_origin := _joint_axis` quirk (robot_pykdl.py:104): origin = R axis_local + t.
+ * ------------------------------------------------------------------------------------------- */
+int omgx_forward_kinematics(const double* robot, int32_t n_points, const double* joints, int64_t num_configs,
+                            double* link_poses, double* joint_origins, double* joint_axes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * (3) omgx_goalset_cost
@@ -216,13 +232,17 @@ int omgx_goalset_cost(const double* robot, int32_t n_points,
  *   potentials [S,n,10,P], grads [S,n,10,P,3], collides [S,n,10,P] float32 from omgx_fk_sdf
  *   active [S] int32, optional: 0 = leave this trajectory untouched (terminated), NULL = all active
  * Outputs: grad [S,n,9] double (info["gradient"]), cost_traj [S,n] double, info [S,16] double.
+ *   aux    optional [S, omgx_chomp_aux_doubles(n)] double: the un-weighted pieces the reference's
+ *          compute_collision_loss / compute_smooth_loss return — obs_grad [n,9] | obs_cost [n,10] |
+ *          smooth_grad [n,9] | smooth_loss [n+1]   (NULL to skip)
  * ------------------------------------------------------------------------------------------- */
+int64_t omgx_chomp_aux_doubles(int32_t n_waypoints);
 int omgx_chomp_optimize(const double* robot, const omgx_chomp_params* h_params,
                         double* traj, const double* start, const double* end, const double* goal,
                         const double* goal_point,
                         const float* potentials, const float* grads, const float* collides,
                         const int32_t* active, int32_t num_scenes,
-                        double* grad, double* cost_traj, double* info, void* stream);
+                        double* grad, double* cost_traj, double* info, double* aux, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Diagnostics

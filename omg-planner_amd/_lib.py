@@ -16,8 +16,8 @@ OMGX_OK, OMGX_ERR_INVALID, OMGX_ERR_LAUNCH, OMGX_ERR_UNSUPPORTED = 0, -1, -2, -3
 NUM_DOF, INFO_STRIDE = 9, 16
 
 # every symbol include/omg_hip.h declares
-EXPORTS = ["omgx_sdf_loss_forward", "omgx_fk_sdf_workspace_bytes", "omgx_fk_sdf", "omgx_goalset_workspace_bytes",
-           "omgx_goalset_cost", "omgx_chomp_optimize", "omgx_last_error", "omgx_abi_version", "omgx_device_arch",
+EXPORTS = ["omgx_sdf_loss_forward", "omgx_fk_sdf_workspace_bytes", "omgx_fk_sdf", "omgx_forward_kinematics",
+           "omgx_goalset_workspace_bytes", "omgx_goalset_cost", "omgx_chomp_aux_doubles", "omgx_chomp_optimize", "omgx_last_error", "omgx_abi_version", "omgx_device_arch",
            "omgx_timing_enable", "omgx_timing_collect"]
 
 
@@ -56,16 +56,19 @@ def lib() -> C.CDLL:
         l.omgx_sdf_loss_forward.argtypes = [vp] * 8 + [i64, i32] + [vp] * 3 + [vp]
         l.omgx_fk_sdf_workspace_bytes.argtypes = [i32, i32, i32]
         l.omgx_fk_sdf_workspace_bytes.restype = i64
-        l.omgx_fk_sdf.argtypes = [vp, i32, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]
+        l.omgx_fk_sdf.argtypes = [vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, vp, f64, vp, vp, vp, vp, vp]
+        l.omgx_forward_kinematics.argtypes = [vp, i32, vp, i64, vp, vp, vp, vp]
+        l.omgx_chomp_aux_doubles.argtypes = [i32]
+        l.omgx_chomp_aux_doubles.restype = i64
         l.omgx_goalset_workspace_bytes.argtypes = [i32, i32, i32, i32]
         l.omgx_goalset_workspace_bytes.restype = i64
         l.omgx_goalset_cost.argtypes = [vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, f64, i32, vp, vp, vp, vp, vp]
-        l.omgx_chomp_optimize.argtypes = [vp, C.POINTER(ChompParams)] + [vp] * 9 + [i32] + [vp] * 3 + [vp]
+        l.omgx_chomp_optimize.argtypes = [vp, C.POINTER(ChompParams)] + [vp] * 9 + [i32] + [vp] * 4 + [vp]
         l.omgx_last_error.restype = C.c_char_p
         l.omgx_device_arch.argtypes = [C.c_char_p, i32]
         l.omgx_timing_enable.argtypes = [i32]
         l.omgx_timing_collect.argtypes = [C.POINTER(C.c_float), i32]
-        for name in ("omgx_sdf_loss_forward", "omgx_fk_sdf", "omgx_goalset_cost", "omgx_chomp_optimize",
+        for name in ("omgx_sdf_loss_forward", "omgx_fk_sdf", "omgx_forward_kinematics", "omgx_goalset_cost", "omgx_chomp_optimize",
                      "omgx_abi_version", "omgx_device_arch", "omgx_timing_enable", "omgx_timing_collect"):
             getattr(l, name).restype = C.c_int
         _lib = l

@@ -1,0 +1,267 @@
+"""`Cost` — host-side mirror of the reference's cost class surface (omg/cost.py:12-532), backed by the
+HIP kernels of libomg_hip.so.
+
+What callers of the reference touch (grep over omg/planner.py, online_learner.py, core.py):
+``Cost(env)``, the attributes ``env / cfg / target_obj / sdf_loss``, ``batch_obstacle_cost(...)`` and
+``compute_total_loss(traj)`` (through ``Optimizer.optimize``).  Those run on the device:
+
+===============================  ==========================================================
+method                           device entry point (include/omg_hip.h)
+===============================  ==========================================================
+compute_obstacle_cost_layer      omgx_sdf_loss_forward (the SDF layer on explicit points)
+batch_obstacle_cost              omgx_fk_sdf (FK -> points -> SDF, optional arc-length weights)
+compute_total_loss               omgx_fk_sdf + omgx_chomp_optimize (info only)
+compute_collision_loss           same launch, un-weighted pieces from the `aux` buffer
+compute_smooth_loss              same launch, un-weighted pieces from the `aux` buffer
+forward_poses                    omgx_forward_kinematics
+===============================  ==========================================================
+
+``env`` is duck-typed like the reference's ``Env`` (omg/core.py:239-411): ``env.robot`` with
+``collision_points [10,P,3]``, ``joint_lower_limit / joint_upper_limit [1,9]`` and (optionally)
+``robot_kinematics`` carrying the ``_pose_0 / _tip2joint / _joint_axis / center_offset`` tables;
+``env.objects[i]`` with ``name / pose_mat / attached``; ``env.target_idx``; ``env.sdf_torch [O,X,Y,Z]`` and
+``env.sdf_limits [O,10]`` device tensors (used in place, never copied); ``env.config``.
+
+The remaining small methods (``forward_points``, ``color_point``) are array plumbing for visualisation,
+kept in numpy exactly because they are not on the hot path.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from . import scenes as sc
+from .robot import PandaModel
+
+
+def _np(x):
+    return x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
+
+
+class SDFLoss:
+    """Callable with the signature of layers/sdf_matching_loss.py:SDFLoss.forward."""
+
+    def __call__(self, pose_init, sdf_grids, sdf_limits, points, epsilons, padding_scales, clearances, disables):
+        return tuple(ops.sdf_loss_forward(pose_init, sdf_grids, sdf_limits, points, epsilons, padding_scales,
+                                          clearances, disables))
+
+    forward = __call__
+
+
+class Cost(object):
+    """Obstacle and smoothness cost + gradients of a trajectory (omg/cost.py:12-16)."""
+
+    def __init__(self, env):
+        self.env = env
+        self.cfg = env.config
+        self.sdf_loss = SDFLoss()
+        if len(self.env.objects) > 0:
+            self.target_obj = self.env.objects[self.env.target_idx]
+        self.device = env.sdf_torch.device if isinstance(getattr(env, "sdf_torch", None), torch.Tensor) else torch.device("cuda:0")
+        self._model = None
+        self._robot = None
+        self._points_version = None
+
+    # -- device-side state -------------------------------------------------------------------------
+    def _robot_model(self):
+        """Robot blob (kinematic tables + current collision points); rebuilt when the points change
+        (Robot.resample_attached_object_collision_points swaps them, omg/core.py:192-236)."""
+        pts = np.asarray(self.env.robot.collision_points, dtype=np.float64)
+        key = (pts.shape, pts.tobytes())
+        if self._points_version != key:
+            m = PandaModel(collision_points=pts)
+            kin = getattr(self.env.robot, "robot_kinematics", None)
+            if kin is not None and hasattr(kin, "_pose_0"):
+                m.pose_0 = np.ascontiguousarray(kin._pose_0, np.float64)
+                m.tip2joint = np.ascontiguousarray(kin._tip2joint, np.float64)
+                m.joint_axis = np.ascontiguousarray(kin._joint_axis, np.float64)
+                m.center_offset = np.ascontiguousarray(kin.center_offset, np.float64)
+            m.joint_lower_limit = np.asarray(self.env.robot.joint_lower_limit, np.float64).reshape(1, 9).copy()
+            m.joint_upper_limit = np.asarray(self.env.robot.joint_upper_limit, np.float64).reshape(1, 9).copy()
+            self._model, self._robot, self._points_version = m, ops.robot_blob(m, self.device), key
+        return self._model, self._robot
+
+    def _layer_params(self):
+        """Per-object parameters of compute_obstacle_cost_layer (cost.py:303-328), numpy float32."""
+        scene = sc.Scene([sc.SceneObject(o.name, np.asarray(o.pose_mat), None, bool(getattr(o, "attached", False)))
+                          for o in self.env.objects], int(self.env.target_idx))
+        return sc.layer_params(scene, epsilon=self.cfg.epsilon, target_epsilon=self.cfg.target_epsilon,
+                               clearance=self.cfg.clearance, target_clearance=self.cfg.target_clearance,
+                               disable_collision_set=tuple(self.cfg.disable_collision_set))
+
+    def _scenes(self) -> ops.DeviceScenes:
+        """One-scene object table addressing env.sdf_torch IN PLACE (rebuilt per call like the reference
+        rebuilds its five parameter tensors per call; object poses may have changed)."""
+        poses, eps, pad, clr, dis = self._layer_params()
+        limits = _np(self.env.sdf_limits).astype(np.float32)
+        table = sc.table_from_padded(poses, limits, eps, pad, clr, dis)
+        ds = ops.DeviceScenes.__new__(ops.DeviceScenes)
+        ds.device = self.device
+        ds.num_scenes = 1
+        ds.objects = torch.from_numpy(table.view(np.uint8).copy()).to(self.device)
+        ds.scene_begin = torch.tensor([0, len(table)], dtype=torch.int32, device=self.device)
+        ds.pool = self.env.sdf_torch.reshape(-1)
+        if not (ds.pool.is_cuda and ds.pool.dtype == torch.float32 and ds.pool.is_contiguous()):
+            raise _lib.OmgHipError("env.sdf_torch must be a contiguous float32 device tensor")
+        return ds
+
+    def _params(self, n: int, do_update: int) -> _lib.ChompParams:
+        cfg = self.cfg
+        p = _lib.ChompParams()
+        p.n_waypoints, p.n_points = n, self._robot_model()[0].points_per_link
+        p.top_k = int(cfg.top_k_collision)
+        p.consider_finger = int(cfg.consider_finger)
+        p.goal_set_proj = int(cfg.goal_set_proj)
+        p.use_standoff = int(cfg.use_standoff)
+        p.constraint_num = int(cfg.reach_tail_length) if cfg.use_standoff else 1
+        p.uncheck_finger_collision = int(cfg.uncheck_finger_collision)
+        p.joint_limit_max_steps = int(cfg.joint_limit_max_steps)
+        p.allow_collision_point = int(cfg.allow_collision_point)
+        p.pre_terminate = int(cfg.pre_terminate)
+        p.do_update = do_update
+        p.time_interval = float(cfg.time_interval)
+        p.obstacle_weight = float(cfg.obstacle_weight)
+        p.smoothness_weight = float(cfg.smoothness_weight)
+        p.step_size = float(cfg.step_size)
+        p.clip_grad_scale = float(cfg.clip_grad_scale)
+        p.terminate_smooth_loss = float(cfg.terminate_smooth_loss)
+        w = np.broadcast_to(np.asarray(cfg.link_smooth_weight, np.float64).ravel(), (9,))
+        for d in range(9):
+            p.link_smooth_weight[d] = float(w[d])
+        return p
+
+    def _t(self, a, dtype=torch.float64):
+        return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(self.device)
+
+    # -- kinematics helpers --------------------------------------------------------------------------
+    def forward_poses(self, joints):
+        """Link poses [10,4,4], joint origins [10,3] and axes [10,3] of ONE configuration given in DEGREES
+        with the dummy hand joint (the output of wrap_value), as omg/cost.py:45-58."""
+        model, robot = self._robot_model()
+        j = np.asarray(joints, np.float64)
+        q = np.deg2rad(np.concatenate([j[:7], j[8:10]]) if j.shape[0] > 9 else j)
+        poses, org, ax = ops.forward_kinematics(robot, model.points_per_link, self._t(q[None]))
+        return _np(poses[0]), _np(org[0]), _np(ax[0])
+
+    def forward_points(self, pose, pts, normals=None):
+        """x = R pts + t, returned as [p, links, n, 3] (omg/cost.py:60-72)."""
+        x = np.matmul(pose[..., :3, :3], pts[None, ...]) + pose[..., :3, [3]]
+        if normals is not None:
+            x = np.concatenate([x, np.matmul(pose[..., :3, :3], normals[None, ...])], 2)
+        return x.transpose([3, 1, 0, 2])
+
+    def color_point(self, vis_pts, collide):
+        """Visualisation colours from relative potential (omg/cost.py:74-90)."""
+        pmax = np.amax(vis_pts[..., 6], axis=(-2, -1))[..., None, None]
+        pmin = np.amin(vis_pts[..., 6], axis=(-2, -1))[..., None, None]
+        vis_pts[..., 6] = 255 * (vis_pts[..., 6] - pmin) / ((pmax - pmin + 1e-8) + 1e-8)
+        vis_pts[..., 7] = 255 - vis_pts[..., 6]
+        vis_pts[_np(collide).astype(bool), 6:9] = 255, 0, 0
+
+    # -- SDF layer -----------------------------------------------------------------------------------
+    def compute_obstacle_cost_layer(self, ws_positions, vis_pts=None, special_check_id=0, uncheck_finger_collision=-1,
+                                    grad_free=True):
+        """SDF layer on explicit workspace points [n, m, p, 3] (device tensor) — omg/cost.py:288-360."""
+        n, m, p, _ = ws_positions.shape
+        points = ws_positions.reshape([-1, 3]).contiguous().float()
+        poses, eps, pad, clr, dis = self._layer_params()
+        dev = points.device
+        potentials, potential_grads, collides = self.sdf_loss(
+            torch.from_numpy(poses).to(dev), self.env.sdf_torch, self.env.sdf_limits, points, torch.from_numpy(eps).to(dev),
+            torch.from_numpy(pad).to(dev), torch.from_numpy(clr).to(dev), torch.from_numpy(dis).to(dev))
+        potentials = potentials.reshape([n, m, p])
+        potential_grads = potential_grads.reshape([n, m, p, 3])
+        collides = collides.reshape([n, m, p])
+        if uncheck_finger_collision == -1:  # cost.py:350-353
+            potentials[:, -2:] *= 0.1
+            potential_grads[:, -2:] *= 0.1
+            collides[:, -2:] = 0
+        if vis_pts is not None:
+            vis_pts[:, :m, :, :3] = _np(points.reshape([n, m, p, 3]))
+            vis_pts[:, :m, :, 6] = _np(potentials)
+            vis_pts[:, :m, :, 9:] = _np(potential_grads)
+        return potentials, potential_grads, collides
+
+    def batch_obstacle_cost(self, joints, arc_length=-1, only_collide=False, special_check_id=0,
+                            uncheck_finger_collision=-1, start=None, end=None, want_vis=True):
+        """Obstacle cost of a batch of configurations joints [B,9] — omg/cost.py:192-286.  FK, the point
+        transform, the SDF layer and the arc-length weighting all run on the device (omgx_fk_sdf).
+        Returns (potentials [B,m,p], grad [B,m,p,3], vis_pts, collide) like the reference; ``want_vis=False``
+        skips the [B,m,p,12] host array (5.5 GB at 100 scenes x 128 goals)."""
+        model, robot = self._robot_model()
+        P = model.points_per_link
+        q = self._t(np.asarray(joints, np.float64).reshape(1, -1, 9))
+        B = q.shape[1]
+        arc = int(arc_length) if arc_length is not None and arc_length > 0 else 0
+        pot, grad, col = ops.fk_sdf(robot, P, self._scenes(), q, soften_fingers=uncheck_finger_collision == -1,
+                                    arc_length=arc, arc_start=self._t(np.asarray(start, np.float64).reshape(1, 9)) if arc else None,
+                                    dt=float(self.cfg.time_interval))
+        potentials, grad, collide = pot[0], grad[0], col[0]
+        vis_pts = None
+        if want_vis:
+            vis_pts = np.zeros([B, 10, P, 12])
+            vis_pts[..., 6] = _np(potentials)
+            vis_pts[..., 9:] = _np(grad)
+            self.color_point(vis_pts, collide)
+        if only_collide:  # cost.py:279-284
+            thr = 0.5 * (self.cfg.epsilon - self.cfg.clearance) ** 2 / self.cfg.epsilon
+            potentials = potentials * (potentials > thr).any()
+        return potentials, grad, vis_pts, collide
+
+    # -- trajectory losses -----------------------------------------------------------------------------
+    def _evaluate(self, xi, start, end, goal_point=None, want_aux=False):
+        """One info-only k_chomp_optimize launch for a single trajectory."""
+        model, robot = self._robot_model()
+        P = model.points_per_link
+        xi = np.asarray(xi, np.float64)
+        n = xi.shape[0]
+        traj = self._t(xi[None])
+        pot, pgrad, col = ops.fk_sdf(robot, P, self._scenes(), traj,
+                                     soften_fingers=self.cfg.uncheck_finger_collision == -1)
+        prm = self._params(n, 0)
+        end_t = self._t(np.asarray(end, np.float64)[None])
+        gp = end_t if goal_point is None else self._t(np.asarray(goal_point, np.float64)[None])
+        goal = end_t[:, None, :].expand(1, prm.constraint_num, 9).contiguous()  # unused by an info-only launch
+        aux = torch.empty((1, _lib.lib().omgx_chomp_aux_doubles(n)), dtype=torch.float64, device=self.device) if want_aux else None
+        grad, cost_traj, info = ops.chomp_optimize(robot, prm, traj, self._t(np.asarray(start, np.float64)[None]), end_t, goal, gp,
+                                                   pot, pgrad, col, aux=aux)
+        return n, pot, pgrad, col, grad, cost_traj, info, aux
+
+    def compute_collision_loss(self, xi, start, end):
+        """-> obs_cost [n, 10], obs_grad [n, 9], vis_pts, collide  (omg/cost.py:362-423)."""
+        n, pot, pgrad, col, _, _, info, aux = self._evaluate(xi, start, end, want_aux=True)
+        a = _np(aux[0])
+        vis_pts = np.zeros([n, 11, pot.shape[-1], 12])
+        vis_pts[:, :10, :, 6] = _np(pot[0])
+        vis_pts[:, :10, :, 9:] = _np(pgrad[0])
+        return a[n * 9: n * 19].reshape(n, 10), a[: n * 9].reshape(n, 9), vis_pts, np.float32(_np(info)[0, 8])
+
+    def compute_smooth_loss(self, xi, start, end):
+        """-> smoothness_loss [n+1], smoothness_grad [n, 9]  (omg/cost.py:425-449)."""
+        n, _, _, _, _, _, _, aux = self._evaluate(xi, start, end, want_aux=True)
+        a = _np(aux[0])
+        return a[n * 28: n * 28 + n + 1].copy(), a[n * 19: n * 28].reshape(n, 9).copy()
+
+    def compute_total_loss(self, traj):
+        """-> cost, grad [n, 9], info (the 20 keys of omg/cost.py:509-530)."""
+        gp = traj.goal_set[traj.goal_idx] if self.cfg.goal_set_proj and len(traj.goal_set) > 0 else traj.end
+        n, pot, pgrad, col, grad, cost_traj, info_t, _ = self._evaluate(traj.data, traj.start, traj.end, goal_point=gp)
+        i = _np(info_t)[0]
+        grad = _np(grad[0])
+        cfg = self.cfg
+        # compute_total_loss's own flag does not know about joint limits (check_joint_limit amends it later,
+        # optimizer.py:166-174); rebuild it from the kernel's numbers (cost.py:489-494)
+        terminate = bool((i[8] <= cfg.allow_collision_point) and cfg.pre_terminate and (i[9] < 0.01)
+                         and (i[2] < cfg.terminate_smooth_loss))
+        vis_pts = np.zeros([n, 11, pot.shape[-1], 12])
+        vis_pts[:, :10, :, 6] = _np(pot[0])
+        vis_pts[:, :10, :, 9:] = _np(pgrad[0])
+        info = {
+            "collision_pts": vis_pts, "obs": i[1], "smooth": i[2], "grasp": 0, "weighted_obs": i[3], "weighted_smooth": i[4],
+            "weighted_smooth_grad": i[6], "weighted_obs_grad": i[5], "weighted_grasp_grad": 0, "weighted_grasp": 0,
+            "gradient": grad, "failure_terminate": bool(i[11]), "cost": i[0], "grad": i[7], "terminate": terminate,
+            "collide": np.float32(i[8]), "standoff_idx": int(i[13]), "reach": i[9], "execute": bool(i[12]),
+            "cost_traj": _np(cost_traj[0]),
+        }
+        return info["cost"], grad, info

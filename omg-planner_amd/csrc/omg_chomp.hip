@@ -57,6 +57,7 @@ struct ChompArgs {
     double* grad;              // [S][n][9]
     double* cost_traj;         // [S][n]
     double* info;              // [S][16]
+    double* aux;               // [S][aux_doubles(n)] or null
 };
 
 // wrap_joint(l+1) (omg/util.py:213-220): k-th joint index (into the 10-joint tables) of link l; count via njoints().
@@ -443,6 +444,11 @@ __global__ __launch_bounds__(CH_TPB) void k_chomp_optimize(ChompArgs a) {
         L.sml[i] = 0.5 * nrm * nrm;
     }
     __syncthreads();
+    if (a.aux) {  // un-weighted pieces: obs_grad | obs_cost | smooth_grad | smooth_loss
+        double* ax = a.aux + (size_t)s * (n * 9 + n * 10 + n * 9 + n + 1);
+        for (int e = tid; e < n * 9; e += blockDim.x) { ax[e] = L.og[e]; ax[n * 19 + e] = L.sg[e]; }
+        for (int i = tid; i <= n; i += blockDim.x) ax[n * 28 + i] = L.sml[i];
+    }
 
     // ---------------------------------------------------------------- phase 5: totals (cost.py:464-530)
     // link costs: top-k branch broadcasts each link's summed cost to every waypoint (cost.py:416)
@@ -460,12 +466,20 @@ __global__ __launch_bounds__(CH_TPB) void k_chomp_optimize(ChompArgs a) {
         obs_sum = per_wp * (double)n;
         for (int i = tid; i < n; i += blockDim.x)
             a.cost_traj[(size_t)s * n + i] = prm.obstacle_weight * per_wp + prm.smoothness_weight * L.sml[i];
+        if (a.aux) {
+            double* oc = a.aux + (size_t)s * (n * 9 + n * 10 + n * 9 + n + 1) + n * 9;
+            for (int e = tid; e < n * 10; e += blockDim.x) oc[e] = L.red[32 + e % 10];
+        }
     } else {
         obs_sum = block_sum(L, L.gcost, n * 10, 0);
         for (int i = tid; i < n; i += blockDim.x) {
             double r = 0.0;
             for (int l = 0; l < 10; ++l) r += L.gcost[i * 10 + l];
             a.cost_traj[(size_t)s * n + i] = prm.obstacle_weight * r + prm.smoothness_weight * L.sml[i];
+        }
+        if (a.aux) {
+            double* oc = a.aux + (size_t)s * (n * 9 + n * 10 + n * 9 + n + 1) + n * 9;
+            for (int e = tid; e < n * 10; e += blockDim.x) oc[e] = L.gcost[e];
         }
     }
     const double smooth_sum = block_sum(L, L.sml, n + 1, 1);
@@ -538,8 +552,13 @@ __global__ __launch_bounds__(CH_TPB) void k_chomp_optimize(ChompArgs a) {
         info[OMGX_INFO_STANDOFF_IDX] = prm.use_standoff ? (double)(n - c) : (double)(n - 1);
         info[OMGX_INFO_VIOLATE_LIMIT] = violate ? 1.0 : 0.0;
         info[OMGX_INFO_LIMIT_STEPS] = 0.0;
+        L.red[52] = terminate ? 1.0 : 0.0;
     }
     if (!prm.do_update) return;
+    if (prm.do_update == 2) {  // Optimizer.optimize without force_update: a terminated trajectory is left alone
+        __syncthreads();
+        if (L.red[52] > 0.0) return;
+    }
 
     // ---------------------------------------------------------------- phase 6: covariant (projected) step
     __syncthreads();
@@ -618,11 +637,13 @@ static size_t host_lds_bytes(int n, int P) {
     return d * 8 + i * 4;
 }
 
+extern "C" int64_t omgx_chomp_aux_doubles(int32_t n) { return n < 1 ? 0 : (int64_t)n * 9 + (int64_t)n * 10 + (int64_t)n * 9 + n + 1; }
+
 extern "C" int omgx_chomp_optimize(const double* robot, const omgx_chomp_params* h_params, double* traj,
                                    const double* start, const double* end, const double* goal,
                                    const double* goal_point, const float* potentials, const float* grads,
                                    const float* collides, const int32_t* active, int32_t num_scenes, double* grad,
-                                   double* cost_traj, double* info, void* stream) {
+                                   double* cost_traj, double* info, double* aux, void* stream) {
     if (!h_params || num_scenes < 0) return OMGX_ERR_INVALID;
     if (num_scenes == 0) return OMGX_OK;
     if (!robot || !traj || !start || !end || !goal || !goal_point || !potentials || !grads || !collides || !grad ||
@@ -632,11 +653,11 @@ extern "C" int omgx_chomp_optimize(const double* robot, const omgx_chomp_params*
     if (p.n_waypoints < 1 || p.n_waypoints > OMGX_MAX_WAYPOINTS || p.n_points < 1 || p.n_points > OMGX_MAX_POINTS ||
         p.constraint_num < 1 || p.constraint_num > OMGX_MAX_CONSTRAINTS || p.constraint_num > p.n_waypoints)
         return OMGX_ERR_UNSUPPORTED;
-    if (!(p.time_interval > 0.0) || p.top_k < 0) return OMGX_ERR_INVALID;
+    if (!(p.time_interval > 0.0) || p.top_k < 0 || p.do_update < 0 || p.do_update > 2) return OMGX_ERR_INVALID;
     ChompArgs a{};
     a.robot = robot; a.prm = p; a.traj = traj; a.start = start; a.end = end; a.goal = goal; a.goal_point = goal_point;
     a.pot = potentials; a.pgrad = grads; a.col = collides; a.active = active; a.grad = grad; a.cost_traj = cost_traj;
-    a.info = info;
+    a.info = info; a.aux = aux;
     const size_t lds = host_lds_bytes(p.n_waypoints, p.n_points);
     static bool attr_set = false;
     if (!attr_set) {

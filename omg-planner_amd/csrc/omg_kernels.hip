@@ -93,6 +93,7 @@ __global__ __launch_bounds__(256) void k_sdf_loss(RawObjects R, const float* __r
 //   mode 0: joints[S][C][9] given                                   (omgx_fk_sdf, chomp waypoints)
 //   mode 1: joints interpolated start + (i+1)/(n+1) (goal - start)  (omgx_goalset_cost; util.py:261-290 "linear")
 //           plus one extra configuration per scene = traj_start itself, written to ws_start
+//   mode 2: joints[S][C][9] given + the extra start configuration      (omgx_fk_sdf with arc_length > 0)
 // Output layout ws[S][NCH][10][CH][12]: for a fixed link the 64 configurations of a wave are contiguous
 // (6 KiB), so each link's poses are staged in LDS and stored cooperatively, fully coalesced.
 struct FkArgs {
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(64) void k_fk_poses(FkArgs a) {
     __shared__ double* rowptr[64];
     __shared__ int rowstride[64];
     const RobotView rv(a.robot, a.P);
-    const int per_scene = a.C + (a.mode == 1 ? 1 : 0);
+    const int per_scene = a.C + (a.mode != 0 ? 1 : 0);
     const int64_t total = (int64_t)a.S * per_scene;
     const int lane = threadIdx.x;
     const int64_t id0 = (int64_t)blockIdx.x * 64;
@@ -125,12 +126,20 @@ __global__ __launch_bounds__(64) void k_fk_poses(FkArgs a) {
     const int CH = a.CH;
     const int NCH = (a.C + CH - 1) / CH;
     double q[9];
-    if (a.mode == 0) {
-        const double* src = a.joints + ((int64_t)s * a.C + c) * 9;
+    if (a.mode == 0 || a.mode == 2) {  // explicit joints; mode 2 adds one start configuration per scene
+        if (a.mode == 2 && c == a.C) {
+            const double* q0 = a.traj_start + 9 * (int64_t)s;
 #pragma unroll
-        for (int d = 0; d < 9; ++d) q[d] = src[d];
-        rowptr[lane] = a.ws + ((((int64_t)s * NCH + c / CH) * 10) * CH + c % CH) * 12;
-        rowstride[lane] = CH * 12;
+            for (int d = 0; d < 9; ++d) q[d] = q0[d];
+            rowptr[lane] = a.ws_start + (int64_t)s * 120;
+            rowstride[lane] = 12;
+        } else {
+            const double* src = a.joints + ((int64_t)s * a.C + c) * 9;
+#pragma unroll
+            for (int d = 0; d < 9; ++d) q[d] = src[d];
+            rowptr[lane] = a.ws + ((((int64_t)s * NCH + c / CH) * 10) * CH + c % CH) * 12;
+            rowstride[lane] = CH * 12;
+        }
     } else {
         const double* q0 = a.traj_start + 9 * (int64_t)s;
         if (c == a.C) {  // the start configuration of the scene (ws_positions_start, cost.py:240-251)
@@ -355,10 +364,10 @@ static inline int chunk_configs_fk_sdf(int C) { return C < 16 ? C : 16; }
 
 extern "C" int64_t omgx_fk_sdf_workspace_bytes(int32_t num_scenes, int32_t configs_per_scene, int32_t n_points) {
     if (num_scenes <= 0 || configs_per_scene <= 0 || n_points <= 0) return 0;
-    const int CH = chunk_configs_fk_sdf(configs_per_scene);
-    const int64_t NCH = (configs_per_scene + CH - 1) / CH;
-    (void)n_points;
-    return (int64_t)num_scenes * NCH * 10 * CH * 12 * sizeof(double);
+    // link poses [S][NCH][10][CH][12] double; NCH*CH <= C + 63 for either chunking (16 configurations, or
+    // arc_length <= 64 configurations per chunk), plus one start pose set [10][12] per scene
+    const int64_t rows = (int64_t)configs_per_scene + 64;
+    return (int64_t)num_scenes * (rows * 10 * 12 + 120) * (int64_t)sizeof(double);
 }
 
 extern "C" int64_t omgx_goalset_workspace_bytes(int32_t num_scenes, int32_t num_goals, int32_t n_remaining, int32_t n_points) {
@@ -393,26 +402,81 @@ static int launch_chunks(const ChunkArgs& ca, hipStream_t st) {
 
 extern "C" int omgx_fk_sdf(const double* robot, int32_t n_points, const omgx_object* objects, const int32_t* scene_begin,
                            const float* sdf_pool, const double* joints, int32_t num_scenes, int32_t configs_per_scene,
-                           int32_t soften_fingers, float* potentials, float* grads, float* collides, void* workspace,
-                           void* stream) {
+                           int32_t soften_fingers, int32_t arc_length, const double* arc_start, double time_interval,
+                           float* potentials, float* grads, float* collides, void* workspace, void* stream) {
     if (num_scenes < 0 || configs_per_scene < 0) return OMGX_ERR_INVALID;
     if (num_scenes == 0 || configs_per_scene == 0) return OMGX_OK;
     if (!robot || !objects || !scene_begin || !joints || !workspace) return OMGX_ERR_INVALID;
     if (n_points < 1 || n_points > OMGX_MAX_POINTS) return OMGX_ERR_UNSUPPORTED;
+    const bool arc = arc_length > 0;
+    if (arc) {
+        if (!arc_start || !(time_interval > 0.0)) return OMGX_ERR_INVALID;
+        if (arc_length > OMGX_MAX_WAYPOINTS || configs_per_scene % arc_length != 0) return OMGX_ERR_UNSUPPORTED;
+    }
     hipStream_t st = (hipStream_t)stream;
-    const int CH = chunk_configs_fk_sdf(configs_per_scene);
+    const int CH = arc ? arc_length : chunk_configs_fk_sdf(configs_per_scene);
     const int NCH = (configs_per_scene + CH - 1) / CH;
+    double* ws = (double*)workspace;
+    double* ws_start = ws + (int64_t)num_scenes * NCH * 10 * CH * 12;
     FkArgs fa{};
-    fa.robot = robot; fa.P = n_points; fa.mode = 0; fa.joints = joints; fa.S = num_scenes; fa.C = configs_per_scene;
-    fa.CH = CH; fa.ws = (double*)workspace;
-    const int64_t total = (int64_t)num_scenes * configs_per_scene;
+    fa.robot = robot; fa.P = n_points; fa.mode = arc ? 2 : 0; fa.joints = joints; fa.traj_start = arc_start;
+    fa.S = num_scenes; fa.C = configs_per_scene; fa.CH = CH; fa.ws = ws; fa.ws_start = ws_start;
+    const int64_t total = (int64_t)num_scenes * (configs_per_scene + (arc ? 1 : 0));
     hipLaunchKernelGGL(k_fk_poses, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, st, fa);
     OMGX_CHECK_LAUNCH("k_fk_poses");
     ChunkArgs ca{};
-    ca.robot = robot; ca.objects = objects; ca.scene_begin = scene_begin; ca.pool = sdf_pool; ca.ws = (const double*)workspace;
+    ca.robot = robot; ca.objects = objects; ca.scene_begin = scene_begin; ca.pool = sdf_pool; ca.ws = ws; ca.ws_start = ws_start;
     ca.S = num_scenes; ca.C = configs_per_scene; ca.CH = CH; ca.NCH = NCH; ca.P = n_points; ca.soften = soften_fingers != 0;
+    ca.arc = arc ? 1 : 0; ca.inv_dt = arc ? (float)(1.0 / time_interval) : 0.0f;
     ca.pot = potentials; ca.grad = grads; ca.col = collides;
     return launch_chunks(ca, st);
+}
+
+// (2b) forward kinematics with joint info, one lane per configuration
+__global__ __launch_bounds__(64) void k_forward_kinematics(const double* __restrict__ robot, int P,
+                                                            const double* __restrict__ joints, int64_t B,
+                                                            double* __restrict__ poses, double* __restrict__ origins,
+                                                            double* __restrict__ axes) {
+#pragma clang fp contract(fast)
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const RobotView rv(robot, P);
+    double q[9];
+#pragma unroll
+    for (int d = 0; d < 9; ++d) q[d] = joints[9 * b + d];
+    fk_chain(rv, q, [&](int l, const Pose& pose) {
+        const double* co = robot + OMGX_ROBOT_CENTER_OFFSET + 16 * l;  // output_pose @ center_offset (robot_pykdl.py:203-204)
+        double* out = poses + (b * 10 + l) * 16;
+        for (int r = 0; r < 3; ++r) {
+            for (int c = 0; c < 4; ++c)
+                out[4 * r + c] = pose.R[3 * r] * co[c] + pose.R[3 * r + 1] * co[4 + c] + pose.R[3 * r + 2] * co[8 + c] +
+                                 (c == 3 ? pose.t[r] : 0.0);
+        }
+        out[12] = 0.0; out[13] = 0.0; out[14] = 0.0; out[15] = 1.0;
+        if (origins && axes) {
+            const double* ax = rv.ax(l);
+            const double* og = rv.og(l);
+            for (int r = 0; r < 3; ++r) {
+                const double w = pose.R[3 * r] * ax[0] + pose.R[3 * r + 1] * ax[1] + pose.R[3 * r + 2] * ax[2];
+                const double t = pose.R[3 * r] * og[0] + pose.R[3 * r + 1] * og[1] + pose.R[3 * r + 2] * og[2] + pose.t[r];
+                axes[(b * 10 + l) * 3 + r] = w;
+                origins[(b * 10 + l) * 3 + r] = w + t;  // `_joint_origin` is loaded from `_joint_axis` (robot_pykdl.py:104)
+            }
+        }
+    });
+}
+
+extern "C" int omgx_forward_kinematics(const double* robot, int32_t n_points, const double* joints, int64_t num_configs,
+                                       double* link_poses, double* joint_origins, double* joint_axes, void* stream) {
+    if (num_configs < 0) return OMGX_ERR_INVALID;
+    if (num_configs == 0) return OMGX_OK;
+    if (!robot || !joints || !link_poses) return OMGX_ERR_INVALID;
+    if ((joint_origins == nullptr) != (joint_axes == nullptr)) return OMGX_ERR_INVALID;
+    if (n_points < 1 || n_points > OMGX_MAX_POINTS) return OMGX_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(k_forward_kinematics, dim3((unsigned)((num_configs + 63) / 64)), dim3(64), 0, (hipStream_t)stream,
+                       robot, n_points, joints, num_configs, link_poses, joint_origins, joint_axes);
+    OMGX_CHECK_LAUNCH("k_forward_kinematics");
+    return OMGX_OK;
 }
 
 extern "C" int omgx_goalset_cost(const double* robot, int32_t n_points, const omgx_object* objects,

@@ -71,8 +71,9 @@ def robot_blob(model, device="cuda:0") -> torch.Tensor:
 
 
 def fk_sdf(robot: torch.Tensor, P: int, scenes: DeviceScenes, joints: torch.Tensor, soften_fingers=False,
-           want_grad=True, want_col=True, out=None):
-    """joints [S,C,9] f64 -> potentials [S,C,10,P], grads [S,C,10,P,3] | None, collides [S,C,10,P] | None."""
+           want_grad=True, want_col=True, out=None, arc_length=0, arc_start=None, dt=0.1):
+    """joints [S,C,9] f64 -> potentials [S,C,10,P], grads [S,C,10,P,3] | None, collides [S,C,10,P] | None.
+    arc_length > 0: groups of arc_length waypoints, potentials weighted by the float32 point speed."""
     _need(joints, torch.float64, "joints")
     S, Cn = joints.shape[0], joints.shape[1]
     dev = joints.device
@@ -85,9 +86,11 @@ def fk_sdf(robot: torch.Tensor, P: int, scenes: DeviceScenes, joints: torch.Tens
     l = _lib.lib()
     with torch.cuda.device(dev):
         ws = _workspace(l.omgx_fk_sdf_workspace_bytes(S, Cn, P), dev)
+        if arc_length > 0:
+            _need(arc_start, torch.float64, "arc_start")
         check(l.omgx_fk_sdf(_ptr(robot), P, _ptr(scenes.objects), _ptr(scenes.scene_begin), _ptr(scenes.pool),
-                            _ptr(joints), S, Cn, int(bool(soften_fingers)), _ptr(pot), _ptr(grad), _ptr(col), _ptr(ws),
-                            _stream()), "omgx_fk_sdf")
+                            _ptr(joints), S, Cn, int(bool(soften_fingers)), int(arc_length), _ptr(arc_start), float(dt),
+                            _ptr(pot), _ptr(grad), _ptr(col), _ptr(ws), _stream()), "omgx_fk_sdf")
     return pot, grad, col
 
 
@@ -113,8 +116,23 @@ def goalset_cost(robot, P, scenes: DeviceScenes, traj_start, goals, n_remaining,
     return cost, col, pots
 
 
-def chomp_optimize(robot, params: ChompParams, traj, start, end, goal, goal_point, pot, pgrad, col, active=None, out=None):
-    """In-place step on traj [S,n,9] f64 -> grad [S,n,9], cost_traj [S,n], info [S,16] (f64)."""
+def forward_kinematics(robot, P, joints, want_joint_info=True):
+    """joints [B,9] f64 -> link poses [B,10,4,4], joint origins [B,10,3] | None, joint axes [B,10,3] | None."""
+    _need(joints, torch.float64, "joints")
+    B, dev = joints.shape[0], joints.device
+    poses = torch.empty((B, 10, 4, 4), dtype=torch.float64, device=dev)
+    org = torch.empty((B, 10, 3), dtype=torch.float64, device=dev) if want_joint_info else None
+    ax = torch.empty((B, 10, 3), dtype=torch.float64, device=dev) if want_joint_info else None
+    with torch.cuda.device(dev):
+        check(_lib.lib().omgx_forward_kinematics(_ptr(robot), P, _ptr(joints), B, _ptr(poses), _ptr(org), _ptr(ax), _stream()),
+              "omgx_forward_kinematics")
+    return poses, org, ax
+
+
+def chomp_optimize(robot, params: ChompParams, traj, start, end, goal, goal_point, pot, pgrad, col, active=None, out=None,
+                   aux=None):
+    """In-place step on traj [S,n,9] f64 -> grad [S,n,9], cost_traj [S,n], info [S,16] (f64).
+    aux: optional [S, omgx_chomp_aux_doubles(n)] f64 receiving obs_grad | obs_cost | smooth_grad | smooth_loss."""
     for n_, t in (("traj", traj), ("start", start), ("end", end), ("goal", goal), ("goal_point", goal_point)):
         _need(t, torch.float64, n_)
     for n_, t in (("potentials", pot), ("grads", pgrad), ("collides", col)):
@@ -130,5 +148,5 @@ def chomp_optimize(robot, params: ChompParams, traj, start, end, goal, goal_poin
     with torch.cuda.device(dev):
         check(_lib.lib().omgx_chomp_optimize(_ptr(robot), C.byref(params), _ptr(traj), _ptr(start), _ptr(end), _ptr(goal),
                                              _ptr(goal_point), _ptr(pot), _ptr(pgrad), _ptr(col), _ptr(active), S,
-                                             _ptr(grad), _ptr(cost_traj), _ptr(info), _stream()), "omgx_chomp_optimize")
+                                             _ptr(grad), _ptr(cost_traj), _ptr(info), _ptr(aux), _stream()), "omgx_chomp_optimize")
     return grad, cost_traj, info

@@ -1,0 +1,143 @@
+"""`Optimizer` — host-side mirror of the reference's CHOMP optimiser class (omg/optimizer.py:9-174).
+
+``optimize(traj, force_update=False, info_only=False)`` is ONE device launch pair
+(omgx_fk_sdf + omgx_chomp_optimize): schedules -> total loss -> joint-limit check -> projected
+A^-1 step -> Trajectory.update -> smooth joint-limit projection, all inside k_chomp_optimize; the
+trajectory comes back once.  ``goal_set_projection`` / ``handle_joint_limit`` / ``compute_traj_v`` /
+``check_joint_limit`` are kept as small numpy utilities with the reference's signatures for callers that
+use them on their own; ``optimize`` does not go through them.
+"""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+
+
+class Optimizer(object):
+    def __init__(self, scene, cost):
+        self.cfg = scene.config
+        self.joint_lower_limit = scene.robot.joint_lower_limit
+        self.joint_upper_limit = scene.robot.joint_upper_limit
+        self.cost = cost
+        self.step = 0
+        self.time = 0.0
+        self.time_elapsed = time.time()
+
+    def report(self, curve, info):
+        """Debug text (omg/optimizer.py:23-57)."""
+        text = []
+        if self.cfg.report_cost:
+            text = [
+                "=================================================",
+                "step: {:.2f}, time: {:.2f}, lr: {:.5f}, collide: {}".format(self.step, self.time_elapsed, self.cfg.step_size, info["collide"]),
+                "joint limit: {:.2f}/{:.2f}, {:.2f}/{:.2f}, violate: {} reach: {:.2f} timestep {}".format(
+                    curve.min(), np.min(self.joint_lower_limit), curve.max(), np.max(self.joint_upper_limit),
+                    info["violate_limit"], info["reach"], self.cfg.timesteps),
+                "obs:{:.2f}, smooth:{:.2f}, grasp:{:.2f} total:{:.2f} ".format(info["obs"], info["smooth"], info["grasp"], info["cost"]),
+                "obs_grad:{:.2f}, smooth_grad:{:.2f}, grasp_grad:{:.2f} total_grad:{:.2f}".format(
+                    info["weighted_obs_grad"], info["weighted_smooth_grad"], info["weighted_grasp_grad"], info["grad"]),
+                "=================================================",
+            ]
+            for t in text:
+                print(t)
+        return text
+
+    def update(self):
+        """Weight / step-size schedules, written into cfg like the reference (omg/optimizer.py:59-80)."""
+        self.step += 1
+        self.time_elapsed = time.time() - self.time
+        self.time = time.time()
+        cfg = self.cfg
+        cfg.obstacle_weight = cfg.base_obstacle_weight * cfg.cost_schedule_decay ** self.step
+        cfg.smoothness_weight = cfg.smoothness_base_weight * cfg.cost_schedule_boost ** self.step
+        cfg.grasp_weight = cfg.base_grasp_weight * cfg.cost_schedule_decay ** self.step
+        cfg.step_size = cfg.step_decay_rate ** self.step * cfg.base_step_size
+
+    def reset(self):
+        self.step = 0
+
+    def optimize(self, traj, force_update=False, info_only=False):
+        """One CHOMP step (omg/optimizer.py:115-135); returns the reference's info dict."""
+        self.update()
+        cost, cfg = self.cost, self.cfg
+        model, robot = cost._robot_model()
+        P = model.points_per_link
+        n = traj.data.shape[0]
+        data = cost._t(np.asarray(traj.data, np.float64)[None])
+        pot, pgrad, col = ops.fk_sdf(robot, P, cost._scenes(), data, soften_fingers=cfg.uncheck_finger_collision == -1)
+        prm = cost._params(n, 0 if info_only else (1 if force_update else 2))
+        if cfg.goal_set_proj:
+            if cfg.use_standoff:
+                chosen = np.asarray(cost.target_obj.reach_grasps[int(traj.goal_idx)], np.float64)
+            else:
+                chosen = np.asarray(traj.goal_set[int(traj.goal_idx)], np.float64)[None]
+            goal_point = np.asarray(traj.goal_set[int(traj.goal_idx)], np.float64)
+        else:
+            chosen = np.tile(np.asarray(traj.end, np.float64), (prm.constraint_num, 1))
+            goal_point = np.asarray(traj.end, np.float64)
+        if chosen.shape[0] != prm.constraint_num:
+            raise _lib.OmgHipError(f"chosen goal has {chosen.shape[0]} rows, cfg implies {prm.constraint_num}")
+        grad, cost_traj, info_t = ops.chomp_optimize(robot, prm, data, cost._t(np.asarray(traj.start)[None]),
+                                                     cost._t(np.asarray(traj.end)[None]), cost._t(chosen[None]),
+                                                     cost._t(goal_point[None]), pot, pgrad, col)
+        i = info_t[0].cpu().numpy()
+        vis_pts = np.zeros([n, 11, P, 12])
+        vis_pts[:, :10, :, 6] = pot[0].cpu().numpy()
+        vis_pts[:, :10, :, 9:] = pgrad[0].cpu().numpy()
+        info = {
+            "collision_pts": vis_pts, "obs": i[1], "smooth": i[2], "grasp": 0, "weighted_obs": i[3], "weighted_smooth": i[4],
+            "weighted_smooth_grad": i[6], "weighted_obs_grad": i[5], "weighted_grasp_grad": 0, "weighted_grasp": 0,
+            "gradient": grad[0].cpu().numpy(), "failure_terminate": bool(i[11]), "cost": i[0], "grad": i[7],
+            "terminate": bool(i[10]), "collide": np.float32(i[8]), "standoff_idx": int(i[13]), "reach": i[9],
+            "execute": bool(i[12]), "cost_traj": cost_traj[0].cpu().numpy(), "violate_limit": bool(i[14]),
+        }
+        info["text"] = self.report(np.asarray(traj.data), info)
+        if (info["terminate"] and not force_update) or info_only:
+            return info
+        traj.set(data[0].cpu().numpy())  # update + handle_joint_limit already applied on the device
+        return info
+
+    # ---- numpy utilities with the reference's signatures (not used by optimize) -----------------------
+    def goal_set_projection(self, traj, grad):
+        """Projected update (omg/optimizer.py:88-113) with the closed-form projector of csrc/omg_chomp.hip."""
+        cfg = self.cfg
+        if cfg.use_standoff:
+            chosen = np.asarray(self.cost.target_obj.reach_grasps[int(traj.goal_idx)])
+        else:
+            chosen = np.asarray(traj.goal_set[int(traj.goal_idx)])[None]
+        c, n = chosen.shape[0], traj.data.shape[0]
+        Ag = cfg.Ainv.dot(grad)
+        b = traj.data[-c:] - chosen
+        M = np.zeros((n, c))
+        M[: n - c, 0] = (np.arange(n - c) + 1.0) / (n - c + 1.0)
+        M[n - c:, :] = np.eye(c)
+        return -cfg.step_size * Ag + cfg.step_size * M.dot(Ag[-c:]) - M.dot(b)
+
+    def compute_traj_v(self, curve):
+        low = curve < self.joint_lower_limit
+        high = curve > self.joint_upper_limit
+        return low * (self.joint_lower_limit - curve) + high * (self.joint_upper_limit - curve)
+
+    def handle_joint_limit(self, curve):
+        """Smooth joint-limit projection (omg/optimizer.py:148-164)."""
+        cnt = 0
+        v = self.compute_traj_v(curve)
+        while np.linalg.norm(v) > 1e-2 and cnt < self.cfg.joint_limit_max_steps:
+            vs = self.cfg.Ainv.dot(v)
+            k = np.unravel_index(np.abs(v).argmax(), v.shape)
+            curve = curve + np.abs(v).max() / (np.abs(vs[k]) + 1e-8) * vs
+            v = self.compute_traj_v(curve)
+            cnt += 1
+        return curve
+
+    def check_joint_limit(self, curve, info):
+        """Needs BOTH a low and a high violation, like the reference (omg/optimizer.py:166-174)."""
+        low = (curve < self.joint_lower_limit - 5e-3).any()
+        high = curve > self.joint_upper_limit + 5e-3
+        over = bool((low * high).any())
+        info["violate_limit"] = over
+        info["terminate"] = info["terminate"] and (not over)

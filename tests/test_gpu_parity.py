@@ -296,3 +296,139 @@ def test_chomp_optimize_batched_matches_oracle(dev):
         np.testing.assert_allclose(g.cpu().numpy()[act], g_ref[act], rtol=1e-6, atol=1e-6)
         np.testing.assert_allclose(info.cpu().numpy()[act], info_ref[act], rtol=1e-6, atol=1e-6)
     np.testing.assert_array_equal(t_dev[3].cpu().numpy(), traj0[3])  # inactive trajectory untouched
+
+
+# ------------------------------------------------------------------------------------------------
+# (5) the reference's class surface: Cost / Optimizer / omg_cuda
+# ------------------------------------------------------------------------------------------------
+class _Traj:
+    """The attributes of omg.core.Trajectory the path reads (core.py:23-57)."""
+
+    def __init__(self, data, start, end, goal_set, goal_idx=0):
+        self.data, self.start, self.end = np.array(data), np.array(start), np.array(end)
+        self.goal_set, self.goal_idx = goal_set, goal_idx
+
+    def set(self, new):
+        self.data = new
+
+
+def _env_from(fx, dev, cfg):
+    import types
+    m = H.model_from(fx)
+    robot = types.SimpleNamespace(collision_points=m.collision_points, joint_lower_limit=m.joint_lower_limit,
+                                  joint_upper_limit=m.joint_upper_limit)
+    objs = [types.SimpleNamespace(name=str(n), pose_mat=fx["obj_pose"][i], attached=bool(fx["attached"][i]), reach_grasps=[])
+            for i, n in enumerate(fx["obj_names"])]
+    return types.SimpleNamespace(robot=robot, objects=objs, target_idx=int(fx["target_idx"]), config=cfg,
+                                 sdf_torch=_t(fx["sdf"], dev), sdf_limits=_t(fx["limits"], dev))
+
+
+def _cfg_from(fx, n):
+    from omg_planner_amd.config import Config
+    cfg = Config(timesteps=n, top_k_collision=int(fx["cfg_top_k"]), goal_set_proj=bool(fx["cfg_goal_set_proj"]),
+                 use_standoff=bool(fx["cfg_use_standoff"]), consider_finger=bool(fx.get("cfg_consider_finger", 0)),
+                 uncheck_finger_collision=int(fx.get("cfg_uncheck", 0)))
+    cfg.time_interval = float(fx["cfg_dt"])
+    cfg._mats = None
+    return cfg
+
+
+@pytest.mark.parametrize("case", ["topk1000", "clean", "fixed_end", "finger_n50"])
+def test_cost_class_matches_reference_fixture(dev, case):
+    from omg_planner_amd.cost import Cost
+    fx = H.load(f"cost_{case}.npz")
+    n = fx["xi"].shape[0]
+    cfg = _cfg_from(fx, n)
+    cfg.obstacle_weight, cfg.smoothness_weight = float(fx["cfg_obstacle_weight"]), float(fx["cfg_smoothness_weight"])
+    cost = Cost(_env_from(fx, dev, cfg))
+    traj = _Traj(fx["xi"], fx["start"], fx["end"], fx["goal_point"][None])
+    total, grad, info = cost.compute_total_loss(traj)
+    np.testing.assert_allclose(total, fx["total_cost"], rtol=1e-6)        # north_star bar: 1e-4
+    np.testing.assert_allclose(grad, fx["total_grad"], rtol=1e-5, atol=1e-5)
+    for key in ["obs", "smooth", "weighted_obs", "weighted_smooth", "collide", "reach", "standoff_idx", "terminate", "execute"]:
+        np.testing.assert_allclose(float(info[key]), float(fx["info_" + key]), rtol=1e-6, atol=1e-6, err_msg=key)
+    obs_cost, obs_grad, _, col = cost.compute_collision_loss(fx["xi"], fx["start"], fx["end"])
+    np.testing.assert_allclose(obs_cost, fx["obs_cost"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(obs_grad, fx["obs_grad"], rtol=1e-5, atol=1e-5)
+    sm_loss, sm_grad = cost.compute_smooth_loss(fx["xi"], fx["start"], fx["end"])
+    np.testing.assert_allclose(sm_loss, fx["smooth_loss"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(sm_grad, fx["smooth_grad"], rtol=1e-9, atol=1e-7)
+
+
+def test_cost_forward_poses_matches_reference_fk(dev):
+    from omg_planner_amd.config import Config
+    from omg_planner_amd.cost import Cost
+    fk = H.load("fk.npz")
+    fx = H.load("cost_topk1000.npz")
+    cost = Cost(_env_from(fx, dev, Config()))
+    for b in range(4):
+        q = fk["joints"][b]
+        deg = np.rad2deg(np.concatenate([q[:7], [0.0], q[7:]]))  # wrap_value
+        poses, org, ax = cost.forward_poses(deg)
+        np.testing.assert_allclose(poses, fk["poses"][b], atol=1e-12)
+        np.testing.assert_allclose(org, fk["joint_origins"][b], atol=1e-12)
+        np.testing.assert_allclose(ax, fk["joint_axis"][b], atol=1e-12)
+
+
+@pytest.mark.parametrize("case", ["arc_g6_n30", "arc_g5_n7", "noarc_soft_g8"])
+def test_cost_batch_obstacle_cost_matches_reference_fixture(dev, case):
+    from omg_planner_amd.config import Config
+    from omg_planner_amd.cost import Cost
+    fx = H.load(f"batch_{case}.npz")
+    cfg = Config(timesteps=30)
+    cost = Cost(_env_from(fx, dev, cfg))
+    arc = int(fx["n_remaining"]) if int(fx["arc_length"]) else -1
+    pot, grad, vis, col = cost.batch_obstacle_cost(fx["joints"], arc_length=arc, special_check_id=0,
+                                                   uncheck_finger_collision=int(fx["uncheck"]), start=fx["traj_start"], end=fx["goals"])
+    np.testing.assert_allclose(pot.cpu().numpy(), fx["potentials"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(grad.cpu().numpy(), fx["grads"], rtol=0, atol=2e-4)
+    np.testing.assert_array_equal(col.cpu().numpy(), fx["collides"])
+    assert vis.shape == (fx["joints"].shape[0], 10, 15, 12)
+
+
+@pytest.mark.parametrize("case", ["standoff_20", "fixed_end_5", "limits_5"])
+def test_optimizer_class_matches_reference_fixture(dev, case):
+    """Optimizer.optimize through the class surface, free-running from the reference's start: 1e-6 (bar 1e-4)."""
+    from omg_planner_amd.cost import Cost
+    from omg_planner_amd.optimizer import Optimizer
+    import types
+    fx = H.load(f"opt_{case}.npz")
+    hist = fx["traj_history"]
+    steps, n = hist.shape[0] - 1, hist.shape[1]
+    fx2 = dict(fx)
+    fx2.setdefault("cfg_consider_finger", 0)
+    cfg = _cfg_from(fx2, n)
+    env = _env_from(fx, dev, cfg)
+    env.objects[env.target_idx].reach_grasps = fx["reach_grasps"]
+    cost = Cost(env)
+    opt = Optimizer(types.SimpleNamespace(config=cfg, robot=env.robot), cost)
+    traj = _Traj(hist[0], fx["start"], fx["end"], fx["goal_set"], int(fx["goal_idx"]))
+    for k in range(steps):
+        info = opt.optimize(traj, force_update=True)
+        np.testing.assert_allclose(traj.data, hist[k + 1], rtol=0, atol=1e-6, err_msg=f"step {k}")
+        np.testing.assert_allclose(info["cost"], fx["info_cost"][k], rtol=1e-5, err_msg=f"step {k}")
+        assert bool(info["violate_limit"]) == bool(fx["info_violate_limit"][k])
+    final = opt.optimize(traj, info_only=True)
+    np.testing.assert_allclose(final["cost"], fx["info_cost"][steps], rtol=1e-5)
+    np.testing.assert_allclose(np.array(fx["schedule"][steps]), [cfg.obstacle_weight, cfg.smoothness_weight, cfg.step_size])
+
+
+def test_omg_cuda_module_is_a_drop_in(dev):
+    """`import omg_cuda; omg_cuda.sdf_loss_forward(...)` as layers/sdf_matching_loss.py:21-30 calls it."""
+    import importlib
+    import sys
+    from pathlib import Path
+    from oracle import oracle as orc
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "omg-planner_amd"))
+    try:
+        omg_cuda = importlib.import_module("omg_cuda")
+    finally:
+        sys.path.pop(0)
+    fx = H.load("cost_topk300.npz")
+    poses, sdf, lim, eps, pad, clr, dis = _padded_inputs(fx)
+    pts = np.random.RandomState(5).uniform([-0.2, -0.6, 0.0], [1.0, 0.6, 1.0], size=(5000, 3)).astype(np.float32)
+    out = omg_cuda.sdf_loss_forward(*[_t(a, dev) for a in (poses, sdf, lim, pts, eps, pad, clr, dis)])
+    ref = orc.sdf_loss_forward(poses, sdf, lim, pts, eps, pad, clr, dis)
+    assert len(out) == 3
+    for r, g in zip(ref, out):
+        np.testing.assert_array_equal(g.cpu().numpy(), r)
