@@ -55,7 +55,8 @@ extern "C" {
  *   D+246  PTS [10][P][3]    center_offset[l] applied to collision_points[l][p]
  *   D+246+30P AX [10][3]     tip2joint[l][:3,:3] . joint_axis[l]
  *   D+276+30P OG [10][3]     tip2joint[l][:3,3]
- * Total length 528 + 60P + 306 doubles.
+ *   D+306+30P RAD [10]       max_p |PTS[l][p]|: bounding-sphere radius of a link's points about its frame origin
+ * Total length 528 + 60P + 316 doubles.
  * ------------------------------------------------------------------------------------------- */
 #define OMGX_ROBOT_POSE0 0
 #define OMGX_ROBOT_TIP2JOINT 160
@@ -66,7 +67,7 @@ extern "C" {
 #define OMGX_ROBOT_POINTS 528
 
 /* ---------------------------------------------------------------------------------------------
- * Scene object table.  One 160-byte record per obstacle/target object; replaces the five per-call
+ * Scene object table.  One 176-byte record per obstacle/target object; replaces the five per-call
  * host->device copies of Cost.compute_obstacle_cost_layer (omg/cost.py:303-335) and the
  * pad-to-max `sdf_torch[O,X,Y,Z]` + `sdf_limits[O,10]` contract of Env.combine_sdfs
  * (omg/core.py:366-411).  `grid_offset` lets grids live ragged in one float pool; the reference's
@@ -86,7 +87,10 @@ typedef struct omgx_object {
     double inv_extent[3]; /* derived: 1.0 / (double)((float)hi[a] - (float)lo[a])                     */
     float far_lo[3];     /* derived: -1.5 voxels   } a point whose offset t = R p + t - lo lies outside  */
     float far_hi[3];     /* derived: extent + 1.5 voxels } [far_lo, far_hi] is out of range for sure     */
-} omgx_object; /* sizeof == 160; derived fields: scenes.finish_records() is the reference derivation */
+    double inv_delta;    /* derived: 1.0 / (double)delta                                              */
+    float inv_2eps;      /* derived: 1.0f / (2.0f * epsilon)   (float32 arithmetic, .cu:167)           */
+    float inv_eps;       /* derived: 1.0f / epsilon            (float32 arithmetic, .cu:168)           */
+} omgx_object; /* sizeof == 176; derived fields: scenes.finish_records() is the reference derivation */
 
 /* ---------------------------------------------------------------------------------------------
  * CHOMP parameters for one optimiser step (a frozen snapshot of the reference's global mutable

@@ -86,6 +86,8 @@ struct ObjParams {  // wave-uniform (SGPR-resident) per-object parameters
     float delta, eps, pad, clr;
     double rw[3];   // 1 / (double)(float)(hi - lo): t / w == (float)((double)t * rw) exactly (see pair_exact)
     float flo[3], fhi[3];  // far box in offset-from-lo coordinates (1.5 voxels of slack)
+    double rdelta;         // 1 / (double)delta
+    float i2eps, ieps;     // 1.0f / (2.0f * eps), 1.0f / eps in float32
 };
 
 // far box of an object from its limits (used where the record does not carry it: the raw-tensor API)
@@ -98,6 +100,9 @@ __device__ __forceinline__ void derive_far_box(ObjParams& o) {
         o.flo[k] = ok ? -1.5f * vox : -__builtin_inff();
         o.fhi[k] = ok ? w + 1.5f * vox : __builtin_inff();
     }
+    o.rdelta = 1.0 / (double)o.delta;
+    o.i2eps = 1.0f / (2.0f * o.eps);
+    o.ieps = 1.0f / o.eps;
 }
 
 struct Accum { float pot, gx, gy, gz, col; };
@@ -165,7 +170,7 @@ __device__ __forceinline__ void pair_exact(const ObjParams& o, const float* __re
         acc.col += (in_c && value < o.clr) ? 1.0f : 0.0f;                       // .cu:150-151
         const float p_in = (float)(-(double)value + 0.5 * (double)o.eps);        // .cu:158-160
         const float d = value - o.eps;
-        const float p_band = 1.0f / (2.0f * o.eps) * d * d * o.pad;             // .cu:165-167
+        const float p_band = o.i2eps * d * d * o.pad;                           // .cu:165-167
         acc.pot += value <= 0.0f ? p_in : (value <= o.eps ? p_band : 0.0f);
         return;
     }
@@ -223,17 +228,19 @@ __device__ __forceinline__ void pair_exact(const ObjParams& o, const float* __re
         fmy = sdf_value(G, ax, aym, az);
         fmz = sdf_value(G, ax, ay, azm);
     }
-    const float g0 = (float)(0.5 * (double)(fpx - fmx) / (double)o.delta);  // .cu:82-84
-    const float g1 = (float)(0.5 * (double)(fpy - fmy) / (double)o.delta);
-    const float g2 = (float)(0.5 * (double)(fpz - fmz) / (double)o.delta);
+    // .cu:82-84: 0.5 * (f_p - f_m) / delta in double, narrowed.  x / delta == (float)(x * fl64(1/delta)) after the
+    // narrowing for the same reason as in the grid-coordinate quotient (x and delta are 24-bit values).
+    const float g0 = (float)(0.5 * (double)(fpx - fmx) * o.rdelta);
+    const float g1 = (float)(0.5 * (double)(fpy - fmy) * o.rdelta);
+    const float g2 = (float)(0.5 * (double)(fpz - fmz) * o.rdelta);
     float v0, v1, v2;
     if (value <= 0.0f) {  // .cu:158-164
         acc.pot += (float)(-(double)value + 0.5 * (double)o.eps);
         v0 = -g0; v1 = -g1; v2 = -g2;
     } else {  // 0 < value <= eps (.cu:165-171)
         const float d = value - o.eps;
-        acc.pot += 1.0f / (2.0f * o.eps) * d * d * o.pad;
-        const float ie = 1.0f / o.eps;
+        acc.pot += o.i2eps * d * d * o.pad;
+        const float ie = o.ieps;
         v0 = ie * g0 * d * o.pad; v1 = ie * g1 * d * o.pad; v2 = ie * g2 * d * o.pad;
     }
     // rotationMatrix.transpose() * vgrad (.cu:176-179)
@@ -268,6 +275,7 @@ __device__ __forceinline__ ObjParams load_object(ObjTablePtr ob) {
     o.delta = ob->delta; o.eps = ob->epsilon; o.pad = ob->padding_scale; o.clr = ob->clearance;
 #pragma unroll
     for (int k = 0; k < 3; ++k) { o.rw[k] = ob->inv_extent[k]; o.flo[k] = ob->far_lo[k]; o.fhi[k] = ob->far_hi[k]; }
+    o.rdelta = ob->inv_delta; o.i2eps = ob->inv_2eps; o.ieps = ob->inv_eps;
     return o;
 }
 
@@ -299,6 +307,7 @@ __device__ __forceinline__ Accum sdf_point(const omgx_object* __restrict__ objs,
 //   D+246  PTS  [10][P][3]  center_offset[l] applied to collision_points[l][p]  (:203-204 folded into cost.py:60-72)
 //   D+246+30P AX [10][3]    tip2joint[l][:3,:3] . joint_axis[l]                  (:190-197)
 //   D+276+30P OG [10][3]    tip2joint[l][:3,3]
+//   D+306+30P RAD [10]      bounding-sphere radius of each link's centred points
 struct RobotView {
     const double* __restrict__ raw;
     const double* __restrict__ d;
@@ -312,6 +321,7 @@ struct RobotView {
     __device__ __forceinline__ const double* pts(int l, int p) const { return d + 246 + 3 * (l * P + p); }
     __device__ __forceinline__ const double* ax(int l) const { return d + 246 + 30 * P + 3 * l; }
     __device__ __forceinline__ const double* og(int l) const { return d + 276 + 30 * P + 3 * l; }
+    __device__ __forceinline__ double radius(int l) const { return d[306 + 30 * P + l]; }
     __device__ __forceinline__ const double* lower() const { return raw + OMGX_ROBOT_LOWER; }
     __device__ __forceinline__ const double* upper() const { return raw + OMGX_ROBOT_UPPER; }
 };

@@ -184,6 +184,7 @@ struct ChunkArgs {
     const double* ws;        // [S][NCH][10][CH][12] link poses
     const double* ws_start;  // [S][10][12] or null
     int S, C, CH, NCH, P;
+    int LPW;                // links per workgroup (10, or fewer to expose more workgroups for small batches)
     int soften;             // uncheck_finger_collision == -1 (cost.py:350-353)
     int arc;                // weight potentials by ||(x_i - x_{i-1}) / dt|| (cost.py:235-275)
     float inv_dt;
@@ -205,12 +206,17 @@ struct ChunkArgs {
 template <bool WANT_GRAD, int LB>
 __global__ __launch_bounds__(256) void k_sdf_chunks(ChunkArgs a) {
     __shared__ float red[2][4];
+    __shared__ uint32_t rowmask[10 * OMGX_MAX_WAYPOINTS];  // candidate objects of each row (link, config)
     // XCD-aware placement: workgroup b runs on XCD b % 8 (observed; used for L2 affinity only).
     // All chunks of a scene go to the same XCD so the scene's SDF volumes stay in one 4 MiB L2.
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    const int sgrp = j / a.NCH;  // wave-uniform (one division per workgroup)
+    const int xcd = blockIdx.x & 7;
+    const int nlg = 10 / a.LPW;                 // link groups per chunk
+    const int jj = blockIdx.x >> 3;
+    const int j = jj / nlg, lg = jj - j * nlg;  // wave-uniform divisions, once per workgroup
+    const int sgrp = j / a.NCH;
     const int s = sgrp * 8 + xcd, chunk = j - sgrp * a.NCH;
     if (s >= a.S) return;
+    const int l_begin = lg * a.LPW, l_end = l_begin + a.LPW;
     const int o_begin = as_const(a.scene_begin)[s], o_end = as_const(a.scene_begin)[s + 1];
     const int P = a.P, CH = a.CH;
     const int nvalid = min(CH, a.C - chunk * CH);  // configs in this (possibly last, partial) chunk
@@ -218,30 +224,77 @@ __global__ __launch_bounds__(256) void k_sdf_chunks(ChunkArgs a) {
     const RobotView rv(a.robot, P);
     const double* base = a.ws + ((int64_t)s * a.NCH + chunk) * (int64_t)(10 * CH) * 12;
     const double* sbase = a.arc ? a.ws_start + (int64_t)s * 120 : nullptr;
+
+    // ---- phase A: row-level culling.  All P points of a row lie in the ball (link origin, RAD[l]); an object
+    // whose far box (grown by that radius + 1e-4 m for float rounding) misses the ball centre on any axis
+    // cannot be in range for any of them.  One lane per row; objects >= 31 share the last mask bit.
+    for (int row = l_begin * CH + threadIdx.x; row < l_end * CH; row += 256) {
+        const int l = row / CH, ci = row - l * CH;
+        uint32_t m = 0;
+        if (ci < nvalid) {
+            const double* A = base + (int64_t)row * 12;
+            const float cx = (float)A[9], cy = (float)A[10], cz = (float)A[11];
+            const float rad = (float)rv.radius(l) + 1.0e-4f;
+            for (int o = o_begin; o < o_end; ++o) {
+                ObjTablePtr ob = as_const(a.objects) + o;
+                if (ob->disabled > 0) continue;
+                const int oo = o - o_begin;
+                const uint32_t bit = 1u << (oo < 31 ? oo : 31);
+                const float ux = __builtin_fmaf(ob->pose_inv[2], cz, __builtin_fmaf(ob->pose_inv[1], cy, __builtin_fmaf(ob->pose_inv[0], cx, ob->pose_inv[3]))) - ob->lo[0];
+                const float uy = __builtin_fmaf(ob->pose_inv[6], cz, __builtin_fmaf(ob->pose_inv[5], cy, __builtin_fmaf(ob->pose_inv[4], cx, ob->pose_inv[7]))) - ob->lo[1];
+                const float uz = __builtin_fmaf(ob->pose_inv[10], cz, __builtin_fmaf(ob->pose_inv[9], cy, __builtin_fmaf(ob->pose_inv[8], cx, ob->pose_inv[11]))) - ob->lo[2];
+                const bool near = (ux >= ob->far_lo[0] - rad) & (ux <= ob->far_hi[0] + rad) & (uy >= ob->far_lo[1] - rad) &
+                                  (uy <= ob->far_hi[1] + rad) & (uz >= ob->far_lo[2] - rad) & (uz <= ob->far_hi[2] + rad);
+                const bool cullable = ob->epsilon < 1.0f && ob->clearance <= 1.0f;  // else out-of-range values matter
+                if (near || !cullable) m |= bit;
+            }
+        }
+        rowmask[row] = m;
+    }
+    __syncthreads();
+
+    // ---- phase B: points
     float tsum = 0.0f, tcol = 0.0f;
     if (p < P) {
         for (int ci = r; ci < nvalid; ci += 16) {
             const int64_t out_cfg = ((int64_t)s * a.C + chunk * CH + ci) * 10;
 #pragma unroll 1
-            for (int l0 = 0; l0 < 10; l0 += LB) {
+            for (int l0 = l_begin; l0 < l_end; l0 += LB) {
                 float px[LB], py[LB], pz[LB];
+                uint32_t msk[LB];
+                uint32_t many = 0;
                 Accum acc[LB];
 #pragma unroll
                 for (int k = 0; k < LB; ++k) {
-                    pose12_apply(base + ((int64_t)(l0 + k) * CH + ci) * 12, rv.pts(l0 + k, p), px[k], py[k], pz[k]);
+                    msk[k] = rowmask[(l0 + k) * CH + ci];
+                    many |= msk[k];
                     acc[k] = Accum{0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
                 }
-                for (int o = o_begin; o < o_end; ++o) {  // wave-uniform trip count and addresses
-                    ObjTablePtr ob = as_const(a.objects) + o;
-                    if (ob->disabled > 0) continue;  // .cu:115-116
-                    const ObjParams op = load_object(ob);
-                    const float* grid = a.pool + ob->grid_offset;
-                    PairPrep pp[LB];
-#pragma unroll
-                    for (int k = 0; k < LB; ++k) pp[k] = pair_prepare(op, px[k], py[k], pz[k]);
+                const bool work = __any(many != 0);
+                if (work) {
 #pragma unroll
                     for (int k = 0; k < LB; ++k)
-                        if (!pp[k].far) pair_exact<WANT_GRAD>(op, grid, pp[k].tx, pp[k].ty, pp[k].tz, acc[k]);
+                        pose12_apply(base + ((int64_t)(l0 + k) * CH + ci) * 12, rv.pts(l0 + k, p), px[k], py[k], pz[k]);
+                }
+                if (work) {
+                    for (int o = o_begin; o < o_end; ++o) {  // wave-uniform trip count and addresses
+                        const int oo = o - o_begin;
+                        const uint32_t bit = 1u << (oo < 31 ? oo : 31);
+                        if (!__any((many & bit) != 0)) continue;  // no row of this wave can reach the object
+                        ObjTablePtr ob = as_const(a.objects) + o;
+                        if (ob->disabled > 0) continue;  // .cu:115-116
+                        const ObjParams op = load_object(ob);
+                        const float* grid = a.pool + ob->grid_offset;
+                        PairPrep pp[LB];
+#pragma unroll
+                        for (int k = 0; k < LB; ++k) {
+                            pp[k] = pair_prepare(op, px[k], py[k], pz[k]);
+                            pp[k].far = pp[k].far || !(msk[k] & bit);
+                        }
+#pragma unroll
+                        for (int k = 0; k < LB; ++k)
+                            if (!pp[k].far) pair_exact<WANT_GRAD>(op, grid, pp[k].tx, pp[k].ty, pp[k].tz, acc[k]);
+                    }
                 }
 #pragma unroll
                 for (int k = 0; k < LB; ++k) {
@@ -249,7 +302,7 @@ __global__ __launch_bounds__(256) void k_sdf_chunks(ChunkArgs a) {
                     if (a.soften && l >= 8) {  // cost.py:350-353
                         acc[k].pot *= 0.1f; acc[k].gx *= 0.1f; acc[k].gy *= 0.1f; acc[k].gz *= 0.1f; acc[k].col = 0.0f;
                     }
-                    if (a.arc) {  // ||(x_i - x_{i-1}) / dt|| in float32 (config.py:162-187, cost.py:260-275)
+                    if (a.arc && acc[k].pot != 0.0f) {  // ||(x_i - x_{i-1}) / dt|| in float32 (config.py:162-187, cost.py:260-275)
                         float qx, qy, qz;
                         pose12_apply(ci > 0 ? base + ((int64_t)l * CH + ci - 1) * 12 : sbase + l * 12, rv.pts(l, p), qx, qy, qz);
                         const float vx = (px[k] - qx) * a.inv_dt, vy = (py[k] - qy) * a.inv_dt, vz = (pz[k] - qz) * a.inv_dt;
@@ -378,21 +431,32 @@ extern "C" int64_t omgx_goalset_workspace_bytes(int32_t num_scenes, int32_t num_
     return poses + start;
 }
 
-static int launch_chunks(const ChunkArgs& ca, hipStream_t st) {
+static int launch_chunks(ChunkArgs& ca, hipStream_t st) {
     const int scene_groups = (ca.S + 7) / 8;
-    const int64_t grid = (int64_t)scene_groups * ca.NCH * 8;
+    // Small batches (the S*n waypoint configurations of an optimiser step) would leave most CUs idle with one
+    // workgroup per (scene, chunk): split the 10 links over workgroups until ~4 workgroups per CU exist.
+    // Per-chunk reductions need all links in one workgroup.
+    int lpw = 10;
+    if (!ca.chunk_cost && !ca.chunk_col) {
+        const int64_t wgs = (int64_t)scene_groups * ca.NCH * 8;
+        if (wgs * 5 <= 1024) lpw = 2; else if (wgs * 2 <= 1024) lpw = 5;
+    }
+    ca.LPW = lpw;
+    const int64_t grid = (int64_t)scene_groups * ca.NCH * 8 * (10 / lpw);
     if (grid > 0x7fffffff) return OMGX_ERR_UNSUPPORTED;
     const int slot = timing_slot();
     if (slot >= 0) (void)hipEventRecord(g_ev[slot][0], st);
     static int lb = -1;  // links per batch; OMGX_LB overrides the tuned default (tuning aid)
     if (lb < 0) { const char* e = getenv("OMGX_LB"); lb = e ? atoi(e) : 2; }
+    int lbu = lb;
+    if (lpw % lbu != 0) lbu = 1;  // the link batch must divide the links of a workgroup
 #define OMGX_LAUNCH_CHUNKS(G_, LB_) hipLaunchKernelGGL((k_sdf_chunks<G_, LB_>), dim3((unsigned)grid), dim3(256), 0, st, ca)
     if (ca.grad) {
-        if (lb == 1) OMGX_LAUNCH_CHUNKS(true, 1); else if (lb == 2) OMGX_LAUNCH_CHUNKS(true, 2);
-        else if (lb == 10) OMGX_LAUNCH_CHUNKS(true, 10); else OMGX_LAUNCH_CHUNKS(true, 5);
+        if (lbu == 1) OMGX_LAUNCH_CHUNKS(true, 1); else if (lbu == 2) OMGX_LAUNCH_CHUNKS(true, 2);
+        else if (lbu == 10) OMGX_LAUNCH_CHUNKS(true, 10); else OMGX_LAUNCH_CHUNKS(true, 5);
     } else {
-        if (lb == 1) OMGX_LAUNCH_CHUNKS(false, 1); else if (lb == 2) OMGX_LAUNCH_CHUNKS(false, 2);
-        else if (lb == 10) OMGX_LAUNCH_CHUNKS(false, 10); else OMGX_LAUNCH_CHUNKS(false, 5);
+        if (lbu == 1) OMGX_LAUNCH_CHUNKS(false, 1); else if (lbu == 2) OMGX_LAUNCH_CHUNKS(false, 2);
+        else if (lbu == 10) OMGX_LAUNCH_CHUNKS(false, 10); else OMGX_LAUNCH_CHUNKS(false, 5);
     }
 #undef OMGX_LAUNCH_CHUNKS
     if (slot >= 0) { (void)hipEventRecord(g_ev[slot][1], st); ++g_timing_n; }

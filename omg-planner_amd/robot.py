@@ -83,9 +83,10 @@ class PandaModel:
         pts = np.einsum("lrc,lpc->lpr", self.center_offset[:, :3, :3], self.collision_points) + self.center_offset[:, None, :3, 3]
         ax = np.einsum("lrc,lc->lr", self.tip2joint[:, :3, :3], self.joint_axis)
         og = self.tip2joint[:, :3, 3]
+        radius = np.linalg.norm(pts, axis=-1).max(axis=1)  # bounding-sphere radius of each link's centred points
         out = np.concatenate([np.array(uvw).ravel(), np.array(tp).ravel(), rows(self.pose_0[7]), rows(self.pose_0[8]),
-                              rows(self.pose_0[9]), pts.ravel(), ax.ravel(), og.ravel()])
-        assert out.size == 306 + 30 * P
+                              rows(self.pose_0[9]), pts.ravel(), ax.ravel(), og.ravel(), radius.ravel()])
+        assert out.size == 316 + 30 * P
         return out
 
 

@@ -19,7 +19,7 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
-# numpy mirror of `omgx_object` (include/omg_hip.h), 160 bytes
+# numpy mirror of `omgx_object` (include/omg_hip.h), 176 bytes
 OBJECT_DTYPE = np.dtype([
     ("pose_inv", np.float32, (12,)),
     ("lo", np.float32, (3,)),
@@ -34,8 +34,11 @@ OBJECT_DTYPE = np.dtype([
     ("inv_extent", np.float64, (3,)),
     ("far_lo", np.float32, (3,)),
     ("far_hi", np.float32, (3,)),
+    ("inv_delta", np.float64),
+    ("inv_2eps", np.float32),
+    ("inv_eps", np.float32),
 ], align=True)
-assert OBJECT_DTYPE.itemsize == 160
+assert OBJECT_DTYPE.itemsize == 176
 
 
 def finish_records(rec: np.ndarray) -> np.ndarray:
@@ -50,6 +53,11 @@ def finish_records(rec: np.ndarray) -> np.ndarray:
     ok = (w > 0) & (rec["dim"] > 0)
     rec["far_lo"] = np.where(ok, -1.5 * vox, -np.inf).astype(np.float32)
     rec["far_hi"] = np.where(ok, w + 1.5 * vox, np.inf).astype(np.float32)
+    with np.errstate(divide="ignore"):
+        rec["inv_delta"] = 1.0 / rec["delta"].astype(np.float64)
+        eps = rec["epsilon"].astype(np.float32)
+        rec["inv_2eps"] = np.float32(1.0) / (np.float32(2.0) * eps)   # float32 arithmetic like the kernel's literals
+        rec["inv_eps"] = np.float32(1.0) / eps
     return rec
 
 

@@ -1,0 +1,60 @@
+"""CPU test: libomg_hip.so loads without a GPU and exports every function include/omg_hip.h declares
+(no compute calls), and the POD structs have the sizes the header documents."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def _declared_functions():
+    text = (ROOT / "include" / "omg_hip.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(omgx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from omg_planner_amd import _lib
+    names = _declared_functions()
+    assert len(names) >= 12 and "omgx_sdf_loss_forward" in names
+    lib = _lib.lib()
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    assert sorted(_lib.EXPORTS) == names  # the loader's list is the header's list
+    assert lib.omgx_abi_version() >= 1
+
+
+def test_struct_layouts_match_header():
+    from omg_planner_amd import _lib, scenes
+    assert scenes.OBJECT_DTYPE.itemsize == 176
+    assert scenes.OBJECT_DTYPE.fields["grid_offset"][1] == 104 and scenes.OBJECT_DTYPE.fields["inv_extent"][1] == 112
+    assert C.sizeof(_lib.ChompParams) == 12 * 4 + 6 * 8 + 9 * 8
+    from oracle import oracle as orc
+    assert orc.lib().orc_sizeof_object() == 176 and orc.lib().orc_sizeof_params() == C.sizeof(_lib.ChompParams)
+
+
+def test_workspace_and_aux_sizes_without_gpu():
+    from omg_planner_amd import _lib
+    lib = _lib.lib()
+    assert lib.omgx_chomp_aux_doubles(30) == 30 * 9 + 30 * 10 + 30 * 9 + 31
+    assert lib.omgx_goalset_workspace_bytes(100, 64, 30, 15) == (100 * 64 * 10 * 30 * 12 + 100 * 120) * 8
+    assert lib.omgx_fk_sdf_workspace_bytes(100, 30, 15) >= 100 * 10 * 32 * 12 * 8
+    assert lib.omgx_fk_sdf_workspace_bytes(0, 30, 15) == 0
+
+
+def test_robot_blob_layout():
+    from omg_planner_amd import robot as rb
+    m = rb.PandaModel(seed=0)
+    b = m.blob()
+    P = m.points_per_link
+    assert b.size == 528 + 30 * P + 316 + 30 * P
+    np.testing.assert_array_equal(b[:160].reshape(10, 4, 4), m.pose_0)
+    np.testing.assert_array_equal(b[528:528 + 30 * P].reshape(10, P, 3), m.collision_points)
+    # derived joint-0 matrices reproduce pose_0[0] @ Rz(q) @ Rx(0)
+    D = 528 + 30 * P
+    U, V, W = b[D:D + 9].reshape(3, 3), b[D + 9:D + 18].reshape(3, 3), b[D + 18:D + 27].reshape(3, 3)
+    q = 0.37
+    Rz = np.array([[np.cos(q), -np.sin(q), 0], [np.sin(q), np.cos(q), 0], [0, 0, 1]])
+    np.testing.assert_allclose(np.cos(q) * U + np.sin(q) * V + W, m.pose_0[0][:3, :3] @ Rz, atol=1e-15)

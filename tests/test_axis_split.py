@@ -63,3 +63,15 @@ def test_double_reciprocal_gives_ieee_float_quotient():
     q_ref = (t / w).astype(np.float32)
     q_new = (t.astype(np.float64) * (1.0 / w.astype(np.float64))).astype(np.float32)
     assert np.array_equal(q_ref.view(np.int32), q_new.view(np.int32))
+
+
+def test_double_reciprocal_gives_reference_gradient_quotient():
+    """getGradientInterpolated (.cu:82-84): (float)(0.5 * (double)(f_p - f_m) / (double)delta) equals
+    (float)(0.5 * (double)(f_p - f_m) * fl64(1 / delta))."""
+    rng = np.random.RandomState(2)
+    n = 4_000_000
+    d = (rng.uniform(-0.05, 0.05, n).astype(np.float32) - rng.uniform(-0.05, 0.05, n).astype(np.float32)).astype(np.float32)
+    delta = rng.choice(np.array([0.6 / 64, 0.01, 0.0125, 0.02, 0.03, 0.03125, 0.05, 1.5 / 128], np.float32), n)
+    ref = (0.5 * d.astype(np.float64) / delta.astype(np.float64)).astype(np.float32)
+    new = (0.5 * d.astype(np.float64) * (1.0 / delta.astype(np.float64))).astype(np.float32)
+    assert np.array_equal(ref.view(np.int32), new.view(np.int32))
