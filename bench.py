@@ -14,7 +14,7 @@ points per link, 64 goal candidates per scene.
 One "step" = one planner-loop iteration for every scene of the rank:
     Learner.cost_vector  -> omgx_goalset_cost  (S x 64 goals x 30 interpolated waypoints; window pinned
                                                at the full 30 waypoints = the most expensive iteration)
-    goal selection (follow-the-leader, on device)
+    Learner.update_goal  -> omgx_goal_update   (cost-vector tail + mirror descent `MD`, the reference default)
     Optimizer.optimize   -> omgx_fk_sdf + omgx_chomp_optimize (loss, gradient, projected A^-1 step, limits)
 value = (scenes on all ranks) x K / (max over ranks of the timed region) in scene-iterations per second.
 Scenes are independent, so N GPUs hold N x 100 scenes (weak scaling); one all-gather of the final
@@ -114,6 +114,8 @@ def main():
     ap.add_argument("--share-grids", action="store_true", help="store identical SDF volumes once (model library)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--plan", action="store_true", help="also time a full 70-iteration plan (ms_per_plan)")
+    ap.add_argument("--streams", type=int, default=1, help="split the rank's scenes over this many HIP streams")
+    ap.add_argument("--ol-alg", default="MD", help="goal-selection rule (reference default: MD, omg/config.py:67)")
     args = ap.parse_args()
 
     import torch
@@ -137,12 +139,24 @@ def main():
 
     S, G, n = args.scenes, args.goals, args.waypoints
     cfg, model, batch, start, goals = build_workload(S, G, n, args.grid, seed0=rank * S, share_grids=args.share_grids)
-    eng = ChompEngine(model, batch, cfg, start, goals, device=dev, ol_alg="FTL")
+    # Scenes are independent: the rank's scenes are split over `--streams` engines on separate HIP streams so the
+    # latency-bound kernels of one subset (FK, waypoint SDF, k_chomp_optimize: ~100-200 workgroups) overlap the
+    # throughput-bound goal-set kernel of another.
+    import copy
+    ns = max(1, min(args.streams, S))
+    engines = []
+    for k in range(ns):
+        idx = list(range(k * S // ns, (k + 1) * S // ns))
+        sub = batch.subset(idx[0], idx[-1] + 1) if ns > 1 else batch
+        engines.append(ChompEngine(model, sub, copy.deepcopy(cfg), start[idx], goals[idx], device=dev, ol_alg=args.ol_alg,
+                                   stream=torch.cuda.Stream(device=dev) if ns > 1 else None))
+    eng = engines[0]
     lib = _lib.lib()
 
     def step():
-        eng.t = 0  # pin the goal-set window at the full n waypoints (first-iteration workload)
-        eng.iterate(0)
+        for e in engines:
+            e.t = 0  # pin the goal-set window at the full n waypoints (first-iteration workload)
+            e.iterate(0)
 
     def barrier():
         if world > 1:
@@ -157,7 +171,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    costs = eng.final_costs()
+    torch.cuda.synchronize()
+    costs = torch.cat([e.final_costs() for e in engines])
     if world > 1:
         import torch.distributed as dist
         allc = torch.empty(world * S, dtype=costs.dtype, device=dev)
@@ -175,7 +190,7 @@ def main():
 
     ms_per_plan = None
     if args.plan and rank == 0:
-        eng2 = ChompEngine(model, batch, cfg, start, goals, device=dev, ol_alg="FTL")
+        eng2 = ChompEngine(model, batch, copy.deepcopy(cfg), start, goals, device=dev, ol_alg=args.ol_alg)
         torch.cuda.synchronize()
         tp = time.perf_counter()
         eng2.plan(early_stop=False)
@@ -188,7 +203,7 @@ def main():
         goal_ms = durs[0::2] if nrec >= 2 else durs
         wp_ms = durs[1::2]
         O_active = 5
-        pts_per_launch = S * G * n * 10 * model.points_per_link
+        pts_per_launch = engines[0].S * G * n * 10 * model.points_per_link
         alg_bytes = pts_per_launch * (32 + 128 * O_active)  # N (32 + 128 O_active)
         avg_ms = float(goal_ms.mean()) if len(goal_ms) else float("nan")
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
@@ -212,7 +227,7 @@ def main():
             "config": {"workload": "100 table-top scenes/GPU x (64-goal goal-set cost + CHOMP step), Panda 9-dof, 30 waypoints",
                        "scenes_per_gpu": S, "goals": G, "waypoints": n, "objects_per_scene": O_active,
                        "sdf_grid": f"4x{args.grid}^3 + 128x96x32 per scene, {'shared' if args.share_grids else 'private'}",
-                       "goal_selection": "FTL on device", "top_k_collision": cfg.top_k_collision},
+                       "goal_selection": f"{args.ol_alg} on device (omgx_goal_update)", "top_k_collision": cfg.top_k_collision, "streams": ns},
             "roofline": {"bound": "hbm", "kernel": "k_sdf_chunks<false> (goal-set batch)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": avg_ms, "launches": int(len(goal_ms)), "algorithmic_bytes_per_launch": alg_bytes,

@@ -249,6 +249,50 @@ int omgx_chomp_optimize(const double* robot, const omgx_chomp_params* h_params,
                         double* grad, double* cost_traj, double* info, double* aux, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * (5) omgx_goal_update
+ * Replaces Learner.update_goal (omg/online_learner.py:237-249) for S scenes: the host arithmetic of
+ * Learner.cost_vector after the obstacle batch (online_learner.py:145-160: per-goal sum is omgx_goalset_cost's
+ * output; smoothness proxy ||diff(traj_start - goal_set, axis=-1)||^2 — adjacent JOINT columns, sic —,
+ * weights, optional normalisation), update_goal_dist (162-235: FTL, FTC, Exp, MD = mirror descent over 5 experts
+ * with the Bregman projection `bp` + `find_zero`, 16-58, or Proj) and the argmax / goal gather (243-246,
+ * optimizer.py:93-99).
+ *   traj        [S,n,9] double; traj_start = traj[:, start_idx]; Proj uses traj[:, n-1]
+ *   goal_set    [S,G,9] double  (traj.goal_set)
+ *   reach       [S,G,c,9] double or NULL (target_obj.reach_grasps when use_standoff)
+ *   goal_cost   [S,G] float32 from omgx_goalset_cost (ignored for Proj)
+ *   state       [S, omgx_learner_state_doubles(G)] double, in/out:
+ *               sum_costs [G] | p [G] | experts_p [5][G] | q [5] | experts_costs [5]
+ *               (initialise with omgx_learner_state_init semantics: zeros | 1/G | 1/G | 1/5 | zeros)
+ * Outputs: goal_idx [S] int32, end [S,9] (traj.end), goal_rows [S,c,9] (chosen goal rows for the projection),
+ *          goal_point [S,9] (goal_set[goal_idx]), cost_vector [S,G] double (optional, NULL to skip).
+ * G <= OMGX_MAX_GOALS.
+ * ------------------------------------------------------------------------------------------- */
+#define OMGX_MAX_GOALS 256
+#define OMGX_ALG_FTL 0
+#define OMGX_ALG_FTC 1
+#define OMGX_ALG_EXP 2
+#define OMGX_ALG_MD 3
+#define OMGX_ALG_PROJ 4
+typedef struct omgx_learner_params {
+    int32_t alg;             /* OMGX_ALG_*  (cfg.ol_alg)                                            */
+    int32_t num_goals;       /* G                                                                   */
+    int32_t n_waypoints;     /* cfg.timesteps                                                       */
+    int32_t start_idx;       /* min(int(t / optim_steps * timesteps), timesteps - 1), online_learner.py:109-110 */
+    int32_t constraint_num;  /* c rows of goal_rows: reach_tail_length if use_standoff else 1        */
+    int32_t use_standoff;    /* goal_rows from `reach` instead of goal_set                           */
+    int32_t normalize_cost;  /* cfg.normalize_cost                                                  */
+    int32_t reserved;
+    double base_obstacle_weight; /* cfg.base_obstacle_weight                                        */
+    double smooth_weight;        /* cfg.smoothness_base_weight * cfg.dist_eps                       */
+    double eta;                  /* sqrt(log(G + 1) / optim_steps), online_learner.py:80            */
+} omgx_learner_params;
+int64_t omgx_learner_state_doubles(int32_t num_goals);
+int omgx_goal_update(const omgx_learner_params* h_params, const double* traj, const double* goal_set, const double* reach,
+                     const float* goal_cost, double* state, int32_t num_scenes,
+                     int32_t* goal_idx, double* end, double* goal_rows, double* goal_point, double* cost_vector,
+                     void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Diagnostics
  * ------------------------------------------------------------------------------------------- */
 const char* omgx_last_error(void); /* thread-local text of the last OMGX_ERR_LAUNCH               */

@@ -17,7 +17,8 @@ NUM_DOF, INFO_STRIDE = 9, 16
 
 # every symbol include/omg_hip.h declares
 EXPORTS = ["omgx_sdf_loss_forward", "omgx_fk_sdf_workspace_bytes", "omgx_fk_sdf", "omgx_forward_kinematics",
-           "omgx_goalset_workspace_bytes", "omgx_goalset_cost", "omgx_chomp_aux_doubles", "omgx_chomp_optimize", "omgx_last_error", "omgx_abi_version", "omgx_device_arch",
+           "omgx_goalset_workspace_bytes", "omgx_goalset_cost", "omgx_chomp_aux_doubles", "omgx_chomp_optimize",
+           "omgx_learner_state_doubles", "omgx_goal_update", "omgx_last_error", "omgx_abi_version", "omgx_device_arch",
            "omgx_timing_enable", "omgx_timing_collect"]
 
 
@@ -33,6 +34,16 @@ class ChompParams(C.Structure):
         "pre_terminate", "do_update")] + [(n, C.c_double) for n in (
         "time_interval", "obstacle_weight", "smoothness_weight", "step_size", "clip_grad_scale",
         "terminate_smooth_loss")] + [("link_smooth_weight", C.c_double * NUM_DOF)]
+
+
+class LearnerParams(C.Structure):
+    """Mirror of `omgx_learner_params` (include/omg_hip.h)."""
+    _fields_ = [(n, C.c_int32) for n in ("alg", "num_goals", "n_waypoints", "start_idx", "constraint_num", "use_standoff",
+                                          "normalize_cost", "reserved")] + [(n, C.c_double) for n in (
+        "base_obstacle_weight", "smooth_weight", "eta")]
+
+
+ALG = {"FTL": 0, "FTC": 1, "Exp": 2, "MD": 3, "Proj": 4}
 
 
 def build(force: bool = False) -> Path:
@@ -64,6 +75,10 @@ def lib() -> C.CDLL:
         l.omgx_goalset_workspace_bytes.restype = i64
         l.omgx_goalset_cost.argtypes = [vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, f64, i32, vp, vp, vp, vp, vp]
         l.omgx_chomp_optimize.argtypes = [vp, C.POINTER(ChompParams)] + [vp] * 9 + [i32] + [vp] * 4 + [vp]
+        l.omgx_learner_state_doubles.argtypes = [i32]
+        l.omgx_learner_state_doubles.restype = i64
+        l.omgx_goal_update.argtypes = [C.POINTER(LearnerParams)] + [vp] * 5 + [i32] + [vp] * 5 + [vp]
+        l.omgx_goal_update.restype = C.c_int
         l.omgx_last_error.restype = C.c_char_p
         l.omgx_device_arch.argtypes = [C.c_char_p, i32]
         l.omgx_timing_enable.argtypes = [i32]

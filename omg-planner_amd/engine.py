@@ -13,9 +13,8 @@ trip inside an iteration: per iteration three C-ABI calls on one stream
     omgx_fk_sdf         (S x n waypoint configurations -> potentials / gradients)
     omgx_chomp_optimize (S trajectories: loss, gradient, projected A^-1 step, joint limits)
 
-plus O(S*G) goal-selection arithmetic (torch elementwise ops; Learner.update_goal,
-omg/online_learner.py:162-249 — the follow-the-leader family runs on device, mirror descent is the
-"next" row of SURVEY.md §8f and is not part of this round).
+plus one omgx_goal_update launch (Learner.update_goal, omg/online_learner.py:104-249: cost-vector tail, FTL / FTC /
+Exp / MD mirror descent / Proj, argmax, goal gather) — SURVEY.md §8f-1.
 
 Multi-GPU: scenes are independent (omg/core.py:869-885 loops them), so rank r of R owns a contiguous block
 of the scene list; nothing is exchanged during planning and one all-gather of the final per-scene costs
@@ -42,17 +41,20 @@ def shard_range(num_items: int, rank: int, world: int) -> range:
 class ChompEngine:
     def __init__(self, model: PandaModel, batch: SceneBatch, cfg: Config, start: np.ndarray, goal_set: np.ndarray,
                  reach_grasps: np.ndarray | None = None, traj_init: np.ndarray | None = None, device="cuda:0",
-                 ol_alg: str = "FTL"):
-        """start [S,9]; goal_set [S,G,9]; reach_grasps [S,G,c,9] (needed when cfg.use_standoff)."""
+                 ol_alg: str = "FTL", stream: "torch.cuda.Stream | None" = None):
+        """start [S,9]; goal_set [S,G,9]; reach_grasps [S,G,c,9] (needed when cfg.use_standoff).
+        `stream`: run every launch of this engine on that HIP stream (several engines holding disjoint scene
+        subsets on different streams overlap each other's latency-bound kernels)."""
         self.cfg = cfg
+        self.stream = stream
         self.model = model
         self.device = torch.device(device)
         self.S, self.G = goal_set.shape[0], goal_set.shape[1]
         self.n = cfg.timesteps
         self.P = model.points_per_link
         self.ol_alg = ol_alg
-        if ol_alg not in ("FTL", "FTC", "Exp", "Proj", "Baseline"):
-            raise ValueError(f"ol_alg {ol_alg!r} is not available on device (MD is SURVEY.md §8f-1, a later round)")
+        if ol_alg not in ("FTL", "FTC", "Exp", "MD", "Proj", "Baseline"):
+            raise ValueError(f"unknown ol_alg {ol_alg!r}")
         assert batch.num_scenes == self.S
         dev = self.device
         f64 = dict(dtype=torch.float64, device=dev)
@@ -70,7 +72,7 @@ class ChompEngine:
         else:
             self.reach = None
             self.cv_goals = self.goal_set
-        self.goal_idx = torch.zeros(self.S, dtype=torch.int64, device=dev)
+        self.goal_idx = torch.zeros(self.S, dtype=torch.int32, device=dev)
         S, n, P, G = self.S, self.n, self.P, self.G
         if traj_init is None:
             from .scenes import cubic_init
@@ -89,8 +91,8 @@ class ChompEngine:
         self.info = torch.zeros((S, _lib.INFO_STRIDE), **f64)
         self.goal_cost = torch.empty((S, G), **f32)
         self.goal_col = torch.empty((S, G), **f32)
-        self.sum_costs = torch.zeros((S, G), **f64)
-        self.p = torch.full((S, G), 1.0 / G, **f64)
+        self.learner_state = ops.learner_state(S, G, dev)  # sum_costs | p | experts_p | q | experts_costs
+        self.cost_vec = torch.empty((S, G), **f64)
         self.eta = float(np.sqrt(np.log(G + 1) / cfg.optim_steps))  # online_learner.py:80
         self.active = torch.ones(S, dtype=torch.int32, device=dev)
         self.step_count = 0  # Optimizer.step
@@ -134,7 +136,7 @@ class ChompEngine:
 
     def _gather_goal(self):
         """traj.end / chosen goal rows for the current goal_idx (online_learner.py:243-245, optimizer.py:93-99)."""
-        idx = self.goal_idx
+        idx = self.goal_idx.long()
         ar = torch.arange(self.S, device=self.device)
         torch.index_select(self.goal_set.view(self.S * self.G, 9), 0, ar * self.G + idx, out=self.goal_point)
         self.end.copy_(self.goal_point)
@@ -144,44 +146,32 @@ class ChompEngine:
             self.goal_rows.copy_(self.goal_point[:, None, :])
 
     # ---------------------------------------------------------------------------------------------
-    def cost_vector(self) -> torch.Tensor:
-        """Learner.cost_vector (omg/online_learner.py:104-160) for every scene: [S,G] float64 on device."""
+    def _learner_params(self) -> _lib.LearnerParams:
         cfg = self.cfg
-        start_idx = min(int((self.t / cfg.optim_steps) * cfg.timesteps), cfg.timesteps - 1)
-        n_rem = cfg.timesteps - start_idx
-        traj_start = self.traj[:, start_idx].contiguous()
-        ops.goalset_cost(self.robot, self.P, self.scenes, traj_start, self.cv_goals, n_rem, cfg.time_interval,
-                         soften_fingers=False, out=(self.goal_cost, self.goal_col))
-        d = traj_start[:, None, :] - self.goal_set  # np.diff(..., axis=-1): adjacent JOINT columns (sic)
-        smooth = (d[..., 1:] - d[..., :-1]).pow(2).sum(-1)
-        pot = cfg.base_obstacle_weight * self.goal_cost.double() + cfg.smoothness_base_weight * cfg.dist_eps * smooth
-        if cfg.normalize_cost:
-            pot = pot / torch.linalg.norm(pot, dim=-1, keepdim=True)
-        return pot
+        p = _lib.LearnerParams()
+        p.alg = _lib.ALG[self.ol_alg]
+        p.num_goals, p.n_waypoints = self.G, self.n
+        p.start_idx = min(int((self.t / cfg.optim_steps) * cfg.timesteps), cfg.timesteps - 1)  # online_learner.py:109-110
+        p.constraint_num, p.use_standoff = self.c, int(self.use_standoff)
+        p.normalize_cost = int(cfg.normalize_cost)
+        p.base_obstacle_weight = float(cfg.base_obstacle_weight)
+        p.smooth_weight = float(cfg.smoothness_base_weight * cfg.dist_eps)
+        p.eta = self.eta
+        return p
 
     def update_goal(self):
-        """Learner.update_goal (online_learner.py:237-249) with the device-side policies."""
+        """Learner.update_goal (online_learner.py:237-249): omgx_goalset_cost + omgx_goal_update, no host sync."""
         self.t += 1
-        alg = self.ol_alg
-        if alg == "Baseline":
+        if self.ol_alg == "Baseline":
             return
-        if alg == "Proj":  # online_learner.py:196-206
-            dist = torch.linalg.norm(self.traj[:, -1][:, None, :] - self.goal_set, dim=-1)
-            self.goal_idx = torch.argmin(dist, dim=-1)
-        else:
-            cv = self.cost_vector()
-            if alg == "FTL":  # :175-181
-                self.sum_costs += cv
-                self.goal_idx = torch.argmin(self.sum_costs, dim=-1)
-            elif alg == "FTC":  # :183-189
-                self.goal_idx = torch.argmin(cv, dim=-1)
-            elif alg == "Exp":  # :208-217
-                self.sum_costs += cv
-                norm_sum = self.sum_costs / (self.sum_costs.sum(-1, keepdim=True) + 1e-8)
-                p = torch.exp(-self.eta * cv) * self.p * 0.999 + norm_sum * 0.001
-                self.p = p / (p.sum(-1, keepdim=True) + 1e-8)
-                self.goal_idx = torch.argmax(self.p, dim=-1)
-        self._gather_goal()
+        prm = self._learner_params()
+        if self.ol_alg != "Proj":  # cost_vector's obstacle batch (online_learner.py:128-148)
+            n_rem = self.cfg.timesteps - prm.start_idx
+            traj_start = self.traj[:, prm.start_idx].contiguous()
+            ops.goalset_cost(self.robot, self.P, self.scenes, traj_start, self.cv_goals, n_rem, self.cfg.time_interval,
+                             soften_fingers=False, out=(self.goal_cost, self.goal_col))
+        ops.goal_update(prm, self.traj, self.goal_set, self.reach, self.goal_cost, self.learner_state, self.goal_idx,
+                        self.end, self.goal_rows, self.goal_point, self.cost_vec)
 
     def optimize(self, do_update: bool = True):
         """Optimizer.optimize(traj, force_update=True) (omg/optimizer.py:115-135) for all scenes."""
@@ -195,6 +185,9 @@ class ChompEngine:
 
     def iterate(self, t: int, early_stop: bool = False):
         """One pass of the planner loop body (planner.py:612-621) over all scenes."""
+        if self.stream is not None and torch.cuda.current_stream(self.device) != self.stream:
+            with torch.cuda.stream(self.stream):
+                return self.iterate(t, early_stop)
         cfg = self.cfg
         if cfg.goal_set_proj and t < cfg.optim_steps:
             self.update_goal()

@@ -8,7 +8,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import ChompParams, check
+from ._lib import ChompParams, LearnerParams, check
 
 _ws_cache: dict = {}
 
@@ -150,3 +150,26 @@ def chomp_optimize(robot, params: ChompParams, traj, start, end, goal, goal_poin
                                              _ptr(goal_point), _ptr(pot), _ptr(pgrad), _ptr(col), _ptr(active), S,
                                              _ptr(grad), _ptr(cost_traj), _ptr(info), _ptr(aux), _stream()), "omgx_chomp_optimize")
     return grad, cost_traj, info
+
+
+def learner_state(S: int, G: int, device) -> torch.Tensor:
+    """Initial Learner state [S, 7G+10] f64: sum_costs 0 | p 1/G | experts_p 1/G | q 1/5 | experts_costs 0
+    (Learner.__init__, omg/online_learner.py:66-95)."""
+    st = torch.zeros((S, 7 * G + 10), dtype=torch.float64, device=device)
+    st[:, G:7 * G] = 1.0 / G
+    st[:, 7 * G:7 * G + 5] = 0.2
+    return st
+
+
+def goal_update(params: LearnerParams, traj, goal_set, reach, goal_cost, state, goal_idx, end, goal_rows, goal_point,
+                cost_vector=None):
+    """Learner.update_goal for S scenes in one launch (omgx_goal_update); all outputs are written in place."""
+    _need(traj, torch.float64, "traj")
+    _need(goal_set, torch.float64, "goal_set")
+    _need(state, torch.float64, "state")
+    if goal_idx.dtype != torch.int32:
+        raise _lib.OmgHipError("goal_idx must be int32")
+    with torch.cuda.device(traj.device):
+        check(_lib.lib().omgx_goal_update(C.byref(params), _ptr(traj), _ptr(goal_set), _ptr(reach), _ptr(goal_cost), _ptr(state),
+                                          traj.shape[0], _ptr(goal_idx), _ptr(end), _ptr(goal_rows), _ptr(goal_point),
+                                          _ptr(cost_vector), _stream()), "omgx_goal_update")

@@ -217,6 +217,17 @@ class SceneBatch:
     def num_scenes(self) -> int:
         return len(self.scene_begin) - 1
 
+    def subset(self, first: int, last: int) -> "SceneBatch":
+        """Scenes [first, last) as their own batch: records copied, scene_begin rebased, and the pool cut to
+        the range those records address (grid offsets rebased)."""
+        lo_o, hi_o = int(self.scene_begin[first]), int(self.scene_begin[last])
+        rec = self.objects[lo_o:hi_o].copy()
+        sizes = rec["dim"].astype(np.int64).prod(axis=1)
+        p0 = int(rec["grid_offset"].min()) if len(rec) else 0
+        p1 = int((rec["grid_offset"] + sizes).max()) if len(rec) else 0
+        rec["grid_offset"] -= p0
+        return SceneBatch(rec, (self.scene_begin[first:last + 1] - lo_o).astype(np.int32), self.pool[p0:p1])
+
 
 def pack_table(scenes, cfg_kwargs=None, ragged: bool = True, share_grids: bool = True) -> SceneBatch:
     """Pack scenes into the engine layout.

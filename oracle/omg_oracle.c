@@ -691,6 +691,172 @@ int orc_chomp_optimize(const double* robot, const omgx_chomp_params* prm, double
     return rc;
 }
 
+/* =============================================================================================
+ * 6. Learner.update_goal — omg/online_learner.py
+ * =========================================================================================== */
+
+/* numpy's pairwise summation (add.reduce on a contiguous float64 vector): plain loop below 8 elements,
+ * 8 strided partial sums up to 128, recursion above. */
+static double np_sum(const double* a, int n) {
+    if (n < 8) {
+        double r = 0.0;
+        for (int i = 0; i < n; ++i) r += a[i];
+        return n ? r : 0.0;
+    }
+    if (n <= 128) {
+        double r[8];
+        for (int k = 0; k < 8; ++k) r[k] = a[k];
+        int i = 8;
+        for (; i < n - (n % 8); i += 8)
+            for (int k = 0; k < 8; ++k) r[k] += a[i + k];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += a[i];
+        return res;
+    }
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_sum(a, n2) + np_sum(a + n2, n - n2);
+}
+
+static double orc_sign(double y) { return (y > 0) - (y < 0); }
+
+/* bp (online_learner.py:32-58) with find_zero (16-29) inlined: Bregman projection onto the simplex. */
+static void orc_bp(const double* x, const double* v, const double* delta, const double* w, int n, double* y) {
+    const int max_iter = 100; const double err = 1e-6;
+    double *alpha = (double*)calloc(n, sizeof(double)), *z = (double*)malloc(sizeof(double) * n),
+           *shiftx = (double*)malloc(sizeof(double) * n), *tmp = (double*)malloc(sizeof(double) * n),
+           *ap = (double*)malloc(sizeof(double) * n);
+    for (int it = 0; it < max_iter; ++it) {
+        for (int i = 0; i < n; ++i) { z[i] = (alpha[i] - v[i]) / w[i]; shiftx[i] = x[i] + delta[i]; }
+        const double target = 1.0 + np_sum(delta, n);
+        double x1 = w[0] + v[0];
+        for (int i = 1; i < n; ++i) if (w[i] + v[i] > x1) x1 = w[i] + v[i];
+        /* find_zero(f, 0, max(w + v), err, max_iter) */
+        double L = (0.0 + x1) / 2.0, sstep = (x1 - 0.0) / 4.0;
+        for (int k = 0; k < max_iter; ++k) {
+            for (int i = 0; i < n; ++i) tmp[i] = shiftx[i] * exp(L / w[i] + z[i]);
+            const double fy = np_sum(tmp, n) - target;
+            if (fabs(fy) < err) break;
+            L -= sstep * orc_sign(fy);
+            sstep /= 2.0;
+        }
+        for (int i = 0; i < n; ++i) y[i] = shiftx[i] * exp((L + alpha[i] - v[i]) / w[i]) - delta[i];
+        double nrm = 0.0;
+        for (int i = 0; i < n; ++i) {
+            ap[i] = fmax(0.0, v[i] - L + w[i] * log(delta[i] / shiftx[i]));
+            nrm += (alpha[i] - ap[i]) * (alpha[i] - ap[i]);
+        }
+        if (sqrt(nrm) < err) break;
+        memcpy(alpha, ap, sizeof(double) * n);
+    }
+    for (int i = 0; i < n; ++i) tmp[i] = y[i] = fmax(y[i], 0.0);
+    const double sy = np_sum(tmp, n);
+    for (int i = 0; i < n; ++i) y[i] /= sy;
+    free(alpha); free(z); free(shiftx); free(tmp); free(ap);
+}
+
+int orc_goal_update(const omgx_learner_params* prm, const double* traj, const double* goal_set, const double* reach,
+                    const float* goal_cost, double* state, int32_t S, int32_t* goal_idx, double* end, double* goal_rows,
+                    double* goal_point, double* cost_vector) {
+    const int G = prm->num_goals, n = prm->n_waypoints, c = prm->constraint_num;
+    if (G < 1 || G > OMGX_MAX_GOALS) return OMGX_ERR_UNSUPPORTED;
+    const int64_t SS = 7 * (int64_t)G + 10;
+    for (int s = 0; s < S; ++s) {
+        double* st = state + s * SS;
+        double *sum_costs = st, *p = st + G, *experts_p = st + 2 * G, *q = st + 7 * G, *ecost = st + 7 * G + 5;
+        const double* gs = goal_set + (int64_t)s * G * ND;
+        double* cv = (double*)malloc(sizeof(double) * G);
+        double* tmp = (double*)malloc(sizeof(double) * G);
+        int idx = 0;
+        if (prm->alg == OMGX_ALG_PROJ) { /* online_learner.py:196-206: closest goal to the last waypoint */
+            const double* last = traj + ((int64_t)s * n + n - 1) * ND;
+            double best = 0.0;
+            for (int g = 0; g < G; ++g) {
+                double d2 = 0.0;
+                for (int d = 0; d < ND; ++d) { const double e = last[d] - gs[g * ND + d]; d2 += e * e; }
+                const double dist = sqrt(d2);
+                if (g == 0 || dist < best) { best = dist; idx = g; }
+                p[g] = 0.0;
+            }
+            p[idx] = 1.0;
+        } else {
+            /* cost_vector tail, online_learner.py:145-160 */
+            const double* ts = traj + ((int64_t)s * n + prm->start_idx) * ND;
+            for (int g = 0; g < G; ++g) {
+                double s2 = 0.0;
+                for (int d = 0; d + 1 < ND; ++d) { /* np.diff(traj_start - goal_set, axis=-1) */
+                    const double a = (ts[d + 1] - gs[g * ND + d + 1]) - (ts[d] - gs[g * ND + d]);
+                    s2 += a * a;
+                }
+                const double nr = sqrt(s2);
+                const float wc = (float)prm->base_obstacle_weight * goal_cost[(int64_t)s * G + g]; /* float32 product */
+                cv[g] = (double)wc + prm->smooth_weight * (nr * nr);
+            }
+            if (prm->normalize_cost) {
+                double nn = 0.0;
+                for (int g = 0; g < G; ++g) nn += cv[g] * cv[g];
+                nn = sqrt(nn);
+                for (int g = 0; g < G; ++g) cv[g] /= nn;
+            }
+            if (cost_vector) memcpy(cost_vector + (int64_t)s * G, cv, sizeof(double) * G);
+            if (prm->alg == OMGX_ALG_FTL || prm->alg == OMGX_ALG_FTC) { /* :175-189 */
+                const double* key = cv;
+                if (prm->alg == OMGX_ALG_FTL) { for (int g = 0; g < G; ++g) sum_costs[g] += cv[g]; key = sum_costs; }
+                for (int g = 1; g < G; ++g) if (key[g] < key[idx]) idx = g;
+                for (int g = 0; g < G; ++g) p[g] = 0.0;
+                p[idx] = 1.0;
+            } else if (prm->alg == OMGX_ALG_EXP) { /* :208-217 */
+                for (int g = 0; g < G; ++g) sum_costs[g] += cv[g];
+                const double tot = np_sum(sum_costs, G);
+                for (int g = 0; g < G; ++g) {
+                    const double pn = exp(-prm->eta * cv[g]) * p[g];
+                    p[g] = pn * 0.999 + (sum_costs[g] / (tot + 1e-8)) * 0.001;
+                }
+                const double ps = np_sum(p, G);
+                for (int g = 0; g < G; ++g) p[g] = p[g] / (ps + 1e-8);
+            } else { /* MD, :219-235 */
+                static const double pw[5] = {0.25, 0.5, 1.0, 4.0, 16.0}; /* eta * 2**[-2,-1,0,2,4] */
+                double *v = (double*)malloc(sizeof(double) * G), *delta = (double*)malloc(sizeof(double) * G),
+                       *w = (double*)malloc(sizeof(double) * G), *pn = (double*)malloc(sizeof(double) * G);
+                for (int g = 0; g < G; ++g) { delta[g] = 1.0 / (4.0 * G + 1.0); w[g] = 1.0; }
+                for (int i = 0; i < 5; ++i) {
+                    double* ep = experts_p + (int64_t)i * G;
+                    for (int g = 0; g < G; ++g) v[g] = prm->eta * pw[i] * cv[g];
+                    orc_bp(ep, v, delta, w, G, pn);
+                    double dcv = 0.0, dw = 0.0;
+                    for (int g = 0; g < G; ++g) { dcv += cv[g] * pn[g]; dw += w[g] * fabs(pn[g] - ep[g]); }
+                    ecost[i] = dcv + dw;
+                    memcpy(ep, pn, sizeof(double) * G);
+                    /* the mixture update sits INSIDE the expert loop (online_learner.py:231-235) */
+                    for (int k = 0; k < 5; ++k) q[k] = q[k] * exp(-1.0 * ecost[k]);
+                    const double qs = np_sum(q, 5);
+                    for (int k = 0; k < 5; ++k) q[k] /= qs;
+                    for (int g = 0; g < G; ++g) {
+                        double m = 0.0;
+                        for (int k = 0; k < 5; ++k) m += experts_p[(int64_t)k * G + g] * q[k];
+                        p[g] = m;
+                    }
+                    const double ps = np_sum(p, G);
+                    for (int g = 0; g < G; ++g) p[g] /= ps;
+                }
+                free(v); free(delta); free(w); free(pn);
+            }
+            if (prm->alg == OMGX_ALG_EXP || prm->alg == OMGX_ALG_MD) { /* np.argmax(self.p), :243 */
+                idx = 0;
+                for (int g = 1; g < G; ++g) if (p[g] > p[idx]) idx = g;
+            }
+        }
+        goal_idx[s] = idx;
+        for (int d = 0; d < ND; ++d) { end[s * ND + d] = gs[idx * ND + d]; goal_point[s * ND + d] = gs[idx * ND + d]; }
+        for (int r = 0; r < c; ++r)
+            for (int d = 0; d < ND; ++d)
+                goal_rows[((int64_t)s * c + r) * ND + d] =
+                    prm->use_standoff ? reach[(((int64_t)s * G + idx) * c + r) * ND + d] : gs[idx * ND + d];
+        free(cv); free(tmp);
+    }
+    return 0;
+}
+
 /* Exposed pieces for fine-grained golden checks. */
 void orc_points_of_config(const double* robot, int32_t P, const double* q, double* x /*[10][P][3]*/) {
     double pose[160];
@@ -701,3 +867,4 @@ void orc_points_of_config(const double* robot, int32_t P, const double* q, doubl
 
 int orc_sizeof_object(void) { return (int)sizeof(omgx_object); }
 int orc_sizeof_params(void) { return (int)sizeof(omgx_chomp_params); }
+int orc_sizeof_learner_params(void) { return (int)sizeof(omgx_learner_params); }

@@ -30,6 +30,24 @@ class ChompParams(C.Structure):
         "terminate_smooth_loss")] + [("link_smooth_weight", C.c_double * NUM_DOF)]
 
 
+class LearnerParams(C.Structure):
+    """Mirror of `omgx_learner_params` (include/omg_hip.h)."""
+    _fields_ = [(n, C.c_int32) for n in ("alg", "num_goals", "n_waypoints", "start_idx", "constraint_num", "use_standoff",
+                                          "normalize_cost", "reserved")] + [(n, C.c_double) for n in (
+        "base_obstacle_weight", "smooth_weight", "eta")]
+
+
+ALG = {"FTL": 0, "FTC": 1, "Exp": 2, "MD": 3, "Proj": 4}
+
+
+def learner_state_init(S: int, G: int) -> np.ndarray:
+    """sum_costs 0 | p 1/G | experts_p 1/G | q 1/5 | experts_costs 0  (Learner.__init__, online_learner.py:66-95)."""
+    st = np.zeros((S, 7 * G + 10))
+    st[:, G:7 * G] = 1.0 / G
+    st[:, 7 * G:7 * G + 5] = 0.2
+    return st
+
+
 def build(force: bool = False) -> Path:
     src = _HERE / "omg_oracle.c"
     hdr = _HERE.parent / "include" / "omg_hip.h"
@@ -47,13 +65,14 @@ def lib() -> C.CDLL:
     if _lib is None:
         build()
         _lib = C.CDLL(str(_SO))
-        for name in ("orc_sdf_loss_forward", "orc_fk_sdf", "orc_goalset_cost", "orc_chomp_optimize",
-                     "orc_sizeof_object", "orc_sizeof_params"):
+        for name in ("orc_sdf_loss_forward", "orc_fk_sdf", "orc_goalset_cost", "orc_chomp_optimize", "orc_goal_update",
+                     "orc_sizeof_object", "orc_sizeof_params", "orc_sizeof_learner_params"):
             getattr(_lib, name).restype = C.c_int
         for name in ("orc_fk_batch", "orc_smooth_matrices", "orc_points_of_config"):
             getattr(_lib, name).restype = None
         assert _lib.orc_sizeof_object() == 176
         assert _lib.orc_sizeof_params() == C.sizeof(ChompParams)
+        assert _lib.orc_sizeof_learner_params() == C.sizeof(LearnerParams)
     return _lib
 
 
@@ -168,3 +187,19 @@ def chomp_optimize(robot_blob, params: ChompParams, traj, start, end, goal, goal
                                   C.c_int32(S), _p(grad, C.c_double), _p(cost_traj, C.c_double), _p(info, C.c_double))
     assert rc == 0, rc
     return traj, grad, cost_traj, info
+
+
+def goal_update(params: LearnerParams, traj, goal_set, reach, goal_cost, state):
+    """-> goal_idx [S], end [S,9], goal_rows [S,c,9], goal_point [S,9], cost_vector [S,G]; `state` is updated in place."""
+    traj, goal_set = _f64(traj), _f64(goal_set)
+    S, G, c = traj.shape[0], params.num_goals, params.constraint_num
+    reach = None if reach is None else _f64(reach)
+    goal_cost = _f32(goal_cost)
+    assert state.dtype == np.float64 and state.flags.c_contiguous and state.shape == (S, 7 * G + 10)
+    idx = np.zeros(S, np.int32)
+    end = np.zeros((S, 9)); rows = np.zeros((S, c, 9)); gp = np.zeros((S, 9)); cv = np.zeros((S, G))
+    rc = lib().orc_goal_update(C.byref(params), _p(traj, C.c_double), _p(goal_set, C.c_double), _p(reach, C.c_double),
+                               _p(goal_cost, C.c_float), _p(state, C.c_double), C.c_int32(S), _p(idx, C.c_int32),
+                               _p(end, C.c_double), _p(rows, C.c_double), _p(gp, C.c_double), _p(cv, C.c_double))
+    assert rc == 0, rc
+    return idx, end, rows, gp, cv

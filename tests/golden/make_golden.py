@@ -104,6 +104,8 @@ def load_reference():
     optimizer = importlib.import_module("omg.optimizer")
     util = importlib.import_module("omg.util")
     rk = importlib.import_module("ycb_render.robotPose.robot_pykdl")
+    global LEARNER_MOD
+    LEARNER_MOD = importlib.import_module("omg.online_learner")
     return config, cost, optimizer, util, rk
 
 
@@ -158,6 +160,7 @@ def make_env(cfg, kin, model, scene):
 
 
 CFG_DEFAULTS = None
+LEARNER_MOD = None
 
 
 def reset_cfg(cfg, **over):
@@ -394,6 +397,47 @@ def main():
         out.update(scene_arrays(scene, sdf, lim))
         np.savez_compressed(OUT / f"batch_{name}.npz", **out)
         print(f"batch_{name}.npz  goal_cost {out['goal_cost'][:4]}")
+
+    # ---- (f-1) Learner.update_goal: cost_vector + FTL / FTC / Exp / MD (omg/online_learner.py) ----------
+    def run_learner_case(alg, scene_seed, G, steps, use_standoff, spread=0.12, tag=""):
+        reset_cfg(cfg, timesteps=30, ol_alg=alg, use_standoff=use_standoff)
+        scene = small_scene(sc, scene_seed)
+        env, sdf, lim = make_env(cfg, kin, model, scene)
+        r = np.random.RandomState(400 + scene_seed)
+        goals = goal[None] + np.concatenate([r.normal(0, spread, size=(G, 7)), np.zeros((G, 2))], 1)
+        reach = np.stack([np.concatenate([sc.linear_init(g - np.array([0.1, -0.05, 0.1, 0.15, 0, -0.1, 0.1, 0, 0]), g, 4), g[None]], 0)
+                          for g in goals])  # [G,5,9] standoff tails ending at the goal
+        env.objects[env.target_idx].reach_grasps = reach
+        c = cost_mod.Cost(env)
+        traj = Traj(cfg, sc.cubic_init(start, goals[0], 30), start, goals[0], goal_set=goals, goal_idx=0)
+        traj.interpolate_waypoints = lambda *a, **k: None  # Learner.__init__ re-initialises the trajectory; kept fixed here
+        learner = LEARNER_MOD.Learner(env, traj, c)
+        rec = dict(goal_set=goals, reach_grasps=reach, traj=np.array(traj.data), start=start, collision_points=model.collision_points,
+                   init_goal_idx=np.int64(traj.goal_idx), eta=np.float64(learner.eta), alg=np.array(alg),
+                   cfg_dt=np.float64(cfg.time_interval), cfg_use_standoff=np.int64(use_standoff), optim_steps=np.int64(cfg.optim_steps),
+                   dist_eps=np.float64(cfg.dist_eps))
+        cvs, ps, idxs, qs, trajs = [], [], [], [], []
+        for k in range(steps):
+            # move the trajectory between calls (as the optimiser would) so the cost vectors change
+            traj.data = traj.data + r.normal(0, 0.06, size=(1, 9)) * np.array([1] * 7 + [0, 0]) * np.linspace(0.2, 1.0, 30)[:, None]
+            trajs.append(np.array(traj.data).copy())
+            learner.t += 1
+            cv = learner.cost_vector()
+            learner.t -= 1
+            learner.update_goal()
+            cvs.append(cv.copy()); ps.append(np.array(learner.p, dtype=np.float64).copy()); idxs.append(int(traj.goal_idx))
+            qs.append(np.array(learner.q).copy())
+        rec.update(trajs=np.stack(trajs), cost_vectors=np.stack(cvs), p=np.stack(ps), goal_idx=np.array(idxs), q=np.stack(qs), sum_costs=np.array(learner.sum_costs),
+                   experts_p=np.stack(learner.experts_p), final_t=np.float64(learner.t))
+        rec.update(scene_arrays(scene, sdf, lim))
+        np.savez_compressed(OUT / f"learner_{alg}_{int(use_standoff)}{tag}.npz", **rec)
+        print(f"learner_{alg}_{int(use_standoff)}{tag}.npz  goal_idx {idxs}")
+
+    for alg in ("FTL", "FTC", "Exp", "MD"):
+        run_learner_case(alg, 31, 8, 6, False)
+    run_learner_case("MD", 32, 12, 8, True)
+    run_learner_case("FTC", 33, 8, 8, False, spread=0.015, tag="_close")
+    run_learner_case("MD", 34, 8, 8, False, spread=0.015, tag="_close")
 
     run_batch_case("arc_g6_n30", 21, 6, 30, True, 0)
     run_batch_case("arc_g5_n7", 22, 5, 7, True, 0, floor=True)

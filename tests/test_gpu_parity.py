@@ -432,3 +432,72 @@ def test_omg_cuda_module_is_a_drop_in(dev):
     assert len(out) == 3
     for r, g in zip(ref, out):
         np.testing.assert_array_equal(g.cpu().numpy(), r)
+
+
+# ------------------------------------------------------------------------------------------------
+# (6) omgx_goal_update — Learner.update_goal
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", ["FTL_0", "FTC_0", "Exp_0", "MD_0", "MD_1", "FTC_0_close", "MD_0_close"])
+def test_goal_update_matches_reference_learner_fixture(dev, case):
+    from omg_planner_amd import _lib, ops
+    from tests.test_oracle_learner import learner_params
+    fx = H.load(f"learner_{case}.npz")
+    m = H.model_from(fx)
+    G = fx["goal_set"].shape[0]
+    standoff = int(fx["cfg_use_standoff"])
+    c = fx["reach_grasps"].shape[1] if standoff else 1
+    robot, ds = ops.robot_blob(m, dev), ops.DeviceScenes(H.batch_from(fx), dev)
+    goal_set, reach = _t(fx["goal_set"][None], dev), _t(fx["reach_grasps"][None], dev)
+    cv_goals = _t((fx["reach_grasps"][:, -1, :] if standoff else fx["goal_set"])[None], dev)
+    state = ops.learner_state(1, G, dev)
+    idx = torch.zeros(1, dtype=torch.int32, device=dev)
+    end, rows, gp = (torch.zeros((1, 9), dtype=torch.float64, device=dev), torch.zeros((1, c, 9), dtype=torch.float64, device=dev),
+                     torch.zeros((1, 9), dtype=torch.float64, device=dev))
+    cv = torch.zeros((1, G), dtype=torch.float64, device=dev)
+    for k in range(fx["trajs"].shape[0]):
+        po = learner_params(fx, k + 1)
+        prm = _lib.LearnerParams()
+        for f, _ in prm._fields_:
+            setattr(prm, f, getattr(po, f))
+        traj = _t(fx["trajs"][k][None], dev)
+        cost, _, _ = ops.goalset_cost(robot, m.points_per_link, ds, traj[:, prm.start_idx].contiguous(), cv_goals,
+                                      prm.n_waypoints - prm.start_idx, float(fx["cfg_dt"]))
+        ops.goal_update(prm, traj, goal_set, reach, cost, state, idx, end, rows, gp, cv)
+        np.testing.assert_allclose(cv[0].cpu().numpy(), fx["cost_vectors"][k], rtol=2e-5, atol=1e-7, err_msg=f"cv step {k}")
+        np.testing.assert_allclose(state[0, G:2 * G].cpu().numpy(), fx["p"][k], rtol=1e-4, atol=1e-6, err_msg=f"p step {k}")
+        assert int(idx[0]) == int(fx["goal_idx"][k])
+        np.testing.assert_array_equal(end[0].cpu().numpy(), fx["goal_set"][int(idx[0])])
+        exp_rows = fx["reach_grasps"][int(idx[0])] if standoff else fx["goal_set"][int(idx[0])][None]
+        np.testing.assert_array_equal(rows[0].cpu().numpy(), exp_rows)
+        if str(fx["alg"]) == "MD":
+            np.testing.assert_allclose(state[0, 7 * G:7 * G + 5].cpu().numpy(), fx["q"][k], rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("alg,G", [("MD", 64), ("Exp", 100), ("FTL", 200), ("Proj", 33), ("MD", 130)])
+def test_goal_update_matches_oracle_many_scenes(dev, alg, G):
+    from omg_planner_amd import _lib, ops
+    from oracle import oracle as orc
+    S, n, c = 7, 30, 5
+    rng = np.random.RandomState(G)
+    traj = rng.normal(0, 0.5, size=(S, n, 9))
+    goal_set = rng.normal(0, 0.5, size=(S, G, 9))
+    reach = rng.normal(0, 0.5, size=(S, G, c, 9))
+    po = orc.LearnerParams()
+    po.alg, po.num_goals, po.n_waypoints, po.start_idx, po.constraint_num, po.use_standoff = orc.ALG[alg], G, n, 4, c, 1
+    po.normalize_cost, po.base_obstacle_weight, po.smooth_weight, po.eta = 1, 1.0, 0.01, float(np.sqrt(np.log(G + 1) / 50))
+    pd = _lib.LearnerParams()
+    for f, _ in pd._fields_:
+        setattr(pd, f, getattr(po, f))
+    st_ref = orc.learner_state_init(S, G)
+    st = ops.learner_state(S, G, dev)
+    idx = torch.zeros(S, dtype=torch.int32, device=dev)
+    end, rows, gp = (torch.zeros((S, 9), dtype=torch.float64, device=dev), torch.zeros((S, c, 9), dtype=torch.float64, device=dev),
+                     torch.zeros((S, 9), dtype=torch.float64, device=dev))
+    for step in range(4):
+        gc = rng.gamma(2.0, 2.0, size=(S, G)).astype(np.float32)
+        r_idx, r_end, r_rows, r_gp, _ = orc.goal_update(po, traj, goal_set, reach, gc, st_ref)
+        ops.goal_update(pd, _t(traj, dev), _t(goal_set, dev), _t(reach, dev), _t(gc, dev), st, idx, end, rows, gp)
+        np.testing.assert_array_equal(idx.cpu().numpy(), r_idx)
+        np.testing.assert_allclose(st.cpu().numpy(), st_ref, rtol=1e-5, atol=1e-8)
+        np.testing.assert_array_equal(rows.cpu().numpy(), r_rows)
+        np.testing.assert_array_equal(end.cpu().numpy(), r_end)
