@@ -501,3 +501,146 @@ def test_goal_update_matches_oracle_many_scenes(dev, alg, G):
         np.testing.assert_allclose(st.cpu().numpy(), st_ref, rtol=1e-5, atol=1e-8)
         np.testing.assert_array_equal(rows.cpu().numpy(), r_rows)
         np.testing.assert_array_equal(end.cpu().numpy(), r_end)
+
+
+# ------------------------------------------------------------------------------------------------
+# (7) the whole planner loop: ChompEngine against the same loop driven through the oracle
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("alg,standoff", [("MD", False), ("FTL", True)])
+def test_engine_plan_loop_matches_oracle_loop(dev, alg, standoff):
+    """Planner.plan's loop body (omg/planner.py:612-621) for 4 scenes x 10 iterations: goal selection indices
+    identical, trajectories within 1e-6 of the oracle-driven loop (every oracle piece is pinned to the reference)."""
+    from omg_planner_amd import robot as rb, scenes as sc
+    from omg_planner_amd.config import Config
+    from omg_planner_amd.engine import ChompEngine
+    from oracle import oracle as orc
+    S, G, n, iters = 4, 6, 30, 10
+    cfg = Config(timesteps=n, use_standoff=standoff, optim_steps=12)
+    m = rb.PandaModel(seed=6)
+    P = m.points_per_link
+    scenes, batch = _multi_scene_batch(S)
+    goals = np.stack([sc.make_reach_goals(scenes[s], m, G, s) for s in range(S)])
+    start = np.tile(rb.HOME_CONFIG, (S, 1))
+    c = cfg.reach_tail_length if standoff else 1
+    reach = None
+    if standoff:
+        reach = np.stack([[np.concatenate([sc.linear_init(g - np.array([0.1, -0.05, 0.1, 0.15, 0, -0.1, 0.1, 0, 0]), g, c - 1), g[None]], 0)
+                           for g in goals[s]] for s in range(S)])
+    eng = ChompEngine(m, batch, cfg, start, goals, reach_grasps=reach, device=dev, ol_alg=alg)
+    traj = eng.traj.cpu().numpy().copy()
+    state = orc.learner_state_init(S, G)
+    cfg_o = Config(timesteps=n, use_standoff=standoff, optim_steps=12)
+    cv_goals = reach[:, :, -1, :] if standoff else goals
+    for t in range(iters):
+        eng.iterate(t)
+        # ---- oracle loop
+        if t < cfg_o.optim_steps:
+            lp = orc.LearnerParams()
+            lp.alg, lp.num_goals, lp.n_waypoints = orc.ALG[alg], G, n
+            lp.start_idx = min(int(((t + 1) / cfg_o.optim_steps) * n), n - 1)
+            lp.constraint_num, lp.use_standoff, lp.normalize_cost = c, int(standoff), 1
+            lp.base_obstacle_weight, lp.smooth_weight, lp.eta = 1.0, 0.1 * 0.1, float(np.sqrt(np.log(G + 1) / cfg_o.optim_steps))
+            gc, _ = orc.goalset_cost(m.blob(), P, batch, traj[:, lp.start_idx], cv_goals, n - lp.start_idx, cfg_o.time_interval)
+            idx, end, rows, gp, _ = orc.goal_update(lp, traj, goals, reach, gc, state)
+        k = t + 1
+        po = orc.ChompParams()
+        src = eng._params(True)
+        for f, _ in po._fields_:
+            setattr(po, f, getattr(src, f))
+        po.smoothness_weight = 0.1 * 1.02 ** k
+        pot, pg, col = orc.fk_sdf(m.blob(), P, batch, traj)
+        traj, _, _, info = orc.chomp_optimize(m.blob(), po, traj, start, end, rows, gp, pot, pg, col)
+        np.testing.assert_array_equal(eng.goal_idx.cpu().numpy(), idx, err_msg=f"iteration {t}")
+        np.testing.assert_allclose(eng.traj.cpu().numpy(), traj, rtol=0, atol=1e-6, err_msg=f"iteration {t}")
+        np.testing.assert_allclose(eng.info.cpu().numpy()[:, :10], info[:, :10], rtol=1e-5, atol=1e-6, err_msg=f"iteration {t}")
+
+
+# ------------------------------------------------------------------------------------------------
+# (8) BASELINE config 5 shape (kitchen-like: 50 waypoints, 12 obstacle SDFs incl. a point-cloud SDF) and
+#     full-size properties at BASELINE config 4 size (100 scenes x 128 goals x 30 waypoints)
+# ------------------------------------------------------------------------------------------------
+def _kitchen_scene(seed):
+    from omg_planner_amd import scenes as sc
+    rng = np.random.RandomState(seed)
+    objs = []
+    for i in range(9):
+        g = (24, 20, 16)[i % 3]
+        sdf = sc.sphere_sdf(rng.uniform(0.05, 0.09), (g, g, g), 0.5 / g) if i % 2 else sc.box_sdf(rng.uniform(0.03, 0.1, 3), (g, g, g), 0.5 / g)
+        objs.append(sc.SceneObject(f"obj_{i}", sc._yaw_pose(rng.uniform(0.2, 0.8), rng.uniform(-0.4, 0.4), rng.uniform(0.1, 0.6), rng.uniform(-3, 3)), sdf))
+    cloud = rng.uniform([0.3, -0.3, 0.0], [0.7, 0.3, 0.4], size=(4096, 3))  # PointEnv.compute_sdf_from_points input
+    objs.append(sc.SceneObject("perception/env_points", np.eye(4), sc.point_cloud_sdf(cloud)))
+    objs.append(sc.SceneObject("floor", sc._yaw_pose(0, 0, -0.2, 0), sc.box_sdf((0.4, 0.4, 0.02), (12, 12, 8), 0.1)))
+    objs.append(sc.SceneObject("table", sc._yaw_pose(0.5, 0, 0.02, 0), sc.box_sdf((0.6, 0.4, 0.02), (48, 36, 12), 0.03)))
+    return sc.Scene(objs, target_idx=1)
+
+
+def test_kitchen_config_50_waypoints_12_objects_matches_oracle(dev):
+    from omg_planner_amd import _lib, ops, robot as rb, scenes as sc
+    from omg_planner_amd.config import Config
+    from oracle import oracle as orc
+    S, n, G = 3, 50, 5
+    cfg = Config(use_standoff=False)
+    cfg.get_global_param(n)  # called from the 30-step default state: dt = 0.1 * 30 / 50 = 0.06 (omg/config.py:201)
+    assert abs(cfg.time_interval - 0.06) < 1e-12 and cfg.timesteps == n
+    m = rb.PandaModel(seed=8)
+    P = m.points_per_link
+    scenes = [_kitchen_scene(s) for s in range(S)]
+    batch = sc.pack_table(scenes, cfg.layer_kwargs())
+    assert all(batch.scene_begin[s + 1] - batch.scene_begin[s] == 12 for s in range(S))
+    goals = np.stack([sc.make_reach_goals(scenes[s], m, G, s) for s in range(S)])
+    start = np.tile(rb.HOME_CONFIG, (S, 1))
+    traj = np.stack([sc.cubic_init(start[s], goals[s, 0], n) for s in range(S)])
+    robot, ds = ops.robot_blob(m, dev), ops.DeviceScenes(batch, dev)
+    # goal-set cost with a 37-waypoint window
+    gc_ref, col_ref = orc.goalset_cost(m.blob(), P, batch, traj[:, 13], goals, 37, cfg.time_interval)
+    gc, col, _ = ops.goalset_cost(robot, P, ds, _t(traj[:, 13], dev), _t(goals, dev), 37, cfg.time_interval)
+    np.testing.assert_allclose(gc.cpu().numpy(), gc_ref, rtol=1e-5, atol=1e-6)
+    np.testing.assert_array_equal(col.cpu().numpy(), col_ref)
+    # optimiser steps
+    fx = dict(cfg_top_k=1000, cfg_goal_set_proj=1, cfg_use_standoff=0, cfg_dt=cfg.time_interval)
+    t_dev, t_ref = _t(traj, dev), traj.copy()
+    for step in (1, 2, 3):
+        po = H.params_from(fx, orc.ChompParams, n, P, 1, 1.0, 0.1 * 1.02 ** step)
+        pd = H.params_from(fx, _lib.ChompParams, n, P, 1, 1.0, 0.1 * 1.02 ** step)
+        rp, rg, rc = orc.fk_sdf(m.blob(), P, batch, t_ref)
+        t_ref, g_ref, _, i_ref = orc.chomp_optimize(m.blob(), po, t_ref, start, goals[:, 0], goals[:, :1], goals[:, 0], rp, rg, rc)
+        pot, pg, cl = ops.fk_sdf(robot, P, ds, t_dev)
+        assert (pot.cpu().numpy() == rp).mean() > 0.999
+        g, _, info = ops.chomp_optimize(robot, pd, t_dev, _t(start, dev), _t(goals[:, 0], dev), _t(goals[:, :1], dev),
+                                        _t(goals[:, 0], dev), pot, pg, cl)
+        np.testing.assert_allclose(t_dev.cpu().numpy(), t_ref, rtol=0, atol=1e-7)
+        np.testing.assert_allclose(info.cpu().numpy()[:, :10], i_ref[:, :10], rtol=1e-6, atol=1e-6)
+    assert i_ref[:, 8].max() > 0  # the scene really collides somewhere
+
+
+def test_goalset_full_size_properties(dev):
+    """BASELINE config 4 size on one GPU: 100 scenes x 128 goals x 30 waypoints = 57.6 M points per launch.
+    Size-independent properties: run-to-run identical (no atomics), duplicated goals get identical costs,
+    permuting the goals permutes the costs, the per-goal cost equals the in-order sum of its potentials."""
+    from omg_planner_amd import ops, robot as rb, scenes as sc
+    from omg_planner_amd.config import Config
+    S, G, n = 100, 128, 30
+    cfg = Config(timesteps=n, use_standoff=False)
+    m = rb.PandaModel(seed=0)
+    P = m.points_per_link
+    scenes = [sc.make_tabletop_scene(s, grid=32, table_grid=(64, 48, 16)) for s in range(S)]
+    batch = sc.pack_table(scenes, cfg.layer_kwargs())
+    goals = np.stack([sc.make_reach_goals(scenes[s], m, G, s) for s in range(S)])
+    goals[:, 7] = goals[:, 3]  # a duplicated goal
+    start = np.tile(rb.HOME_CONFIG, (S, 1))
+    ts = np.stack([sc.cubic_init(start[s], goals[s, 0], n)[0] for s in range(S)])
+    robot, ds = ops.robot_blob(m, dev), ops.DeviceScenes(batch, dev)
+    c1, k1, _ = ops.goalset_cost(robot, P, ds, _t(ts, dev), _t(goals, dev), n, 0.1)
+    c1, k1 = c1.clone(), k1.clone()
+    c2, k2, _ = ops.goalset_cost(robot, P, ds, _t(ts, dev), _t(goals, dev), n, 0.1)
+    assert torch.equal(c1, c2) and torch.equal(k1, k2)
+    assert torch.equal(c1[:, 7], c1[:, 3])
+    perm = np.random.RandomState(0).permutation(G)
+    c3, _, _ = ops.goalset_cost(robot, P, ds, _t(ts, dev), _t(goals[:, perm], dev), n, 0.1)
+    assert torch.equal(c3, c1[:, torch.from_numpy(perm).to(dev)])
+    # potentials of a slice of scenes: per-goal cost == sum over its [n,10,P] potentials (float32, loose order tolerance)
+    sub = sc.SceneBatch(batch.objects[: batch.scene_begin[8]].copy(), batch.scene_begin[:9].copy(), batch.pool)
+    c4, _, pots = ops.goalset_cost(robot, P, ops.DeviceScenes(sub, dev), _t(ts[:8], dev), _t(goals[:8], dev), n, 0.1, want_potentials=True)
+    assert torch.equal(c4, c1[:8])
+    np.testing.assert_allclose(pots.double().sum(dim=(2, 3, 4)).cpu().numpy(), c4.double().cpu().numpy(), rtol=2e-6, atol=1e-6)
+    assert float((c1 > 0).float().mean()) > 0.9
