@@ -173,14 +173,13 @@ def main():
         step()
     torch.cuda.synchronize()
     costs = torch.cat([e.final_costs() for e in engines])
-    if world > 1:
-        import torch.distributed as dist
-        allc = torch.empty(world * S, dtype=costs.dtype, device=dev)
-        dist.all_gather_into_tensor(allc, costs)  # the job's one collective (RCCL over xGMI)
+    from omg_planner_amd.engine import gather_costs_equal
+    allc = gather_costs_equal(costs, world)  # the job's one collective (RCCL all-gather over xGMI)
     barrier()
     elapsed = time.perf_counter() - t0
     buf = (C.c_float * 4096)()
-    nrec = lib.omgx_timing_collect(buf, 4096)
+    kinds = (C.c_int32 * 4096)()
+    nrec = lib.omgx_timing_collect(buf, kinds, 4096)
     lib.omgx_timing_enable(0)
     if world > 1:
         import torch.distributed as dist
@@ -199,9 +198,9 @@ def main():
 
     if rank == 0:
         durs = np.array([buf[i] for i in range(nrec)], dtype=np.float64)
-        # launches alternate: goal-set batch (dominant), waypoint batch
-        goal_ms = durs[0::2] if nrec >= 2 else durs
-        wp_ms = durs[1::2]
+        kind = np.array([kinds[i] for i in range(nrec)])
+        goal_ms = durs[kind == 0]  # potentials-only variant = the goal-set batch (dominant kernel)
+        wp_ms = durs[kind == 1]    # gradient variant = the waypoint batch of the optimiser step
         O_active = 5
         pts_per_launch = engines[0].S * G * n * 10 * model.points_per_link
         alg_bytes = pts_per_launch * (32 + 128 * O_active)  # N (32 + 128 O_active)

@@ -298,9 +298,11 @@ int omgx_goal_update(const omgx_learner_params* h_params, const double* traj, co
 const char* omgx_last_error(void); /* thread-local text of the last OMGX_ERR_LAUNCH               */
 /* Measurement hook (bench.py): while enabled, every launch of the SDF kernel behind omgx_fk_sdf /
  * omgx_goalset_cost is bracketed by HIP events on its own stream.  omgx_timing_collect waits for them,
- * writes the per-launch durations (ms) to h_ms[0..cap) and returns how many; not for graph capture. */
+ * writes the per-launch durations (ms) to h_ms[0..cap) and the variant to h_kind (0 = potentials only, i.e. the
+ * goal-set batch; 1 = with gradients, i.e. the waypoint batch; may be NULL) and returns how many;
+ * not for graph capture. */
 int omgx_timing_enable(int32_t on);
-int omgx_timing_collect(float* h_ms, int32_t cap);
+int omgx_timing_collect(float* h_ms, int32_t* h_kind, int32_t cap);
 int omgx_abi_version(void);        /* bumps when a signature or struct layout changes              */
 int omgx_device_arch(char* h_buf, int32_t h_len); /* writes gcnArchName of the current device      */
 

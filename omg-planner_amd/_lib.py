@@ -82,7 +82,7 @@ def lib() -> C.CDLL:
         l.omgx_last_error.restype = C.c_char_p
         l.omgx_device_arch.argtypes = [C.c_char_p, i32]
         l.omgx_timing_enable.argtypes = [i32]
-        l.omgx_timing_collect.argtypes = [C.POINTER(C.c_float), i32]
+        l.omgx_timing_collect.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_int32), i32]
         for name in ("omgx_sdf_loss_forward", "omgx_fk_sdf", "omgx_forward_kinematics", "omgx_goalset_cost", "omgx_chomp_optimize",
                      "omgx_abi_version", "omgx_device_arch", "omgx_timing_enable", "omgx_timing_collect"):
             getattr(l, name).restype = C.c_int

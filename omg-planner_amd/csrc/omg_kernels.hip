@@ -349,6 +349,7 @@ static bool g_timing = false;
 static int g_timing_n = 0;
 static hipEvent_t g_ev[OMGX_TIMING_CAP][2];
 static bool g_ev_made[OMGX_TIMING_CAP];
+static int g_ev_kind[OMGX_TIMING_CAP];  // 0 = potentials-only variant (goal-set batch), 1 = gradient variant (waypoints)
 
 extern "C" int omgx_timing_enable(int32_t on) {
     g_timing = on != 0;
@@ -357,9 +358,10 @@ extern "C" int omgx_timing_enable(int32_t on) {
 }
 
 // Waits for the recorded launches and writes their durations in milliseconds; returns the count.
-extern "C" int omgx_timing_collect(float* h_ms, int32_t cap) {
+extern "C" int omgx_timing_collect(float* h_ms, int32_t* h_kind, int32_t cap) {
     int n = g_timing_n < cap ? g_timing_n : cap;
     for (int i = 0; i < n; ++i) {
+        if (h_kind) h_kind[i] = g_ev_kind[i];
         hipError_t e = hipEventSynchronize(g_ev[i][1]);
         if (e != hipSuccess) return omgx_set_error("hipEventSynchronize", e);
         e = hipEventElapsedTime(&h_ms[i], g_ev[i][0], g_ev[i][1]);
@@ -445,7 +447,7 @@ static int launch_chunks(ChunkArgs& ca, hipStream_t st) {
     const int64_t grid = (int64_t)scene_groups * ca.NCH * 8 * (10 / lpw);
     if (grid > 0x7fffffff) return OMGX_ERR_UNSUPPORTED;
     const int slot = timing_slot();
-    if (slot >= 0) (void)hipEventRecord(g_ev[slot][0], st);
+    if (slot >= 0) { g_ev_kind[slot] = ca.grad ? 1 : 0; (void)hipEventRecord(g_ev[slot][0], st); }
     static int lb = -1;  // links per batch; OMGX_LB overrides the tuned default (tuning aid)
     if (lb < 0) { const char* e = getenv("OMGX_LB"); lb = e ? atoi(e) : 2; }
     int lbu = lb;

@@ -97,6 +97,11 @@ class ChompEngine:
         self.active = torch.ones(S, dtype=torch.int32, device=dev)
         self.step_count = 0  # Optimizer.step
         self.t = 0           # Learner.t
+        # The waypoint SDF batch (omgx_fk_sdf on traj) does not depend on the goal selection, only k_chomp_optimize
+        # does: it runs on a side stream concurrently with the goal-set batch + goal update and joins before the step.
+        self.side_stream = torch.cuda.Stream(device=dev)
+        self._ev_fork = torch.cuda.Event()
+        self._ev_join = torch.cuda.Event()
         self._gather_goal()
 
     # ---------------------------------------------------------------------------------------------
@@ -173,25 +178,45 @@ class ChompEngine:
         ops.goal_update(prm, self.traj, self.goal_set, self.reach, self.goal_cost, self.learner_state, self.goal_idx,
                         self.end, self.goal_rows, self.goal_point, self.cost_vec)
 
-    def optimize(self, do_update: bool = True):
-        """Optimizer.optimize(traj, force_update=True) (omg/optimizer.py:115-135) for all scenes."""
-        self._schedule()
+    def _layer(self):
+        """SDF layer outputs of the current waypoints (first half of Cost.compute_total_loss)."""
         ops.fk_sdf(self.robot, self.P, self.scenes, self.traj, soften_fingers=self.cfg.uncheck_finger_collision == -1,
                    out=(self.pot, self.pgrad, self.col))
+
+    def _step(self, do_update: bool):
         ops.chomp_optimize(self.robot, self._params(do_update), self.traj, self.start, self.end, self.goal_rows,
                            self.goal_point, self.pot, self.pgrad, self.col, active=self.active,
                            out=(self.grad, self.cost_traj, self.info))
         return self.info
 
-    def iterate(self, t: int, early_stop: bool = False):
+    def optimize(self, do_update: bool = True):
+        """Optimizer.optimize(traj, force_update=True) (omg/optimizer.py:115-135) for all scenes."""
+        self._schedule()
+        self._layer()
+        return self._step(do_update)
+
+    def iterate(self, t: int, early_stop: bool = False, overlap: bool = True):
         """One pass of the planner loop body (planner.py:612-621) over all scenes."""
         if self.stream is not None and torch.cuda.current_stream(self.device) != self.stream:
             with torch.cuda.stream(self.stream):
-                return self.iterate(t, early_stop)
+                return self.iterate(t, early_stop, overlap)
         cfg = self.cfg
-        if cfg.goal_set_proj and t < cfg.optim_steps:
+        select = cfg.goal_set_proj and t < cfg.optim_steps
+        if select and overlap:
+            main = torch.cuda.current_stream(self.device)
+            self._ev_fork.record(main)
+            self.side_stream.wait_event(self._ev_fork)
+            with torch.cuda.stream(self.side_stream):
+                self._layer()
+                self._ev_join.record(self.side_stream)
             self.update_goal()
-        self.optimize(True)
+            self._schedule()
+            main.wait_event(self._ev_join)
+            self._step(True)
+        else:
+            if select:
+                self.update_goal()
+            self.optimize(True)
         if early_stop and t > 0:  # planner.py:627: terminated scenes stop iterating
             self.active = self.active * (self.info[:, 10] < 0.5).to(torch.int32)
 
@@ -205,6 +230,16 @@ class ChompEngine:
 
     def final_costs(self) -> torch.Tensor:
         return self.info[:, 0].contiguous()
+
+
+def gather_costs_equal(local_costs: torch.Tensor, world: int) -> torch.Tensor:
+    """All-gather for equal-sized shards (bench.py's weak-scaling layout): one collective, no host sync."""
+    if world == 1:
+        return local_costs
+    import torch.distributed as dist
+    out = torch.empty(world * local_costs.numel(), dtype=local_costs.dtype, device=local_costs.device)
+    dist.all_gather_into_tensor(out, local_costs.contiguous())
+    return out
 
 
 def gather_costs(local_costs: torch.Tensor, world: int) -> torch.Tensor:

@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from omg_planner_amd.engine import gather_costs, shard_range
+from omg_planner_amd.engine import gather_costs, gather_costs_equal, shard_range
 
 
 def test_shard_range_partitions_exactly():
@@ -61,6 +61,8 @@ def _worker(rank, world, port, total, out_dir):
     local = torch.from_numpy(_scene_costs(mine))
     allc = gather_costs(local, world)
     np.save(os.path.join(out_dir, f"rank{rank}.npy"), allc.numpy())
+    eq = gather_costs_equal(torch.full((3,), float(rank), dtype=torch.float64), world)  # bench.py's equal-shard path
+    np.save(os.path.join(out_dir, f"eq{rank}.npy"), eq.numpy())
     dist.destroy_process_group()
 
 
@@ -74,3 +76,4 @@ def test_sharded_costs_gathered_over_gloo_equal_single_process(tmp_path):
     for r in range(world):
         got = np.load(tmp_path / f"rank{r}.npy")
         np.testing.assert_allclose(got, ref, rtol=0, atol=1e-12)  # scenes are independent: sharding changes nothing
+        np.testing.assert_array_equal(np.load(tmp_path / f"eq{r}.npy"), np.repeat(np.arange(world, dtype=np.float64), 3))
