@@ -28,23 +28,22 @@ class Optimizer(object):
         self.time_elapsed = time.time()
 
     def report(self, curve, info):
-        """Debug text (omg/optimizer.py:23-57)."""
-        text = []
-        if self.cfg.report_cost:
-            text = [
-                "=================================================",
-                "step: {:.2f}, time: {:.2f}, lr: {:.5f}, collide: {}".format(self.step, self.time_elapsed, self.cfg.step_size, info["collide"]),
-                "joint limit: {:.2f}/{:.2f}, {:.2f}/{:.2f}, violate: {} reach: {:.2f} timestep {}".format(
-                    curve.min(), np.min(self.joint_lower_limit), curve.max(), np.max(self.joint_upper_limit),
-                    info["violate_limit"], info["reach"], self.cfg.timesteps),
-                "obs:{:.2f}, smooth:{:.2f}, grasp:{:.2f} total:{:.2f} ".format(info["obs"], info["smooth"], info["grasp"], info["cost"]),
-                "obs_grad:{:.2f}, smooth_grad:{:.2f}, grasp_grad:{:.2f} total_grad:{:.2f}".format(
-                    info["weighted_obs_grad"], info["weighted_smooth_grad"], info["weighted_grasp_grad"], info["grad"]),
-                "=================================================",
-            ]
-            for t in text:
-                print(t)
-        return text
+        """Debug text when cfg.report_cost is set (the role of omg/optimizer.py:23-57); returns the lines."""
+        if not self.cfg.report_cost:
+            return []
+        bar = "=" * 49
+        lines = [
+            bar,
+            f"step: {self.step:.2f}, time: {self.time_elapsed:.2f}, lr: {self.cfg.step_size:.5f}, collide: {info['collide']}",
+            f"joint limit: {curve.min():.2f}/{np.min(self.joint_lower_limit):.2f}, {curve.max():.2f}/{np.max(self.joint_upper_limit):.2f}, "
+            f"violate: {info['violate_limit']} reach: {info['reach']:.2f} timestep {self.cfg.timesteps}",
+            f"obs:{info['obs']:.2f}, smooth:{info['smooth']:.2f}, grasp:{info['grasp']:.2f} total:{info['cost']:.2f} ",
+            f"obs_grad:{info['weighted_obs_grad']:.2f}, smooth_grad:{info['weighted_smooth_grad']:.2f}, "
+            f"grasp_grad:{info['weighted_grasp_grad']:.2f} total_grad:{info['grad']:.2f}",
+            bar,
+        ]
+        print("\n".join(lines))
+        return lines
 
     def update(self):
         """Weight / step-size schedules, written into cfg like the reference (omg/optimizer.py:59-80)."""
