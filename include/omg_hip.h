@@ -293,6 +293,18 @@ int omgx_goal_update(const omgx_learner_params* h_params, const double* traj, co
                      void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * (6) omgx_point_cloud_sdf
+ * Replaces the distance query of PointEnv.compute_sdf_from_points (omg/core.py:426-457): the workspace grid
+ * np.arange(lo[a], hi[a], resolution) per axis ("ij" meshgrid), value = Euclidean distance from each grid node to
+ * the nearest of the N perceived points (scipy cKDTree.query, k=1, p=2) — unsigned, float64 arithmetic, stored as
+ * the float32 grid SignedDensityField.data_torch holds (omg/sdf_tools.py:31), x-major like every other grid.
+ *   points [N,3] double;  origin[3] = bounds_min - margin;  dims[3] = len(np.arange(...)) per axis;
+ *   node (i,j,k) sits at origin + (i,j,k) * resolution (np.arange's start + i*step).   out [X,Y,Z] float32.
+ * ------------------------------------------------------------------------------------------- */
+int omgx_point_cloud_sdf(const double* points, int32_t num_points, const double* h_origin, double resolution,
+                         const int32_t* h_dims, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Diagnostics
  * ------------------------------------------------------------------------------------------- */
 const char* omgx_last_error(void); /* thread-local text of the last OMGX_ERR_LAUNCH               */

@@ -18,7 +18,7 @@ NUM_DOF, INFO_STRIDE = 9, 16
 # every symbol include/omg_hip.h declares
 EXPORTS = ["omgx_sdf_loss_forward", "omgx_fk_sdf_workspace_bytes", "omgx_fk_sdf", "omgx_forward_kinematics",
            "omgx_goalset_workspace_bytes", "omgx_goalset_cost", "omgx_chomp_aux_doubles", "omgx_chomp_optimize",
-           "omgx_learner_state_doubles", "omgx_goal_update", "omgx_last_error", "omgx_abi_version", "omgx_device_arch",
+           "omgx_learner_state_doubles", "omgx_goal_update", "omgx_point_cloud_sdf", "omgx_last_error", "omgx_abi_version", "omgx_device_arch",
            "omgx_timing_enable", "omgx_timing_collect"]
 
 
@@ -79,6 +79,8 @@ def lib() -> C.CDLL:
         l.omgx_learner_state_doubles.restype = i64
         l.omgx_goal_update.argtypes = [C.POINTER(LearnerParams)] + [vp] * 5 + [i32] + [vp] * 5 + [vp]
         l.omgx_goal_update.restype = C.c_int
+        l.omgx_point_cloud_sdf.argtypes = [vp, i32, C.POINTER(C.c_double), f64, C.POINTER(i32), vp, vp]
+        l.omgx_point_cloud_sdf.restype = C.c_int
         l.omgx_last_error.restype = C.c_char_p
         l.omgx_device_arch.argtypes = [C.c_char_p, i32]
         l.omgx_timing_enable.argtypes = [i32]

@@ -413,6 +413,48 @@ extern "C" int omgx_sdf_loss_forward(const float* pose_init, const float* sdf_gr
     return OMGX_OK;
 }
 
+// =================================================================================================
+// (6) k_point_cloud_sdf — nearest-point distance grid (PointEnv.compute_sdf_from_points, omg/core.py:426-457)
+// =================================================================================================
+// One thread per grid node; the point cloud streams through LDS in tiles of 1024 points (24 KiB), every lane
+// reading the same point at a time (LDS broadcast).  fp64 like the reference's cKDTree query.
+#define PCS_TILE 1024
+__global__ __launch_bounds__(256) void k_point_cloud_sdf(const double* __restrict__ pts, int N, double ox, double oy, double oz,
+                                                          double res, int dx, int dy, int dz, float* __restrict__ out) {
+#pragma clang fp contract(off)
+    __shared__ double tile[PCS_TILE * 3];
+    const int64_t total = (int64_t)dx * dy * dz;
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t idc = id < total ? id : total - 1;
+    const int k = (int)(idc % dz), j = (int)((idc / dz) % dy), i = (int)(idc / ((int64_t)dz * dy));
+    const double x = ox + (double)i * res, y = oy + (double)j * res, z = oz + (double)k * res;  // np.arange: start + i*step
+    double best = 1.0e300;
+    for (int t0 = 0; t0 < N; t0 += PCS_TILE) {
+        const int cnt = min(PCS_TILE, N - t0);
+        __syncthreads();
+        for (int e = threadIdx.x; e < cnt * 3; e += blockDim.x) tile[e] = pts[(int64_t)t0 * 3 + e];
+        __syncthreads();
+        for (int q = 0; q < cnt; ++q) {
+            const double a = tile[3 * q] - x, b = tile[3 * q + 1] - y, c = tile[3 * q + 2] - z;
+            const double d2 = (a * a + b * b) + c * c;
+            best = d2 < best ? d2 : best;
+        }
+    }
+    if (id < total) out[id] = (float)sqrt(best);
+}
+
+extern "C" int omgx_point_cloud_sdf(const double* points, int32_t num_points, const double* h_origin, double resolution,
+                                    const int32_t* h_dims, float* out, void* stream) {
+    if (!points || !h_origin || !h_dims || !out || num_points < 1 || !(resolution > 0.0)) return OMGX_ERR_INVALID;
+    if (h_dims[0] < 1 || h_dims[1] < 1 || h_dims[2] < 1) return OMGX_ERR_INVALID;
+    const int64_t total = (int64_t)h_dims[0] * h_dims[1] * h_dims[2];
+    if (total > (int64_t)1 << 31) return OMGX_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(k_point_cloud_sdf, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, points,
+                       num_points, h_origin[0], h_origin[1], h_origin[2], resolution, h_dims[0], h_dims[1], h_dims[2], out);
+    OMGX_CHECK_LAUNCH("k_point_cloud_sdf");
+    return OMGX_OK;
+}
+
 // ---- workspace sizing -------------------------------------------------------------------------
 // 16 configurations per workgroup: one row per configuration, more workgroups for small batches
 static inline int chunk_configs_fk_sdf(int C) { return C < 16 ? C : 16; }

@@ -173,3 +173,20 @@ def goal_update(params: LearnerParams, traj, goal_set, reach, goal_cost, state, 
         check(_lib.lib().omgx_goal_update(C.byref(params), _ptr(traj), _ptr(goal_set), _ptr(reach), _ptr(goal_cost), _ptr(state),
                                           traj.shape[0], _ptr(goal_idx), _ptr(end), _ptr(goal_rows), _ptr(goal_point),
                                           _ptr(cost_vector), _stream()), "omgx_goal_update")
+
+
+def point_cloud_sdf(points: torch.Tensor, grid_resolution: float = 0.02, margin: float = 0.24):
+    """PointEnv.compute_sdf_from_points (omg/core.py:426-457) on the device: points [N,3] f64 (robot base frame) ->
+    (grid float32 [X,Y,Z] of nearest-point distances, origin [3] float64 numpy, resolution).  The workspace bounds
+    are the cloud's bounding box +- margin and the nodes np.arange(lo, hi, resolution), as in the reference."""
+    _need(points, torch.float64, "points")
+    lo = points.min(0).values.cpu().numpy() - margin
+    hi = points.max(0).values.cpu().numpy() + margin
+    dims = np.array([len(np.arange(lo[a], hi[a], grid_resolution)) for a in range(3)], np.int32)
+    out = torch.empty(tuple(int(d) for d in dims), dtype=torch.float32, device=points.device)
+    origin = np.ascontiguousarray(lo, np.float64)
+    with torch.cuda.device(points.device):
+        check(_lib.lib().omgx_point_cloud_sdf(_ptr(points), points.shape[0], origin.ctypes.data_as(C.POINTER(C.c_double)),
+                                              float(grid_resolution), dims.ctypes.data_as(C.POINTER(C.c_int32)), _ptr(out),
+                                              _stream()), "omgx_point_cloud_sdf")
+    return out, origin, float(grid_resolution)

@@ -857,6 +857,26 @@ int orc_goal_update(const omgx_learner_params* prm, const double* traj, const do
     return 0;
 }
 
+/* =============================================================================================
+ * 7. Point-cloud SDF — PointEnv.compute_sdf_from_points, omg/core.py:426-457 (cKDTree.query k=1, p=2, brute force here)
+ * =========================================================================================== */
+int orc_point_cloud_sdf(const double* points, int32_t N, const double* origin, double res, const int32_t* dims, float* out) {
+    const int64_t total = (int64_t)dims[0] * dims[1] * dims[2];
+#pragma omp parallel for schedule(static)
+    for (int64_t id = 0; id < total; ++id) {
+        const int k = (int)(id % dims[2]), j = (int)((id / dims[2]) % dims[1]), i = (int)(id / ((int64_t)dims[2] * dims[1]));
+        const double x = origin[0] + (double)i * res, y = origin[1] + (double)j * res, z = origin[2] + (double)k * res;
+        double best = 1.0e300;
+        for (int q = 0; q < N; ++q) {
+            const double a = points[3 * q] - x, b = points[3 * q + 1] - y, c = points[3 * q + 2] - z;
+            const double d2 = (a * a + b * b) + c * c;
+            if (d2 < best) best = d2;
+        }
+        out[id] = (float)sqrt(best);
+    }
+    return 0;
+}
+
 /* Exposed pieces for fine-grained golden checks. */
 void orc_points_of_config(const double* robot, int32_t P, const double* q, double* x /*[10][P][3]*/) {
     double pose[160];

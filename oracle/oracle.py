@@ -65,7 +65,7 @@ def lib() -> C.CDLL:
     if _lib is None:
         build()
         _lib = C.CDLL(str(_SO))
-        for name in ("orc_sdf_loss_forward", "orc_fk_sdf", "orc_goalset_cost", "orc_chomp_optimize", "orc_goal_update",
+        for name in ("orc_sdf_loss_forward", "orc_fk_sdf", "orc_goalset_cost", "orc_chomp_optimize", "orc_goal_update", "orc_point_cloud_sdf",
                      "orc_sizeof_object", "orc_sizeof_params", "orc_sizeof_learner_params"):
             getattr(_lib, name).restype = C.c_int
         for name in ("orc_fk_batch", "orc_smooth_matrices", "orc_points_of_config"):
@@ -203,3 +203,14 @@ def goal_update(params: LearnerParams, traj, goal_set, reach, goal_cost, state):
                                _p(end, C.c_double), _p(rows, C.c_double), _p(gp, C.c_double), _p(cv, C.c_double))
     assert rc == 0, rc
     return idx, end, rows, gp, cv
+
+
+def point_cloud_sdf(points, origin, resolution, dims):
+    """-> float32 [X,Y,Z] nearest-point distance grid (PointEnv.compute_sdf_from_points)."""
+    points, origin = _f64(points), _f64(origin)
+    dims = np.ascontiguousarray(dims, np.int32)
+    out = np.zeros(tuple(int(d) for d in dims), np.float32)
+    rc = lib().orc_point_cloud_sdf(_p(points, C.c_double), C.c_int32(points.shape[0]), _p(origin, C.c_double), C.c_double(resolution),
+                                   _p(dims, C.c_int32), _p(out, C.c_float))
+    assert rc == 0
+    return out

@@ -644,3 +644,34 @@ def test_goalset_full_size_properties(dev):
     assert torch.equal(c4, c1[:8])
     np.testing.assert_allclose(pots.double().sum(dim=(2, 3, 4)).cpu().numpy(), c4.double().cpu().numpy(), rtol=2e-6, atol=1e-6)
     assert float((c1 > 0).float().mean()) > 0.9
+
+
+# ------------------------------------------------------------------------------------------------
+# (9) omgx_point_cloud_sdf — PointEnv.compute_sdf_from_points (BASELINE config 5 input path)
+# ------------------------------------------------------------------------------------------------
+def test_point_cloud_sdf_matches_oracle_and_feeds_the_sdf_layer(dev):
+    from omg_planner_amd import ops, scenes as sc
+    from oracle import oracle as orc
+    from tests.test_oracle_pointcloud import reference_grid
+    rng = np.random.RandomState(3)
+    pts = rng.uniform([0.3, -0.3, 0.0], [0.7, 0.3, 0.4], size=(4096, 3))
+    ref, origin, dims = reference_grid(pts)  # scipy cKDTree, as the reference calls it
+    grid, org, res = ops.point_cloud_sdf(_t(pts, dev))
+    torch.cuda.synchronize()
+    g = grid.cpu().numpy()
+    assert g.shape == ref.shape and np.array_equal(org, origin)
+    np.testing.assert_array_equal(g, orc.point_cloud_sdf(pts, origin, 0.02, dims))  # same arithmetic: bit-exact vs oracle
+    assert (g == ref).mean() > 0.9999
+    np.testing.assert_allclose(g, ref, rtol=0, atol=1e-7)
+    # the device-built grid is a valid obstacle for the SDF layer: same potentials as with the host-built grid
+    host = sc.point_cloud_sdf(pts)
+    np.testing.assert_allclose(host.data, ref, rtol=0, atol=0)
+    q = np.random.RandomState(4).uniform([0.2, -0.4, 0.0], [0.8, 0.4, 0.5], size=(20000, 3)).astype(np.float32)
+    def layer(data):
+        scene = sc.Scene([sc.SceneObject("perception/env_points", np.eye(4), sc.SdfGrid(data, origin, 0.02))], 0)
+        sdf, lim = sc.pack_padded(scene.objects)
+        poses, eps, pad, clr, dis = sc.layer_params(scene, **H.LAYER_CFG)
+        return ops.sdf_loss_forward(*[_t(a, dev) for a in (poses, sdf, lim, q, eps, pad, clr, dis)])
+    a, b = layer(g), layer(ref)
+    assert float((a[0] > 0).float().mean()) > 0.3
+    np.testing.assert_allclose(a[0].cpu().numpy(), b[0].cpu().numpy(), rtol=0, atol=1e-6)
