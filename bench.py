@@ -206,10 +206,11 @@ def main():
         alg_bytes = pts_per_launch * (32 + 128 * O_active)  # N (32 + 128 O_active)
         avg_ms = float(goal_ms.mean()) if len(goal_ms) else float("nan")
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, valu_busy, l2_hit = None, None, None
         tfile = ROOT / "profiles" / "traffic.json"
-        if tfile.exists():
-            traffic = json.loads(tfile.read_text()).get("k_sdf_chunks_goalset_bytes_per_launch")
+        if tfile.exists():  # PMC numbers of the same command, collected by tools/collect_profiles.sh
+            tj = json.loads(tfile.read_text())
+            traffic, valu_busy, l2_hit = tj.get("k_sdf_chunks_goalset_bytes_per_launch"), tj.get("valu_busy_frac"), tj.get("l2_hit_rate")
         out = {
             "metric": "CHOMP iterations/sec (batched scenes)",
             "value": world * S * args.steps / elapsed,
@@ -230,7 +231,12 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_sdf_chunks<false> (goal-set batch)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": avg_ms, "launches": int(len(goal_ms)), "algorithmic_bytes_per_launch": alg_bytes,
-                         "waypoint_launch_avg_ms": float(wp_ms.mean()) if len(wp_ms) else None},
+                         "waypoint_launch_avg_ms": float(wp_ms.mean()) if len(wp_ms) else None,
+                         "pairs_per_s": pts_per_launch * O_active / (avg_ms * 1e-3), "valu_busy_frac_pmc": valu_busy,
+                         "l2_hit_rate_pmc": l2_hit,
+                         "note": "frac > 1: the algorithmic figure charges the reference's 56 loads to every (point, object) pair; "
+                                 "the kernel retires 83% of pairs before any load and the rest hit L2, so it is VALU/latency-bound "
+                                 "(see DESIGN.md section 5)"},
         }
         if ms_per_plan is not None:
             out["ms_per_plan"] = ms_per_plan

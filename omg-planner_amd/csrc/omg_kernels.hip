@@ -193,6 +193,9 @@ struct ChunkArgs {
     float* col;             // [S][C][10][P] or null
     float* chunk_cost;      // [S][NCH] or null: sum of (weighted) potentials of the chunk
     float* chunk_col;       // [S][NCH] or null: sum of collides of the chunk
+    // fused FK (goal-set batch): the workgroup computes its own link poses into LDS instead of reading ws
+    const double* traj_start;  // [S][9]
+    const double* goals;       // [S][NCH][9]
 };
 
 // Thread layout: 256 threads = 16 rows x 16 lanes.  Lane = collision point p of a link (P <= 16), row =
@@ -203,8 +206,13 @@ struct ChunkArgs {
 // The point itself is x = R_link p' + t_link (double, rounded to float32) from the FK kernel's pose
 // (96 bytes shared by the 16 lanes of a row) and the centred collision point of the robot blob.
 // No integer division by run-time sizes anywhere.
-template <bool WANT_GRAD, int LB>
+// FUSED (goal-set batch only): chunk = goal, its CH = n_remaining configurations are the linear interpolation
+// start + (i+1)/(n+1) (goal - start) (util.py:261-290) and the workgroup runs their FK itself (one lane per
+// configuration, plus the start configuration) into dynamic LDS [(CH+1)][10][12] — no pose workspace round trip
+// through HBM and no separate FK launch.
+template <bool WANT_GRAD, int LB, bool FUSED>
 __global__ __launch_bounds__(256) void k_sdf_chunks(ChunkArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double lds_pose[];
     __shared__ float red[2][4];
     __shared__ uint32_t rowmask[10 * OMGX_MAX_WAYPOINTS];  // candidate objects of each row (link, config)
     // XCD-aware placement: workgroup b runs on XCD b % 8 (observed; used for L2 affinity only).
@@ -222,8 +230,29 @@ __global__ __launch_bounds__(256) void k_sdf_chunks(ChunkArgs a) {
     const int nvalid = min(CH, a.C - chunk * CH);  // configs in this (possibly last, partial) chunk
     const int p = threadIdx.x & 15, r = threadIdx.x >> 4;
     const RobotView rv(a.robot, P);
-    const double* base = a.ws + ((int64_t)s * a.NCH + chunk) * (int64_t)(10 * CH) * 12;
-    const double* sbase = a.arc ? a.ws_start + (int64_t)s * 120 : nullptr;
+    if (FUSED) {
+        for (int cfg = threadIdx.x; cfg < CH + 1; cfg += 256) {
+            const double* q0 = a.traj_start + 9 * (int64_t)s;
+            const double* qg = a.goals + ((int64_t)s * a.NCH + chunk) * 9;
+            const double t = (double)cfg / (double)(CH + 1);  // cfg 0 = start itself, cfg i+1 = linspace(0,1,n+2)[1:-1][i]
+            double q[9];
+#pragma unroll
+            for (int d = 0; d < 9; ++d) q[d] = cfg == 0 ? q0[d] : q0[d] + t * (qg[d] - q0[d]);
+            fk_chain(rv, q, [&](int l, const Pose& pose) {
+                // layout [link][config][12] (config 0 = start) so that phase B indexes like the workspace
+                double* dst = lds_pose + ((size_t)l * (CH + 1) + cfg) * 12;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) dst[k] = pose.R[k];
+                dst[9] = pose.t[0]; dst[10] = pose.t[1]; dst[11] = pose.t[2];
+            });
+        }
+        __syncthreads();
+    }
+    // pose of (link l, config ci): FUSED -> LDS [l][ci+1]; else workspace [l][ci]
+    const double* base = FUSED ? lds_pose + 12 : a.ws + ((int64_t)s * a.NCH + chunk) * (int64_t)(10 * CH) * 12;
+    const int pstride = FUSED ? (CH + 1) : CH;  // configs per link in the pose array
+    const double* sbase = FUSED ? lds_pose : (a.arc ? a.ws_start + (int64_t)s * 120 : nullptr);
+    const int sstride = FUSED ? (CH + 1) * 12 : 12;  // distance between the start poses of consecutive links
 
     // ---- phase A: row-level culling.  All P points of a row lie in the ball (link origin, RAD[l]); an object
     // whose far box (grown by that radius + 1e-4 m for float rounding) misses the ball centre on any axis
@@ -232,7 +261,7 @@ __global__ __launch_bounds__(256) void k_sdf_chunks(ChunkArgs a) {
         const int l = row / CH, ci = row - l * CH;
         uint32_t m = 0;
         if (ci < nvalid) {
-            const double* A = base + (int64_t)row * 12;
+            const double* A = base + ((int64_t)l * pstride + ci) * 12;
             const float cx = (float)A[9], cy = (float)A[10], cz = (float)A[11];
             const float rad = (float)rv.radius(l) + 1.0e-4f;
             for (int o = o_begin; o < o_end; ++o) {
@@ -274,7 +303,7 @@ __global__ __launch_bounds__(256) void k_sdf_chunks(ChunkArgs a) {
                 if (work) {
 #pragma unroll
                     for (int k = 0; k < LB; ++k)
-                        pose12_apply(base + ((int64_t)(l0 + k) * CH + ci) * 12, rv.pts(l0 + k, p), px[k], py[k], pz[k]);
+                        pose12_apply(base + ((int64_t)(l0 + k) * pstride + ci) * 12, rv.pts(l0 + k, p), px[k], py[k], pz[k]);
                 }
                 if (work) {
                     for (int o = o_begin; o < o_end; ++o) {  // wave-uniform trip count and addresses
@@ -304,7 +333,7 @@ __global__ __launch_bounds__(256) void k_sdf_chunks(ChunkArgs a) {
                     }
                     if (a.arc && acc[k].pot != 0.0f) {  // ||(x_i - x_{i-1}) / dt|| in float32 (config.py:162-187, cost.py:260-275)
                         float qx, qy, qz;
-                        pose12_apply(ci > 0 ? base + ((int64_t)l * CH + ci - 1) * 12 : sbase + l * 12, rv.pts(l, p), qx, qy, qz);
+                        pose12_apply(ci > 0 ? base + ((int64_t)l * pstride + ci - 1) * 12 : sbase + (int64_t)l * sstride, rv.pts(l, p), qx, qy, qz);
                         const float vx = (px[k] - qx) * a.inv_dt, vy = (py[k] - qy) * a.inv_dt, vz = (pz[k] - qz) * a.inv_dt;
                         acc[k].pot = acc[k].pot * sqrtf(vx * vx + vy * vy + vz * vz);
                     }
@@ -494,8 +523,12 @@ static int launch_chunks(ChunkArgs& ca, hipStream_t st) {
     if (lb < 0) { const char* e = getenv("OMGX_LB"); lb = e ? atoi(e) : 2; }
     int lbu = lb;
     if (lpw % lbu != 0) lbu = 1;  // the link batch must divide the links of a workgroup
-#define OMGX_LAUNCH_CHUNKS(G_, LB_) hipLaunchKernelGGL((k_sdf_chunks<G_, LB_>), dim3((unsigned)grid), dim3(256), 0, st, ca)
-    if (ca.grad) {
+#define OMGX_LAUNCH_CHUNKS(G_, LB_) hipLaunchKernelGGL((k_sdf_chunks<G_, LB_, false>), dim3((unsigned)grid), dim3(256), 0, st, ca)
+    if (ca.traj_start) {  // fused FK (goal-set batch): dynamic LDS holds (CH + 1) x 10 poses
+        const size_t lds = (size_t)(ca.CH + 1) * 120 * sizeof(double);
+        if (lbu == 1) hipLaunchKernelGGL((k_sdf_chunks<false, 1, true>), dim3((unsigned)grid), dim3(256), lds, st, ca);
+        else hipLaunchKernelGGL((k_sdf_chunks<false, 2, true>), dim3((unsigned)grid), dim3(256), lds, st, ca);
+    } else if (ca.grad) {
         if (lbu == 1) OMGX_LAUNCH_CHUNKS(true, 1); else if (lbu == 2) OMGX_LAUNCH_CHUNKS(true, 2);
         else if (lbu == 10) OMGX_LAUNCH_CHUNKS(true, 10); else OMGX_LAUNCH_CHUNKS(true, 5);
     } else {
@@ -602,16 +635,21 @@ extern "C" int omgx_goalset_cost(const double* robot, int32_t n_points, const om
     const int n = n_remaining, C = num_goals * n;
     double* ws = (double*)workspace;
     double* ws_start = ws + (int64_t)num_scenes * num_goals * 10 * n * 12;
-    FkArgs fa{};
-    fa.robot = robot; fa.P = n_points; fa.mode = 1; fa.traj_start = traj_start; fa.goals = goals; fa.S = num_scenes;
-    fa.C = C; fa.n = n; fa.CH = n; fa.ws = ws; fa.ws_start = ws_start;
-    const int64_t total = (int64_t)num_scenes * (C + 1);
-    hipLaunchKernelGGL(k_fk_poses, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, st, fa);
-    OMGX_CHECK_LAUNCH("k_fk_poses");
+    static int fused = -1;  // OMGX_FUSED_FK=0 keeps the separate FK launch (A/B measurements)
+    if (fused < 0) { const char* e = getenv("OMGX_FUSED_FK"); fused = e ? atoi(e) : 1; }
+    if (!fused) {
+        FkArgs fa{};
+        fa.robot = robot; fa.P = n_points; fa.mode = 1; fa.traj_start = traj_start; fa.goals = goals; fa.S = num_scenes;
+        fa.C = C; fa.n = n; fa.CH = n; fa.ws = ws; fa.ws_start = ws_start;
+        const int64_t total = (int64_t)num_scenes * (C + 1);
+        hipLaunchKernelGGL(k_fk_poses, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, st, fa);
+        OMGX_CHECK_LAUNCH("k_fk_poses");
+    }
     ChunkArgs ca{};
     ca.robot = robot; ca.objects = objects; ca.scene_begin = scene_begin; ca.pool = sdf_pool; ca.ws = ws; ca.ws_start = ws_start;
     ca.S = num_scenes; ca.C = C; ca.CH = n; ca.NCH = num_goals; ca.P = n_points; ca.soften = soften_fingers != 0;
     ca.arc = 1; ca.inv_dt = (float)(1.0 / time_interval);
     ca.pot = potentials; ca.grad = nullptr; ca.col = nullptr; ca.chunk_cost = goal_cost; ca.chunk_col = collides;
+    if (fused) { ca.traj_start = traj_start; ca.goals = goals; }
     return launch_chunks(ca, st);
 }
