@@ -178,7 +178,7 @@ __device__ __forceinline__ double block_sum(const Lds& L, const double* arr, int
     if (threadIdx.x < 64) {
         double s = 0.0;
         for (int k = threadIdx.x; k < count; k += 64) s += arr[k];
-        s = wave_sum(s);
+        s = wave_allsum(s);
         if (threadIdx.x == 0) L.red[slot] = s;
     }
     __syncthreads();
@@ -354,14 +354,15 @@ __global__ __launch_bounds__(CH_TPB) void k_chomp_optimize(ChompArgs a) {
             // ("last write wins" of the buffered fancy-index +=, cost.py:421)
             float bv = sel ? cf : -1.0f;
             int bp = sel ? p : -1;
-#pragma unroll
-            for (int off = 8; off > 0; off >>= 1) {
-                const float ov = __shfl_xor(bv, off, 16);
-                const int op = __shfl_xor(bp, off, 16);
-                if (ov > bv || (ov == bv && op > bp)) { bv = ov; bp = op; }
-            }
-#pragma unroll
-            for (int off = 8; off > 0; off >>= 1) contrib += __shfl_xor(contrib, off, 16);
+#define OMG_ARGMAX_STEP(CTRL)                                                   \
+    {                                                                           \
+        const float ov = dpp_f32<CTRL>(bv);                                     \
+        const int op = dpp_i32<CTRL>(bp);                                       \
+        if (ov > bv || (ov == bv && op > bp)) { bv = ov; bp = op; }             \
+    }
+            OMG_ARGMAX_STEP(0xB1) OMG_ARGMAX_STEP(0x4E) OMG_ARGMAX_STEP(0x141) OMG_ARGMAX_STEP(0x140)
+#undef OMG_ARGMAX_STEP
+            contrib = row16_allsum(contrib);
             if (inb && p == 0) { L.gwin[grp] = bp; L.gcost[grp] = contrib; }
         } else {
             // clean branch (cost.py:380-388): every point of every link contributes J.g
@@ -374,12 +375,9 @@ __global__ __launch_bounds__(CH_TPB) void k_chomp_optimize(ChompArgs a) {
                 const int nk = njoints(l);
                 for (int k = 0; k < nk; ++k) out[k] = jacobian_dot(L, i, l, k, x, g);
             }
+            contrib = row16_allsum(contrib);
 #pragma unroll
-            for (int off = 8; off > 0; off >>= 1) {
-                contrib += __shfl_xor(contrib, off, 16);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) out[k] += __shfl_xor(out[k], off, 16);
-            }
+            for (int k = 0; k < 8; ++k) out[k] = row16_allsum(out[k]);
             if (inb && p == 0) {
                 L.gcost[grp] = contrib;
 #pragma unroll
@@ -497,7 +495,7 @@ __global__ __launch_bounds__(CH_TPB) void k_chomp_optimize(ChompArgs a) {
     // collide.sum() over the layer output (cost.py:187): per-thread partials -> fixed-order block sum
     {
         __syncthreads();
-        const double wsum = wave_sum(colsum);
+        const double wsum = wave_allsum(colsum);
         if ((tid & 63) == 0) L.red[40 + (tid >> 6)] = wsum;
         __syncthreads();
     }

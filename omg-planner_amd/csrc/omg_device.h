@@ -411,6 +411,41 @@ __device__ __forceinline__ void pose12_apply(const double* __restrict__ A, const
 // -------------------------------------------------------------------------------------------------
 // wave / block reductions with a fixed combination order (deterministic results)
 // -------------------------------------------------------------------------------------------------
+// DPP cross-lane moves (one VALU instruction, no LDS round trip; __shfl_* lowers to ds_bpermute, ~10x slower
+// on a dependent chain).  CTRL: 0xB1 = quad_perm[1,0,3,2] (lane^1), 0x4E = quad_perm[2,3,0,1] (lane^2),
+// 0x141 = row_half_mirror (i <-> 7-i), 0x140 = row_mirror (i <-> 15-i).  All lanes of the row must be active.
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) { return __int_as_float(dpp_i32<CTRL>(__float_as_int(v))); }
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    return __hiloint2double(dpp_i32<CTRL>(__double2hiint(v)), dpp_i32<CTRL>(__double2loint(v)));
+}
+// sum over each aligned group of 16 lanes (a DPP row), result in every lane of the group
+__device__ __forceinline__ double row16_allsum(double v) {
+    v += dpp_f64<0xB1>(v);
+    v += dpp_f64<0x4E>(v);
+    v += dpp_f64<0x141>(v);
+    v += dpp_f64<0x140>(v);
+    return v;
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+// sum over the 64 lanes of a wave, identical in every lane, fixed order
+__device__ __forceinline__ double wave_allsum(double v) {
+    v = row16_allsum(v);
+    return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
+}
+__device__ __forceinline__ double wave_allmax(double v) {
+    v = fmax(v, dpp_f64<0xB1>(v));
+    v = fmax(v, dpp_f64<0x4E>(v));
+    v = fmax(v, dpp_f64<0x141>(v));
+    v = fmax(v, dpp_f64<0x140>(v));
+    return fmax(fmax(readlane_f64(v, 0), readlane_f64(v, 16)), fmax(readlane_f64(v, 32), readlane_f64(v, 48)));
+}
+
 template <class T>
 __device__ __forceinline__ T wave_sum(T v) {
 #pragma unroll

@@ -40,16 +40,8 @@ struct LearnerArgs {
     double* cost_vector;
 };
 
-__device__ __forceinline__ double wsum(double v) {  // butterfly: identical result in every lane
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-__device__ __forceinline__ double wmax(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
-    return v;
-}
+__device__ __forceinline__ double wsum(double v) { return omg::wave_allsum(v); }  // identical result in every lane
+__device__ __forceinline__ double wmax(double v) { return omg::wave_allmax(v); }
 // arg-extreme with the lowest index on ties (np.argmin / np.argmax return the first occurrence)
 template <bool MIN>
 __device__ __forceinline__ int warg(double v, int i) {
@@ -79,16 +71,25 @@ __device__ void bregman_projection(const double* x, const double* v, double delt
             if (ok) vmax = fmax(vmax, 1.0 + v[j]);
         }
         const double x1 = wmax(vmax);
-        double L = (0.0 + x1) / 2.0, sstep = (x1 - 0.0) / 4.0;
-        for (int k = 0; k < max_iter; ++k) {  // find_zero
-            double part = 0.0;
+        // find_zero (online_learner.py:16-29) on f(L) = sum_j shiftx_j exp(L + z_j) - target = exp(L) * C - target:
+        // C is summed once; exp(L) follows the bisection by E *= exp(+-s) with exp(s/2) = sqrt(exp(s)), so a step
+        // costs a multiply and a square root instead of G exponentials and a wave reduction.  L itself is updated
+        // exactly like the reference (same dyadic sequence); E carries ~1e-16 relative error per step against a
+        // decision threshold of 1e-6.
+        double partC = 0.0;
 #pragma unroll
-            for (int j = 0; j < NPL; ++j)
-                if (lane + 64 * j < G) part += shiftx[j] * exp(L + z[j]);
-            const double fy = wsum(part) - target;
+        for (int j = 0; j < NPL; ++j)
+            if (lane + 64 * j < G) partC += shiftx[j] * exp(z[j]);
+        const double Csum = wsum(partC);
+        double L = (0.0 + x1) / 2.0, sstep = (x1 - 0.0) / 4.0;
+        double E = exp(L), Es = exp(sstep);
+        for (int k = 0; k < max_iter; ++k) {
+            const double fy = E * Csum - target;
             if (fabs(fy) < err) break;
-            L -= sstep * (double)((fy > 0) - (fy < 0));
+            if (fy > 0) { L -= sstep; E /= Es; }
+            else if (fy < 0) { L += sstep; E *= Es; }
             sstep /= 2.0;
+            Es = sqrt(Es);
         }
         double nrm = 0.0, ap[NPL];
 #pragma unroll
