@@ -7,6 +7,7 @@ Layout (only what the path needs):
   cost.py      `Cost`      — host-side mirror of omg/cost.py's class surface
   optimizer.py `Optimizer` — host-side mirror of omg/optimizer.py's class surface
   config.py    `cfg`       — the hyper-parameters the path reads (omg/config.py)
+  trajectory.py / util.py   — `Trajectory` container and the index/angle helpers of the path
   engine.py    `ChompEngine` — batched, device-resident planner loop over S scenes (+ sharding over ranks)
   robot.py / scenes.py      — robot constants, SDF volume layouts, synthetic scenes
   omg_cuda.py  drop-in for the reference's `omg_cuda` extension module (sdf_loss_forward)

@@ -102,6 +102,32 @@ class Config:
     def Ainv(self):
         return self._build()[2]
 
+    # config.py:134-187: finite differences along the waypoint axis with the start/end boundary terms folded in
+    def get_derivative(self, data, start, end, diff_rule=1):
+        """data [..., n, 3] -> D_k data with x_{-1} = start, x_n = end; v_i = (x_i - x_{i-1})/dt, a_i = (x_{i-1} - 2x_i + x_{i+1})/dt^2."""
+        n = data.shape[-2]
+        D = self.diff_matrices[diff_rule - 1][: n + 1, :n]
+        out = np.matmul(D, data)
+        mid = self.diff_rule_length // 2
+        scale = self.time_interval ** diff_rule
+        out[..., 0, :] += self.diff_rule[diff_rule - 1][mid - 1] * start / scale
+        out[..., -2, :] += self.diff_rule[diff_rule - 1][mid + 1] * end / scale
+        out[..., -1, :] += self.diff_rule[diff_rule - 1][mid] * end / scale
+        return out[..., :-1, :]
+
+    def get_derivative_torch(self, data, start, end, diff_rule=1):
+        """float32 torch twin of get_derivative (config.py:162-187)."""
+        import torch
+        n = data.shape[-2]
+        D = torch.as_tensor(self.diff_matrices[diff_rule - 1][: n + 1, :n], dtype=torch.float32, device=data.device)
+        out = torch.matmul(D, data)
+        mid = self.diff_rule_length // 2
+        scale = self.time_interval ** diff_rule
+        out[..., 0, :] += float(self.diff_rule[diff_rule - 1][mid - 1]) * start / scale
+        out[..., -2, :] += float(self.diff_rule[diff_rule - 1][mid + 1]) * end / scale
+        out[..., -1, :] += float(self.diff_rule[diff_rule - 1][mid]) * end / scale
+        return out[..., :-1, :]
+
     def layer_kwargs(self) -> dict:
         return dict(epsilon=self.epsilon, target_epsilon=self.target_epsilon, clearance=self.clearance,
                     target_clearance=self.target_clearance, disable_collision_set=tuple(self.disable_collision_set))

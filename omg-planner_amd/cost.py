@@ -159,6 +159,57 @@ class Cost(object):
         vis_pts[..., 7] = 255 - vis_pts[..., 6]
         vis_pts[_np(collide).astype(bool), 6:9] = 255, 0, 0
 
+    # -- reference helpers kept for callers that want the intermediate tensors (not used by compute_total_loss,
+    #    which computes the same quantities inside k_chomp_optimize) ------------------------------------------
+    def functional_grad(self, v, a, JT, ws_cost, ws_grad):
+        """CHOMP workspace functional gradient of points (omg/cost.py:24-43): cost = sum c ||v||,
+        grad = J . (||v|| P grad_c - c P a / (||v||^2 + 1e-8)) with P = I - vhat vhat^T."""
+        speed = np.linalg.norm(v, axis=-1, keepdims=True)
+        vhat = v / (speed + 1e-8)
+        P = np.eye(3) - vhat[..., :, None] * vhat[..., None, :]
+        kappa = ws_cost[..., None] * np.einsum("...ij,...j->...i", P, a) / (speed ** 2 + 1e-8)
+        g = speed * np.einsum("...ij,...j->...i", P, ws_grad) - kappa
+        return np.sum(ws_cost * speed[..., 0], axis=-1), np.einsum("...kj,...j->...k", JT, g)
+
+    def compute_point_jacobian(self, joint_origin, x, joint_axis, potentials, type="revolute"):
+        """Per-point Jacobians [n, p, joints, 6] of one link (omg/cost.py:92-110); x is [p, n, 3]."""
+        xt = np.transpose(x, (1, 0, 2))[:, :, None, :]
+        J = np.zeros([xt.shape[0], xt.shape[1], joint_axis.shape[1], 6])
+        J[..., :3] = np.cross(joint_axis[:, None], xt - joint_origin[:, None])
+        J[..., 3:] = joint_axis[:, None]
+        if type == "prsimatic":  # (sic) finger joint: pure translation along its axis
+            J[..., -1, :3] = joint_axis[:, [-1], :]
+            J[..., -1, 3:] = 0
+        return J
+
+    def forward_kinematics_obstacle(self, xi, start, end, arc_length=True):
+        """x, v, a [n,10,p,3], Js, potentials, potential_grads, vis_pts, collide of a trajectory (omg/cost.py:112-190):
+        FK and the SDF layer on the device, the finite differences / Jacobians with the helpers above."""
+        from .util import wrap_joint
+        model, robot = self._robot_model()
+        P = model.points_per_link
+        xi = np.asarray(xi, np.float64)
+        n = xi.shape[0]
+        q = self._t(np.concatenate([xi, np.asarray(start)[None], np.asarray(end)[None]], 0))
+        poses, org, ax = (_np(t) for t in ops.forward_kinematics(robot, P, q))
+        pts = np.asarray(self.env.robot.collision_points, np.float64).transpose([0, 2, 1])
+        ws = self.forward_points(poses[:n], pts)  # [p, 10, n, 3]
+        pot, grad, col = ops.fk_sdf(robot, P, self._scenes(), self._t(xi[None]), soften_fingers=self.cfg.uncheck_finger_collision == -1)
+        potentials, potential_grads, collide = _np(pot[0]), _np(grad[0]), _np(col[0])
+        vis_pts = np.zeros([n, 11, P, 12])
+        vis_pts[:, :10, :, :3] = ws.transpose([2, 1, 0, 3])
+        vis_pts[:, :10, :, 6] = potentials
+        vis_pts[:, :10, :, 9:] = potential_grads
+        Js = [self.compute_point_jacobian(org[:n][:, wrap_joint(j + 1)], ws[:, j], ax[:n][:, wrap_joint(j + 1)], potentials[:, j],
+                                          "prsimatic" if j >= 8 else "revolute") for j in range(10)]
+        if not arc_length:
+            return Js, potentials, potential_grads, collide.sum()
+        ws_start = self.forward_points(poses[n][None], pts)[:, :, 0]
+        ws_end = self.forward_points(poses[n + 1][None], pts)[:, :, 0]
+        v = self.cfg.get_derivative(ws, ws_start, ws_end, 1).transpose([2, 1, 0, 3])
+        a = self.cfg.get_derivative(ws, ws_start, ws_end, 2).transpose([2, 1, 0, 3])
+        return ws.transpose([2, 1, 0, 3]), v, a, Js, potentials, potential_grads, vis_pts, collide.sum()
+
     # -- SDF layer -----------------------------------------------------------------------------------
     def compute_obstacle_cost_layer(self, ws_positions, vis_pts=None, special_check_id=0, uncheck_finger_collision=-1,
                                     grad_free=True):

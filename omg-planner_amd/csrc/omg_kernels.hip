@@ -212,9 +212,10 @@ struct ChunkArgs {
 // through HBM and no separate FK launch.
 template <bool WANT_GRAD, int LB, bool FUSED>
 __global__ __launch_bounds__(256) void k_sdf_chunks(ChunkArgs a) {
+    // dynamic LDS: [FUSED: (CH+1) x 10 poses of 12 doubles] then 10*CH row masks (candidate objects of each row)
     extern __shared__ __attribute__((aligned(16))) double lds_pose[];
     __shared__ float red[2][4];
-    __shared__ uint32_t rowmask[10 * OMGX_MAX_WAYPOINTS];  // candidate objects of each row (link, config)
+    uint32_t* rowmask = reinterpret_cast<uint32_t*>(lds_pose + (FUSED ? (size_t)(a.CH + 1) * 120 : 0));
     // XCD-aware placement: workgroup b runs on XCD b % 8 (observed; used for L2 affinity only).
     // All chunks of a scene go to the same XCD so the scene's SDF volumes stay in one 4 MiB L2.
     const int xcd = blockIdx.x & 7;
@@ -523,9 +524,10 @@ static int launch_chunks(ChunkArgs& ca, hipStream_t st) {
     if (lb < 0) { const char* e = getenv("OMGX_LB"); lb = e ? atoi(e) : 2; }
     int lbu = lb;
     if (lpw % lbu != 0) lbu = 1;  // the link batch must divide the links of a workgroup
-#define OMGX_LAUNCH_CHUNKS(G_, LB_) hipLaunchKernelGGL((k_sdf_chunks<G_, LB_, false>), dim3((unsigned)grid), dim3(256), 0, st, ca)
+    const size_t mask_bytes = (size_t)10 * ca.CH * sizeof(uint32_t);
+#define OMGX_LAUNCH_CHUNKS(G_, LB_) hipLaunchKernelGGL((k_sdf_chunks<G_, LB_, false>), dim3((unsigned)grid), dim3(256), mask_bytes, st, ca)
     if (ca.traj_start) {  // fused FK (goal-set batch): dynamic LDS holds (CH + 1) x 10 poses
-        const size_t lds = (size_t)(ca.CH + 1) * 120 * sizeof(double);
+        const size_t lds = (size_t)(ca.CH + 1) * 120 * sizeof(double) + mask_bytes;
         if (lbu == 1) hipLaunchKernelGGL((k_sdf_chunks<false, 1, true>), dim3((unsigned)grid), dim3(256), lds, st, ca);
         else hipLaunchKernelGGL((k_sdf_chunks<false, 2, true>), dim3((unsigned)grid), dim3(256), lds, st, ca);
     } else if (ca.grad) {

@@ -675,3 +675,22 @@ def test_point_cloud_sdf_matches_oracle_and_feeds_the_sdf_layer(dev):
     a, b = layer(g), layer(ref)
     assert float((a[0] > 0).float().mean()) > 0.3
     np.testing.assert_allclose(a[0].cpu().numpy(), b[0].cpu().numpy(), rtol=0, atol=1e-6)
+
+
+def test_cost_forward_kinematics_obstacle_matches_reference_fixture(dev):
+    """The reference's intermediate tensors (x, v, a, per-link Jacobians) from Cost.forward_kinematics_obstacle."""
+    from omg_planner_amd.cost import Cost
+    from omg_planner_amd.util import wrap_joint
+    for case in ("topk1000", "short_n5"):
+        fx = H.load(f"cost_{case}.npz")
+        n = fx["xi"].shape[0]
+        cost = Cost(_env_from(fx, dev, _cfg_from(fx, n)))
+        x, v, a, Js, pot, pgrad, vis, col = cost.forward_kinematics_obstacle(fx["xi"], fx["start"], fx["end"])
+        np.testing.assert_allclose(x, fx["x"], atol=1e-12)
+        np.testing.assert_allclose(v, fx["v"], atol=1e-9)
+        np.testing.assert_allclose(a, fx["a"], atol=1e-7)
+        for j in range(10):
+            k = len(wrap_joint(j + 1))
+            np.testing.assert_allclose(Js[j][..., :3], fx["J"][:, j, :, :k], atol=1e-12)
+        np.testing.assert_allclose(pot, fx["potentials"], atol=2e-6)
+        assert float(col) == float(fx["collide_sum"])

@@ -1,0 +1,85 @@
+"""CPU tests of the host-side mirrors (util / config / trajectory / Cost helper methods) against the reference
+fixtures."""
+import numpy as np
+
+from tests import helpers as H
+
+
+def test_wrap_helpers():
+    from omg_planner_amd import util
+    assert util.wrap_index(3) == [0, 1, 2] and util.wrap_index(8) == list(range(7)) and util.wrap_index(9) == list(range(8))
+    assert util.wrap_index(10) == list(range(7)) + [8]
+    assert util.wrap_joint(8) == list(range(7)) and util.wrap_joint(9) == list(range(7)) + [8] and util.wrap_joint(10) == list(range(7)) + [9]
+    q = np.arange(9) * 0.1
+    w = util.wrap_value(q)
+    assert w.shape == (10,) and w[7] == 0 and np.allclose(w[8:], np.rad2deg(q[7:]))
+    assert np.allclose(util.wrap_values(q[None])[0], w)
+    assert util.safe_div(1.0, 1.0) == 1.0 / (1.0 + 1e-8)
+
+
+def test_config_matrices_and_derivatives_match_reference():
+    from omg_planner_amd.config import Config
+    fx = H.load("matrices.npz")
+    for n, gsp in ((30, True), (30, False), (50, True)):
+        cfg = Config(timesteps=n, goal_set_proj=gsp)
+        tag = f"n{n}_g{int(gsp)}_dt0.10"
+        np.testing.assert_allclose(cfg.diff_matrices[0], fx[tag + "_D1"], atol=1e-12)
+        np.testing.assert_allclose(cfg.diff_matrices[1], fx[tag + "_D2"], atol=1e-12)
+        np.testing.assert_allclose(cfg.A, fx[tag + "_A"], atol=1e-9)
+        np.testing.assert_allclose(cfg.Ainv, fx[tag + "_Ainv"], rtol=1e-9, atol=1e-12)
+    cfg = Config()
+    cfg.get_global_param(50)
+    assert abs(cfg.time_interval - 0.06) < 1e-15  # dt from the PREVIOUS timesteps (config.py:201)
+    np.testing.assert_allclose(cfg.Ainv, fx["n50_g1_dt0.06_Ainv"], rtol=1e-9, atol=1e-12)
+    # finite differences reproduce the reference's v and a of forward_kinematics_obstacle
+    full = H.load("cost_topk1000.npz")
+    cfg = Config(timesteps=30)
+    x = full["x"]  # [n,10,p,3]
+    m = H.model_from(full)
+    from oracle import oracle as orc
+    xs = orc.config_points(m.blob(), m.points_per_link, full["start"]).transpose(1, 0, 2)  # [p,10,3]
+    xe = orc.config_points(m.blob(), m.points_per_link, full["end"]).transpose(1, 0, 2)
+    ws = x.transpose(2, 1, 0, 3)  # [p,10,n,3]
+    np.testing.assert_allclose(cfg.get_derivative(ws, xs, xe, 1).transpose(2, 1, 0, 3), full["v"], atol=1e-9)
+    np.testing.assert_allclose(cfg.get_derivative(ws, xs, xe, 2).transpose(2, 1, 0, 3), full["a"], atol=1e-7)
+
+
+def test_trajectory_container():
+    from scipy import interpolate
+    from omg_planner_amd.config import Config
+    from omg_planner_amd.trajectory import Trajectory
+    cfg = Config(timesteps=30)
+    t = Trajectory(cfg=cfg)
+    assert t.data.shape == (30, 9)
+    # the closed-form blend equals scipy's clamped cubic spline through the two knots (omg/util.py:238-258)
+    f = interpolate.CubicSpline(np.linspace(0, 1, 2), np.stack([t.start, t.end]), bc_type="clamped")
+    np.testing.assert_allclose(t.data, f(np.linspace(0, 1, 32)[1:-1]), atol=1e-12)
+    g = np.ones((30, 9))
+    before = t.data.copy()
+    t.update(g)
+    np.testing.assert_allclose(t.data[:, :7], before[:, :7] + 1)
+    assert (t.data[:, 7:] <= 0.04).all() and (t.data[:, 7:] >= 0).all()
+
+
+def test_cost_numpy_helpers_match_reference_intermediates():
+    """functional_grad / compute_point_jacobian reproduce obs_grad of the clean branch from the fixture's x, v, a, J."""
+    from omg_planner_amd.cost import Cost
+    from omg_planner_amd.util import wrap_index
+    fx = H.load("cost_topk1000.npz")
+    c = Cost.__new__(Cost)
+    n = fx["xi"].shape[0]
+    total = np.zeros((n, 9))
+    for j in range(10):
+        k = len(wrap_index(j + 1))
+        cost_j, grad_j = c.functional_grad(fx["v"][:, j], fx["a"][:, j], fx["J"][:, j, :, :k], fx["potentials"][:, j].astype(np.float64),
+                                           fx["potential_grads"][:, j].astype(np.float64))
+        total[:, wrap_index(j + 1)] += grad_j.sum(1)
+    # cross-check against the oracle's clean branch on the same inputs
+    from oracle import oracle as orc
+    m = H.model_from(fx)
+    prm = H.params_from(dict(fx, cfg_top_k=0), orc.ChompParams, n, m.points_per_link, 0, 1.0, 0.0)
+    prm.clip_grad_scale = 1e30
+    col = np.zeros_like(fx["potentials"])[None]
+    _, grad, _, _ = orc.chomp_optimize(m.blob(), prm, fx["xi"][None], fx["start"][None], fx["end"][None], fx["end"][None, None],
+                                       fx["end"][None], fx["potentials"][None], fx["potential_grads"][None], col)
+    np.testing.assert_allclose(total, grad[0], rtol=1e-9, atol=1e-9)
