@@ -14,8 +14,9 @@
 //
 // The SDF potentials/gradients of the n waypoint configurations come from omgx_fk_sdf (float32,
 // [n][10][P] reference layout).  Everything else lives in LDS for the duration of the step:
-//   link poses of start, n waypoints, end (double [n+2][10][12]), joint axes/origins ([n][10][3] each),
-//   per-(waypoint,link) gradient slots ([n][10][8]), the trajectory and its gradient ([n][9]).
+//   link poses of start, n waypoints, end (double [n+2][10][12]; joint axes/origins are re-derived from them on
+//   use: axis = R_link ax', origin = R_link og' + t_link), per-(waypoint,link) gradient slots ([n][10][8]), the
+//   trajectory and its gradient ([n][9]).  ~147 KB at the 64-waypoint limit.
 //
 // A = D^T D is tridiagonal (-1,2,-1)/dt^2 with last diagonal 1/dt^2 (goal-set, free end) or 2/dt^2
 // (fixed end) — omg/config.py:208-220, util.py:165-178 — so A^-1 has the closed forms
@@ -73,8 +74,7 @@ __device__ __forceinline__ uint32_t float_key(float f) {  // order-preserving fl
 
 struct Lds {
     double* pose;    // [n+2][10][12]
-    double* jax;     // [n][10][3]
-    double* jog;     // [n][10][3]
+    double* jconst;  // [10][6] joint axis ax' and origin og' in their link frames (robot blob AX, OG)
     double* gl;      // [n][10][8]
     double* gcost;   // [n][10]
     double* xi;      // [n][9]
@@ -96,8 +96,7 @@ __device__ __forceinline__ Lds carve(unsigned char* base, int n, int P) {
     Lds L;
     double* d = reinterpret_cast<double*>(base);
     L.pose = d; d += (size_t)(n + 2) * 120;
-    L.jax = d; d += (size_t)n * 30;
-    L.jog = d; d += (size_t)n * 30;
+    L.jconst = d; d += 60;
     L.gl = d; d += (size_t)n * 80;
     L.gcost = d; d += (size_t)n * 10;
     L.xi = d; d += (size_t)n * 9;
@@ -151,9 +150,14 @@ __device__ __forceinline__ double functional_g(const double* v, const double* a,
 // J_k . g for the k-th joint of link l at waypoint i (cost.py:92-110)
 __device__ __forceinline__ double jacobian_dot(const Lds& L, int i, int l, int k, const double* x, const double* g) {
     const int j = joint_of(l, k);
-    const double* ax = L.jax + ((size_t)i * 10 + j) * 3;
+    // joint frame = out_j . tip2joint_j (robot_pykdl.py:190-201): axis = R_j ax'_j, origin = R_j og'_j + t_j
+    const double* A = L.pose + ((size_t)(i + 1) * 10 + j) * 12;
+    const double* c = L.jconst + 6 * j;
+    const double ax[3] = {A[0] * c[0] + A[1] * c[1] + A[2] * c[2], A[3] * c[0] + A[4] * c[1] + A[5] * c[2],
+                          A[6] * c[0] + A[7] * c[1] + A[8] * c[2]};
     if (l >= 8 && k == 7) return ax[0] * g[0] + ax[1] * g[1] + ax[2] * g[2];  // "prsimatic" finger joint
-    const double* o = L.jog + ((size_t)i * 10 + j) * 3;
+    const double o[3] = {A[0] * c[3] + A[1] * c[4] + A[2] * c[5] + A[9], A[3] * c[3] + A[4] * c[4] + A[5] * c[5] + A[10],
+                         A[6] * c[3] + A[7] * c[4] + A[8] * c[5] + A[11]};
     const double d0 = x[0] - o[0], d1 = x[1] - o[1], d2 = x[2] - o[2];
     const double J0 = ax[1] * d2 - ax[2] * d1, J1 = ax[2] * d0 - ax[0] * d2, J2 = ax[0] * d1 - ax[1] * d0;
     return J0 * g[0] + J1 * g[1] + J2 * g[2];
@@ -225,6 +229,7 @@ __global__ __launch_bounds__(CH_TPB) void k_chomp_optimize(ChompArgs a) {
     // ---------------------------------------------------------------- phase 0: loads + FK
     for (int e = tid; e < n * 9; e += blockDim.x) L.xi[e] = traj[e];
     for (int e = tid; e < 30 * P; e += blockDim.x) L.pts[e] = rv.pts(0, 0)[e];
+    for (int e = tid; e < 60; e += blockDim.x) L.jconst[e] = (e % 6 < 3) ? rv.ax(e / 6)[e % 6] : rv.og(e / 6)[e % 6 - 3];
     for (int e = tid; e < 256; e += blockDim.x) L.hist[e] = 0;
     for (int e = tid; e < (nitems + 31) / 32; e += blockDim.x) L.tie[e] = 0;
     __syncthreads();
@@ -233,23 +238,11 @@ __global__ __launch_bounds__(CH_TPB) void k_chomp_optimize(ChompArgs a) {
         const double* src = tid == 0 ? start : (tid == n + 1 ? end : L.xi + 9 * (tid - 1));
 #pragma unroll
         for (int d = 0; d < 9; ++d) q[d] = src[d];
-        const bool wp = tid >= 1 && tid <= n;
         fk_chain(rv, q, [&](int l, const Pose& pose) {
             double* dst = L.pose + ((size_t)tid * 10 + l) * 12;
 #pragma unroll
             for (int k = 0; k < 9; ++k) dst[k] = pose.R[k];
             dst[9] = pose.t[0]; dst[10] = pose.t[1]; dst[11] = pose.t[2];
-            if (wp) {  // joint frame = out_l . tip2joint_l (robot_pykdl.py:190-201); origin = its translation
-                const double* ax = rv.ax(l);
-                const double* og = rv.og(l);
-                double* ja = L.jax + ((size_t)(tid - 1) * 10 + l) * 3;
-                double* jo = L.jog + ((size_t)(tid - 1) * 10 + l) * 3;
-#pragma unroll
-                for (int r = 0; r < 3; ++r) {
-                    ja[r] = pose.R[3 * r] * ax[0] + pose.R[3 * r + 1] * ax[1] + pose.R[3 * r + 2] * ax[2];
-                    jo[r] = pose.R[3 * r] * og[0] + pose.R[3 * r + 1] * og[1] + pose.R[3 * r + 2] * og[2] + pose.t[r];
-                }
-            }
         });
     }
 
@@ -630,7 +623,7 @@ __global__ __launch_bounds__(CH_TPB) void k_chomp_optimize(ChompArgs a) {
 }
 
 static size_t host_lds_bytes(int n, int P) {
-    size_t d = (size_t)(n + 2) * 120 + (size_t)n * 30 * 2 + (size_t)n * 80 + (size_t)n * 10 + (size_t)n * 9 * 6 + (n + 1) + 30 * P + 64;
+    size_t d = (size_t)(n + 2) * 120 + 60 + (size_t)n * 80 + (size_t)n * 10 + (size_t)n * 9 * 6 + (n + 1) + 30 * P + 64;
     size_t i = (size_t)n * 10 + 256 + (n * 160 + 31) / 32 + 16;
     return d * 8 + i * 4;
 }

@@ -694,3 +694,35 @@ def test_cost_forward_kinematics_obstacle_matches_reference_fixture(dev):
             np.testing.assert_allclose(Js[j][..., :3], fx["J"][:, j, :, :k], atol=1e-12)
         np.testing.assert_allclose(pot, fx["potentials"], atol=2e-6)
         assert float(col) == float(fx["collide_sum"])
+
+
+def test_maximum_waypoints_64_matches_oracle(dev):
+    """The build's size limits (64 waypoints, 16 points per link, 8 constraint rows) against the oracle."""
+    from omg_planner_amd import _lib, ops, robot as rb, scenes as sc
+    from oracle import oracle as orc
+    S, n, G, Pn, c = 2, 64, 3, 16, 8
+    m = rb.PandaModel(points_per_link=Pn, seed=9)
+    scenes, batch = _multi_scene_batch(S)
+    goals = np.stack([sc.make_reach_goals(scenes[s], m, G, s) for s in range(S)])
+    start = np.tile(rb.HOME_CONFIG, (S, 1))
+    traj = np.stack([sc.cubic_init(start[s], goals[s, 0], n) for s in range(S)])
+    robot, ds = ops.robot_blob(m, dev), ops.DeviceScenes(batch, dev)
+    gc_ref, _ = orc.goalset_cost(m.blob(), Pn, batch, traj[:, 0], goals, n, 0.05)
+    gc, _, _ = ops.goalset_cost(robot, Pn, ds, _t(traj[:, 0], dev), _t(goals, dev), n, 0.05)
+    np.testing.assert_allclose(gc.cpu().numpy(), gc_ref, rtol=1e-5, atol=1e-6)
+    reach = np.stack([[np.concatenate([sc.linear_init(g - 0.1, g, c - 1), g[None]], 0) for g in goals[s]] for s in range(S)])
+    fx = dict(cfg_top_k=1000, cfg_goal_set_proj=1, cfg_use_standoff=1, cfg_dt=0.05)
+    po = H.params_from(fx, orc.ChompParams, n, Pn, 1, 1.0, 0.102, reach_tail_length=c)
+    pd = H.params_from(fx, _lib.ChompParams, n, Pn, 1, 1.0, 0.102, reach_tail_length=c)
+    rp, rg, rc = orc.fk_sdf(m.blob(), Pn, batch, traj)
+    t_ref, g_ref, _, i_ref = orc.chomp_optimize(m.blob(), po, traj, start, goals[:, 0], reach[:, 0], goals[:, 0], rp, rg, rc)
+    t_dev = _t(traj, dev)
+    pot, pg, cl = ops.fk_sdf(robot, Pn, ds, t_dev)
+    g, _, info = ops.chomp_optimize(robot, pd, t_dev, _t(start, dev), _t(goals[:, 0], dev), _t(reach[:, 0], dev), _t(goals[:, 0], dev), pot, pg, cl)
+    np.testing.assert_allclose(t_dev.cpu().numpy(), t_ref, rtol=0, atol=1e-7)
+    np.testing.assert_allclose(g.cpu().numpy(), g_ref, rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(info.cpu().numpy()[:, :10], i_ref[:, :10], rtol=1e-6, atol=1e-6)
+    # one past the limits is refused with an error code, not a crash
+    pd.n_waypoints = 65
+    with pytest.raises(_lib.OmgHipError):
+        ops.chomp_optimize(robot, pd, t_dev, _t(start, dev), _t(goals[:, 0], dev), _t(reach[:, 0], dev), _t(goals[:, 0], dev), pot, pg, cl)
