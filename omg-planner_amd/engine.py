@@ -220,10 +220,29 @@ class ChompEngine:
         if early_stop and t > 0:  # planner.py:627: terminated scenes stop iterating
             self.active = self.active * (self.info[:, 10] < 0.5).to(torch.int32)
 
-    def plan(self, early_stop: bool = True) -> torch.Tensor:
+    def select_initial_goal(self):
+        """Learner.__init__ (online_learner.py:96-102): before planning, pick the cheapest goal by one cost_vector
+        evaluation at t = 0 and re-interpolate the trajectory towards it (Trajectory.interpolate_waypoints, cubic)."""
+        if self.ol_alg in ("Proj", "Baseline"):
+            return
+        saved_t, saved_alg = self.t, self.ol_alg
+        scratch = self.learner_state.clone()
+        keep = self.learner_state
+        try:
+            self.t, self.ol_alg, self.learner_state = -1, "FTC", scratch  # update_goal increments t to 0: start_idx 0, argmin(costs)
+            self.update_goal()
+        finally:
+            self.t, self.ol_alg, self.learner_state = saved_t, saved_alg, keep
+        tt = (torch.arange(1, self.n + 1, device=self.device, dtype=torch.float64) / (self.n + 1.0))[None, :, None]
+        h = 3.0 * tt * tt - 2.0 * tt * tt * tt  # clamped cubic through (0,start),(1,end)
+        self.traj.copy_(self.start[:, None, :] + h * (self.end - self.start)[:, None, :])
+
+    def plan(self, early_stop: bool = True, initial_goal: bool = True) -> torch.Tensor:
         """Planner.plan (planner.py:600-653): up to optim_steps + extra_smooth_steps iterations, then one
         info-only evaluation; returns the final info [S,16] (device)."""
         cfg = self.cfg
+        if initial_goal and cfg.goal_set_proj:
+            self.select_initial_goal()
         for t in range(cfg.optim_steps + cfg.extra_smooth_steps):
             self.iterate(t, early_stop)
         return self.optimize(False)

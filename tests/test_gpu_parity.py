@@ -726,3 +726,31 @@ def test_maximum_waypoints_64_matches_oracle(dev):
     pd.n_waypoints = 65
     with pytest.raises(_lib.OmgHipError):
         ops.chomp_optimize(robot, pd, t_dev, _t(start, dev), _t(goals[:, 0], dev), _t(reach[:, 0], dev), _t(goals[:, 0], dev), pot, pg, cl)
+
+
+def test_engine_full_plan_runs_and_improves(dev):
+    """Planner.plan through ChompEngine (initial goal pick, 50 + 20 iterations, final info): costs finite, the
+    goal-set constraint holds (last waypoint on the selected goal) and the smoothness cost dropped."""
+    from omg_planner_amd import robot as rb, scenes as sc
+    from omg_planner_amd.config import Config
+    from omg_planner_amd.engine import ChompEngine
+    S, G, n = 6, 16, 30
+    cfg = Config(timesteps=n, use_standoff=False)
+    m = rb.PandaModel(seed=0)
+    scenes = [sc.make_tabletop_scene(s, grid=32, table_grid=(64, 48, 16)) for s in range(S)]
+    batch = sc.pack_table(scenes, cfg.layer_kwargs())
+    goals = np.stack([sc.make_reach_goals(scenes[s], m, G, s) for s in range(S)])
+    eng = ChompEngine(m, batch, cfg, np.tile(rb.HOME_CONFIG, (S, 1)), goals, device=dev, ol_alg="MD")
+    first = eng.optimize(False).clone()
+    eng.step_count = 0
+    info = eng.plan(early_stop=False)
+    torch.cuda.synchronize()
+    assert torch.isfinite(info).all() and torch.isfinite(eng.traj).all()
+    idx = eng.goal_idx.long()
+    sel = eng.goal_set[torch.arange(S, device=dev), idx]
+    assert float((eng.traj[:, -1] - sel).abs().max()) < 1e-9       # goal_set_projection pins the end point
+    assert float(info[:, 9].max()) < 1e-9                           # info["reach"]
+    lo = torch.as_tensor(m.joint_lower_limit, device=dev) - 1e-2
+    hi = torch.as_tensor(m.joint_upper_limit, device=dev) + 1e-2
+    assert bool(((eng.traj >= lo) & (eng.traj <= hi)).all())       # handle_joint_limit
+    assert float(info[:, 8].sum()) <= float(first[:, 8].sum())     # fewer colliding points than the initial guess
