@@ -10,6 +10,7 @@ Layout (only what the path needs):
   trajectory.py / util.py   — `Trajectory` container and the index/angle helpers of the path
   engine.py    `ChompEngine` — batched, device-resident planner loop over S scenes (+ sharding over ranks)
   robot.py / scenes.py      — robot constants, SDF volume layouts, synthetic scenes
+  scene_io.py               — the reference's scene .mat / SDF .pth file formats
   omg_cuda.py  drop-in for the reference's `omg_cuda` extension module (sdf_loss_forward)
 
 Import as ``omg_planner_amd`` (shim at the repo root).

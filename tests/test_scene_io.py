@@ -1,0 +1,33 @@
+"""CPU test: the reference's on-disk formats (SDF .pth, scene .mat) round-trip through scene_io."""
+import numpy as np
+
+
+def test_scene_and_sdf_files_round_trip(tmp_path):
+    from omg_planner_amd import scene_io, scenes as sc
+    scene = sc.make_tabletop_scene(3, grid=16, table_grid=(24, 16, 8))
+    for i, o in enumerate(scene.objects):
+        o.name = f"model_{i:03d}"
+    scene.target_idx = 2
+    goals = sc.make_goal_set(3, 7)
+    reach = np.repeat(goals[:, None], 5, axis=1)
+    mat = str(tmp_path / "scene_0.mat")
+    scene_io.save_scene_mat(mat, str(tmp_path), scene, goals, reach)
+    cache = {}
+    got = scene_io.load_scene_mat(mat, str(tmp_path), sdf_cache=cache)
+    assert got.scene.target_idx == 2 and [o.name for o in got.scene.objects] == [o.name for o in scene.objects]
+    for a, b in zip(got.scene.objects, scene.objects):
+        np.testing.assert_array_equal(a.sdf.data, b.sdf.data)
+        np.testing.assert_allclose(a.sdf.min_coords, b.sdf.min_coords)
+        assert a.sdf.delta == b.sdf.delta
+        np.testing.assert_allclose(a.pose_mat, b.pose_mat)
+    np.testing.assert_array_equal(got.goals, goals)
+    np.testing.assert_array_equal(got.reach_grasps, reach)
+    # the .pth axis convention: stored tensor is the grid with its first two axes swapped (sdf_tools.py:189)
+    import torch
+    d = torch.load(str(tmp_path / "data/objects/model_000/model_normalized_chomp.pth"), weights_only=False)
+    assert tuple(d["sdf_torch"].shape[2:]) == (scene.objects[0].sdf.data.shape[1], scene.objects[0].sdf.data.shape[0], scene.objects[0].sdf.data.shape[2])
+    # identical packing either way
+    b1 = sc.pack_table([scene], {})
+    b2 = sc.pack_table([got.scene], {})
+    np.testing.assert_array_equal(b1.pool, b2.pool)
+    assert b1.objects.tobytes() == b2.objects.tobytes()
