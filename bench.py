@@ -228,7 +228,7 @@ def main():
                        "scenes_per_gpu": S, "goals": G, "waypoints": n, "objects_per_scene": O_active,
                        "sdf_grid": f"4x{args.grid}^3 + 128x96x32 per scene, {'shared' if args.share_grids else 'private'}",
                        "goal_selection": f"{args.ol_alg} on device (omgx_goal_update)", "top_k_collision": cfg.top_k_collision, "streams": ns},
-            "roofline": {"bound": "hbm", "kernel": "k_sdf_chunks<false> (goal-set batch)", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": "k_goalset_compact<2> (goal-set batch: FK + SDF + arc-length cost)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": avg_ms, "launches": int(len(goal_ms)), "algorithmic_bytes_per_launch": alg_bytes,
                          "waypoint_launch_avg_ms": float(wp_ms.mean()) if len(wp_ms) else None,

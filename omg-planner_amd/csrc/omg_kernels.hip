@@ -362,6 +362,171 @@ __global__ __launch_bounds__(256) void k_sdf_chunks(ChunkArgs a) {
 }
 
 // =================================================================================================
+// (3b) k_goalset_compact — the goal-set batch with wave-level compaction of the exact path
+// =================================================================================================
+// Same work split as k_sdf_chunks<false, ., true> (one workgroup per (scene, goal), FK in LDS, row culling, far
+// tests per point), but the pairs that survive the far test are first PACKED: within a wave the surviving
+// (lane, link-of-batch) items are ranked with ballots, their object-space offsets go to a 1 KiB wave-private LDS
+// scratch, lanes 0..count-1 each run the exact path (grid coordinates, trilinear value, hinge) for one packed
+// item, and the owners read the results back.  The per-point far pattern left only ~49 % of the lanes useful in
+// the unpacked exact path (a link's 10 cm point cloud straddles the far box); packed, a batch of LB links needs
+// ceil(survivors / 64) exact passes instead of one per link.  Arithmetic per pair is unchanged (bit-identical).
+template <int LB>
+__global__ __launch_bounds__(256) void k_goalset_compact(ChunkArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double lds_pose[];
+    __shared__ float red[2][4];
+    const int xcd = blockIdx.x & 7;
+    const int j = blockIdx.x >> 3;
+    const int sgrp = j / a.NCH;
+    const int s = sgrp * 8 + xcd, chunk = j - sgrp * a.NCH;
+    if (s >= a.S) return;
+    const int o_begin = as_const(a.scene_begin)[s], o_end = as_const(a.scene_begin)[s + 1];
+    const int P = a.P, CH = a.CH;
+    const int nvalid = CH;
+    const int p = threadIdx.x & 15, r = threadIdx.x >> 4, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const RobotView rv(a.robot, P);
+    uint32_t* rowmask = reinterpret_cast<uint32_t*>(lds_pose + (size_t)(CH + 1) * 120);
+    float4* scratch = reinterpret_cast<float4*>(rowmask + ((10 * CH + 3) & ~3)) + wave * 64;  // wave-private [64]
+
+    for (int cfg = threadIdx.x; cfg < CH + 1; cfg += 256) {  // FK of start + CH interpolated configurations
+        const double* q0 = a.traj_start + 9 * (int64_t)s;
+        const double* qg = a.goals + ((int64_t)s * a.NCH + chunk) * 9;
+        const double t = (double)cfg / (double)(CH + 1);
+        double q[9];
+#pragma unroll
+        for (int d = 0; d < 9; ++d) q[d] = cfg == 0 ? q0[d] : q0[d] + t * (qg[d] - q0[d]);
+        fk_chain(rv, q, [&](int l, const Pose& pose) {
+            double* dst = lds_pose + ((size_t)l * (CH + 1) + cfg) * 12;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) dst[k] = pose.R[k];
+            dst[9] = pose.t[0]; dst[10] = pose.t[1]; dst[11] = pose.t[2];
+        });
+    }
+    __syncthreads();
+    const double* base = lds_pose + 12;
+    const int pstride = CH + 1;
+
+    for (int row = threadIdx.x; row < 10 * CH; row += 256) {  // phase A: row-level culling (see k_sdf_chunks)
+        const int l = row / CH, ci = row - l * CH;
+        const double* A = base + ((int64_t)l * pstride + ci) * 12;
+        const float cx = (float)A[9], cy = (float)A[10], cz = (float)A[11];
+        const float rad = (float)rv.radius(l) + 1.0e-4f;
+        uint32_t m = 0;
+        for (int o = o_begin; o < o_end; ++o) {
+            ObjTablePtr ob = as_const(a.objects) + o;
+            if (ob->disabled > 0) continue;
+            const int oo = o - o_begin;
+            const uint32_t bit = 1u << (oo < 31 ? oo : 31);
+            const float ux = __builtin_fmaf(ob->pose_inv[2], cz, __builtin_fmaf(ob->pose_inv[1], cy, __builtin_fmaf(ob->pose_inv[0], cx, ob->pose_inv[3]))) - ob->lo[0];
+            const float uy = __builtin_fmaf(ob->pose_inv[6], cz, __builtin_fmaf(ob->pose_inv[5], cy, __builtin_fmaf(ob->pose_inv[4], cx, ob->pose_inv[7]))) - ob->lo[1];
+            const float uz = __builtin_fmaf(ob->pose_inv[10], cz, __builtin_fmaf(ob->pose_inv[9], cy, __builtin_fmaf(ob->pose_inv[8], cx, ob->pose_inv[11]))) - ob->lo[2];
+            const bool near = (ux >= ob->far_lo[0] - rad) & (ux <= ob->far_hi[0] + rad) & (uy >= ob->far_lo[1] - rad) &
+                              (uy <= ob->far_hi[1] + rad) & (uz >= ob->far_lo[2] - rad) & (uz <= ob->far_hi[2] + rad);
+            const bool cullable = ob->epsilon < 1.0f && ob->clearance <= 1.0f;
+            if (near || !cullable) m |= bit;
+        }
+        rowmask[row] = m;
+    }
+    __syncthreads();
+
+    float tsum = 0.0f, tcol = 0.0f;
+    for (int ci0 = 0; ci0 < nvalid; ci0 += 16) {  // every lane stays active: invalid items are flagged, not skipped
+        const int ci = ci0 + r;
+        const bool valid = (p < P) && (ci < nvalid);
+        const int cic = valid ? ci : 0, pc = valid ? p : 0;
+#pragma unroll 1
+        for (int l0 = 0; l0 < 10; l0 += LB) {
+            float px[LB], py[LB], pz[LB];
+            uint32_t msk[LB];
+            uint32_t many = 0;
+            Accum acc[LB];
+#pragma unroll
+            for (int k = 0; k < LB; ++k) {
+                msk[k] = valid ? rowmask[(l0 + k) * CH + cic] : 0u;
+                many |= msk[k];
+                acc[k] = Accum{0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+            }
+            if (!__any(many != 0)) continue;  // nothing in reach of any row of this wave: potentials stay 0
+#pragma unroll
+            for (int k = 0; k < LB; ++k)
+                pose12_apply(base + ((int64_t)(l0 + k) * pstride + cic) * 12, rv.pts(l0 + k, pc), px[k], py[k], pz[k]);
+            for (int o = o_begin; o < o_end; ++o) {
+                const int oo = o - o_begin;
+                const uint32_t bit = 1u << (oo < 31 ? oo : 31);
+                if (!__any((many & bit) != 0)) continue;
+                ObjTablePtr ob = as_const(a.objects) + o;
+                if (ob->disabled > 0) continue;
+                const ObjParams op = load_object(ob);
+                const float* grid = a.pool + ob->grid_offset;
+                PairPrep pp[LB];
+                int rank[LB];
+                int total = 0;
+#pragma unroll
+                for (int k = 0; k < LB; ++k) {
+                    pp[k] = pair_prepare(op, px[k], py[k], pz[k]);
+                    const bool live = (msk[k] & bit) && !pp[k].far;
+                    const unsigned long long bal = __ballot(live);
+                    const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+                    rank[k] = live ? total + before : -1;
+                    total += __popcll(bal);
+                }
+                for (int b0 = 0; b0 < total; b0 += 64) {  // wave-uniform
+#pragma unroll
+                    for (int k = 0; k < LB; ++k)
+                        if (rank[k] >= b0 && rank[k] < b0 + 64) scratch[rank[k] - b0] = make_float4(pp[k].tx, pp[k].ty, pp[k].tz, 0.0f);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    if (lane < total - b0) {
+                        const float4 t = scratch[lane];
+                        Accum one{0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+                        pair_exact<false>(op, grid, t.x, t.y, t.z, one);
+                        scratch[lane] = make_float4(one.pot, one.col, 0.0f, 0.0f);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                    for (int k = 0; k < LB; ++k)
+                        if (rank[k] >= b0 && rank[k] < b0 + 64) {
+                            const float4 res = scratch[rank[k] - b0];
+                            acc[k].pot += res.x;
+                            acc[k].col += res.y;
+                        }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < LB; ++k) {
+                const int l = l0 + k;
+                if (a.soften && l >= 8) { acc[k].pot *= 0.1f; acc[k].col = 0.0f; }  // cost.py:350-353
+                if (acc[k].pot != 0.0f) {  // ||(x_i - x_{i-1}) / dt|| in float32 (config.py:162-187, cost.py:260-275)
+                    float qx, qy, qz;
+                    pose12_apply(ci > 0 ? base + ((int64_t)l * pstride + ci - 1) * 12 : lds_pose + (int64_t)l * pstride * 12, rv.pts(l, pc), qx, qy, qz);
+                    const float vx = (px[k] - qx) * a.inv_dt, vy = (py[k] - qy) * a.inv_dt, vz = (pz[k] - qz) * a.inv_dt;
+                    acc[k].pot = acc[k].pot * sqrtf(vx * vx + vy * vy + vz * vz);
+                }
+                if (valid && a.pot) a.pot[(((int64_t)s * a.C + chunk * CH + ci) * 10 + l) * P + p] = acc[k].pot;
+                tsum += acc[k].pot;
+                tcol += acc[k].col;
+            }
+        }
+    }
+    // a.pot must also receive the zeros of batches skipped above
+    {
+        const float ws_ = wave_sum(tsum), wc_ = wave_sum(tcol);
+        if (lane == 0) { red[0][wave] = ws_; red[1][wave] = wc_; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int64_t k = (int64_t)s * a.NCH + chunk;
+            if (a.chunk_cost) a.chunk_cost[k] = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
+            if (a.chunk_col) a.chunk_col[k] = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
+        }
+    }
+}
+
+// =================================================================================================
 // C ABI
 // =================================================================================================
 static thread_local char g_err[256] = "";
@@ -526,7 +691,15 @@ static int launch_chunks(ChunkArgs& ca, hipStream_t st) {
     if (lpw % lbu != 0) lbu = 1;  // the link batch must divide the links of a workgroup
     const size_t mask_bytes = (size_t)10 * ca.CH * sizeof(uint32_t);
 #define OMGX_LAUNCH_CHUNKS(G_, LB_) hipLaunchKernelGGL((k_sdf_chunks<G_, LB_, false>), dim3((unsigned)grid), dim3(256), mask_bytes, st, ca)
-    if (ca.traj_start) {  // fused FK (goal-set batch): dynamic LDS holds (CH + 1) x 10 poses
+    static int compact = -1;  // OMGX_COMPACT=0 keeps the unpacked exact path (A/B measurements)
+    if (compact < 0) { const char* e = getenv("OMGX_COMPACT"); compact = e ? atoi(e) : 1; }
+    if (ca.traj_start && compact && !ca.pot) {  // goal-set batch, cost only: packed exact path
+        const size_t lds = (size_t)(ca.CH + 1) * 120 * sizeof(double) + (((size_t)10 * ca.CH + 3) & ~(size_t)3) * sizeof(uint32_t) +
+                           4 * 64 * sizeof(float4);
+        if (lb == 10) hipLaunchKernelGGL((k_goalset_compact<10>), dim3((unsigned)grid), dim3(256), lds, st, ca);
+        else if (lb == 2) hipLaunchKernelGGL((k_goalset_compact<2>), dim3((unsigned)grid), dim3(256), lds, st, ca);
+        else hipLaunchKernelGGL((k_goalset_compact<5>), dim3((unsigned)grid), dim3(256), lds, st, ca);
+    } else if (ca.traj_start) {  // fused FK (goal-set batch): dynamic LDS holds (CH + 1) x 10 poses
         const size_t lds = (size_t)(ca.CH + 1) * 120 * sizeof(double) + mask_bytes;
         if (lbu == 1) hipLaunchKernelGGL((k_sdf_chunks<false, 1, true>), dim3((unsigned)grid), dim3(256), lds, st, ca);
         else hipLaunchKernelGGL((k_sdf_chunks<false, 2, true>), dim3((unsigned)grid), dim3(256), lds, st, ca);
