@@ -210,11 +210,11 @@ struct ChunkArgs {
 // start + (i+1)/(n+1) (goal - start) (util.py:261-290) and the workgroup runs their FK itself (one lane per
 // configuration, plus the start configuration) into dynamic LDS [(CH+1)][10][12] — no pose workspace round trip
 // through HBM and no separate FK launch.
-template <bool WANT_GRAD, int LB, bool FUSED>
-__global__ __launch_bounds__(256) void k_sdf_chunks(ChunkArgs a) {
+template <bool WANT_GRAD, int LB, bool FUSED, int TPB = 256>
+__global__ __launch_bounds__(TPB) void k_sdf_chunks(ChunkArgs a) {
     // dynamic LDS: [FUSED: (CH+1) x 10 poses of 12 doubles] then 10*CH row masks (candidate objects of each row)
     extern __shared__ __attribute__((aligned(16))) double lds_pose[];
-    __shared__ float red[2][4];
+    __shared__ float red[2][TPB / 64];
     uint32_t* rowmask = reinterpret_cast<uint32_t*>(lds_pose + (FUSED ? (size_t)(a.CH + 1) * 120 : 0));
     // XCD-aware placement: workgroup b runs on XCD b % 8 (observed; used for L2 affinity only).
     // All chunks of a scene go to the same XCD so the scene's SDF volumes stay in one 4 MiB L2.
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void k_sdf_chunks(ChunkArgs a) {
     const int p = threadIdx.x & 15, r = threadIdx.x >> 4;
     const RobotView rv(a.robot, P);
     if (FUSED) {
-        for (int cfg = threadIdx.x; cfg < CH + 1; cfg += 256) {
+        for (int cfg = threadIdx.x; cfg < CH + 1; cfg += TPB) {
             const double* q0 = a.traj_start + 9 * (int64_t)s;
             const double* qg = a.goals + ((int64_t)s * a.NCH + chunk) * 9;
             const double t = (double)cfg / (double)(CH + 1);  // cfg 0 = start itself, cfg i+1 = linspace(0,1,n+2)[1:-1][i]
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256) void k_sdf_chunks(ChunkArgs a) {
     // ---- phase A: row-level culling.  All P points of a row lie in the ball (link origin, RAD[l]); an object
     // whose far box (grown by that radius + 1e-4 m for float rounding) misses the ball centre on any axis
     // cannot be in range for any of them.  One lane per row; objects >= 31 share the last mask bit.
-    for (int row = l_begin * CH + threadIdx.x; row < l_end * CH; row += 256) {
+    for (int row = l_begin * CH + threadIdx.x; row < l_end * CH; row += TPB) {
         const int l = row / CH, ci = row - l * CH;
         uint32_t m = 0;
         if (ci < nvalid) {
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256) void k_sdf_chunks(ChunkArgs a) {
     // ---- phase B: points
     float tsum = 0.0f, tcol = 0.0f;
     if (p < P) {
-        for (int ci = r; ci < nvalid; ci += 16) {
+        for (int ci = r; ci < nvalid; ci += TPB / 16) {
             const int64_t out_cfg = ((int64_t)s * a.C + chunk * CH + ci) * 10;
 #pragma unroll 1
             for (int l0 = l_begin; l0 < l_end; l0 += LB) {
@@ -355,8 +355,11 @@ __global__ __launch_bounds__(256) void k_sdf_chunks(ChunkArgs a) {
         __syncthreads();
         if (threadIdx.x == 0) {
             const int64_t k = (int64_t)s * a.NCH + chunk;
-            if (a.chunk_cost) a.chunk_cost[k] = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
-            if (a.chunk_col) a.chunk_col[k] = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
+            float c0 = red[0][0], c1 = red[1][0];
+#pragma unroll
+            for (int w2 = 1; w2 < TPB / 64; ++w2) { c0 += red[0][w2]; c1 += red[1][w2]; }  // fixed order
+            if (a.chunk_cost) a.chunk_cost[k] = c0;
+            if (a.chunk_col) a.chunk_col[k] = c1;
         }
     }
 }
