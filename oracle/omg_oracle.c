@@ -10,10 +10,13 @@
  *     optimiser step are PINNED against outputs of the reference Python itself
  *     (tests/golden/make_golden.py imports /root/reference/omg/{cost,optimizer,config,util}.py and
  *     ycb_render/robotPose/robot_pykdl.py and dumps the .npz fixtures under tests/golden/).
- *   - The SDF op (orc_sdf_loss_forward) is PARITY UNPINNED by the reference: its only implementation
- *     is CUDA (layers/sdf_matching_loss_kernel.cu) which needs nvcc + Eigen + Sophus, none present,
- *     and the reference holds no test vectors for it.  It follows .cu:15-181 line by line and is
- *     checked by closed-form known-answer tests (tests/test_oracle_sdf.py).
+ *   - The SDF op (orc_sdf_loss_forward): its interpolation helpers (orc_sdf_value = getValueInterpolated, the
+ *     central differences = getGradientInterpolated, .cu:15-86) are PINNED against the reference's own source compiled
+ *     for the host (oracle/_ref, `make -C oracle ref`; tests/test_oracle_ref_helpers.py: bit-exact against the
+ *     FMA-contracted build).  The kernel BODY (.cu:96-181: pose transform, hinge, rotate-back, reduction) is PARITY
+ *     UNPINNED by the reference: it needs nvcc + ATen + Eigen + Sophus, none present, and the reference holds no test
+ *     vectors for it; it follows the source line by line and is checked by closed-form known-answer tests
+ *     (tests/test_oracle_sdf.py).
  *
  * Floating-point conventions, shared bit-for-bit with the HIP kernels (both are compiled with
  * -ffp-contract=off so only the explicit fma()s below fuse):
@@ -60,6 +63,21 @@ static float orc_sdf_value(float gx, float gy, float gz, int dx, int dy, int dz,
     const float dxy0 = orc_lerp(dx00, dx10, fy);
     const float dxy1 = orc_lerp(dx01, dx11, fy);
     return orc_lerp(dxy0, dxy1, fz);
+}
+
+/* Exported twins of the reference helpers, checked against oracle/_ref (the reference's own .cu:15-86 compiled for the
+ * host) in tests/test_oracle_ref_helpers.py. */
+float orc_value_interpolated(float gx, float gy, float gz, int dx, int dy, int dz, const float* g) {
+    return orc_sdf_value(gx, gy, gz, dx, dy, dz, g);
+}
+void orc_gradient_interpolated(float gx, float gy, float gz, int dx, int dy, int dz, const float* g, float delta, float* out3) {
+    /* getGradientInterpolated, .cu:66-86 */
+    const float fpx = orc_sdf_value(gx + 1.0f, gy, gz, dx, dy, dz, g), fmx = orc_sdf_value(gx - 1.0f, gy, gz, dx, dy, dz, g);
+    const float fpy = orc_sdf_value(gx, gy + 1.0f, gz, dx, dy, dz, g), fmy = orc_sdf_value(gx, gy - 1.0f, gz, dx, dy, dz, g);
+    const float fpz = orc_sdf_value(gx, gy, gz + 1.0f, dx, dy, dz, g), fmz = orc_sdf_value(gx, gy, gz - 1.0f, dx, dy, dz, g);
+    out3[0] = (float)(0.5 * (double)(fpx - fmx) / (double)delta);
+    out3[1] = (float)(0.5 * (double)(fpy - fmy) / (double)delta);
+    out3[2] = (float)(0.5 * (double)(fpz - fmz) / (double)delta);
 }
 
 /* One (point, object) pair: the body of SDFdistanceForward, .cu:111-180.  Adds into pot/grad/col. */
