@@ -408,6 +408,17 @@ __device__ __forceinline__ void pose12_apply(const double* __restrict__ A, const
     z = (float)(A[6] * p[0] + A[7] * p[1] + A[8] * p[2] + A[11]);
 }
 
+// Same for a pose stored as 9 doubles (rotation rows 0 and 1, translation): the third row of a proper rotation is
+// r0 x r1.  Saves a quarter of the LDS a workgroup needs for its poses (5 instead of 4 workgroups per CU); the
+// reconstructed row differs from the FK product's by ~1e-16 relative, like any re-association of the float64 FK.
+__device__ __forceinline__ void pose9_apply(const double* __restrict__ A, const double* __restrict__ p, float& x, float& y, float& z) {
+#pragma clang fp contract(fast)
+    const double r20 = A[1] * A[5] - A[2] * A[4], r21 = A[2] * A[3] - A[0] * A[5], r22 = A[0] * A[4] - A[1] * A[3];
+    x = (float)(A[0] * p[0] + A[1] * p[1] + A[2] * p[2] + A[6]);
+    y = (float)(A[3] * p[0] + A[4] * p[1] + A[5] * p[2] + A[7]);
+    z = (float)(r20 * p[0] + r21 * p[1] + r22 * p[2] + A[8]);
+}
+
 // -------------------------------------------------------------------------------------------------
 // wave / block reductions with a fixed combination order (deterministic results)
 // -------------------------------------------------------------------------------------------------

@@ -375,7 +375,7 @@ __global__ __launch_bounds__(TPB) void k_sdf_chunks(ChunkArgs a) {
 // the unpacked exact path (a link's 10 cm point cloud straddles the far box); packed, a batch of LB links needs
 // ceil(survivors / 64) exact passes instead of one per link.  Arithmetic per pair is unchanged (bit-identical).
 template <int LB>
-__global__ __launch_bounds__(256) void k_goalset_compact(ChunkArgs a) {
+__global__ __launch_bounds__(256, 5) void k_goalset_compact(ChunkArgs a) {
     extern __shared__ __attribute__((aligned(16))) double lds_pose[];
     __shared__ float red[2][4];
     const int xcd = blockIdx.x & 7;
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256) void k_goalset_compact(ChunkArgs a) {
     const int nvalid = CH;
     const int p = threadIdx.x & 15, r = threadIdx.x >> 4, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const RobotView rv(a.robot, P);
-    uint32_t* rowmask = reinterpret_cast<uint32_t*>(lds_pose + (size_t)(CH + 1) * 120);
+    uint32_t* rowmask = reinterpret_cast<uint32_t*>(lds_pose + (size_t)(CH + 1) * 90);  // poses: 9 doubles (see pose9_apply)
     float4* scratch = reinterpret_cast<float4*>(rowmask + ((10 * CH + 3) & ~3)) + wave * 64;  // wave-private [64]
 
     for (int cfg = threadIdx.x; cfg < CH + 1; cfg += 256) {  // FK of start + CH interpolated configurations
@@ -399,20 +399,20 @@ __global__ __launch_bounds__(256) void k_goalset_compact(ChunkArgs a) {
 #pragma unroll
         for (int d = 0; d < 9; ++d) q[d] = cfg == 0 ? q0[d] : q0[d] + t * (qg[d] - q0[d]);
         fk_chain(rv, q, [&](int l, const Pose& pose) {
-            double* dst = lds_pose + ((size_t)l * (CH + 1) + cfg) * 12;
+            double* dst = lds_pose + ((size_t)l * (CH + 1) + cfg) * 9;
 #pragma unroll
-            for (int k = 0; k < 9; ++k) dst[k] = pose.R[k];
-            dst[9] = pose.t[0]; dst[10] = pose.t[1]; dst[11] = pose.t[2];
+            for (int k = 0; k < 6; ++k) dst[k] = pose.R[k];
+            dst[6] = pose.t[0]; dst[7] = pose.t[1]; dst[8] = pose.t[2];
         });
     }
     __syncthreads();
-    const double* base = lds_pose + 12;
+    const double* base = lds_pose + 9;
     const int pstride = CH + 1;
 
     for (int row = threadIdx.x; row < 10 * CH; row += 256) {  // phase A: row-level culling (see k_sdf_chunks)
         const int l = row / CH, ci = row - l * CH;
-        const double* A = base + ((int64_t)l * pstride + ci) * 12;
-        const float cx = (float)A[9], cy = (float)A[10], cz = (float)A[11];
+        const double* A = base + ((int64_t)l * pstride + ci) * 9;
+        const float cx = (float)A[6], cy = (float)A[7], cz = (float)A[8];
         const float rad = (float)rv.radius(l) + 1.0e-4f;
         uint32_t m = 0;
         for (int o = o_begin; o < o_end; ++o) {
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(256) void k_goalset_compact(ChunkArgs a) {
             if (!__any(many != 0)) continue;  // nothing in reach of any row of this wave: potentials stay 0
 #pragma unroll
             for (int k = 0; k < LB; ++k)
-                pose12_apply(base + ((int64_t)(l0 + k) * pstride + cic) * 12, rv.pts(l0 + k, pc), px[k], py[k], pz[k]);
+                pose9_apply(base + ((int64_t)(l0 + k) * pstride + cic) * 9, rv.pts(l0 + k, pc), px[k], py[k], pz[k]);
             for (int o = o_begin; o < o_end; ++o) {
                 const int oo = o - o_begin;
                 const uint32_t bit = 1u << (oo < 31 ? oo : 31);
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(256) void k_goalset_compact(ChunkArgs a) {
                 if (a.soften && l >= 8) { acc[k].pot *= 0.1f; acc[k].col = 0.0f; }  // cost.py:350-353
                 if (acc[k].pot != 0.0f) {  // ||(x_i - x_{i-1}) / dt|| in float32 (config.py:162-187, cost.py:260-275)
                     float qx, qy, qz;
-                    pose12_apply(ci > 0 ? base + ((int64_t)l * pstride + ci - 1) * 12 : lds_pose + (int64_t)l * pstride * 12, rv.pts(l, pc), qx, qy, qz);
+                    pose9_apply(ci > 0 ? base + ((int64_t)l * pstride + ci - 1) * 9 : lds_pose + (int64_t)l * pstride * 9, rv.pts(l, pc), qx, qy, qz);
                     const float vx = (px[k] - qx) * a.inv_dt, vy = (py[k] - qy) * a.inv_dt, vz = (pz[k] - qz) * a.inv_dt;
                     acc[k].pot = acc[k].pot * sqrtf(vx * vx + vy * vy + vz * vz);
                 }
@@ -697,7 +697,7 @@ static int launch_chunks(ChunkArgs& ca, hipStream_t st) {
     static int compact = -1;  // OMGX_COMPACT=0 keeps the unpacked exact path (A/B measurements)
     if (compact < 0) { const char* e = getenv("OMGX_COMPACT"); compact = e ? atoi(e) : 1; }
     if (ca.traj_start && compact && !ca.pot) {  // goal-set batch, cost only: packed exact path
-        const size_t lds = (size_t)(ca.CH + 1) * 120 * sizeof(double) + (((size_t)10 * ca.CH + 3) & ~(size_t)3) * sizeof(uint32_t) +
+        const size_t lds = (size_t)(ca.CH + 1) * 90 * sizeof(double) + (((size_t)10 * ca.CH + 3) & ~(size_t)3) * sizeof(uint32_t) +
                            4 * 64 * sizeof(float4);
         if (lb == 10) hipLaunchKernelGGL((k_goalset_compact<10>), dim3((unsigned)grid), dim3(256), lds, st, ca);
         else if (lb == 2) hipLaunchKernelGGL((k_goalset_compact<2>), dim3((unsigned)grid), dim3(256), lds, st, ca);
