@@ -254,48 +254,64 @@ __global__ __launch_bounds__(CH_TPB) void k_chomp_optimize(ChompArgs a) {
     int tie_take = 0;      // how many keys == tau are selected (those with the highest flat index)
     bool tau_is_zero = false;
     if (topk_mode && K < total) {
-        uint32_t prefix = 0, mask = 0;
-        int want = K;  // rank (from the top) still to locate inside the current prefix bucket
-        for (int pass = 0; pass < 4; ++pass) {
-            const int shift = 24 - 8 * pass;
-            __syncthreads();
-            for (int e = tid; e < 256; e += blockDim.x) L.hist[e] = 0;
-            __syncthreads();
-            for (int f = tid; f < total; f += blockDim.x) {
-                const uint32_t key = float_key(pot[f]);
-                if ((key & mask) == prefix) atomicAdd(&L.hist[(key >> shift) & 255u], 1u);
-            }
-            __syncthreads();
-            if (tid < 64) {  // wave 0: locate the bin holding the `want`-th largest key (suffix sums over 256 bins)
-                // lane j owns bins 4j..4j+3; `above` = number of keys in bins above lane j's bins
-                const uint32_t h0 = L.hist[4 * tid], h1 = L.hist[4 * tid + 1], h2 = L.hist[4 * tid + 2], h3 = L.hist[4 * tid + 3];
-                const int mine = (int)(h0 + h1 + h2 + h3);
-                int incl = mine;  // inclusive suffix sum over lanes tid..63
+        // Most potentials are exactly 0 (points out of every object's reach).  They are the smallest keys and add
+        // nothing to cost or gradient, so count the non-zero ones first: if no more than K of them exist, every
+        // non-zero potential is selected and the radix select is not needed at all (the common case: K = 1000).
+        const uint32_t key0 = float_key(0.0f);
+        int mine = 0;
+        for (int f = tid; f < total; f += blockDim.x) mine += float_key(pot[f]) > key0 ? 1 : 0;
+        if (tid == 0) L.iscr[2] = 0;
+        __syncthreads();
+        if (mine) atomicAdd(&L.iscr[2], mine);
+        __syncthreads();
+        const int nz = L.iscr[2];
+        if (nz <= K) {
+            tau = key0;
+            tau_is_zero = true;
+            tie_take = K - nz;
+        } else {
+            uint32_t prefix = 0, mask = 0;
+            int want = K;  // rank (from the top) still to locate inside the current prefix bucket
+            for (int pass = 0; pass < 4; ++pass) {
+                const int shift = 24 - 8 * pass;
+                __syncthreads();
+                for (int e = tid; e < 256; e += blockDim.x) L.hist[e] = 0;
+                __syncthreads();
+                for (int f = tid; f < total; f += blockDim.x) {
+                    const uint32_t key = float_key(pot[f]);
+                    if (key > key0 && (key & mask) == prefix) atomicAdd(&L.hist[(key >> shift) & 255u], 1u);
+                }
+                __syncthreads();
+                if (tid < 64) {  // wave 0: locate the bin holding the `want`-th largest key (suffix sums over 256 bins)
+                    const uint32_t h0 = L.hist[4 * tid], h1 = L.hist[4 * tid + 1], h2 = L.hist[4 * tid + 2], h3 = L.hist[4 * tid + 3];
+                    const int minel = (int)(h0 + h1 + h2 + h3);
+                    int incl = minel;  // inclusive suffix sum over lanes tid..63
 #pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const int v = __shfl_down(incl, off, 64);
-                    if (tid + off < 64) incl += v;
-                }
-                const int above = incl - mine;
-                if (above < want && want <= incl) {  // exactly one lane
-                    int acc = above, b = 4 * tid + 3;
-                    const uint32_t hh[4] = {h0, h1, h2, h3};
-                    for (; b > 4 * tid; --b) {
-                        if (acc + (int)hh[b - 4 * tid] >= want) break;
-                        acc += (int)hh[b - 4 * tid];
+                    for (int off = 1; off < 64; off <<= 1) {
+                        const int v = __shfl_down(incl, off, 64);
+                        if (tid + off < 64) incl += v;
                     }
-                    L.iscr[0] = b;
-                    L.iscr[1] = want - acc;
+                    const int above = incl - minel;
+                    if (above < want && want <= incl) {  // exactly one lane
+                        int acc = above, b = 4 * tid + 3;
+                        const uint32_t hh[4] = {h0, h1, h2, h3};
+                        for (; b > 4 * tid; --b) {
+                            if (acc + (int)hh[b - 4 * tid] >= want) break;
+                            acc += (int)hh[b - 4 * tid];
+                        }
+                        L.iscr[0] = b;
+                        L.iscr[1] = want - acc;
+                    }
                 }
+                __syncthreads();
+                prefix |= (uint32_t)L.iscr[0] << shift;
+                mask |= 255u << shift;
+                want = L.iscr[1];
             }
-            __syncthreads();
-            prefix |= (uint32_t)L.iscr[0] << shift;
-            mask |= 255u << shift;
-            want = L.iscr[1];
+            tau = prefix;
+            tie_take = want;  // >= 1
+            tau_is_zero = false;
         }
-        tau = prefix;
-        tie_take = want;  // >= 1
-        tau_is_zero = (tau == float_key(0.0f));
     }
     __syncthreads();  // FK results visible
     // Ties at a non-zero threshold: the reference keeps whichever numpy's unstable argsort placed last;
