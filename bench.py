@@ -105,8 +105,8 @@ def cpu_baseline(cfg, model, batch, start, goals, n, budget_s=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--scenes", type=int, default=100, help="scenes per GPU")
     ap.add_argument("--goals", type=int, default=64)
     ap.add_argument("--waypoints", type=int, default=30)
@@ -167,7 +167,7 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    lib.omgx_timing_enable(1)
+    lib.omgx_timing_enable(0 if os.environ.get("OMGX_NO_TIMING") else 1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()

@@ -203,7 +203,8 @@ int omgx_forward_kinematics(const double* robot, int32_t n_points, const double*
  * multi_interpolate_waypoints(..., "linear") (omg/util.py:261-290) -> Cost.batch_obstacle_cost with
  * arc_length = n_remaining (omg/cost.py:192-286, incl. get_derivative_torch, config.py:162-187)
  * -> sum over (link, point) and over the n_remaining waypoints, for S scenes x G goals.
- *   traj_start [S,9]  the waypoint the interpolation starts from (traj.data[start])
+ *   traj_start row s at traj_start + s * traj_start_stride doubles: the waypoint the interpolation starts from
+ *              (traj.data[start]); stride 9 for a dense [S,9] array, n*9 to point into a [S,n,9] trajectory tensor
  *   goals      [S,G,9]
  *   goal_cost  [S,G]  float32 out: sum_i sum_link sum_pt potential * ||velocity||
  *   potentials [S,G,n_remaining,10,P] float32 out, optional (NULL to skip) — the weighted
@@ -214,7 +215,7 @@ int omgx_forward_kinematics(const double* robot, int32_t n_points, const double*
 int64_t omgx_goalset_workspace_bytes(int32_t num_scenes, int32_t num_goals, int32_t n_remaining, int32_t n_points);
 int omgx_goalset_cost(const double* robot, int32_t n_points,
                       const omgx_object* objects, const int32_t* scene_begin, const float* sdf_pool,
-                      const double* traj_start, const double* goals,
+                      const double* traj_start, int64_t traj_start_stride, const double* goals,
                       int32_t num_scenes, int32_t num_goals, int32_t n_remaining,
                       double time_interval, int32_t soften_fingers,
                       float* goal_cost, float* potentials, float* collides, void* workspace, void* stream);

@@ -101,7 +101,8 @@ struct FkArgs {
     int P;
     int mode;
     const double* joints;      // mode 0: [S][C][9]
-    const double* traj_start;  // mode 1: [S][9]
+    const double* traj_start;  // mode 1/2: row s at traj_start + s * ts_stride
+    int64_t ts_stride;
     const double* goals;       // mode 1: [S][G][9]
     int S, C;                  // C configs per scene (mode 1: C = G * n)
     int n;                     // mode 1: waypoints per goal
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(64) void k_fk_poses(FkArgs a) {
     double q[9];
     if (a.mode == 0 || a.mode == 2) {  // explicit joints; mode 2 adds one start configuration per scene
         if (a.mode == 2 && c == a.C) {
-            const double* q0 = a.traj_start + 9 * (int64_t)s;
+            const double* q0 = a.traj_start + a.ts_stride * (int64_t)s;
 #pragma unroll
             for (int d = 0; d < 9; ++d) q[d] = q0[d];
             rowptr[lane] = a.ws_start + (int64_t)s * 120;
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(64) void k_fk_poses(FkArgs a) {
             rowstride[lane] = CH * 12;
         }
     } else {
-        const double* q0 = a.traj_start + 9 * (int64_t)s;
+        const double* q0 = a.traj_start + a.ts_stride * (int64_t)s;
         if (c == a.C) {  // the start configuration of the scene (ws_positions_start, cost.py:240-251)
 #pragma unroll
             for (int d = 0; d < 9; ++d) q[d] = q0[d];
@@ -194,7 +195,8 @@ struct ChunkArgs {
     float* chunk_cost;      // [S][NCH] or null: sum of (weighted) potentials of the chunk
     float* chunk_col;       // [S][NCH] or null: sum of collides of the chunk
     // fused FK (goal-set batch): the workgroup computes its own link poses into LDS instead of reading ws
-    const double* traj_start;  // [S][9]
+    const double* traj_start;  // row s at traj_start + s * ts_stride
+    int64_t ts_stride;
     const double* goals;       // [S][NCH][9]
 };
 
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(TPB) void k_sdf_chunks(ChunkArgs a) {
     const RobotView rv(a.robot, P);
     if (FUSED) {
         for (int cfg = threadIdx.x; cfg < CH + 1; cfg += TPB) {
-            const double* q0 = a.traj_start + 9 * (int64_t)s;
+            const double* q0 = a.traj_start + a.ts_stride * (int64_t)s;
             const double* qg = a.goals + ((int64_t)s * a.NCH + chunk) * 9;
             const double t = (double)cfg / (double)(CH + 1);  // cfg 0 = start itself, cfg i+1 = linspace(0,1,n+2)[1:-1][i]
             double q[9];
@@ -392,7 +394,7 @@ __global__ __launch_bounds__(256, 5) void k_goalset_compact(ChunkArgs a) {
     float4* scratch = reinterpret_cast<float4*>(rowmask + ((10 * CH + 3) & ~3)) + wave * 64;  // wave-private [64]
 
     for (int cfg = threadIdx.x; cfg < CH + 1; cfg += 256) {  // FK of start + CH interpolated configurations
-        const double* q0 = a.traj_start + 9 * (int64_t)s;
+        const double* q0 = a.traj_start + a.ts_stride * (int64_t)s;
         const double* qg = a.goals + ((int64_t)s * a.NCH + chunk) * 9;
         const double t = (double)cfg / (double)(CH + 1);
         double q[9];
@@ -738,7 +740,7 @@ extern "C" int omgx_fk_sdf(const double* robot, int32_t n_points, const omgx_obj
     double* ws = (double*)workspace;
     double* ws_start = ws + (int64_t)num_scenes * NCH * 10 * CH * 12;
     FkArgs fa{};
-    fa.robot = robot; fa.P = n_points; fa.mode = arc ? 2 : 0; fa.joints = joints; fa.traj_start = arc_start;
+    fa.robot = robot; fa.P = n_points; fa.mode = arc ? 2 : 0; fa.joints = joints; fa.traj_start = arc_start; fa.ts_stride = 9;
     fa.S = num_scenes; fa.C = configs_per_scene; fa.CH = CH; fa.ws = ws; fa.ws_start = ws_start;
     const int64_t total = (int64_t)num_scenes * (configs_per_scene + (arc ? 1 : 0));
     hipLaunchKernelGGL(k_fk_poses, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, st, fa);
@@ -800,7 +802,8 @@ extern "C" int omgx_forward_kinematics(const double* robot, int32_t n_points, co
 
 extern "C" int omgx_goalset_cost(const double* robot, int32_t n_points, const omgx_object* objects,
                                  const int32_t* scene_begin, const float* sdf_pool, const double* traj_start,
-                                 const double* goals, int32_t num_scenes, int32_t num_goals, int32_t n_remaining,
+                                 int64_t traj_start_stride, const double* goals, int32_t num_scenes, int32_t num_goals,
+                                 int32_t n_remaining,
                                  double time_interval, int32_t soften_fingers, float* goal_cost, float* potentials,
                                  float* collides, void* workspace, void* stream) {
     if (num_scenes < 0 || num_goals < 0) return OMGX_ERR_INVALID;
@@ -808,7 +811,7 @@ extern "C" int omgx_goalset_cost(const double* robot, int32_t n_points, const om
     if (!robot || !objects || !scene_begin || !traj_start || !goals || !goal_cost || !workspace) return OMGX_ERR_INVALID;
     if (n_points < 1 || n_points > OMGX_MAX_POINTS || n_remaining < 1 || n_remaining > OMGX_MAX_WAYPOINTS)
         return OMGX_ERR_UNSUPPORTED;
-    if (!(time_interval > 0.0)) return OMGX_ERR_INVALID;
+    if (!(time_interval > 0.0) || traj_start_stride < 9) return OMGX_ERR_INVALID;
     hipStream_t st = (hipStream_t)stream;
     const int n = n_remaining, C = num_goals * n;
     double* ws = (double*)workspace;
@@ -817,7 +820,7 @@ extern "C" int omgx_goalset_cost(const double* robot, int32_t n_points, const om
     if (fused < 0) { const char* e = getenv("OMGX_FUSED_FK"); fused = e ? atoi(e) : 1; }
     if (!fused) {
         FkArgs fa{};
-        fa.robot = robot; fa.P = n_points; fa.mode = 1; fa.traj_start = traj_start; fa.goals = goals; fa.S = num_scenes;
+        fa.robot = robot; fa.P = n_points; fa.mode = 1; fa.traj_start = traj_start; fa.ts_stride = traj_start_stride; fa.goals = goals; fa.S = num_scenes;
         fa.C = C; fa.n = n; fa.CH = n; fa.ws = ws; fa.ws_start = ws_start;
         const int64_t total = (int64_t)num_scenes * (C + 1);
         hipLaunchKernelGGL(k_fk_poses, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, st, fa);
@@ -828,6 +831,6 @@ extern "C" int omgx_goalset_cost(const double* robot, int32_t n_points, const om
     ca.S = num_scenes; ca.C = C; ca.CH = n; ca.NCH = num_goals; ca.P = n_points; ca.soften = soften_fingers != 0;
     ca.arc = 1; ca.inv_dt = (float)(1.0 / time_interval);
     ca.pot = potentials; ca.grad = nullptr; ca.col = nullptr; ca.chunk_cost = goal_cost; ca.chunk_col = collides;
-    if (fused) { ca.traj_start = traj_start; ca.goals = goals; }
+    if (fused) { ca.traj_start = traj_start; ca.ts_stride = traj_start_stride; ca.goals = goals; }
     return launch_chunks(ca, st);
 }

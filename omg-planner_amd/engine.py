@@ -172,7 +172,7 @@ class ChompEngine:
         prm = self._learner_params()
         if self.ol_alg != "Proj":  # cost_vector's obstacle batch (online_learner.py:128-148)
             n_rem = self.cfg.timesteps - prm.start_idx
-            traj_start = self.traj[:, prm.start_idx].contiguous()
+            traj_start = self.traj[:, prm.start_idx]  # strided view into the trajectory tensor: no copy kernel
             ops.goalset_cost(self.robot, self.P, self.scenes, traj_start, self.cv_goals, n_rem, self.cfg.time_interval,
                              soften_fingers=False, out=(self.goal_cost, self.goal_col))
         ops.goal_update(prm, self.traj, self.goal_set, self.reach, self.goal_cost, self.learner_state, self.goal_idx,
