@@ -226,7 +226,7 @@ def main():
         tfile = ROOT / "profiles" / "traffic.json"
         if tfile.exists():  # PMC numbers of the same command, collected by tools/collect_profiles.sh
             tj = json.loads(tfile.read_text())
-            traffic, valu_busy, l2_hit = tj.get("k_sdf_chunks_goalset_bytes_per_launch"), tj.get("valu_busy_frac"), tj.get("l2_hit_rate")
+            traffic, valu_busy, l2_hit = tj.get("goalset_kernel_bytes_per_launch", tj.get("k_sdf_chunks_goalset_bytes_per_launch")), tj.get("valu_busy_frac"), tj.get("l2_hit_rate")
         out = {
             "metric": "CHOMP iterations/sec (batched scenes)",
             "value": world * S * args.steps / elapsed,

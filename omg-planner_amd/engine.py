@@ -22,6 +22,8 @@ closes the job (``gather_costs``).
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -99,7 +101,7 @@ class ChompEngine:
         self.t = 0           # Learner.t
         # The waypoint SDF batch (omgx_fk_sdf on traj) does not depend on the goal selection, only k_chomp_optimize
         # does: it runs on a side stream concurrently with the goal-set batch + goal update and joins before the step.
-        self.side_stream = torch.cuda.Stream(device=dev)
+        self.side_stream = torch.cuda.Stream(device=dev, priority=-1)  # high priority: its few workgroups slot in early
         self._ev_fork = torch.cuda.Event()
         self._ev_join = torch.cuda.Event()
         self._gather_goal()
@@ -202,6 +204,8 @@ class ChompEngine:
                 return self.iterate(t, early_stop, overlap)
         cfg = self.cfg
         select = cfg.goal_set_proj and t < cfg.optim_steps
+        if os.environ.get("OMGX_NO_OVERLAP"):  # profiling aid: device-wide PMC counters need kernels one at a time
+            overlap = False
         if select and overlap:
             main = torch.cuda.current_stream(self.device)
             self._ev_fork.record(main)
