@@ -127,12 +127,18 @@ def main():
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU; OMGX_BENCH_BACKEND=gloo lets several ranks share one GPU for a functional test of this path
+    backend = os.environ.get("OMGX_BENCH_BACKEND", "nccl")
+    local_dev = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from omg_planner_amd import _lib
     from omg_planner_amd.engine import ChompEngine
@@ -174,7 +180,9 @@ def main():
     torch.cuda.synchronize()
     costs = torch.cat([e.final_costs() for e in engines])
     from omg_planner_amd.engine import gather_costs_equal
-    allc = gather_costs_equal(costs, world)  # the job's one collective (RCCL all-gather over xGMI)
+    # the job's one collective (RCCL all-gather over xGMI; host tensors under the gloo test backend)
+    allc = gather_costs_equal(costs if backend == "nccl" else costs.cpu(), world)
+    assert allc.numel() == world * S
     barrier()
     elapsed = time.perf_counter() - t0
     buf = (C.c_float * 4096)()
@@ -183,7 +191,7 @@ def main():
     lib.omgx_timing_enable(0)
     if world > 1:
         import torch.distributed as dist
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
