@@ -85,8 +85,9 @@ typedef struct omgx_object {
     int32_t disabled;    /* 1 = skip (name == "floor" or in cfg.disable_collision_set)               */
     int64_t grid_offset; /* element offset of this object's grid inside the sdf pool                 */
     double inv_extent[3]; /* derived: 1.0 / (double)((float)hi[a] - (float)lo[a])                     */
-    float far_lo[3];     /* derived: -1.5 voxels   } a point whose offset t = R p + t - lo lies outside  */
-    float far_hi[3];     /* derived: extent + 1.5 voxels } [far_lo, far_hi] is out of range for sure     */
+    float far_lo[3];     /* derived: any box in offset coordinates t = R p + t - lo outside which a lookup adds nothing  */
+    float far_hi[3];     /*   (value > epsilon and >= clearance).  Default: the grid, [-1.5 voxels, extent + 1.5 voxels];  */
+                         /*   scenes.tighten_far_boxes() shrinks it to the base cells that can matter                     */
     double inv_delta;    /* derived: 1.0 / (double)delta                                              */
     float inv_2eps;      /* derived: 1.0f / (2.0f * epsilon)   (float32 arithmetic, .cu:167)           */
     float inv_eps;       /* derived: 1.0f / epsilon            (float32 arithmetic, .cu:168)           */

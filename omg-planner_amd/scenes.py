@@ -61,6 +61,65 @@ def finish_records(rec: np.ndarray) -> np.ndarray:
     return rec
 
 
+def influence_range(grid: np.ndarray, epsilon: float, clearance: float):
+    """Per-axis range [bmin, bmax] of the lookup base indices whose trilinear value can be <= epsilon or < clearance
+    (anything else adds neither potential, gradient nor collision, .cu:150-171), or None when no base index can.
+
+    A lookup with base index b evaluates the trilinear polynomial of voxels b..b+1 at fractions in [0,1), and in
+    (-1,1) on an axis where b == 0 (trunc-toward-zero extrapolation, .cu:39-48).  A multilinear function takes its
+    extrema at the vertices of its domain, so the minimum over a base cell is the minimum of the corner voxels and,
+    on a b == 0 axis, of the linearly extended layer 2 v[0] - v[1].  A relative margin absorbs the float32 rounding of
+    the lerp chain; non-finite voxels count as reachable."""
+    g = np.asarray(grid, np.float32).astype(np.float64)
+    if min(g.shape) < 2:
+        return None
+    for ax in range(3):  # prepend the extended layer f = -1 on every axis
+        first = np.take(g, [0], axis=ax) * 2.0 - np.take(g, [1], axis=ax)
+        g = np.concatenate([first, g], axis=ax)
+    bad = ~np.isfinite(g)
+    g = np.where(bad, -np.inf, g)
+    for ax in range(3):  # min over the vertices of every base cell; cell 0 also sees the extended layer
+        n = g.shape[ax]
+        w = np.minimum(np.take(g, range(0, n - 1), axis=ax), np.take(g, range(1, n), axis=ax))  # ext windows [e, e+1]
+        head = np.minimum(np.take(w, [0], axis=ax), np.take(w, [1], axis=ax))
+        g = np.concatenate([head, np.take(w, range(2, n - 1), axis=ax)], axis=ax)
+    margin = 1e-5 * max(1.0, float(np.abs(np.asarray(grid, np.float64)[np.isfinite(grid)]).max(initial=1.0)))
+    need = (g <= float(np.float32(epsilon)) + margin) | (g < float(np.float32(clearance)) + margin)
+    if not need.any():
+        return None
+    lo, hi = [], []
+    for ax in range(3):
+        idx = np.flatnonzero(need.any(axis=tuple(a for a in range(3) if a != ax)))
+        lo.append(int(idx[0])); hi.append(int(idx[-1]))
+    return np.array(lo), np.array(hi)
+
+
+def tighten_far_boxes(rec: np.ndarray, pool: np.ndarray) -> np.ndarray:
+    """Shrink the far box of every record from the whole grid to the voxels that can matter (influence_range):
+    far_lo = (bmin - 1.5) voxels, far_hi = (bmax + 3.5) voxels — the same 1 / 2 voxels of slack around the
+    exact thresholds g >= bmin - 0.5 and g < bmax + 1.5 as the default box of finish_records (bmin = 0, bmax = dim - 2).
+    Only meaningful where the kernels use the box at all (epsilon < 1 and clearance <= 1)."""
+    cache = {}
+    for r in rec:
+        d = r["dim"].astype(np.int64)
+        w = (r["hi"].astype(np.float32) - r["lo"].astype(np.float32)).astype(np.float32)
+        if not ((w > 0).all() and (d > 1).all() and r["epsilon"] < 1.0 and r["clearance"] <= 1.0):
+            continue
+        key = (int(r["grid_offset"]), tuple(d), float(r["epsilon"]), float(r["clearance"]))
+        if key not in cache:
+            g = pool[key[0]: key[0] + int(d.prod())].reshape(tuple(d))
+            cache[key] = influence_range(g, key[2], key[3])
+        rng = cache[key]
+        vox = w / d.astype(np.float32)
+        if rng is None:  # nothing reachable: an empty box rejects every point
+            r["far_lo"] = np.inf
+            r["far_hi"] = -np.inf
+            continue
+        r["far_lo"] = np.maximum(r["far_lo"], ((rng[0] - 1.5) * vox).astype(np.float32))
+        r["far_hi"] = np.minimum(r["far_hi"], ((rng[1] + 3.5) * vox).astype(np.float32))
+    return rec
+
+
 @dataclass
 class SdfGrid:
     """What the path reads of SignedDensityField (omg/sdf_tools.py:17-35): data[x,y,z], origin, delta."""
@@ -229,7 +288,7 @@ class SceneBatch:
         return SceneBatch(rec, (self.scene_begin[first:last + 1] - lo_o).astype(np.int32), self.pool[p0:p1])
 
 
-def pack_table(scenes, cfg_kwargs=None, ragged: bool = True, share_grids: bool = True) -> SceneBatch:
+def pack_table(scenes, cfg_kwargs=None, ragged: bool = True, share_grids: bool = True, tight: bool = True) -> SceneBatch:
     """Pack scenes into the engine layout.
 
     ragged=True keeps every grid at its own shape (true limits); ragged=False reproduces the
@@ -237,6 +296,8 @@ def pack_table(scenes, cfg_kwargs=None, ragged: bool = True, share_grids: bool =
     rounding of the grid coordinate (u-lo)/(hi-lo)*dim; inside the stretched box the padded layout reads
     the 1.0 padding value where the ragged one returns the out-of-range 1.0 — the same number.
     share_grids=True stores a grid referenced by several scenes once (same ndarray object).
+    tight=True shrinks each record's far box to the voxels that can contribute (tighten_far_boxes): same results,
+    fewer exact lookups.
     """
     cfg_kwargs = cfg_kwargs or {}
     recs, begins, chunks, offset = [], [0], [], 0
@@ -272,8 +333,11 @@ def pack_table(scenes, cfg_kwargs=None, ragged: bool = True, share_grids: bool =
             offset += sdf.size
             recs.extend(list(t))
         begins.append(len(recs))
-    return SceneBatch(finish_records(np.array(recs, OBJECT_DTYPE)), np.array(begins, np.int32),
-                      np.concatenate(chunks) if chunks else np.zeros(0, np.float32))
+    rec = finish_records(np.array(recs, OBJECT_DTYPE))
+    pool = np.concatenate(chunks) if chunks else np.zeros(0, np.float32)
+    if tight:
+        tighten_far_boxes(rec, pool)
+    return SceneBatch(rec, np.array(begins, np.int32), pool)
 
 
 # ------------------------------------------------------------------------------------------------
