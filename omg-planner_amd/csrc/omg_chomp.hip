@@ -41,6 +41,17 @@ using namespace omg;
 #define CH_TPB 512
 #define CH_WAVES (CH_TPB / 64)
 
+// Debug aid (make CXXFLAGS+=-DOMGX_PHASE_TIMING): workgroup 0 stamps the shader clock at the phase boundaries;
+// tools/phase_timing.py reads them through omgx_debug_phase_times.  Not part of the ABI, compiled out by default.
+#ifdef OMGX_PHASE_TIMING
+__device__ unsigned long long g_chomp_phase[32];
+#define PHASE_MARK(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_chomp_phase[i] = __builtin_readcyclecounter(); } while (0)
+#define PHASE_MARK_T(i, t) do { if (blockIdx.x == 0 && threadIdx.x == (t)) g_chomp_phase[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define PHASE_MARK_T(i, t) do { } while (0)
+#define PHASE_MARK(i) do { } while (0)
+#endif
+
 namespace {
 
 struct ChompArgs {
@@ -59,6 +70,7 @@ struct ChompArgs {
     double* cost_traj;         // [S][n]
     double* info;              // [S][16]
     double* aux;               // [S][aux_doubles(n)] or null
+    int pot_in_lds;            // host decision: the item-ordered copy of the potentials fits beside the rest
 };
 
 // wrap_joint(l+1) (omg/util.py:213-220): k-th joint index (into the 10-joint tables) of link l; count via njoints().
@@ -90,9 +102,10 @@ struct Lds {
     uint32_t* hist;  // [256]
     uint32_t* tie;   // [(n*10*16+31)/32] tie bit mask
     int* iscr;       // [16] int scalars
+    float* potl;     // [n*160] this trajectory's potentials by item (0 in the padding lanes), or null when LDS is short
 };
 
-__device__ __forceinline__ Lds carve(unsigned char* base, int n, int P) {
+__device__ __forceinline__ Lds carve(unsigned char* base, int n, int P, bool pot_in_lds) {
     Lds L;
     double* d = reinterpret_cast<double*>(base);
     L.pose = d; d += (size_t)(n + 2) * 120;
@@ -112,7 +125,8 @@ __device__ __forceinline__ Lds carve(unsigned char* base, int n, int P) {
     L.gwin = ip; ip += n * 10;
     L.hist = reinterpret_cast<uint32_t*>(ip); ip += 256;
     L.tie = reinterpret_cast<uint32_t*>(ip); ip += (n * 160 + 31) / 32;
-    L.iscr = ip;
+    L.iscr = ip; ip += 16;
+    L.potl = pot_in_lds ? reinterpret_cast<float*>(ip) : nullptr;
     return L;
 }
 
@@ -214,7 +228,7 @@ __global__ __launch_bounds__(CH_TPB) void k_chomp_optimize(ChompArgs a) {
     const int n = prm.n_waypoints, P = prm.n_points, c = prm.constraint_num;
     const double dt = prm.time_interval, dt2 = dt * dt;
     const bool free_end = prm.goal_set_proj != 0;
-    const Lds L = carve(smem, n, P);
+    const Lds L = carve(smem, n, P, a.pot_in_lds != 0);
     const RobotView rv(a.robot, P);
     const int tid = threadIdx.x;
     const int total = n * 10 * P;             // reference flat size of potentials [n][10][P]
@@ -227,26 +241,68 @@ __global__ __launch_bounds__(CH_TPB) void k_chomp_optimize(ChompArgs a) {
     const double* end = a.end + 9 * (size_t)s;
 
     // ---------------------------------------------------------------- phase 0: loads + FK
+    PHASE_MARK(0);
     for (int e = tid; e < n * 9; e += blockDim.x) L.xi[e] = traj[e];
     for (int e = tid; e < 30 * P; e += blockDim.x) L.pts[e] = rv.pts(0, 0)[e];
     for (int e = tid; e < 60; e += blockDim.x) L.jconst[e] = (e % 6 < 3) ? rv.ax(e / 6)[e % 6] : rv.og(e / 6)[e % 6 - 3];
     for (int e = tid; e < 256; e += blockDim.x) L.hist[e] = 0;
     for (int e = tid; e < (nitems + 31) / 32; e += blockDim.x) L.tie[e] = 0;
+    if (tid == 0) { L.iscr[2] = 0; L.red[50] = 0.0; L.red[51] = 0.0; }
+    // This thread's potentials / collision flags: all loads are issued back to back (one memory latency instead of
+    // one per item) and stay in flight while the FK waves work; first use is after the FK.
+    // Items it = r * CH_TPB + tid, item = (i*10 + l)*16 + p.
+    constexpr int MAXIT = (OMGX_MAX_WAYPOINTS * 160 + CH_TPB - 1) / CH_TPB;
+    float pv[MAXIT], cv[MAXIT];
+    if (L.potl) {
+#pragma unroll
+        for (int r = 0; r < MAXIT; ++r) {
+            const int it = r * CH_TPB + tid, p = it & 15, grp = it >> 4;
+            const bool valid = it < nitems && p < P;
+            const int f = valid ? grp * P + p : 0;  // padding lanes read element 0 and are masked at the use sites:
+            pv[r] = pot[f];                         // a select here would make the wave wait for the load right away
+            cv[r] = col[f];
+        }
+    }
     __syncthreads();
-    if (tid < n + 2) {  // one lane per configuration: start, waypoints, end (cost.py:124-165)
-        double q[9];
-        const double* src = tid == 0 ? start : (tid == n + 1 ? end : L.xi + 9 * (tid - 1));
-#pragma unroll
-        for (int d = 0; d < 9; ++d) q[d] = src[d];
-        fk_chain(rv, q, [&](int l, const Pose& pose) {
-            double* dst = L.pose + ((size_t)tid * 10 + l) * 12;
-#pragma unroll
-            for (int k = 0; k < 9; ++k) dst[k] = pose.R[k];
-            dst[9] = pose.t[0]; dst[10] = pose.t[1]; dst[11] = pose.t[2];
+    PHASE_MARK_T(16, CH_TPB - 128);
+    // FK of start, waypoints, end (cost.py:124-165) in two stages (omg_device.h: fk_chain_row); the (sin, cos) table
+    // borrows L.gl, which is first written in phase 2/3.
+    const int ncfg = n + 2;
+    double* sc = L.gl;  // [ncfg][7][2]
+    auto config_of = [&](int cfg) { return cfg == 0 ? start : (cfg == ncfg - 1 ? end : L.xi + 9 * (cfg - 1)); };
+    for (int t = tid; t < ncfg * 7; t += blockDim.x) {
+        const int cfg = t / 7, i = t - cfg * 7;
+        double sn, cs;
+        fk_joint_sincos(config_of(cfg)[i], sn, cs);
+        sc[2 * t] = sn; sc[2 * t + 1] = cs;
+    }
+    __syncthreads();
+    for (int t = tid; t < ncfg * 3; t += blockDim.x) {
+        const int cfg = t / 3, r = t - cfg * 3;
+        const double* q = config_of(cfg);
+        double* dst0 = L.pose + (size_t)cfg * 120 + 3 * r;
+        fk_chain_row(rv, r, sc + 14 * cfg, q[7], q[8], [&](int l, double r0, double r1, double r2, double tr) {
+            double* dst = dst0 + 12 * l;
+            dst[0] = r0; dst[1] = r1; dst[2] = r2;
+            dst[9 - 2 * r] = tr;  // element 9 + r of the pose
         });
     }
 
+    PHASE_MARK_T(17, CH_TPB - 128);
+    PHASE_MARK_T(20, 0);
+    double colsum = 0.0;
+    if (L.potl) {
+#pragma unroll
+        for (int r = 0; r < MAXIT; ++r) {  // same order as the per-item loop; padding adds +0.0
+            const int it = r * CH_TPB + tid;
+            const bool valid = it < nitems && (it & 15) < P;
+            asm volatile("" : "+v"(pv[r]), "+v"(cv[r]));  // first use stays here: no wait for the loads before the FK
+            pv[r] = valid ? pv[r] : 0.0f;
+            colsum += valid ? (double)cv[r] : 0.0;
+        }
+    }
     // ---------------------------------------------------------------- phase 1: top-k threshold (cost.py:392-398)
+    PHASE_MARK(1);
     // Radix select of the K-th largest key over the `total` potentials, 4 passes of 8 bits.
     const int K = prm.top_k;
     const bool topk_mode = K > 0;
@@ -259,10 +315,13 @@ __global__ __launch_bounds__(CH_TPB) void k_chomp_optimize(ChompArgs a) {
         // non-zero potential is selected and the radix select is not needed at all (the common case: K = 1000).
         const uint32_t key0 = float_key(0.0f);
         int mine = 0;
-        for (int f = tid; f < total; f += blockDim.x) mine += float_key(pot[f]) > key0 ? 1 : 0;
-        if (tid == 0) L.iscr[2] = 0;
-        __syncthreads();
-        if (mine) atomicAdd(&L.iscr[2], mine);
+        if (L.potl) {
+#pragma unroll
+            for (int r = 0; r < MAXIT; ++r) mine += float_key(pv[r]) > key0 ? 1 : 0;
+        } else {
+            for (int f = tid; f < total; f += blockDim.x) mine += float_key(pot[f]) > key0 ? 1 : 0;
+        }
+        if (mine) atomicAdd(&L.iscr[2], mine);  // zeroed before the first barrier
         __syncthreads();
         const int nz = L.iscr[2];
         if (nz <= K) {
@@ -313,7 +372,18 @@ __global__ __launch_bounds__(CH_TPB) void k_chomp_optimize(ChompArgs a) {
             tau_is_zero = false;
         }
     }
+    PHASE_MARK_T(18, CH_TPB - 128);
+    PHASE_MARK_T(21, 0);
+    if (L.potl) {
+#pragma unroll
+        for (int r = 0; r < MAXIT; ++r) {
+            const int it = r * CH_TPB + tid;
+            if (it < nitems) L.potl[it] = pv[r];
+        }
+    }
+    PHASE_MARK_T(22, 0);
     __syncthreads();  // FK results visible
+    PHASE_MARK_T(19, CH_TPB - 128);
     // Ties at a non-zero threshold: the reference keeps whichever numpy's unstable argsort placed last;
     // this build (like the oracle) defines it as the highest flat indices.  Mark them in a bit mask.
     if (topk_mode && K < total && !tau_is_zero) {
@@ -323,16 +393,20 @@ __global__ __launch_bounds__(CH_TPB) void k_chomp_optimize(ChompArgs a) {
     }
 
     // ---------------------------------------------------------------- phase 2: per point
+    PHASE_MARK(2);
     const int mlinks = topk_mode ? (prm.consider_finger ? 10 : 8) : 10;  // cost.py:401-404
-    double colsum = 0.0;
     for (int it0 = 0; it0 < nitems; it0 += blockDim.x) {
         const int it = it0 + tid;
         const bool inb = it < nitems;
         const int p = it & 15, grp = it >> 4, l = grp % 10, i = grp / 10;
         const bool valid = inb && p < P;
         const int f = valid ? (i * 10 + l) * P + p : 0;
-        const float cf = valid ? pot[f] : 0.0f;
-        if (valid) colsum += (double)col[f];
+        float cf;
+        if (L.potl) cf = inb ? L.potl[it] : 0.0f;
+        else {
+            cf = valid ? pot[f] : 0.0f;
+            if (valid) colsum += (double)col[f];
+        }
         double contrib = 0.0;
         if (topk_mode) {
             bool sel = false;
@@ -394,9 +468,14 @@ __global__ __launch_bounds__(CH_TPB) void k_chomp_optimize(ChompArgs a) {
             }
         }
     }
+    {   // collide.sum() over the layer output (cost.py:187): per-thread partials -> wave sums (block sum in phase 5)
+        const double wsum = wave_allsum(colsum);
+        if ((tid & 63) == 0) L.red[56 + (tid >> 6)] = wsum;
+    }
     __syncthreads();
 
     // ---------------------------------------------------------------- phase 3: winners' gradients (top-k branch)
+    PHASE_MARK(3);
     if (topk_mode) {
         for (int grp = tid; grp < n * 10; grp += blockDim.x) {
             const int l = grp % 10, i = grp / 10;
@@ -407,7 +486,7 @@ __global__ __launch_bounds__(CH_TPB) void k_chomp_optimize(ChompArgs a) {
                 double x[3], v[3], acc[3], g[3];
                 point_kinematics(L, i, l, p, P, dt, x, v, acc);
                 const double dc[3] = {(double)pgrad[3 * f], (double)pgrad[3 * f + 1], (double)pgrad[3 * f + 2]};
-                functional_g(v, acc, (double)pot[f], dc, g);
+                functional_g(v, acc, (double)(L.potl ? L.potl[(grp << 4) + p] : pot[f]), dc, g);
                 const int nk = njoints(l);
                 for (int k = 0; k < nk; ++k) out[k] = jacobian_dot(L, i, l, k, x, g);
             }
@@ -418,6 +497,7 @@ __global__ __launch_bounds__(CH_TPB) void k_chomp_optimize(ChompArgs a) {
     }
 
     // ---------------------------------------------------------------- phase 4: obstacle gradient [n][9], smoothness
+    PHASE_MARK(4);
     const double* w = prm.link_smooth_weight;
     for (int e = tid; e < n * 9; e += blockDim.x) {
         const int i = e / 9, d = e % 9;
@@ -458,16 +538,50 @@ __global__ __launch_bounds__(CH_TPB) void k_chomp_optimize(ChompArgs a) {
     }
 
     // ---------------------------------------------------------------- phase 5: totals (cost.py:464-530)
-    // link costs: top-k branch broadcasts each link's summed cost to every waypoint (cost.py:416)
-    double obs_sum;
-    if (topk_mode) {
-        if (tid < 10) {
+    PHASE_MARK(5);
+    for (int e = tid; e < n * 9; e += blockDim.x) {
+        double og = prm.obstacle_weight * L.og[e];
+        og = fmin(fmax(og, -prm.clip_grad_scale), prm.clip_grad_scale);
+        const double sgw = prm.smoothness_weight * L.sg[e];
+        const double gt = og + sgw;
+        L.og[e] = og * og; L.sg[e] = sgw * sgw; L.g[e] = gt; L.tv[e] = gt * gt;
+        a.grad[(size_t)s * n * 9 + e] = gt;
+    }
+    // check_joint_limit (optimizer.py:166-174): flags only when a low AND a high violation exist
+    const double* lower = rv.lower();
+    const double* upper = rv.upper();
+    {
+        bool lowv = false, highv = false;
+        for (int e = tid; e < n * 9; e += blockDim.x) {
+            const int d = e % 9;
+            lowv = lowv || (L.xi[e] < lower[d] - 5e-3);
+            highv = highv || (L.xi[e] > upper[d] + 5e-3);
+        }
+        if (lowv) L.red[50] = 1.0;   // benign same-value races; both were zeroed in phase 0
+        if (highv) L.red[51] = 1.0;
+    }
+    __syncthreads();
+    // The independent block sums run on different waves at once, each in wave_allsum's fixed order.
+    {
+        const int wv = tid >> 6, ln = tid & 63;
+        const double* arr = wv == 0 ? L.sml : (wv == 1 ? L.og : (wv == 2 ? L.sg : (wv == 3 ? L.tv : L.gcost)));
+        const int count = wv == 0 ? n + 1 : (wv <= 3 ? n * 9 : n * 10);
+        if (wv <= 3 || (wv == 4 && !topk_mode)) {
+            double acc = 0.0;
+            for (int k = ln; k < count; k += 64) acc += arr[k];
+            acc = wave_allsum(acc);
+            if (ln == 0) L.red[wv == 4 ? 0 : wv + 1] = acc;  // slots: 1 smooth, 2 |w og|^2, 3 |w sg|^2, 4 |g|^2, 0 obstacle (clean branch)
+        } else if (wv == 4 && ln < 10) {
+            // top-k branch: each link's summed cost is broadcast to every waypoint (cost.py:416)
             double cl = 0.0;
             bool any = false;
-            for (int i = 0; i < n; ++i) { cl += L.gcost[i * 10 + tid]; any = any || (L.gwin[i * 10 + tid] >= 0); }
-            L.red[32 + tid] = (tid < mlinks && any) ? cl : 0.0;
+            for (int i = 0; i < n; ++i) { cl += L.gcost[i * 10 + ln]; any = any || (L.gwin[i * 10 + ln] >= 0); }
+            L.red[32 + ln] = (ln < mlinks && any) ? cl : 0.0;
         }
-        __syncthreads();
+    }
+    __syncthreads();
+    double obs_sum;
+    if (topk_mode) {
         double per_wp = 0.0;
         for (int l = 0; l < 10; ++l) per_wp += L.red[32 + l];
         obs_sum = per_wp * (double)n;
@@ -478,7 +592,7 @@ __global__ __launch_bounds__(CH_TPB) void k_chomp_optimize(ChompArgs a) {
             for (int e = tid; e < n * 10; e += blockDim.x) oc[e] = L.red[32 + e % 10];
         }
     } else {
-        obs_sum = block_sum(L, L.gcost, n * 10, 0);
+        obs_sum = L.red[0];
         for (int i = tid; i < n; i += blockDim.x) {
             double r = 0.0;
             for (int l = 0; l < 10; ++l) r += L.gcost[i * 10 + l];
@@ -489,44 +603,9 @@ __global__ __launch_bounds__(CH_TPB) void k_chomp_optimize(ChompArgs a) {
             for (int e = tid; e < n * 10; e += blockDim.x) oc[e] = L.gcost[e];
         }
     }
-    const double smooth_sum = block_sum(L, L.sml, n + 1, 1);
-    for (int e = tid; e < n * 9; e += blockDim.x) {
-        double og = prm.obstacle_weight * L.og[e];
-        og = fmin(fmax(og, -prm.clip_grad_scale), prm.clip_grad_scale);
-        const double sgw = prm.smoothness_weight * L.sg[e];
-        const double gt = og + sgw;
-        L.og[e] = og * og; L.sg[e] = sgw * sgw; L.g[e] = gt; L.tv[e] = gt * gt;
-        a.grad[(size_t)s * n * 9 + e] = gt;
-    }
-    const double n_og = block_sum(L, L.og, n * 9, 2);
-    const double n_sg = block_sum(L, L.sg, n * 9, 3);
-    const double n_g = block_sum(L, L.tv, n * 9, 4);
-    // collide.sum() over the layer output (cost.py:187): per-thread partials -> fixed-order block sum
-    {
-        __syncthreads();
-        const double wsum = wave_allsum(colsum);
-        if ((tid & 63) == 0) L.red[40 + (tid >> 6)] = wsum;
-        __syncthreads();
-    }
+    const double smooth_sum = L.red[1], n_og = L.red[2], n_sg = L.red[3], n_g = L.red[4];
     double collide = 0.0;
-    for (int wv = 0; wv < CH_WAVES; ++wv) collide += L.red[40 + wv];
-
-    // check_joint_limit (optimizer.py:166-174): flags only when a low AND a high violation exist
-    const double* lower = rv.lower();
-    const double* upper = rv.upper();
-    if (tid == 0) { L.red[50] = 0.0; L.red[51] = 0.0; }
-    __syncthreads();
-    {
-        bool lowv = false, highv = false;
-        for (int e = tid; e < n * 9; e += blockDim.x) {
-            const int d = e % 9;
-            lowv = lowv || (L.xi[e] < lower[d] - 5e-3);
-            highv = highv || (L.xi[e] > upper[d] + 5e-3);
-        }
-        if (lowv) L.red[50] = 1.0;   // benign same-value races
-        if (highv) L.red[51] = 1.0;
-    }
-    __syncthreads();
+    for (int wv = 0; wv < CH_WAVES; ++wv) collide += L.red[56 + wv];
 
     if (tid == 0) {
         double goal_dist = 0.0;
@@ -568,6 +647,7 @@ __global__ __launch_bounds__(CH_TPB) void k_chomp_optimize(ChompArgs a) {
     }
 
     // ---------------------------------------------------------------- phase 6: covariant (projected) step
+    PHASE_MARK(6);
     __syncthreads();
     apply_ainv(L.g, L.tvs, n, free_end, dt2);  // Ag = Ainv g
     __syncthreads();
@@ -600,6 +680,7 @@ __global__ __launch_bounds__(CH_TPB) void k_chomp_optimize(ChompArgs a) {
     for (int e = tid; e < n * 9; e += blockDim.x) L.xi[e] = L.g[e];
 
     // ---------------------------------------------------------------- phase 7: handle_joint_limit (optimizer.py:148-164)
+    PHASE_MARK(7);
     int cnt = 0;
     for (;;) {
         __syncthreads();
@@ -636,13 +717,22 @@ __global__ __launch_bounds__(CH_TPB) void k_chomp_optimize(ChompArgs a) {
     }
     for (int e = tid; e < n * 9; e += blockDim.x) traj[e] = L.xi[e];
     if (tid == 0) a.info[(size_t)s * OMGX_INFO_STRIDE + OMGX_INFO_LIMIT_STEPS] = (double)cnt;
+    PHASE_MARK(8);
 }
+
+#ifdef OMGX_PHASE_TIMING
+extern "C" int omgx_debug_chomp_phase_times(unsigned long long* h_out, int n) {
+    return (int)hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_chomp_phase), sizeof(unsigned long long) * (n < 32 ? n : 32));
+}
+#endif
 
 static size_t host_lds_bytes(int n, int P) {
     size_t d = (size_t)(n + 2) * 120 + 60 + (size_t)n * 80 + (size_t)n * 10 + (size_t)n * 9 * 6 + (n + 1) + 30 * P + 64;
     size_t i = (size_t)n * 10 + 256 + (n * 160 + 31) / 32 + 16;
     return d * 8 + i * 4;
 }
+static const size_t kLdsLimit = 160 * 1024;  // gfx950: 160 KB per workgroup
+static bool host_pot_in_lds(int n, int P) { return host_lds_bytes(n, P) + (size_t)n * 160 * 4 <= kLdsLimit; }
 
 extern "C" int64_t omgx_chomp_aux_doubles(int32_t n) { return n < 1 ? 0 : (int64_t)n * 9 + (int64_t)n * 10 + (int64_t)n * 9 + n + 1; }
 
@@ -665,7 +755,8 @@ extern "C" int omgx_chomp_optimize(const double* robot, const omgx_chomp_params*
     a.robot = robot; a.prm = p; a.traj = traj; a.start = start; a.end = end; a.goal = goal; a.goal_point = goal_point;
     a.pot = potentials; a.pgrad = grads; a.col = collides; a.active = active; a.grad = grad; a.cost_traj = cost_traj;
     a.info = info; a.aux = aux;
-    const size_t lds = host_lds_bytes(p.n_waypoints, p.n_points);
+    a.pot_in_lds = host_pot_in_lds(p.n_waypoints, p.n_points) ? 1 : 0;
+    const size_t lds = host_lds_bytes(p.n_waypoints, p.n_points) + (a.pot_in_lds ? (size_t)p.n_waypoints * 160 * 4 : 0);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)k_chomp_optimize, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

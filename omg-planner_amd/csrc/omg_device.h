@@ -392,6 +392,47 @@ __device__ __forceinline__ void fk_chain(const RobotView& rv, const double* __re
     }
 }
 
+// The same kinematics split for a workgroup (k_goalset_compact, k_chomp_optimize), where one lane per configuration
+// leaves most of the workgroup idle behind a ~2200-instruction serial chain:
+//   stage 1, one lane per (configuration, arm joint):  fk_joint_sincos -> (sin, cos) of the round-tripped angle;
+//   stage 2, one lane per (configuration, row r < 3):  row r of every link pose.  Row r of a product A.B depends on
+//            row r of A only, so the three rows of the chain are independent: 7 x (18 + 12) FMAs per lane.
+// f(l, R_r0, R_r1, R_r2, t_r) receives row r of link l's pose (before center_offset, like fk_chain).
+__device__ __forceinline__ void fk_joint_sincos(double q, double& s, double& c) { sincos(deg_round_trip(q), &s, &c); }
+
+template <class F>
+__device__ __forceinline__ void fk_chain_row(const RobotView& rv, int r, const double* __restrict__ sc /* [7][2] sin, cos */,
+                                             double q7, double q8, F&& f) {
+#pragma clang fp contract(fast)
+    double a0 = r == 0 ? 1.0 : 0.0, a1 = r == 1 ? 1.0 : 0.0, a2 = r == 2 ? 1.0 : 0.0, at = 0.0;
+#pragma unroll 1  // unrolled, the 7 x 27 wave-uniform constants are hoisted into (spilled) SGPRs all at once
+    for (int i = 0; i < 7; ++i) {
+        const double s = sc[2 * i], c = sc[2 * i + 1];
+        const double* uvw = rv.uvw(i);
+        const double* tp = rv.tp(i);
+        double B[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) B[k] = c * uvw[k] + s * uvw[9 + k] + uvw[18 + k];
+        const double n0 = a0 * B[0] + a1 * B[3] + a2 * B[6];
+        const double n1 = a0 * B[1] + a1 * B[4] + a2 * B[7];
+        const double n2 = a0 * B[2] + a1 * B[5] + a2 * B[8];
+        at = a0 * tp[0] + a1 * tp[1] + a2 * tp[2] + at;
+        a0 = n0; a1 = n1; a2 = n2;
+        f(i, a0, a1, a2, at);
+    }
+    // hand = link7 . pose_0[7]; fingers = hand . pose_0[8|9] with y -+ q (robot_pykdl.py:181-188)
+    const double* H = rv.hand();
+    const double h0 = a0 * H[0] + a1 * H[4] + a2 * H[8], h1 = a0 * H[1] + a1 * H[5] + a2 * H[9], h2 = a0 * H[2] + a1 * H[6] + a2 * H[10];
+    const double ht = a0 * H[3] + a1 * H[7] + a2 * H[11] + at;
+    f(7, h0, h1, h2, ht);
+    const double* Lf = rv.lf();
+    f(8, h0 * Lf[0] + h1 * Lf[4] + h2 * Lf[8], h0 * Lf[1] + h1 * Lf[5] + h2 * Lf[9], h0 * Lf[2] + h1 * Lf[6] + h2 * Lf[10],
+      h0 * Lf[3] + h1 * (Lf[7] + deg_round_trip(q7)) + h2 * Lf[11] + ht);
+    const double* Rf = rv.rf();
+    f(9, h0 * Rf[0] + h1 * Rf[4] + h2 * Rf[8], h0 * Rf[1] + h1 * Rf[5] + h2 * Rf[9], h0 * Rf[2] + h1 * Rf[6] + h2 * Rf[10],
+      h0 * Rf[3] + h1 * (Rf[7] - deg_round_trip(q8)) + h2 * Rf[11] + ht);
+}
+
 __device__ __forceinline__ void pose_apply(const Pose& A, const double* __restrict__ p, double& x, double& y, double& z) {
 #pragma clang fp contract(fast)
     x = A.R[0] * p[0] + A.R[1] * p[1] + A.R[2] * p[2] + A.t[0];

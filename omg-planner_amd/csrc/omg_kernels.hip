@@ -393,19 +393,29 @@ __global__ __launch_bounds__(256, 5) void k_goalset_compact(ChunkArgs a) {
     uint32_t* rowmask = reinterpret_cast<uint32_t*>(lds_pose + (size_t)(CH + 1) * 90);  // poses: 9 doubles (see pose9_apply)
     float4* scratch = reinterpret_cast<float4*>(rowmask + ((10 * CH + 3) & ~3)) + wave * 64;  // wave-private [64]
 
-    for (int cfg = threadIdx.x; cfg < CH + 1; cfg += 256) {  // FK of start + CH interpolated configurations
+    {   // FK of start + CH interpolated configurations in two stages (omg_device.h: fk_chain_row); the (sin, cos)
+        // table borrows the row-mask / scratch region, which is first written after the barriers below.
         const double* q0 = a.traj_start + a.ts_stride * (int64_t)s;
         const double* qg = a.goals + ((int64_t)s * a.NCH + chunk) * 9;
-        const double t = (double)cfg / (double)(CH + 1);
-        double q[9];
-#pragma unroll
-        for (int d = 0; d < 9; ++d) q[d] = cfg == 0 ? q0[d] : q0[d] + t * (qg[d] - q0[d]);
-        fk_chain(rv, q, [&](int l, const Pose& pose) {
-            double* dst = lds_pose + ((size_t)l * (CH + 1) + cfg) * 9;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) dst[k] = pose.R[k];
-            dst[6] = pose.t[0]; dst[7] = pose.t[1]; dst[8] = pose.t[2];
-        });
+        const int ncfg = CH + 1;
+        double* sc = reinterpret_cast<double*>(rowmask);  // [ncfg][7][2]
+        // cfg 0 = start itself, cfg i+1 = linspace(0,1,n+2)[1:-1][i]
+        auto joint = [&](int cfg, int d) { return cfg == 0 ? q0[d] : q0[d] + ((double)cfg / (double)(CH + 1)) * (qg[d] - q0[d]); };
+        for (int t = threadIdx.x; t < ncfg * 7; t += 256) {
+            const int cfg = t / 7, i = t - cfg * 7;
+            double sn, cs;
+            fk_joint_sincos(joint(cfg, i), sn, cs);
+            sc[2 * t] = sn; sc[2 * t + 1] = cs;
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < ncfg * 3; t += 256) {
+            const int cfg = t / 3, r = t - cfg * 3;
+            fk_chain_row(rv, r, sc + 14 * cfg, joint(cfg, 7), joint(cfg, 8), [&](int l, double r0, double r1, double r2, double tr) {
+                double* dst = lds_pose + ((size_t)l * (CH + 1) + cfg) * 9;  // rows 0 and 1 of R, then t
+                if (r < 2) { dst[3 * r] = r0; dst[3 * r + 1] = r1; dst[3 * r + 2] = r2; }
+                dst[6 + r] = tr;
+            });
+        }
     }
     __syncthreads();
     const double* base = lds_pose + 9;
@@ -699,8 +709,10 @@ static int launch_chunks(ChunkArgs& ca, hipStream_t st) {
     static int compact = -1;  // OMGX_COMPACT=0 keeps the unpacked exact path (A/B measurements)
     if (compact < 0) { const char* e = getenv("OMGX_COMPACT"); compact = e ? atoi(e) : 1; }
     if (ca.traj_start && compact && !ca.pot) {  // goal-set batch, cost only: packed exact path
-        const size_t lds = (size_t)(ca.CH + 1) * 90 * sizeof(double) + (((size_t)10 * ca.CH + 3) & ~(size_t)3) * sizeof(uint32_t) +
-                           4 * 64 * sizeof(float4);
+        size_t tail = (((size_t)10 * ca.CH + 3) & ~(size_t)3) * sizeof(uint32_t) + 4 * 64 * sizeof(float4);  // row masks + scratch
+        const size_t sincos = (size_t)(ca.CH + 1) * 14 * sizeof(double);                                       // FK stage 1 table
+        if (tail < sincos) tail = sincos;
+        const size_t lds = (size_t)(ca.CH + 1) * 90 * sizeof(double) + tail;
         if (lb == 10) hipLaunchKernelGGL((k_goalset_compact<10>), dim3((unsigned)grid), dim3(256), lds, st, ca);
         else if (lb == 2) hipLaunchKernelGGL((k_goalset_compact<2>), dim3((unsigned)grid), dim3(256), lds, st, ca);
         else hipLaunchKernelGGL((k_goalset_compact<5>), dim3((unsigned)grid), dim3(256), lds, st, ca);

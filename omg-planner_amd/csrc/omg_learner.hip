@@ -21,6 +21,16 @@
 
 #pragma clang fp contract(fast)
 
+// Debug aid (make CXXFLAGS+=-DOMGX_PHASE_TIMING), see omg_chomp.hip.  Slots 0-7 clocks, 8.. iteration counts.
+#ifdef OMGX_PHASE_TIMING
+__device__ unsigned long long g_learner_phase[32];
+#define PHASE_MARK(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_learner_phase[i] = __builtin_readcyclecounter(); } while (0)
+#define PHASE_COUNT(i, v) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) g_learner_phase[i] = (unsigned long long)(v); } while (0)
+#else
+#define PHASE_MARK(i) do { } while (0)
+#define PHASE_COUNT(i, v) do { } while (0)
+#endif
+
 namespace {
 
 #define NPL 4  // goals per lane
@@ -40,6 +50,10 @@ struct LearnerArgs {
     double* cost_vector;
 };
 
+__device__ __forceinline__ double lane_bcast(double v, int k) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), k), hi = __builtin_amdgcn_readlane(__double2hiint(v), k);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wsum(double v) { return omg::wave_allsum(v); }  // identical result in every lane
 __device__ __forceinline__ double wmax(double v) { return omg::wave_allmax(v); }
 // arg-extreme with the lowest index on ties (np.argmin / np.argmax return the first occurrence)
@@ -56,53 +70,76 @@ __device__ __forceinline__ int warg(double v, int i) {
 }
 
 // bp (online_learner.py:32-58) with find_zero (:16-29) inlined.  x, v per-lane slices; w = 1, delta = 1/(4G+1).
-__device__ void bregman_projection(const double* x, const double* v, double delta, int G, int lane, double* y) {
+//
+// find_zero bisects f(L) = sum_j shiftx_j exp(L + z_j) - target = exp(L) * C - target over L: C is summed once per
+// outer iteration and exp(L) follows the bisection, E *= exp(+-s_k) with s_k = x1 / 2^(k+2).  Neither x1 = max(1 + v)
+// nor shiftx change between outer iterations, so the step factors exp(+-s_k) are tabulated once per projection
+// (lane k evaluates entry k; `tab` is a wave-private LDS array of 2 x 64 doubles, later factors are exactly 1), and a bisection step is a
+// fused multiply-add, a compare and a multiply by a table entry.  L itself is updated exactly like the reference
+// (same dyadic sequence); E carries ~1e-16 relative error per step against a decision threshold of 1e-6.
+__device__ void bregman_projection(const double* x, const double* v, double delta, int G, int lane, double* y, double* tab) {
     const int max_iter = 100;
     const double err = 1e-6;
-    double alpha[NPL] = {0, 0, 0, 0}, shiftx[NPL], z[NPL];
+    double alpha[NPL] = {0, 0, 0, 0}, shiftx[NPL], lds[NPL], ez[NPL];
     const double target = 1.0 + delta * (double)G;
-    for (int it = 0; it < max_iter; ++it) {
-        double vmax = -1e300;
+    double vmax = -1e300;
 #pragma unroll
-        for (int j = 0; j < NPL; ++j) {
-            const bool ok = lane + 64 * j < G;
-            z[j] = alpha[j] - v[j];
-            shiftx[j] = x[j] + delta;
-            if (ok) vmax = fmax(vmax, 1.0 + v[j]);
-        }
-        const double x1 = wmax(vmax);
-        // find_zero (online_learner.py:16-29) on f(L) = sum_j shiftx_j exp(L + z_j) - target = exp(L) * C - target:
-        // C is summed once; exp(L) follows the bisection by E *= exp(+-s) with exp(s/2) = sqrt(exp(s)), so a step
-        // costs a multiply and a square root instead of G exponentials and a wave reduction.  L itself is updated
-        // exactly like the reference (same dyadic sequence); E carries ~1e-16 relative error per step against a
-        // decision threshold of 1e-6.
+    for (int j = 0; j < NPL; ++j) {
+        const bool ok = lane + 64 * j < G;
+        shiftx[j] = x[j] + delta;
+        lds[j] = ok ? log(delta / shiftx[j]) : 0.0;
+        ez[j] = 0.0;
+        if (ok) vmax = fmax(vmax, 1.0 + v[j]);
+    }
+    const double x1 = wmax(vmax);
+    const double L0 = (0.0 + x1) / 2.0, s0 = (x1 - 0.0) / 4.0;
+    const double E0 = exp(L0);
+    {   // s_k = s0 / 2^k is exact (power-of-two scaling); for k >= 64 exp(+-s_k) rounds to 1 (s_k < 2^-60 x1)
+        const double up = exp(ldexp(s0, -lane));
+        tab[2 * lane] = up;
+        tab[2 * lane + 1] = 1.0 / up;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    int dbg_outer = 0, dbg_inner = 0;
+    for (int it = 0; it < max_iter; ++it) {
+        ++dbg_outer;
         double partC = 0.0;
 #pragma unroll
         for (int j = 0; j < NPL; ++j)
-            if (lane + 64 * j < G) partC += shiftx[j] * exp(z[j]);
+            if (lane + 64 * j < G) { ez[j] = exp(alpha[j] - v[j]); partC += shiftx[j] * ez[j]; }
         const double Csum = wsum(partC);
-        double L = (0.0 + x1) / 2.0, sstep = (x1 - 0.0) / 4.0;
-        double E = exp(L), Es = exp(sstep);
+        double L = L0, sstep = s0, E = E0;
+        double up = tab[0], dn = tab[1];
         for (int k = 0; k < max_iter; ++k) {
             const double fy = E * Csum - target;
+            ++dbg_inner;
             if (fabs(fy) < err) break;
-            if (fy > 0) { L -= sstep; E /= Es; }
-            else if (fy < 0) { L += sstep; E *= Es; }
+            const int kn = k + 1 < 64 ? k + 1 : 63;  // prefetch the next pair; beyond k = 63 the factors are 1
+            const double nup = tab[2 * kn], ndn = tab[2 * kn + 1];
+            const bool pos = fy > 0;                  // fy == 0 left the loop above
+            L += pos ? -sstep : sstep;
+            E *= pos ? dn : up;
             sstep /= 2.0;
-            Es = sqrt(Es);
+            up = k + 1 < 64 ? nup : 1.0;
+            dn = k + 1 < 64 ? ndn : 1.0;
         }
+        const double EL = E;  // exp(L) up to the accumulated ~1e-15
         double nrm = 0.0, ap[NPL];
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {
             const bool ok = lane + 64 * j < G;
-            y[j] = ok ? shiftx[j] * exp(L + alpha[j] - v[j]) - delta : 0.0;
-            ap[j] = ok ? fmax(0.0, v[j] - L + log(delta / shiftx[j])) : 0.0;
+            y[j] = ok ? shiftx[j] * (EL * ez[j]) - delta : 0.0;  // shiftx exp(L + alpha - v) - delta
+            ap[j] = ok ? fmax(0.0, v[j] - L + lds[j]) : 0.0;
             nrm += (alpha[j] - ap[j]) * (alpha[j] - ap[j]);
         }
         if (sqrt(wsum(nrm)) < err) break;
 #pragma unroll
         for (int j = 0; j < NPL; ++j) alpha[j] = ap[j];
     }
+    PHASE_COUNT(8 + 2 * (threadIdx.x >> 6), dbg_outer);
+    PHASE_COUNT(9 + 2 * (threadIdx.x >> 6), dbg_inner);
     double part = 0.0;
 #pragma unroll
     for (int j = 0; j < NPL; ++j) { y[j] = fmax(y[j], 0.0); part += y[j]; }
@@ -113,6 +150,8 @@ __device__ void bregman_projection(const double* x, const double* v, double delt
 
 __global__ __launch_bounds__(320) void k_goal_update(LearnerArgs a) {
     __shared__ double sh_pn[5][OMGX_MAX_GOALS];
+    __shared__ double sh_tab[5][128];
+    PHASE_MARK(0);
     const int s = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (a.prm.alg != OMGX_ALG_MD && wave > 0) return;
     const omgx_learner_params& prm = a.prm;
@@ -198,6 +237,7 @@ __global__ __launch_bounds__(320) void k_goal_update(LearnerArgs a) {
             }
             idx = warg<false>(best, bi);
         } else {  // MD, :219-235
+            PHASE_MARK(1);
             const double pw[5] = {0.25, 0.5, 1.0, 4.0, 16.0};  // eta * 2**[-2,-1,0,2,4], :82
             const double delta = 1.0 / (4.0 * (double)G + 1.0);
             {   // every wave: Bregman projection of its own expert (reads the OLD experts_p, like the reference)
@@ -207,10 +247,12 @@ __global__ __launch_bounds__(320) void k_goal_update(LearnerArgs a) {
                     v[j] = prm.eta * pw[wave] * cv[j];
                     epw[j] = g < G ? experts_p[(int64_t)wave * G + g] : 0.0;
                 }
-                bregman_projection(epw, v, delta, G, lane, pn);
+                bregman_projection(epw, v, delta, G, lane, pn, sh_tab[wave]);
+                PHASE_MARK(2);
                 for (int j = 0; j < NPL; ++j) { const int g = lane + 64 * j; if (g < G) sh_pn[wave][g] = pn[j]; }
             }
             __syncthreads();
+            PHASE_MARK(3);
             if (wave > 0) return;
             double qv[5], ec[5], ep[5][NPL];
             for (int i = 0; i < 5; ++i) {
@@ -228,7 +270,12 @@ __global__ __launch_bounds__(320) void k_goal_update(LearnerArgs a) {
                 for (int j = 0; j < NPL; ++j) ep[i][j] = pn[j];
                 // the mixture update sits INSIDE the expert loop (:231-235)
                 double qs = 0.0;
-                for (int k = 0; k < 5; ++k) { qv[k] = qv[k] * exp(-1.0 * ec[k]); qs += qv[k]; }
+                {   // exp(-ec[k]) for the 5 experts: lane k evaluates one, broadcast by readlane
+                    double mine = 0.0;
+                    for (int k = 0; k < 5; ++k) mine = lane == k ? ec[k] : mine;
+                    const double ex = exp(-1.0 * mine);
+                    for (int k = 0; k < 5; ++k) { qv[k] = qv[k] * lane_bcast(ex, k); qs += qv[k]; }
+                }
                 for (int k = 0; k < 5; ++k) qv[k] /= qs;
                 double ps = 0.0;
                 for (int j = 0; j < NPL; ++j) {
@@ -256,6 +303,7 @@ __global__ __launch_bounds__(320) void k_goal_update(LearnerArgs a) {
         }
     }
     // traj.end / goal rows (online_learner.py:243-245, optimizer.py:93-99)
+    PHASE_MARK(4);
     if (lane == 0) a.goal_idx[s] = idx;
     if (lane < 9) {
         const double v = gs[idx * 9 + lane];
@@ -268,6 +316,12 @@ __global__ __launch_bounds__(320) void k_goal_update(LearnerArgs a) {
 }
 
 }  // namespace
+
+#ifdef OMGX_PHASE_TIMING
+extern "C" int omgx_debug_learner_phase_times(unsigned long long* h_out, int n) {
+    return (int)hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_learner_phase), sizeof(unsigned long long) * (n < 32 ? n : 32));
+}
+#endif
 
 extern "C" int64_t omgx_learner_state_doubles(int32_t num_goals) { return num_goals < 1 ? 0 : 7 * (int64_t)num_goals + 10; }
 

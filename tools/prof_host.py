@@ -2,8 +2,12 @@ import sys, time, cProfile, pstats
 sys.path.insert(0, '.')
 import torch, bench
 from omg_planner_amd.engine import ChompEngine
-cfg, model, batch, start, goals = bench.build_workload(100, 64, 30, 64, 0, False)
-eng = ChompEngine(model, batch, cfg, start, goals, device="cuda:0", ol_alg="FTL")
+# tiny workload by default: the GPU finishes long before the host has issued the next iteration -> pure host cost
+S = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+G = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+alg = sys.argv[3] if len(sys.argv) > 3 else "MD"
+cfg, model, batch, start, goals = bench.build_workload(S, G, 30, 64, 0, False)
+eng = ChompEngine(model, batch, cfg, start, goals, device="cuda:0", ol_alg=alg)
 for _ in range(5):
     eng.t = 0; eng.iterate(0)
 torch.cuda.synchronize()
@@ -19,4 +23,4 @@ pr = cProfile.Profile(); pr.enable()
 for _ in range(50):
     eng.t = 0; eng.iterate(0)
 pr.disable(); torch.cuda.synchronize()
-pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
+pstats.Stats(pr).sort_stats("cumulative").print_stats(40)
