@@ -424,6 +424,10 @@ __global__ __launch_bounds__(CH_TPB) void k_chomp_optimize(ChompArgs a) {
                     }
                 }
             }
+            if (!__any(sel)) {  // nothing selected in this wave's four groups (the common case): empty groups
+                if (inb && p == 0) { L.gwin[grp] = -1; L.gcost[grp] = 0.0; }
+                continue;
+            }
             double vn = 0.0;
             if (sel) {
                 double x[3], xm[3];

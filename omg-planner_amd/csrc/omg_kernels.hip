@@ -13,6 +13,7 @@
 //              points of one link at one waypoint) share one 96-byte pose; a wave = 4 consecutive
 //              waypoints of one link -> spatially coherent gathers
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <stdint.h>
 #include <stdio.h>
@@ -698,14 +699,22 @@ static int launch_chunks(ChunkArgs& ca, hipStream_t st) {
     ca.LPW = lpw;
     const int64_t grid = (int64_t)scene_groups * ca.NCH * 8 * (10 / lpw);
     if (grid > 0x7fffffff) return OMGX_ERR_UNSUPPORTED;
+    // Timed launches attach the start/stop events to the dispatch itself (hipExtLaunchKernelGGL): the events then
+    // bracket exactly this kernel and cost no extra packets on the stream.
     const int slot = timing_slot();
-    if (slot >= 0) { g_ev_kind[slot] = ca.grad ? 1 : 0; (void)hipEventRecord(g_ev[slot][0], st); }
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (slot >= 0) { g_ev_kind[slot] = ca.grad ? 1 : 0; ev0 = g_ev[slot][0]; ev1 = g_ev[slot][1]; ++g_timing_n; }
+#define OMGX_LAUNCH(KERNEL_, LDS_)                                                                                       \
+    do {                                                                                                                 \
+        if (ev0) hipExtLaunchKernelGGL(KERNEL_, dim3((unsigned)grid), dim3(256), (uint32_t)(LDS_), st, ev0, ev1, 0, ca); \
+        else hipLaunchKernelGGL(KERNEL_, dim3((unsigned)grid), dim3(256), (LDS_), st, ca);                               \
+    } while (0)
     static int lb = -1;  // links per batch; OMGX_LB overrides the tuned default (tuning aid)
     if (lb < 0) { const char* e = getenv("OMGX_LB"); lb = e ? atoi(e) : 2; }
     int lbu = lb;
     if (lpw % lbu != 0) lbu = 1;  // the link batch must divide the links of a workgroup
     const size_t mask_bytes = (size_t)10 * ca.CH * sizeof(uint32_t);
-#define OMGX_LAUNCH_CHUNKS(G_, LB_) hipLaunchKernelGGL((k_sdf_chunks<G_, LB_, false>), dim3((unsigned)grid), dim3(256), mask_bytes, st, ca)
+#define OMGX_LAUNCH_CHUNKS(G_, LB_) OMGX_LAUNCH((k_sdf_chunks<G_, LB_, false>), mask_bytes)
     static int compact = -1;  // OMGX_COMPACT=0 keeps the unpacked exact path (A/B measurements)
     if (compact < 0) { const char* e = getenv("OMGX_COMPACT"); compact = e ? atoi(e) : 1; }
     if (ca.traj_start && compact && !ca.pot) {  // goal-set batch, cost only: packed exact path
@@ -713,13 +722,13 @@ static int launch_chunks(ChunkArgs& ca, hipStream_t st) {
         const size_t sincos = (size_t)(ca.CH + 1) * 14 * sizeof(double);                                       // FK stage 1 table
         if (tail < sincos) tail = sincos;
         const size_t lds = (size_t)(ca.CH + 1) * 90 * sizeof(double) + tail;
-        if (lb == 10) hipLaunchKernelGGL((k_goalset_compact<10>), dim3((unsigned)grid), dim3(256), lds, st, ca);
-        else if (lb == 2) hipLaunchKernelGGL((k_goalset_compact<2>), dim3((unsigned)grid), dim3(256), lds, st, ca);
-        else hipLaunchKernelGGL((k_goalset_compact<5>), dim3((unsigned)grid), dim3(256), lds, st, ca);
+        if (lb == 10) OMGX_LAUNCH((k_goalset_compact<10>), lds);
+        else if (lb == 2) OMGX_LAUNCH((k_goalset_compact<2>), lds);
+        else OMGX_LAUNCH((k_goalset_compact<5>), lds);
     } else if (ca.traj_start) {  // fused FK (goal-set batch): dynamic LDS holds (CH + 1) x 10 poses
         const size_t lds = (size_t)(ca.CH + 1) * 120 * sizeof(double) + mask_bytes;
-        if (lbu == 1) hipLaunchKernelGGL((k_sdf_chunks<false, 1, true>), dim3((unsigned)grid), dim3(256), lds, st, ca);
-        else hipLaunchKernelGGL((k_sdf_chunks<false, 2, true>), dim3((unsigned)grid), dim3(256), lds, st, ca);
+        if (lbu == 1) OMGX_LAUNCH((k_sdf_chunks<false, 1, true>), lds);
+        else OMGX_LAUNCH((k_sdf_chunks<false, 2, true>), lds);
     } else if (ca.grad) {
         if (lbu == 1) OMGX_LAUNCH_CHUNKS(true, 1); else if (lbu == 2) OMGX_LAUNCH_CHUNKS(true, 2);
         else if (lbu == 10) OMGX_LAUNCH_CHUNKS(true, 10); else OMGX_LAUNCH_CHUNKS(true, 5);
@@ -728,7 +737,7 @@ static int launch_chunks(ChunkArgs& ca, hipStream_t st) {
         else if (lbu == 10) OMGX_LAUNCH_CHUNKS(false, 10); else OMGX_LAUNCH_CHUNKS(false, 5);
     }
 #undef OMGX_LAUNCH_CHUNKS
-    if (slot >= 0) { (void)hipEventRecord(g_ev[slot][1], st); ++g_timing_n; }
+#undef OMGX_LAUNCH
     OMGX_CHECK_LAUNCH("k_sdf_chunks");
     return OMGX_OK;
 }
