@@ -378,7 +378,7 @@ __global__ __launch_bounds__(TPB) void k_sdf_chunks(ChunkArgs a) {
 // the unpacked exact path (a link's 10 cm point cloud straddles the far box); packed, a batch of LB links needs
 // ceil(survivors / 64) exact passes instead of one per link.  Arithmetic per pair is unchanged (bit-identical).
 template <int LB>
-__global__ __launch_bounds__(256, 5) void k_goalset_compact(ChunkArgs a) {
+__global__ __launch_bounds__(256, 6) void k_goalset_compact(ChunkArgs a) {
     extern __shared__ __attribute__((aligned(16))) double lds_pose[];
     __shared__ float red[2][4];
     const int xcd = blockIdx.x & 7;
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(256, 5) void k_goalset_compact(ChunkArgs a) {
     const int p = threadIdx.x & 15, r = threadIdx.x >> 4, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const RobotView rv(a.robot, P);
     uint32_t* rowmask = reinterpret_cast<uint32_t*>(lds_pose + (size_t)(CH + 1) * 90);  // poses: 9 doubles (see pose9_apply)
-    float4* scratch = reinterpret_cast<float4*>(rowmask + ((10 * CH + 3) & ~3)) + wave * 64;  // wave-private [64]
+    float* scratch = reinterpret_cast<float*>(rowmask + ((10 * CH + 3) & ~3)) + wave * 192;  // wave-private [64][3]: 12 B entries keep 6 workgroups per CU inside 160 KB
 
     {   // FK of start + CH interpolated configurations in two stages (omg_device.h: fk_chain_row); the (sin, cos)
         // table borrows the row-mask / scratch region, which is first written after the barriers below.
@@ -489,15 +489,15 @@ __global__ __launch_bounds__(256, 5) void k_goalset_compact(ChunkArgs a) {
                 for (int b0 = 0; b0 < total; b0 += 64) {  // wave-uniform
 #pragma unroll
                     for (int k = 0; k < LB; ++k)
-                        if (rank[k] >= b0 && rank[k] < b0 + 64) scratch[rank[k] - b0] = make_float4(pp[k].tx, pp[k].ty, pp[k].tz, 0.0f);
+                        if (rank[k] >= b0 && rank[k] < b0 + 64) { float* e = scratch + 3 * (rank[k] - b0); e[0] = pp[k].tx; e[1] = pp[k].ty; e[2] = pp[k].tz; }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     if (lane < total - b0) {
-                        const float4 t = scratch[lane];
+                        const float tx = scratch[3 * lane], ty = scratch[3 * lane + 1], tz = scratch[3 * lane + 2];
                         Accum one{0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-                        pair_exact<false>(op, grid, t.x, t.y, t.z, one);
-                        scratch[lane] = make_float4(one.pot, one.col, 0.0f, 0.0f);
+                        pair_exact<false>(op, grid, tx, ty, tz, one);
+                        scratch[3 * lane] = one.pot; scratch[3 * lane + 1] = one.col;
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
@@ -505,9 +505,9 @@ __global__ __launch_bounds__(256, 5) void k_goalset_compact(ChunkArgs a) {
 #pragma unroll
                     for (int k = 0; k < LB; ++k)
                         if (rank[k] >= b0 && rank[k] < b0 + 64) {
-                            const float4 res = scratch[rank[k] - b0];
-                            acc[k].pot += res.x;
-                            acc[k].col += res.y;
+                            const float* e = scratch + 3 * (rank[k] - b0);
+                            acc[k].pot += e[0];
+                            acc[k].col += e[1];
                         }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
@@ -718,7 +718,7 @@ static int launch_chunks(ChunkArgs& ca, hipStream_t st) {
     static int compact = -1;  // OMGX_COMPACT=0 keeps the unpacked exact path (A/B measurements)
     if (compact < 0) { const char* e = getenv("OMGX_COMPACT"); compact = e ? atoi(e) : 1; }
     if (ca.traj_start && compact && !ca.pot) {  // goal-set batch, cost only: packed exact path
-        size_t tail = (((size_t)10 * ca.CH + 3) & ~(size_t)3) * sizeof(uint32_t) + 4 * 64 * sizeof(float4);  // row masks + scratch
+        size_t tail = (((size_t)10 * ca.CH + 3) & ~(size_t)3) * sizeof(uint32_t) + 4 * 64 * 3 * sizeof(float);  // row masks + scratch
         const size_t sincos = (size_t)(ca.CH + 1) * 14 * sizeof(double);                                       // FK stage 1 table
         if (tail < sincos) tail = sincos;
         const size_t lds = (size_t)(ca.CH + 1) * 90 * sizeof(double) + tail;
