@@ -222,6 +222,24 @@ int omgx_goalset_cost(const double* robot, int32_t n_points,
                       float* goal_cost, float* potentials, float* collides, void* workspace, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * (3b) omgx_goalset_cost_layer
+ * omgx_goalset_cost (cost-only: no per-point potentials) and, in the SAME launch, omgx_fk_sdf of the current
+ * trajectories traj [S,n_waypoints,9] (arc_length off): one extra workgroup per scene writes
+ *   layer_potentials [S,n,10,P], layer_grads [S,n,10,P,3], layer_collides [S,n,10,P] float32
+ * — the inputs of omgx_chomp_optimize.  One planner iteration (omg/planner.py:612-621) is then two launches on one
+ * stream: this one and omgx_goal_update_optimize.  Results are identical to the two separate calls
+ * (goal_cost: same float32 summation order; layer outputs: bit-identical).
+ * ------------------------------------------------------------------------------------------- */
+int omgx_goalset_cost_layer(const double* robot, int32_t n_points,
+                            const omgx_object* objects, const int32_t* scene_begin, const float* sdf_pool,
+                            const double* traj_start, int64_t traj_start_stride, const double* goals,
+                            int32_t num_scenes, int32_t num_goals, int32_t n_remaining,
+                            double time_interval, int32_t soften_fingers,
+                            float* goal_cost, float* collides, void* workspace,
+                            const double* traj, int32_t n_waypoints, int32_t layer_soften_fingers,
+                            float* layer_potentials, float* layer_grads, float* layer_collides, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * (4) omgx_chomp_optimize
  * Replaces one Optimizer.optimize step (omg/optimizer.py:115-135) for S independent trajectories:
  * Cost.compute_total_loss (omg/cost.py:451-532) = compute_smooth_loss (425-449) +
@@ -293,6 +311,22 @@ int omgx_goal_update(const omgx_learner_params* h_params, const double* traj, co
                      const float* goal_cost, double* state, int32_t num_scenes,
                      int32_t* goal_idx, double* end, double* goal_rows, double* goal_point, double* cost_vector,
                      void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * (5b) omgx_goal_update_optimize
+ * omgx_goal_update immediately followed by omgx_chomp_optimize for the same scenes in ONE launch — the pair
+ * `learner.update_goal(); optim.optimize(traj, force_update=True)` of the planner loop (omg/planner.py:612-621).
+ * Same arguments, same arithmetic and bit-identical results as the two calls in that order: `end`, `goal` (the
+ * learner's goal_rows) and `goal_point` are written by the goal update and consumed by the step inside the kernel.
+ * The two parameter blocks must agree on n_waypoints and constraint_num.
+ * ------------------------------------------------------------------------------------------- */
+int omgx_goal_update_optimize(const omgx_learner_params* h_learner, const double* goal_set, const double* reach,
+                              const float* goal_cost, double* learner_state, int32_t* goal_idx, double* cost_vector,
+                              const double* robot, const omgx_chomp_params* h_params, double* traj,
+                              const double* start, double* end, double* goal, double* goal_point,
+                              const float* potentials, const float* grads, const float* collides,
+                              const int32_t* active, int32_t num_scenes,
+                              double* grad, double* cost_traj, double* info, double* aux, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * (6) omgx_point_cloud_sdf

@@ -31,6 +31,7 @@
 
 #include "omg_device.h"
 #include "omg_host.h"
+#include "omg_learner_body.h"
 
 using namespace omg;
 
@@ -220,9 +221,8 @@ __device__ __forceinline__ void apply_ainv(const double* in, double* out, int n,
 
 }  // namespace
 
-__global__ __launch_bounds__(CH_TPB) void k_chomp_optimize(ChompArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int s = blockIdx.x;
+// Optimizer.optimize for scene s; called by all CH_TPB threads of a workgroup, smem = the dynamic LDS (host_lds_bytes).
+__device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* smem, const int s) {
     if (a.active && a.active[s] == 0) return;
     const omgx_chomp_params& prm = a.prm;
     const int n = prm.n_waypoints, P = prm.n_points, c = prm.constraint_num;
@@ -724,6 +724,24 @@ __global__ __launch_bounds__(CH_TPB) void k_chomp_optimize(ChompArgs a) {
     PHASE_MARK(8);
 }
 
+__global__ __launch_bounds__(CH_TPB) void k_chomp_optimize(ChompArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    chomp_scene(a, smem, blockIdx.x);
+}
+
+// Learner.update_goal followed by Optimizer.optimize for the same scene in one workgroup (planner.py:612-621 calls them
+// back to back): one launch and no stream round trip between the goal choice and the step that uses it.  The
+// learner's LDS (5 x 256 + 5 x 128 doubles) borrows the front of the dynamic region, which chomp_scene initialises
+// itself after the barrier.
+__global__ __launch_bounds__(CH_TPB) void k_update_optimize(omg_learner::LearnerArgs la, ChompArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* shl = reinterpret_cast<double*>(smem);
+    omg_learner::learner_scene(la, blockIdx.x, reinterpret_cast<double (*)[OMGX_MAX_GOALS]>(shl),
+                               reinterpret_cast<double (*)[128]>(shl + 5 * OMGX_MAX_GOALS));
+    __syncthreads();  // the goal written by wave 0 (global memory) is visible to the whole workgroup
+    chomp_scene(a, smem, blockIdx.x);
+}
+
 #ifdef OMGX_PHASE_TIMING
 extern "C" int omgx_debug_chomp_phase_times(unsigned long long* h_out, int n) {
     return (int)hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_chomp_phase), sizeof(unsigned long long) * (n < 32 ? n : 32));
@@ -740,13 +758,12 @@ static bool host_pot_in_lds(int n, int P) { return host_lds_bytes(n, P) + (size_
 
 extern "C" int64_t omgx_chomp_aux_doubles(int32_t n) { return n < 1 ? 0 : (int64_t)n * 9 + (int64_t)n * 10 + (int64_t)n * 9 + n + 1; }
 
-extern "C" int omgx_chomp_optimize(const double* robot, const omgx_chomp_params* h_params, double* traj,
-                                   const double* start, const double* end, const double* goal,
-                                   const double* goal_point, const float* potentials, const float* grads,
-                                   const float* collides, const int32_t* active, int32_t num_scenes, double* grad,
-                                   double* cost_traj, double* info, double* aux, void* stream) {
+// Argument checks + ChompArgs of omgx_chomp_optimize (shared with omgx_goal_update_optimize).
+static int chomp_make_args(const double* robot, const omgx_chomp_params* h_params, double* traj, const double* start,
+                           const double* end, const double* goal, const double* goal_point, const float* potentials,
+                           const float* grads, const float* collides, const int32_t* active, int32_t num_scenes, double* grad,
+                           double* cost_traj, double* info, double* aux, ChompArgs& a, size_t& lds) {
     if (!h_params || num_scenes < 0) return OMGX_ERR_INVALID;
-    if (num_scenes == 0) return OMGX_OK;
     if (!robot || !traj || !start || !end || !goal || !goal_point || !potentials || !grads || !collides || !grad ||
         !cost_traj || !info)
         return OMGX_ERR_INVALID;
@@ -755,19 +772,68 @@ extern "C" int omgx_chomp_optimize(const double* robot, const omgx_chomp_params*
         p.constraint_num < 1 || p.constraint_num > OMGX_MAX_CONSTRAINTS || p.constraint_num > p.n_waypoints)
         return OMGX_ERR_UNSUPPORTED;
     if (!(p.time_interval > 0.0) || p.top_k < 0 || p.do_update < 0 || p.do_update > 2) return OMGX_ERR_INVALID;
-    ChompArgs a{};
+    a = ChompArgs{};
     a.robot = robot; a.prm = p; a.traj = traj; a.start = start; a.end = end; a.goal = goal; a.goal_point = goal_point;
     a.pot = potentials; a.pgrad = grads; a.col = collides; a.active = active; a.grad = grad; a.cost_traj = cost_traj;
     a.info = info; a.aux = aux;
     a.pot_in_lds = host_pot_in_lds(p.n_waypoints, p.n_points) ? 1 : 0;
-    const size_t lds = host_lds_bytes(p.n_waypoints, p.n_points) + (a.pot_in_lds ? (size_t)p.n_waypoints * 160 * 4 : 0);
+    lds = host_lds_bytes(p.n_waypoints, p.n_points) + (a.pot_in_lds ? (size_t)p.n_waypoints * 160 * 4 : 0);
+    return OMGX_OK;
+}
+
+template <class K>
+static int allow_big_lds(K kernel, const char* what) {
+    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return e == hipSuccess ? OMGX_OK : omgx_set_error(what, e);
+}
+
+extern "C" int omgx_chomp_optimize(const double* robot, const omgx_chomp_params* h_params, double* traj,
+                                   const double* start, const double* end, const double* goal,
+                                   const double* goal_point, const float* potentials, const float* grads,
+                                   const float* collides, const int32_t* active, int32_t num_scenes, double* grad,
+                                   double* cost_traj, double* info, double* aux, void* stream) {
+    if (h_params && num_scenes == 0) return OMGX_OK;
+    ChompArgs a;
+    size_t lds = 0;
+    int rc = chomp_make_args(robot, h_params, traj, start, end, goal, goal_point, potentials, grads, collides, active, num_scenes,
+                             grad, cost_traj, info, aux, a, lds);
+    if (rc != OMGX_OK) return rc;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_chomp_optimize, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return omgx_set_error("hipFuncSetAttribute(k_chomp_optimize)", e);
+        if ((rc = allow_big_lds(k_chomp_optimize, "hipFuncSetAttribute(k_chomp_optimize)")) != OMGX_OK) return rc;
         attr_set = true;
     }
     hipLaunchKernelGGL(k_chomp_optimize, dim3(num_scenes), dim3(CH_TPB), lds, (hipStream_t)stream, a);
     OMGX_CHECK_LAUNCH("k_chomp_optimize");
+    return OMGX_OK;
+}
+
+extern "C" int omgx_goal_update_optimize(const omgx_learner_params* h_learner, const double* goal_set, const double* reach,
+                                         const float* goal_cost, double* learner_state, int32_t* goal_idx, double* cost_vector,
+                                         const double* robot, const omgx_chomp_params* h_params, double* traj,
+                                         const double* start, double* end, double* goal, double* goal_point,
+                                         const float* potentials, const float* grads, const float* collides,
+                                         const int32_t* active, int32_t num_scenes, double* grad, double* cost_traj, double* info,
+                                         double* aux, void* stream) {
+    if (h_learner && h_params && num_scenes == 0) return OMGX_OK;
+    omg_learner::LearnerArgs la;
+    int rc = omg_learner::make_args(h_learner, traj, goal_set, reach, goal_cost, learner_state, num_scenes, goal_idx, end, goal,
+                                    goal_point, cost_vector, la);
+    if (rc != OMGX_OK) return rc;
+    ChompArgs a;
+    size_t lds = 0;
+    rc = chomp_make_args(robot, h_params, traj, start, end, goal, goal_point, potentials, grads, collides, active, num_scenes, grad,
+                         cost_traj, info, aux, a, lds);
+    if (rc != OMGX_OK) return rc;
+    if (h_learner->n_waypoints != h_params->n_waypoints || h_learner->constraint_num != h_params->constraint_num) return OMGX_ERR_INVALID;
+    const size_t learner_lds = (size_t)(5 * OMGX_MAX_GOALS + 5 * 128) * sizeof(double);
+    if (lds < learner_lds) lds = learner_lds;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if ((rc = allow_big_lds(k_update_optimize, "hipFuncSetAttribute(k_update_optimize)")) != OMGX_OK) return rc;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_update_optimize, dim3(num_scenes), dim3(CH_TPB), lds, (hipStream_t)stream, la, a);
+    OMGX_CHECK_LAUNCH("k_update_optimize");
     return OMGX_OK;
 }

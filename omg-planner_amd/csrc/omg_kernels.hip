@@ -199,6 +199,13 @@ struct ChunkArgs {
     const double* traj_start;  // row s at traj_start + s * ts_stride
     int64_t ts_stride;
     const double* goals;       // [S][NCH][9]
+    // SDF layer of the current trajectories inside the goal-set launch (k_goalset_compact only): one extra workgroup per scene
+    const double* wp_traj;     // [S][wp_n][9] or null
+    int wp_n, wp_soften;
+    float* wp_pot;             // [S][wp_n][10][P]
+    float* wp_grad;            // [S][wp_n][10][P][3]
+    float* wp_col;             // [S][wp_n][10][P]
+    int PS, MR;                // LDS pose stride (configurations per link) and mask rows per link: max over both kinds of workgroup
 };
 
 // Thread layout: 256 threads = 16 rows x 16 lanes.  Lane = collision point p of a link (P <= 16), row =
@@ -377,22 +384,112 @@ __global__ __launch_bounds__(TPB) void k_sdf_chunks(ChunkArgs a) {
 // item, and the owners read the results back.  The per-point far pattern left only ~49 % of the lanes useful in
 // the unpacked exact path (a link's 10 cm point cloud straddles the far box); packed, a batch of LB links needs
 // ceil(survivors / 64) exact passes instead of one per link.  Arithmetic per pair is unchanged (bit-identical).
+// The SDF layer of scene s's current trajectory (what omgx_fk_sdf computes for Optimizer.optimize: potentials,
+// gradients, collisions of wp_n x 10 x P points) as ONE extra workgroup of the goal-set launch.  The optimiser step
+// that follows on the same stream then depends on a single kernel: no side stream, no events.  Arithmetic is that of
+// k_sdf_chunks<true> (same sdf_pair calls on the same float32 points), FK as in the goal-set workgroups.
+__device__ __forceinline__ void waypoint_layer_block(const ChunkArgs& a, const int s, double* lds_pose, uint32_t* rowmask,
+                                                     const int o_begin, const int o_end, const RobotView& rv) {
+    const int n = a.wp_n, P = a.P, PS = a.PS, MR = a.MR;
+    const double* tr = a.wp_traj + (int64_t)s * n * 9;
+    double* sc = reinterpret_cast<double*>(rowmask);  // [n][7][2], dead before the masks are written
+    for (int t = threadIdx.x; t < n * 7; t += 256) {
+        const int cfg = t / 7, i = t - cfg * 7;
+        double sn, cs;
+        fk_joint_sincos(tr[cfg * 9 + i], sn, cs);
+        sc[2 * t] = sn; sc[2 * t + 1] = cs;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < n * 3; t += 256) {
+        const int cfg = t / 3, r = t - cfg * 3;
+        fk_chain_row(rv, r, sc + 14 * cfg, tr[cfg * 9 + 7], tr[cfg * 9 + 8], [&](int l, double r0, double r1, double r2, double tt) {
+            double* dst = lds_pose + ((size_t)l * PS + cfg) * 9;
+            if (r < 2) { dst[3 * r] = r0; dst[3 * r + 1] = r1; dst[3 * r + 2] = r2; }
+            dst[6 + r] = tt;
+        });
+    }
+    __syncthreads();
+    for (int row = threadIdx.x; row < 10 * n; row += 256) {  // row-level culling
+        const int l = row / n, ci = row - l * n;
+        const double* A = lds_pose + ((int64_t)l * PS + ci) * 9;
+        const float cx = (float)A[6], cy = (float)A[7], cz = (float)A[8];
+        const float rad = (float)rv.radius(l) + 1.0e-4f;
+        uint32_t m = 0;
+        for (int o = o_begin; o < o_end; ++o) {
+            ObjTablePtr ob = as_const(a.objects) + o;
+            if (ob->disabled > 0) continue;
+            const int oo = o - o_begin;
+            const uint32_t bit = 1u << (oo < 31 ? oo : 31);
+            const float ux = __builtin_fmaf(ob->pose_inv[2], cz, __builtin_fmaf(ob->pose_inv[1], cy, __builtin_fmaf(ob->pose_inv[0], cx, ob->pose_inv[3]))) - ob->lo[0];
+            const float uy = __builtin_fmaf(ob->pose_inv[6], cz, __builtin_fmaf(ob->pose_inv[5], cy, __builtin_fmaf(ob->pose_inv[4], cx, ob->pose_inv[7]))) - ob->lo[1];
+            const float uz = __builtin_fmaf(ob->pose_inv[10], cz, __builtin_fmaf(ob->pose_inv[9], cy, __builtin_fmaf(ob->pose_inv[8], cx, ob->pose_inv[11]))) - ob->lo[2];
+            const bool near = (ux >= ob->far_lo[0] - rad) & (ux <= ob->far_hi[0] + rad) & (uy >= ob->far_lo[1] - rad) &
+                              (uy <= ob->far_hi[1] + rad) & (uz >= ob->far_lo[2] - rad) & (uz <= ob->far_hi[2] + rad);
+            const bool cullable = ob->epsilon < 1.0f && ob->clearance <= 1.0f;
+            if (near || !cullable) m |= bit;
+        }
+        rowmask[l * MR + ci] = m;
+    }
+    __syncthreads();
+    const int p = threadIdx.x & 15, r = threadIdx.x >> 4;
+    for (int ci0 = 0; ci0 < n; ci0 += 16) {
+        const int ci = ci0 + r;
+        const bool valid = (p < P) && (ci < n);
+        const int cic = valid ? ci : 0, pc = valid ? p : 0;
+#pragma unroll 1
+        for (int l = 0; l < 10; ++l) {
+            const uint32_t msk = valid ? rowmask[l * MR + cic] : 0u;
+            Accum acc{0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+            if (__any(msk != 0)) {
+                float px, py, pz;
+                pose9_apply(lds_pose + ((int64_t)l * PS + cic) * 9, rv.pts(l, pc), px, py, pz);
+                for (int o = o_begin; o < o_end; ++o) {
+                    const int oo = o - o_begin;
+                    const uint32_t bit = 1u << (oo < 31 ? oo : 31);
+                    if (!__any((msk & bit) != 0)) continue;
+                    ObjTablePtr ob = as_const(a.objects) + o;
+                    if (ob->disabled > 0) continue;
+                    const ObjParams op = load_object(ob);
+                    const PairPrep pp = pair_prepare(op, px, py, pz);
+                    if ((msk & bit) && !pp.far) pair_exact<true>(op, a.pool + ob->grid_offset, pp.tx, pp.ty, pp.tz, acc);
+                }
+            }
+            if (a.wp_soften && l >= 8) {  // cost.py:350-353
+                acc.pot *= 0.1f; acc.gx *= 0.1f; acc.gy *= 0.1f; acc.gz *= 0.1f; acc.col = 0.0f;
+            }
+            if (valid) {
+                const int64_t kk = (((int64_t)s * n + ci) * 10 + l) * P + p;
+                a.wp_pot[kk] = acc.pot;
+                a.wp_col[kk] = acc.col;
+                a.wp_grad[3 * kk] = acc.gx; a.wp_grad[3 * kk + 1] = acc.gy; a.wp_grad[3 * kk + 2] = acc.gz;
+            }
+        }
+    }
+}
+
 template <int LB>
 __global__ __launch_bounds__(256, 6) void k_goalset_compact(ChunkArgs a) {
     extern __shared__ __attribute__((aligned(16))) double lds_pose[];
     __shared__ float red[2][4];
     const int xcd = blockIdx.x & 7;
     const int j = blockIdx.x >> 3;
-    const int sgrp = j / a.NCH;
-    const int s = sgrp * 8 + xcd, chunk = j - sgrp * a.NCH;
+    const int nchx = a.NCH + (a.wp_traj ? 1 : 0);  // with a trajectory layer, workgroup 0 of every scene computes it
+    const int sgrp = j / nchx;
+    const int s = sgrp * 8 + xcd, cx = j - sgrp * nchx;
     if (s >= a.S) return;
     const int o_begin = as_const(a.scene_begin)[s], o_end = as_const(a.scene_begin)[s + 1];
     const int P = a.P, CH = a.CH;
     const int nvalid = CH;
     const int p = threadIdx.x & 15, r = threadIdx.x >> 4, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const RobotView rv(a.robot, P);
-    uint32_t* rowmask = reinterpret_cast<uint32_t*>(lds_pose + (size_t)(CH + 1) * 90);  // poses: 9 doubles (see pose9_apply)
-    float* scratch = reinterpret_cast<float*>(rowmask + ((10 * CH + 3) & ~3)) + wave * 192;  // wave-private [64][3]: 12 B entries keep 6 workgroups per CU inside 160 KB
+    const int pstride = a.PS, MR = a.MR;
+    uint32_t* rowmask = reinterpret_cast<uint32_t*>(lds_pose + (size_t)pstride * 90);  // poses: 9 doubles (see pose9_apply)
+    float* scratch = reinterpret_cast<float*>(rowmask + ((10 * MR + 3) & ~3)) + wave * 192;  // wave-private [64][3]: 12 B entries keep 6 workgroups per CU inside 160 KB
+    if (a.wp_traj && cx == 0) {
+        waypoint_layer_block(a, s, lds_pose, rowmask, o_begin, o_end, rv);
+        return;
+    }
+    const int chunk = a.wp_traj ? cx - 1 : cx;
 
     {   // FK of start + CH interpolated configurations in two stages (omg_device.h: fk_chain_row); the (sin, cos)
         // table borrows the row-mask / scratch region, which is first written after the barriers below.
@@ -412,7 +509,7 @@ __global__ __launch_bounds__(256, 6) void k_goalset_compact(ChunkArgs a) {
         for (int t = threadIdx.x; t < ncfg * 3; t += 256) {
             const int cfg = t / 3, r = t - cfg * 3;
             fk_chain_row(rv, r, sc + 14 * cfg, joint(cfg, 7), joint(cfg, 8), [&](int l, double r0, double r1, double r2, double tr) {
-                double* dst = lds_pose + ((size_t)l * (CH + 1) + cfg) * 9;  // rows 0 and 1 of R, then t
+                double* dst = lds_pose + ((size_t)l * pstride + cfg) * 9;  // rows 0 and 1 of R, then t
                 if (r < 2) { dst[3 * r] = r0; dst[3 * r + 1] = r1; dst[3 * r + 2] = r2; }
                 dst[6 + r] = tr;
             });
@@ -420,7 +517,6 @@ __global__ __launch_bounds__(256, 6) void k_goalset_compact(ChunkArgs a) {
     }
     __syncthreads();
     const double* base = lds_pose + 9;
-    const int pstride = CH + 1;
 
     for (int row = threadIdx.x; row < 10 * CH; row += 256) {  // phase A: row-level culling (see k_sdf_chunks)
         const int l = row / CH, ci = row - l * CH;
@@ -697,7 +793,10 @@ static int launch_chunks(ChunkArgs& ca, hipStream_t st) {
         if (wgs * 5 <= 1024) lpw = 2; else if (wgs * 2 <= 1024) lpw = 5;
     }
     ca.LPW = lpw;
-    const int64_t grid = (int64_t)scene_groups * ca.NCH * 8 * (10 / lpw);
+    const bool layer = ca.wp_traj != nullptr;  // only with k_goalset_compact (checked by the caller)
+    ca.PS = ca.CH + 1; ca.MR = ca.CH;
+    if (layer) { if (ca.wp_n > ca.PS) ca.PS = ca.wp_n; if (ca.wp_n > ca.MR) ca.MR = ca.wp_n; }
+    const int64_t grid = (int64_t)scene_groups * (ca.NCH + (layer ? 1 : 0)) * 8 * (10 / lpw);
     if (grid > 0x7fffffff) return OMGX_ERR_UNSUPPORTED;
     // Timed launches attach the start/stop events to the dispatch itself (hipExtLaunchKernelGGL): the events then
     // bracket exactly this kernel and cost no extra packets on the stream.
@@ -718,10 +817,10 @@ static int launch_chunks(ChunkArgs& ca, hipStream_t st) {
     static int compact = -1;  // OMGX_COMPACT=0 keeps the unpacked exact path (A/B measurements)
     if (compact < 0) { const char* e = getenv("OMGX_COMPACT"); compact = e ? atoi(e) : 1; }
     if (ca.traj_start && compact && !ca.pot) {  // goal-set batch, cost only: packed exact path
-        size_t tail = (((size_t)10 * ca.CH + 3) & ~(size_t)3) * sizeof(uint32_t) + 4 * 64 * 3 * sizeof(float);  // row masks + scratch
-        const size_t sincos = (size_t)(ca.CH + 1) * 14 * sizeof(double);                                       // FK stage 1 table
+        size_t tail = (((size_t)10 * ca.MR + 3) & ~(size_t)3) * sizeof(uint32_t) + 4 * 64 * 3 * sizeof(float);  // row masks + scratch
+        const size_t sincos = (size_t)ca.PS * 14 * sizeof(double);                                             // FK stage 1 table
         if (tail < sincos) tail = sincos;
-        const size_t lds = (size_t)(ca.CH + 1) * 90 * sizeof(double) + tail;
+        const size_t lds = (size_t)ca.PS * 90 * sizeof(double) + tail;
         if (lb == 10) OMGX_LAUNCH((k_goalset_compact<10>), lds);
         else if (lb == 2) OMGX_LAUNCH((k_goalset_compact<2>), lds);
         else OMGX_LAUNCH((k_goalset_compact<5>), lds);
@@ -821,12 +920,12 @@ extern "C" int omgx_forward_kinematics(const double* robot, int32_t n_points, co
     return OMGX_OK;
 }
 
-extern "C" int omgx_goalset_cost(const double* robot, int32_t n_points, const omgx_object* objects,
-                                 const int32_t* scene_begin, const float* sdf_pool, const double* traj_start,
-                                 int64_t traj_start_stride, const double* goals, int32_t num_scenes, int32_t num_goals,
-                                 int32_t n_remaining,
-                                 double time_interval, int32_t soften_fingers, float* goal_cost, float* potentials,
-                                 float* collides, void* workspace, void* stream) {
+static int goalset_cost_impl(const double* robot, int32_t n_points, const omgx_object* objects, const int32_t* scene_begin,
+                             const float* sdf_pool, const double* traj_start, int64_t traj_start_stride, const double* goals,
+                             int32_t num_scenes, int32_t num_goals, int32_t n_remaining, double time_interval,
+                             int32_t soften_fingers, float* goal_cost, float* potentials, float* collides, void* workspace,
+                             const double* layer_traj, int32_t layer_n, int32_t layer_soften, float* layer_pot, float* layer_grad,
+                             float* layer_col, void* stream) {
     if (num_scenes < 0 || num_goals < 0) return OMGX_ERR_INVALID;
     if (num_scenes == 0 || num_goals == 0) return OMGX_OK;
     if (!robot || !objects || !scene_begin || !traj_start || !goals || !goal_cost || !workspace) return OMGX_ERR_INVALID;
@@ -839,6 +938,13 @@ extern "C" int omgx_goalset_cost(const double* robot, int32_t n_points, const om
     double* ws_start = ws + (int64_t)num_scenes * num_goals * 10 * n * 12;
     static int fused = -1;  // OMGX_FUSED_FK=0 keeps the separate FK launch (A/B measurements)
     if (fused < 0) { const char* e = getenv("OMGX_FUSED_FK"); fused = e ? atoi(e) : 1; }
+    static int compact = -1;
+    if (compact < 0) { const char* e = getenv("OMGX_COMPACT"); compact = e ? atoi(e) : 1; }
+    if (layer_traj) {  // the trajectory layer rides on k_goalset_compact only
+        if (!layer_pot || !layer_grad || !layer_col) return OMGX_ERR_INVALID;
+        if (layer_n < 1 || layer_n > OMGX_MAX_WAYPOINTS) return OMGX_ERR_UNSUPPORTED;
+        if (potentials || !fused || !compact) return OMGX_ERR_UNSUPPORTED;
+    }
     if (!fused) {
         FkArgs fa{};
         fa.robot = robot; fa.P = n_points; fa.mode = 1; fa.traj_start = traj_start; fa.ts_stride = traj_start_stride; fa.goals = goals; fa.S = num_scenes;
@@ -853,5 +959,33 @@ extern "C" int omgx_goalset_cost(const double* robot, int32_t n_points, const om
     ca.arc = 1; ca.inv_dt = (float)(1.0 / time_interval);
     ca.pot = potentials; ca.grad = nullptr; ca.col = nullptr; ca.chunk_cost = goal_cost; ca.chunk_col = collides;
     if (fused) { ca.traj_start = traj_start; ca.ts_stride = traj_start_stride; ca.goals = goals; }
+    if (layer_traj) {
+        ca.wp_traj = layer_traj; ca.wp_n = layer_n; ca.wp_soften = layer_soften != 0;
+        ca.wp_pot = layer_pot; ca.wp_grad = layer_grad; ca.wp_col = layer_col;
+    }
     return launch_chunks(ca, st);
+}
+
+extern "C" int omgx_goalset_cost(const double* robot, int32_t n_points, const omgx_object* objects,
+                                 const int32_t* scene_begin, const float* sdf_pool, const double* traj_start,
+                                 int64_t traj_start_stride, const double* goals, int32_t num_scenes, int32_t num_goals,
+                                 int32_t n_remaining,
+                                 double time_interval, int32_t soften_fingers, float* goal_cost, float* potentials,
+                                 float* collides, void* workspace, void* stream) {
+    return goalset_cost_impl(robot, n_points, objects, scene_begin, sdf_pool, traj_start, traj_start_stride, goals, num_scenes,
+                             num_goals, n_remaining, time_interval, soften_fingers, goal_cost, potentials, collides, workspace,
+                             nullptr, 0, 0, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int omgx_goalset_cost_layer(const double* robot, int32_t n_points, const omgx_object* objects,
+                                       const int32_t* scene_begin, const float* sdf_pool, const double* traj_start,
+                                       int64_t traj_start_stride, const double* goals, int32_t num_scenes, int32_t num_goals,
+                                       int32_t n_remaining, double time_interval, int32_t soften_fingers, float* goal_cost,
+                                       float* collides, void* workspace, const double* traj, int32_t n_waypoints,
+                                       int32_t layer_soften_fingers, float* layer_potentials, float* layer_grads,
+                                       float* layer_collides, void* stream) {
+    if (!traj) return OMGX_ERR_INVALID;
+    return goalset_cost_impl(robot, n_points, objects, scene_begin, sdf_pool, traj_start, traj_start_stride, goals, num_scenes,
+                             num_goals, n_remaining, time_interval, soften_fingers, goal_cost, nullptr, collides, workspace, traj,
+                             n_waypoints, layer_soften_fingers, layer_potentials, layer_grads, layer_collides, stream);
 }

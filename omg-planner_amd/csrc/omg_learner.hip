@@ -1,327 +1,16 @@
-// omg_learner.hip — k_goal_update: Learner.update_goal for S scenes, one wavefront per scene.
-//
-// Replaces (float64, like the reference's numpy code):
-//   Learner.cost_vector tail        omg/online_learner.py:145-160  (weights, smoothness proxy, normalisation)
-//   Learner.update_goal_dist        :162-235  FTL / FTC / Exp / MD (mirror descent over 5 experts) / Proj
-//   bp + find_zero                  :16-58    Bregman projection onto the simplex by nested bisection
-//   Learner.update_goal             :237-249  argmax of the goal distribution, traj.end
-//   chosen goal rows                omg/optimizer.py:93-99
-//
-// Lane j of a wave owns goals j, j+64, j+128, j+192 (G <= 256); every sum is a 64-lane butterfly, so all
-// lanes hold identical values and the bisection's control flow is wave-uniform.  The workgroup has 5 waves:
-// for MD each wave runs the Bregman projection of one expert (they are independent; only the mixture update
-// that follows is sequential in the expert index), handing its result to wave 0 through LDS.  The other
-// rules use wave 0 only.
-#include <hip/hip_runtime.h>
-
-#include <stdint.h>
-
-#include "omg_device.h"
-#include "omg_host.h"
-
-#pragma clang fp contract(fast)
-
-// Debug aid (make CXXFLAGS+=-DOMGX_PHASE_TIMING), see omg_chomp.hip.  Slots 0-7 clocks, 8.. iteration counts.
-#ifdef OMGX_PHASE_TIMING
-__device__ unsigned long long g_learner_phase[32];
-#define PHASE_MARK(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_learner_phase[i] = __builtin_readcyclecounter(); } while (0)
-#define PHASE_COUNT(i, v) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) g_learner_phase[i] = (unsigned long long)(v); } while (0)
-#else
-#define PHASE_MARK(i) do { } while (0)
-#define PHASE_COUNT(i, v) do { } while (0)
-#endif
+// omg_learner.hip — k_goal_update: Learner.update_goal for S scenes, one workgroup of 5 waves per scene
+// (device code: omg_learner_body.h).
+#include "omg_learner_body.h"
 
 namespace {
 
-#define NPL 4  // goals per lane
-
-struct LearnerArgs {
-    omgx_learner_params prm;
-    const double* traj;
-    const double* goal_set;
-    const double* reach;
-    const float* goal_cost;
-    double* state;
-    int S;
-    int32_t* goal_idx;
-    double* end;
-    double* goal_rows;
-    double* goal_point;
-    double* cost_vector;
-};
-
-__device__ __forceinline__ double lane_bcast(double v, int k) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), k), hi = __builtin_amdgcn_readlane(__double2hiint(v), k);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double wsum(double v) { return omg::wave_allsum(v); }  // identical result in every lane
-__device__ __forceinline__ double wmax(double v) { return omg::wave_allmax(v); }
-// arg-extreme with the lowest index on ties (np.argmin / np.argmax return the first occurrence)
-template <bool MIN>
-__device__ __forceinline__ int warg(double v, int i) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const double ov = __shfl_xor(v, off, 64);
-        const int oi = __shfl_xor(i, off, 64);
-        const bool better = MIN ? (ov < v) : (ov > v);
-        if (better || (ov == v && oi < i)) { v = ov; i = oi; }
-    }
-    return i;
-}
-
-// bp (online_learner.py:32-58) with find_zero (:16-29) inlined.  x, v per-lane slices; w = 1, delta = 1/(4G+1).
-//
-// find_zero bisects f(L) = sum_j shiftx_j exp(L + z_j) - target = exp(L) * C - target over L: C is summed once per
-// outer iteration and exp(L) follows the bisection, E *= exp(+-s_k) with s_k = x1 / 2^(k+2).  Neither x1 = max(1 + v)
-// nor shiftx change between outer iterations, so the step factors exp(+-s_k) are tabulated once per projection
-// (lane k evaluates entry k; `tab` is a wave-private LDS array of 2 x 64 doubles, later factors are exactly 1), and a bisection step is a
-// fused multiply-add, a compare and a multiply by a table entry.  L itself is updated exactly like the reference
-// (same dyadic sequence); E carries ~1e-16 relative error per step against a decision threshold of 1e-6.
-__device__ void bregman_projection(const double* x, const double* v, double delta, int G, int lane, double* y, double* tab) {
-    const int max_iter = 100;
-    const double err = 1e-6;
-    double alpha[NPL] = {0, 0, 0, 0}, shiftx[NPL], lds[NPL], ez[NPL];
-    const double target = 1.0 + delta * (double)G;
-    double vmax = -1e300;
-#pragma unroll
-    for (int j = 0; j < NPL; ++j) {
-        const bool ok = lane + 64 * j < G;
-        shiftx[j] = x[j] + delta;
-        lds[j] = ok ? log(delta / shiftx[j]) : 0.0;
-        ez[j] = 0.0;
-        if (ok) vmax = fmax(vmax, 1.0 + v[j]);
-    }
-    const double x1 = wmax(vmax);
-    const double L0 = (0.0 + x1) / 2.0, s0 = (x1 - 0.0) / 4.0;
-    const double E0 = exp(L0);
-    {   // s_k = s0 / 2^k is exact (power-of-two scaling); for k >= 64 exp(+-s_k) rounds to 1 (s_k < 2^-60 x1)
-        const double up = exp(ldexp(s0, -lane));
-        tab[2 * lane] = up;
-        tab[2 * lane + 1] = 1.0 / up;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    int dbg_outer = 0, dbg_inner = 0;
-    for (int it = 0; it < max_iter; ++it) {
-        ++dbg_outer;
-        double partC = 0.0;
-#pragma unroll
-        for (int j = 0; j < NPL; ++j)
-            if (lane + 64 * j < G) { ez[j] = exp(alpha[j] - v[j]); partC += shiftx[j] * ez[j]; }
-        const double Csum = wsum(partC);
-        double L = L0, sstep = s0, E = E0;
-        double up = tab[0], dn = tab[1];
-        for (int k = 0; k < max_iter; ++k) {
-            const double fy = E * Csum - target;
-            ++dbg_inner;
-            if (fabs(fy) < err) break;
-            const int kn = k + 1 < 64 ? k + 1 : 63;  // prefetch the next pair; beyond k = 63 the factors are 1
-            const double nup = tab[2 * kn], ndn = tab[2 * kn + 1];
-            const bool pos = fy > 0;                  // fy == 0 left the loop above
-            L += pos ? -sstep : sstep;
-            E *= pos ? dn : up;
-            sstep /= 2.0;
-            up = k + 1 < 64 ? nup : 1.0;
-            dn = k + 1 < 64 ? ndn : 1.0;
-        }
-        const double EL = E;  // exp(L) up to the accumulated ~1e-15
-        double nrm = 0.0, ap[NPL];
-#pragma unroll
-        for (int j = 0; j < NPL; ++j) {
-            const bool ok = lane + 64 * j < G;
-            y[j] = ok ? shiftx[j] * (EL * ez[j]) - delta : 0.0;  // shiftx exp(L + alpha - v) - delta
-            ap[j] = ok ? fmax(0.0, v[j] - L + lds[j]) : 0.0;
-            nrm += (alpha[j] - ap[j]) * (alpha[j] - ap[j]);
-        }
-        if (sqrt(wsum(nrm)) < err) break;
-#pragma unroll
-        for (int j = 0; j < NPL; ++j) alpha[j] = ap[j];
-    }
-    PHASE_COUNT(8 + 2 * (threadIdx.x >> 6), dbg_outer);
-    PHASE_COUNT(9 + 2 * (threadIdx.x >> 6), dbg_inner);
-    double part = 0.0;
-#pragma unroll
-    for (int j = 0; j < NPL; ++j) { y[j] = fmax(y[j], 0.0); part += y[j]; }
-    const double sy = wsum(part);
-#pragma unroll
-    for (int j = 0; j < NPL; ++j) y[j] /= sy;
-}
-
-__global__ __launch_bounds__(320) void k_goal_update(LearnerArgs a) {
+__global__ __launch_bounds__(320) void k_goal_update(omg_learner::LearnerArgs a) {
     __shared__ double sh_pn[5][OMGX_MAX_GOALS];
     __shared__ double sh_tab[5][128];
-    PHASE_MARK(0);
-    const int s = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (a.prm.alg != OMGX_ALG_MD && wave > 0) return;
-    const omgx_learner_params& prm = a.prm;
-    const int G = prm.num_goals, n = prm.n_waypoints, c = prm.constraint_num;
-    double* st = a.state + (int64_t)s * (7 * (int64_t)G + 10);
-    double *sum_costs = st, *p = st + G, *experts_p = st + 2 * G, *q = st + 7 * G, *ecost = st + 7 * G + 5;
-    const double* gs = a.goal_set + (int64_t)s * G * 9;
-    int idx = 0;
-    if (prm.alg == OMGX_ALG_PROJ) {  // :196-206
-        const double* last = a.traj + ((int64_t)s * n + n - 1) * 9;
-        double best = 1e300;
-        int bi = 0x7fffffff;
-        for (int j = 0; j < NPL; ++j) {
-            const int g = lane + 64 * j;
-            if (g < G) {
-                double d2 = 0.0;
-                for (int d = 0; d < 9; ++d) { const double e = last[d] - gs[g * 9 + d]; d2 += e * e; }
-                const double dist = sqrt(d2);
-                if (dist < best) { best = dist; bi = g; }
-            }
-        }
-        idx = warg<true>(best, bi);
-        for (int j = 0; j < NPL; ++j) { const int g = lane + 64 * j; if (g < G) p[g] = (g == idx) ? 1.0 : 0.0; }
-    } else {
-        const double* ts = a.traj + ((int64_t)s * n + prm.start_idx) * 9;
-        double cv[NPL];
-        double part = 0.0;
-        for (int j = 0; j < NPL; ++j) {
-            const int g = lane + 64 * j;
-            cv[j] = 0.0;
-            if (g < G) {
-                double s2 = 0.0;
-                for (int d = 0; d + 1 < 9; ++d) {  // np.diff(traj_start - goal_set, axis=-1): adjacent joint columns
-                    const double e = (ts[d + 1] - gs[g * 9 + d + 1]) - (ts[d] - gs[g * 9 + d]);
-                    s2 += e * e;
-                }
-                const double nr = sqrt(s2);
-                const float wc = (float)prm.base_obstacle_weight * a.goal_cost[(int64_t)s * G + g];  // float32 product
-                cv[j] = (double)wc + prm.smooth_weight * (nr * nr);
-                part += cv[j] * cv[j];
-            }
-        }
-        if (prm.normalize_cost) {
-            const double nn = sqrt(wsum(part));
-            for (int j = 0; j < NPL; ++j) cv[j] /= nn;
-        }
-        if (a.cost_vector && wave == 0)
-            for (int j = 0; j < NPL; ++j) { const int g = lane + 64 * j; if (g < G) a.cost_vector[(int64_t)s * G + g] = cv[j]; }
-
-        if (prm.alg == OMGX_ALG_FTL || prm.alg == OMGX_ALG_FTC) {  // :175-189
-            double best = 1e300;
-            int bi = 0x7fffffff;
-            for (int j = 0; j < NPL; ++j) {
-                const int g = lane + 64 * j;
-                if (g < G) {
-                    double key = cv[j];
-                    if (prm.alg == OMGX_ALG_FTL) { key = sum_costs[g] + cv[j]; sum_costs[g] = key; }
-                    if (key < best) { best = key; bi = g; }
-                }
-            }
-            idx = warg<true>(best, bi);
-            for (int j = 0; j < NPL; ++j) { const int g = lane + 64 * j; if (g < G) p[g] = (g == idx) ? 1.0 : 0.0; }
-        } else if (prm.alg == OMGX_ALG_EXP) {  // :208-217
-            double sc[NPL], pn[NPL], tot = 0.0;
-            for (int j = 0; j < NPL; ++j) {
-                const int g = lane + 64 * j;
-                sc[j] = 0.0;
-                if (g < G) { sc[j] = sum_costs[g] + cv[j]; sum_costs[g] = sc[j]; tot += sc[j]; }
-            }
-            tot = wsum(tot);
-            double ps = 0.0;
-            for (int j = 0; j < NPL; ++j) {
-                const int g = lane + 64 * j;
-                pn[j] = 0.0;
-                if (g < G) { pn[j] = exp(-prm.eta * cv[j]) * p[g] * 0.999 + (sc[j] / (tot + 1e-8)) * 0.001; ps += pn[j]; }
-            }
-            ps = wsum(ps);
-            double best = -1e300;
-            int bi = 0x7fffffff;
-            for (int j = 0; j < NPL; ++j) {
-                const int g = lane + 64 * j;
-                if (g < G) { const double v = pn[j] / (ps + 1e-8); p[g] = v; if (v > best) { best = v; bi = g; } }
-            }
-            idx = warg<false>(best, bi);
-        } else {  // MD, :219-235
-            PHASE_MARK(1);
-            const double pw[5] = {0.25, 0.5, 1.0, 4.0, 16.0};  // eta * 2**[-2,-1,0,2,4], :82
-            const double delta = 1.0 / (4.0 * (double)G + 1.0);
-            {   // every wave: Bregman projection of its own expert (reads the OLD experts_p, like the reference)
-                double v[NPL], epw[NPL], pn[NPL];
-                for (int j = 0; j < NPL; ++j) {
-                    const int g = lane + 64 * j;
-                    v[j] = prm.eta * pw[wave] * cv[j];
-                    epw[j] = g < G ? experts_p[(int64_t)wave * G + g] : 0.0;
-                }
-                bregman_projection(epw, v, delta, G, lane, pn, sh_tab[wave]);
-                PHASE_MARK(2);
-                for (int j = 0; j < NPL; ++j) { const int g = lane + 64 * j; if (g < G) sh_pn[wave][g] = pn[j]; }
-            }
-            __syncthreads();
-            PHASE_MARK(3);
-            if (wave > 0) return;
-            double qv[5], ec[5], ep[5][NPL];
-            for (int i = 0; i < 5; ++i) {
-                qv[i] = q[i]; ec[i] = ecost[i];
-                for (int j = 0; j < NPL; ++j) { const int g = lane + 64 * j; ep[i][j] = g < G ? experts_p[(int64_t)i * G + g] : 0.0; }
-            }
-            double pm[NPL] = {0, 0, 0, 0};
-            for (int i = 0; i < 5; ++i) {
-                double pn[NPL];
-                for (int j = 0; j < NPL; ++j) { const int g = lane + 64 * j; pn[j] = g < G ? sh_pn[i][g] : 0.0; }
-                double part2 = 0.0;
-                for (int j = 0; j < NPL; ++j)
-                    if (lane + 64 * j < G) part2 += cv[j] * pn[j] + fabs(pn[j] - ep[i][j]);
-                ec[i] = wsum(part2);
-                for (int j = 0; j < NPL; ++j) ep[i][j] = pn[j];
-                // the mixture update sits INSIDE the expert loop (:231-235)
-                double qs = 0.0;
-                {   // exp(-ec[k]) for the 5 experts: lane k evaluates one, broadcast by readlane
-                    double mine = 0.0;
-                    for (int k = 0; k < 5; ++k) mine = lane == k ? ec[k] : mine;
-                    const double ex = exp(-1.0 * mine);
-                    for (int k = 0; k < 5; ++k) { qv[k] = qv[k] * lane_bcast(ex, k); qs += qv[k]; }
-                }
-                for (int k = 0; k < 5; ++k) qv[k] /= qs;
-                double ps = 0.0;
-                for (int j = 0; j < NPL; ++j) {
-                    double m = 0.0;
-                    for (int k = 0; k < 5; ++k) m += ep[k][j] * qv[k];
-                    pm[j] = (lane + 64 * j < G) ? m : 0.0;
-                    ps += pm[j];
-                }
-                ps = wsum(ps);
-                for (int j = 0; j < NPL; ++j) pm[j] /= ps;
-            }
-            double best = -1e300;
-            int bi = 0x7fffffff;
-            for (int j = 0; j < NPL; ++j) {
-                const int g = lane + 64 * j;
-                if (g < G) {
-                    p[g] = pm[j];
-                    for (int i = 0; i < 5; ++i) experts_p[(int64_t)i * G + g] = ep[i][j];
-                    if (pm[j] > best) { best = pm[j]; bi = g; }
-                }
-            }
-            if (lane == 0)
-                for (int i = 0; i < 5; ++i) { q[i] = qv[i]; ecost[i] = ec[i]; }
-            idx = warg<false>(best, bi);
-        }
-    }
-    // traj.end / goal rows (online_learner.py:243-245, optimizer.py:93-99)
-    PHASE_MARK(4);
-    if (lane == 0) a.goal_idx[s] = idx;
-    if (lane < 9) {
-        const double v = gs[idx * 9 + lane];
-        a.end[s * 9 + lane] = v;
-        a.goal_point[s * 9 + lane] = v;
-    }
-    for (int e = lane; e < c * 9; e += 64)
-        a.goal_rows[(int64_t)s * c * 9 + e] =
-            prm.use_standoff ? a.reach[((int64_t)s * G + idx) * c * 9 + e] : gs[idx * 9 + e % 9];
+    omg_learner::learner_scene(a, blockIdx.x, sh_pn, sh_tab);
 }
 
 }  // namespace
-
-#ifdef OMGX_PHASE_TIMING
-extern "C" int omgx_debug_learner_phase_times(unsigned long long* h_out, int n) {
-    return (int)hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_learner_phase), sizeof(unsigned long long) * (n < 32 ? n : 32));
-}
-#endif
 
 extern "C" int64_t omgx_learner_state_doubles(int32_t num_goals) { return num_goals < 1 ? 0 : 7 * (int64_t)num_goals + 10; }
 
@@ -329,20 +18,11 @@ extern "C" int omgx_goal_update(const omgx_learner_params* h_params, const doubl
                                 const double* reach, const float* goal_cost, double* state, int32_t num_scenes,
                                 int32_t* goal_idx, double* end, double* goal_rows, double* goal_point, double* cost_vector,
                                 void* stream) {
-    if (!h_params || num_scenes < 0) return OMGX_ERR_INVALID;
-    if (num_scenes == 0) return OMGX_OK;
-    const omgx_learner_params& p = *h_params;
-    if (!traj || !goal_set || !state || !goal_idx || !end || !goal_rows || !goal_point) return OMGX_ERR_INVALID;
-    if (p.alg < OMGX_ALG_FTL || p.alg > OMGX_ALG_PROJ) return OMGX_ERR_INVALID;
-    if (p.alg != OMGX_ALG_PROJ && !goal_cost) return OMGX_ERR_INVALID;
-    if (p.use_standoff && !reach) return OMGX_ERR_INVALID;
-    if (p.num_goals < 1 || p.num_goals > OMGX_MAX_GOALS || p.n_waypoints < 1 || p.constraint_num < 1 ||
-        p.constraint_num > OMGX_MAX_CONSTRAINTS)
-        return OMGX_ERR_UNSUPPORTED;
-    if (p.start_idx < 0 || p.start_idx >= p.n_waypoints) return OMGX_ERR_INVALID;
-    LearnerArgs a{};
-    a.prm = p; a.traj = traj; a.goal_set = goal_set; a.reach = reach; a.goal_cost = goal_cost; a.state = state; a.S = num_scenes;
-    a.goal_idx = goal_idx; a.end = end; a.goal_rows = goal_rows; a.goal_point = goal_point; a.cost_vector = cost_vector;
+    if (h_params && num_scenes == 0) return OMGX_OK;
+    omg_learner::LearnerArgs a;
+    const int rc = omg_learner::make_args(h_params, traj, goal_set, reach, goal_cost, state, num_scenes, goal_idx, end, goal_rows,
+                                          goal_point, cost_vector, a);
+    if (rc != OMGX_OK) return rc;
     hipLaunchKernelGGL(k_goal_update, dim3(num_scenes), dim3(320), 0, (hipStream_t)stream, a);
     OMGX_CHECK_LAUNCH("k_goal_update");
     return OMGX_OK;

@@ -94,7 +94,7 @@ class ChompEngine:
         self.goal_cost = torch.empty((S, G), **f32)
         self.goal_col = torch.empty((S, G), **f32)
         self.learner_state = ops.learner_state(S, G, dev)  # sum_costs | p | experts_p | q | experts_costs
-        self.cost_vec = torch.empty((S, G), **f64)
+        self.cost_vec = torch.zeros((S, G), **f64)
         self.eta = float(np.sqrt(np.log(G + 1) / cfg.optim_steps))  # online_learner.py:80
         self.active = torch.ones(S, dtype=torch.int32, device=dev)
         self.step_count = 0  # Optimizer.step
@@ -166,26 +166,45 @@ class ChompEngine:
         p.eta = self.eta
         return p
 
-    def update_goal(self):
-        """Learner.update_goal (online_learner.py:237-249): omgx_goalset_cost + omgx_goal_update, no host sync."""
+    def update_goal(self, defer_update: bool = False, with_layer: bool = False):
+        """Learner.update_goal (online_learner.py:237-249): omgx_goalset_cost + omgx_goal_update, no host sync.
+        defer_update=True launches only the goal-set batch and returns the learner parameters: the caller then runs
+        the goal update fused with the optimiser step (omgx_goal_update_optimize)."""
         self.t += 1
         if self.ol_alg == "Baseline":
-            return
+            return None
         prm = self._learner_params()
         if self.ol_alg != "Proj":  # cost_vector's obstacle batch (online_learner.py:128-148)
             n_rem = self.cfg.timesteps - prm.start_idx
             traj_start = self.traj[:, prm.start_idx]  # strided view into the trajectory tensor: no copy kernel
-            ops.goalset_cost(self.robot, self.P, self.scenes, traj_start, self.cv_goals, n_rem, self.cfg.time_interval,
-                             soften_fingers=False, out=(self.goal_cost, self.goal_col))
+            if with_layer:  # the SDF layer of the current trajectories rides on the goal-set launch
+                ops.goalset_cost_layer(self.robot, self.P, self.scenes, traj_start, self.cv_goals, n_rem, self.cfg.time_interval,
+                                       self.traj, (self.pot, self.pgrad, self.col), soften_fingers=False,
+                                       layer_soften_fingers=self.cfg.uncheck_finger_collision == -1,
+                                       out=(self.goal_cost, self.goal_col))
+            else:
+                ops.goalset_cost(self.robot, self.P, self.scenes, traj_start, self.cv_goals, n_rem, self.cfg.time_interval,
+                                 soften_fingers=False, out=(self.goal_cost, self.goal_col))
+        elif with_layer:
+            self._layer()
+        if defer_update:
+            return prm
         ops.goal_update(prm, self.traj, self.goal_set, self.reach, self.goal_cost, self.learner_state, self.goal_idx,
                         self.end, self.goal_rows, self.goal_point, self.cost_vec)
+        return None
 
     def _layer(self):
         """SDF layer outputs of the current waypoints (first half of Cost.compute_total_loss)."""
         ops.fk_sdf(self.robot, self.P, self.scenes, self.traj, soften_fingers=self.cfg.uncheck_finger_collision == -1,
                    out=(self.pot, self.pgrad, self.col))
 
-    def _step(self, do_update: bool):
+    def _step(self, do_update: bool, learner_prm=None):
+        if learner_prm is not None:  # goal update + step in one launch
+            ops.goal_update_optimize(learner_prm, self.goal_set, self.reach, self.goal_cost, self.learner_state, self.goal_idx,
+                                     self.robot, self._params(do_update), self.traj, self.start, self.end, self.goal_rows,
+                                     self.goal_point, self.pot, self.pgrad, self.col, active=self.active,
+                                     out=(self.grad, self.cost_traj, self.info), cost_vector=self.cost_vec)
+            return self.info
         ops.chomp_optimize(self.robot, self._params(do_update), self.traj, self.start, self.end, self.goal_rows,
                            self.goal_point, self.pot, self.pgrad, self.col, active=self.active,
                            out=(self.grad, self.cost_traj, self.info))
@@ -206,21 +225,33 @@ class ChompEngine:
         select = cfg.goal_set_proj and t < cfg.optim_steps
         if os.environ.get("OMGX_NO_OVERLAP"):  # profiling aid: device-wide PMC counters need kernels one at a time
             overlap = False
-        if select and overlap:
+        mode = os.environ.get("OMGX_ITERATION", "fused")  # fused | streams | serial (A/B measurements)
+        if os.environ.get("OMGX_NO_OVERLAP"):  # profiling aid: device-wide PMC counters need kernels one at a time
+            mode = "serial"
+        if select and mode == "fused" and self.ol_alg != "Baseline":
+            # two launches on one stream: goal-set batch + trajectory layer, then goal update + optimiser step
+            lprm = self.update_goal(defer_update=True, with_layer=True)
+            self._schedule()
+            self._step(True, lprm)
+        elif select and overlap and mode == "streams":
+            # the trajectory layer on a side stream, concurrent with the goal-set batch; joined before the step
             main = torch.cuda.current_stream(self.device)
             self._ev_fork.record(main)
             self.side_stream.wait_event(self._ev_fork)
             with torch.cuda.stream(self.side_stream):
                 self._layer()
                 self._ev_join.record(self.side_stream)
-            self.update_goal()
+            fuse = not os.environ.get("OMGX_NO_FUSED_UPDATE")
+            lprm = self.update_goal(defer_update=fuse)
             self._schedule()
             main.wait_event(self._ev_join)
-            self._step(True)
+            self._step(True, lprm)
         else:
-            if select:
-                self.update_goal()
-            self.optimize(True)
+            self._layer()  # needs only the trajectory: first, so that nothing sits between the goal-set batch and the step
+            fuse = not os.environ.get("OMGX_NO_FUSED_UPDATE")
+            lprm = self.update_goal(defer_update=fuse) if select else None
+            self._schedule()
+            self._step(True, lprm)
         if early_stop and t > 0:  # planner.py:627: terminated scenes stop iterating
             self.active = self.active * (self.info[:, 10] < 0.5).to(torch.int32)
 

@@ -120,6 +120,39 @@ def goalset_cost(robot, P, scenes: DeviceScenes, traj_start, goals, n_remaining,
     return cost, col, pots
 
 
+def goalset_cost_layer(robot, P, scenes: DeviceScenes, traj_start, goals, n_remaining, dt, traj, layer_out, soften_fingers=False,
+                       layer_soften_fingers=False, out=None):
+    """goalset_cost (cost only) + fk_sdf(traj) in one launch (omgx_goalset_cost_layer).  traj [S,n,9] f64;
+    layer_out = (potentials [S,n,10,P], grads [S,n,10,P,3], collides [S,n,10,P]) float32, written in place."""
+    if not (traj_start.is_cuda and traj_start.dtype == torch.float64 and traj_start.dim() == 2 and traj_start.shape[1] == 9
+            and traj_start.stride(1) == 1 and (traj_start.shape[0] == 1 or traj_start.stride(0) >= 9)):
+        raise _lib.OmgHipError("traj_start must be a float64 device tensor [S,9] with unit inner stride")
+    ts_stride = traj_start.stride(0) if traj_start.shape[0] > 1 else 9
+    _need(goals, torch.float64, "goals")
+    _need(traj, torch.float64, "traj")
+    lp, lg, lc = layer_out
+    for n_, t in (("layer potentials", lp), ("layer grads", lg), ("layer collides", lc)):
+        _need(t, torch.float32, n_)
+    S, G, n = goals.shape[0], goals.shape[1], traj.shape[1]
+    if traj.shape[0] != S or lp.numel() != S * n * 10 * P or lg.numel() != 3 * lp.numel() or lc.numel() != lp.numel():
+        raise _lib.OmgHipError("layer outputs must be [S,n,10,P], [S,n,10,P,3], [S,n,10,P]")
+    dev = goals.device
+    if out is None:
+        cost = torch.empty((S, G), dtype=torch.float32, device=dev)
+        col = torch.empty((S, G), dtype=torch.float32, device=dev)
+    else:
+        cost, col = out
+    l = _lib.lib()
+    with torch.cuda.device(dev):
+        ws = _workspace(l.omgx_goalset_workspace_bytes(S, G, n_remaining, P), dev)
+        check(l.omgx_goalset_cost_layer(_ptr(robot), P, _ptr(scenes.objects), _ptr(scenes.scene_begin), _ptr(scenes.pool),
+                                        _ptr(traj_start), ts_stride, _ptr(goals), S, G, n_remaining, float(dt),
+                                        int(bool(soften_fingers)), _ptr(cost), _ptr(col), _ptr(ws), _ptr(traj), n,
+                                        int(bool(layer_soften_fingers)), _ptr(lp), _ptr(lg), _ptr(lc), _stream()),
+              "omgx_goalset_cost_layer")
+    return cost, col
+
+
 def forward_kinematics(robot, P, joints, want_joint_info=True):
     """joints [B,9] f64 -> link poses [B,10,4,4], joint origins [B,10,3] | None, joint axes [B,10,3] | None."""
     _need(joints, torch.float64, "joints")
@@ -177,6 +210,33 @@ def goal_update(params: LearnerParams, traj, goal_set, reach, goal_cost, state, 
         check(_lib.lib().omgx_goal_update(C.byref(params), _ptr(traj), _ptr(goal_set), _ptr(reach), _ptr(goal_cost), _ptr(state),
                                           traj.shape[0], _ptr(goal_idx), _ptr(end), _ptr(goal_rows), _ptr(goal_point),
                                           _ptr(cost_vector), _stream()), "omgx_goal_update")
+
+
+def goal_update_optimize(lparams: LearnerParams, goal_set, reach, goal_cost, state, goal_idx, robot, params: ChompParams, traj,
+                         start, end, goal, goal_point, pot, pgrad, col, active=None, out=None, aux=None, cost_vector=None):
+    """goal_update followed by chomp_optimize in one launch (omgx_goal_update_optimize): same results as the two calls."""
+    for n_, t in (("traj", traj), ("start", start), ("end", end), ("goal", goal), ("goal_point", goal_point),
+                  ("goal_set", goal_set), ("state", state)):
+        _need(t, torch.float64, n_)
+    for n_, t in (("potentials", pot), ("grads", pgrad), ("collides", col)):
+        _need(t, torch.float32, n_)
+    if goal_idx.dtype != torch.int32:
+        raise _lib.OmgHipError("goal_idx must be int32")
+    S, n = traj.shape[0], traj.shape[1]
+    dev = traj.device
+    if out is None:
+        grad = torch.empty((S, n, 9), dtype=torch.float64, device=dev)
+        cost_traj = torch.empty((S, n), dtype=torch.float64, device=dev)
+        info = torch.zeros((S, _lib.INFO_STRIDE), dtype=torch.float64, device=dev)
+    else:
+        grad, cost_traj, info = out
+    with torch.cuda.device(dev):
+        check(_lib.lib().omgx_goal_update_optimize(C.byref(lparams), _ptr(goal_set), _ptr(reach), _ptr(goal_cost), _ptr(state),
+                                                   _ptr(goal_idx), _ptr(cost_vector), _ptr(robot), C.byref(params), _ptr(traj),
+                                                   _ptr(start), _ptr(end), _ptr(goal), _ptr(goal_point), _ptr(pot), _ptr(pgrad),
+                                                   _ptr(col), _ptr(active), S, _ptr(grad), _ptr(cost_traj), _ptr(info), _ptr(aux),
+                                                   _stream()), "omgx_goal_update_optimize")
+    return grad, cost_traj, info
 
 
 def point_cloud_sdf(points: torch.Tensor, grid_resolution: float = 0.02, margin: float = 0.24):

@@ -555,6 +555,46 @@ def test_engine_plan_loop_matches_oracle_loop(dev, alg, standoff):
         np.testing.assert_allclose(eng.info.cpu().numpy()[:, :10], info[:, :10], rtol=1e-5, atol=1e-6, err_msg=f"iteration {t}")
 
 
+@pytest.mark.parametrize("alg,standoff,n", [("MD", False, 30), ("Exp", True, 30), ("FTL", False, 64), ("Proj", False, 12)])
+def test_fused_update_optimize_equals_separate_launches(dev, alg, standoff, n, monkeypatch):
+    """omgx_goalset_cost_layer + omgx_goal_update_optimize == omgx_fk_sdf, omgx_goalset_cost, omgx_goal_update, omgx_chomp_optimize,
+    bit for bit (n = 64: largest LDS layout; later iterations: goal-set window shorter than the trajectory)."""
+    from omg_planner_amd import robot as rb, scenes as sc
+    from omg_planner_amd.config import Config
+    from omg_planner_amd.engine import ChompEngine
+    S, G = 5, 9
+    m = rb.PandaModel(seed=8)
+    scenes, batch = _multi_scene_batch(S)
+    goals = np.stack([sc.make_reach_goals(scenes[s], m, G, s) for s in range(S)])
+    start = np.tile(rb.HOME_CONFIG, (S, 1))
+    cfg0 = Config()
+    cfg0.use_standoff = standoff
+    cfg0.optim_steps = 8
+    cfg0.get_global_param(n)
+    c = cfg0.reach_tail_length if standoff else 1
+    reach = None
+    if standoff:
+        reach = np.stack([[np.concatenate([sc.linear_init(g - np.array([0.1, -0.05, 0.1, 0.15, 0, -0.1, 0.1, 0, 0]), g, c - 1), g[None]], 0)
+                           for g in goals[s]] for s in range(S)])
+    import copy
+    outs = []
+    for fused in (True, False):
+        if fused:  # two launches per iteration: goal-set batch + trajectory layer | goal update + step
+            monkeypatch.delenv("OMGX_NO_FUSED_UPDATE", raising=False)
+            monkeypatch.setenv("OMGX_ITERATION", "fused")
+        else:      # five launches: FK, trajectory layer, goal-set batch, goal update, step
+            monkeypatch.setenv("OMGX_NO_FUSED_UPDATE", "1")
+            monkeypatch.setenv("OMGX_ITERATION", "serial")
+        eng = ChompEngine(m, batch, copy.deepcopy(cfg0), start, goals, reach_grasps=reach, device=dev, ol_alg=alg)
+        for t in range(5):
+            eng.iterate(t)
+        torch.cuda.synchronize()
+        outs.append([x.clone() for x in (eng.traj, eng.info, eng.goal_idx, eng.learner_state, eng.end, eng.goal_rows, eng.cost_vec, eng.grad,
+                                         eng.pot, eng.pgrad, eng.col, eng.goal_cost)])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 # ------------------------------------------------------------------------------------------------
 # (8) BASELINE config 5 shape (kitchen-like: 50 waypoints, 12 obstacle SDFs incl. a point-cloud SDF) and
 #     full-size properties at BASELINE config 4 size (100 scenes x 128 goals x 30 waypoints)
