@@ -1,8 +1,8 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence for bench.py on the GPU box (run through gpurun from the repo root):
 #   gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh r01'
-# PMC passes run with OMGX_NO_OVERLAP=1 (the counters are device-wide: a co-running kernel on the side stream would be
-# charged to the profiled one); the kernel-trace pass keeps the overlap, so side-stream kernels show inflated durations.
+# The default iteration is two launches on one stream, so nothing co-runs with the profiled kernel (the device-wide PMC
+# counters are attributed cleanly).
 # Writes gpurun_out/<tag>_kernel_stats.csv, <tag>_pmc_<COUNTER>.csv and <tag>_traffic.json; copy the
 # ones to be judged into profiles/.  PMC passes are separate runs (no trace domains beside kernel-trace).
 TAG=${1:-r01}
@@ -15,7 +15,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $T/stats -o $TAG -- pyth
 cp $T/stats/*kernel_stats*.csv $O/${TAG}_kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU" "GRBM_GUI_ACTIVE"; do
   n=$(echo $c | cut -d" " -f1)
-  OMGX_NO_OVERLAP=1 rocprofv3 --pmc $c --output-format csv -d $T/pmc_$n -o $TAG -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-plan > $O/${TAG}_pmc_$n.log 2>&1
+  rocprofv3 --pmc $c --output-format csv -d $T/pmc_$n -o $TAG -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-plan > $O/${TAG}_pmc_$n.log 2>&1
   python3 $R/tools/pmc_summary.py $T/pmc_$n $O/${TAG}_pmc_$n.csv
 done
 python3 - $O $TAG <<'PY'
