@@ -319,6 +319,10 @@ int omgx_goal_update(const omgx_learner_params* h_params, const double* traj, co
  * Same arguments, same arithmetic and bit-identical results as the two calls in that order: `end`, `goal` (the
  * learner's goal_rows) and `goal_point` are written by the goal update and consumed by the step inside the kernel.
  * The two parameter blocks must agree on n_waypoints and constraint_num.
+ *   scene_flags  optional [S] int32 device scratch, zeroed once by the caller.  When given, the goal update and the
+ *                goal-independent part of the step (FK, top-k, per-point costs, most gradients) run in different
+ *                workgroups of the launch and meet through scene_flags[s] == ticket; `ticket` must differ from every
+ *                value still stored there (use 1, 2, 3, ... per call).  NULL: one workgroup per scene does both in turn.
  * ------------------------------------------------------------------------------------------- */
 int omgx_goal_update_optimize(const omgx_learner_params* h_learner, const double* goal_set, const double* reach,
                               const float* goal_cost, double* learner_state, int32_t* goal_idx, double* cost_vector,
@@ -326,7 +330,8 @@ int omgx_goal_update_optimize(const omgx_learner_params* h_learner, const double
                               const double* start, double* end, double* goal, double* goal_point,
                               const float* potentials, const float* grads, const float* collides,
                               const int32_t* active, int32_t num_scenes,
-                              double* grad, double* cost_traj, double* info, double* aux, void* stream);
+                              double* grad, double* cost_traj, double* info, double* aux,
+                              int32_t* scene_flags, int32_t ticket, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * (6) omgx_point_cloud_sdf

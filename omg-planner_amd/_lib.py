@@ -82,7 +82,7 @@ def lib() -> C.CDLL:
         l.omgx_goal_update.argtypes = [C.POINTER(LearnerParams)] + [vp] * 5 + [i32] + [vp] * 5 + [vp]
         l.omgx_goal_update.restype = C.c_int
         l.omgx_goal_update_optimize.argtypes = ([C.POINTER(LearnerParams)] + [vp] * 6 + [vp, C.POINTER(ChompParams)] + [vp] * 9 +
-                                                [i32] + [vp] * 4 + [vp])
+                                                [i32] + [vp] * 4 + [vp, i32] + [vp])
         l.omgx_goal_update_optimize.restype = C.c_int
         l.omgx_point_cloud_sdf.argtypes = [vp, i32, C.POINTER(C.c_double), f64, C.POINTER(i32), vp, vp]
         l.omgx_point_cloud_sdf.restype = C.c_int

@@ -46,8 +46,8 @@ using namespace omg;
 // tools/phase_timing.py reads them through omgx_debug_phase_times.  Not part of the ABI, compiled out by default.
 #ifdef OMGX_PHASE_TIMING
 __device__ unsigned long long g_chomp_phase[32];
-#define PHASE_MARK(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_chomp_phase[i] = __builtin_readcyclecounter(); } while (0)
-#define PHASE_MARK_T(i, t) do { if (blockIdx.x == 0 && threadIdx.x == (t)) g_chomp_phase[i] = __builtin_readcyclecounter(); } while (0)
+#define PHASE_MARK(i) do { if (s == 0 && threadIdx.x == 0) g_chomp_phase[i] = __builtin_readcyclecounter(); } while (0)
+#define PHASE_MARK_T(i, t) do { if (s == 0 && threadIdx.x == (t)) g_chomp_phase[i] = __builtin_readcyclecounter(); } while (0)
 #else
 #define PHASE_MARK_T(i, t) do { } while (0)
 #define PHASE_MARK(i) do { } while (0)
@@ -104,6 +104,7 @@ struct Lds {
     uint32_t* tie;   // [(n*10*16+31)/32] tie bit mask
     int* iscr;       // [16] int scalars
     float* potl;     // [n*160] this trajectory's potentials by item (0 in the padding lanes), or null when LDS is short
+    double* fkc;     // [246] kinematic-chain constants of the robot blob (UVW, TP, H, LF, RF)
 };
 
 __device__ __forceinline__ Lds carve(unsigned char* base, int n, int P, bool pot_in_lds) {
@@ -122,6 +123,7 @@ __device__ __forceinline__ Lds carve(unsigned char* base, int n, int P, bool pot
     L.sml = d; d += (n + 1);
     L.pts = d; d += 30 * P;
     L.red = d; d += 64;
+    L.fkc = d; d += 246;
     int* ip = reinterpret_cast<int*>(d);
     L.gwin = ip; ip += n * 10;
     L.hist = reinterpret_cast<uint32_t*>(ip); ip += 256;
@@ -222,7 +224,11 @@ __device__ __forceinline__ void apply_ainv(const double* in, double* out, int n,
 }  // namespace
 
 // Optimizer.optimize for scene s; called by all CH_TPB threads of a workgroup, smem = the dynamic LDS (host_lds_bytes).
-__device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* smem, const int s) {
+// wait_goal != nullptr (k_update_optimize_split): the goal (end, goal rows, goal point) is being written by ANOTHER
+// workgroup; everything that does not need it — FK of start and waypoints, top-k, per-point costs, the winners'
+// gradients of all but the last waypoint — runs first, then thread 0 waits for *wait_goal == ticket.
+__device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* smem, const int s, const uint32_t* wait_goal = nullptr,
+                                            const uint32_t ticket = 0) {
     if (a.active && a.active[s] == 0) return;
     const omgx_chomp_params& prm = a.prm;
     const int n = prm.n_waypoints, P = prm.n_points, c = prm.constraint_num;
@@ -247,6 +253,7 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
     for (int e = tid; e < 60; e += blockDim.x) L.jconst[e] = (e % 6 < 3) ? rv.ax(e / 6)[e % 6] : rv.og(e / 6)[e % 6 - 3];
     for (int e = tid; e < 256; e += blockDim.x) L.hist[e] = 0;
     for (int e = tid; e < (nitems + 31) / 32; e += blockDim.x) L.tie[e] = 0;
+    for (int e = tid; e < 246; e += blockDim.x) L.fkc[e] = rv.uvw(0)[e];  // chain constants: LDS reads instead of scalar loads per joint
     if (tid == 0) { L.iscr[2] = 0; L.red[50] = 0.0; L.red[51] = 0.0; }
     // This thread's potentials / collision flags: all loads are issued back to back (one memory latency instead of
     // one per item) and stay in flight while the FK waves work; first use is after the FK.
@@ -270,23 +277,29 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
     const int ncfg = n + 2;
     double* sc = L.gl;  // [ncfg][7][2]
     auto config_of = [&](int cfg) { return cfg == 0 ? start : (cfg == ncfg - 1 ? end : L.xi + 9 * (cfg - 1)); };
-    for (int t = tid; t < ncfg * 7; t += blockDim.x) {
-        const int cfg = t / 7, i = t - cfg * 7;
-        double sn, cs;
-        fk_joint_sincos(config_of(cfg)[i], sn, cs);
-        sc[2 * t] = sn; sc[2 * t + 1] = cs;
-    }
-    __syncthreads();
-    for (int t = tid; t < ncfg * 3; t += blockDim.x) {
-        const int cfg = t / 3, r = t - cfg * 3;
-        const double* q = config_of(cfg);
-        double* dst0 = L.pose + (size_t)cfg * 120 + 3 * r;
-        fk_chain_row(rv, r, sc + 14 * cfg, q[7], q[8], [&](int l, double r0, double r1, double r2, double tr) {
-            double* dst = dst0 + 12 * l;
-            dst[0] = r0; dst[1] = r1; dst[2] = r2;
-            dst[9 - 2 * r] = tr;  // element 9 + r of the pose
-        });
-    }
+    const RobotView rvl(a.robot, P, L.fkc);
+    auto fk_configs = [&](int c_begin, int c_end, double* tab) {  // tab [c_end - c_begin][7][2]; two barriers inside: call from all threads
+        const int nc = c_end - c_begin;
+        for (int t = tid; t < nc * 7; t += blockDim.x) {
+            const int cfg = c_begin + t / 7, i = t % 7;
+            double sn, cs;
+            fk_joint_sincos(config_of(cfg)[i], sn, cs);
+            tab[2 * t] = sn; tab[2 * t + 1] = cs;
+        }
+        __syncthreads();
+        for (int t = tid; t < nc * 3; t += blockDim.x) {
+            const int cfg = c_begin + t / 3, r = t % 3;
+            const double* q = config_of(cfg);
+            double* dst0 = L.pose + (size_t)cfg * 120 + 3 * r;
+            fk_chain_row(rvl, r, tab + 14 * (cfg - c_begin), q[7], q[8], [&](int l, double r0, double r1, double r2, double tr) {
+                double* dst = dst0 + 12 * l;
+                dst[0] = r0; dst[1] = r1; dst[2] = r2;
+                dst[9 - 2 * r] = tr;  // element 9 + r of the pose
+            });
+        }
+        __syncthreads();
+    };
+    fk_configs(0, wait_goal ? ncfg - 1 : ncfg, sc);  // the end configuration is the goal: later, if it is not known yet
 
     PHASE_MARK_T(17, CH_TPB - 128);
     PHASE_MARK_T(20, 0);
@@ -395,8 +408,8 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
     // ---------------------------------------------------------------- phase 2: per point
     PHASE_MARK(2);
     const int mlinks = topk_mode ? (prm.consider_finger ? 10 : 8) : 10;  // cost.py:401-404
-    for (int it0 = 0; it0 < nitems; it0 += blockDim.x) {
-        const int it = it0 + tid;
+    const int i_defer = wait_goal ? n - 1 : n;  // waypoints >= i_defer need the end pose (acceleration): second pass
+    auto phase2_item = [&](const int it, const bool second_pass) {
         const bool inb = it < nitems;
         const int p = it & 15, grp = it >> 4, l = grp % 10, i = grp / 10;
         const bool valid = inb && p < P;
@@ -405,7 +418,7 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
         if (L.potl) cf = inb ? L.potl[it] : 0.0f;
         else {
             cf = valid ? pot[f] : 0.0f;
-            if (valid) colsum += (double)col[f];
+            if (valid && !second_pass) colsum += (double)col[f];
         }
         double contrib = 0.0;
         if (topk_mode) {
@@ -426,7 +439,7 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
             }
             if (!__any(sel)) {  // nothing selected in this wave's four groups (the common case): empty groups
                 if (inb && p == 0) { L.gwin[grp] = -1; L.gcost[grp] = 0.0; }
-                continue;
+                return;
             }
             double vn = 0.0;
             if (sel) {
@@ -454,7 +467,7 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
         } else {
             // clean branch (cost.py:380-388): every point of every link contributes J.g
             double out[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (valid) {
+            if (valid && (second_pass || i < i_defer)) {
                 double x[3], v[3], acc[3], g[3];
                 point_kinematics(L, i, l, p, P, dt, x, v, acc);
                 const double dc[3] = {(double)pgrad[3 * f], (double)pgrad[3 * f + 1], (double)pgrad[3 * f + 2]};
@@ -471,7 +484,8 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
                 for (int k = 0; k < 8; ++k) L.gl[(size_t)grp * 8 + k] = out[k];
             }
         }
-    }
+    };
+    for (int it0 = 0; it0 < nitems; it0 += blockDim.x) phase2_item(it0 + tid, false);
     {   // collide.sum() over the layer output (cost.py:187): per-thread partials -> wave sums (block sum in phase 5)
         const double wsum = wave_allsum(colsum);
         if ((tid & 63) == 0) L.red[56 + (tid >> 6)] = wsum;
@@ -480,24 +494,54 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
 
     // ---------------------------------------------------------------- phase 3: winners' gradients (top-k branch)
     PHASE_MARK(3);
-    if (topk_mode) {
-        for (int grp = tid; grp < n * 10; grp += blockDim.x) {
-            const int l = grp % 10, i = grp / 10;
-            const int p = L.gwin[grp];
-            double out[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (p >= 0) {
-                const int f = (i * 10 + l) * P + p;
-                double x[3], v[3], acc[3], g[3];
-                point_kinematics(L, i, l, p, P, dt, x, v, acc);
-                const double dc[3] = {(double)pgrad[3 * f], (double)pgrad[3 * f + 1], (double)pgrad[3 * f + 2]};
-                functional_g(v, acc, (double)(L.potl ? L.potl[(grp << 4) + p] : pot[f]), dc, g);
-                const int nk = njoints(l);
-                for (int k = 0; k < nk; ++k) out[k] = jacobian_dot(L, i, l, k, x, g);
-            }
+    auto winner_gradient = [&](const int grp) {
+        const int l = grp % 10, i = grp / 10;
+        const int p = L.gwin[grp];
+        double out[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (p >= 0) {
+            const int f = (i * 10 + l) * P + p;
+            double x[3], v[3], acc[3], g[3];
+            point_kinematics(L, i, l, p, P, dt, x, v, acc);
+            const double dc[3] = {(double)pgrad[3 * f], (double)pgrad[3 * f + 1], (double)pgrad[3 * f + 2]};
+            functional_g(v, acc, (double)(L.potl ? L.potl[(grp << 4) + p] : pot[f]), dc, g);
+            const int nk = njoints(l);
+            for (int k = 0; k < nk; ++k) out[k] = jacobian_dot(L, i, l, k, x, g);
+        }
 #pragma unroll
-            for (int k = 0; k < 8; ++k) L.gl[(size_t)grp * 8 + k] = out[k];
+        for (int k = 0; k < 8; ++k) L.gl[(size_t)grp * 8 + k] = out[k];
+    };
+    if (topk_mode) {
+        for (int grp = tid; grp < i_defer * 10; grp += blockDim.x) winner_gradient(grp);
+        __syncthreads();
+    }
+    if (wait_goal) {
+        // ------------------------------------------------------------ the goal: wait for the learner's workgroup
+        PHASE_MARK_T(23, 0);
+        if (tid == 0) {
+            int spins = 0;
+            while (__hip_atomic_load(wait_goal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ticket) {
+                __builtin_amdgcn_s_sleep(4);
+                if (++spins > (1 << 26)) {  // ~ seconds: the producer is gone; fail loudly instead of hanging the device
+                    a.info[(size_t)s * OMGX_INFO_STRIDE + OMGX_INFO_COST] = __builtin_nan("");
+                    break;
+                }
+            }
+            // one acquire for the workgroup: it invalidates this CU's L1 (shared by all its waves) and the stale L2 lines;
+            // the barrier below orders the other threads' reads of the goal after it
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         __syncthreads();
+        PHASE_MARK_T(24, 0);
+        fk_configs(ncfg - 1, ncfg, L.red + 8);  // the end configuration; red[8..21] is free scratch
+        PHASE_MARK_T(28, 0);
+        if (topk_mode) {
+            for (int grp = i_defer * 10 + tid; grp < n * 10; grp += blockDim.x) winner_gradient(grp);
+        } else {
+            for (int it0 = i_defer * 160; it0 < nitems; it0 += blockDim.x) phase2_item(it0 + tid, true);
+        }
+        PHASE_MARK_T(29, 0);
+        __syncthreads();
+        PHASE_MARK_T(25, 0);
     }
 
     // ---------------------------------------------------------------- phase 4: obstacle gradient [n][9], smoothness
@@ -729,6 +773,33 @@ __global__ __launch_bounds__(CH_TPB) void k_chomp_optimize(ChompArgs a) {
     chomp_scene(a, smem, blockIdx.x);
 }
 
+// The same pair with the goal update in its own workgroup: workgroups [0, S) run the learner of scene b and publish
+// ticket in goal_flags[b]; workgroups [S, 2S) run the optimiser step of scene b - S, whose goal-independent two thirds
+// (FK, top-k, per-point costs, winners' gradients) overlap the learner; they wait for the flag only before the part that
+// uses the goal.  Learner workgroups come first in the grid, so a waiting workgroup's producer has always been
+// dispatched already (no deadlock); the wait is bounded anyway.
+__global__ __launch_bounds__(CH_TPB) void k_update_optimize_split(omg_learner::LearnerArgs la, ChompArgs a, uint32_t* goal_flags,
+                                                                  uint32_t ticket) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int S = la.S;
+    if ((int)blockIdx.x < S) {
+#ifdef OMGX_PHASE_TIMING
+        if (blockIdx.x == 0 && threadIdx.x == 0) g_chomp_phase[26] = __builtin_readcyclecounter();
+#endif
+        double* shl = reinterpret_cast<double*>(smem);
+        omg_learner::learner_scene(la, blockIdx.x, reinterpret_cast<double (*)[OMGX_MAX_GOALS]>(shl),
+                                   reinterpret_cast<double (*)[128]>(shl + 5 * OMGX_MAX_GOALS));
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(goal_flags + blockIdx.x, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef OMGX_PHASE_TIMING
+        if (blockIdx.x == 0 && threadIdx.x == 0) g_chomp_phase[27] = __builtin_readcyclecounter();
+#endif
+        return;
+    }
+    const int s = (int)blockIdx.x - S;
+    chomp_scene(a, smem, s, goal_flags + s, ticket);
+}
+
 // Learner.update_goal followed by Optimizer.optimize for the same scene in one workgroup (planner.py:612-621 calls them
 // back to back): one launch and no stream round trip between the goal choice and the step that uses it.  The
 // learner's LDS (5 x 256 + 5 x 128 doubles) borrows the front of the dynamic region, which chomp_scene initialises
@@ -749,7 +820,7 @@ extern "C" int omgx_debug_chomp_phase_times(unsigned long long* h_out, int n) {
 #endif
 
 static size_t host_lds_bytes(int n, int P) {
-    size_t d = (size_t)(n + 2) * 120 + 60 + (size_t)n * 80 + (size_t)n * 10 + (size_t)n * 9 * 6 + (n + 1) + 30 * P + 64;
+    size_t d = (size_t)(n + 2) * 120 + 60 + (size_t)n * 80 + (size_t)n * 10 + (size_t)n * 9 * 6 + (n + 1) + 30 * P + 64 + 246;
     size_t i = (size_t)n * 10 + 256 + (n * 160 + 31) / 32 + 16;
     return d * 8 + i * 4;
 }
@@ -814,7 +885,7 @@ extern "C" int omgx_goal_update_optimize(const omgx_learner_params* h_learner, c
                                          const double* start, double* end, double* goal, double* goal_point,
                                          const float* potentials, const float* grads, const float* collides,
                                          const int32_t* active, int32_t num_scenes, double* grad, double* cost_traj, double* info,
-                                         double* aux, void* stream) {
+                                         double* aux, int32_t* scene_flags, int32_t ticket, void* stream) {
     if (h_learner && h_params && num_scenes == 0) return OMGX_OK;
     omg_learner::LearnerArgs la;
     int rc = omg_learner::make_args(h_learner, traj, goal_set, reach, goal_cost, learner_state, num_scenes, goal_idx, end, goal,
@@ -831,7 +902,14 @@ extern "C" int omgx_goal_update_optimize(const omgx_learner_params* h_learner, c
     static bool attr_set = false;
     if (!attr_set) {
         if ((rc = allow_big_lds(k_update_optimize, "hipFuncSetAttribute(k_update_optimize)")) != OMGX_OK) return rc;
+        if ((rc = allow_big_lds(k_update_optimize_split, "hipFuncSetAttribute(k_update_optimize_split)")) != OMGX_OK) return rc;
         attr_set = true;
+    }
+    if (scene_flags) {
+        hipLaunchKernelGGL(k_update_optimize_split, dim3(2 * num_scenes), dim3(CH_TPB), lds, (hipStream_t)stream, la, a,
+                           reinterpret_cast<uint32_t*>(scene_flags), (uint32_t)ticket);
+        OMGX_CHECK_LAUNCH("k_update_optimize_split");
+        return OMGX_OK;
     }
     hipLaunchKernelGGL(k_update_optimize, dim3(num_scenes), dim3(CH_TPB), lds, (hipStream_t)stream, la, a);
     OMGX_CHECK_LAUNCH("k_update_optimize");

@@ -313,6 +313,8 @@ struct RobotView {
     const double* __restrict__ d;
     int P;
     __device__ __forceinline__ RobotView(const double* blob, int P_) : raw(blob), d(blob + OMGX_ROBOT_POINTS + 30 * P_), P(P_) {}
+    // the first 246 derived doubles (UVW, TP, H, LF, RF: all the kinematic chain needs) from a copy elsewhere, e.g. LDS
+    __device__ __forceinline__ RobotView(const double* blob, int P_, const double* chain_constants) : raw(blob), d(chain_constants), P(P_) {}
     __device__ __forceinline__ const double* uvw(int i) const { return d + 27 * i; }
     __device__ __forceinline__ const double* tp(int i) const { return d + 189 + 3 * i; }
     __device__ __forceinline__ const double* hand() const { return d + 210; }

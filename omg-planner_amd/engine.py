@@ -91,8 +91,8 @@ class ChompEngine:
         self.grad = torch.empty((S, n, 9), **f64)
         self.cost_traj = torch.empty((S, n), **f64)
         self.info = torch.zeros((S, _lib.INFO_STRIDE), **f64)
-        self.goal_cost = torch.empty((S, G), **f32)
-        self.goal_col = torch.empty((S, G), **f32)
+        self.goal_cost = torch.zeros((S, G), **f32)
+        self.goal_col = torch.zeros((S, G), **f32)
         self.learner_state = ops.learner_state(S, G, dev)  # sum_costs | p | experts_p | q | experts_costs
         self.cost_vec = torch.zeros((S, G), **f64)
         self.eta = float(np.sqrt(np.log(G + 1) / cfg.optim_steps))  # online_learner.py:80
@@ -104,6 +104,8 @@ class ChompEngine:
         self.side_stream = torch.cuda.Stream(device=dev, priority=-1)  # high priority: its few workgroups slot in early
         self._ev_fork = torch.cuda.Event()
         self._ev_join = torch.cuda.Event()
+        self._scene_flags = torch.zeros(S, dtype=torch.int32, device=dev)  # omgx_goal_update_optimize's rendezvous
+        self._ticket = 0
         self._gather_goal()
 
     # ---------------------------------------------------------------------------------------------
@@ -200,10 +202,13 @@ class ChompEngine:
 
     def _step(self, do_update: bool, learner_prm=None):
         if learner_prm is not None:  # goal update + step in one launch
+            split = not os.environ.get("OMGX_NO_SPLIT_UPDATE")  # learner and step in different workgroups of the launch
+            self._ticket += 1
             ops.goal_update_optimize(learner_prm, self.goal_set, self.reach, self.goal_cost, self.learner_state, self.goal_idx,
                                      self.robot, self._params(do_update), self.traj, self.start, self.end, self.goal_rows,
                                      self.goal_point, self.pot, self.pgrad, self.col, active=self.active,
-                                     out=(self.grad, self.cost_traj, self.info), cost_vector=self.cost_vec)
+                                     out=(self.grad, self.cost_traj, self.info), cost_vector=self.cost_vec,
+                                     scene_flags=self._scene_flags if split else None, ticket=self._ticket)
             return self.info
         ops.chomp_optimize(self.robot, self._params(do_update), self.traj, self.start, self.end, self.goal_rows,
                            self.goal_point, self.pot, self.pgrad, self.col, active=self.active,

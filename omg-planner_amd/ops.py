@@ -213,7 +213,8 @@ def goal_update(params: LearnerParams, traj, goal_set, reach, goal_cost, state, 
 
 
 def goal_update_optimize(lparams: LearnerParams, goal_set, reach, goal_cost, state, goal_idx, robot, params: ChompParams, traj,
-                         start, end, goal, goal_point, pot, pgrad, col, active=None, out=None, aux=None, cost_vector=None):
+                         start, end, goal, goal_point, pot, pgrad, col, active=None, out=None, aux=None, cost_vector=None,
+                         scene_flags=None, ticket=0):
     """goal_update followed by chomp_optimize in one launch (omgx_goal_update_optimize): same results as the two calls."""
     for n_, t in (("traj", traj), ("start", start), ("end", end), ("goal", goal), ("goal_point", goal_point),
                   ("goal_set", goal_set), ("state", state)):
@@ -222,6 +223,8 @@ def goal_update_optimize(lparams: LearnerParams, goal_set, reach, goal_cost, sta
         _need(t, torch.float32, n_)
     if goal_idx.dtype != torch.int32:
         raise _lib.OmgHipError("goal_idx must be int32")
+    if scene_flags is not None and (scene_flags.dtype != torch.int32 or scene_flags.numel() < traj.shape[0] or not scene_flags.is_cuda):
+        raise _lib.OmgHipError("scene_flags must be an int32 device tensor [S]")
     S, n = traj.shape[0], traj.shape[1]
     dev = traj.device
     if out is None:
@@ -235,7 +238,7 @@ def goal_update_optimize(lparams: LearnerParams, goal_set, reach, goal_cost, sta
                                                    _ptr(goal_idx), _ptr(cost_vector), _ptr(robot), C.byref(params), _ptr(traj),
                                                    _ptr(start), _ptr(end), _ptr(goal), _ptr(goal_point), _ptr(pot), _ptr(pgrad),
                                                    _ptr(col), _ptr(active), S, _ptr(grad), _ptr(cost_traj), _ptr(info), _ptr(aux),
-                                                   _stream()), "omgx_goal_update_optimize")
+                                                   _ptr(scene_flags), int(ticket), _stream()), "omgx_goal_update_optimize")
     return grad, cost_traj, info
 
 

@@ -578,11 +578,15 @@ def test_fused_update_optimize_equals_separate_launches(dev, alg, standoff, n, m
                            for g in goals[s]] for s in range(S)])
     import copy
     outs = []
-    for fused in (True, False):
-        if fused:  # two launches per iteration: goal-set batch + trajectory layer | goal update + step
-            monkeypatch.delenv("OMGX_NO_FUSED_UPDATE", raising=False)
+    for mode in ("split", "fused", "separate"):
+        monkeypatch.delenv("OMGX_NO_SPLIT_UPDATE", raising=False)
+        monkeypatch.delenv("OMGX_NO_FUSED_UPDATE", raising=False)
+        if mode == "split":    # two launches: goal-set batch + trajectory layer | learner and step in different workgroups
             monkeypatch.setenv("OMGX_ITERATION", "fused")
-        else:      # five launches: FK, trajectory layer, goal-set batch, goal update, step
+        elif mode == "fused":  # two launches, learner then step in one workgroup
+            monkeypatch.setenv("OMGX_ITERATION", "fused")
+            monkeypatch.setenv("OMGX_NO_SPLIT_UPDATE", "1")
+        else:                  # five launches: FK, trajectory layer, goal-set batch, goal update, step
             monkeypatch.setenv("OMGX_NO_FUSED_UPDATE", "1")
             monkeypatch.setenv("OMGX_ITERATION", "serial")
         eng = ChompEngine(m, batch, copy.deepcopy(cfg0), start, goals, reach_grasps=reach, device=dev, ol_alg=alg)
@@ -591,8 +595,9 @@ def test_fused_update_optimize_equals_separate_launches(dev, alg, standoff, n, m
         torch.cuda.synchronize()
         outs.append([x.clone() for x in (eng.traj, eng.info, eng.goal_idx, eng.learner_state, eng.end, eng.goal_rows, eng.cost_vec, eng.grad,
                                          eng.pot, eng.pgrad, eng.col, eng.goal_cost)])
-    for a, b in zip(*outs):
-        assert torch.equal(a, b)
+    for other in outs[:-1]:
+        for a, b in zip(other, outs[-1]):
+            assert torch.equal(a, b)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -22,7 +22,7 @@ for it in range(6):
     eng.t = 0
     eng.iterate(0)
 torch.cuda.synchronize()
-for name, fn in (("k_chomp_optimize", "omgx_debug_chomp_phase_times"), ("k_goal_update", "omgx_debug_learner_phase_times")):
+for name, fn in (("k_chomp_optimize", "omgx_debug_chomp_phase_times"),):
     buf = (C.c_ulonglong * 32)()
     rc = getattr(lib, fn)(buf, 32)
     t = np.array(list(buf), dtype=np.float64)
@@ -30,7 +30,7 @@ for name, fn in (("k_chomp_optimize", "omgx_debug_chomp_phase_times"), ("k_goal_
     if name == "k_chomp_optimize":
         d = np.diff(t[:9])
         print("  phase clocks (phases 0..7):", d.astype(int).tolist(), "total", int(t[8] - t[0]))
-        print("  extra marks relative to start:", {k: int(t[k] - t[0]) for k in range(16, 24) if t[k] > 0})
+        print("  extra marks relative to start:", {k: int(t[k] - t[0]) for k in range(16, 30) if t[k] > 0})
     else:
         d = np.diff(t[:5])
         print("  clocks [cost-vector, projection (wave 0), wait for other experts, mixture]:", d.astype(int).tolist(), "total", int(t[4] - t[0]))
