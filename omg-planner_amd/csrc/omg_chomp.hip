@@ -514,7 +514,48 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
         for (int grp = tid; grp < i_defer * 10; grp += blockDim.x) winner_gradient(grp);
         __syncthreads();
     }
+    const double* w = prm.link_smooth_weight;
+    auto obstacle_rows = [&](const int e_begin, const int e_end) {  // obstacle gradient [n][9] from the groups' J.g
+        for (int e = e_begin + tid; e < e_end; e += blockDim.x) {
+            const int i = e / 9, d = e % 9;
+            double sgrad = 0.0;
+            for (int l = 0; l < mlinks; ++l) {  // ascending link order = the reference's += order
+                int k = -1;
+                if (d < 7) { if (d < njoints(l)) k = d; }
+                else if (l == d + 1) k = 7;  // column 7 <- link 8, column 8 <- link 9
+                if (k >= 0) sgrad += L.gl[((size_t)i * 10 + l) * 8 + k];
+            }
+            L.og[e] = sgrad;
+        }
+    };
+    auto smooth_terms = [&]() {  // needs the end configuration only for a fixed end (not goal-set mode)
+        for (int e = tid; e < n * 9; e += blockDim.x) {
+            const int i = e / 9, d = e % 9;
+            // compute_smooth_loss gradient: A xi + D1^T ed (cost.py:447-448)
+            const double xc = L.xi[e];
+            const double xm = i > 0 ? L.xi[e - 9] : start[d];
+            double sm;
+            if (i < n - 1) sm = (2.0 * xc - xm - L.xi[e + 9]) / dt2;
+            else sm = free_end ? (xc - xm) / dt2 : (2.0 * xc - xm - end[d]) / dt2;
+            L.sg[e] = sm * w[d];
+        }
+        for (int i = tid; i <= n; i += blockDim.x) {  // smoothness loss rows 0..n (cost.py:430-445)
+            double s2 = 0.0;
+            for (int d = 0; d < 9; ++d) {
+                double vel;
+                if (i == 0) vel = L.xi[d] / dt + (-1.0 * start[d] / dt);
+                else if (i < n) vel = (L.xi[i * 9 + d] - L.xi[(i - 1) * 9 + d]) / dt;
+                else vel = free_end ? 0.0 : (-L.xi[(n - 1) * 9 + d] / dt + end[d] / dt);
+                const double ev = vel * w[d];
+                s2 += ev * ev;
+            }
+            const double nrm = sqrt(s2);
+            L.sml[i] = 0.5 * nrm * nrm;
+        }
+    };
     if (wait_goal) {
+        obstacle_rows(0, i_defer * 9);  // everything that does not involve the goal, before waiting for it
+        if (free_end) smooth_terms();
         // ------------------------------------------------------------ the goal: wait for the learner's workgroup
         PHASE_MARK_T(23, 0);
         if (tid == 0) {
@@ -546,37 +587,12 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
 
     // ---------------------------------------------------------------- phase 4: obstacle gradient [n][9], smoothness
     PHASE_MARK(4);
-    const double* w = prm.link_smooth_weight;
-    for (int e = tid; e < n * 9; e += blockDim.x) {
-        const int i = e / 9, d = e % 9;
-        double sgrad = 0.0;
-        for (int l = 0; l < mlinks; ++l) {  // ascending link order = the reference's += order
-            int k = -1;
-            if (d < 7) { if (d < njoints(l)) k = d; }
-            else if (l == d + 1) k = 7;  // column 7 <- link 8, column 8 <- link 9
-            if (k >= 0) sgrad += L.gl[((size_t)i * 10 + l) * 8 + k];
-        }
-        L.og[e] = sgrad;
-        // compute_smooth_loss gradient: A xi + D1^T ed (cost.py:447-448)
-        const double xc = L.xi[e];
-        const double xm = i > 0 ? L.xi[e - 9] : start[d];
-        double sm;
-        if (i < n - 1) sm = (2.0 * xc - xm - L.xi[e + 9]) / dt2;
-        else sm = free_end ? (xc - xm) / dt2 : (2.0 * xc - xm - end[d]) / dt2;
-        L.sg[e] = sm * w[d];
-    }
-    for (int i = tid; i <= n; i += blockDim.x) {  // smoothness loss rows 0..n (cost.py:430-445)
-        double s2 = 0.0;
-        for (int d = 0; d < 9; ++d) {
-            double vel;
-            if (i == 0) vel = L.xi[d] / dt + (-1.0 * start[d] / dt);
-            else if (i < n) vel = (L.xi[i * 9 + d] - L.xi[(i - 1) * 9 + d]) / dt;
-            else vel = free_end ? 0.0 : (-L.xi[(n - 1) * 9 + d] / dt + end[d] / dt);
-            const double ev = vel * w[d];
-            s2 += ev * ev;
-        }
-        const double nrm = sqrt(s2);
-        L.sml[i] = 0.5 * nrm * nrm;
+    if (wait_goal) {  // only what the goal-dependent passes above produced is still missing
+        obstacle_rows(i_defer * 9, n * 9);
+        if (!free_end) smooth_terms();
+    } else {
+        obstacle_rows(0, n * 9);
+        smooth_terms();
     }
     __syncthreads();
     if (a.aux) {  // un-weighted pieces: obs_grad | obs_cost | smooth_grad | smooth_loss

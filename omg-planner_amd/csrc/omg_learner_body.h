@@ -234,43 +234,47 @@ __device__ __forceinline__ void learner_scene(const LearnerArgs& a, int s, doubl
                     epw[j] = g < G ? experts_p[(int64_t)wave * G + g] : 0.0;
                 }
                 bregman_projection(epw, v, delta, G, lane, pn, sh_tab[wave]);
-                for (int j = 0; j < NPL; ++j) { const int g = lane + 64 * j; if (g < G) sh_pn[wave][g] = pn[j]; }
+                // this expert's cost (:229-230) on its own wave: sum_g cv pn + |pn - old p|; the step table is dead by now
+                double part2 = 0.0;
+                for (int j = 0; j < NPL; ++j) {
+                    const int g = lane + 64 * j;
+                    if (g < G) { sh_pn[wave][g] = pn[j]; part2 += cv[j] * pn[j] + fabs(pn[j] - epw[j]); }
+                }
+                const double ecw = wsum(part2);
+                if (lane == 0) sh_tab[wave][0] = ecw;
             }
             __syncthreads();
             if (wave > 0) return;
+            // The mixture update sits INSIDE the expert loop (:231-235): after expert i, q_k *= exp(-cost_k) for ALL k with
+            // the costs as they stand (new for k <= i, last iteration's for k > i), then q is normalised.  All ten
+            // exponentials are known up front: lanes 0..4 evaluate the new ones, lanes 5..9 the old ones.  The mixture
+            // p = sum_k q_k p_k is overwritten in every pass of the reference loop, so only the last one is formed.
             double qv[5], ec[5], ep[5][NPL];
             for (int i = 0; i < 5; ++i) {
-                qv[i] = q[i]; ec[i] = ecost[i];
-                for (int j = 0; j < NPL; ++j) { const int g = lane + 64 * j; ep[i][j] = g < G ? experts_p[(int64_t)i * G + g] : 0.0; }
+                qv[i] = q[i]; ec[i] = sh_tab[i][0];
+                for (int j = 0; j < NPL; ++j) { const int g = lane + 64 * j; ep[i][j] = g < G ? sh_pn[i][g] : 0.0; }
             }
-            double pm[NPL] = {0, 0, 0, 0};
+            double e_new[5], e_old[5];
+            {
+                double mine = 0.0;
+                for (int k = 0; k < 5; ++k) { mine = lane == k ? ec[k] : mine; mine = lane == 5 + k ? ecost[k] : mine; }
+                const double ex = exp(-1.0 * mine);
+                for (int k = 0; k < 5; ++k) { e_new[k] = lane_bcast(ex, k); e_old[k] = lane_bcast(ex, 5 + k); }
+            }
             for (int i = 0; i < 5; ++i) {
-                double pn[NPL];
-                for (int j = 0; j < NPL; ++j) { const int g = lane + 64 * j; pn[j] = g < G ? sh_pn[i][g] : 0.0; }
-                double part2 = 0.0;
-                for (int j = 0; j < NPL; ++j)
-                    if (lane + 64 * j < G) part2 += cv[j] * pn[j] + fabs(pn[j] - ep[i][j]);
-                ec[i] = wsum(part2);
-                for (int j = 0; j < NPL; ++j) ep[i][j] = pn[j];
-                // the mixture update sits INSIDE the expert loop (:231-235)
                 double qs = 0.0;
-                {   // exp(-ec[k]) for the 5 experts: lane k evaluates one, broadcast by readlane
-                    double mine = 0.0;
-                    for (int k = 0; k < 5; ++k) mine = lane == k ? ec[k] : mine;
-                    const double ex = exp(-1.0 * mine);
-                    for (int k = 0; k < 5; ++k) { qv[k] = qv[k] * lane_bcast(ex, k); qs += qv[k]; }
-                }
+                for (int k = 0; k < 5; ++k) { qv[k] = qv[k] * (k <= i ? e_new[k] : e_old[k]); qs += qv[k]; }
                 for (int k = 0; k < 5; ++k) qv[k] /= qs;
-                double ps = 0.0;
-                for (int j = 0; j < NPL; ++j) {
-                    double m = 0.0;
-                    for (int k = 0; k < 5; ++k) m += ep[k][j] * qv[k];
-                    pm[j] = (lane + 64 * j < G) ? m : 0.0;
-                    ps += pm[j];
-                }
-                ps = wsum(ps);
-                for (int j = 0; j < NPL; ++j) pm[j] /= ps;
             }
+            double pm[NPL], ps = 0.0;
+            for (int j = 0; j < NPL; ++j) {
+                double m = 0.0;
+                for (int k = 0; k < 5; ++k) m += ep[k][j] * qv[k];
+                pm[j] = (lane + 64 * j < G) ? m : 0.0;
+                ps += pm[j];
+            }
+            ps = wsum(ps);
+            for (int j = 0; j < NPL; ++j) pm[j] /= ps;
             double best = -1e300;
             int bi = 0x7fffffff;
             for (int j = 0; j < NPL; ++j) {
