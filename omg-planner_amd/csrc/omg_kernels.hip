@@ -472,10 +472,12 @@ __global__ __launch_bounds__(256, 6) void k_goalset_compact(ChunkArgs a) {
     extern __shared__ __attribute__((aligned(16))) double lds_pose[];
     __shared__ float red[2][4];
     const int xcd = blockIdx.x & 7;
-    const int j = blockIdx.x >> 3;
-    const int nchx = a.NCH + (a.wp_traj ? 1 : 0);  // with a trajectory layer, workgroup 0 of every scene computes it
-    const int sgrp = j / nchx;
-    const int s = sgrp * 8 + xcd, cx = j - sgrp * nchx;
+    // with a trajectory layer, the first workgroup of every scene computes it; those (longer) workgroups lead the grid
+    const int nlayer = a.wp_traj ? ((a.S + 7) >> 3) : 0;  // in units of 8 workgroups (one per XCD)
+    const bool is_layer = (int)(blockIdx.x >> 3) < nlayer;
+    const int j = (int)(blockIdx.x >> 3) - nlayer;
+    const int sgrp = is_layer ? (int)(blockIdx.x >> 3) : j / a.NCH;
+    const int s = sgrp * 8 + xcd, chunk = is_layer ? 0 : j - sgrp * a.NCH;
     if (s >= a.S) return;
     const int o_begin = as_const(a.scene_begin)[s], o_end = as_const(a.scene_begin)[s + 1];
     const int P = a.P, CH = a.CH;
@@ -485,11 +487,10 @@ __global__ __launch_bounds__(256, 6) void k_goalset_compact(ChunkArgs a) {
     const int pstride = a.PS, MR = a.MR;
     uint32_t* rowmask = reinterpret_cast<uint32_t*>(lds_pose + (size_t)pstride * 90);  // poses: 9 doubles (see pose9_apply)
     float* scratch = reinterpret_cast<float*>(rowmask + ((10 * MR + 3) & ~3)) + wave * 192;  // wave-private [64][3]: 12 B entries keep 6 workgroups per CU inside 160 KB
-    if (a.wp_traj && cx == 0) {
+    if (is_layer) {
         waypoint_layer_block(a, s, lds_pose, rowmask, o_begin, o_end, rv);
         return;
     }
-    const int chunk = a.wp_traj ? cx - 1 : cx;
 
     {   // FK of start + CH interpolated configurations in two stages (omg_device.h: fk_chain_row); the (sin, cos)
         // table borrows the row-mask / scratch region, which is first written after the barriers below.
