@@ -600,6 +600,41 @@ def test_fused_update_optimize_equals_separate_launches(dev, alg, standoff, n, m
             assert torch.equal(a, b)
 
 
+def test_split_update_with_more_scenes_than_compute_units(dev, monkeypatch):
+    """600 workgroups of k_update_optimize_split cannot be resident at once on 256 CUs: the learner workgroups lead the
+    grid, so a waiting optimiser workgroup always finds its producer dispatched.  Same results as the one-workgroup kernel."""
+    from omg_planner_amd import robot as rb, scenes as sc
+    from omg_planner_amd.config import Config
+    from omg_planner_amd.engine import ChompEngine
+    import copy
+    S, G, n = 300, 4, 12
+    m = rb.PandaModel(seed=9)
+    scenes = [sc.make_tabletop_scene(s % 6, grid=24, table_grid=(32, 24, 8)) for s in range(S)]
+    batch = sc.pack_table(scenes)
+    rng = np.random.RandomState(5)
+    goals = np.stack([sc.make_goal_set(s, G) for s in range(S)])
+    start = np.tile(rb.HOME_CONFIG, (S, 1)) + rng.normal(0, 0.02, (S, 9)) * np.array([1] * 7 + [0, 0])
+    cfg0 = Config()
+    cfg0.use_standoff = False
+    cfg0.optim_steps = 6
+    cfg0.get_global_param(n)
+    outs = []
+    for split in (True, False):
+        monkeypatch.setenv("OMGX_ITERATION", "fused")
+        if split:
+            monkeypatch.delenv("OMGX_NO_SPLIT_UPDATE", raising=False)
+        else:
+            monkeypatch.setenv("OMGX_NO_SPLIT_UPDATE", "1")
+        eng = ChompEngine(m, batch, copy.deepcopy(cfg0), start, goals, device=dev, ol_alg="MD")
+        for t in range(3):
+            eng.iterate(t)
+        torch.cuda.synchronize()
+        outs.append([x.clone() for x in (eng.traj, eng.info, eng.goal_idx, eng.learner_state)])
+    assert not torch.isnan(outs[0][1]).any()
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 # ------------------------------------------------------------------------------------------------
 # (8) BASELINE config 5 shape (kitchen-like: 50 waypoints, 12 obstacle SDFs incl. a point-cloud SDF) and
 #     full-size properties at BASELINE config 4 size (100 scenes x 128 goals x 30 waypoints)

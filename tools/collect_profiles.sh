@@ -11,7 +11,7 @@ O=$R/gpurun_out
 T=/tmp/prof_$TAG
 mkdir -p $O $T
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $T/stats -o $TAG -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-plan > $O/${TAG}_bench_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $T/stats -o $TAG -- python3 $R/bench.py --no-cpu-baseline --no-plan > $O/${TAG}_bench_under_rocprof.log 2>&1
 cp $T/stats/*kernel_stats*.csv $O/${TAG}_kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU" "GRBM_GUI_ACTIVE"; do
   n=$(echo $c | cut -d" " -f1)
