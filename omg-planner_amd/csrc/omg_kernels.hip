@@ -388,8 +388,9 @@ __global__ __launch_bounds__(TPB) void k_sdf_chunks(ChunkArgs a) {
 // gradients, collisions of wp_n x 10 x P points) as ONE extra workgroup of the goal-set launch.  The optimiser step
 // that follows on the same stream then depends on a single kernel: no side stream, no events.  Arithmetic is that of
 // k_sdf_chunks<true> (same sdf_pair calls on the same float32 points), FK as in the goal-set workgroups.
-__device__ __forceinline__ void waypoint_layer_block(const ChunkArgs& a, const int s, double* lds_pose, uint32_t* rowmask,
-                                                     const int o_begin, const int o_end, const RobotView& rv) {
+__device__ __forceinline__ void waypoint_layer_block(const ChunkArgs& a, const int s, const int l_begin, const int l_end,
+                                                     double* lds_pose, uint32_t* rowmask, const int o_begin, const int o_end,
+                                                     const RobotView& rv) {
     const int n = a.wp_n, P = a.P, PS = a.PS, MR = a.MR;
     const double* tr = a.wp_traj + (int64_t)s * n * 9;
     double* sc = reinterpret_cast<double*>(rowmask);  // [n][7][2], dead before the masks are written
@@ -409,7 +410,7 @@ __device__ __forceinline__ void waypoint_layer_block(const ChunkArgs& a, const i
         });
     }
     __syncthreads();
-    for (int row = threadIdx.x; row < 10 * n; row += 256) {  // row-level culling
+    for (int row = l_begin * n + threadIdx.x; row < l_end * n; row += 256) {  // row-level culling of this workgroup's links
         const int l = row / n, ci = row - l * n;
         const double* A = lds_pose + ((int64_t)l * PS + ci) * 9;
         const float cx = (float)A[6], cy = (float)A[7], cz = (float)A[8];
@@ -437,7 +438,7 @@ __device__ __forceinline__ void waypoint_layer_block(const ChunkArgs& a, const i
         const bool valid = (p < P) && (ci < n);
         const int cic = valid ? ci : 0, pc = valid ? p : 0;
 #pragma unroll 1
-        for (int l = 0; l < 10; ++l) {
+        for (int l = l_begin; l < l_end; ++l) {
             const uint32_t msk = valid ? rowmask[l * MR + cic] : 0u;
             Accum acc{0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
             if (__any(msk != 0)) {
@@ -467,16 +468,19 @@ __device__ __forceinline__ void waypoint_layer_block(const ChunkArgs& a, const i
     }
 }
 
+#define GS_LAYER_PARTS 5  // trajectory-layer workgroups per scene
 template <int LB>
 __global__ __launch_bounds__(256, 6) void k_goalset_compact(ChunkArgs a) {
     extern __shared__ __attribute__((aligned(16))) double lds_pose[];
     __shared__ float red[2][4];
     const int xcd = blockIdx.x & 7;
     // with a trajectory layer, the first workgroup of every scene computes it; those (longer) workgroups lead the grid
-    const int nlayer = a.wp_traj ? ((a.S + 7) >> 3) : 0;  // in units of 8 workgroups (one per XCD)
+    // (GS_LAYER_PARTS workgroups per scene, 10 / GS_LAYER_PARTS links each: a lone scene is not held up by one long workgroup)
+    const int nlayer = a.wp_traj ? ((a.S + 7) >> 3) * GS_LAYER_PARTS : 0;  // in units of 8 workgroups (one per XCD)
     const bool is_layer = (int)(blockIdx.x >> 3) < nlayer;
     const int j = (int)(blockIdx.x >> 3) - nlayer;
-    const int sgrp = is_layer ? (int)(blockIdx.x >> 3) : j / a.NCH;
+    const int sgrp = is_layer ? (int)(blockIdx.x >> 3) / GS_LAYER_PARTS : j / a.NCH;
+    const int layer_part = (int)(blockIdx.x >> 3) - sgrp * GS_LAYER_PARTS;
     const int s = sgrp * 8 + xcd, chunk = is_layer ? 0 : j - sgrp * a.NCH;
     if (s >= a.S) return;
     const int o_begin = as_const(a.scene_begin)[s], o_end = as_const(a.scene_begin)[s + 1];
@@ -488,7 +492,8 @@ __global__ __launch_bounds__(256, 6) void k_goalset_compact(ChunkArgs a) {
     uint32_t* rowmask = reinterpret_cast<uint32_t*>(lds_pose + (size_t)pstride * 90);  // poses: 9 doubles (see pose9_apply)
     float* scratch = reinterpret_cast<float*>(rowmask + ((10 * MR + 3) & ~3)) + wave * 192;  // wave-private [64][3]: 12 B entries keep 6 workgroups per CU inside 160 KB
     if (is_layer) {
-        waypoint_layer_block(a, s, lds_pose, rowmask, o_begin, o_end, rv);
+        waypoint_layer_block(a, s, layer_part * (10 / GS_LAYER_PARTS), (layer_part + 1) * (10 / GS_LAYER_PARTS), lds_pose, rowmask, o_begin,
+                             o_end, rv);
         return;
     }
 
@@ -797,7 +802,7 @@ static int launch_chunks(ChunkArgs& ca, hipStream_t st) {
     const bool layer = ca.wp_traj != nullptr;  // only with k_goalset_compact (checked by the caller)
     ca.PS = ca.CH + 1; ca.MR = ca.CH;
     if (layer) { if (ca.wp_n > ca.PS) ca.PS = ca.wp_n; if (ca.wp_n > ca.MR) ca.MR = ca.wp_n; }
-    const int64_t grid = (int64_t)scene_groups * (ca.NCH + (layer ? 1 : 0)) * 8 * (10 / lpw);
+    const int64_t grid = (int64_t)scene_groups * (ca.NCH + (layer ? GS_LAYER_PARTS : 0)) * 8 * (10 / lpw);
     if (grid > 0x7fffffff) return OMGX_ERR_UNSUPPORTED;
     // Timed launches attach the start/stop events to the dispatch itself (hipExtLaunchKernelGGL): the events then
     // bracket exactly this kernel and cost no extra packets on the stream.

@@ -1,5 +1,5 @@
 import sys, time
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import numpy as np, torch, bench, copy
 from omg_planner_amd.engine import ChompEngine
 cfg, model, batch, start, goals = bench.build_workload(1, 64, 30, 64, 0, False)
