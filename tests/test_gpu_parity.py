@@ -600,6 +600,37 @@ def test_fused_update_optimize_equals_separate_launches(dev, alg, standoff, n, m
             assert torch.equal(a, b)
 
 
+def test_two_launch_entry_points_reject_bad_arguments(dev):
+    """omgx_goalset_cost_layer / omgx_goal_update_optimize: error codes, never a crash; odd sizes (1 scene, 1 goal, window
+    shorter than the trajectory) agree with the separate entry points."""
+    from omg_planner_amd import _lib, ops, robot as rb, scenes as sc
+    import ctypes as C
+    l = _lib.lib()
+    rc = l.omgx_goalset_cost_layer(None, 15, None, None, None, None, 9, None, 1, 1, 5, 0.1, 0, None, None, None, None, 5, 0, None, None, None, None)
+    assert rc == _lib.OMGX_ERR_INVALID
+    lp, cp = _lib.LearnerParams(), _lib.ChompParams()
+    rc = l.omgx_goal_update_optimize(C.byref(lp), *([None] * 6), None, C.byref(cp), *([None] * 9), 3, *([None] * 4), None, 0, None)
+    assert rc == _lib.OMGX_ERR_INVALID
+    # one scene, one goal, 7-waypoint window on a 12-waypoint trajectory
+    m = rb.PandaModel(seed=2)
+    P = m.points_per_link
+    scenes, batch = _multi_scene_batch(1)
+    n, G = 12, 1
+    goals = np.stack([sc.make_reach_goals(scenes[0], m, G, 0)])
+    traj = np.stack([sc.cubic_init(rb.HOME_CONFIG, goals[0, 0], n)])
+    robot, ds = ops.robot_blob(m, dev), ops.DeviceScenes(batch, dev)
+    tt, gg = _t(traj, dev), _t(goals, dev)
+    lay = (torch.empty((1, n, 10, P), dtype=torch.float32, device=dev), torch.empty((1, n, 10, P, 3), dtype=torch.float32, device=dev),
+           torch.empty((1, n, 10, P), dtype=torch.float32, device=dev))
+    c1, k1 = ops.goalset_cost_layer(robot, P, ds, tt[:, 5], gg, n - 5, 0.1, tt, lay)
+    c2, k2, _ = ops.goalset_cost(robot, P, ds, tt[:, 5], gg, n - 5, 0.1)
+    p2, g2, o2 = ops.fk_sdf(robot, P, ds, tt)
+    assert torch.equal(c1, c2) and torch.equal(k1, k2)
+    assert torch.equal(lay[0], p2.view_as(lay[0])) and torch.equal(lay[1], g2.view_as(lay[1])) and torch.equal(lay[2], o2.view_as(lay[2]))
+    with pytest.raises(_lib.OmgHipError):  # layer outputs of the wrong size
+        ops.goalset_cost_layer(robot, P, ds, tt[:, 5], gg, n - 5, 0.1, tt, (lay[0][:, :3], lay[1], lay[2]))
+
+
 def test_split_update_with_more_scenes_than_compute_units(dev, monkeypatch):
     """600 workgroups of k_update_optimize_split cannot be resident at once on 256 CUs: the learner workgroups lead the
     grid, so a waiting optimiser workgroup always finds its producer dispatched.  Same results as the one-workgroup kernel."""
