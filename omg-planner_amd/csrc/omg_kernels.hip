@@ -861,6 +861,32 @@ extern "C" int omgx_fk_sdf(const double* robot, int32_t n_points, const omgx_obj
         if (arc_length > OMGX_MAX_WAYPOINTS || configs_per_scene % arc_length != 0) return OMGX_ERR_UNSUPPORTED;
     }
     hipStream_t st = (hipStream_t)stream;
+    const char* fast_env = getenv("OMGX_LAYER_FAST");  // =0 keeps the two-launch path (A/B measurements, cross-check in the tests)
+    const int fast = fast_env ? atoi(fast_env) : 1;
+    if (fast && !arc && potentials && grads && collides && configs_per_scene <= OMGX_MAX_WAYPOINTS) {
+        // A trajectory-sized layer (the optimiser's input): the goal-set kernel's layer workgroups alone — FK in LDS,
+        // GS_LAYER_PARTS workgroups per scene, one launch instead of k_fk_poses + k_sdf_chunks.  Same arithmetic.
+        ChunkArgs ca{};
+        ca.robot = robot; ca.objects = objects; ca.scene_begin = scene_begin; ca.pool = sdf_pool;
+        ca.S = num_scenes; ca.P = n_points; ca.NCH = 0; ca.CH = 0; ca.C = 0;
+        ca.wp_traj = joints; ca.wp_n = configs_per_scene; ca.wp_soften = soften_fingers != 0;
+        ca.wp_pot = potentials; ca.wp_grad = grads; ca.wp_col = collides;
+        ca.PS = configs_per_scene; ca.MR = configs_per_scene; ca.LPW = 10;
+        const int64_t grid = (int64_t)((num_scenes + 7) / 8) * GS_LAYER_PARTS * 8;
+        size_t tail = (((size_t)10 * ca.MR + 3) & ~(size_t)3) * sizeof(uint32_t) + 4 * 64 * 3 * sizeof(float);
+        const size_t sincos = (size_t)ca.PS * 14 * sizeof(double);
+        if (tail < sincos) tail = sincos;
+        const size_t lds = (size_t)ca.PS * 90 * sizeof(double) + tail;
+        const int slot = timing_slot();
+        if (slot >= 0) {
+            g_ev_kind[slot] = 1; ++g_timing_n;
+            hipExtLaunchKernelGGL((k_goalset_compact<2>), dim3((unsigned)grid), dim3(256), (uint32_t)lds, st, g_ev[slot][0], g_ev[slot][1], 0, ca);
+        } else {
+            hipLaunchKernelGGL((k_goalset_compact<2>), dim3((unsigned)grid), dim3(256), lds, st, ca);
+        }
+        OMGX_CHECK_LAUNCH("k_goalset_compact (layer only)");
+        return OMGX_OK;
+    }
     const int CH = arc ? arc_length : chunk_configs_fk_sdf(configs_per_scene);
     const int NCH = (configs_per_scene + CH - 1) / CH;
     double* ws = (double*)workspace;

@@ -600,7 +600,7 @@ def test_fused_update_optimize_equals_separate_launches(dev, alg, standoff, n, m
             assert torch.equal(a, b)
 
 
-def test_two_launch_entry_points_reject_bad_arguments(dev):
+def test_two_launch_entry_points_reject_bad_arguments(dev, monkeypatch):
     """omgx_goalset_cost_layer / omgx_goal_update_optimize: error codes, never a crash; odd sizes (1 scene, 1 goal, window
     shorter than the trajectory) agree with the separate entry points."""
     from omg_planner_amd import _lib, ops, robot as rb, scenes as sc
@@ -624,7 +624,11 @@ def test_two_launch_entry_points_reject_bad_arguments(dev):
            torch.empty((1, n, 10, P), dtype=torch.float32, device=dev))
     c1, k1 = ops.goalset_cost_layer(robot, P, ds, tt[:, 5], gg, n - 5, 0.1, tt, lay)
     c2, k2, _ = ops.goalset_cost(robot, P, ds, tt[:, 5], gg, n - 5, 0.1)
+    monkeypatch.setenv("OMGX_LAYER_FAST", "0")  # the two-launch path of omgx_fk_sdf: k_fk_poses + k_sdf_chunks<true>
     p2, g2, o2 = ops.fk_sdf(robot, P, ds, tt)
+    monkeypatch.delenv("OMGX_LAYER_FAST")
+    p3, g3, o3 = ops.fk_sdf(robot, P, ds, tt)   # the single-launch path (layer workgroups of k_goalset_compact)
+    assert torch.equal(p2, p3) and torch.equal(g2, g3) and torch.equal(o2, o3)
     assert torch.equal(c1, c2) and torch.equal(k1, k2)
     assert torch.equal(lay[0], p2.view_as(lay[0])) and torch.equal(lay[1], g2.view_as(lay[1])) and torch.equal(lay[2], o2.view_as(lay[2]))
     with pytest.raises(_lib.OmgHipError):  # layer outputs of the wrong size
