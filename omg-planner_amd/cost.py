@@ -96,6 +96,16 @@ class Cost(object):
         poses, eps, pad, clr, dis = self._layer_params()
         limits = _np(self.env.sdf_limits).astype(np.float32)
         table = sc.table_from_padded(poses, limits, eps, pad, clr, dis)
+        # shrink the far boxes to the voxels that can contribute (same results, fewer exact lookups); the ranges are
+        # cached per (volume, epsilon, clearance) on a host copy of the volumes taken once per env.sdf_torch
+        # (same tensor OBJECT and same in-place version counter: a rebuilt env.sdf_torch may reuse the old address)
+        t = self.env.sdf_torch
+        ref = getattr(self, "_pool_ref", None)
+        if ref is None or ref() is not t or self._pool_version != t._version:
+            import weakref
+            self._pool_ref, self._pool_version = weakref.ref(t), t._version
+            self._pool_host, self._infl_cache = t.detach().reshape(-1).cpu().numpy(), {}
+        sc.tighten_far_boxes(table, self._pool_host, self._infl_cache)
         ds = ops.DeviceScenes.__new__(ops.DeviceScenes)
         ds.device = self.device
         ds.num_scenes = 1

@@ -94,12 +94,13 @@ def influence_range(grid: np.ndarray, epsilon: float, clearance: float):
     return np.array(lo), np.array(hi)
 
 
-def tighten_far_boxes(rec: np.ndarray, pool: np.ndarray) -> np.ndarray:
+def tighten_far_boxes(rec: np.ndarray, pool: np.ndarray, cache: dict | None = None) -> np.ndarray:
     """Shrink the far box of every record from the whole grid to the voxels that can matter (influence_range):
     far_lo = (bmin - 1.5) voxels, far_hi = (bmax + 3.5) voxels — the same 1 / 2 voxels of slack around the
     exact thresholds g >= bmin - 0.5 and g < bmax + 1.5 as the default box of finish_records (bmin = 0, bmax = dim - 2).
-    Only meaningful where the kernels use the box at all (epsilon < 1 and clearance <= 1)."""
-    cache = {}
+    Only meaningful where the kernels use the box at all (epsilon < 1 and clearance <= 1).
+    `cache` (optional dict) keeps the ranges between calls on the same pool (key: grid offset, dims, epsilon, clearance)."""
+    cache = {} if cache is None else cache
     for r in rec:
         d = r["dim"].astype(np.int64)
         w = (r["hi"].astype(np.float32) - r["lo"].astype(np.float32)).astype(np.float32)
