@@ -469,8 +469,11 @@ __device__ __forceinline__ void waypoint_layer_block(const ChunkArgs& a, const i
 }
 
 #define GS_LAYER_PARTS 5  // trajectory-layer workgroups per scene
+#ifndef GS_WG_PER_CU
+#define GS_WG_PER_CU 6  // 80 VGPRs; the LDS of a 30-waypoint goal (26.6 KB) allows no more
+#endif
 template <int LB>
-__global__ __launch_bounds__(256, 6) void k_goalset_compact(ChunkArgs a) {
+__global__ __launch_bounds__(256, GS_WG_PER_CU) void k_goalset_compact(ChunkArgs a) {
     extern __shared__ __attribute__((aligned(16))) double lds_pose[];
     __shared__ float red[2][4];
     const int xcd = blockIdx.x & 7;
