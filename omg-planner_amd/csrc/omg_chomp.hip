@@ -760,17 +760,17 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
         apply_ainv(L.tv, L.tvs, n, free_end, dt2);
         __syncthreads();
         if (tid < 64) {  // np.abs(traj_v).argmax(): first maximum in flat order
-            double best = -1.0;
+            double best = -__builtin_inf();  // numpy order: first occurrence, NaN wins (omg::np_arg_better)
             int bi = 0x7fffffff;
             for (int e = tid; e < n * 9; e += 64) {
                 const double v = fabs(L.tv[e]);
-                if (v > best) { best = v; bi = e; }
+                if (np_arg_better<false>(v, e, best, bi)) { best = v; bi = e; }
             }
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {
                 const double ov = __shfl_xor(best, off, 64);
                 const int oi = __shfl_xor(bi, off, 64);
-                if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+                if (np_arg_better<false>(ov, oi, best, bi)) { best = ov; bi = oi; }
             }
             if (tid == 0) L.red[6] = best / (fabs(L.tvs[bi]) + 1e-8);  // safe_div
         }

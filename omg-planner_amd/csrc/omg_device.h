@@ -462,6 +462,16 @@ __device__ __forceinline__ void pose9_apply(const double* __restrict__ A, const 
     z = (float)(r20 * p[0] + r21 * p[1] + r22 * p[2] + A[8]);
 }
 
+// np.argmin / np.argmax order: does (v, i) beat (bv, bi)?  The first occurrence wins, and a NaN counts as the extreme
+// for BOTH (numpy propagates NaN: np.argmax([1, nan, 3]) == np.argmin([1, nan, 0]) == 1) — a degenerate cost vector
+// (0/0 after normalisation) therefore selects index 0 like the reference instead of leaving the index undefined.
+template <bool MIN>
+__device__ __forceinline__ bool np_arg_better(double v, int i, double bv, int bi) {
+    const bool vn = v != v, bn = bv != bv;
+    if (vn | bn) return vn && (!bn || i < bi);
+    return (MIN ? v < bv : v > bv) || (v == bv && i < bi);
+}
+
 // -------------------------------------------------------------------------------------------------
 // wave / block reductions with a fixed combination order (deterministic results)
 // -------------------------------------------------------------------------------------------------

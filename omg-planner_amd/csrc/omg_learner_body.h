@@ -49,18 +49,20 @@ __device__ __forceinline__ double lane_bcast(double v, int k) {
 }
 __device__ __forceinline__ double wsum(double v) { return omg::wave_allsum(v); }  // identical result in every lane
 __device__ __forceinline__ double wmax(double v) { return omg::wave_allmax(v); }
-// arg-extreme with the lowest index on ties (np.argmin / np.argmax return the first occurrence)
+// arg-extreme in numpy's order (first occurrence, NaN wins; omg::np_arg_better).  Lanes start from the neutral element
+// (+-inf, INT_MAX), which loses every tie against a real entry.
 template <bool MIN>
 __device__ __forceinline__ int warg(double v, int i) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         const double ov = __shfl_xor(v, off, 64);
         const int oi = __shfl_xor(i, off, 64);
-        const bool better = MIN ? (ov < v) : (ov > v);
-        if (better || (ov == v && oi < i)) { v = ov; i = oi; }
+        if (omg::np_arg_better<MIN>(ov, oi, v, i)) { v = ov; i = oi; }
     }
     return i;
 }
+#define OMG_ARG_NEUTRAL_MIN __builtin_inf()
+#define OMG_ARG_NEUTRAL_MAX (-__builtin_inf())
 
 // bp (online_learner.py:32-58) with find_zero (:16-29) inlined.  x, v per-lane slices; w = 1, delta = 1/(4G+1).
 //
@@ -149,7 +151,7 @@ __device__ __forceinline__ void learner_scene(const LearnerArgs& a, int s, doubl
     int idx = 0;
     if (prm.alg == OMGX_ALG_PROJ) {  // :196-206
         const double* last = a.traj + ((int64_t)s * n + n - 1) * 9;
-        double best = 1e300;
+        double best = OMG_ARG_NEUTRAL_MIN;
         int bi = 0x7fffffff;
         for (int j = 0; j < NPL; ++j) {
             const int g = lane + 64 * j;
@@ -157,7 +159,7 @@ __device__ __forceinline__ void learner_scene(const LearnerArgs& a, int s, doubl
                 double d2 = 0.0;
                 for (int d = 0; d < 9; ++d) { const double e = last[d] - gs[g * 9 + d]; d2 += e * e; }
                 const double dist = sqrt(d2);
-                if (dist < best) { best = dist; bi = g; }
+                if (omg::np_arg_better<true>(dist, g, best, bi)) { best = dist; bi = g; }
             }
         }
         idx = warg<true>(best, bi);
@@ -189,14 +191,14 @@ __device__ __forceinline__ void learner_scene(const LearnerArgs& a, int s, doubl
             for (int j = 0; j < NPL; ++j) { const int g = lane + 64 * j; if (g < G) a.cost_vector[(int64_t)s * G + g] = cv[j]; }
 
         if (prm.alg == OMGX_ALG_FTL || prm.alg == OMGX_ALG_FTC) {  // :175-189
-            double best = 1e300;
+            double best = OMG_ARG_NEUTRAL_MIN;
             int bi = 0x7fffffff;
             for (int j = 0; j < NPL; ++j) {
                 const int g = lane + 64 * j;
                 if (g < G) {
                     double key = cv[j];
                     if (prm.alg == OMGX_ALG_FTL) { key = sum_costs[g] + cv[j]; sum_costs[g] = key; }
-                    if (key < best) { best = key; bi = g; }
+                    if (omg::np_arg_better<true>(key, g, best, bi)) { best = key; bi = g; }
                 }
             }
             idx = warg<true>(best, bi);
@@ -216,11 +218,11 @@ __device__ __forceinline__ void learner_scene(const LearnerArgs& a, int s, doubl
                 if (g < G) { pn[j] = exp(-prm.eta * cv[j]) * p[g] * 0.999 + (sc[j] / (tot + 1e-8)) * 0.001; ps += pn[j]; }
             }
             ps = wsum(ps);
-            double best = -1e300;
+            double best = OMG_ARG_NEUTRAL_MAX;
             int bi = 0x7fffffff;
             for (int j = 0; j < NPL; ++j) {
                 const int g = lane + 64 * j;
-                if (g < G) { const double v = pn[j] / (ps + 1e-8); p[g] = v; if (v > best) { best = v; bi = g; } }
+                if (g < G) { const double v = pn[j] / (ps + 1e-8); p[g] = v; if (omg::np_arg_better<false>(v, g, best, bi)) { best = v; bi = g; } }
             }
             idx = warg<false>(best, bi);
         } else {  // MD, :219-235
@@ -275,14 +277,14 @@ __device__ __forceinline__ void learner_scene(const LearnerArgs& a, int s, doubl
             }
             ps = wsum(ps);
             for (int j = 0; j < NPL; ++j) pm[j] /= ps;
-            double best = -1e300;
+            double best = OMG_ARG_NEUTRAL_MAX;
             int bi = 0x7fffffff;
             for (int j = 0; j < NPL; ++j) {
                 const int g = lane + 64 * j;
                 if (g < G) {
                     p[g] = pm[j];
                     for (int i = 0; i < 5; ++i) experts_p[(int64_t)i * G + g] = ep[i][j];
-                    if (pm[j] > best) { best = pm[j]; bi = g; }
+                    if (omg::np_arg_better<false>(pm[j], g, best, bi)) { best = pm[j]; bi = g; }
                 }
             }
             if (lane == 0)

@@ -675,8 +675,11 @@ int orc_chomp_optimize_one(const double* robot, const omgx_chomp_params* prm, do
                     for (int k = 0; k < n; ++k) s += Ainv[i * n + k] * tv[k * ND + d];
                     tvs[i * ND + d] = s;
                 }
-            int am = 0; /* np.abs(traj_v).argmax(): first maximum in flat order */
-            for (int i = 1; i < n * ND; ++i) if (fabs(tv[i]) > fabs(tv[am])) am = i;
+            int am = 0; /* np.abs(traj_v).argmax(): first maximum in flat order, NaN wins */
+            for (int i = 1; i < n * ND; ++i) {
+                if (tv[am] != tv[am]) break;
+                if (tv[i] != tv[i] || fabs(tv[i]) > fabs(tv[am])) am = i;
+            }
             const double scale = fabs(tv[am]) / (fabs(tvs[am]) + 1e-8);
             for (int i = 0; i < n * ND; ++i) traj[i] += scale * tvs[i];
             ++cnt;
@@ -773,6 +776,16 @@ static void orc_bp(const double* x, const double* v, const double* delta, const 
     free(alpha); free(z); free(shiftx); free(tmp); free(ap);
 }
 
+/* np.argmin / np.argmax: first occurrence of the extreme; a NaN counts as the extreme for both (numpy propagates NaN) */
+static int np_argext(const double* a, int n, int want_min) {
+    int idx = 0;
+    for (int g = 1; g < n; ++g) {
+        if (a[idx] != a[idx]) break; /* the first NaN stays */
+        if (a[g] != a[g] || (want_min ? a[g] < a[idx] : a[g] > a[idx])) idx = g;
+    }
+    return idx;
+}
+
 int orc_goal_update(const omgx_learner_params* prm, const double* traj, const double* goal_set, const double* reach,
                     const float* goal_cost, double* state, int32_t S, int32_t* goal_idx, double* end, double* goal_rows,
                     double* goal_point, double* cost_vector) {
@@ -788,14 +801,13 @@ int orc_goal_update(const omgx_learner_params* prm, const double* traj, const do
         int idx = 0;
         if (prm->alg == OMGX_ALG_PROJ) { /* online_learner.py:196-206: closest goal to the last waypoint */
             const double* last = traj + ((int64_t)s * n + n - 1) * ND;
-            double best = 0.0;
             for (int g = 0; g < G; ++g) {
                 double d2 = 0.0;
                 for (int d = 0; d < ND; ++d) { const double e = last[d] - gs[g * ND + d]; d2 += e * e; }
-                const double dist = sqrt(d2);
-                if (g == 0 || dist < best) { best = dist; idx = g; }
+                tmp[g] = sqrt(d2);
                 p[g] = 0.0;
             }
+            idx = np_argext(tmp, G, 1);
             p[idx] = 1.0;
         } else {
             /* cost_vector tail, online_learner.py:145-160 */
@@ -820,7 +832,7 @@ int orc_goal_update(const omgx_learner_params* prm, const double* traj, const do
             if (prm->alg == OMGX_ALG_FTL || prm->alg == OMGX_ALG_FTC) { /* :175-189 */
                 const double* key = cv;
                 if (prm->alg == OMGX_ALG_FTL) { for (int g = 0; g < G; ++g) sum_costs[g] += cv[g]; key = sum_costs; }
-                for (int g = 1; g < G; ++g) if (key[g] < key[idx]) idx = g;
+                idx = np_argext(key, G, 1);
                 for (int g = 0; g < G; ++g) p[g] = 0.0;
                 p[idx] = 1.0;
             } else if (prm->alg == OMGX_ALG_EXP) { /* :208-217 */
@@ -860,8 +872,7 @@ int orc_goal_update(const omgx_learner_params* prm, const double* traj, const do
                 free(v); free(delta); free(w); free(pn);
             }
             if (prm->alg == OMGX_ALG_EXP || prm->alg == OMGX_ALG_MD) { /* np.argmax(self.p), :243 */
-                idx = 0;
-                for (int g = 1; g < G; ++g) if (p[g] > p[idx]) idx = g;
+                idx = np_argext(p, G, 0);
             }
         }
         goal_idx[s] = idx;

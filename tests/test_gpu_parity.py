@@ -503,6 +503,38 @@ def test_goal_update_matches_oracle_many_scenes(dev, alg, G):
         np.testing.assert_array_equal(end.cpu().numpy(), r_end)
 
 
+@pytest.mark.parametrize("alg", ["FTL", "FTC", "Exp", "MD"])
+def test_goal_update_degenerate_cost_vector_keeps_a_valid_index(dev, alg):
+    """Zero cost vector -> 0/0 = NaN after normalisation: numpy's argmin/argmax pick the first NaN (goal 0); the kernel must
+    not leave the index undefined (out-of-bounds goal gather; found by tools/fuzz_parity.py)."""
+    from omg_planner_amd import _lib, ops
+    from oracle import oracle as orc
+    S, G, n = 3, 5, 12
+    rng = np.random.RandomState(2)
+    traj = rng.uniform(-1, 1, (S, n, 9))
+    goals = np.repeat(traj[:, 7][:, None, :], G, axis=1)  # every goal == traj_start
+    prm = _lib.LearnerParams()
+    prm.alg, prm.num_goals, prm.n_waypoints, prm.start_idx = _lib.ALG[alg], G, n, 7
+    prm.constraint_num, prm.use_standoff, prm.normalize_cost = 1, 0, 1
+    prm.base_obstacle_weight, prm.smooth_weight, prm.eta = 1.0, 0.01, 0.3
+    po = orc.LearnerParams()
+    for f, _ in po._fields_:
+        setattr(po, f, getattr(prm, f))
+    st_ref = orc.learner_state_init(S, G)
+    r_idx, r_end, r_rows, r_gp, r_cv = orc.goal_update(po, traj, goals, None, np.zeros((S, G), np.float32), st_ref)
+    st = ops.learner_state(S, G, dev)
+    idx = torch.full((S,), -7, dtype=torch.int32, device=dev)
+    end, rows, gp = (torch.zeros((S, 9), dtype=torch.float64, device=dev), torch.zeros((S, 1, 9), dtype=torch.float64, device=dev),
+                     torch.zeros((S, 9), dtype=torch.float64, device=dev))
+    cv = torch.zeros((S, G), dtype=torch.float64, device=dev)
+    ops.goal_update(prm, _t(traj, dev), _t(goals, dev), None, torch.zeros((S, G), dtype=torch.float32, device=dev), st, idx, end, rows, gp, cv)
+    torch.cuda.synchronize()
+    assert torch.isnan(cv).all() and np.isnan(r_cv).all()
+    np.testing.assert_array_equal(idx.cpu().numpy(), r_idx)
+    assert (idx.cpu().numpy() == 0).all()
+    np.testing.assert_array_equal(end.cpu().numpy(), r_end)
+
+
 # ------------------------------------------------------------------------------------------------
 # (7) the whole planner loop: ChompEngine against the same loop driven through the oracle
 # ------------------------------------------------------------------------------------------------

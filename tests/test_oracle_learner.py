@@ -80,3 +80,20 @@ def test_proj_picks_closest_goal():
     d = np.linalg.norm(fx["trajs"][0][-1][None] - fx["goal_set"], axis=-1)
     assert idx[0] == int(np.argmin(d))
     np.testing.assert_array_equal(end[0], fx["goal_set"][idx[0]])
+
+
+@pytest.mark.parametrize("alg", ["FTL", "FTC", "Exp"])
+def test_degenerate_cost_vector_selects_like_numpy(alg):
+    """A zero cost vector normalises to 0/0 = NaN (online_learner.py:153-156).  np.argmin / np.argmax then return the
+    FIRST NaN, i.e. goal 0 — the index must stay valid (found by tools/fuzz_parity.py: one goal, one-waypoint window)."""
+    fx = H.load("learner_FTL_0.npz")
+    prm = learner_params(fx, 1)
+    prm.alg = orc.ALG[alg]
+    G = fx["goal_set"].shape[0]
+    traj = fx["trajs"][0][None].copy()
+    goals = np.repeat(traj[:, prm.start_idx][:, None, :], G, axis=1)   # every goal == traj_start: smoothness proxy 0
+    state = orc.learner_state_init(1, G)
+    idx, end, rows, gp, cv = orc.goal_update(prm, traj, goals, None, np.zeros((1, G), np.float32), state)
+    assert np.isnan(cv).all()
+    assert idx[0] == 0 == int(np.argmin(cv[0])) == int(np.argmax(cv[0]))
+    np.testing.assert_array_equal(end[0], goals[0, 0])

@@ -1,0 +1,137 @@
+"""Randomised differential test of the whole planner loop on the GPU box: ChompEngine (two launches per iteration,
+learner and step in different workgroups) against the same loop driven through the CPU oracle, over random batch sizes,
+goal counts, trajectory lengths, points per link, scene contents, SDF-layer parameters, top-k settings, finger options,
+goal-selection rules and standoff tails.  A tool (test infrastructure like tests/): prints one line per trial and a summary.
+
+    python tools/fuzz_parity.py [trials] [seed]
+"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from omg_planner_amd import robot as rb, scenes as sc
+from omg_planner_amd.config import Config
+from omg_planner_amd.engine import ChompEngine
+from oracle import oracle as orc
+
+
+def random_scene(rng, seed, grid):
+    scn = sc.make_tabletop_scene(seed, num_objects=int(rng.randint(1, 6)), grid=grid, table_grid=(grid + 8, grid, max(8, grid // 3)))
+    for ob in scn.objects:  # fixture-style ramp: no exact ties in the top-k cut
+        sh = ob.sdf.data.shape
+        ramp = 1e-4 * (np.arange(sh[0])[:, None, None] + 0.37 * np.arange(sh[1])[None, :, None] + 0.11 * np.arange(sh[2])[None, None, :])
+        ob.sdf = sc.SdfGrid((ob.sdf.data + ramp.astype(np.float32)).astype(np.float32), ob.sdf.origin, ob.sdf.delta)
+    if rng.rand() < 0.25 and len(scn.objects) > 2:
+        scn.objects[1].name = "floor"  # disabled
+    if rng.rand() < 0.2:
+        scn.objects[0].attached = True  # table override (cost.py:325-328)
+    return scn
+
+
+def one_trial(rng, trial, dev, dry=False):
+    S, G = int(rng.randint(1, 7)), int(rng.randint(1, 13))
+    n = int(rng.choice([5, 8, 12, 20, 30, 30, 41, 50, 64]))
+    P = int(rng.choice([4, 9, 15, 15, 16]))
+    alg = str(rng.choice(["FTL", "FTC", "Exp", "MD", "MD", "Proj"]))
+    standoff = bool(rng.rand() < 0.35) and n >= 8
+    iters = int(rng.randint(2, 6))
+    cfg = Config()
+    cfg.use_standoff = standoff
+    cfg.optim_steps = int(rng.randint(3, 9))
+    cfg.top_k_collision = int(rng.choice([0, 40, 300, 1000, 1000]))
+    cfg.consider_finger = bool(rng.rand() < 0.3)
+    cfg.uncheck_finger_collision = int(rng.choice([0, 0, -1]))
+    cfg.epsilon = float(rng.choice([0.2, 0.2, 0.12, 0.3]))
+    cfg.target_epsilon = float(rng.choice([0.1, 0.05, 0.15]))
+    cfg.clearance = float(rng.choice([0.01, 0.0, 0.03]))
+    cfg.allow_collision_point = int(rng.choice([5, 0, 50]))
+    cfg.get_global_param(n)
+    grid = int(rng.choice([20, 24, 32]))
+    print(f"  trial {trial}: S={S} G={G} n={n} P={P} alg={alg} standoff={standoff} iters={iters} optim_steps={cfg.optim_steps} "
+          f"top_k={cfg.top_k_collision} finger={cfg.consider_finger} uncheck={cfg.uncheck_finger_collision} eps={cfg.epsilon} "
+          f"teps={cfg.target_epsilon} clr={cfg.clearance} grid={grid}", flush=True)
+    m = rb.PandaModel(points_per_link=P, seed=int(rng.randint(0, 1000)))
+    scenes = [random_scene(rng, int(rng.randint(0, 50)), grid) for _ in range(S)]
+    batch = sc.pack_table(scenes, cfg.layer_kwargs())
+    goals = np.stack([sc.make_reach_goals(scenes[s], m, G, int(rng.randint(0, 99))) for s in range(S)])
+    start = np.tile(rb.HOME_CONFIG, (S, 1)) + rng.normal(0, 0.05, (S, 9)) * np.array([1] * 7 + [0, 0])
+    c = cfg.reach_tail_length if standoff else 1
+    reach = None
+    if standoff:
+        reach = np.stack([[np.concatenate([sc.linear_init(g - rng.normal(0.1, 0.03, 9) * np.array([1] * 7 + [0, 0]), g, c - 1), g[None]], 0)
+                           for g in goals[s]] for s in range(S)])
+    if dry:  # only advance the random stream (to reach a later trial quickly)
+        return None, 0.0
+    import copy
+    eng = ChompEngine(m, batch, copy.deepcopy(cfg), start, goals, reach_grasps=reach, device=dev, ol_alg=alg)
+    traj = eng.traj.cpu().numpy().copy()
+    state = orc.learner_state_init(S, G)
+    cv_goals = reach[:, :, -1, :] if standoff else goals
+    end, rows, gp = eng.end.cpu().numpy().copy(), eng.goal_rows.cpu().numpy().copy(), eng.goal_point.cpu().numpy().copy()
+    blob = m.blob()
+    worst = 0.0
+    for t in range(iters):
+        if os.environ.get("OMGX_FUZZ_DEBUG"):
+            print(f"    iterate {t}", flush=True)
+        eng.iterate(t)
+        if os.environ.get("OMGX_FUZZ_DEBUG"):
+            torch.cuda.synchronize()
+        idx = None
+        if t < cfg.optim_steps:
+            lp = orc.LearnerParams()
+            lp.alg, lp.num_goals, lp.n_waypoints = orc.ALG[alg], G, n
+            lp.start_idx = min(int(((t + 1) / cfg.optim_steps) * n), n - 1)
+            lp.constraint_num, lp.use_standoff, lp.normalize_cost = c, int(standoff), int(cfg.normalize_cost)
+            lp.base_obstacle_weight, lp.smooth_weight = float(cfg.base_obstacle_weight), float(cfg.smoothness_base_weight * cfg.dist_eps)
+            lp.eta = float(np.sqrt(np.log(G + 1) / cfg.optim_steps))
+            gc = np.zeros((S, G), np.float32)
+            if alg != "Proj":
+                gc, _ = orc.goalset_cost(blob, P, batch, traj[:, lp.start_idx], cv_goals, n - lp.start_idx, cfg.time_interval)
+            idx, end, rows, gp, _ = orc.goal_update(lp, traj, goals, reach, gc, state)
+        po = orc.ChompParams()
+        src = eng._params(True)
+        for f, _ in po._fields_:
+            setattr(po, f, getattr(src, f))
+        pot, pg, col = orc.fk_sdf(blob, P, batch, traj, soften_fingers=cfg.uncheck_finger_collision == -1)
+        traj, _, _, info = orc.chomp_optimize(blob, po, traj, start, end, rows, gp, pot, pg, col)
+        if idx is not None and not np.array_equal(eng.goal_idx.cpu().numpy(), idx):
+            return f"goal index mismatch at iteration {t}: {eng.goal_idx.cpu().numpy()} vs {idx}", worst
+        d = float(np.abs(eng.traj.cpu().numpy() - traj).max())
+        worst = max(worst, d)
+        if not d <= 1e-6:
+            return f"trajectory differs by {d:.3e} at iteration {t}", worst
+        gi, oi = eng.info.cpu().numpy()[:, :10], info[:, :10]
+        if not np.allclose(gi, oi, rtol=1e-5, atol=1e-6):
+            return f"info differs at iteration {t}: max abs {np.abs(gi - oi).max():.3e}", worst
+    return None, worst
+
+
+def main():
+    trials = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    rng = np.random.RandomState(seed)
+    dev = torch.device("cuda:0")
+    bad, t0, worst_all = 0, time.time(), 0.0
+    for k in range(trials):
+        st = rng.get_state()
+        try:
+            only = os.environ.get("OMGX_FUZZ_ONLY")
+            err, worst = one_trial(rng, k, dev, dry=only is not None and int(only) != k)
+        except Exception as e:  # noqa: BLE001
+            err, worst = f"exception {type(e).__name__}: {e}", float("nan")
+        worst_all = max(worst_all, worst if worst == worst else 0.0)
+        if err:
+            bad += 1
+            print(f"trial {k}: FAIL {err} (rng position {st[2]})", flush=True)
+        else:
+            print(f"trial {k}: ok, max |traj - oracle| {worst:.2e}", flush=True)
+    print(f"{trials - bad}/{trials} trials agree; worst trajectory difference {worst_all:.2e}; {time.time() - t0:.0f} s")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
