@@ -19,6 +19,9 @@ from omg_planner_amd.engine import ChompEngine
 from oracle import oracle as orc
 
 
+STATS = {"limit_steps": 0, "violations": 0}
+
+
 def random_scene(rng, seed, grid):
     scn = sc.make_tabletop_scene(seed, num_objects=int(rng.randint(1, 6)), grid=grid, table_grid=(grid + 8, grid, max(8, grid // 3)))
     for ob in scn.objects:  # fixture-style ramp: no exact ties in the top-k cut
@@ -34,11 +37,13 @@ def random_scene(rng, seed, grid):
 
 def one_trial(rng, trial, dev, dry=False):
     S, G = int(rng.randint(1, 7)), int(rng.randint(1, 13))
+    if rng.rand() < 0.08:
+        G = int(rng.choice([64, 65, 130, 200, 256]))  # more than one goal per lane of the learner
     n = int(rng.choice([5, 8, 12, 20, 30, 30, 41, 50, 64]))
     P = int(rng.choice([4, 9, 15, 15, 16]))
     alg = str(rng.choice(["FTL", "FTC", "Exp", "MD", "MD", "Proj"]))
     standoff = bool(rng.rand() < 0.35) and n >= 8
-    iters = int(rng.randint(2, 6))
+    iters = int(rng.randint(2, 6)) if rng.rand() < 0.8 else int(rng.randint(8, 16))
     cfg = Config()
     cfg.use_standoff = standoff
     cfg.optim_steps = int(rng.randint(3, 9))
@@ -49,16 +54,20 @@ def one_trial(rng, trial, dev, dry=False):
     cfg.target_epsilon = float(rng.choice([0.1, 0.05, 0.15]))
     cfg.clearance = float(rng.choice([0.01, 0.0, 0.03]))
     cfg.allow_collision_point = int(rng.choice([5, 0, 50]))
+    cfg.goal_set_proj = bool(rng.rand() < 0.85)  # False: fixed end, plain -eta Ainv g step, no goal selection
+    wild = rng.rand() < 0.25                     # start far from home: joint-limit projection kicks in
     cfg.get_global_param(n)
     grid = int(rng.choice([20, 24, 32]))
     print(f"  trial {trial}: S={S} G={G} n={n} P={P} alg={alg} standoff={standoff} iters={iters} optim_steps={cfg.optim_steps} "
           f"top_k={cfg.top_k_collision} finger={cfg.consider_finger} uncheck={cfg.uncheck_finger_collision} eps={cfg.epsilon} "
-          f"teps={cfg.target_epsilon} clr={cfg.clearance} grid={grid}", flush=True)
+          f"teps={cfg.target_epsilon} clr={cfg.clearance} grid={grid} proj={cfg.goal_set_proj} wild={wild}", flush=True)
     m = rb.PandaModel(points_per_link=P, seed=int(rng.randint(0, 1000)))
     scenes = [random_scene(rng, int(rng.randint(0, 50)), grid) for _ in range(S)]
     batch = sc.pack_table(scenes, cfg.layer_kwargs())
     goals = np.stack([sc.make_reach_goals(scenes[s], m, G, int(rng.randint(0, 99))) for s in range(S)])
-    start = np.tile(rb.HOME_CONFIG, (S, 1)) + rng.normal(0, 0.05, (S, 9)) * np.array([1] * 7 + [0, 0])
+    start = np.tile(rb.HOME_CONFIG, (S, 1)) + rng.normal(0, 0.6 if wild else 0.05, (S, 9)) * np.array([1] * 7 + [0, 0])
+    if wild:
+        goals = goals + rng.normal(0, 0.4, goals.shape) * np.array([1] * 7 + [0, 0])
     c = cfg.reach_tail_length if standoff else 1
     reach = None
     if standoff:
@@ -81,7 +90,7 @@ def one_trial(rng, trial, dev, dry=False):
         if os.environ.get("OMGX_FUZZ_DEBUG"):
             torch.cuda.synchronize()
         idx = None
-        if t < cfg.optim_steps:
+        if t < cfg.optim_steps and cfg.goal_set_proj:
             lp = orc.LearnerParams()
             lp.alg, lp.num_goals, lp.n_waypoints = orc.ALG[alg], G, n
             lp.start_idx = min(int(((t + 1) / cfg.optim_steps) * n), n - 1)
@@ -98,6 +107,8 @@ def one_trial(rng, trial, dev, dry=False):
             setattr(po, f, getattr(src, f))
         pot, pg, col = orc.fk_sdf(blob, P, batch, traj, soften_fingers=cfg.uncheck_finger_collision == -1)
         traj, _, _, info = orc.chomp_optimize(blob, po, traj, start, end, rows, gp, pot, pg, col)
+        STATS["limit_steps"] += int(info[:, 15].sum())
+        STATS["violations"] += int(info[:, 14].sum())
         if idx is not None and not np.array_equal(eng.goal_idx.cpu().numpy(), idx):
             return f"goal index mismatch at iteration {t}: {eng.goal_idx.cpu().numpy()} vs {idx}", worst
         d = float(np.abs(eng.traj.cpu().numpy() - traj).max())
@@ -129,7 +140,8 @@ def main():
             print(f"trial {k}: FAIL {err} (rng position {st[2]})", flush=True)
         else:
             print(f"trial {k}: ok, max |traj - oracle| {worst:.2e}", flush=True)
-    print(f"{trials - bad}/{trials} trials agree; worst trajectory difference {worst_all:.2e}; {time.time() - t0:.0f} s")
+    print(f"{trials - bad}/{trials} trials agree; worst trajectory difference {worst_all:.2e}; joint-limit projection steps "
+          f"{STATS['limit_steps']}, limit-violation flags {STATS['violations']}; {time.time() - t0:.0f} s")
     return 1 if bad else 0
 
 
