@@ -615,7 +615,8 @@ int orc_chomp_optimize_one(const double* robot, const omgx_chomp_params* prm, do
     info[OMGX_INFO_VIOLATE_LIMIT] = any_both;
     info[OMGX_INFO_LIMIT_STEPS] = 0;
 
-    if (prm->do_update) {
+    /* optimizer.py:126-127: `if (info["terminate"] and not force_update) or info_only: return` — do_update 2 = no force_update */
+    if (prm->do_update == 1 || (prm->do_update == 2 && !terminate)) {
         /* ---- goal_set_projection (optimizer.py:88-113) or plain step (:132) ---- */
         double* Ag = (double*)malloc(sizeof(double) * n * ND);
         double* upd = (double*)malloc(sizeof(double) * n * ND);

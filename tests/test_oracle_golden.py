@@ -116,3 +116,26 @@ def test_optimizer_steps_match_reference(case):
                 free = traj[0]
     if case == "limits_5":
         assert fx["info_violate_limit"].max() >= 0  # fixture exercised handle_joint_limit
+
+
+def test_optimize_without_force_update_leaves_a_terminated_trajectory_alone():
+    """Optimizer.optimize(traj) with force_update=False (optimizer.py:126-127): `if info["terminate"] and not force_update:
+    return` — do_update = 2.  A collision-free straight trajectory that ends on its goal terminates; do_update = 1 moves it."""
+    fx = H.load("cost_topk1000.npz")
+    m = H.model_from(fx)
+    n, P = 6, m.points_per_link
+    start = fx["start"]
+    xi = start[None] + np.linspace(0, 1e-3, n)[:, None] * np.ones(9)[None] * np.array([1] * 7 + [0, 0])
+    end = xi[-1].copy()
+    zeros = np.zeros((1, n, 10, P), np.float32)
+    out = {}
+    for mode in (1, 2):
+        prm = H.params_from(fx, orc.ChompParams, n, P, mode, 1.0, 0.1)
+        prm.goal_set_proj, prm.use_standoff, prm.constraint_num, prm.pre_terminate = 1, 0, 1, 1
+        prm.terminate_smooth_loss = 1e9
+        traj, _, _, info = orc.chomp_optimize(m.blob(), prm, xi[None], start[None], end[None], end[None, None], end[None], zeros,
+                                              np.zeros((1, n, 10, P, 3), np.float32), zeros)
+        assert info[0, H.INFO_IDX["terminate"]] == 1.0
+        out[mode] = traj[0]
+    np.testing.assert_array_equal(out[2], xi)
+    assert np.abs(out[1] - xi).max() > 0

@@ -1,0 +1,122 @@
+"""Randomised differential test of omgx_chomp_optimize on the GPU box against the CPU oracle with ADVERSARIAL layer outputs
+(not produced by an SDF): quantised potentials with many exact ties around the top-k cut, all-zero and all-equal sets,
+k = 1 / k = total / k > total / k = 0 (clean branch), 1..64 waypoints, 1..16 points per link, standoff tails of 1..8 rows,
+fixed end, inactive scenes, do_update 0 / 1 / 2, trajectories outside the joint limits.  Ties at the cut are resolved by
+ascending flat index in both builds, so results must agree to round-off.
+
+    python tools/fuzz_chomp.py [trials] [seed]
+"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from omg_planner_amd import _lib, ops, robot as rb
+from oracle import oracle as orc
+
+STATS = {"radix": 0, "ties_at_cut": 0, "limit_steps": 0}
+
+
+def trial(rng, dev):
+    S = int(rng.randint(1, 6))
+    n = int(rng.choice([1, 2, 3, 5, 12, 30, 30, 50, 64]))
+    P = int(rng.choice([1, 4, 15, 15, 16]))
+    m = rb.PandaModel(points_per_link=P, seed=int(rng.randint(0, 999)))
+    total = n * 10 * P
+    top_k = int(rng.choice([0, 1, 7, 100, 1000, total, total + 5, max(1, total // 2)]))
+    standoff = bool(rng.rand() < 0.3)
+    c = int(rng.randint(1, min(8, n) + 1)) if standoff else 1
+    lo, hi = m.joint_lower_limit[0], m.joint_upper_limit[0]
+    wide = rng.rand() < 0.3
+    traj = rng.uniform(lo - (0.4 if wide else 0), hi + (0.4 if wide else 0), (S, n, 9))
+    start, end = rng.uniform(lo, hi, (S, 9)), rng.uniform(lo, hi, (S, 9))
+    goal, gp = rng.uniform(lo, hi, (S, c, 9)), rng.uniform(lo, hi, (S, 9))
+    kind = rng.randint(0, 5)
+    if kind == 0:    # sparse, continuous
+        pot = rng.uniform(0, 0.3, (S, n, 10, P)) * (rng.rand(S, n, 10, P) < 0.1)
+    elif kind == 1:  # dense, heavily quantised: exact ties everywhere
+        pot = rng.randint(0, 4, (S, n, 10, P)) * 0.05
+    elif kind == 2:  # all zero
+        pot = np.zeros((S, n, 10, P))
+    elif kind == 3:  # all equal
+        pot = np.full((S, n, 10, P), 0.125)
+    else:            # dense continuous with some exact duplicates
+        pot = rng.uniform(0, 0.3, (S, n, 10, P))
+        pot.ravel()[rng.randint(0, pot.size, pot.size // 3)] = pot.ravel()[rng.randint(0, pot.size, pot.size // 3)]
+    pot = pot.astype(np.float32)
+    pgrad = (rng.normal(0, 1, (S, n, 10, P, 3)) * (pot[..., None] != 0)).astype(np.float32)
+    col = (rng.rand(S, n, 10, P) < 0.05).astype(np.float32)
+    active = (rng.rand(S) < 0.85).astype(np.int32) if rng.rand() < 0.5 else None
+    pd, po = _lib.ChompParams(), orc.ChompParams()
+    vals = dict(n_waypoints=n, n_points=P, top_k=top_k, consider_finger=int(rng.rand() < 0.4), goal_set_proj=int(rng.rand() < 0.75),
+                constraint_num=c, use_standoff=int(standoff), uncheck_finger_collision=int(rng.choice([0, -1])),
+                joint_limit_max_steps=int(rng.choice([10, 0, 3])), allow_collision_point=int(rng.choice([5, 0])),
+                pre_terminate=int(rng.rand() < 0.8), do_update=int(rng.choice([1, 1, 0, 2])), time_interval=float(rng.choice([0.1, 0.06, 0.25])),
+                obstacle_weight=float(rng.choice([1.0, 0.3])), smoothness_weight=float(rng.uniform(0.05, 0.3)), step_size=float(rng.choice([0.1, 0.02])),
+                clip_grad_scale=float(rng.choice([10.0, 0.5])), terminate_smooth_loss=float(rng.choice([35.0, 1e9])))
+    for k, v in vals.items():
+        setattr(pd, k, v); setattr(po, k, v)
+    for d in range(9):
+        pd.link_smooth_weight[d] = po.link_smooth_weight[d] = float(rng.choice([1.0, 1.0, 0.5]))
+    # coverage statistics (per scene): does the radix select run, are there ties exactly at the cut?
+    if 0 < top_k < total:
+        for s in range(S):
+            v = np.sort(pot[s].ravel())[::-1]
+            if (v > 0).sum() > top_k:
+                STATS["radix"] += 1
+                if top_k < total and v[top_k - 1] == v[top_k]:
+                    STATS["ties_at_cut"] += 1
+    t_ref, g_ref, ct_ref, info_ref = orc.chomp_optimize(m.blob(), po, traj, start, end, goal, gp, pot, pgrad, col, active)
+    STATS["limit_steps"] += int(info_ref[:, 15].sum())
+    t = lambda a, dt=torch.float64: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=dev)  # noqa: E731
+    td = t(traj)
+    info0 = torch.full((S, _lib.INFO_STRIDE), -7.0, dtype=torch.float64, device=dev)
+    g, ct, info = ops.chomp_optimize(ops.robot_blob(m, dev), pd, td, t(start), t(end), t(goal), t(gp), t(pot, torch.float32),
+                                     t(pgrad, torch.float32), t(col, torch.float32), active=None if active is None else t(active, torch.int32),
+                                     out=(torch.zeros((S, n, 9), dtype=torch.float64, device=dev), torch.zeros((S, n), dtype=torch.float64, device=dev), info0))
+    torch.cuda.synchronize()
+    act = np.ones(S, bool) if active is None else active.astype(bool)
+    errs = []
+    tag = f"S={S} n={n} P={P} k={top_k} c={c} kind={kind} proj={vals['goal_set_proj']} upd={vals['do_update']}"
+    scale = max(1.0, float(np.abs(g_ref).max()))
+    if not np.allclose(td.cpu().numpy()[act], t_ref[act], rtol=0, atol=1e-8 * max(1.0, float(np.abs(t_ref).max()))):
+        errs.append(f"traj {np.abs(td.cpu().numpy()[act] - t_ref[act]).max():.2e}")
+    if errs and os.environ.get("OMGX_FUZZ_DEBUG"):
+        np.set_printoptions(precision=6, linewidth=200)
+        print("active", act, "\ninfo gpu\n", info.cpu().numpy(), "\ninfo ref\n", info_ref, "\ntraj gpu\n", td.cpu().numpy().reshape(S, -1),
+              "\ntraj ref\n", t_ref.reshape(S, -1), "\ntraj in\n", traj.reshape(S, -1), "\nlimits", lo, hi, flush=True)
+    if not np.array_equal(td.cpu().numpy()[~act], traj[~act]):
+        errs.append("inactive trajectory touched")
+    if not np.allclose(g.cpu().numpy()[act], g_ref[act], rtol=1e-9, atol=1e-9 * scale):
+        errs.append(f"grad {np.abs(g.cpu().numpy()[act] - g_ref[act]).max():.2e} (scale {scale:.1e})")
+    if not np.allclose(ct.cpu().numpy()[act], ct_ref[act], rtol=1e-9, atol=1e-9):
+        errs.append("cost_traj")
+    if not np.allclose(info.cpu().numpy()[act], info_ref[act], rtol=1e-9, atol=1e-9 * scale):
+        errs.append(f"info {np.abs(info.cpu().numpy()[act] - info_ref[act]).max():.2e}")
+    return errs, tag
+
+
+def main():
+    trials = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    rng = np.random.RandomState(seed)
+    dev = torch.device("cuda:0")
+    bad, t0 = 0, time.time()
+    for k in range(trials):
+        try:
+            errs, tag = trial(rng, dev)
+        except Exception as e:  # noqa: BLE001
+            errs, tag = [f"exception {type(e).__name__}: {e}"], "?"
+        if errs:
+            bad += 1
+            print(f"trial {k} [{tag}]: FAIL " + "; ".join(errs), flush=True)
+    print(f"{trials - bad}/{trials} trials agree; radix select ran for {STATS['radix']} trajectories, {STATS['ties_at_cut']} with ties at the "
+          f"cut; joint-limit projection steps {STATS['limit_steps']}; {time.time() - t0:.0f} s")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
