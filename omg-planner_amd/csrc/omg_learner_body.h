@@ -66,63 +66,61 @@ __device__ __forceinline__ int warg(double v, int i) {
 
 // bp (online_learner.py:32-58) with find_zero (:16-29) inlined.  x, v per-lane slices; w = 1, delta = 1/(4G+1).
 //
-// find_zero bisects f(L) = sum_j shiftx_j exp(L + z_j) - target = exp(L) * C - target over L: C is summed once per
-// outer iteration and exp(L) follows the bisection, E *= exp(+-s_k) with s_k = x1 / 2^(k+2).  Neither x1 = max(1 + v)
-// nor shiftx change between outer iterations, so the step factors exp(+-s_k) are tabulated once per projection
-// (lane k evaluates entry k; `tab` is a wave-private LDS array of 2 x 64 doubles, later factors are exactly 1), and a bisection step is a
-// fused multiply-add, a compare and a multiply by a table entry.  L itself is updated exactly like the reference
-// (same dyadic sequence); E carries ~1e-16 relative error per step against a decision threshold of 1e-6.
-__device__ void bregman_projection(const double* x, const double* v, double delta, int G, int lane, double* y, double* tab) {
+// find_zero bisects f(L) = sum_j shiftx_j exp(L + z_j) - target, z = alpha - v.  With zmax = max_j z_j and
+// C = sum_j shiftx_j exp(z_j - zmax) (no overflow: every term <= shiftx_j, one term == shiftx_j), f(L) = target (exp(d) - 1)
+// for d = (L + zmax) - log(target / C): the sign of f is the sign of d and |f| < err is log1p(-err/target) < d < log1p(err/target).
+// A bisection step is therefore two compares and an add on L's own dyadic sequence (the reference's x -= s sign(y); s /= 2) —
+// no exponentials, no table, and nothing that can overflow for un-normalised costs (v ~ 1e4: the termwise exp(L + z_j) of
+// the reference stays finite near the root, a factored exp(L) * sum exp(z_j) would be inf * 0).  exp(L + zmax) at the
+// end is (target / C) exp(d) with |d| <~ 1e-6 (third-order series; the full exp only if the bisection did not converge).
+// Decisions can differ from the reference's floating-point f only when |f| is within ~1e-15 of 0 or of err.
+__device__ void bregman_projection(const double* x, const double* v, double delta, int G, int lane, double* y) {
     const int max_iter = 100;
     const double err = 1e-6;
-    double alpha[NPL] = {0, 0, 0, 0}, shiftx[NPL], lds[NPL], ez[NPL];
+    double alpha[NPL] = {0, 0, 0, 0}, shiftx[NPL], lds[NPL], ezs[NPL];
     const double target = 1.0 + delta * (double)G;
-    double vmax = -1e300;
+    const double dlo = log1p(-err / target), dhi = log1p(err / target), ltarget = log(target);
+    double vmax = -__builtin_inf();
 #pragma unroll
     for (int j = 0; j < NPL; ++j) {
         const bool ok = lane + 64 * j < G;
         shiftx[j] = x[j] + delta;
         lds[j] = ok ? log(delta / shiftx[j]) : 0.0;
-        ez[j] = 0.0;
+        ezs[j] = 0.0;
         if (ok) vmax = fmax(vmax, 1.0 + v[j]);
     }
     const double x1 = wmax(vmax);
     const double L0 = (0.0 + x1) / 2.0, s0 = (x1 - 0.0) / 4.0;
-    const double E0 = exp(L0);
-    {   // s_k = s0 / 2^k is exact (power-of-two scaling); for k >= 64 exp(+-s_k) rounds to 1 (s_k < 2^-60 x1)
-        const double up = exp(ldexp(s0, -lane));
-        tab[2 * lane] = up;
-        tab[2 * lane + 1] = 1.0 / up;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     for (int it = 0; it < max_iter; ++it) {
+        double zm = -__builtin_inf();
+#pragma unroll
+        for (int j = 0; j < NPL; ++j)
+            if (lane + 64 * j < G) zm = fmax(zm, alpha[j] - v[j]);
+        const double zmax = wmax(zm);
         double partC = 0.0;
 #pragma unroll
         for (int j = 0; j < NPL; ++j)
-            if (lane + 64 * j < G) { ez[j] = exp(alpha[j] - v[j]); partC += shiftx[j] * ez[j]; }
+            if (lane + 64 * j < G) { ezs[j] = exp((alpha[j] - v[j]) - zmax); partC += shiftx[j] * ezs[j]; }
         const double Csum = wsum(partC);
-        double L = L0, sstep = s0, E = E0;
-        double up = tab[0], dn = tab[1];
+        const double lstar = ltarget - log(Csum);  // L + zmax at the root
+        double L = L0, sstep = s0, d = (L0 + zmax) - lstar;
+        bool converged = false;
         for (int k = 0; k < max_iter; ++k) {
-            const double fy = E * Csum - target;
-            if (fabs(fy) < err) break;
-            const int kn = k + 1 < 64 ? k + 1 : 63;  // prefetch the next pair; beyond k = 63 the factors are 1
-            const double nup = tab[2 * kn], ndn = tab[2 * kn + 1];
-            const bool pos = fy > 0;                  // fy == 0 left the loop above
-            L += pos ? -sstep : sstep;
-            E *= pos ? dn : up;
+            if (d > dlo && d < dhi) { converged = true; break; }
+            if (d > 0) L -= sstep;
+            else if (d < 0) L += sstep;
+            else L = d;  // NaN: x -= s * np.sign(nan) poisons x in the reference too
             sstep /= 2.0;
-            up = k + 1 < 64 ? nup : 1.0;
-            dn = k + 1 < 64 ? ndn : 1.0;
+            d = (L + zmax) - lstar;
         }
-        const double EL = E;  // exp(L) up to the accumulated ~1e-15
+        // exp(L + zmax) = exp(lstar) exp(d) = (target / Csum) exp(d)
+        const double ed = converged ? 1.0 + d * (1.0 + d * (0.5 + d * (1.0 / 6.0))) : exp(d);
+        const double EL = (target / Csum) * ed;
         double nrm = 0.0, ap[NPL];
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {
             const bool ok = lane + 64 * j < G;
-            y[j] = ok ? shiftx[j] * (EL * ez[j]) - delta : 0.0;  // shiftx exp(L + alpha - v) - delta
+            y[j] = ok ? shiftx[j] * (EL * ezs[j]) - delta : 0.0;  // shiftx exp(L + alpha - v) - delta
             ap[j] = ok ? fmax(0.0, v[j] - L + lds[j]) : 0.0;
             nrm += (alpha[j] - ap[j]) * (alpha[j] - ap[j]);
         }
@@ -235,7 +233,7 @@ __device__ __forceinline__ void learner_scene(const LearnerArgs& a, int s, doubl
                     v[j] = prm.eta * pw[wave] * cv[j];
                     epw[j] = g < G ? experts_p[(int64_t)wave * G + g] : 0.0;
                 }
-                bregman_projection(epw, v, delta, G, lane, pn, sh_tab[wave]);
+                bregman_projection(epw, v, delta, G, lane, pn);
                 // this expert's cost (:229-230) on its own wave: sum_g cv pn + |pn - old p|; the step table is dead by now
                 double part2 = 0.0;
                 for (int j = 0; j < NPL; ++j) {

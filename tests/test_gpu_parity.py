@@ -535,6 +535,35 @@ def test_goal_update_degenerate_cost_vector_keeps_a_valid_index(dev, alg):
     np.testing.assert_array_equal(end.cpu().numpy(), r_end)
 
 
+@pytest.mark.parametrize("G", [7, 64, 200])
+def test_goal_update_md_with_unnormalised_large_costs(dev, G):
+    """cfg.normalize_cost = False with costs ~1e4: the mirror-descent exponents reach +-1e5.  The reference's termwise
+    exp(L + z_j) stays finite near the root; a factored exp(L) * sum exp(z_j) is inf * 0 (found by tools/fuzz_learner.py)."""
+    from omg_planner_amd import _lib, ops
+    from oracle import oracle as orc
+    S, n = 3, 30
+    rng = np.random.RandomState(G)
+    traj, goals = rng.uniform(-2, 2, (S, n, 9)), rng.uniform(-2, 2, (S, G, 9))
+    prm = _lib.LearnerParams()
+    prm.alg, prm.num_goals, prm.n_waypoints, prm.start_idx = _lib.ALG["MD"], G, n, 3
+    prm.constraint_num, prm.use_standoff, prm.normalize_cost = 1, 0, 0
+    prm.base_obstacle_weight, prm.smooth_weight, prm.eta = 1.0, 0.01, float(np.sqrt(np.log(G + 1) / 50))
+    po = orc.LearnerParams()
+    for f, _ in po._fields_:
+        setattr(po, f, getattr(prm, f))
+    st_ref, st = orc.learner_state_init(S, G), ops.learner_state(S, G, dev)
+    idx = torch.zeros(S, dtype=torch.int32, device=dev)
+    end, rows, gp = (torch.zeros((S, 9), dtype=torch.float64, device=dev), torch.zeros((S, 1, 9), dtype=torch.float64, device=dev),
+                     torch.zeros((S, 9), dtype=torch.float64, device=dev))
+    for step in range(4):
+        gc = rng.uniform(0, 1e4, (S, G)).astype(np.float32)
+        r_idx, r_end, _, _, _ = orc.goal_update(po, traj, goals, None, gc, st_ref)
+        ops.goal_update(prm, _t(traj, dev), _t(goals, dev), None, _t(gc, dev), st, idx, end, rows, gp)
+        assert not np.isnan(st_ref).any() and not torch.isnan(st).any()
+        np.testing.assert_array_equal(idx.cpu().numpy(), r_idx, err_msg=f"step {step}")
+        np.testing.assert_allclose(st.cpu().numpy(), st_ref, rtol=1e-5, atol=1e-8, err_msg=f"step {step}")
+
+
 # ------------------------------------------------------------------------------------------------
 # (7) the whole planner loop: ChompEngine against the same loop driven through the oracle
 # ------------------------------------------------------------------------------------------------
