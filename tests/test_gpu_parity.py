@@ -537,7 +537,7 @@ def test_goal_update_degenerate_cost_vector_keeps_a_valid_index(dev, alg):
 
 @pytest.mark.parametrize("G", [7, 64, 200])
 def test_goal_update_md_with_unnormalised_large_costs(dev, G):
-    """cfg.normalize_cost = False with costs ~1e4: the mirror-descent exponents reach +-1e5.  The reference's termwise
+    """cfg.normalize_cost = False with costs ~1e3: the mirror-descent exponents reach +-5e3.  The reference's termwise
     exp(L + z_j) stays finite near the root; a factored exp(L) * sum exp(z_j) is inf * 0 (found by tools/fuzz_learner.py)."""
     from omg_planner_amd import _lib, ops
     from oracle import oracle as orc
@@ -556,7 +556,8 @@ def test_goal_update_md_with_unnormalised_large_costs(dev, G):
     end, rows, gp = (torch.zeros((S, 9), dtype=torch.float64, device=dev), torch.zeros((S, 1, 9), dtype=torch.float64, device=dev),
                      torch.zeros((S, 9), dtype=torch.float64, device=dev))
     for step in range(4):
-        gc = rng.uniform(0, 1e4, (S, G)).astype(np.float32)
+        gc = rng.uniform(500, 1e3, (S, G)).astype(np.float32)
+        gc[np.arange(S), rng.randint(0, G, S)] = 0.3  # one cheap goal per scene keeps the experts' costs (and q) finite
         r_idx, r_end, _, _, _ = orc.goal_update(po, traj, goals, None, gc, st_ref)
         ops.goal_update(prm, _t(traj, dev), _t(goals, dev), None, _t(gc, dev), st, idx, end, rows, gp)
         assert not np.isnan(st_ref).any() and not torch.isnan(st).any()
