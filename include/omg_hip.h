@@ -340,7 +340,8 @@ int omgx_goal_update_optimize(const omgx_learner_params* h_learner, const double
  * the nearest of the N perceived points (scipy cKDTree.query, k=1, p=2) — unsigned, float64 arithmetic, stored as
  * the float32 grid SignedDensityField.data_torch holds (omg/sdf_tools.py:31), x-major like every other grid.
  *   points [N,3] double;  origin[3] = bounds_min - margin;  dims[3] = len(np.arange(...)) per axis;
- *   node (i,j,k) sits at origin + (i,j,k) * resolution (np.arange's start + i*step).   out [X,Y,Z] float32.
+ *   node i of an axis sits where np.arange puts it: origin, origin + resolution, then origin + i * ((origin + resolution) - origin)
+ *   (numpy's fill, which is not origin + i * resolution in the last bit).   out [X,Y,Z] float32.
  * ------------------------------------------------------------------------------------------- */
 int omgx_point_cloud_sdf(const double* points, int32_t num_points, const double* h_origin, double resolution,
                          const int32_t* h_dims, float* out, void* stream);

@@ -743,7 +743,13 @@ __global__ __launch_bounds__(256) void k_point_cloud_sdf(const double* __restric
     const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t idc = id < total ? id : total - 1;
     const int k = (int)(idc % dz), j = (int)((idc / dz) % dy), i = (int)(idc / ((int64_t)dz * dy));
-    const double x = ox + (double)i * res, y = oy + (double)j * res, z = oz + (double)k * res;  // np.arange: start + i*step
+    // np.arange(start, stop, step) fills start, start + step, then start + i * delta with delta = (start + step) - start
+    // (numpy's DOUBLE_fill) — not start + i * step: the two differ in the last bit for most nodes
+    auto node = [](double start, double step, int i) {
+        const double second = start + step, delta = second - start;
+        return i == 0 ? start : (i == 1 ? second : start + (double)i * delta);
+    };
+    const double x = node(ox, res, i), y = node(oy, res, j), z = node(oz, res, k);
     double best = 1.0e300;
     for (int t0 = 0; t0 < N; t0 += PCS_TILE) {
         const int cnt = min(PCS_TILE, N - t0);

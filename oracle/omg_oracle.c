@@ -895,7 +895,14 @@ int orc_point_cloud_sdf(const double* points, int32_t N, const double* origin, d
 #pragma omp parallel for schedule(static)
     for (int64_t id = 0; id < total; ++id) {
         const int k = (int)(id % dims[2]), j = (int)((id / dims[2]) % dims[1]), i = (int)(id / ((int64_t)dims[2] * dims[1]));
-        const double x = origin[0] + (double)i * res, y = origin[1] + (double)j * res, z = origin[2] + (double)k * res;
+        /* np.arange fills start, start + step, start + i * ((start + step) - start)  (numpy DOUBLE_fill) */
+        double xyz[3];
+        const int ijk[3] = {i, j, k};
+        for (int a = 0; a < 3; ++a) {
+            const double second = origin[a] + res, delta = second - origin[a];
+            xyz[a] = ijk[a] == 0 ? origin[a] : (ijk[a] == 1 ? second : origin[a] + (double)ijk[a] * delta);
+        }
+        const double x = xyz[0], y = xyz[1], z = xyz[2];
         double best = 1.0e300;
         for (int q = 0; q < N; ++q) {
             const double a = points[3 * q] - x, b = points[3 * q + 1] - y, c = points[3 * q + 2] - z;

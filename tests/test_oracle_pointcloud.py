@@ -21,5 +21,21 @@ def test_point_cloud_sdf_matches_ckdtree():
         ref, origin, dims = reference_grid(pts)
         got = orc.point_cloud_sdf(pts, origin, 0.02, dims)
         assert got.shape == ref.shape
-        assert (got == ref).mean() > 0.9999  # identical up to a last-ulp of the float64 distance flipping the float32 rounding
-        np.testing.assert_allclose(got, ref, rtol=0, atol=1e-7)
+        np.testing.assert_array_equal(got.view(np.int32), ref.view(np.int32))  # bit for bit (see the test below)
+
+
+def test_grid_nodes_follow_numpys_arange_fill():
+    """np.arange(start, stop, step) yields start, start + step, start + i * ((start + step) - start) — not start + i * step
+    (numpy's DOUBLE_fill).  With the naive nodes a few voxels per grid round differently (found by tools/fuzz_misc.py)."""
+    rng = np.random.RandomState(0)
+    naive_differs = 0
+    for _ in range(25):
+        n = int(rng.choice([1, 2, 17, 300]))
+        pts = rng.normal(0, rng.uniform(0.01, 0.3), (n, 3)) + rng.uniform(-1, 1, 3)
+        res, margin = float(rng.choice([0.02, 0.05, 0.013])), float(rng.choice([0.24, 0.05, 0.1]))
+        ref, origin, dims = reference_grid(pts, res, margin)
+        got = orc.point_cloud_sdf(pts, origin, res, dims)
+        np.testing.assert_array_equal(got.view(np.int32), ref.view(np.int32))
+        ax = np.arange(origin[0], pts[:, 0].max() + margin, res)
+        naive_differs += int((origin[0] + np.arange(len(ax)) * res != ax).sum())
+    assert naive_differs > 0
