@@ -234,26 +234,13 @@ def scene_arrays(scene, sdf, lim):
 
 
 # --------------------------------------------------------------------------------------------------
-def main():
-    config, cost_mod, opt_mod, util, rk = load_reference()
-    cfg = config.cfg
-    import torch
-    from importlib import import_module
-
-    sc = import_module("omg_planner_amd.scenes")
-    rb = import_module("omg_planner_amd.robot")
-    kin = make_kinematics(rk)
-    model = rb.PandaModel(seed=0)
-    rng = np.random.RandomState(7)
-    lo, hi = model.joint_lower_limit[0], model.joint_upper_limit[0]
-
-    # ---- (i) FK ---------------------------------------------------------------------------------
+def _fixed_fk_and_matrices(out_dir, cfg, kin, util, model, rng, lo, hi, rb):
     q = rng.uniform(lo, hi, size=(24, 9))
     q[0] = rb.HOME_CONFIG
     poses, org, ax = kin.forward_kinematics_parallel(util.wrap_values(q), return_joint_info=True)
     poses_no_info = kin.forward_kinematics_parallel(util.wrap_values(q))
     assert np.array_equal(poses, poses_no_info)
-    np.savez_compressed(OUT / "fk.npz", joints=q, poses=poses, joint_origins=org, joint_axis=ax,
+    np.savez_compressed(out_dir / "fk.npz", joints=q, poses=poses, joint_origins=org, joint_axis=ax,
                         collision_points=model.collision_points)
     print("fk.npz")
 
@@ -270,18 +257,46 @@ def main():
                 mats[tag + "_D2"] = cfg.diff_matrices[1]
                 mats[tag + "_A"] = cfg.A
                 mats[tag + "_Ainv"] = cfg.Ainv
-    np.savez_compressed(OUT / "matrices.npz", **mats)
+    np.savez_compressed(out_dir / "matrices.npz", **mats)
     print("matrices.npz")
+
+
+
+def main(out_dir=OUT, script=None):
+    """script=None regenerates the committed fixtures; otherwise script(ns) is called with the case generators
+    (ns.run_cost_case, ns.run_opt_case, ns.run_batch_case, ns.run_learner_case: same code, any parameters) writing into
+    out_dir — used by tools/fuzz_reference.py to check the oracle against the reference on random cases."""
+    fixed = script is None
+    config, cost_mod, opt_mod, util, rk = load_reference()
+    cfg = config.cfg
+    import torch
+    from importlib import import_module
+
+    sc = import_module("omg_planner_amd.scenes")
+    rb = import_module("omg_planner_amd.robot")
+    kin = make_kinematics(rk)
+    model = rb.PandaModel(seed=0)
+    rng = np.random.RandomState(7)
+    lo, hi = model.joint_lower_limit[0], model.joint_upper_limit[0]
+
+    # ---- (i) FK ---------------------------------------------------------------------------------
+    if fixed:
+        _fixed_fk_and_matrices(out_dir, cfg, kin, util, model, rng, lo, hi, rb)
 
     # ---- (ii)-(iv) cost path --------------------------------------------------------------------
     start = rb.HOME_CONFIG.copy()
     goal = np.array([0.3, 0.2, 0.1, -1.6, 0.1, 1.9, 1.0, 0.04, 0.04])
 
+    def cfg_record():  # the scalars of cfg that the totals / termination logic reads (cost.py:464-530, optimizer.py:137-174)
+        return dict(cfg_allow_collision_point=np.int64(cfg.allow_collision_point), cfg_pre_terminate=np.int64(cfg.pre_terminate),
+                    cfg_terminate_smooth_loss=np.float64(cfg.terminate_smooth_loss), cfg_clip_grad_scale=np.float64(cfg.clip_grad_scale),
+                    cfg_joint_limit_max_steps=np.int64(cfg.joint_limit_max_steps))
+
     def run_cost_case(name, scene_seed, n, top_k, goal_set_proj=True, uncheck=0, consider_finger=False, dt=None,
-                      attached=False, floor=False, wiggle=0.0, use_standoff=True, full=False):
+                      attached=False, floor=False, wiggle=0.0, use_standoff=True, full=False, cfg_over=None):
         reset_cfg(cfg, timesteps=n, top_k_collision=top_k, goal_set_proj=goal_set_proj,
                   uncheck_finger_collision=uncheck, consider_finger=consider_finger, use_standoff=use_standoff,
-                  **({"time_interval": dt} if dt else {}))
+                  **({"time_interval": dt} if dt else {}), **(cfg_over or {}))
         scene = small_scene(sc, scene_seed, attached=attached, floor=floor)
         env, sdf, lim = make_env(cfg, kin, model, scene)
         c = cost_mod.Cost(env)
@@ -313,26 +328,36 @@ def main():
                    cfg_dt=np.float64(cfg.time_interval),
                    cfg_obstacle_weight=np.float64(cfg.obstacle_weight), cfg_smoothness_weight=np.float64(cfg.smoothness_weight),
                    nonzero_potentials=np.int64((pot > 0).sum()))
+        out.update(cfg_record())
         if full:  # intermediate tensors of forward_kinematics_obstacle (large): kept for two cases only
             out.update(x=x, v=v, a=a, J=Jmax)
         out.update(scene_arrays(scene, sdf, lim))
         out.update(info_arrays(info, "info_"))
-        np.savez_compressed(OUT / f"cost_{name}.npz", **out)
+        np.savez_compressed(out_dir / f"cost_{name}.npz", **out)
         print(f"cost_{name}.npz  nonzero potentials {int((pot > 0).sum())}/{pot.size}  collide {float(col)}")
 
-    run_cost_case("topk1000", 1, 30, 1000, full=True)
-    run_cost_case("topk300", 2, 30, 300, wiggle=0.02)          # cut falls among non-zero potentials
-    run_cost_case("clean", 3, 30, 0, wiggle=0.02)              # top_k == 0 branch
-    run_cost_case("fixed_end", 4, 30, 1000, goal_set_proj=False)
-    run_cost_case("soft_finger", 5, 30, 1000, uncheck=-1, floor=True)
-    run_cost_case("finger_n50", 6, 50, 400, consider_finger=True, dt=0.06, wiggle=0.01)
-    run_cost_case("attached", 7, 30, 1000, attached=True)
-    run_cost_case("short_n5", 8, 5, 1000, use_standoff=False, full=True)  # fewer than top_k points in total
+    if fixed:
+        run_cost_case("topk1000", 1, 30, 1000, full=True)
+    if fixed:
+        run_cost_case("topk300", 2, 30, 300, wiggle=0.02)          # cut falls among non-zero potentials
+    if fixed:
+        run_cost_case("clean", 3, 30, 0, wiggle=0.02)              # top_k == 0 branch
+    if fixed:
+        run_cost_case("fixed_end", 4, 30, 1000, goal_set_proj=False)
+    if fixed:
+        run_cost_case("soft_finger", 5, 30, 1000, uncheck=-1, floor=True)
+    if fixed:
+        run_cost_case("finger_n50", 6, 50, 400, consider_finger=True, dt=0.06, wiggle=0.01)
+    if fixed:
+        run_cost_case("attached", 7, 30, 1000, attached=True)
+    if fixed:
+        run_cost_case("short_n5", 8, 5, 1000, use_standoff=False, full=True)  # fewer than top_k points in total
 
     # ---- (v) optimiser sequences ----------------------------------------------------------------
-    def run_opt_case(name, scene_seed, n, steps, use_standoff, goal_set_proj=True, top_k=1000, bad_limits=False, dt=None):
+    def run_opt_case(name, scene_seed, n, steps, use_standoff, goal_set_proj=True, top_k=1000, bad_limits=False, dt=None,
+                     force_update=True, cfg_over=None, at_goal=False):
         reset_cfg(cfg, timesteps=n, top_k_collision=top_k, goal_set_proj=goal_set_proj, use_standoff=use_standoff,
-                  **({"time_interval": dt} if dt else {}))
+                  **({"time_interval": dt} if dt else {}), **(cfg_over or {}))
         scene = small_scene(sc, scene_seed)
         env, sdf, lim = make_env(cfg, kin, model, scene)
         r = np.random.RandomState(200 + scene_seed)
@@ -341,6 +366,8 @@ def main():
         reach = np.concatenate([reach, g[None]], 0)  # [5,9] standoff tail ending at the goal
         env.objects[env.target_idx].reach_grasps = np.array([reach, reach + 0.02])
         xi = sc.cubic_init(start, g, n)
+        if at_goal:  # a short trajectory that already ends within 1 cm of its goal: info["terminate"] can become true
+            xi = g[None] + (xi - g[None]) * 0.2
         if bad_limits:  # push some waypoints outside the soft limits to trigger handle_joint_limit
             xi[n // 3: n // 3 + 4, 1] = hi[1] + 0.3
             xi[n // 2: n // 2 + 3, 3] = lo[3] - 0.25
@@ -352,7 +379,7 @@ def main():
         infos = []
         sched = []
         for _ in range(steps):
-            info = opt.optimize(traj, force_update=True)
+            info = opt.optimize(traj, force_update=force_update)
             sched.append([cfg.obstacle_weight, cfg.smoothness_weight, cfg.step_size])
             hist.append(np.array(traj.data).copy())
             infos.append(info)
@@ -363,19 +390,26 @@ def main():
                    reach_grasps=env.objects[env.target_idx].reach_grasps, collision_points=model.collision_points,
                    schedule=np.array(sched), joint_lower_limit=model.joint_lower_limit, joint_upper_limit=model.joint_upper_limit,
                    cfg_top_k=np.int64(top_k), cfg_goal_set_proj=np.int64(goal_set_proj), cfg_use_standoff=np.int64(use_standoff),
-                   cfg_dt=np.float64(cfg.time_interval), cfg_reach_tail_length=np.int64(cfg.reach_tail_length))
+                   cfg_dt=np.float64(cfg.time_interval), cfg_reach_tail_length=np.int64(cfg.reach_tail_length),
+                   cfg_force_update=np.int64(force_update))
+        out.update(cfg_record())
         for k in INFO_NUMERIC + INFO_BOOL:
             out["info_" + k] = np.array([float(i[k]) for i in infos])
         out["info_gradient"] = np.stack([i["gradient"] for i in infos])
         out.update(scene_arrays(scene, sdf, lim))
-        np.savez_compressed(OUT / f"opt_{name}.npz", **out)
+        np.savez_compressed(out_dir / f"opt_{name}.npz", **out)
         print(f"opt_{name}.npz  final cost {infos[-1]['cost']:.4f} collide {infos[-1]['collide']}")
 
-    run_opt_case("standoff_20", 11, 30, 20, True)
-    run_opt_case("nostandoff_20", 12, 30, 20, False)
-    run_opt_case("fixed_end_5", 13, 30, 5, False, goal_set_proj=False)
-    run_opt_case("limits_5", 14, 30, 5, True, bad_limits=True)
-    run_opt_case("n50_dt006_5", 15, 50, 5, False, dt=0.06, top_k=500)
+    if fixed:
+        run_opt_case("standoff_20", 11, 30, 20, True)
+    if fixed:
+        run_opt_case("nostandoff_20", 12, 30, 20, False)
+    if fixed:
+        run_opt_case("fixed_end_5", 13, 30, 5, False, goal_set_proj=False)
+    if fixed:
+        run_opt_case("limits_5", 14, 30, 5, True, bad_limits=True)
+    if fixed:
+        run_opt_case("n50_dt006_5", 15, 50, 5, False, dt=0.06, top_k=500)
 
     # ---- (vi),(viii) batch_obstacle_cost / cost_vector reduction ----------------------------------
     def run_batch_case(name, scene_seed, G, n_rem, arc, uncheck, attached=False, floor=False):
@@ -395,12 +429,12 @@ def main():
                    goal_cost=torch.sum(torch.from_numpy(pot), (-2, -1)).reshape([-1, n_rem]).sum(-1).numpy(),
                    collision_points=model.collision_points, cfg_dt=np.float64(cfg.time_interval))
         out.update(scene_arrays(scene, sdf, lim))
-        np.savez_compressed(OUT / f"batch_{name}.npz", **out)
+        np.savez_compressed(out_dir / f"batch_{name}.npz", **out)
         print(f"batch_{name}.npz  goal_cost {out['goal_cost'][:4]}")
 
     # ---- (f-1) Learner.update_goal: cost_vector + FTL / FTC / Exp / MD (omg/online_learner.py) ----------
-    def run_learner_case(alg, scene_seed, G, steps, use_standoff, spread=0.12, tag=""):
-        reset_cfg(cfg, timesteps=30, ol_alg=alg, use_standoff=use_standoff)
+    def run_learner_case(alg, scene_seed, G, steps, use_standoff, spread=0.12, tag="", cfg_over=None):
+        reset_cfg(cfg, timesteps=30, ol_alg=alg, use_standoff=use_standoff, **(cfg_over or {}))
         scene = small_scene(sc, scene_seed)
         env, sdf, lim = make_env(cfg, kin, model, scene)
         r = np.random.RandomState(400 + scene_seed)
@@ -415,7 +449,9 @@ def main():
         rec = dict(goal_set=goals, reach_grasps=reach, traj=np.array(traj.data), start=start, collision_points=model.collision_points,
                    init_goal_idx=np.int64(traj.goal_idx), eta=np.float64(learner.eta), alg=np.array(alg),
                    cfg_dt=np.float64(cfg.time_interval), cfg_use_standoff=np.int64(use_standoff), optim_steps=np.int64(cfg.optim_steps),
-                   dist_eps=np.float64(cfg.dist_eps))
+                   dist_eps=np.float64(cfg.dist_eps), cfg_normalize_cost=np.int64(cfg.normalize_cost),
+                   cfg_base_obstacle_weight=np.float64(cfg.base_obstacle_weight),
+                   cfg_smoothness_base_weight=np.float64(cfg.smoothness_base_weight))
         cvs, ps, idxs, qs, trajs = [], [], [], [], []
         for k in range(steps):
             # move the trajectory between calls (as the optimiser would) so the cost vectors change
@@ -430,19 +466,29 @@ def main():
         rec.update(trajs=np.stack(trajs), cost_vectors=np.stack(cvs), p=np.stack(ps), goal_idx=np.array(idxs), q=np.stack(qs), sum_costs=np.array(learner.sum_costs),
                    experts_p=np.stack(learner.experts_p), final_t=np.float64(learner.t))
         rec.update(scene_arrays(scene, sdf, lim))
-        np.savez_compressed(OUT / f"learner_{alg}_{int(use_standoff)}{tag}.npz", **rec)
+        np.savez_compressed(out_dir / f"learner_{alg}_{int(use_standoff)}{tag}.npz", **rec)
         print(f"learner_{alg}_{int(use_standoff)}{tag}.npz  goal_idx {idxs}")
 
-    for alg in ("FTL", "FTC", "Exp", "MD"):
+    for alg in (("FTL", "FTC", "Exp", "MD") if fixed else ()):
         run_learner_case(alg, 31, 8, 6, False)
-    run_learner_case("MD", 32, 12, 8, True)
-    run_learner_case("FTC", 33, 8, 8, False, spread=0.015, tag="_close")
-    run_learner_case("MD", 34, 8, 8, False, spread=0.015, tag="_close")
+    if fixed:
+        run_learner_case("MD", 32, 12, 8, True)
+    if fixed:
+        run_learner_case("FTC", 33, 8, 8, False, spread=0.015, tag="_close")
+    if fixed:
+        run_learner_case("MD", 34, 8, 8, False, spread=0.015, tag="_close")
 
-    run_batch_case("arc_g6_n30", 21, 6, 30, True, 0)
-    run_batch_case("arc_g5_n7", 22, 5, 7, True, 0, floor=True)
-    run_batch_case("noarc_soft_g8", 23, 8, 1, False, -1)
-    run_batch_case("arc_attached_g4_n12", 24, 4, 12, True, 0, attached=True)
+    if fixed:
+        run_batch_case("arc_g6_n30", 21, 6, 30, True, 0)
+    if fixed:
+        run_batch_case("arc_g5_n7", 22, 5, 7, True, 0, floor=True)
+    if fixed:
+        run_batch_case("noarc_soft_g8", 23, 8, 1, False, -1)
+    if fixed:
+        run_batch_case("arc_attached_g4_n12", 24, 4, 12, True, 0, attached=True)
+    if script is not None:
+        script(types.SimpleNamespace(run_cost_case=run_cost_case, run_opt_case=run_opt_case, run_batch_case=run_batch_case,
+                                     run_learner_case=run_learner_case, cfg=cfg, sc=sc, model=model))
 
 
 if __name__ == "__main__":

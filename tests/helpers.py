@@ -50,16 +50,16 @@ def params_from(fx: dict, params_cls, n: int, P: int, do_update: int, obstacle_w
     p.use_standoff = int(fx["cfg_use_standoff"])
     p.constraint_num = reach_tail_length if p.use_standoff else 1
     p.uncheck_finger_collision = int(fx.get("cfg_uncheck", 0))
-    p.joint_limit_max_steps = 10
-    p.allow_collision_point = 5
-    p.pre_terminate = 1
+    p.joint_limit_max_steps = int(fx.get("cfg_joint_limit_max_steps", 10))
+    p.allow_collision_point = int(fx.get("cfg_allow_collision_point", 5))
+    p.pre_terminate = int(fx.get("cfg_pre_terminate", 1))
     p.do_update = do_update
     p.time_interval = float(fx["cfg_dt"])
     p.obstacle_weight = obstacle_weight
     p.smoothness_weight = smoothness_weight
     p.step_size = step_size
-    p.clip_grad_scale = 10.0
-    p.terminate_smooth_loss = 35.0
+    p.clip_grad_scale = float(fx.get("cfg_clip_grad_scale", 10.0))
+    p.terminate_smooth_loss = float(fx.get("cfg_terminate_smooth_loss", 35.0))
     for d in range(9):
         p.link_smooth_weight[d] = 1.0
     return p

@@ -96,7 +96,8 @@ def test_optimizer_steps_match_reference(case):
     free = hist[0].copy()
     for k in range(steps + 1):
         w_obs, w_sm, eta = fx["schedule"][k]
-        do_update = 1 if k < steps else 0
+        # force_update=False (cfg_force_update 0): a terminated trajectory is returned untouched -> do_update 2
+        do_update = (1 if int(fx.get("cfg_force_update", 1)) else 2) if k < steps else 0
         prm = H.params_from(fx, orc.ChompParams, n, P, do_update, w_obs, w_sm, eta, int(fx["cfg_reach_tail_length"]))
         goal, goal_point = _opt_step_inputs(fx, k)
         for mode, x0 in (("forced", hist[k]), ("free", free)):

@@ -18,9 +18,9 @@ def learner_params(fx, t):
     p.start_idx = min(int((t / int(fx["optim_steps"])) * n), n - 1)
     p.use_standoff = int(fx["cfg_use_standoff"])
     p.constraint_num = fx["reach_grasps"].shape[1] if p.use_standoff else 1
-    p.normalize_cost = 1
-    p.base_obstacle_weight = 1.0
-    p.smooth_weight = 0.1 * float(fx["dist_eps"])
+    p.normalize_cost = int(fx.get("cfg_normalize_cost", 1))
+    p.base_obstacle_weight = float(fx.get("cfg_base_obstacle_weight", 1.0))
+    p.smooth_weight = float(fx.get("cfg_smoothness_base_weight", 0.1)) * float(fx["dist_eps"])
     p.eta = float(fx["eta"])
     return p
 
