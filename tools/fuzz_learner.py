@@ -94,9 +94,9 @@ def trial(rng, dev):
     return errs, f"S={S} G={G} n={n} alg={alg} standoff={standoff} c={c} steps={steps} norm={base['normalize_cost']}"
 
 
-def main():
-    trials = int(sys.argv[1]) if len(sys.argv) > 1 else 50
-    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+def main(trials=None, seed=None):
+    trials = int(trials if trials is not None else (sys.argv[1] if len(sys.argv) > 1 else 50))
+    seed = int(seed if seed is not None else (sys.argv[2] if len(sys.argv) > 2 else 0))
     rng = np.random.RandomState(seed)
     dev = torch.device("cuda:0")
     bad, t0 = 0, time.time()

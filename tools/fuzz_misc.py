@@ -16,9 +16,9 @@ from omg_planner_amd import ops, robot as rb, scenes as sc
 from oracle import oracle as orc
 
 
-def main():
-    trials = int(sys.argv[1]) if len(sys.argv) > 1 else 50
-    rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+def main(trials=None, seed=None):
+    trials = int(trials if trials is not None else (sys.argv[1] if len(sys.argv) > 1 else 50))
+    rng = np.random.RandomState(int(seed if seed is not None else (sys.argv[2] if len(sys.argv) > 2 else 0)))
     dev = torch.device("cuda:0")
     bad, t0, voxels = 0, time.time(), 0
     for k in range(trials):

@@ -121,9 +121,9 @@ def one_trial(rng, trial, dev, dry=False):
     return None, worst
 
 
-def main():
-    trials = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+def main(trials=None, seed=None):
+    trials = int(trials if trials is not None else (sys.argv[1] if len(sys.argv) > 1 else 40))
+    seed = int(seed if seed is not None else (sys.argv[2] if len(sys.argv) > 2 else 0))
     rng = np.random.RandomState(seed)
     dev = torch.device("cuda:0")
     bad, t0, worst_all = 0, time.time(), 0.0
