@@ -173,7 +173,8 @@ def test_goalset_cost_matches_reference_fixture(dev, case):
     n, G = int(fx["n_remaining"]), fx["goals"].shape[0]
     ds = ops.DeviceScenes(H.batch_from(fx), dev)
     cost, col, pots = ops.goalset_cost(ops.robot_blob(m, dev), m.points_per_link, ds, _t(fx["traj_start"][None], dev),
-                                       _t(fx["goals"][None], dev), n, float(fx["cfg_dt"]), want_potentials=True)
+                                       _t(fx["goals"][None], dev), n, float(fx["cfg_dt"]), soften_fingers=int(fx["uncheck"]) == -1,
+                                       want_potentials=True)
     ref = fx["potentials"].reshape(G, n, 10, -1)
     np.testing.assert_allclose(pots[0].cpu().numpy(), ref, rtol=2e-5, atol=2e-6)
     np.testing.assert_allclose(cost[0].cpu().numpy(), fx["goal_cost"], rtol=1e-5, atol=1e-6)  # north_star: 1e-4
@@ -249,7 +250,7 @@ def test_optimizer_sequence_matches_reference_fixture(dev, case):
     free = _t(hist[0][None], dev)
     for k in range(steps + 1):
         w_obs, w_sm, eta = fx["schedule"][k]
-        upd = 1 if k < steps else 0
+        upd = (1 if int(fx.get("cfg_force_update", 1)) else 2) if k < steps else 0  # force_update=False -> do_update 2
         prm = H.params_from(fx, _lib.ChompParams, n, P, upd, w_obs, w_sm, eta, int(fx["cfg_reach_tail_length"]))
         for mode in ("forced", "free"):
             traj = _t(hist[k][None], dev) if mode == "forced" else free
@@ -330,6 +331,9 @@ def _cfg_from(fx, n):
                  uncheck_finger_collision=int(fx.get("cfg_uncheck", 0)))
     cfg.time_interval = float(fx["cfg_dt"])
     cfg._mats = None
+    for key in ("allow_collision_point", "pre_terminate", "terminate_smooth_loss", "clip_grad_scale", "joint_limit_max_steps"):
+        if "cfg_" + key in fx:  # fixtures from tools/make_random_fixtures.py vary them
+            setattr(cfg, key, type(getattr(cfg, key))(fx["cfg_" + key]))
     return cfg
 
 
@@ -404,7 +408,7 @@ def test_optimizer_class_matches_reference_fixture(dev, case):
     opt = Optimizer(types.SimpleNamespace(config=cfg, robot=env.robot), cost)
     traj = _Traj(hist[0], fx["start"], fx["end"], fx["goal_set"], int(fx["goal_idx"]))
     for k in range(steps):
-        info = opt.optimize(traj, force_update=True)
+        info = opt.optimize(traj, force_update=bool(int(fx.get("cfg_force_update", 1))))
         np.testing.assert_allclose(traj.data, hist[k + 1], rtol=0, atol=1e-6, err_msg=f"step {k}")
         np.testing.assert_allclose(info["cost"], fx["info_cost"][k], rtol=1e-5, err_msg=f"step {k}")
         assert bool(info["violate_limit"]) == bool(fx["info_violate_limit"][k])
