@@ -106,6 +106,7 @@ class ChompEngine:
         self._ev_join = torch.cuda.Event()
         self._scene_flags = torch.zeros(S, dtype=torch.int32, device=dev)  # omgx_goal_update_optimize's rendezvous
         self._ticket = 0
+        self._num_cus = torch.cuda.get_device_properties(dev).multi_processor_count
         self._gather_goal()
 
     # ---------------------------------------------------------------------------------------------
@@ -202,7 +203,9 @@ class ChompEngine:
 
     def _step(self, do_update: bool, learner_prm=None):
         if learner_prm is not None:  # goal update + step in one launch
-            split = not os.environ.get("OMGX_NO_SPLIT_UPDATE")  # learner and step in different workgroups of the launch
+            # learner and step in different workgroups of the launch: pays while both sets are resident at once (one
+            # 92 KB-LDS workgroup per CU); beyond that the single-workgroup kernel is a little faster (measured at 200 / 400 scenes)
+            split = not os.environ.get("OMGX_NO_SPLIT_UPDATE") and (2 * self.S <= self._num_cus or os.environ.get("OMGX_FORCE_SPLIT_UPDATE"))
             self._ticket += 1
             ops.goal_update_optimize(learner_prm, self.goal_set, self.reach, self.goal_cost, self.learner_state, self.goal_idx,
                                      self.robot, self._params(do_update), self.traj, self.start, self.end, self.goal_rows,

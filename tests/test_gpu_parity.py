@@ -722,9 +722,11 @@ def test_split_update_with_more_scenes_than_compute_units(dev, monkeypatch):
     outs = []
     for split in (True, False):
         monkeypatch.setenv("OMGX_ITERATION", "fused")
-        if split:
+        if split:  # the engine would not split this many scenes by itself
             monkeypatch.delenv("OMGX_NO_SPLIT_UPDATE", raising=False)
+            monkeypatch.setenv("OMGX_FORCE_SPLIT_UPDATE", "1")
         else:
+            monkeypatch.delenv("OMGX_FORCE_SPLIT_UPDATE", raising=False)
             monkeypatch.setenv("OMGX_NO_SPLIT_UPDATE", "1")
         eng = ChompEngine(m, batch, copy.deepcopy(cfg0), start, goals, device=dev, ol_alg="MD")
         for t in range(3):
