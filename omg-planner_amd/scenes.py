@@ -74,7 +74,8 @@ def influence_range(grid: np.ndarray, epsilon: float, clearance: float):
     if min(g.shape) < 2:
         return None
     for ax in range(3):  # prepend the extended layer f = -1 on every axis
-        first = np.take(g, [0], axis=ax) * 2.0 - np.take(g, [1], axis=ax)
+        with np.errstate(invalid="ignore"):  # inf - inf of non-finite voxels: NaN, counted as reachable below
+            first = np.take(g, [0], axis=ax) * 2.0 - np.take(g, [1], axis=ax)
         g = np.concatenate([first, g], axis=ax)
     bad = ~np.isfinite(g)
     g = np.where(bad, -np.inf, g)
