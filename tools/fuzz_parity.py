@@ -19,7 +19,7 @@ from omg_planner_amd.engine import ChompEngine
 from oracle import oracle as orc
 
 
-STATS = {"limit_steps": 0, "violations": 0}
+STATS = {"limit_steps": 0, "violations": 0, "stopped": 0}
 
 
 def random_scene(rng, seed, grid):
@@ -56,6 +56,9 @@ def one_trial(rng, trial, dev, dry=False):
     cfg.allow_collision_point = int(rng.choice([5, 0, 50]))
     cfg.goal_set_proj = bool(rng.rand() < 0.85)  # False: fixed end, plain -eta Ainv g step, no goal selection
     wild = rng.rand() < 0.25                     # start far from home: joint-limit projection kicks in
+    early = bool(rng.rand() < 0.3)               # planner.py:627: terminated scenes stop iterating (active mask)
+    if early:
+        cfg.allow_collision_point = 10_000        # so that some scenes do terminate
     cfg.get_global_param(n)
     grid = int(rng.choice([20, 24, 32]))
     print(f"  trial {trial}: S={S} G={G} n={n} P={P} alg={alg} standoff={standoff} iters={iters} optim_steps={cfg.optim_steps} "
@@ -83,10 +86,12 @@ def one_trial(rng, trial, dev, dry=False):
     end, rows, gp = eng.end.cpu().numpy().copy(), eng.goal_rows.cpu().numpy().copy(), eng.goal_point.cpu().numpy().copy()
     blob = m.blob()
     worst = 0.0
+    active = np.ones(S, np.int32)
+    info = np.zeros((S, 16))
     for t in range(iters):
         if os.environ.get("OMGX_FUZZ_DEBUG"):
             print(f"    iterate {t}", flush=True)
-        eng.iterate(t)
+        eng.iterate(t, early_stop=early)
         if os.environ.get("OMGX_FUZZ_DEBUG"):
             torch.cuda.synchronize()
         idx = None
@@ -106,14 +111,20 @@ def one_trial(rng, trial, dev, dry=False):
         for f, _ in po._fields_:
             setattr(po, f, getattr(src, f))
         pot, pg, col = orc.fk_sdf(blob, P, batch, traj, soften_fingers=cfg.uncheck_finger_collision == -1)
-        traj, _, _, info = orc.chomp_optimize(blob, po, traj, start, end, rows, gp, pot, pg, col)
+        traj, _, _, info_new = orc.chomp_optimize(blob, po, traj, start, end, rows, gp, pot, pg, col, active)
+        info = np.where(active[:, None] > 0, info_new, info)  # an inactive scene keeps its last info record
+        if early and t > 0:
+            active = active * (info[:, 10] < 0.5).astype(np.int32)
+            STATS["stopped"] += int((active == 0).sum())
         STATS["limit_steps"] += int(info[:, 15].sum())
         STATS["violations"] += int(info[:, 14].sum())
         if idx is not None and not np.array_equal(eng.goal_idx.cpu().numpy(), idx):
             return f"goal index mismatch at iteration {t}: {eng.goal_idx.cpu().numpy()} vs {idx}", worst
         d = float(np.abs(eng.traj.cpu().numpy() - traj).max())
         worst = max(worst, d)
-        if not d <= 1e-6:
+        # free-running: last-bit differences of the float64 kinematics flip a float32 point now and then and the loop feeds
+        # them back; 1e-6 holds for ~10 iterations, the bar of the task (north_star) is 1e-4
+        if not d <= (1e-6 if t < 10 else 1e-5):
             return f"trajectory differs by {d:.3e} at iteration {t}", worst
         gi, oi = eng.info.cpu().numpy()[:, :10], info[:, :10]
         if not np.allclose(gi, oi, rtol=1e-5, atol=1e-6):
@@ -141,7 +152,7 @@ def main(trials=None, seed=None):
         else:
             print(f"trial {k}: ok, max |traj - oracle| {worst:.2e}", flush=True)
     print(f"{trials - bad}/{trials} trials agree; worst trajectory difference {worst_all:.2e}; joint-limit projection steps "
-          f"{STATS['limit_steps']}, limit-violation flags {STATS['violations']}; {time.time() - t0:.0f} s")
+          f"{STATS['limit_steps']}, limit-violation flags {STATS['violations']}, scene-iterations skipped after termination {STATS['stopped']}; {time.time() - t0:.0f} s")
     return 1 if bad else 0
 
 
