@@ -569,6 +569,26 @@ def test_goal_update_md_with_unnormalised_large_costs(dev, G):
         np.testing.assert_allclose(st.cpu().numpy(), st_ref, rtol=1e-5, atol=1e-8, err_msg=f"step {step}")
 
 
+def test_goal_collision_stats_match_oracle(dev):
+    """Planner.setup_goal_set's collision filter (planner.py:512-524) for several scenes at once: per-goal collision counts
+    (exact) and potential sums of the softened-finger layer against the oracle."""
+    from omg_planner_amd import ops, robot as rb, scenes as sc
+    from omg_planner_amd.goalset import goal_collision_stats, select_goals
+    from oracle import oracle as orc
+    S, G0 = 4, 90
+    m = rb.PandaModel(seed=10)
+    scenes, batch = _multi_scene_batch(S)
+    goals = np.stack([sc.make_reach_goals(scenes[s], m, G0, 50 + s) for s in range(S)])
+    goals[:, ::3, :7] += np.random.RandomState(1).normal(0, 0.25, (S, len(range(0, G0, 3)), 7))  # some goals inside obstacles
+    col, pot = goal_collision_stats(ops.robot_blob(m, dev), m.points_per_link, ops.DeviceScenes(batch, dev), _t(goals, dev))
+    rp, _, rc = orc.fk_sdf(m.blob(), m.points_per_link, batch, goals, soften_fingers=True)
+    np.testing.assert_array_equal(col.cpu().numpy(), rc.sum(axis=(-2, -1)))
+    np.testing.assert_allclose(pot.cpu().numpy(), rp.sum(axis=(-2, -1)), rtol=1e-5, atol=1e-6)
+    assert (rc.sum(axis=(-2, -1)) > 5).any() and (rc.sum(axis=(-2, -1)) <= 5).any()
+    grasps, _, _, chosen = select_goals(list(goals[0]), None, col[0].cpu().numpy(), pot[0].cpu().numpy(), rng=np.random.RandomState(3))
+    assert len(grasps) == len(chosen) > 0
+
+
 # ------------------------------------------------------------------------------------------------
 # (7) the whole planner loop: ChompEngine against the same loop driven through the oracle
 # ------------------------------------------------------------------------------------------------

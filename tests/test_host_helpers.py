@@ -83,3 +83,26 @@ def test_cost_numpy_helpers_match_reference_intermediates():
     _, grad, _, _ = orc.chomp_optimize(m.blob(), prm, fx["xi"][None], fx["start"][None], fx["end"][None], fx["end"][None, None],
                                        fx["end"][None], fx["potentials"][None], fx["potential_grads"][None], col)
     np.testing.assert_allclose(total, grad[0], rtol=1e-9, atol=1e-9)
+
+
+def test_select_goals_mirrors_setup_goal_set_quirks():
+    """planner.py:526-575: collision threshold, greedy diversity with the j / j+1 index quirk, sampling from np.random."""
+    from omg_planner_amd.goalset import select_goals
+    goals = [np.full(9, v, float) for v in (0.0, 0.05, 1.0, 1.02, 2.0, 3.0)]
+    reach = [g[None] + 0.0 for g in goals]
+    collide = np.array([0, 0, 9, 0, 5, 6])           # goals 2 and 5 collide too much (allow 5)
+    pots = np.arange(6, dtype=np.float32)
+    # survivors: goals 0, 1, 3, 4 -> filtered list [0.0, 0.05, 1.02, 2.0]; diversity keeps 0.0 (seed), drops 0.05 (too close),
+    # keeps 1.02 and 2.0 but records j = 1 and j = 2 (indices of 0.05 and 1.02 in the filtered list): the reference's quirk
+    rng = np.random.RandomState(0)
+    grasps, r, p, chosen = select_goals(goals, reach, collide, pots, rng=rng)
+    assert sorted(int(c) for c in chosen) == [1, 2]
+    assert sorted(float(g[0]) for g in grasps) == [0.05, 1.02]
+    np.testing.assert_array_equal(np.sort(p), [1.0, 3.0])
+    # same numpy stream -> same order as np.random.choice on [1, 2]
+    np.testing.assert_array_equal(chosen, np.random.RandomState(0).choice([1, 2], 2, replace=False))
+    # without the diversity filter every collision-free goal is a candidate; the cap applies
+    g2, _, _, c2 = select_goals(goals, reach, collide, pots, goal_set_max_num=3, filter_diversity=False, rng=np.random.RandomState(1))
+    assert len(g2) == 3 and set(int(c) for c in c2) <= {0, 1, 2, 3}
+    # nothing survives
+    assert select_goals(goals, reach, np.full(6, 99), pots) == ([], [], [], [])
