@@ -477,6 +477,28 @@ def test_goal_update_matches_reference_learner_fixture(dev, case):
             np.testing.assert_allclose(state[0, 7 * G:7 * G + 5].cpu().numpy(), fx["q"][k], rtol=1e-4, atol=1e-7)
 
 
+@pytest.mark.parametrize("case", ["FTL_0", "MD_1", "FTC_0_close"])
+def test_engine_initial_goal_matches_reference_learner_init(dev, case):
+    """ChompEngine.select_initial_goal = Learner.__init__ (online_learner.py:96-102): argmin of the t = 0 cost vector on the
+    initial trajectory, traj.end <- that goal, clamped-cubic re-interpolation (Trajectory.interpolate_waypoints)."""
+    from omg_planner_amd import scenes as sc
+    from omg_planner_amd.config import Config
+    from omg_planner_amd.engine import ChompEngine
+    fx = H.load(f"learner_{case}.npz")
+    standoff = bool(int(fx["cfg_use_standoff"]))
+    cfg = Config(timesteps=30, use_standoff=standoff)
+    eng = ChompEngine(H.model_from(fx), H.batch_from(fx), cfg, fx["start"][None], fx["goal_set"][None],
+                      reach_grasps=fx["reach_grasps"][None] if standoff else None, traj_init=fx["traj"][None], device=dev,
+                      ol_alg=str(fx["alg"]))
+    state0 = eng.learner_state.clone()
+    eng.select_initial_goal()
+    gi = int(fx["init_goal_idx"])
+    assert int(eng.goal_idx[0]) == gi
+    np.testing.assert_array_equal(eng.end[0].cpu().numpy(), fx["goal_set"][gi])
+    np.testing.assert_allclose(eng.traj[0].cpu().numpy(), sc.cubic_init(fx["start"], fx["goal_set"][gi], 30), rtol=0, atol=1e-12)
+    assert torch.equal(eng.learner_state, state0) and eng.t == 0  # the pick leaves the learner untouched
+
+
 @pytest.mark.parametrize("alg,G", [("MD", 64), ("Exp", 100), ("FTL", 200), ("Proj", 33), ("MD", 130)])
 def test_goal_update_matches_oracle_many_scenes(dev, alg, G):
     from omg_planner_amd import _lib, ops

@@ -97,3 +97,19 @@ def test_degenerate_cost_vector_selects_like_numpy(alg):
     assert np.isnan(cv).all()
     assert idx[0] == 0 == int(np.argmin(cv[0])) == int(np.argmax(cv[0]))
     np.testing.assert_array_equal(end[0], goals[0, 0])
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_initial_goal_pick_matches_reference_learner_init(case):
+    """Learner.__init__ (online_learner.py:96-102): one cost_vector at t = 0 on the initial trajectory, goal = argmin."""
+    fx = H.load(f"learner_{case}.npz")
+    m = H.model_from(fx)
+    cv_goals = fx["reach_grasps"][:, -1, :] if int(fx["cfg_use_standoff"]) else fx["goal_set"]
+    prm = learner_params(fx, 0)
+    prm.alg = orc.ALG["FTC"]  # argmin of the cost vector, no state
+    n = prm.n_waypoints
+    cost, _ = orc.goalset_cost(m.blob(), m.points_per_link, H.batch_from(fx), fx["traj"][0][None], cv_goals[None], n, float(fx["cfg_dt"]))
+    state = orc.learner_state_init(1, fx["goal_set"].shape[0])
+    idx, end, _, _, _ = orc.goal_update(prm, fx["traj"][None], fx["goal_set"][None], fx["reach_grasps"][None], cost, state)
+    assert int(idx[0]) == int(fx["init_goal_idx"])
+    np.testing.assert_array_equal(end[0], fx["goal_set"][int(fx["init_goal_idx"])])
