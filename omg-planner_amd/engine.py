@@ -230,7 +230,9 @@ class ChompEngine:
             with torch.cuda.stream(self.stream):
                 return self.iterate(t, early_stop, overlap)
         cfg = self.cfg
-        select = cfg.goal_set_proj and t < cfg.optim_steps
+        # planner.py:609-618: the learner runs only for the online-learning rules; "Proj" and "Baseline" keep the goal that
+        # was fixed before planning (select_initial_goal)
+        select = cfg.goal_set_proj and t < cfg.optim_steps and self.ol_alg not in ("Baseline", "Proj")
         if os.environ.get("OMGX_NO_OVERLAP"):  # profiling aid: device-wide PMC counters need kernels one at a time
             overlap = False
         mode = os.environ.get("OMGX_ITERATION", "fused")  # fused | streams | serial (A/B measurements)
@@ -267,6 +269,21 @@ class ChompEngine:
         """Learner.__init__ (online_learner.py:96-102): before planning, pick the cheapest goal by one cost_vector
         evaluation at t = 0 and re-interpolate the trajectory towards it (Trajectory.interpolate_waypoints, cubic)."""
         if self.ol_alg in ("Proj", "Baseline"):
+            # planner.py:200-222 (goal setup before planning): "Proj" takes the goal closest to the START in the
+            # link_smooth_weight metric, "Baseline" cfg.goal_idx (>= 0: that goal; the default -2: goal 0; -1 would need the
+            # grasp potentials of the scene file, which the engine does not carry: goal 0); then traj.end and the cubic init
+            if self.ol_alg == "Proj":
+                w = torch.as_tensor(np.broadcast_to(np.asarray(self.cfg.link_smooth_weight, np.float64).ravel(), (9,)).copy(),
+                                    dtype=torch.float64, device=self.device)
+                d = torch.linalg.norm((self.start[:, None, :] - self.goal_set) * w, dim=-1)
+                self.goal_idx.copy_(torch.argmin(d, dim=1).to(torch.int32))
+            else:
+                gi = int(getattr(self.cfg, "goal_idx", -2))
+                self.goal_idx.fill_(gi if 0 <= gi < self.G else 0)
+            self._gather_goal()
+            tt = (torch.arange(1, self.n + 1, device=self.device, dtype=torch.float64) / (self.n + 1.0))[None, :, None]
+            h = 3.0 * tt * tt - 2.0 * tt * tt * tt
+            self.traj.copy_(self.start[:, None, :] + h * (self.end - self.start)[:, None, :])
             return
         saved_t, saved_alg = self.t, self.ol_alg
         scratch = self.learner_state.clone()

@@ -499,6 +499,32 @@ def test_engine_initial_goal_matches_reference_learner_init(dev, case):
     assert torch.equal(eng.learner_state, state0) and eng.t == 0  # the pick leaves the learner untouched
 
 
+def test_engine_proj_and_baseline_keep_a_fixed_goal(dev):
+    """planner.py:200-222, 609-618: with ol_alg "Proj" the goal is the one closest to the START (link_smooth_weight metric),
+    with "Baseline" cfg.goal_idx; neither runs the learner during the plan."""
+    from omg_planner_amd import robot as rb, scenes as sc
+    from omg_planner_amd.config import Config
+    from omg_planner_amd.engine import ChompEngine
+    S, G, n = 3, 7, 12
+    m = rb.PandaModel(seed=11)
+    scenes, batch = _multi_scene_batch(S)
+    goals = np.stack([sc.make_goal_set(s, G) for s in range(S)])
+    start = np.tile(rb.HOME_CONFIG, (S, 1)) + np.random.RandomState(0).normal(0, 0.1, (S, 9)) * np.array([1] * 7 + [0, 0])
+    for alg, expect in (("Proj", np.argmin(np.linalg.norm(start[:, None] - goals, axis=-1), axis=1)), ("Baseline", np.zeros(S, int))):
+        cfg = Config(use_standoff=False)
+        cfg.get_global_param(n)
+        eng = ChompEngine(m, batch, cfg, start, goals, device=dev, ol_alg=alg)
+        eng.select_initial_goal()
+        np.testing.assert_array_equal(eng.goal_idx.cpu().numpy(), expect)
+        np.testing.assert_array_equal(eng.end.cpu().numpy(), goals[np.arange(S), expect])
+        np.testing.assert_allclose(eng.traj.cpu().numpy(), np.stack([sc.cubic_init(start[s], goals[s, expect[s]], n) for s in range(S)]),
+                                   rtol=0, atol=1e-12)
+        for t in range(3):
+            eng.iterate(t)
+        np.testing.assert_array_equal(eng.goal_idx.cpu().numpy(), expect)  # no learner in the loop
+        assert eng.t == 0
+
+
 @pytest.mark.parametrize("alg,G", [("MD", 64), ("Exp", 100), ("FTL", 200), ("Proj", 33), ("MD", 130)])
 def test_goal_update_matches_oracle_many_scenes(dev, alg, G):
     from omg_planner_amd import _lib, ops

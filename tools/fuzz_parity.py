@@ -95,7 +95,7 @@ def one_trial(rng, trial, dev, dry=False):
         if os.environ.get("OMGX_FUZZ_DEBUG"):
             torch.cuda.synchronize()
         idx = None
-        if t < cfg.optim_steps and cfg.goal_set_proj:
+        if t < cfg.optim_steps and cfg.goal_set_proj and alg != "Proj":  # planner.py:609: no learner for Proj / Baseline
             lp = orc.LearnerParams()
             lp.alg, lp.num_goals, lp.n_waypoints = orc.ALG[alg], G, n
             lp.start_idx = min(int(((t + 1) / cfg.optim_steps) * n), n - 1)
