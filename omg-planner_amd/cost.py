@@ -165,7 +165,7 @@ class Cost(object):
         """Visualisation colours from relative potential (omg/cost.py:74-90)."""
         pmax = np.amax(vis_pts[..., 6], axis=(-2, -1))[..., None, None]
         pmin = np.amin(vis_pts[..., 6], axis=(-2, -1))[..., None, None]
-        vis_pts[..., 6] = 255 * (vis_pts[..., 6] - pmin) / ((pmax - pmin + 1e-8) + 1e-8)
+        vis_pts[..., 6] = 255 * ((vis_pts[..., 6] - pmin) / ((pmax - pmin + 1e-8) + 1e-8))
         vis_pts[..., 7] = 255 - vis_pts[..., 6]
         vis_pts[_np(collide).astype(bool), 6:9] = 255, 0, 0
 

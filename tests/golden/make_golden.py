@@ -21,7 +21,9 @@ How the reference is imported on a CPU-only box without its optional dependencie
 What IS pinned by the reference here: forward_kinematics_parallel, Cost.forward_points,
 compute_point_jacobian, get_derivative(_torch), functional_grad, compute_collision_loss (both
 branches), compute_smooth_loss, compute_total_loss, batch_obstacle_cost, Optimizer.optimize
-(update / goal_set_projection / handle_joint_limit / check_joint_limit) and the diff/A/Ainv matrices.
+(update / goal_set_projection / handle_joint_limit / check_joint_limit) and the diff/A/Ainv matrices; host_helpers.npz holds direct outputs
+of the small numpy methods (Optimizer.update / goal_set_projection / compute_traj_v / handle_joint_limit / check_joint_limit,
+Cost.forward_points / color_point).
 
 The fixtures are data only (inputs + the reference's outputs); no reference source is stored.
 """
@@ -262,6 +264,61 @@ def _fixed_fk_and_matrices(out_dir, cfg, kin, util, model, rng, lo, hi, rb):
 
 
 
+def _fixed_host_helpers(out_dir, cfg, cost_mod, opt_mod, model):
+    """Outputs of the reference's small numpy methods (Optimizer.goal_set_projection / compute_traj_v /
+    handle_joint_limit / check_joint_limit / update, Cost.forward_points / color_point) on seeded inputs: pins the
+    host-side mirrors of the same names (tools/fuzz_host_mirror.py runs the same comparison on random cases)."""
+    import torch
+
+    rng = np.random.RandomState(4242)  # own stream: the other fixtures do not move
+    lo, hi = model.joint_lower_limit, model.joint_upper_limit
+    robot = types.SimpleNamespace(joint_lower_limit=lo, joint_upper_limit=hi)
+    out = {"joint_lower_limit": lo, "joint_upper_limit": hi}
+    cases = [(30, None, True, 10), (30, None, False, 10), (50, 0.06, True, 3), (8, None, False, 0), (12, None, True, 25)]
+    for k, (n, dt, standoff, jl_steps) in enumerate(cases):
+        reset_cfg(cfg, timesteps=n, use_standoff=standoff, goal_set_proj=True, joint_limit_max_steps=jl_steps,
+                  **({"time_interval": dt} if dt else {}))
+        c = cfg.reach_tail_length if standoff else 1
+        G = 4
+        goal_set, reach = rng.uniform(lo[0], hi[0], (G, 9)), rng.uniform(lo[0], hi[0], (G, c, 9))
+        opt = opt_mod.Optimizer(types.SimpleNamespace(config=cfg, robot=robot),
+                                types.SimpleNamespace(target_obj=types.SimpleNamespace(reach_grasps=reach)))
+        for _ in range(k + 1):
+            opt.update()
+        wide = (0.0, 0.05, 0.5, 0.5, 0.3)[k]
+        data = rng.uniform(lo[0] - wide, hi[0] + wide, (n, 9))
+        grad = rng.normal(0, 5.0, (n, 9))
+        traj = types.SimpleNamespace(data=data.copy(), end=data[-1].copy(), goal_set=goal_set, goal_idx=k % G)
+        flags = []
+        for kind in range(4):  # no / low only / high only / both violations (optimizer.py:166-174 needs both)
+            probe = rng.uniform(lo[0] + 0.1, hi[0] - 0.1, (n, 9))
+            if kind & 1:
+                probe[1, 2] = -10.0
+            if kind & 2:
+                probe[2, 3] = 10.0
+            info = {"terminate": True}
+            opt.check_joint_limit(probe, info)
+            flags.append([kind, float(bool(info["violate_limit"])), float(bool(info["terminate"]))])
+        out.update({f"c{k}_n": np.int64(n), f"c{k}_standoff": np.int64(standoff), f"c{k}_time_interval": np.float64(cfg.time_interval),
+                    f"c{k}_timesteps_before": np.int64(int(round(cfg.time_interval / 0.1 * n))), f"c{k}_joint_limit_max_steps": np.int64(jl_steps),
+                    f"c{k}_updates": np.int64(k + 1), f"c{k}_goal_set": goal_set, f"c{k}_reach": reach, f"c{k}_goal_idx": np.int64(k % G),
+                    f"c{k}_data": data, f"c{k}_grad": grad,
+                    f"c{k}_schedules": np.array([cfg.obstacle_weight, cfg.smoothness_weight, cfg.grasp_weight, cfg.step_size]),
+                    f"c{k}_projection": opt.goal_set_projection(traj, grad), f"c{k}_traj_v": opt.compute_traj_v(data),
+                    f"c{k}_limited": opt.handle_joint_limit(data.copy()), f"c{k}_limit_flags": np.array(flags)})
+    cst = object.__new__(cost_mod.Cost)
+    pose, pts, nrm = rng.normal(size=(3, 10, 4, 4)), rng.normal(size=(10, 3, 6)), rng.normal(size=(10, 3, 6))
+    vis = rng.uniform(0, 1, (3, 11, 6, 12))
+    vis[1, ..., 6] = 0.25  # flat potentials: only the 1e-8 guards keep the division finite
+    col = (rng.rand(3, 11, 6) < 0.15).astype(np.float32)
+    coloured = vis.copy()
+    cst.color_point(coloured, torch.as_tensor(col))
+    out.update(fp_pose=pose, fp_pts=pts, fp_normals=nrm, fp_out=cst.forward_points(pose, pts),
+               fp_out_normals=cst.forward_points(pose, pts, nrm), cp_vis=vis, cp_collide=col, cp_out=coloured)
+    np.savez_compressed(out_dir / "host_helpers.npz", **out)
+    print("host_helpers.npz")
+
+
 def main(out_dir=OUT, script=None):
     """script=None regenerates the committed fixtures; otherwise script(ns) is called with the case generators
     (ns.run_cost_case, ns.run_opt_case, ns.run_batch_case, ns.run_learner_case: same code, any parameters) writing into
@@ -282,6 +339,7 @@ def main(out_dir=OUT, script=None):
     # ---- (i) FK ---------------------------------------------------------------------------------
     if fixed:
         _fixed_fk_and_matrices(out_dir, cfg, kin, util, model, rng, lo, hi, rb)
+        _fixed_host_helpers(out_dir, cfg, cost_mod, opt_mod, model)
 
     # ---- (ii)-(iv) cost path --------------------------------------------------------------------
     start = rb.HOME_CONFIG.copy()

@@ -106,3 +106,55 @@ def test_select_goals_mirrors_setup_goal_set_quirks():
     assert len(g2) == 3 and set(int(c) for c in c2) <= {0, 1, 2, 3}
     # nothing survives
     assert select_goals(goals, reach, np.full(6, 99), pots) == ([], [], [], [])
+
+
+def test_optimizer_and_cost_numpy_methods_match_reference():
+    """The small numpy methods that keep the reference's signatures (Optimizer.update / goal_set_projection /
+    compute_traj_v / handle_joint_limit / check_joint_limit, Cost.forward_points / color_point) against outputs of the
+    reference's own methods (tests/golden/make_golden.py:_fixed_host_helpers; tools/fuzz_host_mirror.py: random cases)."""
+    import types
+
+    import torch
+    from omg_planner_amd.config import Config
+    from omg_planner_amd.cost import Cost
+    from omg_planner_amd.optimizer import Optimizer
+    fx = H.load("host_helpers.npz")
+    robot = types.SimpleNamespace(joint_lower_limit=fx["joint_lower_limit"], joint_upper_limit=fx["joint_upper_limit"])
+    k = 0
+    while f"c{k}_n" in fx:
+        g = lambda name: fx[f"c{k}_{name}"]  # noqa: E731
+        n = int(g("n"))
+        cfg = Config()
+        cfg.use_standoff, cfg.goal_set_proj, cfg.joint_limit_max_steps = bool(g("standoff")), True, int(g("joint_limit_max_steps"))
+        cfg.timesteps = int(g("timesteps_before"))
+        cfg.get_global_param(n)
+        assert abs(cfg.time_interval - float(g("time_interval"))) < 1e-15
+        opt = Optimizer(types.SimpleNamespace(config=cfg, robot=robot),
+                        types.SimpleNamespace(target_obj=types.SimpleNamespace(reach_grasps=g("reach"))))
+        for _ in range(int(g("updates"))):
+            opt.update()
+        np.testing.assert_allclose([cfg.obstacle_weight, cfg.smoothness_weight, cfg.grasp_weight, cfg.step_size], g("schedules"), rtol=1e-14)
+        data = g("data")
+        traj = types.SimpleNamespace(data=data.copy(), end=data[-1].copy(), goal_set=g("goal_set"), goal_idx=int(g("goal_idx")))
+        np.testing.assert_allclose(opt.goal_set_projection(traj, g("grad")), g("projection"), rtol=1e-8, atol=1e-8)
+        assert np.array_equal(opt.compute_traj_v(data), g("traj_v"))
+        np.testing.assert_allclose(opt.handle_joint_limit(data.copy()), g("limited"), rtol=1e-9, atol=1e-9)
+        rs = np.random.RandomState(k)
+        lo, hi = robot.joint_lower_limit[0], robot.joint_upper_limit[0]
+        for kind, violate, terminate in g("limit_flags"):
+            probe = rs.uniform(lo + 0.1, hi - 0.1, (n, 9))
+            if int(kind) & 1:
+                probe[1, 2] = -10.0
+            if int(kind) & 2:
+                probe[2, 3] = 10.0
+            info = {"terminate": True}
+            opt.check_joint_limit(probe, info)
+            assert (info["violate_limit"], info["terminate"]) == (bool(violate), bool(terminate)), (k, kind)
+        k += 1
+    assert k == 5
+    c = Cost.__new__(Cost)
+    assert np.array_equal(c.forward_points(fx["fp_pose"], fx["fp_pts"]), fx["fp_out"])
+    assert np.array_equal(c.forward_points(fx["fp_pose"], fx["fp_pts"], fx["fp_normals"]), fx["fp_out_normals"])
+    vis = fx["cp_vis"].copy()
+    c.color_point(vis, torch.as_tensor(fx["cp_collide"]))
+    assert np.array_equal(vis, fx["cp_out"])
