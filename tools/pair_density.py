@@ -25,7 +25,8 @@ def main():
     pts = blob[D + 246: D + 246 + 30 * P].reshape(10, P, 3)
     rad = blob[D + 306 + 30 * P: D + 316 + 30 * P]
     tot = dict(rows=0, rows_near=0, pairs=0, pairs_rowlive=0, pairs_box=0, pairs_inrange=0, pairs_contrib=0,
-               wave_obj_iters=0, wave_obj_iters_live=0, compact_batches=0)
+               wave_obj_iters=0, wave_obj_iters_live=0, compact_batches=0, link_tests=0, link_tests_needed=0,
+               merged_batches=0, wave_lb_iters_live=0, box_in_wave_hist=np.zeros(9, np.int64))
     for s in range(S):
         t = (np.arange(1, n + 1) / (n + 1))[None, :, None]
         q = start[s][None, None, :] + t * (goals[s][:, None, :] - start[s][None, None, :])  # [G,n,9]
@@ -37,6 +38,7 @@ def main():
         x = np.einsum("gnlij,lpj->gnlpi", R, pts) + T[..., None, :]  # [G,n,10,P,3]
         ctr = T
         recs = batch.objects[batch.scene_begin[s]: batch.scene_begin[s + 1]]
+        cnt_all = 0
         for r in recs:
             if r["disabled"] > 0:
                 continue
@@ -79,18 +81,30 @@ def main():
             tot["wave_obj_iters"] += it.size
             tot["wave_obj_iters_live"] += int(it.sum())
             tot["compact_batches"] += int((-(-cnt // 64)).sum())
+            cnt_all = cnt_all + cnt
+            per_link = nw.any(axis=2)                   # [G, wave, lb, k]: link k has a row in reach of this object
+            tot["link_tests"] += int(it.sum()) * 2      # pair_prepare calls per executed iteration today
+            tot["link_tests_needed"] += int(per_link.sum())
+            tot["box_in_wave_hist"] += np.bincount(np.minimum(cnt[it] // 16, 8), minlength=9)
             need = (grid <= r["epsilon"]) | (grid < r["clearance"])
             idx = np.argwhere(need)
             print(f"scene {s} obj eps={r['epsilon']:.2f} dim={tuple(dim)} rows_near={near.mean():.3f} box={live.mean():.3f} "
                   f"contrib={(live & contrib).mean():.3f} influence voxel box={idx.min(0)}..{idx.max(0)}")
+        tot["merged_batches"] += int((-(-cnt_all // 64)).sum())
+        tot["wave_lb_iters_live"] += int((cnt_all > 0).sum())
     for k, v in tot.items():
-        print(f"{k:22s} {v:12d}")
+        print(f"{k:22s} {v}")
     print("row survive            %.3f" % (tot["rows_near"] / tot["rows"]))
     print("pair box | row live    %.3f" % (tot["pairs_box"] / max(tot["pairs_rowlive"], 1)))
     print("pair box / all         %.3f" % (tot["pairs_box"] / tot["pairs"]))
     print("contrib / box          %.3f" % (tot["pairs_contrib"] / max(tot["pairs_box"], 1)))
     print("lanes per exec'd iter  %.1f of 128" % (tot["pairs_box"] / max(tot["wave_obj_iters_live"], 1)))
     print("exact batches per exec'd iter %.2f" % (tot["compact_batches"] / max(tot["wave_obj_iters_live"], 1)))
+
+
+    # what-if figures: far tests skipped per link, exact batches if the objects of a link batch shared one queue
+    print("far tests needed / done %.3f" % (tot["link_tests_needed"] / max(tot["link_tests"], 1)))
+    print("exact batches merged over objects / today %.3f" % (tot["merged_batches"] / max(tot["compact_batches"], 1)))
 
 
 if __name__ == "__main__":
