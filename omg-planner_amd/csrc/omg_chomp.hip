@@ -237,6 +237,7 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
     const Lds L = carve(smem, n, P, a.pot_in_lds != 0);
     const RobotView rv(a.robot, P);
     const int tid = threadIdx.x;
+    bool wait_failed = false;  // thread 0: the bounded wait for the learner's workgroup ran out
     const int total = n * 10 * P;             // reference flat size of potentials [n][10][P]
     const int nitems = n * 160;               // 16-lane groups: item = (i*10 + l)*16 + p
     const float* pot = a.pot + (size_t)s * total;
@@ -559,13 +560,15 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
         // ------------------------------------------------------------ the goal: wait for the learner's workgroup
         PHASE_MARK_T(23, 0);
         if (tid == 0) {
-            int spins = 0;
-            while (__hip_atomic_load(wait_goal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ticket) {
-                __builtin_amdgcn_s_sleep(4);
-                if (++spins > (1 << 26)) {  // ~ seconds: the producer is gone; fail loudly instead of hanging the device
-                    a.info[(size_t)s * OMGX_INFO_STRIDE + OMGX_INFO_COST] = __builtin_nan("");
-                    break;
-                }
+            if (__hip_atomic_load(wait_goal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ticket) {
+                const long long t0 = wall_clock64();  // 100 MHz
+                do {
+                    __builtin_amdgcn_s_sleep(4);
+                    if (wall_clock64() - t0 > 200000000LL) {  // 2 s: the producer is gone; fail loudly instead of hanging the device
+                        wait_failed = true;
+                        break;
+                    }
+                } while (__hip_atomic_load(wait_goal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ticket);
             }
             // one acquire for the workgroup: it invalidates this CU's L1 (shared by all its waves) and the stale L2 lines;
             // the barrier below orders the other threads' reads of the goal after it
@@ -686,7 +689,7 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
         const bool failure = (collide >= prm.allow_collision_point * 10) || (smooth_sum >= prm.terminate_smooth_loss * 2.5);
         const bool execute = (collide <= prm.allow_collision_point) && (smooth_sum < prm.terminate_smooth_loss);
         double* info = a.info + (size_t)s * OMGX_INFO_STRIDE;
-        info[OMGX_INFO_COST] = w_obs + w_sm;
+        info[OMGX_INFO_COST] = wait_failed ? __builtin_nan("") : w_obs + w_sm;  // a goal that never arrived must not look like a result
         info[OMGX_INFO_OBS] = obs_sum;
         info[OMGX_INFO_SMOOTH] = smooth_sum;
         info[OMGX_INFO_WEIGHTED_OBS] = w_obs;
