@@ -282,7 +282,7 @@ int omgx_chomp_optimize(const double* robot, const omgx_chomp_params* h_params,
  *   goal_cost   [S,G] float32 from omgx_goalset_cost (ignored for Proj)
  *   state       [S, omgx_learner_state_doubles(G)] double, in/out:
  *               sum_costs [G] | p [G] | experts_p [5][G] | q [5] | experts_costs [5]
- *               (initialise with omgx_learner_state_init semantics: zeros | 1/G | 1/G | 1/5 | zeros)
+ *               (the caller initialises it as Learner.__init__ does, online_learner.py:78-92: zeros | 1/G | 1/G | 1/5 | zeros)
  * Outputs: goal_idx [S] int32, end [S,9] (traj.end), goal_rows [S,c,9] (chosen goal rows for the projection),
  *          goal_point [S,9] (goal_set[goal_idx]), cost_vector [S,G] double (optional, NULL to skip).
  * G <= OMGX_MAX_GOALS.
