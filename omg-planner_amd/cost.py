@@ -49,6 +49,68 @@ class SDFLoss:
     forward = __call__
 
 
+class LazyInfo(dict):
+    """The info dict of compute_total_loss / Optimizer.optimize.  "collision_pts" (the [n,10,p,12] visualisation array read
+    by omg/core.py:561-570,661) is built on first access: it needs one more launch, a copy and numpy work that an
+    optimisation loop without a viewer never uses.  info["collision_pts"] works as in the reference; before that access the
+    key is absent from keys() / len()."""
+
+    def __init__(self, *a, collision_pts=None, **k):
+        super().__init__(*a, **k)
+        self._collision_pts = collision_pts
+
+    def __missing__(self, key):
+        if key == "collision_pts" and self._collision_pts is not None:
+            self[key] = self._collision_pts()
+            self._collision_pts = None
+            return self[key]
+        raise KeyError(key)
+
+
+class _Staging:
+    """Buffers of ONE single-trajectory step (Optimizer.optimize / compute_total_loss): a device buffer holding every input
+    and output of omgx_fk_sdf + omgx_chomp_optimize back to back and a pinned host mirror, so that a call costs one
+    host->device copy (start | end | goal rows | goal point | trajectory), two launches and one device->host copy
+    (trajectory | grad | cost_traj | info | aux | potentials | gradients | collisions) instead of five + six copies."""
+
+    def __init__(self, n: int, c: int, P: int, aux_doubles: int, device):
+        f64 = [("start", (1, 9)), ("end", (1, 9)), ("goal", (1, c, 9)), ("goal_point", (1, 9)), ("traj", (1, n, 9)),
+               ("grad", (1, n, 9)), ("cost_traj", (1, n)), ("info", (1, _lib.INFO_STRIDE)), ("aux", (1, aux_doubles))]
+        f32 = [("pot", (1, n, 10, P)), ("pgrad", (1, n, 10, P, 3)), ("col", (1, n, 10, P))]
+        off, self.slots = 0, {}
+        for name, shape in f64:
+            self.slots[name] = (off, shape, torch.float64, np.float64)
+            off += int(np.prod(shape)) * 8
+        for name, shape in f32:
+            self.slots[name] = (off, shape, torch.float32, np.float32)
+            off += int(np.prod(shape)) * 4
+        self.nbytes = (off + 7) & ~7
+        self.in_end = self.slots["grad"][0]     # inputs: everything up to and including the trajectory
+        self.out_begin = self.slots["traj"][0]  # outputs: from the trajectory (updated in place) to the end
+        self.dev = torch.zeros(self.nbytes, dtype=torch.uint8, device=device)
+        self.host = torch.zeros(self.nbytes, dtype=torch.uint8).pin_memory()
+        hnp = self.host.numpy()
+        self._d = {k: self.dev[off: off + int(np.prod(shape)) * tdt.itemsize].view(tdt).view(shape)
+                   for k, (off, shape, tdt, _) in self.slots.items()}
+        self._h = {k: hnp[off: off + int(np.prod(shape)) * np.dtype(ndt).itemsize].view(ndt).reshape(shape)
+                   for k, (off, shape, _, ndt) in self.slots.items()}
+        self._d_in, self._h_in = self.dev[: self.in_end], self.host[: self.in_end]
+        self._d_out, self._h_out = self.dev[self.out_begin:], self.host[self.out_begin:]
+
+    def d(self, name):  # device view
+        return self._d[name]
+
+    def h(self, name):  # host (numpy) view of the pinned mirror: valid until the next call
+        return self._h[name]
+
+    def upload(self):
+        self._d_in.copy_(self._h_in, non_blocking=True)
+
+    def download(self):
+        self._h_out.copy_(self._d_out, non_blocking=True)
+        torch.cuda.current_stream(self.dev.device).synchronize()
+
+
 class Cost(object):
     """Obstacle and smoothness cost + gradients of a trajectory (omg/cost.py:12-16)."""
 
@@ -62,6 +124,7 @@ class Cost(object):
         self._model = None
         self._robot = None
         self._points_version = None
+        self._staging = {}
 
     # -- device-side state -------------------------------------------------------------------------
     def _robot_model(self):
@@ -93,6 +156,18 @@ class Cost(object):
     def _scenes(self) -> ops.DeviceScenes:
         """One-scene object table addressing env.sdf_torch IN PLACE (rebuilt per call like the reference
         rebuilds its five parameter tensors per call; object poses may have changed)."""
+        # Nothing to rebuild while the inputs are the same as in the previous call (the usual case inside an optimisation
+        # loop): object names / poses / attached flags, target, layer parameters of cfg, and the SDF tensors (same tensor
+        # objects at the same in-place version).
+        cfg, env = self.cfg, self.env
+        lim_t = env.sdf_limits
+        key = (id(env.sdf_torch), env.sdf_torch._version, id(lim_t), getattr(lim_t, "_version", None), int(env.target_idx),
+               float(cfg.epsilon), float(cfg.target_epsilon), float(cfg.clearance), float(cfg.target_clearance),
+               tuple(cfg.disable_collision_set),
+               tuple((o.name, bool(getattr(o, "attached", False)), np.asarray(o.pose_mat, np.float64).tobytes()) for o in env.objects))
+        cached = getattr(self, "_scenes_cache", None)
+        if cached is not None and cached[0] == key and cached[1]() is env.sdf_torch:
+            return cached[2]
         poses, eps, pad, clr, dis = self._layer_params()
         limits = _np(self.env.sdf_limits).astype(np.float32)
         table = sc.table_from_padded(poses, limits, eps, pad, clr, dis)
@@ -114,6 +189,8 @@ class Cost(object):
         ds.pool = self.env.sdf_torch.reshape(-1)
         if not (ds.pool.is_cuda and ds.pool.dtype == torch.float32 and ds.pool.is_contiguous()):
             raise _lib.OmgHipError("env.sdf_torch must be a contiguous float32 device tensor")
+        import weakref
+        self._scenes_cache = (key, weakref.ref(env.sdf_torch), ds)
         return ds
 
     def _params(self, n: int, do_update: int) -> _lib.ChompParams:
@@ -161,6 +238,30 @@ class Cost(object):
             x = np.concatenate([x, np.matmul(pose[..., :3, :3], normals[None, ...])], 2)
         return x.transpose([3, 1, 0, 2])
 
+    def _vis_points(self, q):
+        """World positions of the collision points of configurations q [B,9] as the SDF layer receives them: [B,10,p,3]
+        float32 (omg/cost.py:209-218: numpy FK + forward_points, then .float())."""
+        model, robot = self._robot_model()
+        poses = _np(ops.forward_kinematics(robot, model.points_per_link, self._t(np.asarray(q, np.float64).reshape(-1, 9)),
+                                           want_joint_info=False)[0])
+        pts = np.asarray(self.env.robot.collision_points, np.float64).transpose([0, 2, 1])
+        return self.forward_points(poses, pts).transpose([2, 1, 0, 3]).astype(np.float32)
+
+    def _vis_array(self, q, pot, pgrad, col, highlight_top_k: bool):
+        """vis_pts [B,10,p,12] as compute_obstacle_cost_layer + color_point fill it (cost.py:355-358, 74-90): columns 0:3
+        positions, 6:9 colours from the relative potential (red where colliding), 9:12 gradients; compute_collision_loss
+        then paints the top-k points (cost.py:390-399, same argsort expression on the same float32 potentials)."""
+        vis = np.zeros([pot.shape[0], 10, pot.shape[2], 12])
+        vis[..., :3] = self._vis_points(q)
+        vis[..., 6] = pot
+        vis[..., 9:] = pgrad
+        self.color_point(vis, col)
+        k = int(self.cfg.top_k_collision)
+        if highlight_top_k and k > 0:
+            topk = np.unravel_index(np.argsort(pot.flatten()), pot.shape)
+            vis[topk[0][-k:], topk[1][-k:], topk[2][-k:], 6:9] = [235, 52, 195]
+        return vis
+
     def color_point(self, vis_pts, collide):
         """Visualisation colours from relative potential (omg/cost.py:74-90)."""
         pmax = np.amax(vis_pts[..., 6], axis=(-2, -1))[..., None, None]
@@ -206,10 +307,11 @@ class Cost(object):
         ws = self.forward_points(poses[:n], pts)  # [p, 10, n, 3]
         pot, grad, col = ops.fk_sdf(robot, P, self._scenes(), self._t(xi[None]), soften_fingers=self.cfg.uncheck_finger_collision == -1)
         potentials, potential_grads, collide = _np(pot[0]), _np(grad[0]), _np(col[0])
-        vis_pts = np.zeros([n, 11, P, 12])
-        vis_pts[:, :10, :, :3] = ws.transpose([2, 1, 0, 3])
-        vis_pts[:, :10, :, 6] = potentials
-        vis_pts[:, :10, :, 9:] = potential_grads
+        vis_pts = np.zeros([n, 10, P, 12])  # n x (m + 1) x p x 12 with m = xi.shape[1] = 9 (cost.py:119-121)
+        vis_pts[..., :3] = ws.transpose([2, 1, 0, 3]).astype(np.float32)
+        vis_pts[..., 6] = potentials
+        vis_pts[..., 9:] = potential_grads
+        self.color_point(vis_pts, collide)
         Js = [self.compute_point_jacobian(org[:n][:, wrap_joint(j + 1)], ws[:, j], ax[:n][:, wrap_joint(j + 1)], potentials[:, j],
                                           "prsimatic" if j >= 8 else "revolute") for j in range(10)]
         if not arc_length:
@@ -260,69 +362,97 @@ class Cost(object):
                                     dt=float(self.cfg.time_interval))
         potentials, grad, collide = pot[0], grad[0], col[0]
         vis_pts = None
-        if want_vis:
-            vis_pts = np.zeros([B, 10, P, 12])
-            vis_pts[..., 6] = _np(potentials)
-            vis_pts[..., 9:] = _np(grad)
-            self.color_point(vis_pts, collide)
+        if want_vis:  # coloured from the potentials BEFORE the arc-length weighting (cost.py:219-230)
+            plain = potentials if not arc else ops.fk_sdf(robot, P, self._scenes(), q, soften_fingers=uncheck_finger_collision == -1,
+                                                         want_grad=False, want_col=False)[0][0]
+            vis_pts = self._vis_array(_np(q[0]), _np(plain), _np(grad), _np(collide), False)
         if only_collide:  # cost.py:279-284
             thr = 0.5 * (self.cfg.epsilon - self.cfg.clearance) ** 2 / self.cfg.epsilon
             potentials = potentials * (potentials > thr).any()
         return potentials, grad, vis_pts, collide
 
     # -- trajectory losses -----------------------------------------------------------------------------
-    def _evaluate(self, xi, start, end, goal_point=None, want_aux=False):
-        """One info-only k_chomp_optimize launch for a single trajectory."""
+    def _stage(self, n: int, c: int) -> _Staging:
+        P = self._robot_model()[0].points_per_link
+        key = (n, c, P)
+        st = self._staging.get(key)
+        if st is None:
+            st = self._staging[key] = _Staging(n, c, P, int(_lib.lib().omgx_chomp_aux_doubles(n)), self.device)
+        return st
+
+    def _run_step(self, xi, start, end, goal_rows, goal_point, do_update: int, want_aux: bool) -> _Staging:
+        """omgx_fk_sdf + omgx_chomp_optimize for ONE trajectory through the staging buffers; the results are in the
+        returned object's host views (st.h(name)) until the next call."""
         model, robot = self._robot_model()
         P = model.points_per_link
         xi = np.asarray(xi, np.float64)
         n = xi.shape[0]
-        traj = self._t(xi[None])
-        pot, pgrad, col = ops.fk_sdf(robot, P, self._scenes(), traj,
-                                     soften_fingers=self.cfg.uncheck_finger_collision == -1)
-        prm = self._params(n, 0)
-        end_t = self._t(np.asarray(end, np.float64)[None])
-        gp = end_t if goal_point is None else self._t(np.asarray(goal_point, np.float64)[None])
-        goal = end_t[:, None, :].expand(1, prm.constraint_num, 9).contiguous()  # unused by an info-only launch
-        aux = torch.empty((1, _lib.lib().omgx_chomp_aux_doubles(n)), dtype=torch.float64, device=self.device) if want_aux else None
-        grad, cost_traj, info = ops.chomp_optimize(robot, prm, traj, self._t(np.asarray(start, np.float64)[None]), end_t, goal, gp,
-                                                   pot, pgrad, col, aux=aux)
-        return n, pot, pgrad, col, grad, cost_traj, info, aux
+        prm = self._params(n, do_update)
+        goal_rows = np.asarray(goal_rows, np.float64).reshape(-1, 9)
+        if goal_rows.shape[0] != prm.constraint_num:
+            raise _lib.OmgHipError(f"chosen goal has {goal_rows.shape[0]} rows, cfg implies {prm.constraint_num}")
+        st = self._stage(n, prm.constraint_num)
+        st.h("traj")[0] = xi
+        st.h("start")[0] = np.asarray(start, np.float64)
+        st.h("end")[0] = np.asarray(end, np.float64)
+        st.h("goal")[0] = goal_rows
+        st.h("goal_point")[0] = np.asarray(goal_point, np.float64)
+        with torch.cuda.device(self.device):
+            st.upload()
+            ops.fk_sdf(robot, P, self._scenes(), st.d("traj"), soften_fingers=self.cfg.uncheck_finger_collision == -1,
+                       out=(st.d("pot"), st.d("pgrad"), st.d("col")))
+            ops.chomp_optimize(robot, prm, st.d("traj"), st.d("start"), st.d("end"), st.d("goal"), st.d("goal_point"),
+                               st.d("pot"), st.d("pgrad"), st.d("col"), out=(st.d("grad"), st.d("cost_traj"), st.d("info")),
+                               aux=st.d("aux") if want_aux else None)
+            st.download()
+        return st
+
+    def _collision_pts_builder(self, xi, st: _Staging):
+        """Closure that builds info["collision_pts"] from copies of this call's layer outputs (the staging views are reused)."""
+        xi, pot, pgrad, col = np.array(xi, np.float64), st.h("pot")[0].copy(), st.h("pgrad")[0].copy(), st.h("col")[0].copy()
+        return lambda: self._vis_array(xi, pot, pgrad, col, True)
+
+    def _evaluate(self, xi, start, end, goal_point=None, want_aux=False) -> _Staging:
+        """One info-only k_chomp_optimize launch for a single trajectory."""
+        n = np.asarray(xi).shape[0]
+        c = self._params(n, 0).constraint_num
+        end = np.asarray(end, np.float64)
+        return self._run_step(xi, start, end, np.tile(end, (c, 1)), end if goal_point is None else goal_point, 0, want_aux)
 
     def compute_collision_loss(self, xi, start, end):
         """-> obs_cost [n, 10], obs_grad [n, 9], vis_pts, collide  (omg/cost.py:362-423)."""
-        n, pot, pgrad, col, _, _, info, aux = self._evaluate(xi, start, end, want_aux=True)
-        a = _np(aux[0])
-        vis_pts = np.zeros([n, 11, pot.shape[-1], 12])
-        vis_pts[:, :10, :, 6] = _np(pot[0])
-        vis_pts[:, :10, :, 9:] = _np(pgrad[0])
-        return a[n * 9: n * 19].reshape(n, 10), a[: n * 9].reshape(n, 9), vis_pts, np.float32(_np(info)[0, 8])
+        st = self._evaluate(xi, start, end, want_aux=True)
+        a, pot = st.h("aux")[0].copy(), st.h("pot")[0].copy()
+        n = pot.shape[0]
+        collide_sum = np.float32(st.h("info")[0, 8])
+        vis_pts = self._vis_array(xi, pot, st.h("pgrad")[0].copy(), st.h("col")[0].copy(), True)  # (launches: after the reads above)
+        return a[n * 9: n * 19].reshape(n, 10), a[: n * 9].reshape(n, 9), vis_pts, collide_sum
 
     def compute_smooth_loss(self, xi, start, end):
         """-> smoothness_loss [n+1], smoothness_grad [n, 9]  (omg/cost.py:425-449)."""
-        n, _, _, _, _, _, _, aux = self._evaluate(xi, start, end, want_aux=True)
-        a = _np(aux[0])
+        st = self._evaluate(xi, start, end, want_aux=True)
+        a, n = st.h("aux")[0], np.asarray(xi).shape[0]
         return a[n * 28: n * 28 + n + 1].copy(), a[n * 19: n * 28].reshape(n, 9).copy()
 
     def compute_total_loss(self, traj):
         """-> cost, grad [n, 9], info (the 20 keys of omg/cost.py:509-530)."""
         gp = traj.goal_set[traj.goal_idx] if self.cfg.goal_set_proj and len(traj.goal_set) > 0 else traj.end
-        n, pot, pgrad, col, grad, cost_traj, info_t, _ = self._evaluate(traj.data, traj.start, traj.end, goal_point=gp)
-        i = _np(info_t)[0]
-        grad = _np(grad[0])
+        st = self._evaluate(traj.data, traj.start, traj.end, goal_point=gp)
+        i = st.h("info")[0].copy()
+        grad = st.h("grad")[0].copy()
+        pot = st.h("pot")[0]
+        n = pot.shape[0]
         cfg = self.cfg
         # compute_total_loss's own flag does not know about joint limits (check_joint_limit amends it later,
         # optimizer.py:166-174); rebuild it from the kernel's numbers (cost.py:489-494)
         terminate = bool((i[8] <= cfg.allow_collision_point) and cfg.pre_terminate and (i[9] < 0.01)
                          and (i[2] < cfg.terminate_smooth_loss))
-        vis_pts = np.zeros([n, 11, pot.shape[-1], 12])
-        vis_pts[:, :10, :, 6] = _np(pot[0])
-        vis_pts[:, :10, :, 9:] = _np(pgrad[0])
         info = {
-            "collision_pts": vis_pts, "obs": i[1], "smooth": i[2], "grasp": 0, "weighted_obs": i[3], "weighted_smooth": i[4],
+            "obs": i[1], "smooth": i[2], "grasp": 0, "weighted_obs": i[3], "weighted_smooth": i[4],
             "weighted_smooth_grad": i[6], "weighted_obs_grad": i[5], "weighted_grasp_grad": 0, "weighted_grasp": 0,
             "gradient": grad, "failure_terminate": bool(i[11]), "cost": i[0], "grad": i[7], "terminate": terminate,
             "collide": np.float32(i[8]), "standoff_idx": int(i[13]), "reach": i[9], "execute": bool(i[12]),
-            "cost_traj": _np(cost_traj[0]),
+            "cost_traj": st.h("cost_traj")[0].copy(),
         }
+        info = LazyInfo(info, collision_pts=self._collision_pts_builder(traj.data, st))
         return info["cost"], grad, info

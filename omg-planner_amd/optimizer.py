@@ -63,12 +63,7 @@ class Optimizer(object):
         """One CHOMP step (omg/optimizer.py:115-135); returns the reference's info dict."""
         self.update()
         cost, cfg = self.cost, self.cfg
-        model, robot = cost._robot_model()
-        P = model.points_per_link
         n = traj.data.shape[0]
-        data = cost._t(np.asarray(traj.data, np.float64)[None])
-        pot, pgrad, col = ops.fk_sdf(robot, P, cost._scenes(), data, soften_fingers=cfg.uncheck_finger_collision == -1)
-        prm = cost._params(n, 0 if info_only else (1 if force_update else 2))
         if cfg.goal_set_proj:
             if cfg.use_standoff:
                 chosen = np.asarray(cost.target_obj.reach_grasps[int(traj.goal_idx)], np.float64)
@@ -76,28 +71,24 @@ class Optimizer(object):
                 chosen = np.asarray(traj.goal_set[int(traj.goal_idx)], np.float64)[None]
             goal_point = np.asarray(traj.goal_set[int(traj.goal_idx)], np.float64)
         else:
-            chosen = np.tile(np.asarray(traj.end, np.float64), (prm.constraint_num, 1))
+            chosen = np.tile(np.asarray(traj.end, np.float64), (cost._params(n, 0).constraint_num, 1))
             goal_point = np.asarray(traj.end, np.float64)
-        if chosen.shape[0] != prm.constraint_num:
-            raise _lib.OmgHipError(f"chosen goal has {chosen.shape[0]} rows, cfg implies {prm.constraint_num}")
-        grad, cost_traj, info_t = ops.chomp_optimize(robot, prm, data, cost._t(np.asarray(traj.start)[None]),
-                                                     cost._t(np.asarray(traj.end)[None]), cost._t(chosen[None]),
-                                                     cost._t(goal_point[None]), pot, pgrad, col)
-        i = info_t[0].cpu().numpy()
-        vis_pts = np.zeros([n, 11, P, 12])
-        vis_pts[:, :10, :, 6] = pot[0].cpu().numpy()
-        vis_pts[:, :10, :, 9:] = pgrad[0].cpu().numpy()
+        # one upload, two launches, one download (cost._Staging); results are host views valid until the next call
+        st = cost._run_step(traj.data, traj.start, traj.end, chosen, goal_point, 0 if info_only else (1 if force_update else 2), False)
+        i = st.h("info")[0].copy()
         info = {
-            "collision_pts": vis_pts, "obs": i[1], "smooth": i[2], "grasp": 0, "weighted_obs": i[3], "weighted_smooth": i[4],
+            "obs": i[1], "smooth": i[2], "grasp": 0, "weighted_obs": i[3], "weighted_smooth": i[4],
             "weighted_smooth_grad": i[6], "weighted_obs_grad": i[5], "weighted_grasp_grad": 0, "weighted_grasp": 0,
-            "gradient": grad[0].cpu().numpy(), "failure_terminate": bool(i[11]), "cost": i[0], "grad": i[7],
+            "gradient": st.h("grad")[0].copy(), "failure_terminate": bool(i[11]), "cost": i[0], "grad": i[7],
             "terminate": bool(i[10]), "collide": np.float32(i[8]), "standoff_idx": int(i[13]), "reach": i[9],
-            "execute": bool(i[12]), "cost_traj": cost_traj[0].cpu().numpy(), "violate_limit": bool(i[14]),
+            "execute": bool(i[12]), "cost_traj": st.h("cost_traj")[0].copy(), "violate_limit": bool(i[14]),
         }
+        from .cost import LazyInfo
+        info = LazyInfo(info, collision_pts=cost._collision_pts_builder(traj.data, st))  # built on first access (viewer only)
         info["text"] = self.report(np.asarray(traj.data), info)
         if (info["terminate"] and not force_update) or info_only:
             return info
-        traj.set(data[0].cpu().numpy())  # update + handle_joint_limit already applied on the device
+        traj.set(st.h("traj")[0].copy())  # update + handle_joint_limit already applied on the device
         return info
 
     # ---- numpy utilities with the reference's signatures (not used by optimize) -----------------------

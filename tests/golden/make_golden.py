@@ -319,6 +319,39 @@ def _fixed_host_helpers(out_dir, cfg, cost_mod, opt_mod, model):
     print("host_helpers.npz")
 
 
+def _fixed_vis(out_dir, cfg, cost_mod, util, kin, model, sc, rb):
+    """The visualisation arrays the reference returns beside the numbers (read by omg/core.py:561-570, 661): info["collision_pts"]
+    of compute_total_loss — positions, colours from color_point + the top-k highlight, gradients — and vis_pts of
+    batch_obstacle_cost (coloured from the UNWEIGHTED potentials, cost.py:219-230)."""
+    start = rb.HOME_CONFIG.copy()
+    goal = np.array([0.3, 0.2, 0.1, -1.6, 0.1, 1.9, 1.0, 0.04, 0.04])
+    out = {"collision_points": model.collision_points, "start": start, "end": goal}
+    for tag, seed, top_k, uncheck in (("topk", 2, 300, 0), ("clean", 3, 0, 0), ("soft", 5, 1000, -1)):
+        reset_cfg(cfg, timesteps=30, top_k_collision=top_k, uncheck_finger_collision=uncheck)
+        scene = small_scene(sc, seed, floor=(tag == "soft"))
+        env, sdf, lim = make_env(cfg, kin, model, scene)
+        c = cost_mod.Cost(env)
+        xi = sc.cubic_init(start, goal, 30) + 0.02 * np.random.RandomState(100 + seed).normal(size=(30, 9)) * np.array([1] * 7 + [0, 0])
+        traj = Traj(cfg, xi, start, goal, goal_set=goal[None] + 0.01, goal_idx=0)
+        cfg.obstacle_weight, cfg.smoothness_weight = cfg.base_obstacle_weight, cfg.smoothness_base_weight * cfg.cost_schedule_boost
+        _, _, info = c.compute_total_loss(traj)
+        out.update({f"{tag}_xi": xi, f"{tag}_top_k": np.int64(top_k), f"{tag}_uncheck": np.int64(uncheck),
+                    f"{tag}_collision_pts": info["collision_pts"], f"{tag}_goal_point": traj.goal_set[0]})
+        out.update({f"{tag}_{k}": v for k, v in scene_arrays(scene, sdf, lim).items()})
+    reset_cfg(cfg, timesteps=30)
+    scene = small_scene(sc, 22, floor=True)
+    env, sdf, lim = make_env(cfg, kin, model, scene)
+    c = cost_mod.Cost(env)
+    goals = goal[None] + np.concatenate([np.random.RandomState(322).normal(0, 0.08, size=(3, 7)), np.zeros((3, 2))], 1)
+    t0 = sc.cubic_init(start, goal, 30)[23]
+    joints = util.multi_interpolate_waypoints(t0, goals, 7, 9, "linear")
+    _, _, vis, _ = c.batch_obstacle_cost(joints, arc_length=7, special_check_id=env.target_idx, uncheck_finger_collision=0, start=t0, end=goals)
+    out.update(batch_traj_start=t0, batch_goals=goals, batch_joints=joints, batch_vis_pts=vis)
+    out.update({f"batch_{k}": v for k, v in scene_arrays(scene, sdf, lim).items()})
+    np.savez_compressed(out_dir / "vis.npz", **out)
+    print("vis.npz")
+
+
 def main(out_dir=OUT, script=None):
     """script=None regenerates the committed fixtures; otherwise script(ns) is called with the case generators
     (ns.run_cost_case, ns.run_opt_case, ns.run_batch_case, ns.run_learner_case: same code, any parameters) writing into
@@ -340,6 +373,7 @@ def main(out_dir=OUT, script=None):
     if fixed:
         _fixed_fk_and_matrices(out_dir, cfg, kin, util, model, rng, lo, hi, rb)
         _fixed_host_helpers(out_dir, cfg, cost_mod, opt_mod, model)
+        _fixed_vis(out_dir, cfg, cost_mod, util, kin, model, sc, rb)
 
     # ---- (ii)-(iv) cost path --------------------------------------------------------------------
     start = rb.HOME_CONFIG.copy()

@@ -417,6 +417,54 @@ def test_optimizer_class_matches_reference_fixture(dev, case):
     np.testing.assert_allclose(np.array(fx["schedule"][steps]), [cfg.obstacle_weight, cfg.smoothness_weight, cfg.step_size])
 
 
+def test_visualisation_arrays_match_reference(dev):
+    """info["collision_pts"] of compute_total_loss / Optimizer.optimize (built on first access) and vis_pts of
+    batch_obstacle_cost against the reference's arrays (tests/golden/vis.npz): shape [n,10,p,12], positions, colours from
+    color_point on the un-weighted potentials + the top-k highlight, gradients."""
+    from omg_planner_amd.config import Config
+    from omg_planner_amd.cost import Cost
+    from omg_planner_amd.optimizer import Optimizer
+    import types
+    fx = H.load("vis.npz")
+
+    def sub(prefix):
+        d = {k[len(prefix):]: fx[k] for k in fx if k.startswith(prefix)}
+        d["collision_points"] = fx["collision_points"]
+        return d
+
+    def compare(got, ref, what):
+        assert got.shape == ref.shape, what
+        np.testing.assert_allclose(got[..., :3], ref[..., :3], rtol=0, atol=1e-6, err_msg=what + " positions")
+        np.testing.assert_allclose(got[..., 9:], ref[..., 9:], rtol=0, atol=2e-4, err_msg=what + " gradients")
+        np.testing.assert_array_equal(got[..., 3:6], ref[..., 3:6])
+        # colours: 255 * relative potential; a float32 point that flips by one ulp moves a potential by ~1e-6
+        bad = np.abs(got[..., 6:9] - ref[..., 6:9]).max(-1) > 0.05
+        assert bad.mean() < 2e-3, f"{what}: {int(bad.sum())} of {bad.size} colours differ"
+
+    for tag in ("topk", "clean", "soft"):
+        d = sub(tag + "_")
+        cfg = Config(timesteps=30, top_k_collision=int(d["top_k"]), uncheck_finger_collision=int(d["uncheck"]))
+        cfg.obstacle_weight, cfg.smoothness_weight = cfg.base_obstacle_weight, cfg.smoothness_base_weight * cfg.cost_schedule_boost
+        env = _env_from(d, dev, cfg)
+        cost = Cost(env)
+        traj = _Traj(d["xi"], fx["start"], fx["end"], d["goal_point"][None])
+        _, _, info = cost.compute_total_loss(traj)
+        assert "collision_pts" not in info.keys() and len(info) == 19  # lazy: built by the first info["collision_pts"]
+        compare(info["collision_pts"], d["collision_pts"], tag)
+        assert "collision_pts" in info and len(info) == 20
+        cfg.use_standoff = False  # no reach_grasps in this fixture; the layer outputs do not depend on it
+        opt = Optimizer(types.SimpleNamespace(config=cfg, robot=env.robot), cost)
+        info2 = opt.optimize(traj, info_only=True)  # Optimizer.update moves the weights, not the layer outputs
+        compare(info2["collision_pts"], d["collision_pts"], tag + " (optimize)")
+        _, _, vis, _ = cost.compute_collision_loss(d["xi"], fx["start"], fx["end"])
+        compare(vis, d["collision_pts"], tag + " (compute_collision_loss)")
+    d = sub("batch_")
+    cost = Cost(_env_from(d, dev, Config(timesteps=30)))
+    _, _, vis, _ = cost.batch_obstacle_cost(d["joints"], arc_length=7, special_check_id=0, uncheck_finger_collision=0,
+                                            start=d["traj_start"], end=d["goals"])
+    compare(vis, d["vis_pts"], "batch")
+
+
 def test_omg_cuda_module_is_a_drop_in(dev):
     """`import omg_cuda; omg_cuda.sdf_loss_forward(...)` as layers/sdf_matching_loss.py:21-30 calls it."""
     import importlib

@@ -158,3 +158,19 @@ def test_optimizer_and_cost_numpy_methods_match_reference():
     vis = fx["cp_vis"].copy()
     c.color_point(vis, torch.as_tensor(fx["cp_collide"]))
     assert np.array_equal(vis, fx["cp_out"])
+
+
+def test_lazy_info_builds_collision_pts_on_first_access():
+    """cost.LazyInfo: info["collision_pts"] is built by the first subscript access (the reference's consumers index it,
+    omg/core.py:661) and is an ordinary key afterwards; other missing keys still raise KeyError."""
+    import pytest
+    from omg_planner_amd.cost import LazyInfo
+    calls = []
+    info = LazyInfo({"cost": 1.0}, collision_pts=lambda: calls.append(1) or np.ones((2, 10, 3, 12)))
+    assert "collision_pts" not in info and len(info) == 1 and not calls
+    assert info["collision_pts"].shape == (2, 10, 3, 12) and calls == [1]
+    assert info["collision_pts"].shape == (2, 10, 3, 12) and calls == [1] and "collision_pts" in info and len(info) == 2
+    with pytest.raises(KeyError):
+        info["nope"]
+    with pytest.raises(KeyError):
+        LazyInfo({"cost": 1.0})["collision_pts"]

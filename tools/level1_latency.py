@@ -1,0 +1,83 @@
+"""Latency of the drop-in classes on BASELINE config 1 (one scene, one trajectory: the reference's own use, omg/planner.py:600-653):
+`Optimizer.optimize`, `Cost.compute_total_loss`, `Cost.batch_obstacle_cost` (64 goals x 30 waypoints, as Learner.cost_vector calls
+it) and the raw op `omg_cuda.sdf_loss_forward`, each including the host <-> device copies the reference interface implies
+(numpy in, numpy / torch out).  GPU box.
+
+    python tools/level1_latency.py
+"""
+import os
+import sys
+import time
+import types
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from omg_planner_amd import robot as rb, scenes as sc
+from omg_planner_amd.config import Config
+from omg_planner_amd.cost import Cost
+from omg_planner_amd.optimizer import Optimizer
+
+
+class Traj:
+    def __init__(self, data, start, end, goal_set, goal_idx=0):
+        self.data, self.start, self.end, self.goal_set, self.goal_idx = np.array(data), np.array(start), np.array(end), goal_set, goal_idx
+
+    def set(self, new):
+        self.data = new
+
+    def update(self, g):
+        self.data = self.data + g
+
+
+def bench(fn, reps=100, warm=10):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps * 1e3
+
+
+def main():
+    dev = torch.device("cuda:0")
+    n, G = 30, 64
+    cfg = Config(timesteps=n, use_standoff=False)
+    model = rb.PandaModel(seed=0)
+    scene = sc.make_tabletop_scene(0, grid=64)
+    sdf, lim = sc.pack_padded(scene.objects)  # Env.combine_sdfs layout (omg/core.py:366-411)
+    robot = types.SimpleNamespace(collision_points=model.collision_points, joint_lower_limit=model.joint_lower_limit,
+                                  joint_upper_limit=model.joint_upper_limit)
+    objs = [types.SimpleNamespace(name=o.name, pose_mat=o.pose_mat, attached=False, reach_grasps=[]) for o in scene.objects]
+    env = types.SimpleNamespace(robot=robot, objects=objs, target_idx=scene.target_idx, config=cfg,
+                                sdf_torch=torch.as_tensor(sdf, device=dev), sdf_limits=torch.as_tensor(lim, device=dev))
+    cost = Cost(env)
+    opt = Optimizer(types.SimpleNamespace(config=cfg, robot=robot), cost)
+    goals = sc.make_reach_goals(scene, model, G, 0)
+    start = rb.HOME_CONFIG.copy()
+    traj = Traj(sc.cubic_init(start, goals[0], n), start, goals[0], goals, 0)
+    print("objects %d, padded SDF tensor %s" % (len(objs), tuple(sdf.shape)))
+    print("Optimizer.optimize(force_update=True)        %.3f ms / call" % bench(lambda: opt.optimize(traj, force_update=True)))
+    print("Optimizer.optimize(info_only=True)           %.3f ms / call" % bench(lambda: opt.optimize(traj, info_only=True)))
+    print("Cost.compute_total_loss                      %.3f ms / call" % bench(lambda: cost.compute_total_loss(traj)))
+    tt = (np.arange(1, n + 1) / (n + 1.0))[None, :, None]  # multi_interpolate_waypoints(..., "linear"), omg/util.py:261-290
+    joints = (traj.data[0][None, None, :] + tt * (goals[:, None, :] - traj.data[0][None, None, :])).reshape(-1, 9)
+    f = lambda: cost.batch_obstacle_cost(joints, arc_length=n, special_check_id=0, uncheck_finger_collision=0, start=traj.data[0], end=goals)  # noqa: E731
+    print("Cost.batch_obstacle_cost (64 goals x 30)     %.3f ms / call" % bench(f, reps=30, warm=3))
+    f2 = lambda: cost.batch_obstacle_cost(joints, arc_length=n, special_check_id=0, uncheck_finger_collision=0, start=traj.data[0], end=goals, want_vis=False)  # noqa: E731
+    print("  ... with want_vis=False                    %.3f ms / call" % bench(f2, reps=30, warm=3))
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "omg-planner_amd"))
+    import omg_cuda
+    poses, eps, pad, clr, dis = sc.layer_params(scene, **cfg.layer_kwargs())
+    args = [torch.as_tensor(np.ascontiguousarray(a, np.float32), device=dev) for a in (poses, sdf, lim)]
+    tail = [torch.as_tensor(np.ascontiguousarray(a, np.float32), device=dev) for a in (eps, pad, clr, dis)]
+    for N in (4500, 288000):
+        pts = torch.as_tensor(np.random.RandomState(0).uniform([-0.2, -0.6, 0.0], [1.0, 0.6, 1.0], (N, 3)).astype(np.float32), device=dev)
+        print("omg_cuda.sdf_loss_forward N = %-7d          %.3f ms / call" % (N, bench(lambda: omg_cuda.sdf_loss_forward(*args, pts, *tail))))
+
+
+if __name__ == "__main__":
+    main()
