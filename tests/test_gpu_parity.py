@@ -993,6 +993,22 @@ def test_cost_forward_kinematics_obstacle_matches_reference_fixture(dev):
             np.testing.assert_allclose(Js[j][..., :3], fx["J"][:, j, :, :k], atol=1e-12)
         np.testing.assert_allclose(pot, fx["potentials"], atol=2e-6)
         assert float(col) == float(fx["collide_sum"])
+        assert vis.shape == (n, 10, pot.shape[2], 12)
+        # Cost.compute_obstacle_cost_layer on explicit points (the op through the reference's own call shape, cost.py:288-360)
+        pts = torch.as_tensor(x.astype(np.float32), device=dev)
+        vis2 = np.zeros_like(vis)
+        p2, g2, c2 = cost.compute_obstacle_cost_layer(pts, vis2, special_check_id=0, uncheck_finger_collision=int(fx["cfg_uncheck"]))
+        np.testing.assert_allclose(p2.cpu().numpy(), fx["potentials"], atol=2e-6)
+        np.testing.assert_allclose(g2.cpu().numpy(), fx["potential_grads"], atol=2e-4)
+        assert float(c2.sum()) == float(fx["collide_sum"])
+        np.testing.assert_array_equal(vis2[..., :3], x.astype(np.float32))
+        np.testing.assert_array_equal(vis2[..., 6], p2.cpu().numpy())
+        # only_collide (cost.py:279-284): the whole batch is kept or zeroed by ONE any() over it
+        q = np.concatenate([fx["xi"], fx["xi"][::-1]], 0)
+        pa, _, _, _ = cost.batch_obstacle_cost(q, only_collide=False, uncheck_finger_collision=0, want_vis=False)
+        pb, _, _, _ = cost.batch_obstacle_cost(q, only_collide=True, uncheck_finger_collision=0, want_vis=False)
+        thr = 0.5 * (cost.cfg.epsilon - cost.cfg.clearance) ** 2 / cost.cfg.epsilon
+        assert torch.equal(pb, pa * bool((pa > thr).any()))
 
 
 def test_maximum_waypoints_64_matches_oracle(dev):
