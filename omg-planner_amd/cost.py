@@ -166,7 +166,7 @@ class Cost(object):
                tuple(cfg.disable_collision_set),
                tuple((o.name, bool(getattr(o, "attached", False)), np.asarray(o.pose_mat, np.float64).tobytes()) for o in env.objects))
         cached = getattr(self, "_scenes_cache", None)
-        if cached is not None and cached[0] == key and cached[1]() is env.sdf_torch:
+        if cached is not None and cached[0] == key and cached[1]() is env.sdf_torch and cached[3]() is lim_t:  # same OBJECTS, not recycled ids
             return cached[2]
         poses, eps, pad, clr, dis = self._layer_params()
         limits = _np(self.env.sdf_limits).astype(np.float32)
@@ -190,7 +190,7 @@ class Cost(object):
         if not (ds.pool.is_cuda and ds.pool.dtype == torch.float32 and ds.pool.is_contiguous()):
             raise _lib.OmgHipError("env.sdf_torch must be a contiguous float32 device tensor")
         import weakref
-        self._scenes_cache = (key, weakref.ref(env.sdf_torch), ds)
+        self._scenes_cache = (key, weakref.ref(env.sdf_torch), ds, weakref.ref(lim_t))
         return ds
 
     def _params(self, n: int, do_update: int) -> _lib.ChompParams:
