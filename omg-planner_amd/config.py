@@ -53,6 +53,11 @@ class Config:
         self.report_cost = False
         self.report_time = False
         self.timeout = 3.0
+        self.traj_interpolate = "cubic"   # config.py:63
+        self.dynamic_timestep = False     # config.py:89: trajectory length from the start-goal distance (core.py:64-76)
+        self.traj_delta = 0.05            # config.py:96
+        self.traj_max_step = 50           # config.py:98
+        self.traj_min_step = 2            # config.py:99
         self.base_link = "panda_link0"
         # -- scheduled by Optimizer.update (optimizer.py:68-80)
         self.obstacle_weight = self.base_obstacle_weight

@@ -61,6 +61,25 @@ def test_trajectory_container():
     assert (t.data[:, 7:] <= 0.04).all() and (t.data[:, 7:] >= 0).all()
 
 
+def test_trajectory_dynamic_timestep():
+    """cfg.dynamic_timestep (omg/core.py:64-76): n = clip(int(|start - end| / traj_delta), traj_min_step, traj_max_step);
+    cfg.timesteps is set FIRST, so get_global_param(n) keeps dt = 0.1 * n / n (config.py:201) and only resizes the matrices."""
+    from omg_planner_amd.config import Config
+    from omg_planner_amd.trajectory import Trajectory
+    cfg = Config(timesteps=30, dynamic_timestep=True)
+    t = Trajectory(cfg=cfg)
+    want = min(max(int(np.linalg.norm(t.start - t.end) / 0.05), 2), 50)
+    assert want == 50 and t.data.shape == (50, 9) and cfg.timesteps == 50 and t.timesteps == 50
+    assert abs(cfg.time_interval - 0.1) < 1e-15 and cfg.A.shape == (50, 50)
+    t.end = t.start + np.array([0.3, 0, 0, 0.4, 0, 0, 0, 0, 0])  # distance 0.5 -> 10 waypoints (0.5 / 0.05 = 10.000000000000002)
+    t.interpolate_waypoints(mode="linear")
+    assert t.data.shape == (int(np.linalg.norm(t.start - t.end) / 0.05), 9) and cfg.timesteps == t.data.shape[0]
+    np.testing.assert_allclose(t.data[0], t.start + (t.end - t.start) / (t.data.shape[0] + 1), atol=1e-15)
+    t.end = t.start + 1e-3
+    t.interpolate_waypoints()
+    assert t.data.shape == (2, 9)  # traj_min_step
+
+
 def test_cost_numpy_helpers_match_reference_intermediates():
     """functional_grad / compute_point_jacobian reproduce obs_grad of the clean branch from the fixture's x, v, a, J."""
     from omg_planner_amd.cost import Cost
