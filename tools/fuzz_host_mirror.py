@@ -7,6 +7,7 @@ callers which use them on their own:
     Optimizer.compute_traj_v, handle_joint_limit, check_joint_limit   (optimizer.py:137-174)
     Optimizer.update   (schedules written into cfg, optimizer.py:59-80)
     Cost.forward_points, color_point, functional_grad, compute_point_jacobian   (cost.py:24-110)
+    scene_io.save_sdf_pth / load_sdf_pth vs SignedDensityField.from_pth (+ .resize)   (sdf_tools.py:37-45,186-193)
     config.get_global_param matrices (A, Ainv, diff) for random trajectory lengths / link weights / time steps
 
     python tools/fuzz_host_mirror.py [trials] [seed]
@@ -46,6 +47,12 @@ def main():
     lo, hi = model.joint_lower_limit, model.joint_upper_limit
     stats, fails = {}, []
     t0 = time.time()
+    import importlib
+    import tempfile
+    sdf_tools = importlib.import_module("omg.sdf_tools")
+    from omg_planner_amd import scene_io
+    from omg_planner_amd.scenes import SdfGrid
+    tmpdir = tempfile.mkdtemp(prefix="omg_pth_")
 
     def check(name, a, b, rtol=1e-9, atol=1e-10):
         stats[name] = stats.get(name, 0) + 1
@@ -141,9 +148,27 @@ def main():
         for ty in ("revolute", "prsimatic"):
             check(f"compute_point_jacobian[{ty}]", m_c.compute_point_jacobian(org, x, ax, None, ty),
                   r_c.compute_point_jacobian(org, x, ax, None, ty), rtol=0, atol=0)
+        if k % 10 == 0:  # the SDF volume file format: our writer -> the reference's reader, and our reader on the same file
+            dims = tuple(int(d) for d in rng.randint(2, 12, 3))
+            grid = SdfGrid(rng.normal(0, 0.1, dims).astype(np.float32), rng.uniform(-0.3, 0.0, 3), float(rng.choice([0.01, 0.02, 0.005])))
+            path = f"{tmpdir}/m{k}.pth"
+            scene_io.save_sdf_pth(path, grid)
+            ref = sdf_tools.SignedDensityField.from_pth(path)
+            ratio = float(rng.choice([1.0, 1.0, 0.6, 1.3]))
+            if ratio != 1.0:
+                ref.data = ref.data.copy()
+                ref.origin = ref.origin.copy()
+                ref.resize(ratio)
+            ours = scene_io.load_sdf_pth(path, resize=ratio)
+            check("pth.data", ours.data, ref.data, rtol=0, atol=0)
+            check("pth.origin", ours.origin, ref.origin, rtol=1e-15, atol=0)
+            check("pth.delta", ours.delta, ref.delta, rtol=1e-15, atol=0)
+            check("pth.shape", np.array(ours.data.shape), np.array([ref.nx, ref.ny, ref.nz]), rtol=0, atol=0)
         if fails:
             print(f"trial {k} [n={n} dt={dt} standoff={standoff} c={c}]: FAIL " + "; ".join(fails[:4]), flush=True)
             break
+    import shutil
+    shutil.rmtree(tmpdir, ignore_errors=True)
     total = sum(stats.values())
     print(f"{'FAILED' if fails else 'all agree'}: {total} comparisons over {k + 1} trials ({', '.join(sorted(stats))}); {time.time() - t0:.0f} s")
     return 1 if fails else 0
