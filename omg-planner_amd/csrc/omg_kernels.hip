@@ -152,7 +152,7 @@ __global__ __launch_bounds__(64) void k_fk_poses(FkArgs a) {
         } else {
             const int g = c / a.n, i = c % a.n;
             const double* qg = a.goals + ((int64_t)s * (a.C / a.n) + g) * 9;
-            const double t = (double)(i + 1) / (double)(a.n + 1);  // linspace(0,1,n+2)[1:-1]
+            const double t = (double)(i + 1) * (1.0 / (double)(a.n + 1));  // linspace(0,1,n+2)[1:-1] = i * step, step = fl(1 / (n + 1)) (numpy)
 #pragma unroll
             for (int d = 0; d < 9; ++d) q[d] = q0[d] + t * (qg[d] - q0[d]);
             rowptr[lane] = a.ws + ((((int64_t)s * NCH + c / CH) * 10) * CH + c % CH) * 12;
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(TPB) void k_sdf_chunks(ChunkArgs a) {
         for (int cfg = threadIdx.x; cfg < CH + 1; cfg += TPB) {
             const double* q0 = a.traj_start + a.ts_stride * (int64_t)s;
             const double* qg = a.goals + ((int64_t)s * a.NCH + chunk) * 9;
-            const double t = (double)cfg / (double)(CH + 1);  // cfg 0 = start itself, cfg i+1 = linspace(0,1,n+2)[1:-1][i]
+            const double t = (double)cfg * (1.0 / (double)(CH + 1));  // cfg 0 = start itself, cfg i+1 = linspace(0,1,n+2)[1:-1][i] = (i + 1) * fl(1 / (n + 1))
             double q[9];
 #pragma unroll
             for (int d = 0; d < 9; ++d) q[d] = cfg == 0 ? q0[d] : q0[d] + t * (qg[d] - q0[d]);
@@ -507,7 +507,8 @@ __global__ __launch_bounds__(256, GS_WG_PER_CU) void k_goalset_compact(ChunkArgs
         const int ncfg = CH + 1;
         double* sc = reinterpret_cast<double*>(rowmask);  // [ncfg][7][2]
         // cfg 0 = start itself, cfg i+1 = linspace(0,1,n+2)[1:-1][i]
-        auto joint = [&](int cfg, int d) { return cfg == 0 ? q0[d] : q0[d] + ((double)cfg / (double)(CH + 1)) * (qg[d] - q0[d]); };
+        // numpy's linspace is i * step with step = fl(1 / (n + 1)), not i / (n + 1): bit-identical to util.py:261-290 (interp1d)
+        auto joint = [&](int cfg, int d) { return cfg == 0 ? q0[d] : q0[d] + ((double)cfg * (1.0 / (double)(CH + 1))) * (qg[d] - q0[d]); };
         for (int t = threadIdx.x; t < ncfg * 7; t += 256) {
             const int cfg = t / 7, i = t - cfg * 7;
             double sn, cs;

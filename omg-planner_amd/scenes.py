@@ -465,8 +465,9 @@ def make_reach_goals(scene: "Scene", model, num_goals: int, seed: int = 0) -> np
 
 
 def linear_init(start: np.ndarray, end: np.ndarray, n: int) -> np.ndarray:
-    """Interior waypoints linspace(0,1,n+2)[1:-1] between start and end (util.py:238-258, "linear")."""
-    t = (np.arange(1, n + 1) / (n + 1.0))[:, None]
+    """Interior waypoints linspace(0,1,n+2)[1:-1] between start and end (util.py:238-258, "linear"): bit-identical to
+    the reference's interp1d result (linspace is i * step with step = fl(1 / (n + 1)))."""
+    t = np.linspace(0, 1, n + 2)[1:-1, None]
     return start[None] + t * (end - start)[None]
 
 

@@ -305,7 +305,7 @@ int orc_goalset_cost(const double* robot, int32_t P, const omgx_object* objects,
         float total = 0.0f, ncol = 0.0f;
         for (int i = 0; i < n; ++i) {
             /* multi_interpolate_waypoints "linear": t = linspace(0,1,n+2)[1:-1], util.py:261-290 */
-            const double t = (double)(i + 1) / (double)(n + 1);
+            const double t = (double)(i + 1) * (1.0 / (double)(n + 1)); /* numpy linspace: i * step, step = fl(1 / (n + 1)) */
             double q[ND];
             for (int d = 0; d < ND; ++d) q[d] = q0[d] + t * (qg[d] - q0[d]);
             orc_fk(robot, q, pose, NULL, NULL);

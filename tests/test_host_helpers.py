@@ -61,6 +61,22 @@ def test_trajectory_container():
     assert (t.data[:, 7:] <= 0.04).all() and (t.data[:, 7:] >= 0).all()
 
 
+def test_linear_interpolation_is_bit_identical_to_the_references_interp1d():
+    """omg/util.py:238-290 ("linear"): interp1d over x = [0, 1] at t = linspace(0, 1, n + 2)[1:-1].  numpy's linspace is
+    i * fl(1 / (n + 1)), not i / (n + 1) — the device kernels and the oracle use the same expression (omg_kernels.hip,
+    omg_oracle.c), scenes.linear_init is checked here for every trajectory length."""
+    from scipy import interpolate
+    from omg_planner_amd import scenes as sc
+    rng = np.random.RandomState(0)
+    for n in range(1, 65):
+        a, b = rng.uniform(-3, 3, 9), rng.uniform(-3, 3, 9)
+        f = interpolate.interp1d(np.linspace(0, 1, 2), np.stack([a, b]), "linear", axis=0)
+        want = f(np.linspace(0, 1, n + 2)[1:-1])
+        assert np.array_equal(sc.linear_init(a, b, n), want), n
+        i = np.arange(1, n + 1)[:, None]
+        assert np.array_equal(a + (i * (1.0 / (n + 1.0))) * (b - a), want), n  # the expression of the kernels / the oracle
+
+
 def test_trajectory_dynamic_timestep():
     """cfg.dynamic_timestep (omg/core.py:64-76): n = clip(int(|start - end| / traj_delta), traj_min_step, traj_max_step);
     cfg.timesteps is set FIRST, so get_global_param(n) keeps dt = 0.1 * n / n (config.py:201) and only resizes the matrices."""
