@@ -561,6 +561,57 @@ def main(out_dir=OUT, script=None):
         np.savez_compressed(out_dir / f"learner_{alg}_{int(use_standoff)}{tag}.npz", **rec)
         print(f"learner_{alg}_{int(use_standoff)}{tag}.npz  goal_idx {idxs}")
 
+    # ---- (ix) the whole planner loop: Learner.__init__ + Planner.plan (omg/planner.py:600-653), free-running ----------
+    def run_plan_case(name, scene_seed, G, alg, use_standoff, cfg_over=None):
+        reset_cfg(cfg, timesteps=30, ol_alg=alg, use_standoff=use_standoff, **(cfg_over or {}))
+        scene = small_scene(sc, scene_seed)
+        env, sdf, lim = make_env(cfg, kin, model, scene)
+        r = np.random.RandomState(500 + scene_seed)
+        goals = goal[None] + np.concatenate([r.normal(0, 0.15, size=(G, 7)), np.zeros((G, 2))], 1)
+        reach = np.stack([np.concatenate([sc.linear_init(g - np.array([0.1, -0.05, 0.1, 0.15, 0, -0.1, 0.1, 0, 0]), g, 4), g[None]], 0)
+                          for g in goals])
+        env.objects[env.target_idx].reach_grasps = reach
+        c = cost_mod.Cost(env)
+        traj = Traj(cfg, np.zeros((30, 9)), start, goals[0], goal_set=goals, goal_idx=0)
+        # Trajectory.interpolate_waypoints (core.py:60-76) with the reference's own util function
+        traj.interpolate_waypoints = lambda waypoints=None, mode="cubic": traj.set(
+            util.interpolate_waypoints(np.stack([traj.start, traj.end]), cfg.timesteps, 9, mode=mode))
+        traj.interpolate_waypoints()
+        learner = LEARNER_MOD.Learner(env, traj, c)  # picks the initial goal and re-interpolates (online_learner.py:96-102)
+        optim = opt_mod.Optimizer(types.SimpleNamespace(config=cfg, robot=env.robot), c)
+        rec = dict(goal_set=goals, reach_grasps=reach, start=start, collision_points=model.collision_points, alg=np.array(alg),
+                   init_goal_idx=np.int64(traj.goal_idx), init_traj=np.array(traj.data), cfg_dt=np.float64(cfg.time_interval),
+                   cfg_use_standoff=np.int64(use_standoff), optim_steps=np.int64(cfg.optim_steps),
+                   extra_smooth_steps=np.int64(cfg.extra_smooth_steps))
+        history, infos, selected = [], [], []
+        alg_switch = alg not in ("Baseline", "Proj")
+        for t in range(cfg.optim_steps + cfg.extra_smooth_steps):  # planner.py:612-630
+            if cfg.goal_set_proj and alg_switch and t < cfg.optim_steps:
+                learner.update_goal()
+            selected.append(int(traj.goal_idx))
+            infos.append(optim.optimize(traj, force_update=True))
+            history.append(np.copy(traj.data))
+            if infos[-1]["terminate"] and t > 0:
+                break
+        terminated = bool(infos[-1]["terminate"])
+        if not terminated:
+            infos.append(optim.optimize(traj, info_only=True))
+        rec.update(history=np.stack(history), selected_goals=np.array(selected), terminated=np.int64(terminated),
+                   iterations=np.int64(len(history)))
+        for k in INFO_NUMERIC + INFO_BOOL:
+            rec["info_" + k] = np.array([float(i[k]) for i in infos])
+        rec.update(scene_arrays(scene, sdf, lim))
+        rec.update(cfg_record())
+        np.savez_compressed(out_dir / f"plan_{name}.npz", **rec)
+        print(f"plan_{name}.npz  iterations {len(history)} terminated {terminated} goals {sorted(set(selected))} final cost {infos[-1]['cost']:.4f}")
+
+    if fixed:
+        run_plan_case("md_switch_70", 44, 8, "MD", False)          # 70 iterations, the goal changes on the way, never terminates
+    if fixed:
+        run_plan_case("exp_standoff_41", 47, 8, "Exp", True)       # standoff tails, goal change late, terminates at iteration 41
+    if fixed:
+        run_plan_case("md_early_2", 43, 8, "MD", False)            # terminates after two iterations (planner.py:626)
+
     for alg in (("FTL", "FTC", "Exp", "MD") if fixed else ()):
         run_learner_case(alg, 31, 8, 6, False)
     if fixed:
@@ -580,7 +631,7 @@ def main(out_dir=OUT, script=None):
         run_batch_case("arc_attached_g4_n12", 24, 4, 12, True, 0, attached=True)
     if script is not None:
         script(types.SimpleNamespace(run_cost_case=run_cost_case, run_opt_case=run_opt_case, run_batch_case=run_batch_case,
-                                     run_learner_case=run_learner_case, cfg=cfg, sc=sc, model=model))
+                                     run_learner_case=run_learner_case, run_plan_case=run_plan_case, cfg=cfg, sc=sc, model=model))
 
 
 if __name__ == "__main__":

@@ -822,6 +822,44 @@ def test_fused_update_optimize_equals_separate_launches(dev, alg, standoff, n, m
             assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("case", ["md_switch_70", "exp_standoff_41", "md_early_2"])
+@pytest.mark.parametrize("mode", ["fused", "serial"])
+def test_engine_plan_matches_reference_planner_loop(dev, case, mode, monkeypatch):
+    """ChompEngine on ONE scene against the reference's own planner run (tests/golden/plan_*.npz: Learner.__init__'s goal
+    pick, then Learner.update_goal + Optimizer.optimize per iteration with the break on `terminate`, then the info-only
+    evaluation; omg/planner.py:600-653), free-running for up to 70 iterations: same goal sequence, trajectories 1e-6."""
+    from omg_planner_amd.config import Config
+    from omg_planner_amd.engine import ChompEngine
+    monkeypatch.setenv("OMGX_ITERATION", mode)
+    fx = H.load(f"plan_{case}.npz")
+    m, batch = H.model_from(fx), H.batch_from(fx)
+    standoff = bool(int(fx["cfg_use_standoff"]))
+    cfg = Config(timesteps=30, use_standoff=standoff)
+    assert cfg.optim_steps == int(fx["optim_steps"]) and cfg.extra_smooth_steps == int(fx["extra_smooth_steps"])
+    eng = ChompEngine(m, batch, cfg, fx["start"][None], fx["goal_set"][None], reach_grasps=fx["reach_grasps"][None] if standoff else None,
+                      device=dev, ol_alg=str(fx["alg"]))
+    eng.select_initial_goal()
+    assert int(eng.goal_idx[0]) == int(fx["init_goal_idx"])
+    np.testing.assert_allclose(eng.traj[0].cpu().numpy(), fx["init_traj"], rtol=0, atol=1e-12)
+    iters = int(fx["iterations"])
+    for t in range(cfg.optim_steps + cfg.extra_smooth_steps):
+        eng.iterate(t, early_stop=True)
+        if t < iters:
+            assert int(eng.goal_idx[0]) == int(fx["selected_goals"][t]), t
+            np.testing.assert_allclose(eng.traj[0].cpu().numpy(), fx["history"][t], rtol=0, atol=1e-6, err_msg=f"iteration {t}")
+            info = eng.info[0].cpu().numpy()
+            np.testing.assert_allclose(info[0], fx["info_cost"][t], rtol=1e-5, err_msg=f"iteration {t}")
+            assert float(info[8]) == float(fx["info_collide"][t]) and bool(info[10] > 0.5) == bool(fx["info_terminate"][t]), t
+        else:  # the reference has left its loop (planner.py:626); the engine's scene is inactive and keeps its trajectory
+            assert int(eng.active[0]) == 0
+            np.testing.assert_allclose(eng.traj[0].cpu().numpy(), fx["history"][iters - 1], rtol=0, atol=1e-6)
+    assert bool(int(eng.active[0]) == 0) == bool(int(fx["terminated"]))
+    if not int(fx["terminated"]):
+        final = eng.optimize(False)[0].cpu().numpy()
+        np.testing.assert_allclose(final[0], fx["info_cost"][-1], rtol=1e-5)
+        np.testing.assert_allclose(final[2], fx["info_smooth"][-1], rtol=1e-6)
+
+
 def test_two_launch_entry_points_reject_bad_arguments(dev, monkeypatch):
     """omgx_goalset_cost_layer / omgx_goal_update_optimize: error codes, never a crash; odd sizes (1 scene, 1 goal, window
     shorter than the trajectory) agree with the separate entry points."""
