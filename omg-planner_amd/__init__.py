@@ -6,6 +6,7 @@ Layout (only what the path needs):
   ops.py       thin tensor-level wrappers over the C ABI (torch tensors own the device memory)
   cost.py      `Cost`      — host-side mirror of omg/cost.py's class surface
   optimizer.py `Optimizer` — host-side mirror of omg/optimizer.py's class surface
+  online_learner.py `Learner` — host-side mirror of omg/online_learner.py's class surface (goal selection on the device)
   config.py    `cfg`       — the hyper-parameters the path reads (omg/config.py)
   trajectory.py / util.py   — `Trajectory` container and the index/angle helpers of the path
   engine.py    `ChompEngine` — batched, device-resident planner loop over S scenes (+ sharding over ranks)

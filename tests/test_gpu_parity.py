@@ -860,6 +860,47 @@ def test_engine_plan_matches_reference_planner_loop(dev, case, mode, monkeypatch
         np.testing.assert_allclose(final[2], fx["info_smooth"][-1], rtol=1e-6)
 
 
+@pytest.mark.parametrize("case", ["md_switch_70", "exp_standoff_41", "md_early_2"])
+def test_drop_in_classes_reproduce_reference_planner_loop(dev, case):
+    """The single-scene drop-in level: Planner.plan's loop (omg/planner.py:600-653) written with the mirror classes
+    Trajectory / Cost / Optimizer / Learner exactly as the reference writes it with its own, against the reference's run."""
+    from omg_planner_amd.config import Config
+    from omg_planner_amd.cost import Cost
+    from omg_planner_amd.online_learner import Learner
+    from omg_planner_amd.optimizer import Optimizer
+    from omg_planner_amd.trajectory import Trajectory
+    import types
+    fx = H.load(f"plan_{case}.npz")
+    standoff = bool(int(fx["cfg_use_standoff"]))
+    cfg = Config(timesteps=30, use_standoff=standoff, ol_alg=str(fx["alg"]))
+    env = _env_from(fx, dev, cfg)
+    env.objects[env.target_idx].reach_grasps = fx["reach_grasps"]
+    traj = Trajectory(cfg=cfg)
+    traj.start, traj.goal_set, traj.end = fx["start"].copy(), fx["goal_set"], fx["goal_set"][0].copy()
+    traj.interpolate_waypoints()
+    cost = Cost(env)
+    learner = Learner(env, traj, cost)
+    optim = Optimizer(types.SimpleNamespace(config=cfg, robot=env.robot), cost)
+    assert int(traj.goal_idx) == int(fx["init_goal_idx"])
+    np.testing.assert_allclose(traj.data, fx["init_traj"], rtol=0, atol=1e-12)
+    infos, history = [], []
+    for t in range(cfg.optim_steps + cfg.extra_smooth_steps):
+        if cfg.goal_set_proj and cfg.ol_alg not in ("Baseline", "Proj") and t < cfg.optim_steps:
+            learner.update_goal()
+        assert int(traj.goal_idx) == int(fx["selected_goals"][t]), t
+        infos.append(optim.optimize(traj, force_update=True))
+        history.append(np.copy(traj.data))
+        np.testing.assert_allclose(traj.data, fx["history"][t], rtol=0, atol=1e-6, err_msg=f"iteration {t}")
+        np.testing.assert_allclose(infos[-1]["cost"], fx["info_cost"][t], rtol=1e-5)
+        if infos[-1]["terminate"] and t > 0:
+            break
+    assert len(history) == int(fx["iterations"]) and bool(infos[-1]["terminate"]) == bool(int(fx["terminated"]))
+    if not infos[-1]["terminate"]:
+        infos.append(optim.optimize(traj, info_only=True))
+        np.testing.assert_allclose(infos[-1]["cost"], fx["info_cost"][-1], rtol=1e-5)
+    assert abs(learner.p.sum() - 1.0) < 1e-7 and learner.t == min(len(history), cfg.optim_steps)  # Exp normalises with safe_div (+1e-8)
+
+
 def test_two_launch_entry_points_reject_bad_arguments(dev, monkeypatch):
     """omgx_goalset_cost_layer / omgx_goal_update_optimize: error codes, never a crash; odd sizes (1 scene, 1 goal, window
     shorter than the trajectory) agree with the separate entry points."""

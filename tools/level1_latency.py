@@ -69,6 +69,26 @@ def main():
     print("Cost.batch_obstacle_cost (64 goals x 30)     %.3f ms / call" % bench(f, reps=30, warm=3))
     f2 = lambda: cost.batch_obstacle_cost(joints, arc_length=n, special_check_id=0, uncheck_finger_collision=0, start=traj.data[0], end=goals, want_vis=False)  # noqa: E731
     print("  ... with want_vis=False                    %.3f ms / call" % bench(f2, reps=30, warm=3))
+    from omg_planner_amd.online_learner import Learner
+    from omg_planner_amd.trajectory import Trajectory
+    cfg.ol_alg = "MD"
+    env.objects[env.target_idx].reach_grasps = goals[:, None, :]  # non-empty: Learner.__init__ picks the initial goal
+    t2 = Trajectory(cfg=cfg)
+    t2.start, t2.goal_set, t2.end = start, goals, goals[0]
+    t2.interpolate_waypoints()
+    learner = Learner(env, t2, cost)
+
+    def upd():
+        learner.t = 0.0  # full 30-waypoint window every time
+        learner.update_goal()
+    print("Learner.update_goal (MD, 64 goals x 30)      %.3f ms / call" % bench(upd))
+    t0 = time.perf_counter()
+    for t in range(cfg.optim_steps + cfg.extra_smooth_steps):  # Planner.plan's loop (planner.py:612-630) with the mirror classes
+        if t < cfg.optim_steps:
+            learner.update_goal()
+        opt.optimize(t2, force_update=True)
+    opt.optimize(t2, info_only=True)
+    print("Planner.plan loop, mirror classes (70 it.)   %.3f ms / plan" % ((time.perf_counter() - t0) * 1e3))
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "omg-planner_amd"))
     import omg_cuda
     poses, eps, pad, clr, dis = sc.layer_params(scene, **cfg.layer_kwargs())
