@@ -227,7 +227,7 @@ class Cost(object):
         with the dummy hand joint (the output of wrap_value), as omg/cost.py:45-58."""
         model, robot = self._robot_model()
         j = np.asarray(joints, np.float64)
-        q = np.deg2rad(np.concatenate([j[:7], j[8:10]]) if j.shape[0] > 9 else j)
+        q = (np.concatenate([j[:7], j[8:10]]) if j.shape[0] > 9 else j) / 180.0 * np.pi  # deg2rad as robot_pykdl.py:70-73 writes it
         poses, org, ax = ops.forward_kinematics(robot, model.points_per_link, self._t(q[None]))
         return _np(poses[0]), _np(org[0]), _np(ax[0])
 

@@ -13,14 +13,28 @@ def safe_div(dividend, divisor, eps=1e-8):
     return dividend / (divisor + eps)
 
 
+def rad2deg(rad):
+    """rad / pi * 180 (omg/util.py:73-76) — NOT np.rad2deg, which multiplies by the constant 180 / pi and differs in the last bit."""
+    if type(rad) is list:
+        return [x / np.pi * 180 for x in rad]
+    return rad / np.pi * 180
+
+
+def deg2rad(deg):
+    """deg / 180 * pi (omg/util.py:67-70)."""
+    if type(deg) is list:
+        return [x / 180.0 * np.pi for x in deg]
+    return deg / 180.0 * np.pi
+
+
 def wrap_value(value):
     """One configuration: radians -> degrees, 9 -> 10 entries with a zero for the hand joint (util.py:185-191)."""
     value = np.asarray(value, dtype=np.float64)
     if value.shape[0] <= 7:
-        return np.rad2deg(value)
+        return rad2deg(value)
     out = np.zeros(value.shape[0] + 1)
-    out[:7] = np.rad2deg(value[:7])
-    out[8:] = np.rad2deg(value[7:])
+    out[:7] = rad2deg(value[:7])
+    out[8:] = rad2deg(value[7:])
     return out
 
 
@@ -28,10 +42,10 @@ def wrap_values(value):
     """A batch [B, dof] of configurations (util.py:194-202)."""
     value = np.asarray(value, dtype=np.float64)
     if value.shape[1] <= 7:
-        return np.rad2deg(value)
+        return rad2deg(value)
     out = np.zeros((value.shape[0], value.shape[1] + 1))
-    out[:, :7] = np.rad2deg(value[:, :7])
-    out[:, 8:] = np.rad2deg(value[:, 7:])
+    out[:, :7] = rad2deg(value[:, :7])
+    out[:, 8:] = rad2deg(value[:, 7:])
     return out
 
 

@@ -148,6 +148,29 @@ def main():
         for ty in ("revolute", "prsimatic"):
             check(f"compute_point_jacobian[{ty}]", m_c.compute_point_jacobian(org, x, ax, None, ty),
                   r_c.compute_point_jacobian(org, x, ax, None, ty), rtol=0, atol=0)
+        # util helpers (omg/util.py:129-135,181-220)
+        from omg_planner_amd import util as mutil
+        qv = rng.uniform(-3, 3, int(rng.choice([7, 9])))
+        check("util.wrap_value", mutil.wrap_value(qv), util.wrap_value(qv), rtol=0, atol=0)
+        qs = rng.uniform(-3, 3, (int(rng.randint(1, 5)), 9))
+        check("util.wrap_values", mutil.wrap_values(qs), util.wrap_values(qs), rtol=0, atol=0)
+        for j in range(1, 11):
+            check("util.wrap_index", mutil.wrap_index(j), util.wrap_index(j), rtol=0, atol=0)
+            check("util.wrap_joint", mutil.wrap_joint(j), util.wrap_joint(j), rtol=0, atol=0)
+        RT = np.eye(4)
+        RT[:3, :3] = np.linalg.qr(rng.normal(size=(3, 3)))[0]
+        RT[:3, 3] = rng.normal(size=3)
+        inv_a, inv_b = mutil.se3_inverse(RT), util.se3_inverse(RT)
+        check("util.se3_inverse", inv_a, inv_b, rtol=0, atol=0)
+        check("util.se3_inverse.dtype", np.array([inv_a.dtype == inv_b.dtype]), np.array([True]), rtol=0, atol=0)
+        check("util.rad2deg", mutil.rad2deg(qv), util.rad2deg(qv), rtol=0, atol=0)
+        check("util.deg2rad", mutil.deg2rad(qv * 50), util.deg2rad(qv * 50), rtol=0, atol=0)
+        check("util.safe_div", mutil.safe_div(qv, qv[::-1]), util.safe_div(qv, qv[::-1]), rtol=0, atol=0)
+        # Trajectory initialisation (omg/util.py:238-258 through scipy): linear bit-identical, cubic to round-off
+        from omg_planner_amd import scenes as msc
+        a9, b9 = rng.uniform(-3, 3, 9), rng.uniform(-3, 3, 9)
+        check("interpolate[linear]", msc.linear_init(a9, b9, n), util.interpolate_waypoints(np.stack([a9, b9]), n, 9, "linear"), rtol=0, atol=0)
+        check("interpolate[cubic]", msc.cubic_init(a9, b9, n), util.interpolate_waypoints(np.stack([a9, b9]), n, 9, "cubic"), rtol=0, atol=1e-14)
         if k % 10 == 0:  # the SDF volume file format: our writer -> the reference's reader, and our reader on the same file
             dims = tuple(int(d) for d in rng.randint(2, 12, 3))
             grid = SdfGrid(rng.normal(0, 0.1, dims).astype(np.float32), rng.uniform(-0.3, 0.0, 3), float(rng.choice([0.01, 0.02, 0.005])))
