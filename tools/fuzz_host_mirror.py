@@ -148,6 +148,16 @@ def main():
         for ty in ("revolute", "prsimatic"):
             check(f"compute_point_jacobian[{ty}]", m_c.compute_point_jacobian(org, x, ax, None, ty),
                   r_c.compute_point_jacobian(org, x, ax, None, ty), rtol=0, atol=0)
+        # finite differences with the boundary terms (omg/config.py:134-187), numpy and torch float32
+        import torch
+        pshape = (int(rng.randint(1, 4)), int(rng.randint(1, 4)))
+        dat, st_, en_ = rng.normal(size=pshape + (n, 3)), rng.normal(size=pshape + (3,)), rng.normal(size=pshape + (3,))
+        for order in (1, 2):
+            check(f"get_derivative[{order}]", cfg.get_derivative(dat.copy(), st_, en_, order), rcfg.get_derivative(dat.copy(), st_, en_, order),
+                  rtol=1e-12, atol=1e-9)
+        td, ts_, te_ = (torch.as_tensor(x, dtype=torch.float32) for x in (dat, st_, en_))
+        check("get_derivative_torch", cfg.get_derivative_torch(td.clone(), ts_, te_).numpy(), rcfg.get_derivative_torch(td.clone(), ts_, te_).numpy(),
+              rtol=1e-5, atol=1e-4)
         # util helpers (omg/util.py:129-135,181-220)
         from omg_planner_amd import util as mutil
         qv = rng.uniform(-3, 3, int(rng.choice([7, 9])))
