@@ -1,14 +1,14 @@
 """GPU-box half of the device-vs-REFERENCE check on random cases: runs the fixture-based GPU tests of
 tests/test_gpu_parity.py (C ABI entry points and the drop-in Cost / Optimizer classes against the reference's outputs) on
-every fixture that tools/make_random_fixtures.py wrote to tests/golden_random/.
+every fixture that tests/fuzz/make_random_fixtures.py wrote to tests/golden_random/.
 
-    python tools/check_random_fixtures.py
+    python tests/fuzz/check_random_fixtures.py
 """
 import sys
 import traceback
 from pathlib import Path
 
-ROOT = Path(__file__).resolve().parents[1]
+ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT))
 import torch  # noqa: E402
 
@@ -20,7 +20,7 @@ def main():
     src = ROOT / "tests" / "golden_random"
     files = sorted(src.glob("*.npz"))
     if not files:
-        raise SystemExit(f"no fixtures in {src}: run tools/make_random_fixtures.py in the build container first")
+        raise SystemExit(f"no fixtures in {src}: run tests/fuzz/make_random_fixtures.py in the build container first")
     H.GOLDEN = src
     dev = torch.device("cuda:0")
     stats, bad = {}, 0

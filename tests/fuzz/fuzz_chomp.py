@@ -4,13 +4,13 @@ k = 1 / k = total / k > total / k = 0 (clean branch), 1..64 waypoints, 1..16 poi
 fixed end, inactive scenes, do_update 0 / 1 / 2, trajectories outside the joint limits.  Ties at the cut are resolved by
 ascending flat index in both builds, so results must agree to round-off.
 
-    python tools/fuzz_chomp.py [trials] [seed]
+    python tests/fuzz/fuzz_chomp.py [trials] [seed]
 """
 import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 

@@ -10,7 +10,7 @@ callers which use them on their own:
     scene_io.save_sdf_pth / load_sdf_pth vs SignedDensityField.from_pth (+ .resize)   (sdf_tools.py:37-45,186-193)
     config.get_global_param matrices (A, Ainv, diff) for random trajectory lengths / link weights / time steps
 
-    python tools/fuzz_host_mirror.py [trials] [seed]
+    python tests/fuzz/fuzz_host_mirror.py [trials] [seed]
 """
 import importlib.util
 import sys
@@ -18,7 +18,7 @@ import time
 import types
 from pathlib import Path
 
-ROOT = Path(__file__).resolve().parents[1]
+ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT))
 import numpy as np  # noqa: E402
 

@@ -2,13 +2,13 @@
 sequences of updates that accumulate state (sum of costs, expert distributions, mixture weights), goal costs that are
 sparse / equal (ties) / tiny / huge / all zero (NaN cost vector), with and without standoff tails and normalisation.
 
-    python tools/fuzz_learner.py [trials] [seed]
+    python tests/fuzz/fuzz_learner.py [trials] [seed]
 """
 import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 

@@ -2,13 +2,13 @@
 nearest-point distance grids for random clouds / resolutions / margins) and omgx_forward_kinematics (poses, joint origins
 and axes of random configurations incl. far outside the joint limits, 1e-12).
 
-    python tools/fuzz_misc.py [trials] [seed]
+    python tests/fuzz/fuzz_misc.py [trials] [seed]
 """
 import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 

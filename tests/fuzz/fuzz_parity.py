@@ -3,13 +3,13 @@ learner and step in different workgroups) against the same loop driven through t
 goal counts, trajectory lengths, points per link, scene contents, SDF-layer parameters, top-k settings, finger options,
 goal-selection rules and standoff tails.  A tool (test infrastructure like tests/): prints one line per trial and a summary.
 
-    python tools/fuzz_parity.py [trials] [seed]
+    python tests/fuzz/fuzz_parity.py [trials] [seed]
 """
 import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 

@@ -6,7 +6,7 @@ parameters into a scratch directory and runs the oracle checks of tests/test_ora
 pinned by the reference on hundreds of cases instead of the 26 committed ones.  (The SDF op inside is the oracle's
 restatement on both sides: the reference's own op is CUDA-only)
 
-    python tools/fuzz_reference.py [trials] [seed]
+    python tests/fuzz/fuzz_reference.py [trials] [seed]
 """
 import importlib.util
 import os
@@ -17,7 +17,7 @@ import time
 import traceback
 from pathlib import Path
 
-ROOT = Path(__file__).resolve().parents[1]
+ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT))
 import numpy as np  # noqa: E402
 

@@ -4,13 +4,13 @@ omgx_goalset_cost (arc-length weighted; with per-point potentials and cost-only)
 random smooth + noisy volumes of random shape (2..40 per axis), random poses, epsilons (incl. >= 1: nothing may be
 culled), clearances, padding scales, disabled objects, up to 40 objects per scene (objects >= 31 share a mask bit).
 
-    python tools/fuzz_sdf.py [trials] [seed]
+    python tests/fuzz/fuzz_sdf.py [trials] [seed]
 """
 import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 

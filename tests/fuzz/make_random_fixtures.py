@@ -1,9 +1,9 @@
 """Build-container half of the device-vs-REFERENCE check on random cases: drives the generators of
 tests/golden/make_golden.py (which RUN THE REFERENCE, /root/reference) with random parameters and writes the fixtures
 to tests/golden_random/ (git-ignored; travels to the GPU box with the gpurun snapshot).  The GPU half is
-tools/check_random_fixtures.py.
+tests/fuzz/check_random_fixtures.py.
 
-    python tools/make_random_fixtures.py [count] [seed]
+    python tests/fuzz/make_random_fixtures.py [count] [seed]
 """
 import importlib.util
 import os
@@ -11,7 +11,7 @@ import shutil
 import sys
 from pathlib import Path
 
-ROOT = Path(__file__).resolve().parents[1]
+ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT))
 import numpy as np  # noqa: E402
 

@@ -1,14 +1,14 @@
 """Statistics of the goal-set batch of bench.py's workload: how many (row, object) and (point, object) pairs survive
 each culling level of k_goalset_compact.  CPU only, uses the oracle's FK (a tool, not a product path).
 
-    python tools/pair_density.py [num_scenes] [num_goals]
+    python tests/fuzz/pair_density.py [num_scenes] [num_goals]
 """
 import sys
 from pathlib import Path
 
 import numpy as np
 
-ROOT = Path(__file__).resolve().parents[1]
+ROOT = Path(__file__).resolve().parents[2]
 sys.path[:0] = [str(ROOT)]
 import bench  # noqa: E402
 from oracle import oracle as orc  # noqa: E402

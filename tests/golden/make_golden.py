@@ -267,7 +267,7 @@ def _fixed_fk_and_matrices(out_dir, cfg, kin, util, model, rng, lo, hi, rb):
 def _fixed_host_helpers(out_dir, cfg, cost_mod, opt_mod, model):
     """Outputs of the reference's small numpy methods (Optimizer.goal_set_projection / compute_traj_v /
     handle_joint_limit / check_joint_limit / update, Cost.forward_points / color_point) on seeded inputs: pins the
-    host-side mirrors of the same names (tools/fuzz_host_mirror.py runs the same comparison on random cases)."""
+    host-side mirrors of the same names (tests/fuzz/fuzz_host_mirror.py runs the same comparison on random cases)."""
     import torch
 
     rng = np.random.RandomState(4242)  # own stream: the other fixtures do not move
@@ -355,7 +355,7 @@ def _fixed_vis(out_dir, cfg, cost_mod, util, kin, model, sc, rb):
 def main(out_dir=OUT, script=None):
     """script=None regenerates the committed fixtures; otherwise script(ns) is called with the case generators
     (ns.run_cost_case, ns.run_opt_case, ns.run_batch_case, ns.run_learner_case: same code, any parameters) writing into
-    out_dir — used by tools/fuzz_reference.py to check the oracle against the reference on random cases."""
+    out_dir — used by tests/fuzz/fuzz_reference.py to check the oracle against the reference on random cases."""
     fixed = script is None
     config, cost_mod, opt_mod, util, rk = load_reference()
     cfg = config.cfg

@@ -1,11 +1,11 @@
-"""Short runs of the randomised differential tests in tools/fuzz_*.py (GPU vs CPU oracle); the long campaigns are quoted in
+"""Short runs of the randomised differential tests in tests/fuzz/fuzz_*.py (GPU vs CPU oracle); the long campaigns are quoted in
 DESIGN.md section 2.  Seeds differ from the ones used there."""
 import importlib.util
 from pathlib import Path
 
 import pytest
 
-TOOLS = Path(__file__).resolve().parents[1] / "tools"
+TOOLS = Path(__file__).resolve().parent / "fuzz"
 pytestmark = pytest.mark.gpu
 
 

@@ -332,7 +332,7 @@ def _cfg_from(fx, n):
     cfg.time_interval = float(fx["cfg_dt"])
     cfg._mats = None
     for key in ("allow_collision_point", "pre_terminate", "terminate_smooth_loss", "clip_grad_scale", "joint_limit_max_steps"):
-        if "cfg_" + key in fx:  # fixtures from tools/make_random_fixtures.py vary them
+        if "cfg_" + key in fx:  # fixtures from tests/fuzz/make_random_fixtures.py vary them
             setattr(cfg, key, type(getattr(cfg, key))(fx["cfg_" + key]))
     return cfg
 
@@ -646,7 +646,7 @@ def test_goal_update_matches_oracle_many_scenes(dev, alg, G):
 @pytest.mark.parametrize("alg", ["FTL", "FTC", "Exp", "MD"])
 def test_goal_update_degenerate_cost_vector_keeps_a_valid_index(dev, alg):
     """Zero cost vector -> 0/0 = NaN after normalisation: numpy's argmin/argmax pick the first NaN (goal 0); the kernel must
-    not leave the index undefined (out-of-bounds goal gather; found by tools/fuzz_parity.py)."""
+    not leave the index undefined (out-of-bounds goal gather; found by tests/fuzz/fuzz_parity.py)."""
     from omg_planner_amd import _lib, ops
     from oracle import oracle as orc
     S, G, n = 3, 5, 12
@@ -678,7 +678,7 @@ def test_goal_update_degenerate_cost_vector_keeps_a_valid_index(dev, alg):
 @pytest.mark.parametrize("G", [7, 64, 200])
 def test_goal_update_md_with_unnormalised_large_costs(dev, G):
     """cfg.normalize_cost = False with costs ~1e3: the mirror-descent exponents reach +-5e3.  The reference's termwise
-    exp(L + z_j) stays finite near the root; a factored exp(L) * sum exp(z_j) is inf * 0 (found by tools/fuzz_learner.py)."""
+    exp(L + z_j) stays finite near the root; a factored exp(L) * sum exp(z_j) is inf * 0 (found by tests/fuzz/fuzz_learner.py)."""
     from omg_planner_amd import _lib, ops
     from oracle import oracle as orc
     S, n = 3, 30

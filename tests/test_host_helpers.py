@@ -146,7 +146,7 @@ def test_select_goals_mirrors_setup_goal_set_quirks():
 def test_optimizer_and_cost_numpy_methods_match_reference():
     """The small numpy methods that keep the reference's signatures (Optimizer.update / goal_set_projection /
     compute_traj_v / handle_joint_limit / check_joint_limit, Cost.forward_points / color_point) against outputs of the
-    reference's own methods (tests/golden/make_golden.py:_fixed_host_helpers; tools/fuzz_host_mirror.py: random cases)."""
+    reference's own methods (tests/golden/make_golden.py:_fixed_host_helpers; tests/fuzz/fuzz_host_mirror.py: random cases)."""
     import types
 
     import torch

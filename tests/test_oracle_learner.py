@@ -85,7 +85,7 @@ def test_proj_picks_closest_goal():
 @pytest.mark.parametrize("alg", ["FTL", "FTC", "Exp"])
 def test_degenerate_cost_vector_selects_like_numpy(alg):
     """A zero cost vector normalises to 0/0 = NaN (online_learner.py:153-156).  np.argmin / np.argmax then return the
-    FIRST NaN, i.e. goal 0 — the index must stay valid (found by tools/fuzz_parity.py: one goal, one-waypoint window)."""
+    FIRST NaN, i.e. goal 0 — the index must stay valid (found by tests/fuzz/fuzz_parity.py: one goal, one-waypoint window)."""
     fx = H.load("learner_FTL_0.npz")
     prm = learner_params(fx, 1)
     prm.alg = orc.ALG[alg]

@@ -26,7 +26,7 @@ def test_point_cloud_sdf_matches_ckdtree():
 
 def test_grid_nodes_follow_numpys_arange_fill():
     """np.arange(start, stop, step) yields start, start + step, start + i * ((start + step) - start) — not start + i * step
-    (numpy's DOUBLE_fill).  With the naive nodes a few voxels per grid round differently (found by tools/fuzz_misc.py)."""
+    (numpy's DOUBLE_fill).  With the naive nodes a few voxels per grid round differently (found by tests/fuzz/fuzz_misc.py)."""
     rng = np.random.RandomState(0)
     naive_differs = 0
     for _ in range(25):
