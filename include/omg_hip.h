@@ -354,7 +354,10 @@ const char* omgx_last_error(void); /* thread-local text of the last OMGX_ERR_LAU
  * omgx_goalset_cost is bracketed by HIP events on its own stream.  omgx_timing_collect waits for them,
  * writes the per-launch durations (ms) to h_ms[0..cap) and the variant to h_kind (0 = potentials only, i.e. the
  * goal-set batch; 1 = with gradients, i.e. the waypoint batch; may be NULL) and returns how many;
- * not for graph capture. */
+ * not for graph capture.
+ * Threads: every other entry point may be called concurrently from several host threads (on different streams); the
+ * library's only process-wide state beside this hook is set-once (kernel attributes per device, tuning switches read
+ * from the environment at first use).  The timing hook itself is for ONE measuring thread: enable, launch, collect. */
 int omgx_timing_enable(int32_t on);
 int omgx_timing_collect(float* h_ms, int32_t* h_kind, int32_t cap);
 int omgx_abi_version(void);        /* bumps when a signature or struct layout changes              */

@@ -26,6 +26,7 @@
 //   M[i][0] = (i+1)/(n-c+1) for i < n-c,  M[n-c+q][q] = 1, zero elsewhere
 // (inverse of a min(x_r,x_q) kernel is tridiagonal).  No matrix is stored or inverted on device.
 #include <hip/hip_runtime.h>
+#include <atomic>
 
 #include <stdint.h>
 
@@ -871,10 +872,19 @@ static int chomp_make_args(const double* robot, const omgx_chomp_params* h_param
     return OMGX_OK;
 }
 
+// Once per (kernel, device): the attribute belongs to the device's copy of the function, and entry points may be called from
+// several host threads (one bit per device in an atomic word; a lost race only repeats the idempotent call).
 template <class K>
 static int allow_big_lds(K kernel, const char* what) {
-    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    return e == hipSuccess ? OMGX_OK : omgx_set_error(what, e);
+    static std::atomic<unsigned long long> done{0ull};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return omgx_set_error("hipGetDevice", e);
+    if (dev >= 0 && dev < 64 && ((done.load(std::memory_order_acquire) >> dev) & 1ull)) return OMGX_OK;
+    e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return omgx_set_error(what, e);
+    if (dev >= 0 && dev < 64) done.fetch_or(1ull << dev, std::memory_order_release);
+    return OMGX_OK;
 }
 
 extern "C" int omgx_chomp_optimize(const double* robot, const omgx_chomp_params* h_params, double* traj,
@@ -888,11 +898,7 @@ extern "C" int omgx_chomp_optimize(const double* robot, const omgx_chomp_params*
     int rc = chomp_make_args(robot, h_params, traj, start, end, goal, goal_point, potentials, grads, collides, active, num_scenes,
                              grad, cost_traj, info, aux, a, lds);
     if (rc != OMGX_OK) return rc;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if ((rc = allow_big_lds(k_chomp_optimize, "hipFuncSetAttribute(k_chomp_optimize)")) != OMGX_OK) return rc;
-        attr_set = true;
-    }
+    if ((rc = allow_big_lds(k_chomp_optimize, "hipFuncSetAttribute(k_chomp_optimize)")) != OMGX_OK) return rc;
     hipLaunchKernelGGL(k_chomp_optimize, dim3(num_scenes), dim3(CH_TPB), lds, (hipStream_t)stream, a);
     OMGX_CHECK_LAUNCH("k_chomp_optimize");
     return OMGX_OK;
@@ -918,12 +924,8 @@ extern "C" int omgx_goal_update_optimize(const omgx_learner_params* h_learner, c
     if (h_learner->n_waypoints != h_params->n_waypoints || h_learner->constraint_num != h_params->constraint_num) return OMGX_ERR_INVALID;
     const size_t learner_lds = (size_t)(5 * OMGX_MAX_GOALS + 5 * 128) * sizeof(double);
     if (lds < learner_lds) lds = learner_lds;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if ((rc = allow_big_lds(k_update_optimize, "hipFuncSetAttribute(k_update_optimize)")) != OMGX_OK) return rc;
-        if ((rc = allow_big_lds(k_update_optimize_split, "hipFuncSetAttribute(k_update_optimize_split)")) != OMGX_OK) return rc;
-        attr_set = true;
-    }
+    if ((rc = allow_big_lds(k_update_optimize, "hipFuncSetAttribute(k_update_optimize)")) != OMGX_OK) return rc;
+    if ((rc = allow_big_lds(k_update_optimize_split, "hipFuncSetAttribute(k_update_optimize_split)")) != OMGX_OK) return rc;
     if (scene_flags) {
         hipLaunchKernelGGL(k_update_optimize_split, dim3(2 * num_scenes), dim3(CH_TPB), lds, (hipStream_t)stream, la, a,
                            reinterpret_cast<uint32_t*>(scene_flags), (uint32_t)ticket);

@@ -824,14 +824,14 @@ static int launch_chunks(ChunkArgs& ca, hipStream_t st) {
         if (ev0) hipExtLaunchKernelGGL(KERNEL_, dim3((unsigned)grid), dim3(256), (uint32_t)(LDS_), st, ev0, ev1, 0, ca); \
         else hipLaunchKernelGGL(KERNEL_, dim3((unsigned)grid), dim3(256), (LDS_), st, ca);                               \
     } while (0)
-    static int lb = -1;  // links per batch; OMGX_LB overrides the tuned default (tuning aid)
-    if (lb < 0) { const char* e = getenv("OMGX_LB"); lb = e ? atoi(e) : 2; }
+    // links per batch; OMGX_LB overrides the tuned default (tuning aid).  Read once (thread-safe static initialisation).
+    static const int lb = [] { const char* e = getenv("OMGX_LB"); return e ? atoi(e) : 2; }();
     int lbu = lb;
     if (lpw % lbu != 0) lbu = 1;  // the link batch must divide the links of a workgroup
     const size_t mask_bytes = (size_t)10 * ca.CH * sizeof(uint32_t);
 #define OMGX_LAUNCH_CHUNKS(G_, LB_) OMGX_LAUNCH((k_sdf_chunks<G_, LB_, false>), mask_bytes)
-    static int compact = -1;  // OMGX_COMPACT=0 keeps the unpacked exact path (A/B measurements)
-    if (compact < 0) { const char* e = getenv("OMGX_COMPACT"); compact = e ? atoi(e) : 1; }
+    // OMGX_COMPACT=0 keeps the unpacked exact path (A/B measurements)
+    static const int compact = [] { const char* e = getenv("OMGX_COMPACT"); return e ? atoi(e) : 1; }();
     if (ca.traj_start && compact && !ca.pot) {  // goal-set batch, cost only: packed exact path
         size_t tail = (((size_t)10 * ca.MR + 3) & ~(size_t)3) * sizeof(uint32_t) + 4 * 64 * 3 * sizeof(float);  // row masks + scratch
         const size_t sincos = (size_t)ca.PS * 14 * sizeof(double);                                             // FK stage 1 table
@@ -978,10 +978,9 @@ static int goalset_cost_impl(const double* robot, int32_t n_points, const omgx_o
     const int n = n_remaining, C = num_goals * n;
     double* ws = (double*)workspace;
     double* ws_start = ws + (int64_t)num_scenes * num_goals * 10 * n * 12;
-    static int fused = -1;  // OMGX_FUSED_FK=0 keeps the separate FK launch (A/B measurements)
-    if (fused < 0) { const char* e = getenv("OMGX_FUSED_FK"); fused = e ? atoi(e) : 1; }
-    static int compact = -1;
-    if (compact < 0) { const char* e = getenv("OMGX_COMPACT"); compact = e ? atoi(e) : 1; }
+    // OMGX_FUSED_FK=0 keeps the separate FK launch (A/B measurements)
+    static const int fused = [] { const char* e = getenv("OMGX_FUSED_FK"); return e ? atoi(e) : 1; }();
+    static const int compact = [] { const char* e = getenv("OMGX_COMPACT"); return e ? atoi(e) : 1; }();
     if (layer_traj) {  // the trajectory layer rides on k_goalset_compact only
         if (!layer_pot || !layer_grad || !layer_col) return OMGX_ERR_INVALID;
         if (layer_n < 1 || layer_n > OMGX_MAX_WAYPOINTS) return OMGX_ERR_UNSUPPORTED;
