@@ -565,6 +565,45 @@ def test_goal_update_matches_reference_learner_fixture(dev, case):
             np.testing.assert_allclose(state[0, 7 * G:7 * G + 5].cpu().numpy(), fx["q"][k], rtol=1e-4, atol=1e-7)
 
 
+@pytest.mark.parametrize("case", ["FTL_0", "FTC_0", "Exp_0", "MD_0", "MD_1", "FTC_0_close", "MD_0_close"])
+def test_learner_class_matches_reference_learner_fixture(dev, case):
+    """The mirror class online_learner.Learner driven like the reference's (constructor picks the initial goal; then
+    update_goal per step on the trajectories the fixture recorded): goal indices and the public attributes p, q, sum_costs,
+    experts_p, cost_vector against the reference Learner's own (tests/golden/learner_*.npz)."""
+    from omg_planner_amd.config import Config
+    from omg_planner_amd.cost import Cost
+    from omg_planner_amd.online_learner import Learner
+    fx = H.load(f"learner_{case}.npz")
+    alg, standoff = str(fx["alg"]), bool(int(fx["cfg_use_standoff"]))
+    cfg = Config(timesteps=30, use_standoff=standoff, ol_alg=alg, optim_steps=int(fx["optim_steps"]), dist_eps=float(fx["dist_eps"]),
+                 normalize_cost=bool(int(fx.get("cfg_normalize_cost", 1))), base_obstacle_weight=float(fx.get("cfg_base_obstacle_weight", 1.0)),
+                 smoothness_base_weight=float(fx.get("cfg_smoothness_base_weight", 0.1)))
+    env = _env_from(fx, dev, cfg)
+    env.objects[env.target_idx].reach_grasps = fx["reach_grasps"]
+    traj = _Traj(fx["traj"], fx["start"], fx["goal_set"][0], fx["goal_set"], 0)
+    traj.interpolate_waypoints = lambda *a, **k: None  # the generator kept the trajectory fixed across Learner.__init__ too
+    learner = Learner(env, traj, Cost(env))
+    assert int(traj.goal_idx) == int(fx["init_goal_idx"]) and abs(learner.eta - float(fx["eta"])) < 1e-15
+    np.testing.assert_array_equal(traj.end, fx["goal_set"][int(fx["init_goal_idx"])])
+    for k in range(fx["trajs"].shape[0]):
+        traj.data = fx["trajs"][k]
+        learner.t += 1
+        cv = learner.cost_vector()
+        learner.t -= 1
+        np.testing.assert_allclose(cv, fx["cost_vectors"][k], rtol=2e-5, atol=1e-7, err_msg=f"cost vector step {k}")
+        learner.update_goal()
+        assert int(traj.goal_idx) == int(fx["goal_idx"][k]), k
+        np.testing.assert_array_equal(traj.end, fx["goal_set"][int(fx["goal_idx"][k])])
+        np.testing.assert_allclose(learner.p, fx["p"][k], rtol=1e-4, atol=1e-6, err_msg=f"p step {k}")
+        if alg == "MD":
+            np.testing.assert_allclose(learner.q, fx["q"][k], rtol=1e-4, atol=1e-7, err_msg=f"q step {k}")
+    assert learner.t == float(fx["final_t"])
+    if alg in ("FTL", "Exp"):
+        np.testing.assert_allclose(learner.sum_costs, fx["sum_costs"], rtol=2e-5)
+    if alg == "MD":
+        np.testing.assert_allclose(np.stack(learner.experts_p), fx["experts_p"], rtol=1e-4, atol=1e-6)
+
+
 @pytest.mark.parametrize("case", ["FTL_0", "MD_1", "FTC_0_close"])
 def test_engine_initial_goal_matches_reference_learner_init(dev, case):
     """ChompEngine.select_initial_goal = Learner.__init__ (online_learner.py:96-102): argmin of the t = 0 cost vector on the
