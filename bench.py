@@ -206,6 +206,16 @@ def main():
             torch.cuda.synchronize()
             ms_per_plan = min(ms_per_plan, (time.perf_counter() - tp) * 1e3)
             del eng2
+        # the same plan as the reference runs it: a scene that terminates leaves the loop (planner.py:626) — its goal-set
+        # batch, goal update and step are skipped from then on (active mask)
+        eng3 = ChompEngine(model, batch, copy.deepcopy(cfg), start, goals, device=dev, ol_alg=args.ol_alg)
+        torch.cuda.synchronize()
+        tp = time.perf_counter()
+        eng3.plan(early_stop=True)
+        torch.cuda.synchronize()
+        ms_plan_early = (time.perf_counter() - tp) * 1e3
+        terminated = int((eng3.active == 0).sum().item())
+        del eng3
 
     ms_single = None
     if not args.no_plan and rank == 0:  # BASELINE configs[0]/[1] shape: ONE scene, 64 goals — latency of a whole plan
@@ -269,6 +279,8 @@ def main():
         if ms_per_plan is not None:
             out["ms_per_plan"] = ms_per_plan  # Planner.plan for all scenes of rank 0: initial goal pick + 50 + 20 iterations + final info
             out["ms_per_plan_per_scene"] = ms_per_plan / S
+            out["ms_per_plan_early_stop"] = ms_plan_early  # with the reference's break on `terminate` (informational)
+            out["scenes_terminated_early"] = terminated
         if ms_single is not None:
             out["ms_per_plan_single_scene"] = ms_single  # one scene alone (launch-latency bound), best of 3
         if world == 1 and not args.no_cpu_baseline:

@@ -229,6 +229,8 @@ int omgx_goalset_cost(const double* robot, int32_t n_points,
  * — the inputs of omgx_chomp_optimize.  One planner iteration (omg/planner.py:612-621) is then two launches on one
  * stream: this one and omgx_goal_update_optimize.  Results are identical to the two separate calls
  * (goal_cost: same float32 summation order; layer outputs: bit-identical).
+ *   active  optional [S] int32 (NULL = all): scenes with active[s] == 0 are skipped — the reference leaves a scene's
+ *           loop once it terminates (omg/planner.py:626) — and their outputs keep their previous contents.
  * ------------------------------------------------------------------------------------------- */
 int omgx_goalset_cost_layer(const double* robot, int32_t n_points,
                             const omgx_object* objects, const int32_t* scene_begin, const float* sdf_pool,
@@ -237,7 +239,8 @@ int omgx_goalset_cost_layer(const double* robot, int32_t n_points,
                             double time_interval, int32_t soften_fingers,
                             float* goal_cost, float* collides, void* workspace,
                             const double* traj, int32_t n_waypoints, int32_t layer_soften_fingers,
-                            float* layer_potentials, float* layer_grads, float* layer_collides, void* stream);
+                            float* layer_potentials, float* layer_grads, float* layer_collides,
+                            const int32_t* active, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * (4) omgx_chomp_optimize
@@ -259,14 +262,16 @@ int omgx_goalset_cost_layer(const double* robot, int32_t n_points,
  *   aux    optional [S, omgx_chomp_aux_doubles(n)] double: the un-weighted pieces the reference's
  *          compute_collision_loss / compute_smooth_loss return — obs_grad [n,9] | obs_cost [n,10] |
  *          smooth_grad [n,9] | smooth_loss [n+1]   (NULL to skip)
+ *   stop_on_terminate  non-zero: a scene whose info says `terminate` after this step gets active[s] = 0 (see omgx_goal_update_optimize)
  * ------------------------------------------------------------------------------------------- */
 int64_t omgx_chomp_aux_doubles(int32_t n_waypoints);
 int omgx_chomp_optimize(const double* robot, const omgx_chomp_params* h_params,
                         double* traj, const double* start, const double* end, const double* goal,
                         const double* goal_point,
                         const float* potentials, const float* grads, const float* collides,
-                        const int32_t* active, int32_t num_scenes,
-                        double* grad, double* cost_traj, double* info, double* aux, void* stream);
+                        int32_t* active, int32_t num_scenes,
+                        double* grad, double* cost_traj, double* info, double* aux,
+                        int32_t stop_on_terminate, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * (5) omgx_goal_update
@@ -285,7 +290,8 @@ int omgx_chomp_optimize(const double* robot, const omgx_chomp_params* h_params,
  *               (the caller initialises it as Learner.__init__ does, online_learner.py:78-92: zeros | 1/G | 1/G | 1/5 | zeros)
  * Outputs: goal_idx [S] int32, end [S,9] (traj.end), goal_rows [S,c,9] (chosen goal rows for the projection),
  *          goal_point [S,9] (goal_set[goal_idx]), cost_vector [S,G] double (optional, NULL to skip).
- * G <= OMGX_MAX_GOALS.
+ * G <= OMGX_MAX_GOALS.  active: optional [S] int32 (NULL = all); scenes with 0 keep goal, outputs and state untouched
+ * (omgx_goal_update_optimize applies its `active` to the goal update as well as to the step).
  * ------------------------------------------------------------------------------------------- */
 #define OMGX_MAX_GOALS 256
 #define OMGX_ALG_FTL 0
@@ -310,7 +316,7 @@ int64_t omgx_learner_state_doubles(int32_t num_goals);
 int omgx_goal_update(const omgx_learner_params* h_params, const double* traj, const double* goal_set, const double* reach,
                      const float* goal_cost, double* state, int32_t num_scenes,
                      int32_t* goal_idx, double* end, double* goal_rows, double* goal_point, double* cost_vector,
-                     void* stream);
+                     const int32_t* active, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * (5b) omgx_goal_update_optimize
@@ -323,15 +329,18 @@ int omgx_goal_update(const omgx_learner_params* h_params, const double* traj, co
  *                goal-independent part of the step (FK, top-k, per-point costs, most gradients) run in different
  *                workgroups of the launch and meet through scene_flags[s] == ticket; `ticket` must differ from every
  *                value still stored there (use 1, 2, 3, ... per call).  NULL: one workgroup per scene does both in turn.
+ *   stop_on_terminate  non-zero: a scene whose info says `terminate` after this step gets active[s] = 0 (active must be
+ *                given), i.e. it leaves the planner loop like `if self.info[-1]["terminate"] and t > 0: break`
+ *                (omg/planner.py:626) — later launches that take the mask skip it.
  * ------------------------------------------------------------------------------------------- */
 int omgx_goal_update_optimize(const omgx_learner_params* h_learner, const double* goal_set, const double* reach,
                               const float* goal_cost, double* learner_state, int32_t* goal_idx, double* cost_vector,
                               const double* robot, const omgx_chomp_params* h_params, double* traj,
                               const double* start, double* end, double* goal, double* goal_point,
                               const float* potentials, const float* grads, const float* collides,
-                              const int32_t* active, int32_t num_scenes,
+                              int32_t* active, int32_t num_scenes,
                               double* grad, double* cost_traj, double* info, double* aux,
-                              int32_t* scene_flags, int32_t ticket, void* stream);
+                              int32_t* scene_flags, int32_t ticket, int32_t stop_on_terminate, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * (6) omgx_point_cloud_sdf

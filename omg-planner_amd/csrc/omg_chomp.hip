@@ -68,6 +68,7 @@ struct ChompArgs {
     const float* pgrad;        // [S][n][10][P][3]
     const float* col;          // [S][n][10][P]
     const int32_t* active;     // [S] or null
+    int32_t* deactivate;       // == active (writable) when a scene that terminates is to leave the loop (planner.py:626), else null
     double* grad;              // [S][n][9]
     double* cost_traj;         // [S][n]
     double* info;              // [S][16]
@@ -701,6 +702,7 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
         info[OMGX_INFO_COLLIDE] = collide;
         info[OMGX_INFO_REACH] = goal_dist;
         info[OMGX_INFO_TERMINATE] = terminate ? 1.0 : 0.0;
+        if (a.deactivate && terminate) a.deactivate[s] = 0;  // read again only by later launches on this stream
         info[OMGX_INFO_FAILURE_TERMINATE] = failure ? 1.0 : 0.0;
         info[OMGX_INFO_EXECUTE] = execute ? 1.0 : 0.0;
         info[OMGX_INFO_STANDOFF_IDX] = prm.use_standoff ? (double)(n - c) : (double)(n - 1);
@@ -890,14 +892,18 @@ static int allow_big_lds(K kernel, const char* what) {
 extern "C" int omgx_chomp_optimize(const double* robot, const omgx_chomp_params* h_params, double* traj,
                                    const double* start, const double* end, const double* goal,
                                    const double* goal_point, const float* potentials, const float* grads,
-                                   const float* collides, const int32_t* active, int32_t num_scenes, double* grad,
-                                   double* cost_traj, double* info, double* aux, void* stream) {
+                                   const float* collides, int32_t* active, int32_t num_scenes, double* grad,
+                                   double* cost_traj, double* info, double* aux, int32_t stop_on_terminate, void* stream) {
     if (h_params && num_scenes == 0) return OMGX_OK;
     ChompArgs a;
     size_t lds = 0;
     int rc = chomp_make_args(robot, h_params, traj, start, end, goal, goal_point, potentials, grads, collides, active, num_scenes,
                              grad, cost_traj, info, aux, a, lds);
     if (rc != OMGX_OK) return rc;
+    if (stop_on_terminate) {
+        if (!active) return OMGX_ERR_INVALID;
+        a.deactivate = active;
+    }
     if ((rc = allow_big_lds(k_chomp_optimize, "hipFuncSetAttribute(k_chomp_optimize)")) != OMGX_OK) return rc;
     hipLaunchKernelGGL(k_chomp_optimize, dim3(num_scenes), dim3(CH_TPB), lds, (hipStream_t)stream, a);
     OMGX_CHECK_LAUNCH("k_chomp_optimize");
@@ -909,12 +915,12 @@ extern "C" int omgx_goal_update_optimize(const omgx_learner_params* h_learner, c
                                          const double* robot, const omgx_chomp_params* h_params, double* traj,
                                          const double* start, double* end, double* goal, double* goal_point,
                                          const float* potentials, const float* grads, const float* collides,
-                                         const int32_t* active, int32_t num_scenes, double* grad, double* cost_traj, double* info,
-                                         double* aux, int32_t* scene_flags, int32_t ticket, void* stream) {
+                                         int32_t* active, int32_t num_scenes, double* grad, double* cost_traj, double* info,
+                                         double* aux, int32_t* scene_flags, int32_t ticket, int32_t stop_on_terminate, void* stream) {
     if (h_learner && h_params && num_scenes == 0) return OMGX_OK;
     omg_learner::LearnerArgs la;
     int rc = omg_learner::make_args(h_learner, traj, goal_set, reach, goal_cost, learner_state, num_scenes, goal_idx, end, goal,
-                                    goal_point, cost_vector, la);
+                                    goal_point, cost_vector, active, la);
     if (rc != OMGX_OK) return rc;
     ChompArgs a;
     size_t lds = 0;
@@ -922,6 +928,10 @@ extern "C" int omgx_goal_update_optimize(const omgx_learner_params* h_learner, c
                          cost_traj, info, aux, a, lds);
     if (rc != OMGX_OK) return rc;
     if (h_learner->n_waypoints != h_params->n_waypoints || h_learner->constraint_num != h_params->constraint_num) return OMGX_ERR_INVALID;
+    if (stop_on_terminate) {
+        if (!active) return OMGX_ERR_INVALID;
+        a.deactivate = active;
+    }
     const size_t learner_lds = (size_t)(5 * OMGX_MAX_GOALS + 5 * 128) * sizeof(double);
     if (lds < learner_lds) lds = learner_lds;
     if ((rc = allow_big_lds(k_update_optimize, "hipFuncSetAttribute(k_update_optimize)")) != OMGX_OK) return rc;

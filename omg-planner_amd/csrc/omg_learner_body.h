@@ -41,6 +41,7 @@ struct LearnerArgs {
     double* goal_rows;
     double* goal_point;
     double* cost_vector;
+    const int32_t* active;  // [S] or null: scenes with 0 keep their goal and state (the reference has left its loop, planner.py:626)
 };
 
 __device__ __forceinline__ double lane_bcast(double v, int k) {
@@ -139,6 +140,7 @@ __device__ void bregman_projection(const double* x, const double* v, double delt
 
 // All threads of the workgroup call this (>= 5 waves for MD); sh_pn [5][OMGX_MAX_GOALS] and sh_tab [5][128] are LDS.
 __device__ __forceinline__ void learner_scene(const LearnerArgs& a, int s, double (*sh_pn)[OMGX_MAX_GOALS], double (*sh_tab)[128]) {
+    if (a.active && a.active[s] == 0) return;  // workgroup-uniform
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (a.prm.alg != OMGX_ALG_MD && wave > 0) return;  // no barrier on these paths
     const omgx_learner_params& prm = a.prm;
@@ -306,7 +308,7 @@ __device__ __forceinline__ void learner_scene(const LearnerArgs& a, int s, doubl
 // Host side: argument checks of omgx_goal_update (shared with omgx_goal_update_optimize).
 static inline int make_args(const omgx_learner_params* h_params, const double* traj, const double* goal_set, const double* reach,
                             const float* goal_cost, double* state, int32_t num_scenes, int32_t* goal_idx, double* end,
-                            double* goal_rows, double* goal_point, double* cost_vector, LearnerArgs& a) {
+                            double* goal_rows, double* goal_point, double* cost_vector, const int32_t* active, LearnerArgs& a) {
     if (!h_params || num_scenes < 0) return OMGX_ERR_INVALID;
     const omgx_learner_params& p = *h_params;
     if (!traj || !goal_set || !state || !goal_idx || !end || !goal_rows || !goal_point) return OMGX_ERR_INVALID;
@@ -320,6 +322,7 @@ static inline int make_args(const omgx_learner_params* h_params, const double* t
     a = LearnerArgs{};
     a.prm = p; a.traj = traj; a.goal_set = goal_set; a.reach = reach; a.goal_cost = goal_cost; a.state = state; a.S = num_scenes;
     a.goal_idx = goal_idx; a.end = end; a.goal_rows = goal_rows; a.goal_point = goal_point; a.cost_vector = cost_vector;
+    a.active = active;
     return OMGX_OK;
 }
 

@@ -184,7 +184,7 @@ class ChompEngine:
                 ops.goalset_cost_layer(self.robot, self.P, self.scenes, traj_start, self.cv_goals, n_rem, self.cfg.time_interval,
                                        self.traj, (self.pot, self.pgrad, self.col), soften_fingers=False,
                                        layer_soften_fingers=self.cfg.uncheck_finger_collision == -1,
-                                       out=(self.goal_cost, self.goal_col))
+                                       out=(self.goal_cost, self.goal_col), active=self.active)
             else:
                 ops.goalset_cost(self.robot, self.P, self.scenes, traj_start, self.cv_goals, n_rem, self.cfg.time_interval,
                                  soften_fingers=False, out=(self.goal_cost, self.goal_col))
@@ -193,7 +193,7 @@ class ChompEngine:
         if defer_update:
             return prm
         ops.goal_update(prm, self.traj, self.goal_set, self.reach, self.goal_cost, self.learner_state, self.goal_idx,
-                        self.end, self.goal_rows, self.goal_point, self.cost_vec)
+                        self.end, self.goal_rows, self.goal_point, self.cost_vec, active=self.active)
         return None
 
     def _layer(self):
@@ -201,7 +201,7 @@ class ChompEngine:
         ops.fk_sdf(self.robot, self.P, self.scenes, self.traj, soften_fingers=self.cfg.uncheck_finger_collision == -1,
                    out=(self.pot, self.pgrad, self.col))
 
-    def _step(self, do_update: bool, learner_prm=None):
+    def _step(self, do_update: bool, learner_prm=None, stop_on_terminate: bool = False):
         if learner_prm is not None:  # goal update + step in one launch
             # learner and step in different workgroups of the launch: pays while both sets are resident at once (one
             # 92 KB-LDS workgroup per CU); beyond that the single-workgroup kernel is a little faster (measured at 200 / 400 scenes)
@@ -211,11 +211,12 @@ class ChompEngine:
                                      self.robot, self._params(do_update), self.traj, self.start, self.end, self.goal_rows,
                                      self.goal_point, self.pot, self.pgrad, self.col, active=self.active,
                                      out=(self.grad, self.cost_traj, self.info), cost_vector=self.cost_vec,
-                                     scene_flags=self._scene_flags if split else None, ticket=self._ticket)
+                                     scene_flags=self._scene_flags if split else None, ticket=self._ticket,
+                                     stop_on_terminate=stop_on_terminate)
             return self.info
         ops.chomp_optimize(self.robot, self._params(do_update), self.traj, self.start, self.end, self.goal_rows,
                            self.goal_point, self.pot, self.pgrad, self.col, active=self.active,
-                           out=(self.grad, self.cost_traj, self.info))
+                           out=(self.grad, self.cost_traj, self.info), stop_on_terminate=stop_on_terminate)
         return self.info
 
     def optimize(self, do_update: bool = True):
@@ -238,11 +239,14 @@ class ChompEngine:
         mode = os.environ.get("OMGX_ITERATION", "fused")  # fused | streams | serial (A/B measurements)
         if os.environ.get("OMGX_NO_OVERLAP"):  # profiling aid: device-wide PMC counters need kernels one at a time
             mode = "serial"
+        # planner.py:626-627 (a scene that terminates at t > 0 leaves the loop): the step itself clears active[s] — no extra
+        # kernels between iterations; the goal-set launch, the goal update and the step skip scenes with active[s] == 0
+        stop = bool(early_stop and t > 0)
         if select and mode == "fused" and self.ol_alg != "Baseline":
             # two launches on one stream: goal-set batch + trajectory layer, then goal update + optimiser step
             lprm = self.update_goal(defer_update=True, with_layer=True)
             self._schedule()
-            self._step(True, lprm)
+            self._step(True, lprm, stop_on_terminate=stop)
         elif select and overlap and mode == "streams":
             # the trajectory layer on a side stream, concurrent with the goal-set batch; joined before the step
             main = torch.cuda.current_stream(self.device)
@@ -255,15 +259,13 @@ class ChompEngine:
             lprm = self.update_goal(defer_update=fuse)
             self._schedule()
             main.wait_event(self._ev_join)
-            self._step(True, lprm)
+            self._step(True, lprm, stop_on_terminate=stop)
         else:
             self._layer()  # needs only the trajectory: first, so that nothing sits between the goal-set batch and the step
             fuse = not os.environ.get("OMGX_NO_FUSED_UPDATE")
             lprm = self.update_goal(defer_update=fuse) if select else None
             self._schedule()
-            self._step(True, lprm)
-        if early_stop and t > 0:  # planner.py:627: terminated scenes stop iterating
-            self.active = self.active * (self.info[:, 10] < 0.5).to(torch.int32)
+            self._step(True, lprm, stop_on_terminate=stop)
 
     def select_initial_goal(self):
         """Learner.__init__ (online_learner.py:96-102): before planning, pick the cheapest goal by one cost_vector

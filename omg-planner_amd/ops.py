@@ -121,9 +121,10 @@ def goalset_cost(robot, P, scenes: DeviceScenes, traj_start, goals, n_remaining,
 
 
 def goalset_cost_layer(robot, P, scenes: DeviceScenes, traj_start, goals, n_remaining, dt, traj, layer_out, soften_fingers=False,
-                       layer_soften_fingers=False, out=None):
+                       layer_soften_fingers=False, out=None, active=None):
     """goalset_cost (cost only) + fk_sdf(traj) in one launch (omgx_goalset_cost_layer).  traj [S,n,9] f64;
-    layer_out = (potentials [S,n,10,P], grads [S,n,10,P,3], collides [S,n,10,P]) float32, written in place."""
+    layer_out = (potentials [S,n,10,P], grads [S,n,10,P,3], collides [S,n,10,P]) float32, written in place.
+    active [S] int32 (optional): scenes with 0 are skipped, their outputs keep their previous contents."""
     if not (traj_start.is_cuda and traj_start.dtype == torch.float64 and traj_start.dim() == 2 and traj_start.shape[1] == 9
             and traj_start.stride(1) == 1 and (traj_start.shape[0] == 1 or traj_start.stride(0) >= 9)):
         raise _lib.OmgHipError("traj_start must be a float64 device tensor [S,9] with unit inner stride")
@@ -148,7 +149,7 @@ def goalset_cost_layer(robot, P, scenes: DeviceScenes, traj_start, goals, n_rema
         check(l.omgx_goalset_cost_layer(_ptr(robot), P, _ptr(scenes.objects), _ptr(scenes.scene_begin), _ptr(scenes.pool),
                                         _ptr(traj_start), ts_stride, _ptr(goals), S, G, n_remaining, float(dt),
                                         int(bool(soften_fingers)), _ptr(cost), _ptr(col), _ptr(ws), _ptr(traj), n,
-                                        int(bool(layer_soften_fingers)), _ptr(lp), _ptr(lg), _ptr(lc), _stream()),
+                                        int(bool(layer_soften_fingers)), _ptr(lp), _ptr(lg), _ptr(lc), _ptr(_active(active, S)), _stream()),
               "omgx_goalset_cost_layer")
     return cost, col
 
@@ -167,7 +168,7 @@ def forward_kinematics(robot, P, joints, want_joint_info=True):
 
 
 def chomp_optimize(robot, params: ChompParams, traj, start, end, goal, goal_point, pot, pgrad, col, active=None, out=None,
-                   aux=None):
+                   aux=None, stop_on_terminate=False):
     """In-place step on traj [S,n,9] f64 -> grad [S,n,9], cost_traj [S,n], info [S,16] (f64).
     aux: optional [S, omgx_chomp_aux_doubles(n)] f64 receiving obs_grad | obs_cost | smooth_grad | smooth_loss."""
     for n_, t in (("traj", traj), ("start", start), ("end", end), ("goal", goal), ("goal_point", goal_point)):
@@ -185,7 +186,8 @@ def chomp_optimize(robot, params: ChompParams, traj, start, end, goal, goal_poin
     with torch.cuda.device(dev):
         check(_lib.lib().omgx_chomp_optimize(_ptr(robot), C.byref(params), _ptr(traj), _ptr(start), _ptr(end), _ptr(goal),
                                              _ptr(goal_point), _ptr(pot), _ptr(pgrad), _ptr(col), _ptr(active), S,
-                                             _ptr(grad), _ptr(cost_traj), _ptr(info), _ptr(aux), _stream()), "omgx_chomp_optimize")
+                                             _ptr(grad), _ptr(cost_traj), _ptr(info), _ptr(aux), int(bool(stop_on_terminate)),
+                                             _stream()), "omgx_chomp_optimize")
     return grad, cost_traj, info
 
 
@@ -198,9 +200,16 @@ def learner_state(S: int, G: int, device) -> torch.Tensor:
     return st
 
 
+def _active(active, S):
+    if active is not None and not (active.is_cuda and active.dtype == torch.int32 and active.is_contiguous() and active.numel() == S):
+        raise _lib.OmgHipError("active must be a contiguous int32 device tensor [S]")
+    return active
+
+
 def goal_update(params: LearnerParams, traj, goal_set, reach, goal_cost, state, goal_idx, end, goal_rows, goal_point,
-                cost_vector=None):
-    """Learner.update_goal for S scenes in one launch (omgx_goal_update); all outputs are written in place."""
+                cost_vector=None, active=None):
+    """Learner.update_goal for S scenes in one launch (omgx_goal_update); all outputs are written in place.
+    active [S] int32 (optional): scenes with 0 keep goal, outputs and state."""
     _need(traj, torch.float64, "traj")
     _need(goal_set, torch.float64, "goal_set")
     _need(state, torch.float64, "state")
@@ -209,12 +218,12 @@ def goal_update(params: LearnerParams, traj, goal_set, reach, goal_cost, state, 
     with torch.cuda.device(traj.device):
         check(_lib.lib().omgx_goal_update(C.byref(params), _ptr(traj), _ptr(goal_set), _ptr(reach), _ptr(goal_cost), _ptr(state),
                                           traj.shape[0], _ptr(goal_idx), _ptr(end), _ptr(goal_rows), _ptr(goal_point),
-                                          _ptr(cost_vector), _stream()), "omgx_goal_update")
+                                          _ptr(cost_vector), _ptr(_active(active, traj.shape[0])), _stream()), "omgx_goal_update")
 
 
 def goal_update_optimize(lparams: LearnerParams, goal_set, reach, goal_cost, state, goal_idx, robot, params: ChompParams, traj,
                          start, end, goal, goal_point, pot, pgrad, col, active=None, out=None, aux=None, cost_vector=None,
-                         scene_flags=None, ticket=0):
+                         scene_flags=None, ticket=0, stop_on_terminate=False):
     """goal_update followed by chomp_optimize in one launch (omgx_goal_update_optimize): same results as the two calls."""
     for n_, t in (("traj", traj), ("start", start), ("end", end), ("goal", goal), ("goal_point", goal_point),
                   ("goal_set", goal_set), ("state", state)):
@@ -238,7 +247,8 @@ def goal_update_optimize(lparams: LearnerParams, goal_set, reach, goal_cost, sta
                                                    _ptr(goal_idx), _ptr(cost_vector), _ptr(robot), C.byref(params), _ptr(traj),
                                                    _ptr(start), _ptr(end), _ptr(goal), _ptr(goal_point), _ptr(pot), _ptr(pgrad),
                                                    _ptr(col), _ptr(active), S, _ptr(grad), _ptr(cost_traj), _ptr(info), _ptr(aux),
-                                                   _ptr(scene_flags), int(ticket), _stream()), "omgx_goal_update_optimize")
+                                                   _ptr(scene_flags), int(ticket), int(bool(stop_on_terminate)), _stream()),
+              "omgx_goal_update_optimize")
     return grad, cost_traj, info
 
 

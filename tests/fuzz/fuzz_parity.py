@@ -94,7 +94,8 @@ def one_trial(rng, trial, dev, dry=False):
         eng.iterate(t, early_stop=early)
         if os.environ.get("OMGX_FUZZ_DEBUG"):
             torch.cuda.synchronize()
-        idx = None
+        if t == 0:
+            idx = None
         if t < cfg.optim_steps and cfg.goal_set_proj and alg != "Proj":  # planner.py:609: no learner for Proj / Baseline
             lp = orc.LearnerParams()
             lp.alg, lp.num_goals, lp.n_waypoints = orc.ALG[alg], G, n
@@ -105,7 +106,15 @@ def one_trial(rng, trial, dev, dry=False):
             gc = np.zeros((S, G), np.float32)
             if alg != "Proj":
                 gc, _ = orc.goalset_cost(blob, P, batch, traj[:, lp.start_idx], cv_goals, n - lp.start_idx, cfg.time_interval)
-            idx, end, rows, gp, _ = orc.goal_update(lp, traj, goals, reach, gc, state)
+            keep = (idx, end.copy(), rows.copy(), gp.copy(), state.copy()) if idx is not None else None
+            idx_n, end_n, rows_n, gp_n, _ = orc.goal_update(lp, traj, goals, reach, gc, state)
+            if keep is None:
+                idx, end, rows, gp = idx_n, end_n, rows_n, gp_n
+            else:  # planner.py:626: a terminated scene has left the loop — goal, goal rows and learner state stay
+                on = active > 0
+                idx = np.where(on, idx_n, keep[0])
+                end, rows, gp = (np.where(on.reshape((-1,) + (1,) * (x.ndim - 1)), x, k) for x, k in ((end_n, keep[1]), (rows_n, keep[2]), (gp_n, keep[3])))
+                state[~on] = keep[4][~on]
         po = orc.ChompParams()
         src = eng._params(True)
         for f, _ in po._fields_:

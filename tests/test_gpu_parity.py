@@ -940,16 +940,56 @@ def test_drop_in_classes_reproduce_reference_planner_loop(dev, case):
     assert abs(learner.p.sum() - 1.0) < 1e-7 and learner.t == min(len(history), cfg.optim_steps)  # Exp normalises with safe_div (+1e-8)
 
 
+@pytest.mark.parametrize("mode", ["fused", "serial"])
+def test_inactive_scenes_are_left_alone(dev, mode, monkeypatch):
+    """Once a scene terminates the reference leaves its loop (omg/planner.py:626): no goal-set batch, no goal update, no
+    step.  With an `active` mask the launches skip such scenes — every output of theirs (goal costs, layer, learner state,
+    goal, trajectory, info) keeps its contents, and the other scenes' results are bit-identical to a run without any mask."""
+    from omg_planner_amd import robot as rb, scenes as sc
+    from omg_planner_amd.config import Config
+    from omg_planner_amd.engine import ChompEngine
+    import copy
+    monkeypatch.setenv("OMGX_ITERATION", mode)
+    S, G, n = 11, 6, 30
+    m = rb.PandaModel(seed=3)
+    scenes, batch = _multi_scene_batch(S)
+    goals = np.stack([sc.make_reach_goals(scenes[s], m, G, s) for s in range(S)])
+    start = np.tile(rb.HOME_CONFIG, (S, 1))
+    cfg = Config(use_standoff=False)
+    cfg.optim_steps = 6
+    cfg.get_global_param(n)
+    names = ("traj", "info", "goal_idx", "learner_state", "end", "goal_rows", "goal_point", "cost_vec", "grad", "pot", "pgrad", "col", "goal_cost")
+    a = ChompEngine(m, batch, copy.deepcopy(cfg), start, goals, device=dev, ol_alg="MD")
+    b = ChompEngine(m, batch, copy.deepcopy(cfg), start, goals, device=dev, ol_alg="MD")
+    for t in range(2):
+        a.iterate(t)
+        b.iterate(t)
+    mask = torch.tensor([1, 0, 1, 1, 0, 0, 1, 1, 1, 0, 1], dtype=torch.int32, device=dev)
+    frozen = {k: getattr(b, k).clone() for k in names}
+    b.active = mask.clone()
+    for t in range(2, 5):
+        a.iterate(t)
+        b.iterate(t)
+    torch.cuda.synchronize()
+    on, off = mask.bool(), ~mask.bool()
+    for k in names:
+        assert torch.equal(getattr(b, k)[on], getattr(a, k)[on]), k       # the others: as without a mask
+        if mode == "serial" and k in ("pot", "pgrad", "col", "goal_cost"):
+            continue  # the separate entry points omgx_fk_sdf / omgx_goalset_cost take no mask: computed, then ignored
+        assert torch.equal(getattr(b, k)[off], frozen[k][off]), k          # the masked ones: untouched since iteration 1
+    assert not torch.equal(a.traj[off], frozen["traj"][off])
+
+
 def test_two_launch_entry_points_reject_bad_arguments(dev, monkeypatch):
     """omgx_goalset_cost_layer / omgx_goal_update_optimize: error codes, never a crash; odd sizes (1 scene, 1 goal, window
     shorter than the trajectory) agree with the separate entry points."""
     from omg_planner_amd import _lib, ops, robot as rb, scenes as sc
     import ctypes as C
     l = _lib.lib()
-    rc = l.omgx_goalset_cost_layer(None, 15, None, None, None, None, 9, None, 1, 1, 5, 0.1, 0, None, None, None, None, 5, 0, None, None, None, None)
+    rc = l.omgx_goalset_cost_layer(None, 15, None, None, None, None, 9, None, 1, 1, 5, 0.1, 0, None, None, None, None, 5, 0, None, None, None, None, None)
     assert rc == _lib.OMGX_ERR_INVALID
     lp, cp = _lib.LearnerParams(), _lib.ChompParams()
-    rc = l.omgx_goal_update_optimize(C.byref(lp), *([None] * 6), None, C.byref(cp), *([None] * 9), 3, *([None] * 4), None, 0, None)
+    rc = l.omgx_goal_update_optimize(C.byref(lp), *([None] * 6), None, C.byref(cp), *([None] * 9), 3, *([None] * 4), None, 0, 0, None)
     assert rc == _lib.OMGX_ERR_INVALID
     # one scene, one goal, 7-waypoint window on a 12-waypoint trajectory
     m = rb.PandaModel(seed=2)
