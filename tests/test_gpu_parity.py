@@ -980,6 +980,31 @@ def test_inactive_scenes_are_left_alone(dev, mode, monkeypatch):
     assert not torch.equal(a.traj[off], frozen["traj"][off])
 
 
+def test_plan_stops_launching_when_every_scene_has_terminated(dev):
+    """ChompEngine.plan with early_stop looks at the active mask now and then and leaves the loop once nothing is active
+    (planner.py:626 breaks at once): same results as running all 70 iterations over the inactive scenes."""
+    from omg_planner_amd.config import Config
+    from omg_planner_amd.engine import ChompEngine
+    fx = H.load("plan_md_early_2.npz")  # the reference terminates after two iterations
+    m, batch = H.model_from(fx), H.batch_from(fx)
+    outs = []
+    for stop_early in (True, False):
+        eng = ChompEngine(m, batch, Config(timesteps=30, use_standoff=False), fx["start"][None], fx["goal_set"][None], device=dev, ol_alg="MD")
+        if stop_early:
+            info = eng.plan(early_stop=True)
+            assert eng.iterations_run == 2 and int(eng.active[0]) == 0
+        else:
+            eng.select_initial_goal()
+            for t in range(70):
+                eng.iterate(t, early_stop=True)
+            info = eng.optimize(False)
+        outs.append((info.clone(), eng.traj.clone(), eng.goal_idx.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    np.testing.assert_allclose(outs[0][1][0].cpu().numpy(), fx["history"][1], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(outs[0][0][0, 0].item(), fx["info_cost"][-1], rtol=1e-5)
+
+
 def test_two_launch_entry_points_reject_bad_arguments(dev, monkeypatch):
     """omgx_goalset_cost_layer / omgx_goal_update_optimize: error codes, never a crash; odd sizes (1 scene, 1 goal, window
     shorter than the trajectory) agree with the separate entry points."""
