@@ -177,8 +177,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    torch.cuda.synchronize()
-    costs = torch.cat([e.final_costs() for e in engines])
+    costs = torch.cat([e.final_costs() for e in engines])  # enqueued behind the last step: no host sync before the collective
     from omg_planner_amd.engine import gather_costs_equal
     # the job's one collective (RCCL all-gather over xGMI; host tensors under the gloo test backend)
     allc = gather_costs_equal(costs if backend == "nccl" else costs.cpu(), world)
