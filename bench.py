@@ -159,7 +159,19 @@ def main():
     eng = engines[0]
     lib = _lib.lib()
 
+    # The workload must not drift with the number of steps: a trajectory that has been optimised for hundreds of iterations
+    # has left the obstacles' influence regions (the kernel's culling then retires nearly every pair: 4000 consecutive steps
+    # measured 0.15 ms/step) and Optimizer.update's schedule grows without bound (1.02^k).  A plan runs cfg.optim_steps = 50
+    # goal-selecting iterations, so every 50 steps the engines go back to the fresh plan (device-to-device copies inside the
+    # timed region, no host sync): each block of 50 steps is the first 50 iterations of a plan, whatever --steps is.
+    snaps = [e.snapshot() for e in engines]
+    count = [0]
+
     def step():
+        if count[0] and count[0] % cfg.optim_steps == 0:
+            for e, sn in zip(engines, snaps):
+                e.restore(sn)
+        count[0] += 1
         for e in engines:
             e.t = 0  # pin the goal-set window at the full n waypoints (first-iteration workload)
             e.iterate(0)
@@ -264,7 +276,8 @@ def main():
             "config": {"workload": "100 table-top scenes/GPU x (64-goal goal-set cost + CHOMP step), Panda 9-dof, 30 waypoints",
                        "scenes_per_gpu": S, "goals": G, "waypoints": n, "objects_per_scene": O_active,
                        "sdf_grid": f"4x{args.grid}^3 + 128x96x32 per scene, {'shared' if args.share_grids else 'private'}",
-                       "goal_selection": f"{args.ol_alg} on device (omgx_goal_update_optimize)", "launches_per_iteration": 2, "top_k_collision": cfg.top_k_collision, "streams": ns},
+                       "goal_selection": f"{args.ol_alg} on device (omgx_goal_update_optimize)", "launches_per_iteration": 2, "top_k_collision": cfg.top_k_collision, "streams": ns,
+                       "plan_restart_every_steps": cfg.optim_steps},
             "roofline": {"bound": "hbm", "kernel": "k_goalset_compact<2> (goal-set batch + trajectory layer: FK + SDF + arc-length cost)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": avg_ms, "launches": int(len(goal_ms)), "algorithmic_bytes_per_launch": alg_bytes,

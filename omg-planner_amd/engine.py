@@ -270,6 +270,27 @@ class ChompEngine:
             self._schedule()
             self._step(True, lprm, stop_on_terminate=stop)
 
+    # ---------------------------------------------------------------------------------------------
+    _STATE = ("traj", "end", "goal_rows", "goal_point", "goal_idx", "learner_state", "info", "active", "goal_cost", "goal_col",
+              "cost_vec", "grad", "cost_traj", "pot", "pgrad", "col")
+
+    def snapshot(self) -> dict:
+        """Everything a plan mutates (device tensors cloned + the host-side counters): restore() brings the engine back to
+        this point — e.g. to plan the same scenes again, or to keep a benchmark's workload stationary."""
+        snap = {k: getattr(self, k).clone() for k in self._STATE}
+        snap["_host"] = (self.step_count, self.t, self.cfg.obstacle_weight, self.cfg.smoothness_weight, self.cfg.grasp_weight, self.cfg.step_size)
+        return snap
+
+    def restore(self, snap: dict):
+        """Device-to-device copies on the current stream, no host sync."""
+        for k in self._STATE:
+            cur = getattr(self, k)
+            if cur.shape != snap[k].shape:  # early_stop used to rebind self.active: keep one tensor
+                setattr(self, k, snap[k].clone())
+            else:
+                cur.copy_(snap[k])
+        (self.step_count, self.t, self.cfg.obstacle_weight, self.cfg.smoothness_weight, self.cfg.grasp_weight, self.cfg.step_size) = snap["_host"]
+
     def select_initial_goal(self):
         """Learner.__init__ (online_learner.py:96-102): before planning, pick the cheapest goal by one cost_vector
         evaluation at t = 0 and re-interpolate the trajectory towards it (Trajectory.interpolate_waypoints, cubic)."""
