@@ -1005,6 +1005,36 @@ def test_plan_stops_launching_when_every_scene_has_terminated(dev):
     np.testing.assert_allclose(outs[0][0][0, 0].item(), fx["info_cost"][-1], rtol=1e-5)
 
 
+def test_engine_snapshot_restore_replays_identically(dev):
+    """ChompEngine.snapshot / restore (bench.py restarts the plan with them): the same iterations after a restore give the
+    same bits, including the learner state, the schedules and an active mask that early_stop had changed."""
+    from omg_planner_amd import robot as rb, scenes as sc
+    from omg_planner_amd.config import Config
+    from omg_planner_amd.engine import ChompEngine
+    S, G = 6, 5
+    m = rb.PandaModel(seed=4)
+    scenes, batch = _multi_scene_batch(S)
+    goals = np.stack([sc.make_reach_goals(scenes[s], m, G, s) for s in range(S)])
+    cfg = Config(use_standoff=False)
+    cfg.optim_steps = 4
+    cfg.allow_collision_point = 10_000  # some scenes terminate: the active mask changes
+    cfg.get_global_param(30)
+    eng = ChompEngine(m, batch, cfg, np.tile(rb.HOME_CONFIG, (S, 1)), goals, device=dev, ol_alg="MD")
+    eng.select_initial_goal()
+    snap = eng.snapshot()
+    runs = []
+    for _ in range(2):
+        for t in range(7):
+            eng.iterate(t, early_stop=True)
+        torch.cuda.synchronize()
+        runs.append({k: getattr(eng, k).clone() for k in eng._STATE} | {"w": torch.tensor([cfg.smoothness_weight, float(eng.step_count), float(eng.t)])})
+        eng.restore(snap)
+    assert int(runs[0]["active"].sum()) < S
+    for k in runs[0]:
+        assert torch.equal(runs[0][k], runs[1][k]), k
+    assert eng.step_count == 0 and eng.t == 0 and int(eng.active.sum()) == S
+
+
 def test_two_launch_entry_points_reject_bad_arguments(dev, monkeypatch):
     """omgx_goalset_cost_layer / omgx_goal_update_optimize: error codes, never a crash; odd sizes (1 scene, 1 goal, window
     shorter than the trajectory) agree with the separate entry points."""
