@@ -485,9 +485,31 @@ __global__ __launch_bounds__(256, GS_WG_PER_CU) void k_goalset_compact(ChunkArgs
     const int j = (int)(blockIdx.x >> 3) - nlayer;
     const int sgrp = is_layer ? (int)(blockIdx.x >> 3) / GS_LAYER_PARTS : j / a.NCH;
     const int layer_part = (int)(blockIdx.x >> 3) - sgrp * GS_LAYER_PARTS;
-    const int s = sgrp * 8 + xcd, chunk = is_layer ? 0 : j - sgrp * a.NCH;
+    int s = sgrp * 8 + xcd;
+    const int chunk = is_layer ? 0 : j - sgrp * a.NCH;
     if (s >= a.S) return;
-    if (a.active && a.active[s] == 0) return;  // the planner has left this scene's loop (planner.py:626)
+    if (a.active) {
+        // Scenes the planner has left (planner.py:626) get no workgroups, and the remaining ones are dealt out again so that
+        // every XCD keeps an equal share: slot k = sgrp * 8 + xcd works on the k-th ACTIVE scene (ascending).  Every wave
+        // finds it by itself with ballots over the mask (S / 64 steps, wave-uniform): no barrier, no extra launch, same
+        // result in all waves.  With all scenes active this is the identity.
+        const int k = s, ln = threadIdx.x & 63;
+        int seen = 0;
+        s = -1;
+        for (int base = 0; base < a.S; base += 64) {
+            const int i = base + ln;
+            const unsigned long long bal = __ballot(i < a.S && a.active[i] != 0);
+            const int cnt = __popcll(bal);
+            if (k < seen + cnt) {
+                unsigned long long m = bal;
+                for (int q = k - seen; q > 0; --q) m &= m - 1;  // drop the k - seen lowest set bits
+                s = base + __builtin_ctzll(m);
+                break;
+            }
+            seen += cnt;
+        }
+        if (s < 0) return;  // fewer active scenes than slots
+    }
     const int o_begin = as_const(a.scene_begin)[s], o_end = as_const(a.scene_begin)[s + 1];
     const int P = a.P, CH = a.CH;
     const int nvalid = CH;

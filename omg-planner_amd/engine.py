@@ -99,7 +99,8 @@ class ChompEngine:
         self.learner_state = ops.learner_state(S, G, dev)  # sum_costs | p | experts_p | q | experts_costs
         self.cost_vec = torch.zeros((S, G), **f64)
         self.eta = float(np.sqrt(np.log(G + 1) / cfg.optim_steps))  # online_learner.py:80
-        self.active = torch.ones(S, dtype=torch.int32, device=dev)
+        self._active = torch.ones(S, dtype=torch.int32, device=dev)
+        self._masked = False  # becomes True with the first early_stop iteration or when `active` is assigned: launches then take the mask
         self.step_count = 0  # Optimizer.step
         self.t = 0           # Learner.t
         # The waypoint SDF batch (omgx_fk_sdf on traj) does not depend on the goal selection, only k_chomp_optimize
@@ -111,6 +112,20 @@ class ChompEngine:
         self._ticket = 0
         self._num_cus = torch.cuda.get_device_properties(dev).multi_processor_count
         self._gather_goal()
+
+    @property
+    def active(self) -> torch.Tensor:
+        """[S] int32: 0 = the scene has left the planner loop (planner.py:626) and every launch skips it."""
+        return self._active
+
+    @active.setter
+    def active(self, value: torch.Tensor):
+        self._active = value
+        self._masked = True
+
+    def _mask(self):
+        """The mask for a launch — None while no scene can be inactive (the goal-set kernel then skips its slot look-up)."""
+        return self._active if self._masked else None
 
     # ---------------------------------------------------------------------------------------------
     def _params(self, do_update: bool) -> _lib.ChompParams:
@@ -187,7 +202,7 @@ class ChompEngine:
                 ops.goalset_cost_layer(self.robot, self.P, self.scenes, traj_start, self.cv_goals, n_rem, self.cfg.time_interval,
                                        self.traj, (self.pot, self.pgrad, self.col), soften_fingers=False,
                                        layer_soften_fingers=self.cfg.uncheck_finger_collision == -1,
-                                       out=(self.goal_cost, self.goal_col), active=self.active)
+                                       out=(self.goal_cost, self.goal_col), active=self._mask())
             else:
                 ops.goalset_cost(self.robot, self.P, self.scenes, traj_start, self.cv_goals, n_rem, self.cfg.time_interval,
                                  soften_fingers=False, out=(self.goal_cost, self.goal_col))
@@ -196,7 +211,7 @@ class ChompEngine:
         if defer_update:
             return prm
         ops.goal_update(prm, self.traj, self.goal_set, self.reach, self.goal_cost, self.learner_state, self.goal_idx,
-                        self.end, self.goal_rows, self.goal_point, self.cost_vec, active=self.active)
+                        self.end, self.goal_rows, self.goal_point, self.cost_vec, active=self._mask())
         return None
 
     def _layer(self):
@@ -245,6 +260,8 @@ class ChompEngine:
         # planner.py:626-627 (a scene that terminates at t > 0 leaves the loop): the step itself clears active[s] — no extra
         # kernels between iterations; the goal-set launch, the goal update and the step skip scenes with active[s] == 0
         stop = bool(early_stop and t > 0)
+        if early_stop:
+            self._masked = True
         if select and mode == "fused" and self.ol_alg != "Baseline":
             # two launches on one stream: goal-set batch + trajectory layer, then goal update + optimiser step
             lprm = self.update_goal(defer_update=True, with_layer=True)
