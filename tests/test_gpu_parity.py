@@ -1035,6 +1035,39 @@ def test_engine_snapshot_restore_replays_identically(dev):
     assert eng.step_count == 0 and eng.t == 0 and int(eng.active.sum()) == S
 
 
+def test_goalset_slots_follow_the_active_scenes(dev):
+    """omgx_goalset_cost_layer with a mask over 150 scenes (more than one 64-lane ballot): slot k of the grid works on the
+    k-th active scene — outputs of active scenes equal the unmasked launch bit for bit, those of inactive scenes keep the
+    sentinel they held; all-ones and all-zero masks included."""
+    from omg_planner_amd import ops, robot as rb, scenes as sc
+    S, G, n = 150, 3, 8
+    m = rb.PandaModel(seed=6)
+    P = m.points_per_link
+    scenes = [sc.make_tabletop_scene(s % 7, grid=16, table_grid=(24, 16, 8)) for s in range(S)]
+    batch = sc.pack_table(scenes, H.LAYER_CFG)
+    rng = np.random.RandomState(3)
+    goals = np.stack([sc.make_reach_goals(scenes[s], m, G, s) for s in range(S)])
+    traj = np.stack([sc.cubic_init(rb.HOME_CONFIG + rng.normal(0, 0.05, 9) * np.array([1] * 7 + [0, 0]), goals[s, 0], n) for s in range(S)])
+    robot, ds = ops.robot_blob(m, dev), ops.DeviceScenes(batch, dev)
+    tt, gg = _t(traj, dev), _t(goals, dev)
+
+    def run(mask):
+        lay = tuple(torch.full(shape, -7.0, dtype=torch.float32, device=dev) for shape in ((S, n, 10, P), (S, n, 10, P, 3), (S, n, 10, P)))
+        out = (torch.full((S, G), -7.0, dtype=torch.float32, device=dev), torch.full((S, G), -7.0, dtype=torch.float32, device=dev))
+        ops.goalset_cost_layer(robot, P, ds, tt[:, 2], gg, n - 2, 0.1, tt, lay, out=out,
+                               active=None if mask is None else torch.as_tensor(mask, dtype=torch.int32, device=dev))
+        torch.cuda.synchronize()
+        return out + lay
+
+    full = run(None)
+    for mask in (np.ones(S, np.int32), (rng.rand(S) < 0.6).astype(np.int32), (np.arange(S) >= 140).astype(np.int32), np.zeros(S, np.int32)):
+        got = run(mask)
+        on = torch.as_tensor(mask.astype(bool), device=dev)
+        for a, b in zip(got, full):
+            assert torch.equal(a[on], b[on])
+            assert bool((a[~on] == -7.0).all())
+
+
 def test_two_launch_entry_points_reject_bad_arguments(dev, monkeypatch):
     """omgx_goalset_cost_layer / omgx_goal_update_optimize: error codes, never a crash; odd sizes (1 scene, 1 goal, window
     shorter than the trajectory) agree with the separate entry points."""
