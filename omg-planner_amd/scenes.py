@@ -153,6 +153,20 @@ class Scene:
     target_idx: int = 0
 
 
+def scene_from_env(env) -> Scene:
+    """The `Scene` of a reference `Env` (omg/core.py:239-411), for `pack_table` / `ChompEngine`: every object's name, pose and
+    attached flag and the volume the reference itself puts on the GPU — `obj.sdf.data_torch` (core.py:381), NOT `obj.sdf.data`,
+    whose negative values `Model` has multiplied by cfg.penalize_constant on the numpy copy only (core.py:110) — with origin
+    `sdf.min_coords` and voxel size `sdf.delta`."""
+    objs = []
+    for o in env.objects:
+        vol = getattr(o.sdf, "data_torch", None)
+        vol = np.asarray(o.sdf.data, np.float32) if vol is None else vol.detach().cpu().numpy().astype(np.float32)
+        objs.append(SceneObject(str(o.name), np.array(o.pose_mat, np.float64), SdfGrid(np.ascontiguousarray(vol), np.array(o.sdf.min_coords, np.float64),
+                                                                                   float(o.sdf.delta)), bool(getattr(o, "attached", False))))
+    return Scene(objs, int(env.target_idx))
+
+
 def se3_inverse(pose: np.ndarray) -> np.ndarray:
     """[R t]^-1 = [R^T, -R^T t] as float32 (omg/util.py:129-135)."""
     out = np.eye(4, dtype=np.float32)

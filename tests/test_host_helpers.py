@@ -209,3 +209,44 @@ def test_lazy_info_builds_collision_pts_on_first_access():
         info["nope"]
     with pytest.raises(KeyError):
         LazyInfo({"cost": 1.0})["collision_pts"]
+
+
+def test_scene_from_env_takes_the_gpu_copy_of_the_volumes():
+    """scenes.scene_from_env: a reference-shaped Env -> Scene; the volume is sdf.data_torch (un-penalised), and packing the
+    result reproduces Env.combine_sdfs' padded tensor and limits (omg/core.py:366-411) for the same objects."""
+    import types
+
+    import torch
+    from omg_planner_amd import scenes as sc
+    rng = np.random.RandomState(0)
+    objs = []
+    for k, dims in enumerate([(6, 5, 4), (3, 8, 7)]):
+        g = rng.normal(0, 0.1, dims).astype(np.float32)
+        pen = g.copy()
+        pen[pen < 0] *= 5.0  # Model's penalize_constant on the numpy copy (core.py:110)
+        origin, delta = rng.uniform(-0.2, 0, 3), 0.02 * (k + 1)
+        sdf = types.SimpleNamespace(data=pen, data_torch=torch.from_numpy(g), min_coords=origin, max_coords=origin + delta * np.array(dims), delta=delta)
+        pose = np.eye(4)
+        pose[:3, 3] = rng.normal(size=3)
+        objs.append(types.SimpleNamespace(name=f"obj{k}", pose_mat=pose, attached=bool(k), sdf=sdf))
+    env = types.SimpleNamespace(objects=objs, target_idx=1)
+    scene = sc.scene_from_env(env)
+    assert scene.target_idx == 1 and [o.name for o in scene.objects] == ["obj0", "obj1"] and scene.objects[1].attached
+    for o, ref in zip(scene.objects, objs):
+        assert np.array_equal(o.sdf.data, ref.sdf.data_torch.numpy()) and not np.array_equal(o.sdf.data, ref.sdf.data)
+        assert np.array_equal(o.pose_mat, ref.pose_mat) and o.sdf.delta == ref.sdf.delta
+    # Env.combine_sdfs restated on the same objects (core.py:366-411)
+    mx = np.array([o.sdf.data.shape for o in objs]).max(axis=0)
+    want = np.ones((2, *mx), np.float32)
+    lim = np.zeros((2, 10), np.float32)
+    for i, o in enumerate(objs):
+        size = o.sdf.data.shape
+        want[i, :size[0], :size[1], :size[2]] = o.sdf.data_torch.numpy()
+        lo, hi = o.sdf.min_coords, o.sdf.max_coords
+        for a in range(3):
+            lim[i, a] = lo[a]
+            lim[i, 3 + a] = lo[a] + (hi[a] - lo[a]) * mx[a] / size[a]
+            lim[i, 6 + a] = mx[a]
+        lim[i, 9] = o.sdf.delta
+    sdf, limits = sc.pack_padded(scene.objects)
+    assert np.array_equal(sdf, want) and np.array_equal(limits, lim)
