@@ -231,6 +231,8 @@ int omgx_goalset_cost(const double* robot, int32_t n_points,
  * (goal_cost: same float32 summation order; layer outputs: bit-identical).
  *   active  optional [S] int32 (NULL = all): scenes with active[s] == 0 are skipped — the reference leaves a scene's
  *           loop once it terminates (omg/planner.py:626) — and their outputs keep their previous contents.
+ *   goal_count  optional [S] int32 (NULL = num_goals everywhere): scene s has only goal_count[s] goals, the rest of its
+ *           rows in `goals` / `goal_cost` is padding that is neither read nor written (ragged goal sets in one batch).
  * ------------------------------------------------------------------------------------------- */
 int omgx_goalset_cost_layer(const double* robot, int32_t n_points,
                             const omgx_object* objects, const int32_t* scene_begin, const float* sdf_pool,
@@ -240,7 +242,7 @@ int omgx_goalset_cost_layer(const double* robot, int32_t n_points,
                             float* goal_cost, float* collides, void* workspace,
                             const double* traj, int32_t n_waypoints, int32_t layer_soften_fingers,
                             float* layer_potentials, float* layer_grads, float* layer_collides,
-                            const int32_t* active, void* stream);
+                            const int32_t* active, const int32_t* goal_count, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * (4) omgx_chomp_optimize
@@ -292,6 +294,10 @@ int omgx_chomp_optimize(const double* robot, const omgx_chomp_params* h_params,
  *          goal_point [S,9] (goal_set[goal_idx]), cost_vector [S,G] double (optional, NULL to skip).
  * G <= OMGX_MAX_GOALS.  active: optional [S] int32 (NULL = all); scenes with 0 keep goal, outputs and state untouched
  * (omgx_goal_update_optimize applies its `active` to the goal update as well as to the step).
+ * goal_count / eta: optional [S] int32 / [S] double for ragged goal sets — scene s uses its first goal_count[s] goals (all
+ * arrays keep the padded stride num_goals; a fresh state holds 1 / goal_count[s] there and 0 in the padding) and its own
+ * eta[s] = sqrt(log(goal_count[s] + 1) / optim_steps); every sum, norm and constant (delta = 1 / (4 G + 1)) is taken over
+ * the scene's own goals, so the scene computes exactly what it would compute alone.
  * ------------------------------------------------------------------------------------------- */
 #define OMGX_MAX_GOALS 256
 #define OMGX_ALG_FTL 0
@@ -316,7 +322,7 @@ int64_t omgx_learner_state_doubles(int32_t num_goals);
 int omgx_goal_update(const omgx_learner_params* h_params, const double* traj, const double* goal_set, const double* reach,
                      const float* goal_cost, double* state, int32_t num_scenes,
                      int32_t* goal_idx, double* end, double* goal_rows, double* goal_point, double* cost_vector,
-                     const int32_t* active, void* stream);
+                     const int32_t* active, const int32_t* goal_count, const double* eta, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * (5b) omgx_goal_update_optimize
@@ -340,7 +346,8 @@ int omgx_goal_update_optimize(const omgx_learner_params* h_learner, const double
                               const float* potentials, const float* grads, const float* collides,
                               int32_t* active, int32_t num_scenes,
                               double* grad, double* cost_traj, double* info, double* aux,
-                              int32_t* scene_flags, int32_t ticket, int32_t stop_on_terminate, void* stream);
+                              int32_t* scene_flags, int32_t ticket, int32_t stop_on_terminate,
+                              const int32_t* goal_count, const double* eta, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * (6) omgx_point_cloud_sdf

@@ -916,11 +916,12 @@ extern "C" int omgx_goal_update_optimize(const omgx_learner_params* h_learner, c
                                          const double* start, double* end, double* goal, double* goal_point,
                                          const float* potentials, const float* grads, const float* collides,
                                          int32_t* active, int32_t num_scenes, double* grad, double* cost_traj, double* info,
-                                         double* aux, int32_t* scene_flags, int32_t ticket, int32_t stop_on_terminate, void* stream) {
+                                         double* aux, int32_t* scene_flags, int32_t ticket, int32_t stop_on_terminate, const int32_t* goal_count,
+                                         const double* eta, void* stream) {
     if (h_learner && h_params && num_scenes == 0) return OMGX_OK;
     omg_learner::LearnerArgs la;
     int rc = omg_learner::make_args(h_learner, traj, goal_set, reach, goal_cost, learner_state, num_scenes, goal_idx, end, goal,
-                                    goal_point, cost_vector, active, la);
+                                    goal_point, cost_vector, active, goal_count, eta, la);
     if (rc != OMGX_OK) return rc;
     ChompArgs a;
     size_t lds = 0;

@@ -183,6 +183,8 @@ struct ChunkArgs {
     const omgx_object* objects;
     const int32_t* scene_begin;
     const float* pool;
+    const int32_t* active;     // [S] or null (k_goalset_compact): scenes with 0 are skipped, their outputs stay as they are
+    const int32_t* goal_count; // [S] or null (k_goalset_compact): goals >= goal_count[s] of the padded goal array are skipped
     const double* ws;        // [S][NCH][10][CH][12] link poses
     const double* ws_start;  // [S][10][12] or null
     int S, C, CH, NCH, P;
@@ -206,7 +208,6 @@ struct ChunkArgs {
     float* wp_grad;            // [S][wp_n][10][P][3]
     float* wp_col;             // [S][wp_n][10][P]
     int PS, MR;                // LDS pose stride (configurations per link) and mask rows per link: max over both kinds of workgroup
-    const int32_t* active;     // [S] or null (k_goalset_compact): scenes with 0 are skipped, their outputs stay as they are
 };
 
 // Thread layout: 256 threads = 16 rows x 16 lanes.  Lane = collision point p of a link (P <= 16), row =
@@ -508,8 +509,8 @@ __global__ __launch_bounds__(256, GS_WG_PER_CU) void k_goalset_compact(ChunkArgs
             }
             seen += cnt;
         }
-        if (s < 0) return;  // fewer active scenes than slots
     }
+    if (s < 0) return;  // fewer active scenes than slots
     const int o_begin = as_const(a.scene_begin)[s], o_end = as_const(a.scene_begin)[s + 1];
     const int P = a.P, CH = a.CH;
     const int nvalid = CH;
@@ -524,6 +525,7 @@ __global__ __launch_bounds__(256, GS_WG_PER_CU) void k_goalset_compact(ChunkArgs
         return;
     }
 
+    if (a.goal_count && chunk >= as_const(a.goal_count)[s]) return;  // padding of a ragged goal set
     {   // FK of start + CH interpolated configurations in two stages (omg_device.h: fk_chain_row); the (sin, cos)
         // table borrows the row-mask / scratch region, which is first written after the barriers below.
         const double* q0 = a.traj_start + a.ts_stride * (int64_t)s;
@@ -721,7 +723,7 @@ static inline int timing_slot() {
     }
     return i;
 }
-extern "C" int omgx_abi_version(void) { return 2; }  // 2: `active` masks on omgx_goalset_cost_layer / omgx_goal_update
+extern "C" int omgx_abi_version(void) { return 3; }  // 2: `active` masks; 3: ragged goal sets (goal_count, eta)
 extern "C" int omgx_device_arch(char* h_buf, int32_t h_len) {
     if (!h_buf || h_len <= 0) return OMGX_ERR_INVALID;
     int dev = 0;
@@ -991,7 +993,7 @@ static int goalset_cost_impl(const double* robot, int32_t n_points, const omgx_o
                              int32_t num_scenes, int32_t num_goals, int32_t n_remaining, double time_interval,
                              int32_t soften_fingers, float* goal_cost, float* potentials, float* collides, void* workspace,
                              const double* layer_traj, int32_t layer_n, int32_t layer_soften, float* layer_pot, float* layer_grad,
-                             float* layer_col, const int32_t* active, void* stream) {
+                             float* layer_col, const int32_t* active, const int32_t* goal_count, void* stream) {
     if (num_scenes < 0 || num_goals < 0) return OMGX_ERR_INVALID;
     if (num_scenes == 0 || num_goals == 0) return OMGX_OK;
     if (!robot || !objects || !scene_begin || !traj_start || !goals || !goal_cost || !workspace) return OMGX_ERR_INVALID;
@@ -1028,8 +1030,8 @@ static int goalset_cost_impl(const double* robot, int32_t n_points, const omgx_o
         ca.wp_traj = layer_traj; ca.wp_n = layer_n; ca.wp_soften = layer_soften != 0;
         ca.wp_pot = layer_pot; ca.wp_grad = layer_grad; ca.wp_col = layer_col;
     }
-    if (active && !(fused && compact && !potentials)) return OMGX_ERR_UNSUPPORTED;  // the mask lives in k_goalset_compact
-    ca.active = active;
+    if ((active || goal_count) && !(fused && compact && !potentials)) return OMGX_ERR_UNSUPPORTED;  // the masks live in k_goalset_compact
+    ca.active = active; ca.goal_count = goal_count;
     return launch_chunks(ca, st);
 }
 
@@ -1041,7 +1043,7 @@ extern "C" int omgx_goalset_cost(const double* robot, int32_t n_points, const om
                                  float* collides, void* workspace, void* stream) {
     return goalset_cost_impl(robot, n_points, objects, scene_begin, sdf_pool, traj_start, traj_start_stride, goals, num_scenes,
                              num_goals, n_remaining, time_interval, soften_fingers, goal_cost, potentials, collides, workspace,
-                             nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, stream);
+                             nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
 }
 
 extern "C" int omgx_goalset_cost_layer(const double* robot, int32_t n_points, const omgx_object* objects,
@@ -1050,9 +1052,9 @@ extern "C" int omgx_goalset_cost_layer(const double* robot, int32_t n_points, co
                                        int32_t n_remaining, double time_interval, int32_t soften_fingers, float* goal_cost,
                                        float* collides, void* workspace, const double* traj, int32_t n_waypoints,
                                        int32_t layer_soften_fingers, float* layer_potentials, float* layer_grads,
-                                       float* layer_collides, const int32_t* active, void* stream) {
+                                       float* layer_collides, const int32_t* active, const int32_t* goal_count, void* stream) {
     if (!traj) return OMGX_ERR_INVALID;
     return goalset_cost_impl(robot, n_points, objects, scene_begin, sdf_pool, traj_start, traj_start_stride, goals, num_scenes,
                              num_goals, n_remaining, time_interval, soften_fingers, goal_cost, nullptr, collides, workspace, traj,
-                             n_waypoints, layer_soften_fingers, layer_potentials, layer_grads, layer_collides, active, stream);
+                             n_waypoints, layer_soften_fingers, layer_potentials, layer_grads, layer_collides, active, goal_count, stream);
 }

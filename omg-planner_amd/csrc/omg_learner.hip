@@ -17,11 +17,11 @@ extern "C" int64_t omgx_learner_state_doubles(int32_t num_goals) { return num_go
 extern "C" int omgx_goal_update(const omgx_learner_params* h_params, const double* traj, const double* goal_set,
                                 const double* reach, const float* goal_cost, double* state, int32_t num_scenes,
                                 int32_t* goal_idx, double* end, double* goal_rows, double* goal_point, double* cost_vector,
-                                const int32_t* active, void* stream) {
+                                const int32_t* active, const int32_t* goal_count, const double* eta, void* stream) {
     if (h_params && num_scenes == 0) return OMGX_OK;
     omg_learner::LearnerArgs a;
     const int rc = omg_learner::make_args(h_params, traj, goal_set, reach, goal_cost, state, num_scenes, goal_idx, end, goal_rows,
-                                          goal_point, cost_vector, active, a);
+                                          goal_point, cost_vector, active, goal_count, eta, a);
     if (rc != OMGX_OK) return rc;
     hipLaunchKernelGGL(k_goal_update, dim3(num_scenes), dim3(320), 0, (hipStream_t)stream, a);
     OMGX_CHECK_LAUNCH("k_goal_update");

@@ -42,6 +42,8 @@ struct LearnerArgs {
     double* goal_point;
     double* cost_vector;
     const int32_t* active;  // [S] or null: scenes with 0 keep their goal and state (the reference has left its loop, planner.py:626)
+    const int32_t* goal_count;  // [S] or null: scene s has goal_count[s] <= num_goals goals (arrays stay padded to num_goals)
+    const double* eta;          // [S] or null: per-scene eta = sqrt(log(goal_count + 1) / optim_steps), else prm.eta
 };
 
 __device__ __forceinline__ double lane_bcast(double v, int k) {
@@ -144,10 +146,14 @@ __device__ __forceinline__ void learner_scene(const LearnerArgs& a, int s, doubl
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (a.prm.alg != OMGX_ALG_MD && wave > 0) return;  // no barrier on these paths
     const omgx_learner_params& prm = a.prm;
-    const int G = prm.num_goals, n = prm.n_waypoints, c = prm.constraint_num;
-    double* st = a.state + (int64_t)s * (7 * (int64_t)G + 10);
-    double *sum_costs = st, *p = st + G, *experts_p = st + 2 * G, *q = st + 7 * G, *ecost = st + 7 * G + 5;
-    const double* gs = a.goal_set + (int64_t)s * G * 9;
+    // GS: padded goal count (array strides); G: this scene's own count — every loop, sum and constant below uses G, so a scene
+    // in a ragged batch computes exactly what it would compute alone (padded lanes contribute exact zeros)
+    const int GS = prm.num_goals, n = prm.n_waypoints, c = prm.constraint_num;
+    const int G = a.goal_count ? min(max(a.goal_count[s], 1), GS) : GS;
+    const double eta = a.eta ? a.eta[s] : prm.eta;
+    double* st = a.state + (int64_t)s * (7 * (int64_t)GS + 10);
+    double *sum_costs = st, *p = st + GS, *experts_p = st + 2 * GS, *q = st + 7 * GS, *ecost = st + 7 * GS + 5;
+    const double* gs = a.goal_set + (int64_t)s * GS * 9;
     int idx = 0;
     if (prm.alg == OMGX_ALG_PROJ) {  // :196-206
         const double* last = a.traj + ((int64_t)s * n + n - 1) * 9;
@@ -178,7 +184,7 @@ __device__ __forceinline__ void learner_scene(const LearnerArgs& a, int s, doubl
                     s2 += e * e;
                 }
                 const double nr = sqrt(s2);
-                const float wc = (float)prm.base_obstacle_weight * a.goal_cost[(int64_t)s * G + g];  // float32 product
+                const float wc = (float)prm.base_obstacle_weight * a.goal_cost[(int64_t)s * GS + g];  // float32 product
                 cv[j] = (double)wc + prm.smooth_weight * (nr * nr);
                 part += cv[j] * cv[j];
             }
@@ -188,7 +194,7 @@ __device__ __forceinline__ void learner_scene(const LearnerArgs& a, int s, doubl
             for (int j = 0; j < NPL; ++j) cv[j] /= nn;
         }
         if (a.cost_vector && wave == 0)
-            for (int j = 0; j < NPL; ++j) { const int g = lane + 64 * j; if (g < G) a.cost_vector[(int64_t)s * G + g] = cv[j]; }
+            for (int j = 0; j < NPL; ++j) { const int g = lane + 64 * j; if (g < G) a.cost_vector[(int64_t)s * GS + g] = cv[j]; }
 
         if (prm.alg == OMGX_ALG_FTL || prm.alg == OMGX_ALG_FTC) {  // :175-189
             double best = OMG_ARG_NEUTRAL_MIN;
@@ -215,7 +221,7 @@ __device__ __forceinline__ void learner_scene(const LearnerArgs& a, int s, doubl
             for (int j = 0; j < NPL; ++j) {
                 const int g = lane + 64 * j;
                 pn[j] = 0.0;
-                if (g < G) { pn[j] = exp(-prm.eta * cv[j]) * p[g] * 0.999 + (sc[j] / (tot + 1e-8)) * 0.001; ps += pn[j]; }
+                if (g < G) { pn[j] = exp(-eta * cv[j]) * p[g] * 0.999 + (sc[j] / (tot + 1e-8)) * 0.001; ps += pn[j]; }
             }
             ps = wsum(ps);
             double best = OMG_ARG_NEUTRAL_MAX;
@@ -232,8 +238,8 @@ __device__ __forceinline__ void learner_scene(const LearnerArgs& a, int s, doubl
                 double v[NPL], epw[NPL], pn[NPL];
                 for (int j = 0; j < NPL; ++j) {
                     const int g = lane + 64 * j;
-                    v[j] = prm.eta * pw[wave] * cv[j];
-                    epw[j] = g < G ? experts_p[(int64_t)wave * G + g] : 0.0;
+                    v[j] = eta * pw[wave] * cv[j];
+                    epw[j] = g < G ? experts_p[(int64_t)wave * GS + g] : 0.0;
                 }
                 bregman_projection(epw, v, delta, G, lane, pn);
                 // this expert's cost (:229-230) on its own wave: sum_g cv pn + |pn - old p|; the step table is dead by now
@@ -283,7 +289,7 @@ __device__ __forceinline__ void learner_scene(const LearnerArgs& a, int s, doubl
                 const int g = lane + 64 * j;
                 if (g < G) {
                     p[g] = pm[j];
-                    for (int i = 0; i < 5; ++i) experts_p[(int64_t)i * G + g] = ep[i][j];
+                    for (int i = 0; i < 5; ++i) experts_p[(int64_t)i * GS + g] = ep[i][j];
                     if (omg::np_arg_better<false>(pm[j], g, best, bi)) { best = pm[j]; bi = g; }
                 }
             }
@@ -301,14 +307,15 @@ __device__ __forceinline__ void learner_scene(const LearnerArgs& a, int s, doubl
     }
     for (int e = lane; e < c * 9; e += 64)
         a.goal_rows[(int64_t)s * c * 9 + e] =
-            prm.use_standoff ? a.reach[((int64_t)s * G + idx) * c * 9 + e] : gs[idx * 9 + e % 9];
+            prm.use_standoff ? a.reach[((int64_t)s * GS + idx) * c * 9 + e] : gs[idx * 9 + e % 9];
 }
 
 
 // Host side: argument checks of omgx_goal_update (shared with omgx_goal_update_optimize).
 static inline int make_args(const omgx_learner_params* h_params, const double* traj, const double* goal_set, const double* reach,
                             const float* goal_cost, double* state, int32_t num_scenes, int32_t* goal_idx, double* end,
-                            double* goal_rows, double* goal_point, double* cost_vector, const int32_t* active, LearnerArgs& a) {
+                            double* goal_rows, double* goal_point, double* cost_vector, const int32_t* active, const int32_t* goal_count,
+                            const double* eta, LearnerArgs& a) {
     if (!h_params || num_scenes < 0) return OMGX_ERR_INVALID;
     const omgx_learner_params& p = *h_params;
     if (!traj || !goal_set || !state || !goal_idx || !end || !goal_rows || !goal_point) return OMGX_ERR_INVALID;
@@ -322,7 +329,7 @@ static inline int make_args(const omgx_learner_params* h_params, const double* t
     a = LearnerArgs{};
     a.prm = p; a.traj = traj; a.goal_set = goal_set; a.reach = reach; a.goal_cost = goal_cost; a.state = state; a.S = num_scenes;
     a.goal_idx = goal_idx; a.end = end; a.goal_rows = goal_rows; a.goal_point = goal_point; a.cost_vector = cost_vector;
-    a.active = active;
+    a.active = active; a.goal_count = goal_count; a.eta = eta;
     return OMGX_OK;
 }
 

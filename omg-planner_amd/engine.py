@@ -46,10 +46,12 @@ _ALL_DONE_CHECKS = frozenset((1, 2, 3, 5, 8, 13, 21, 34, 55))  # iterations afte
 class ChompEngine:
     def __init__(self, model: PandaModel, batch: SceneBatch, cfg: Config, start: np.ndarray, goal_set: np.ndarray,
                  reach_grasps: np.ndarray | None = None, traj_init: np.ndarray | None = None, device="cuda:0",
-                 ol_alg: str = "FTL", stream: "torch.cuda.Stream | None" = None):
+                 ol_alg: str = "FTL", stream: "torch.cuda.Stream | None" = None, goal_counts=None):
         """start [S,9]; goal_set [S,G,9]; reach_grasps [S,G,c,9] (needed when cfg.use_standoff).
         `stream`: run every launch of this engine on that HIP stream (several engines holding disjoint scene
-        subsets on different streams overlap each other's latency-bound kernels)."""
+        subsets on different streams overlap each other's latency-bound kernels).
+        `goal_counts` [S]: ragged goal sets — scene s uses goal_set[s, :goal_counts[s]] (and the matching reach_grasps); the
+        rest of its rows is padding that no launch reads.  Each scene then computes exactly what it would compute alone."""
         self.cfg = cfg
         self.stream = stream
         self.model = model
@@ -78,6 +80,14 @@ class ChompEngine:
             self.reach = None
             self.cv_goals = self.goal_set
         self.goal_idx = torch.zeros(self.S, dtype=torch.int32, device=dev)
+        self.goal_count = self.eta_s = None
+        if goal_counts is not None:
+            gc = np.asarray(goal_counts, np.int64).reshape(-1)
+            if gc.shape[0] != self.S or gc.min() < 1 or gc.max() > self.G:
+                raise ValueError("goal_counts must hold one count in [1, G] per scene")
+            self.goal_count = torch.as_tensor(gc, dtype=torch.int32, device=dev)
+            self.eta_s = torch.as_tensor(np.sqrt(np.log(gc + 1) / cfg.optim_steps), dtype=torch.float64, device=dev)  # online_learner.py:80 per scene
+            self._goal_counts_host = gc
         S, n, P, G = self.S, self.n, self.P, self.G
         if traj_init is None:
             from .scenes import cubic_init
@@ -96,7 +106,7 @@ class ChompEngine:
         self.info = torch.zeros((S, _lib.INFO_STRIDE), **f64)
         self.goal_cost = torch.zeros((S, G), **f32)
         self.goal_col = torch.zeros((S, G), **f32)
-        self.learner_state = ops.learner_state(S, G, dev)  # sum_costs | p | experts_p | q | experts_costs
+        self.learner_state = ops.learner_state(S, G, dev, goal_counts)  # sum_costs | p | experts_p | q | experts_costs
         self.cost_vec = torch.zeros((S, G), **f64)
         self.eta = float(np.sqrt(np.log(G + 1) / cfg.optim_steps))  # online_learner.py:80
         self._active = torch.ones(S, dtype=torch.int32, device=dev)
@@ -202,7 +212,7 @@ class ChompEngine:
                 ops.goalset_cost_layer(self.robot, self.P, self.scenes, traj_start, self.cv_goals, n_rem, self.cfg.time_interval,
                                        self.traj, (self.pot, self.pgrad, self.col), soften_fingers=False,
                                        layer_soften_fingers=self.cfg.uncheck_finger_collision == -1,
-                                       out=(self.goal_cost, self.goal_col), active=self._mask())
+                                       out=(self.goal_cost, self.goal_col), active=self._mask(), goal_count=self.goal_count)
             else:
                 ops.goalset_cost(self.robot, self.P, self.scenes, traj_start, self.cv_goals, n_rem, self.cfg.time_interval,
                                  soften_fingers=False, out=(self.goal_cost, self.goal_col))
@@ -211,7 +221,8 @@ class ChompEngine:
         if defer_update:
             return prm
         ops.goal_update(prm, self.traj, self.goal_set, self.reach, self.goal_cost, self.learner_state, self.goal_idx,
-                        self.end, self.goal_rows, self.goal_point, self.cost_vec, active=self._mask())
+                        self.end, self.goal_rows, self.goal_point, self.cost_vec, active=self._mask(),
+                        goal_count=self.goal_count, eta=self.eta_s)
         return None
 
     def _layer(self):
@@ -230,7 +241,7 @@ class ChompEngine:
                                      self.goal_point, self.pot, self.pgrad, self.col, active=self.active,
                                      out=(self.grad, self.cost_traj, self.info), cost_vector=self.cost_vec,
                                      scene_flags=self._scene_flags if split else None, ticket=self._ticket,
-                                     stop_on_terminate=stop_on_terminate)
+                                     stop_on_terminate=stop_on_terminate, goal_count=self.goal_count, eta=self.eta_s)
             return self.info
         ops.chomp_optimize(self.robot, self._params(do_update), self.traj, self.start, self.end, self.goal_rows,
                            self.goal_point, self.pot, self.pgrad, self.col, active=self.active,
@@ -319,6 +330,8 @@ class ChompEngine:
                 w = torch.as_tensor(np.broadcast_to(np.asarray(self.cfg.link_smooth_weight, np.float64).ravel(), (9,)).copy(),
                                     dtype=torch.float64, device=self.device)
                 d = torch.linalg.norm((self.start[:, None, :] - self.goal_set) * w, dim=-1)
+                if self.goal_count is not None:  # padding of a ragged goal set never wins
+                    d = torch.where(torch.arange(self.G, device=self.device)[None, :] < self.goal_count[:, None], d, torch.full_like(d, float("inf")))
                 self.goal_idx.copy_(torch.argmin(d, dim=1).to(torch.int32))
             else:
                 gi = int(getattr(self.cfg, "goal_idx", -2))

@@ -121,7 +121,7 @@ def goalset_cost(robot, P, scenes: DeviceScenes, traj_start, goals, n_remaining,
 
 
 def goalset_cost_layer(robot, P, scenes: DeviceScenes, traj_start, goals, n_remaining, dt, traj, layer_out, soften_fingers=False,
-                       layer_soften_fingers=False, out=None, active=None):
+                       layer_soften_fingers=False, out=None, active=None, goal_count=None):
     """goalset_cost (cost only) + fk_sdf(traj) in one launch (omgx_goalset_cost_layer).  traj [S,n,9] f64;
     layer_out = (potentials [S,n,10,P], grads [S,n,10,P,3], collides [S,n,10,P]) float32, written in place.
     active [S] int32 (optional): scenes with 0 are skipped, their outputs keep their previous contents."""
@@ -149,7 +149,8 @@ def goalset_cost_layer(robot, P, scenes: DeviceScenes, traj_start, goals, n_rema
         check(l.omgx_goalset_cost_layer(_ptr(robot), P, _ptr(scenes.objects), _ptr(scenes.scene_begin), _ptr(scenes.pool),
                                         _ptr(traj_start), ts_stride, _ptr(goals), S, G, n_remaining, float(dt),
                                         int(bool(soften_fingers)), _ptr(cost), _ptr(col), _ptr(ws), _ptr(traj), n,
-                                        int(bool(layer_soften_fingers)), _ptr(lp), _ptr(lg), _ptr(lc), _ptr(_active(active, S)), _stream()),
+                                        int(bool(layer_soften_fingers)), _ptr(lp), _ptr(lg), _ptr(lc), _ptr(_active(active, S)),
+                                        _ptr(_active(goal_count, S)), _stream()),
               "omgx_goalset_cost_layer")
     return cost, col
 
@@ -191,13 +192,25 @@ def chomp_optimize(robot, params: ChompParams, traj, start, end, goal, goal_poin
     return grad, cost_traj, info
 
 
-def learner_state(S: int, G: int, device) -> torch.Tensor:
+def learner_state(S: int, G: int, device, goal_count=None) -> torch.Tensor:
     """Initial Learner state [S, 7G+10] f64: sum_costs 0 | p 1/G | experts_p 1/G | q 1/5 | experts_costs 0
-    (Learner.__init__, omg/online_learner.py:66-95)."""
+    (Learner.__init__, omg/online_learner.py:66-95).  goal_count [S] (ragged goal sets padded to G): scene s holds
+    1 / goal_count[s] in its first goal_count[s] entries and 0 in the padding."""
     st = torch.zeros((S, 7 * G + 10), dtype=torch.float64, device=device)
-    st[:, G:7 * G] = 1.0 / G
+    if goal_count is None:
+        st[:, G:7 * G] = 1.0 / G
+    else:
+        cnt = torch.as_tensor(np.asarray(goal_count), dtype=torch.float64, device=device).reshape(S, 1)
+        row = torch.where(torch.arange(G, device=device)[None, :] < cnt, 1.0 / cnt, torch.zeros((), dtype=torch.float64, device=device))
+        st[:, G:7 * G] = row.repeat(1, 6)
     st[:, 7 * G:7 * G + 5] = 0.2
     return st
+
+
+def _eta(eta, S):
+    if eta is not None and not (eta.is_cuda and eta.dtype == torch.float64 and eta.is_contiguous() and eta.numel() == S):
+        raise _lib.OmgHipError("eta must be a contiguous float64 device tensor [S]")
+    return eta
 
 
 def _active(active, S):
@@ -207,7 +220,7 @@ def _active(active, S):
 
 
 def goal_update(params: LearnerParams, traj, goal_set, reach, goal_cost, state, goal_idx, end, goal_rows, goal_point,
-                cost_vector=None, active=None):
+                cost_vector=None, active=None, goal_count=None, eta=None):
     """Learner.update_goal for S scenes in one launch (omgx_goal_update); all outputs are written in place.
     active [S] int32 (optional): scenes with 0 keep goal, outputs and state."""
     _need(traj, torch.float64, "traj")
@@ -218,12 +231,13 @@ def goal_update(params: LearnerParams, traj, goal_set, reach, goal_cost, state, 
     with torch.cuda.device(traj.device):
         check(_lib.lib().omgx_goal_update(C.byref(params), _ptr(traj), _ptr(goal_set), _ptr(reach), _ptr(goal_cost), _ptr(state),
                                           traj.shape[0], _ptr(goal_idx), _ptr(end), _ptr(goal_rows), _ptr(goal_point),
-                                          _ptr(cost_vector), _ptr(_active(active, traj.shape[0])), _stream()), "omgx_goal_update")
+                                          _ptr(cost_vector), _ptr(_active(active, traj.shape[0])),
+                                          _ptr(_active(goal_count, traj.shape[0])), _ptr(_eta(eta, traj.shape[0])), _stream()), "omgx_goal_update")
 
 
 def goal_update_optimize(lparams: LearnerParams, goal_set, reach, goal_cost, state, goal_idx, robot, params: ChompParams, traj,
                          start, end, goal, goal_point, pot, pgrad, col, active=None, out=None, aux=None, cost_vector=None,
-                         scene_flags=None, ticket=0, stop_on_terminate=False):
+                         scene_flags=None, ticket=0, stop_on_terminate=False, goal_count=None, eta=None):
     """goal_update followed by chomp_optimize in one launch (omgx_goal_update_optimize): same results as the two calls."""
     for n_, t in (("traj", traj), ("start", start), ("end", end), ("goal", goal), ("goal_point", goal_point),
                   ("goal_set", goal_set), ("state", state)):
@@ -247,7 +261,8 @@ def goal_update_optimize(lparams: LearnerParams, goal_set, reach, goal_cost, sta
                                                    _ptr(goal_idx), _ptr(cost_vector), _ptr(robot), C.byref(params), _ptr(traj),
                                                    _ptr(start), _ptr(end), _ptr(goal), _ptr(goal_point), _ptr(pot), _ptr(pgrad),
                                                    _ptr(col), _ptr(active), S, _ptr(grad), _ptr(cost_traj), _ptr(info), _ptr(aux),
-                                                   _ptr(scene_flags), int(ticket), int(bool(stop_on_terminate)), _stream()),
+                                                   _ptr(scene_flags), int(ticket), int(bool(stop_on_terminate)),
+                                                   _ptr(_active(goal_count, S)), _ptr(_eta(eta, S)), _stream()),
               "omgx_goal_update_optimize")
     return grad, cost_traj, info
 

@@ -1068,16 +1068,70 @@ def test_goalset_slots_follow_the_active_scenes(dev):
             assert bool((a[~on] == -7.0).all())
 
 
+@pytest.mark.parametrize("alg,standoff,mode", [("MD", False, "fused"), ("Exp", True, "fused"), ("FTL", False, "serial"), ("Proj", False, "fused")])
+def test_ragged_goal_sets_equal_single_scene_runs(dev, alg, standoff, mode, monkeypatch):
+    """Scenes with different numbers of goals in ONE batch (goal_counts; arrays padded to the largest, padding filled with
+    NaN so that any read of it would show): every scene's goal sequence, trajectory, info and learner state equal, bit for
+    bit, those of the same scene planned alone with its own goal set."""
+    from omg_planner_amd import robot as rb, scenes as sc
+    from omg_planner_amd.config import Config
+    from omg_planner_amd.engine import ChompEngine
+    import copy
+    monkeypatch.setenv("OMGX_ITERATION", mode)
+    counts = [3, 7, 1, 5, 7, 2]
+    S, G, n = len(counts), max(counts), 30
+    m = rb.PandaModel(seed=5)
+    scenes, batch = _multi_scene_batch(S)
+    goals = np.stack([sc.make_reach_goals(scenes[s], m, G, 10 + s) for s in range(S)])
+    start = np.tile(rb.HOME_CONFIG, (S, 1))
+    cfg = Config(use_standoff=standoff)
+    cfg.optim_steps = 5
+    cfg.extra_smooth_steps = 2
+    cfg.get_global_param(n)
+    c = cfg.reach_tail_length
+    reach = np.stack([[np.concatenate([sc.linear_init(g - np.array([0.1, -0.05, 0.1, 0.15, 0, -0.1, 0.1, 0, 0]), g, c - 1), g[None]], 0)
+                       for g in goals[s]] for s in range(S)]) if standoff else None
+    padded, padded_reach = goals.copy(), None if reach is None else reach.copy()
+    for s, k in enumerate(counts):
+        padded[s, k:] = np.nan
+        if padded_reach is not None:
+            padded_reach[s, k:] = np.nan
+    eng = ChompEngine(m, batch, copy.deepcopy(cfg), start, padded, reach_grasps=padded_reach, device=dev, ol_alg=alg, goal_counts=counts)
+    eng.select_initial_goal()
+    singles = []
+    for s, k in enumerate(counts):
+        e1 = ChompEngine(m, batch.subset(s, s + 1), copy.deepcopy(cfg), start[s:s + 1], goals[s:s + 1, :k],
+                         reach_grasps=None if reach is None else reach[s:s + 1, :k], device=dev, ol_alg=alg)
+        e1.select_initial_goal()
+        singles.append(e1)
+    def same(a, b):  # bit-equal, NaN == NaN (a single-goal scene normalises its cost vector to 0/0 in the reference too)
+        return bool(((a == b) | (torch.isnan(a) & torch.isnan(b))).all())
+
+    for t in range(cfg.optim_steps + cfg.extra_smooth_steps):
+        eng.iterate(t)
+        for e1 in singles:
+            e1.iterate(t)
+        for s, (k, e1) in enumerate(zip(counts, singles)):
+            assert int(eng.goal_idx[s]) == int(e1.goal_idx[0]) < k, (t, s)
+            assert torch.equal(eng.traj[s], e1.traj[0]) and torch.equal(eng.info[s], e1.info[0]), (t, s)
+            st, s1 = eng.learner_state[s], e1.learner_state[0]
+            for blk in range(7):  # sum_costs | p | 5 x experts_p, padded stride G vs the single run's stride k
+                assert same(st[blk * G: blk * G + k], s1[blk * k: (blk + 1) * k]), (t, s, blk)
+            assert same(st[7 * G:], s1[7 * k:])
+            assert torch.equal(eng.goal_cost[s, :k], e1.goal_cost[0]) or alg == "Proj"
+    assert not torch.isnan(eng.info).any() and not torch.isnan(eng.traj).any()
+
+
 def test_two_launch_entry_points_reject_bad_arguments(dev, monkeypatch):
     """omgx_goalset_cost_layer / omgx_goal_update_optimize: error codes, never a crash; odd sizes (1 scene, 1 goal, window
     shorter than the trajectory) agree with the separate entry points."""
     from omg_planner_amd import _lib, ops, robot as rb, scenes as sc
     import ctypes as C
     l = _lib.lib()
-    rc = l.omgx_goalset_cost_layer(None, 15, None, None, None, None, 9, None, 1, 1, 5, 0.1, 0, None, None, None, None, 5, 0, None, None, None, None, None)
+    rc = l.omgx_goalset_cost_layer(None, 15, None, None, None, None, 9, None, 1, 1, 5, 0.1, 0, None, None, None, None, 5, 0, None, None, None, None, None, None)
     assert rc == _lib.OMGX_ERR_INVALID
     lp, cp = _lib.LearnerParams(), _lib.ChompParams()
-    rc = l.omgx_goal_update_optimize(C.byref(lp), *([None] * 6), None, C.byref(cp), *([None] * 9), 3, *([None] * 4), None, 0, 0, None)
+    rc = l.omgx_goal_update_optimize(C.byref(lp), *([None] * 6), None, C.byref(cp), *([None] * 9), 3, *([None] * 4), None, 0, 0, None, None, None)
     assert rc == _lib.OMGX_ERR_INVALID
     # one scene, one goal, 7-waypoint window on a 12-waypoint trajectory
     m = rb.PandaModel(seed=2)
