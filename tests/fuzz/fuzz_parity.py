@@ -79,9 +79,27 @@ def one_trial(rng, trial, dev, dry=False):
     if dry:  # only advance the random stream (to reach a later trial quickly)
         return None, 0.0
     import copy
-    eng = ChompEngine(m, batch, copy.deepcopy(cfg), start, goals, reach_grasps=reach, device=dev, ol_alg=alg)
+    # ragged goal sets (a separate random stream: the trials of a given seed stay what they were): scene s keeps its first
+    # counts[s] goals, the engine gets the arrays padded with NaN, the oracle runs every scene's learner on its own goals
+    r2 = np.random.RandomState(7919 * trial + 13)
+    counts = None
+    if G > 1 and r2.rand() < 0.3:
+        counts = r2.randint(1, G + 1, S)
+        counts[r2.randint(0, S)] = G
+        STATS["ragged"] = STATS.get("ragged", 0) + 1
+    e_goals, e_reach = goals, reach
+    if counts is not None:
+        e_goals = goals.copy()
+        e_reach = None if reach is None else reach.copy()
+        for s_ in range(S):
+            e_goals[s_, counts[s_]:] = np.nan
+            if e_reach is not None:
+                e_reach[s_, counts[s_]:] = np.nan
+    eng = ChompEngine(m, batch, copy.deepcopy(cfg), start, e_goals, reach_grasps=e_reach, device=dev, ol_alg=alg,
+                      goal_counts=None if counts is None else counts)
     traj = eng.traj.cpu().numpy().copy()
     state = orc.learner_state_init(S, G)
+    states_r = None if counts is None else [orc.learner_state_init(1, int(k_)) for k_ in counts]
     cv_goals = reach[:, :, -1, :] if standoff else goals
     end, rows, gp = eng.end.cpu().numpy().copy(), eng.goal_rows.cpu().numpy().copy(), eng.goal_point.cpu().numpy().copy()
     blob = m.blob()
@@ -107,7 +125,25 @@ def one_trial(rng, trial, dev, dry=False):
             if alg != "Proj":
                 gc, _ = orc.goalset_cost(blob, P, batch, traj[:, lp.start_idx], cv_goals, n - lp.start_idx, cfg.time_interval)
             keep = (idx, end.copy(), rows.copy(), gp.copy(), state.copy()) if idx is not None else None
-            idx_n, end_n, rows_n, gp_n, _ = orc.goal_update(lp, traj, goals, reach, gc, state)
+            keep_r = None if counts is None else [x.copy() for x in states_r]
+            if counts is None:
+                idx_n, end_n, rows_n, gp_n, _ = orc.goal_update(lp, traj, goals, reach, gc, state)
+            else:
+                outs = []
+                for s_ in range(S):
+                    k_ = int(counts[s_])
+                    lps = orc.LearnerParams()
+                    for f_, _t in lps._fields_:
+                        setattr(lps, f_, getattr(lp, f_))
+                    lps.num_goals, lps.eta = k_, float(np.sqrt(np.log(k_ + 1) / cfg.optim_steps))
+                    gcs = np.zeros((1, k_), np.float32)
+                    if alg != "Proj":
+                        gcs, _ = orc.goalset_cost(blob, P, batch.subset(s_, s_ + 1), traj[s_:s_ + 1, lp.start_idx], cv_goals[s_:s_ + 1, :k_],
+                                                  n - lp.start_idx, cfg.time_interval)
+                    outs.append(orc.goal_update(lps, traj[s_:s_ + 1], goals[s_:s_ + 1, :k_], None if reach is None else reach[s_:s_ + 1, :k_],
+                                                gcs, states_r[s_]))
+                idx_n = np.concatenate([o[0] for o in outs]); end_n = np.concatenate([o[1] for o in outs])
+                rows_n = np.concatenate([o[2] for o in outs]); gp_n = np.concatenate([o[3] for o in outs])
             if keep is None:
                 idx, end, rows, gp = idx_n, end_n, rows_n, gp_n
             else:  # planner.py:626: a terminated scene has left the loop — goal, goal rows and learner state stay
@@ -115,6 +151,9 @@ def one_trial(rng, trial, dev, dry=False):
                 idx = np.where(on, idx_n, keep[0])
                 end, rows, gp = (np.where(on.reshape((-1,) + (1,) * (x.ndim - 1)), x, k) for x, k in ((end_n, keep[1]), (rows_n, keep[2]), (gp_n, keep[3])))
                 state[~on] = keep[4][~on]
+                if counts is not None:
+                    for s_ in np.flatnonzero(~on):
+                        states_r[s_][:] = keep_r[s_]
         po = orc.ChompParams()
         src = eng._params(True)
         for f, _ in po._fields_:
@@ -136,7 +175,9 @@ def one_trial(rng, trial, dev, dry=False):
             print(f"      t={t}: traj diff {d:.3e}; info diff per scene {np.abs(gi_[:, :10] - oi_[:, :10]).max(1)}; cost {oi_[:, 0]}; collide {gi_[:, 8]} vs {oi_[:, 8]}", flush=True)
         # free-running: last-bit differences of the float64 kinematics flip a float32 point now and then and the loop feeds
         # them back; 1e-6 holds for ~10 iterations, the bar of the task (north_star) is 1e-4
-        if not d <= (1e-6 if t < 10 else 1e-5):
+        # ... and 1e-4 beyond: twice in 5 500 trials a 64-waypoint scene with an oscillating collision count amplified round-off by
+        # 4-100 x per iteration (1.4e-5 at iteration 13; the device against itself under a 1e-13 perturbation: 1e-3)
+        if not d <= (1e-6 if t < 10 else 1e-4):
             return f"trajectory differs by {d:.3e} at iteration {t}", worst
         gi, oi = eng.info.cpu().numpy()[:, :10], info[:, :10]
         # the same allowance for the costs of a free-running loop: a scene whose update is unstable amplifies round-off by
@@ -166,7 +207,8 @@ def main(trials=None, seed=None):
         else:
             print(f"trial {k}: ok, max |traj - oracle| {worst:.2e}", flush=True)
     print(f"{trials - bad}/{trials} trials agree; worst trajectory difference {worst_all:.2e}; joint-limit projection steps "
-          f"{STATS['limit_steps']}, limit-violation flags {STATS['violations']}, scene-iterations skipped after termination {STATS['stopped']}; {time.time() - t0:.0f} s")
+          f"{STATS['limit_steps']}, limit-violation flags {STATS['violations']}, scene-iterations skipped after termination {STATS['stopped']}, "
+          f"{STATS.get('ragged', 0)} trials with ragged goal sets; {time.time() - t0:.0f} s")
     return 1 if bad else 0
 
 
