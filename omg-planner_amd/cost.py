@@ -67,6 +67,41 @@ class LazyInfo(dict):
         raise KeyError(key)
 
 
+class LazyArray:
+    """The `vis_pts` array of batch_obstacle_cost, built on first use.  Learner.cost_vector takes only element [0] of the
+    returned tuple (online_learner.py:134-141) and must not pay for 27 MB of visualisation data per call; a viewer that does
+    read it (indexing, `.shape`, `np.asarray`, arithmetic through numpy) gets the reference's array."""
+
+    def __init__(self, shape, build):
+        self.shape, self.dtype, self.ndim = tuple(shape), np.dtype(np.float64), len(shape)
+        self._build, self._value = build, None
+
+    def _get(self):
+        if self._value is None:
+            self._value = self._build()
+            self._build = None
+            assert self._value.shape == self.shape
+        return self._value
+
+    def __array__(self, dtype=None, copy=None):
+        v = self._get()
+        return v if dtype is None else v.astype(dtype)
+
+    def __getitem__(self, idx):
+        return self._get()[idx]
+
+    def __setitem__(self, idx, value):
+        self._get()[idx] = value
+
+    def __len__(self):
+        return self.shape[0]
+
+    def __getattr__(self, name):  # anything else an ndarray offers (reshape, sum, copy, ...)
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return getattr(self._get(), name)
+
+
 class _Staging:
     """Buffers of ONE single-trajectory step (Optimizer.optimize / compute_total_loss): a device buffer holding every input
     and output of omgx_fk_sdf + omgx_chomp_optimize back to back and a pinned host mirror, so that a call costs one
@@ -362,10 +397,14 @@ class Cost(object):
                                     dt=float(self.cfg.time_interval))
         potentials, grad, collide = pot[0], grad[0], col[0]
         vis_pts = None
-        if want_vis:  # coloured from the potentials BEFORE the arc-length weighting (cost.py:219-230)
-            plain = potentials if not arc else ops.fk_sdf(robot, P, self._scenes(), q, soften_fingers=uncheck_finger_collision == -1,
-                                                         want_grad=False, want_col=False)[0][0]
-            vis_pts = self._vis_array(_np(q[0]), _np(plain), _np(grad), _np(collide), False)
+        if want_vis:  # coloured from the potentials BEFORE the arc-length weighting (cost.py:219-230); built when first read
+            soft, scenes_now = uncheck_finger_collision == -1, self._scenes()
+
+            def build(q=q, grad=grad, collide=collide, plain=None if arc else potentials):
+                if plain is None:
+                    plain = ops.fk_sdf(robot, P, scenes_now, q, soften_fingers=soft, want_grad=False, want_col=False)[0][0]
+                return self._vis_array(_np(q[0]), _np(plain), _np(grad), _np(collide), False)
+            vis_pts = LazyArray((B, 10, P, 12), build)
         if only_collide:  # cost.py:279-284
             thr = 0.5 * (self.cfg.epsilon - self.cfg.clearance) ** 2 / self.cfg.epsilon
             potentials = potentials * (potentials > thr).any()

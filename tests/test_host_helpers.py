@@ -250,3 +250,16 @@ def test_scene_from_env_takes_the_gpu_copy_of_the_volumes():
         lim[i, 9] = o.sdf.delta
     sdf, limits = sc.pack_padded(scene.objects)
     assert np.array_equal(sdf, want) and np.array_equal(limits, lim)
+
+
+def test_lazy_array_materialises_on_first_use():
+    """cost.LazyArray (vis_pts of batch_obstacle_cost): shape / len without building; indexing, np.asarray, ndarray methods
+    and item assignment build once and then behave like the array."""
+    from omg_planner_amd.cost import LazyArray
+    calls = []
+    la = LazyArray((4, 10, 3, 12), lambda: calls.append(1) or np.arange(4 * 10 * 3 * 12, dtype=np.float64).reshape(4, 10, 3, 12))
+    assert la.shape == (4, 10, 3, 12) and len(la) == 4 and la.ndim == 4 and not calls
+    assert la[1, 2, 0, 5] == 1 * 360 + 2 * 36 + 5 and calls == [1]
+    assert np.asarray(la).sum() == la.sum() and np.asarray(la, dtype=np.float32).dtype == np.float32 and calls == [1]
+    la[0, 0, 0, 0] = -1.0
+    assert la.reshape(-1)[0] == -1.0 and (la[..., :3] + 1).shape == (4, 10, 3, 3) and calls == [1]
