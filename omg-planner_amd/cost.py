@@ -464,7 +464,8 @@ class Cost(object):
         a, pot = st.h("aux")[0].copy(), st.h("pot")[0].copy()
         n = pot.shape[0]
         collide_sum = np.float32(st.h("info")[0, 8])
-        vis_pts = self._vis_array(xi, pot, st.h("pgrad")[0].copy(), st.h("col")[0].copy(), True)  # (launches: after the reads above)
+        build = self._collision_pts_builder(xi, st)  # copies of this call's layer outputs; the array is built when first read
+        vis_pts = LazyArray((n, 10, pot.shape[-1], 12), build)
         return a[n * 9: n * 19].reshape(n, 10), a[: n * 9].reshape(n, 9), vis_pts, collide_sum
 
     def compute_smooth_loss(self, xi, start, end):
