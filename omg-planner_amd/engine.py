@@ -336,6 +336,8 @@ class ChompEngine:
             else:
                 gi = int(getattr(self.cfg, "goal_idx", -2))
                 self.goal_idx.fill_(gi if 0 <= gi < self.G else 0)
+                if self.goal_count is not None:  # a scene with fewer goals than cfg.goal_idx falls back to goal 0, never to padding
+                    self.goal_idx.copy_(torch.where(self.goal_idx < self.goal_count, self.goal_idx, torch.zeros_like(self.goal_idx)))
             self._gather_goal()
             tt = (torch.arange(1, self.n + 1, device=self.device, dtype=torch.float64) / (self.n + 1.0))[None, :, None]
             h = 3.0 * tt * tt - 2.0 * tt * tt * tt
