@@ -366,8 +366,9 @@ int omgx_point_cloud_sdf(const double* points, int32_t num_points, const double*
  * Diagnostics
  * ------------------------------------------------------------------------------------------- */
 const char* omgx_last_error(void); /* thread-local text of the last OMGX_ERR_LAUNCH               */
-/* Measurement hook (bench.py): while enabled, every launch of the SDF kernel behind omgx_fk_sdf /
- * omgx_goalset_cost is bracketed by HIP events on its own stream.  omgx_timing_collect waits for them,
+/* Measurement hook (bench.py): while enabled (on = 1: every launch; on = N > 1: every N-th launch — an event pair costs
+ * about 6 us of stream time), launches of the SDF kernel behind omgx_fk_sdf / omgx_goalset_cost are bracketed by HIP
+ * events on their own stream.  omgx_timing_collect waits for them,
  * writes the per-launch durations (ms) to h_ms[0..cap) and the variant to h_kind (0 = potentials only, i.e. the
  * goal-set batch; 1 = with gradients, i.e. the waypoint batch; may be NULL) and returns how many;
  * not for graph capture.

@@ -689,6 +689,7 @@ extern "C" const char* omgx_last_error(void) { return g_err; }
 // bench.py enables it around its timed region; events are recorded on the launch stream.
 #define OMGX_TIMING_CAP 4096
 static bool g_timing = false;
+static int g_timing_stride = 1, g_timing_seen = 0;  // every g_timing_stride-th eligible launch is bracketed
 static int g_timing_n = 0;
 static hipEvent_t g_ev[OMGX_TIMING_CAP][2];
 static bool g_ev_made[OMGX_TIMING_CAP];
@@ -696,6 +697,8 @@ static int g_ev_kind[OMGX_TIMING_CAP];  // 0 = potentials-only variant (goal-set
 
 extern "C" int omgx_timing_enable(int32_t on) {
     g_timing = on != 0;
+    g_timing_stride = on > 1 ? on : 1;
+    g_timing_seen = 0;
     g_timing_n = 0;
     return OMGX_OK;
 }
@@ -716,6 +719,7 @@ extern "C" int omgx_timing_collect(float* h_ms, int32_t* h_kind, int32_t cap) {
 
 static inline int timing_slot() {
     if (!g_timing || g_timing_n >= OMGX_TIMING_CAP) return -1;
+    if (g_timing_seen++ % g_timing_stride != 0) return -1;  // sampled: an event pair costs ~6 us of stream time per launch
     const int i = g_timing_n;
     if (!g_ev_made[i]) {
         if (hipEventCreate(&g_ev[i][0]) != hipSuccess || hipEventCreate(&g_ev[i][1]) != hipSuccess) return -1;
