@@ -308,31 +308,40 @@ __device__ __forceinline__ Accum sdf_point(const omgx_object* __restrict__ objs,
 //   D+246+30P AX [10][3]    tip2joint[l][:3,:3] . joint_axis[l]                  (:190-197)
 //   D+276+30P OG [10][3]    tip2joint[l][:3,3]
 //   D+306+30P RAD [10]      bounding-sphere radius of each link's centred points
-struct RobotView {
+// DPtr = pointer type of the derived constants: plain global memory, a copy elsewhere (LDS), or the CONSTANT address space —
+// then wave-uniform reads (the chain constants of joint i, the hand / finger rows, radii) become scalar loads into SGPRs
+// instead of per-lane vector loads of the same address (measured in k_goalset_compact's kinematics: the vector loads and
+// their spills were 20 of a goal workgroup's 69 us).  pts() is indexed per lane and always comes from global memory.
+template <class DPtr>
+struct RobotViewT {
     const double* __restrict__ raw;
-    const double* __restrict__ d;
+    DPtr d;
+    const double* __restrict__ g;  // derived constants in global memory (for pts)
     int P;
-    __device__ __forceinline__ RobotView(const double* blob, int P_) : raw(blob), d(blob + OMGX_ROBOT_POINTS + 30 * P_), P(P_) {}
+    __device__ __forceinline__ RobotViewT(const double* blob, int P_) : raw(blob), d((DPtr)(uintptr_t)(blob + OMGX_ROBOT_POINTS + 30 * P_)), g(blob + OMGX_ROBOT_POINTS + 30 * P_), P(P_) {}
     // the first 246 derived doubles (UVW, TP, H, LF, RF: all the kinematic chain needs) from a copy elsewhere, e.g. LDS
-    __device__ __forceinline__ RobotView(const double* blob, int P_, const double* chain_constants) : raw(blob), d(chain_constants), P(P_) {}
-    __device__ __forceinline__ const double* uvw(int i) const { return d + 27 * i; }
-    __device__ __forceinline__ const double* tp(int i) const { return d + 189 + 3 * i; }
-    __device__ __forceinline__ const double* hand() const { return d + 210; }
-    __device__ __forceinline__ const double* lf() const { return d + 222; }
-    __device__ __forceinline__ const double* rf() const { return d + 234; }
-    __device__ __forceinline__ const double* pts(int l, int p) const { return d + 246 + 3 * (l * P + p); }
-    __device__ __forceinline__ const double* ax(int l) const { return d + 246 + 30 * P + 3 * l; }
-    __device__ __forceinline__ const double* og(int l) const { return d + 276 + 30 * P + 3 * l; }
+    __device__ __forceinline__ RobotViewT(const double* blob, int P_, DPtr chain_constants) : raw(blob), d(chain_constants), g(blob + OMGX_ROBOT_POINTS + 30 * P_), P(P_) {}
+    __device__ __forceinline__ DPtr uvw(int i) const { return d + 27 * i; }
+    __device__ __forceinline__ DPtr tp(int i) const { return d + 189 + 3 * i; }
+    __device__ __forceinline__ DPtr hand() const { return d + 210; }
+    __device__ __forceinline__ DPtr lf() const { return d + 222; }
+    __device__ __forceinline__ DPtr rf() const { return d + 234; }
+    __device__ __forceinline__ const double* pts(int l, int p) const { return g + 246 + 3 * (l * P + p); }
+    __device__ __forceinline__ DPtr ax(int l) const { return d + 246 + 30 * P + 3 * l; }
+    __device__ __forceinline__ DPtr og(int l) const { return d + 276 + 30 * P + 3 * l; }
     __device__ __forceinline__ double radius(int l) const { return d[306 + 30 * P + l]; }
     __device__ __forceinline__ const double* lower() const { return raw + OMGX_ROBOT_LOWER; }
     __device__ __forceinline__ const double* upper() const { return raw + OMGX_ROBOT_UPPER; }
 };
+typedef RobotViewT<const double*> RobotView;                 // global memory or an LDS copy
+typedef RobotViewT<const OMG_CONST_AS double*> RobotViewS;   // scalar loads
 
 struct Pose { double R[9]; double t[3]; };  // link frame BEFORE center_offset (robot_pykdl output_pose)
 
 // The double-precision kinematics may fuse multiply-adds (the file is compiled with -ffp-contract=off
 // for the float32 SDF arithmetic only; FK parity is checked at 1e-12, not bitwise).
-__device__ __forceinline__ void pose_mul(const Pose& A, const double* __restrict__ B /*rows [3][4]*/, Pose& C) {
+template <class BP>
+__device__ __forceinline__ void pose_mul(const Pose& A, BP B /*rows [3][4]*/, Pose& C) {
 #pragma clang fp contract(fast)
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
@@ -347,8 +356,8 @@ __device__ __forceinline__ void pose_mul(const Pose& A, const double* __restrict
 __device__ __forceinline__ double deg_round_trip(double q) { return (q / M_PI * 180.0) / 180.0 * M_PI; }
 
 // Visits the 10 link poses of configuration q[9] (radians) in order; f(l, pose).
-template <class F>
-__device__ __forceinline__ void fk_chain(const RobotView& rv, const double* __restrict__ q, F&& f) {
+template <class RV, class F>
+__device__ __forceinline__ void fk_chain(const RV& rv, const double* __restrict__ q, F&& f) {
 #pragma clang fp contract(fast)
     Pose cur;
 #pragma unroll
@@ -357,8 +366,8 @@ __device__ __forceinline__ void fk_chain(const RobotView& rv, const double* __re
     for (int i = 0; i < 7; ++i) {
         double s, c;
         sincos(deg_round_trip(q[i]), &s, &c);
-        const double* uvw = rv.uvw(i);
-        const double* tp = rv.tp(i);
+        const auto uvw = rv.uvw(i);
+        const auto tp = rv.tp(i);
         double B[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) B[k] = c * uvw[k] + s * uvw[9 + k] + uvw[18 + k];
@@ -378,14 +387,14 @@ __device__ __forceinline__ void fk_chain(const RobotView& rv, const double* __re
     f(7, hand);
     {
         double Fm[12];
-        const double* L = rv.lf();
+        const auto L = rv.lf();
 #pragma unroll
         for (int k = 0; k < 12; ++k) Fm[k] = L[k];
         Fm[7] += deg_round_trip(q[7]);  // left_finger_pose[:, 1, 3] += joints[:, -2]
         Pose fp;
         pose_mul(hand, Fm, fp);
         f(8, fp);
-        const double* Rr = rv.rf();
+        const auto Rr = rv.rf();
 #pragma unroll
         for (int k = 0; k < 12; ++k) Fm[k] = Rr[k];
         Fm[7] -= deg_round_trip(q[8]);  // right_finger_pose[:, 1, 3] -= joints[:, -1]
@@ -402,16 +411,16 @@ __device__ __forceinline__ void fk_chain(const RobotView& rv, const double* __re
 // f(l, R_r0, R_r1, R_r2, t_r) receives row r of link l's pose (before center_offset, like fk_chain).
 __device__ __forceinline__ void fk_joint_sincos(double q, double& s, double& c) { sincos(deg_round_trip(q), &s, &c); }
 
-template <class F>
-__device__ __forceinline__ void fk_chain_row(const RobotView& rv, int r, const double* __restrict__ sc /* [7][2] sin, cos */,
+template <class RV, class F>
+__device__ __forceinline__ void fk_chain_row(const RV& rv, int r, const double* __restrict__ sc /* [7][2] sin, cos */,
                                              double q7, double q8, F&& f) {
 #pragma clang fp contract(fast)
     double a0 = r == 0 ? 1.0 : 0.0, a1 = r == 1 ? 1.0 : 0.0, a2 = r == 2 ? 1.0 : 0.0, at = 0.0;
 #pragma unroll 1  // unrolled, the 7 x 27 wave-uniform constants are hoisted into (spilled) SGPRs all at once
     for (int i = 0; i < 7; ++i) {
         const double s = sc[2 * i], c = sc[2 * i + 1];
-        const double* uvw = rv.uvw(i);
-        const double* tp = rv.tp(i);
+        const auto uvw = rv.uvw(i);
+        const auto tp = rv.tp(i);
         double B[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) B[k] = c * uvw[k] + s * uvw[9 + k] + uvw[18 + k];
@@ -423,14 +432,14 @@ __device__ __forceinline__ void fk_chain_row(const RobotView& rv, int r, const d
         f(i, a0, a1, a2, at);
     }
     // hand = link7 . pose_0[7]; fingers = hand . pose_0[8|9] with y -+ q (robot_pykdl.py:181-188)
-    const double* H = rv.hand();
+    const auto H = rv.hand();
     const double h0 = a0 * H[0] + a1 * H[4] + a2 * H[8], h1 = a0 * H[1] + a1 * H[5] + a2 * H[9], h2 = a0 * H[2] + a1 * H[6] + a2 * H[10];
     const double ht = a0 * H[3] + a1 * H[7] + a2 * H[11] + at;
     f(7, h0, h1, h2, ht);
-    const double* Lf = rv.lf();
+    const auto Lf = rv.lf();
     f(8, h0 * Lf[0] + h1 * Lf[4] + h2 * Lf[8], h0 * Lf[1] + h1 * Lf[5] + h2 * Lf[9], h0 * Lf[2] + h1 * Lf[6] + h2 * Lf[10],
       h0 * Lf[3] + h1 * (Lf[7] + deg_round_trip(q7)) + h2 * Lf[11] + ht);
-    const double* Rf = rv.rf();
+    const auto Rf = rv.rf();
     f(9, h0 * Rf[0] + h1 * Rf[4] + h2 * Rf[8], h0 * Rf[1] + h1 * Rf[5] + h2 * Rf[9], h0 * Rf[2] + h1 * Rf[6] + h2 * Rf[10],
       h0 * Rf[3] + h1 * (Rf[7] - deg_round_trip(q8)) + h2 * Rf[11] + ht);
 }

@@ -392,7 +392,7 @@ __global__ __launch_bounds__(TPB) void k_sdf_chunks(ChunkArgs a) {
 // k_sdf_chunks<true> (same sdf_pair calls on the same float32 points), FK as in the goal-set workgroups.
 __device__ __forceinline__ void waypoint_layer_block(const ChunkArgs& a, const int s, const int l_begin, const int l_end,
                                                      double* lds_pose, uint32_t* rowmask, const int o_begin, const int o_end,
-                                                     const RobotView& rv) {
+                                                     const RobotViewS& rv) {
     const int n = a.wp_n, P = a.P, PS = a.PS, MR = a.MR;
     const double* tr = a.wp_traj + (int64_t)s * n * 9;
     double* sc = reinterpret_cast<double*>(rowmask);  // [n][7][2], dead before the masks are written
@@ -470,6 +470,43 @@ __device__ __forceinline__ void waypoint_layer_block(const ChunkArgs& a, const i
     }
 }
 
+// Debug aid (make CXXFLAGS+=-DOMGX_GS_CLOCK): every goal workgroup's waves add the shader-clock cycles they spend in each
+// phase of k_goalset_compact to g_gs_clock (tools/gs_phase_clock.py reads it).  s_memtime drains lgkmcnt, so the figures
+// are an attribution, not a timing.
+#ifdef OMGX_GS_CLOCK
+__device__ unsigned long long g_gs_clock[16];
+__device__ unsigned long long g_gs_wg[1 << 16][8];  // per workgroup: realtime at start / after the prologue / at end (100 MHz), hardware id
+// the clock read carries a fake dependency on DEP_ (a value the phase produces) and a memory clobber, so that the compiler
+// cannot move the phase's arithmetic or LDS traffic across it
+#if OMGX_GS_CLOCK > 1  // phase clocks inside the loops: s_memtime is a memory operation (~1 us each) — it slows the kernel 12x, shares only
+#define GS_CLK_DECL unsigned int clk_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long clk_t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(clk_t) :: "memory")
+#define GS_CLK_DEP(i, DEP_) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : "v"(DEP_) : "memory"); clk_acc[i] += (unsigned int)(t_ - clk_t); clk_t = t_; } while (0)
+#define GS_CLK(i) GS_CLK_DEP(i, 0)
+#define GS_CLK_FLUSH do { if ((threadIdx.x & 63) == 0) { for (int i_ = 0; i_ < 12; ++i_) atomicAdd(&g_gs_clock[i_], (unsigned long long)clk_acc[i_]); atomicAdd(&g_gs_clock[15], 1ull); } } while (0)
+#else
+#define GS_CLK_DECL
+#define GS_CLK(i)
+#define GS_CLK_DEP(i, DEP_)
+#define GS_CLK_FLUSH
+#endif
+#define GS_WG_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < (1u << 16)) { g_gs_wg[blockIdx.x][k] = wall_clock64(); if (k == 0) { unsigned hw, xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); g_gs_wg[blockIdx.x][7] = ((unsigned long long)xcc << 32) | hw; } } } while (0)
+extern "C" int omgx_debug_gs_clock(unsigned long long* h_out16, int reset) {
+    if (h_out16 && hipMemcpyFromSymbol(h_out16, HIP_SYMBOL(g_gs_clock), sizeof(unsigned long long) * 16) != hipSuccess) return -2;
+    if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_gs_clock), z, sizeof z) != hipSuccess) return -2; }
+    return 0;
+}
+extern "C" int omgx_debug_gs_wg(unsigned long long* h_out, int n_wg) {
+    if (n_wg > (1 << 16)) n_wg = 1 << 16;
+    return hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_gs_wg), sizeof(unsigned long long) * 8 * n_wg) == hipSuccess ? 0 : -2;
+}
+#else
+#define GS_CLK_DECL
+#define GS_CLK(i)
+#define GS_CLK_DEP(i, DEP_)
+#define GS_CLK_FLUSH
+#define GS_WG_STAMP(k)
+#endif
+
 #define GS_LAYER_PARTS 5  // trajectory-layer workgroups per scene
 #ifndef GS_WG_PER_CU
 #define GS_WG_PER_CU 6  // 80 VGPRs; the LDS of a 30-waypoint goal (26.6 KB) allows no more
@@ -478,6 +515,7 @@ template <int LB>
 __global__ __launch_bounds__(256, GS_WG_PER_CU) void k_goalset_compact(ChunkArgs a) {
     extern __shared__ __attribute__((aligned(16))) double lds_pose[];
     __shared__ float red[2][4];
+    GS_WG_STAMP(0);
     const int xcd = blockIdx.x & 7;
     // with a trajectory layer, the first workgroup of every scene computes it; those (longer) workgroups lead the grid
     // (GS_LAYER_PARTS workgroups per scene, 10 / GS_LAYER_PARTS links each: a lone scene is not held up by one long workgroup)
@@ -515,17 +553,19 @@ __global__ __launch_bounds__(256, GS_WG_PER_CU) void k_goalset_compact(ChunkArgs
     const int P = a.P, CH = a.CH;
     const int nvalid = CH;
     const int p = threadIdx.x & 15, r = threadIdx.x >> 4, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const RobotView rv(a.robot, P);
+    const RobotViewS rv(a.robot, P);  // chain constants and radii through scalar loads
     const int pstride = a.PS, MR = a.MR;
     uint32_t* rowmask = reinterpret_cast<uint32_t*>(lds_pose + (size_t)pstride * 90);  // poses: 9 doubles (see pose9_apply)
     float* scratch = reinterpret_cast<float*>(rowmask + ((10 * MR + 3) & ~3)) + wave * 192;  // wave-private [64][3]: 12 B entries keep 6 workgroups per CU inside 160 KB
     if (is_layer) {
         waypoint_layer_block(a, s, layer_part * (10 / GS_LAYER_PARTS), (layer_part + 1) * (10 / GS_LAYER_PARTS), lds_pose, rowmask, o_begin,
                              o_end, rv);
+        GS_WG_STAMP(4);
         return;
     }
 
     if (a.goal_count && chunk >= as_const(a.goal_count)[s]) return;  // padding of a ragged goal set
+    GS_CLK_DECL;
     {   // FK of start + CH interpolated configurations in two stages (omg_device.h: fk_chain_row); the (sin, cos)
         // table borrows the row-mask / scratch region, which is first written after the barriers below.
         const double* q0 = a.traj_start + a.ts_stride * (int64_t)s;
@@ -542,6 +582,7 @@ __global__ __launch_bounds__(256, GS_WG_PER_CU) void k_goalset_compact(ChunkArgs
             sc[2 * t] = sn; sc[2 * t + 1] = cs;
         }
         __syncthreads();
+        GS_WG_STAMP(1);
         for (int t = threadIdx.x; t < ncfg * 3; t += 256) {
             const int cfg = t / 3, r = t - cfg * 3;
             fk_chain_row(rv, r, sc + 14 * cfg, joint(cfg, 7), joint(cfg, 8), [&](int l, double r0, double r1, double r2, double tr) {
@@ -552,6 +593,8 @@ __global__ __launch_bounds__(256, GS_WG_PER_CU) void k_goalset_compact(ChunkArgs
         }
     }
     __syncthreads();
+    GS_CLK(0);
+    GS_WG_STAMP(2);
     const double* base = lds_pose + 9;
 
     for (int row = threadIdx.x; row < 10 * CH; row += 256) {  // phase A: row-level culling (see k_sdf_chunks)
@@ -576,6 +619,8 @@ __global__ __launch_bounds__(256, GS_WG_PER_CU) void k_goalset_compact(ChunkArgs
         rowmask[row] = m;
     }
     __syncthreads();
+    GS_CLK(1);
+    GS_WG_STAMP(3);
 
     float tsum = 0.0f, tcol = 0.0f;
     for (int ci0 = 0; ci0 < nvalid; ci0 += 16) {  // every lane stays active: invalid items are flagged, not skipped
@@ -594,10 +639,11 @@ __global__ __launch_bounds__(256, GS_WG_PER_CU) void k_goalset_compact(ChunkArgs
                 many |= msk[k];
                 acc[k] = Accum{0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
             }
-            if (!__any(many != 0)) continue;  // nothing in reach of any row of this wave: potentials stay 0
+            if (!__any(many != 0)) { GS_CLK(2); continue; }  // nothing in reach of any row of this wave: potentials stay 0
 #pragma unroll
             for (int k = 0; k < LB; ++k)
                 pose9_apply(base + ((int64_t)(l0 + k) * pstride + cic) * 9, rv.pts(l0 + k, pc), px[k], py[k], pz[k]);
+            GS_CLK_DEP(3, (px[0] + py[0]) + (pz[LB - 1] + px[LB - 1]));
             for (int o = o_begin; o < o_end; ++o) {
                 const int oo = o - o_begin;
                 const uint32_t bit = 1u << (oo < 31 ? oo : 31);
@@ -606,6 +652,7 @@ __global__ __launch_bounds__(256, GS_WG_PER_CU) void k_goalset_compact(ChunkArgs
                 if (ob->disabled > 0) continue;
                 const ObjParams op = load_object(ob);
                 const float* grid = a.pool + ob->grid_offset;
+                GS_CLK_DEP(4, (op.T[0] + op.i2eps) + (float)op.rw[2]);
                 PairPrep pp[LB];
                 int rank[LB];
                 int total = 0;
@@ -618,6 +665,7 @@ __global__ __launch_bounds__(256, GS_WG_PER_CU) void k_goalset_compact(ChunkArgs
                     rank[k] = live ? total + before : -1;
                     total += __popcll(bal);
                 }
+                GS_CLK_DEP(5, total + rank[0] + rank[LB - 1]);
                 for (int b0 = 0; b0 < total; b0 += 64) {  // wave-uniform
 #pragma unroll
                     for (int k = 0; k < LB; ++k)
@@ -625,12 +673,14 @@ __global__ __launch_bounds__(256, GS_WG_PER_CU) void k_goalset_compact(ChunkArgs
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    GS_CLK(6);
                     if (lane < total - b0) {
                         const float tx = scratch[3 * lane], ty = scratch[3 * lane + 1], tz = scratch[3 * lane + 2];
                         Accum one{0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
                         pair_exact<false>(op, grid, tx, ty, tz, one);
                         scratch[3 * lane] = one.pot; scratch[3 * lane + 1] = one.col;
                     }
+                    GS_CLK(7);
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -643,6 +693,7 @@ __global__ __launch_bounds__(256, GS_WG_PER_CU) void k_goalset_compact(ChunkArgs
                         }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
+                    GS_CLK(8);
                 }
             }
 #pragma unroll
@@ -659,6 +710,7 @@ __global__ __launch_bounds__(256, GS_WG_PER_CU) void k_goalset_compact(ChunkArgs
                 tsum += acc[k].pot;
                 tcol += acc[k].col;
             }
+            GS_CLK_DEP(9, tsum + tcol);
         }
     }
     // a.pot must also receive the zeros of batches skipped above
@@ -672,6 +724,9 @@ __global__ __launch_bounds__(256, GS_WG_PER_CU) void k_goalset_compact(ChunkArgs
             if (a.chunk_col) a.chunk_col[k] = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
         }
     }
+    GS_CLK(10);
+    GS_CLK_FLUSH;
+    GS_WG_STAMP(4);
 }
 
 // =================================================================================================

@@ -1,0 +1,93 @@
+"""Where the waves of the goal-set kernel spend their cycles (attribution of the `s_waitcnt` share).
+
+Needs the instrumented variant of the library (never the shipped one):
+    make -C omg-planner_amd/csrc BUILD=build_clk OUT=libomg_hip_clk.so EXTRA=-DOMGX_GS_CLOCK=1      (=2 adds in-loop phase clocks: 12x slower, shares only)
+Run on the GPU box:  python tools/gs_phase_clock.py [scenes] [goals]
+Every wave of a goal workgroup adds the shader-clock ticks between phase boundaries to a device array; s_memtime drains
+lgkmcnt at each boundary, so the split is an attribution (it perturbs the schedule), not a timing of the shipped kernel.
+"""
+import ctypes as C
+import json
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from omg_planner_amd import _lib  # noqa: E402
+
+_lib.LIB_PATH = ROOT / "omg-planner_amd" / "csrc" / "libomg_hip_clk.so"
+from omg_planner_amd.engine import ChompEngine  # noqa: E402
+
+PHASES = ["fk_prologue", "row_culling", "skipped_iterations", "masks+points(pose9_apply)", "object_record_s_load", "far_tests+ranks",
+          "compaction_write+wave_barrier", "exact_pass(loads+trilerp+hinge)", "read_back+wave_barriers", "arc_length+sums", "block_reduction"]
+
+
+def main():
+    S = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    G = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+    cfg, model, batch, start, goals = bench.build_workload(S, G, 30, 64, 0, False)
+    eng = ChompEngine(model, batch, cfg, start, goals, device="cuda:0", ol_alg="MD")
+    lib = _lib.lib()
+    lib.omgx_debug_gs_clock.argtypes = [C.c_void_p, C.c_int]
+    for _ in range(3):
+        eng.t = 0
+        eng.iterate(0)
+    torch.cuda.synchronize()
+    lib.omgx_debug_gs_clock(None, 1)
+    iters = 10
+    for _ in range(iters):
+        eng.t = 0
+        eng.iterate(0)
+    torch.cuda.synchronize()
+    buf = (C.c_ulonglong * 16)()
+    assert lib.omgx_debug_gs_clock(buf, 0) == 0
+    t = [int(x) for x in buf]
+    waves, total = t[15], sum(t[:11])
+    out = {"scenes": S, "goals": G, "launches": iters}
+    if waves:  # library built with -DOMGX_GS_CLOCK=2
+        out.update({"waves": waves, "ticks_per_wave": total / waves, "share": {PHASES[i]: round(t[i] / total, 4) for i in range(11)}})
+    # per-workgroup timeline of the LAST launch: 100 MHz realtime stamps at entry / after the prologue / at exit + hardware id
+    import numpy as np
+    nwg = ((S + 7) // 8) * (G + 5) * 8
+    wg = (C.c_ulonglong * (8 * nwg))()
+    lib.omgx_debug_gs_wg.argtypes = [C.c_void_p, C.c_int]
+    assert lib.omgx_debug_gs_wg(wg, nwg) == 0
+    w = np.array(list(wg), dtype=np.uint64).reshape(nwg, 8)
+    ran = w[:, 4] > 0
+    t0 = w[ran, 0].min()
+    st, t_sc, t_ch, pro, en = [(w[:, k].astype(np.int64) - int(t0)) / 100.0 for k in range(5)]  # microseconds
+    nlayer = ((S + 7) // 8) * 5 * 8
+    is_layer = np.arange(nwg) < nlayer
+    xcc = (w[:, 7] >> np.uint64(32)).astype(np.int64) & 0xF
+    hw = w[:, 7].astype(np.int64) & 0xFFFFFFFF
+    cu = (hw >> 8) & 0xF
+    se = (hw >> 13) & 0x7
+    dur = en - st
+    out["timeline_us"] = {
+        "kernel_span": float(en[ran].max()),
+        "last_start": float(st[ran].max()),
+        "goal_wg_duration_mean/p50/p90/max": [float(x) for x in (dur[ran & ~is_layer].mean(), np.percentile(dur[ran & ~is_layer], 50), np.percentile(dur[ran & ~is_layer], 90), dur[ran & ~is_layer].max())],
+        "goal_wg_prologue_mean": float((pro - st)[ran & ~is_layer].mean()),
+        "goal_wg_sincos/chain/rowcull_mean": [float(x[ran & ~is_layer].mean()) for x in (t_sc - st, t_ch - t_sc, pro - t_ch)],
+        "layer_wg_duration_mean/max": [float(dur[ran & is_layer].mean()), float(dur[ran & is_layer].max())],
+        "finish_per_xcc": {int(x): float(en[ran & (xcc == x)].max()) for x in np.unique(xcc[ran])},
+        "wgs_per_xcc": {int(x): int((ran & (xcc == x)).sum()) for x in np.unique(xcc[ran])},
+        "blockidx_mod8_equals_xcc": float((xcc[ran] == (np.arange(nwg)[ran] & 7)).mean()),
+    }
+    # resident workgroups over time (all CUs): fraction of the 1536 slots in use, in 10 slices of the span
+    span = en[ran].max()
+    edges = np.linspace(0, span, 11)
+    occ = []
+    for a, b in zip(edges[:-1], edges[1:]):
+        overlap = np.clip(np.minimum(en[ran], b) - np.maximum(st[ran], a), 0, None).sum() / (b - a)
+        occ.append(round(float(overlap) / 1536.0, 3))
+    out["timeline_us"]["slot_occupancy_by_tenth"] = occ
+    np.save(str(ROOT / "gpurun_out" / "gs_wg_timeline.npy"), w)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
