@@ -233,6 +233,11 @@ int omgx_goalset_cost(const double* robot, int32_t n_points,
  *           loop once it terminates (omg/planner.py:626) — and their outputs keep their previous contents.
  *   goal_count  optional [S] int32 (NULL = num_goals everywhere): scene s has only goal_count[s] goals, the rest of its
  *           rows in `goals` / `goal_cost` is padding that is neither read nor written (ragged goal sets in one batch).
+ *   schedule  optional [ceil(S/8)*8*num_goals] int32 (NULL = scene-major order): the k-th goal workgroup of the launch (it runs
+ *           on XCD k % 8) works on
+ *           goal schedule[k] % num_goals of scene schedule[k] / num_goals (< 0: none).  Any permutation gives the same
+ *           results; omgx_goalset_schedule derives one from `work` that starts the longest goals first (ABI 4).
+ *   work    optional [S*num_goals] uint32: receives how long each goal's workgroup ran, in 10 ns ticks (0 = skipped).
  * ------------------------------------------------------------------------------------------- */
 int omgx_goalset_cost_layer(const double* robot, int32_t n_points,
                             const omgx_object* objects, const int32_t* scene_begin, const float* sdf_pool,
@@ -242,7 +247,8 @@ int omgx_goalset_cost_layer(const double* robot, int32_t n_points,
                             float* goal_cost, float* collides, void* workspace,
                             const double* traj, int32_t n_waypoints, int32_t layer_soften_fingers,
                             float* layer_potentials, float* layer_grads, float* layer_collides,
-                            const int32_t* active, const int32_t* goal_count, void* stream);
+                            const int32_t* active, const int32_t* goal_count,
+                            const int32_t* schedule, uint32_t* work, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * (4) omgx_chomp_optimize

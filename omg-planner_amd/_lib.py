@@ -14,7 +14,7 @@ LIB_PATH = _CSRC / "libomg_hip.so"
 
 OMGX_OK, OMGX_ERR_INVALID, OMGX_ERR_LAUNCH, OMGX_ERR_UNSUPPORTED = 0, -1, -2, -3
 NUM_DOF, INFO_STRIDE = 9, 16
-ABI_VERSION = 3  # omgx_abi_version() of the library these argtypes describe
+ABI_VERSION = 4  # omgx_abi_version() of the library these argtypes describe
 
 # every symbol include/omg_hip.h declares
 EXPORTS = ["omgx_sdf_loss_forward", "omgx_fk_sdf_workspace_bytes", "omgx_fk_sdf", "omgx_forward_kinematics",
@@ -75,7 +75,7 @@ def lib() -> C.CDLL:
         l.omgx_goalset_workspace_bytes.argtypes = [i32, i32, i32, i32]
         l.omgx_goalset_workspace_bytes.restype = i64
         l.omgx_goalset_cost.argtypes = [vp, i32, vp, vp, vp, vp, i64, vp, i32, i32, i32, f64, i32, vp, vp, vp, vp, vp]
-        l.omgx_goalset_cost_layer.argtypes = [vp, i32, vp, vp, vp, vp, i64, vp, i32, i32, i32, f64, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp]
+        l.omgx_goalset_cost_layer.argtypes = [vp, i32, vp, vp, vp, vp, i64, vp, i32, i32, i32, f64, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
         l.omgx_goalset_cost_layer.restype = C.c_int
         l.omgx_chomp_optimize.argtypes = [vp, C.POINTER(ChompParams)] + [vp] * 9 + [i32] + [vp] * 4 + [i32, vp]
         l.omgx_learner_state_doubles.argtypes = [i32]

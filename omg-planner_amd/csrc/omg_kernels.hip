@@ -208,6 +208,12 @@ struct ChunkArgs {
     float* wp_grad;            // [S][wp_n][10][P][3]
     float* wp_col;             // [S][wp_n][10][P]
     int PS, MR;                // LDS pose stride (configurations per link) and mask rows per link: max over both kinds of workgroup
+    // dispatch order of the goal workgroups (k_goalset_compact only).  schedule[k] = scene * NCH + goal of the k-th goal
+    // workgroup in blockIdx order (< 0: nothing), normally the goals of the previous launch sorted by the time they took
+    // (longest first, omgx_goalset_schedule) so that the launch does not end on a few long workgroups.  work[scene * NCH +
+    // goal] receives the workgroup's duration in 10 ns ticks (0 for skipped goals).
+    const int32_t* schedule;
+    uint32_t* work;
 };
 
 // Thread layout: 256 threads = 16 rows x 16 lanes.  Lane = collision point p of a link (P <= 16), row =
@@ -511,7 +517,7 @@ extern "C" int omgx_debug_gs_wg(unsigned long long* h_out, int n_wg) {
 #ifndef GS_WG_PER_CU
 #define GS_WG_PER_CU 6  // 80 VGPRs; the LDS of a 30-waypoint goal (26.6 KB) allows no more
 #endif
-template <int LB>
+template <int LB, bool STAMP = false>  // STAMP: record every goal workgroup's duration in a.work (a separate instantiation: the two clock reads cost registers)
 __global__ __launch_bounds__(256, GS_WG_PER_CU) void k_goalset_compact(ChunkArgs a) {
     extern __shared__ __attribute__((aligned(16))) double lds_pose[];
     __shared__ float red[2][4];
@@ -525,9 +531,18 @@ __global__ __launch_bounds__(256, GS_WG_PER_CU) void k_goalset_compact(ChunkArgs
     const int sgrp = is_layer ? (int)(blockIdx.x >> 3) / GS_LAYER_PARTS : j / a.NCH;
     const int layer_part = (int)(blockIdx.x >> 3) - sgrp * GS_LAYER_PARTS;
     int s = sgrp * 8 + xcd;
-    const int chunk = is_layer ? 0 : j - sgrp * a.NCH;
+    int chunk = is_layer ? 0 : j - sgrp * a.NCH;
+    const bool scheduled = a.schedule && !is_layer;
+    if (scheduled) {  // workgroup b of the goal part works on item schedule[b]
+        const int b = (int)blockIdx.x - nlayer * 8;
+        const int item = as_const(a.schedule)[b];  // [((S + 7) / 8) * 8 * NCH] = the goal part of the grid
+        if (item < 0 || item >= a.S * a.NCH) return;
+        s = item / a.NCH;  // wave-uniform, once per workgroup
+        chunk = item - s * a.NCH;
+        if (a.active && as_const(a.active)[s] == 0) { if (STAMP && threadIdx.x == 0) a.work[item] = 0u; return; }
+    }
     if (s >= a.S) return;
-    if (a.active) {
+    if (a.active && !scheduled) {
         // Scenes the planner has left (planner.py:626) get no workgroups, and the remaining ones are dealt out again so that
         // every XCD keeps an equal share: slot k = sgrp * 8 + xcd works on the k-th ACTIVE scene (ascending).  Every wave
         // finds it by itself with ballots over the mask (S / 64 steps, wave-uniform): no barrier, no extra launch, same
@@ -564,7 +579,11 @@ __global__ __launch_bounds__(256, GS_WG_PER_CU) void k_goalset_compact(ChunkArgs
         return;
     }
 
-    if (a.goal_count && chunk >= as_const(a.goal_count)[s]) return;  // padding of a ragged goal set
+    if (a.goal_count && chunk >= as_const(a.goal_count)[s]) {  // padding of a ragged goal set
+        if (STAMP && threadIdx.x == 0) a.work[(int64_t)s * a.NCH + chunk] = 0u;
+        return;
+    }
+    const unsigned long long work_t0 = STAMP ? wall_clock64() : 0ull;  // s_memrealtime, 100 MHz
     GS_CLK_DECL;
     {   // FK of start + CH interpolated configurations in two stages (omg_device.h: fk_chain_row); the (sin, cos)
         // table borrows the row-mask / scratch region, which is first written after the barriers below.
@@ -722,6 +741,7 @@ __global__ __launch_bounds__(256, GS_WG_PER_CU) void k_goalset_compact(ChunkArgs
             const int64_t k = (int64_t)s * a.NCH + chunk;
             if (a.chunk_cost) a.chunk_cost[k] = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
             if (a.chunk_col) a.chunk_col[k] = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
+            if (STAMP) { const unsigned long long dt = wall_clock64() - work_t0; a.work[k] = dt < 1 ? 1u : (dt > 0xffffffffull ? 0xffffffffu : (uint32_t)dt); }
         }
     }
     GS_CLK(10);
@@ -782,7 +802,7 @@ static inline int timing_slot() {
     }
     return i;
 }
-extern "C" int omgx_abi_version(void) { return 3; }  // 2: `active` masks; 3: ragged goal sets (goal_count, eta)
+extern "C" int omgx_abi_version(void) { return 4; }  // 2: `active` masks; 3: ragged goal sets (goal_count, eta); 4: goal schedule + work
 extern "C" int omgx_device_arch(char* h_buf, int32_t h_len) {
     if (!h_buf || h_len <= 0) return OMGX_ERR_INVALID;
     int dev = 0;
@@ -922,9 +942,8 @@ static int launch_chunks(ChunkArgs& ca, hipStream_t st) {
         const size_t sincos = (size_t)ca.PS * 14 * sizeof(double);                                             // FK stage 1 table
         if (tail < sincos) tail = sincos;
         const size_t lds = (size_t)ca.PS * 90 * sizeof(double) + tail;
-        if (lb == 10) OMGX_LAUNCH((k_goalset_compact<10>), lds);
-        else if (lb == 2) OMGX_LAUNCH((k_goalset_compact<2>), lds);
-        else OMGX_LAUNCH((k_goalset_compact<5>), lds);
+        if (ca.work) OMGX_LAUNCH((k_goalset_compact<2, true>), lds);
+        else OMGX_LAUNCH((k_goalset_compact<2>), lds);
     } else if (ca.traj_start) {  // fused FK (goal-set batch): dynamic LDS holds (CH + 1) x 10 poses
         const size_t lds = (size_t)(ca.CH + 1) * 120 * sizeof(double) + mask_bytes;
         if (lbu == 1) OMGX_LAUNCH((k_sdf_chunks<false, 1, true>), lds);
@@ -1052,7 +1071,8 @@ static int goalset_cost_impl(const double* robot, int32_t n_points, const omgx_o
                              int32_t num_scenes, int32_t num_goals, int32_t n_remaining, double time_interval,
                              int32_t soften_fingers, float* goal_cost, float* potentials, float* collides, void* workspace,
                              const double* layer_traj, int32_t layer_n, int32_t layer_soften, float* layer_pot, float* layer_grad,
-                             float* layer_col, const int32_t* active, const int32_t* goal_count, void* stream) {
+                             float* layer_col, const int32_t* active, const int32_t* goal_count, const int32_t* schedule,
+                             uint32_t* work, void* stream) {
     if (num_scenes < 0 || num_goals < 0) return OMGX_ERR_INVALID;
     if (num_scenes == 0 || num_goals == 0) return OMGX_OK;
     if (!robot || !objects || !scene_begin || !traj_start || !goals || !goal_cost || !workspace) return OMGX_ERR_INVALID;
@@ -1089,8 +1109,8 @@ static int goalset_cost_impl(const double* robot, int32_t n_points, const omgx_o
         ca.wp_traj = layer_traj; ca.wp_n = layer_n; ca.wp_soften = layer_soften != 0;
         ca.wp_pot = layer_pot; ca.wp_grad = layer_grad; ca.wp_col = layer_col;
     }
-    if ((active || goal_count) && !(fused && compact && !potentials)) return OMGX_ERR_UNSUPPORTED;  // the masks live in k_goalset_compact
-    ca.active = active; ca.goal_count = goal_count;
+    if ((active || goal_count || schedule || work) && !(fused && compact && !potentials)) return OMGX_ERR_UNSUPPORTED;  // the masks live in k_goalset_compact
+    ca.active = active; ca.goal_count = goal_count; ca.schedule = schedule; ca.work = work;
     return launch_chunks(ca, st);
 }
 
@@ -1102,7 +1122,7 @@ extern "C" int omgx_goalset_cost(const double* robot, int32_t n_points, const om
                                  float* collides, void* workspace, void* stream) {
     return goalset_cost_impl(robot, n_points, objects, scene_begin, sdf_pool, traj_start, traj_start_stride, goals, num_scenes,
                              num_goals, n_remaining, time_interval, soften_fingers, goal_cost, potentials, collides, workspace,
-                             nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
+                             nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
 }
 
 extern "C" int omgx_goalset_cost_layer(const double* robot, int32_t n_points, const omgx_object* objects,
@@ -1111,9 +1131,11 @@ extern "C" int omgx_goalset_cost_layer(const double* robot, int32_t n_points, co
                                        int32_t n_remaining, double time_interval, int32_t soften_fingers, float* goal_cost,
                                        float* collides, void* workspace, const double* traj, int32_t n_waypoints,
                                        int32_t layer_soften_fingers, float* layer_potentials, float* layer_grads,
-                                       float* layer_collides, const int32_t* active, const int32_t* goal_count, void* stream) {
+                                       float* layer_collides, const int32_t* active, const int32_t* goal_count,
+                                       const int32_t* schedule, uint32_t* work, void* stream) {
     if (!traj) return OMGX_ERR_INVALID;
     return goalset_cost_impl(robot, n_points, objects, scene_begin, sdf_pool, traj_start, traj_start_stride, goals, num_scenes,
                              num_goals, n_remaining, time_interval, soften_fingers, goal_cost, nullptr, collides, workspace, traj,
-                             n_waypoints, layer_soften_fingers, layer_potentials, layer_grads, layer_collides, active, goal_count, stream);
+                             n_waypoints, layer_soften_fingers, layer_potentials, layer_grads, layer_collides, active, goal_count, schedule,
+                             work, stream);
 }

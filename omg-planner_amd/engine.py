@@ -119,6 +119,15 @@ class ChompEngine:
         self._ev_fork = torch.cuda.Event()
         self._ev_join = torch.cuda.Event()
         self._scene_flags = torch.zeros(S, dtype=torch.int32, device=dev)  # omgx_goal_update_optimize's rendezvous
+        # Dispatch order of the goal-set launch.  The first launch of a plan runs in scene-major order and records every goal
+        # workgroup's duration in `work`; build_schedule() turns that — on the device, no host sync — into the order of all
+        # later launches: scenes dealt to the 8 XCDs by weight (heaviest first, serpentine), each scene's goals longest first.
+        # A scene keeps all its workgroups on one XCD (its SDF volumes stay in that XCD's L2: without this affinity the
+        # launch takes 1.7x as long).  Results do not depend on the order.
+        self.work = torch.zeros(S * G, dtype=torch.int32, device=dev)
+        self.schedule = None
+        self.auto_schedule = True
+        self._gs_launches = 0
         self._ticket = 0
         self._num_cus = torch.cuda.get_device_properties(dev).multi_processor_count
         self._gather_goal()
@@ -209,10 +218,16 @@ class ChompEngine:
             n_rem = self.cfg.timesteps - prm.start_idx
             traj_start = self.traj[:, prm.start_idx]  # strided view into the trajectory tensor: no copy kernel
             if with_layer:  # the SDF layer of the current trajectories rides on the goal-set launch
+                # the second launch is the measuring one (the first runs on cold caches and would distort the weights)
+                self._gs_launches += 1
+                measure = self.auto_schedule and self.schedule is None and self._gs_launches >= 2
                 ops.goalset_cost_layer(self.robot, self.P, self.scenes, traj_start, self.cv_goals, n_rem, self.cfg.time_interval,
                                        self.traj, (self.pot, self.pgrad, self.col), soften_fingers=False,
                                        layer_soften_fingers=self.cfg.uncheck_finger_collision == -1,
-                                       out=(self.goal_cost, self.goal_col), active=self._mask(), goal_count=self.goal_count)
+                                       out=(self.goal_cost, self.goal_col), active=self._mask(), goal_count=self.goal_count,
+                                       schedule=self.schedule, work=self.work if measure else None)
+                if measure:
+                    self.schedule = self.build_schedule()
             else:
                 ops.goalset_cost(self.robot, self.P, self.scenes, traj_start, self.cv_goals, n_rem, self.cfg.time_interval,
                                  soften_fingers=False, out=(self.goal_cost, self.goal_col))
@@ -224,6 +239,29 @@ class ChompEngine:
                         self.end, self.goal_rows, self.goal_point, self.cost_vec, active=self._mask(),
                         goal_count=self.goal_count, eta=self.eta_s)
         return None
+
+    def build_schedule(self, active: "torch.Tensor | None" = None) -> torch.Tensor:
+        """Dispatch order for omgx_goalset_cost_layer from the durations in `work` (torch ops on the device, asynchronous).
+        Block b of the goal part runs on XCD b % 8: scene number k of the weight-sorted list goes to XCD x(k) (serpentine
+        0..7,7..0) as that XCD's j-th scene; its goals, longest first, occupy blocks ((j * G + i) * 8 + x)."""
+        S, G, dev = self.S, self.G, self.device
+        w = self.work.view(S, G).to(torch.int64)
+        tot = w.sum(1)
+        if active is not None:
+            tot = torch.where(active != 0, tot + 1, torch.zeros_like(tot))
+        order = torch.argsort(tot, descending=True, stable=True)
+        k = torch.arange(S, device=dev)
+        r = k % 16
+        x = torch.where(r < 8, r, 15 - r)
+        j = (k // 16) * 2 + (r >= 8).to(torch.int64)
+        gorder = torch.argsort(w[order], dim=1, descending=True, stable=True)  # [S,G] goal indices of scene order[k], longest first
+        blocks = (j[:, None] * G + torch.arange(G, device=dev)[None, :]) * 8 + x[:, None]
+        items = order[:, None] * G + gorder
+        if active is not None:
+            items = torch.where((active[order] != 0)[:, None], items, torch.full_like(items, -1))
+        sched = torch.full((((S + 7) // 8) * 8 * G,), -1, dtype=torch.int32, device=dev)
+        sched[blocks.reshape(-1)] = items.reshape(-1).to(torch.int32)
+        return sched
 
     def _layer(self):
         """SDF layer outputs of the current waypoints (first half of Cost.compute_total_loss)."""

@@ -121,7 +121,7 @@ def goalset_cost(robot, P, scenes: DeviceScenes, traj_start, goals, n_remaining,
 
 
 def goalset_cost_layer(robot, P, scenes: DeviceScenes, traj_start, goals, n_remaining, dt, traj, layer_out, soften_fingers=False,
-                       layer_soften_fingers=False, out=None, active=None, goal_count=None):
+                       layer_soften_fingers=False, out=None, active=None, goal_count=None, schedule=None, work=None):
     """goalset_cost (cost only) + fk_sdf(traj) in one launch (omgx_goalset_cost_layer).  traj [S,n,9] f64;
     layer_out = (potentials [S,n,10,P], grads [S,n,10,P,3], collides [S,n,10,P]) float32, written in place.
     active [S] int32 (optional): scenes with 0 are skipped, their outputs keep their previous contents."""
@@ -150,7 +150,8 @@ def goalset_cost_layer(robot, P, scenes: DeviceScenes, traj_start, goals, n_rema
                                         _ptr(traj_start), ts_stride, _ptr(goals), S, G, n_remaining, float(dt),
                                         int(bool(soften_fingers)), _ptr(cost), _ptr(col), _ptr(ws), _ptr(traj), n,
                                         int(bool(layer_soften_fingers)), _ptr(lp), _ptr(lg), _ptr(lc), _ptr(_active(active, S)),
-                                        _ptr(_active(goal_count, S)), _stream()),
+                                        _ptr(_active(goal_count, S)), _ptr(_i32n(schedule, ((S + 7) // 8) * 8 * G, "schedule")), _ptr(_i32n(work, S * G, "work")),
+                                        _stream()),
               "omgx_goalset_cost_layer")
     return cost, col
 
@@ -211,6 +212,13 @@ def _eta(eta, S):
     if eta is not None and not (eta.is_cuda and eta.dtype == torch.float64 and eta.is_contiguous() and eta.numel() == S):
         raise _lib.OmgHipError("eta must be a contiguous float64 device tensor [S]")
     return eta
+
+
+def _i32n(t, n, name):
+    """Optional contiguous 4-byte integer device tensor of n elements (int32 schedules, uint32-as-int32 work counters)."""
+    if t is not None and not (t.is_cuda and t.dtype == torch.int32 and t.is_contiguous() and t.numel() == n):
+        raise _lib.OmgHipError(f"{name} must be a contiguous int32 device tensor of {n} elements")
+    return t
 
 
 def _active(active, S):

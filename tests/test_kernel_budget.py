@@ -21,10 +21,10 @@ def test_goalset_kernel_register_and_spill_budget(tmp_path):
     subprocess.run([HIPCC, *flags, str(ROOT / "omg-planner_amd" / "csrc" / "omg_kernels.hip"), "-o", str(out)], check=True,
                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     text = out.read_text()
-    start = text.index("_Z17k_goalset_compactILi2EEv9ChunkArgs:")
+    start = text.index("_Z17k_goalset_compactILi2ELb0EEv9ChunkArgs:")
     block = text[start: text.index("; Occupancy:", start) + 40]
     vgprs = int(re.search(r"; NumVgprs: (\d+)", block).group(1))
     scratch = int(re.search(r"; ScratchSize: (\d+)", block).group(1))
     occupancy = int(re.search(r"; Occupancy: (\d+)", block).group(1))
     assert vgprs <= 80 and occupancy >= 6, (vgprs, occupancy)
-    assert scratch <= 144, f"k_goalset_compact<2> spills {scratch} bytes per lane (budget 144): check the main loop's speed on the GPU"
+    assert scratch <= 32, f"k_goalset_compact<2> spills {scratch} bytes per lane (budget 32): check the main loop's speed on the GPU"
