@@ -211,7 +211,10 @@ int omgx_forward_kinematics(const double* robot, int32_t n_points, const double*
  *   potentials [S,G,n_remaining,10,P] float32 out, optional (NULL to skip) — the weighted
  *              potentials batch_obstacle_cost returns
  *   collides   [S,G] float32 out, optional: number of (config, link, point, object) collisions
- *   workspace  device scratch of omgx_goalset_workspace_bytes(S, G, n_remaining, P) bytes
+ *   workspace  device scratch of omgx_goalset_workspace_bytes(S, G, n_remaining, P) bytes (may be NULL since ABI 4: every
+ *              workgroup keeps its link poses in LDS; the argument stays for callers written against earlier versions)
+ *   active, goal_count  optional [S] int32 (ABI 4), as in omgx_goalset_cost_layer below: scenes with active[s] == 0 and goals
+ *              >= goal_count[s] are neither read nor written.  Only without `potentials` (else OMGX_ERR_UNSUPPORTED).
  * ------------------------------------------------------------------------------------------- */
 int64_t omgx_goalset_workspace_bytes(int32_t num_scenes, int32_t num_goals, int32_t n_remaining, int32_t n_points);
 int omgx_goalset_cost(const double* robot, int32_t n_points,
@@ -219,7 +222,8 @@ int omgx_goalset_cost(const double* robot, int32_t n_points,
                       const double* traj_start, int64_t traj_start_stride, const double* goals,
                       int32_t num_scenes, int32_t num_goals, int32_t n_remaining,
                       double time_interval, int32_t soften_fingers,
-                      float* goal_cost, float* potentials, float* collides, void* workspace, void* stream);
+                      float* goal_cost, float* potentials, float* collides, void* workspace,
+                      const int32_t* active, const int32_t* goal_count, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * (3b) omgx_goalset_cost_layer

@@ -1,0 +1,394 @@
+// omg_goalset_queue.h — k_goalset_queue: the goal-set batch (Learner.cost_vector's Cost.batch_obstacle_cost with arc length,
+// omg/online_learner.py:104-160, omg/cost.py:192-286) with a per-wave QUEUE of exact-path work.  Included by omg_kernels.hip
+// (needs ChunkArgs, waypoint_layer_block, the GS_* debug macros).
+//
+// Work split as before: one workgroup of 4 waves per (scene, goal); kinematics of the start + n interpolated
+// configurations into LDS; one lane per (link, configuration) row tests the link's bounding ball against every object's
+// influence box (row masks); then every wave walks its rows — 4 consecutive waypoints x 16 point lanes, LB links per step —
+// and far-tests its points against the objects in reach, record in SGPRs.
+//
+// What is new is what happens to a (point, object) pair that survives the far test.  It becomes a 5-dword ENTRY — the
+// object-space offset, the point's arc-length weight ||x_i - x_(i-1)|| / dt and the object's index — and joins a queue
+// that lives in the wave's registers, one entry per lane, across objects, links and waypoints.  Only when 64 entries are
+// there does the wave run the exact path (grid coordinates, 8 voxels, trilinear value, hinge) — on 64 live lanes instead
+// of the 63 % the per-(link pair, object) batches reached — with the per-object constants read per lane from a 64-byte
+// LDS record.  The exact path is also split in two: ISSUE (coordinates, addresses, the four 8-byte gathers) and, a whole
+// queue-fill later, CONSUME (interpolation, hinge, weighted sums), so that the L2 latency of the gathers is covered by the
+// wave's own far tests instead of by other waves.  Nothing between the two uses vector memory (the robot's collision
+// points come from LDS too), so the gathers complete in the background.
+//
+// A pair's arithmetic is operation for operation that of pair_prepare / pair_exact<false> (omg_device.h), i.e. of
+// SDFdistanceForward (layers/sdf_matching_loss_kernel.cu:111-171).  A goal's cost is the float32 sum of pot * weight over
+// its pairs in queue order (fixed by the program: deterministic, no atomics) instead of per-point sums over objects times
+// the weight: equal up to float32 rounding of a sum of ~300 terms (checked against the oracle at 1e-5).
+#pragma once
+
+#define GQ_TBL_N 8       // objects of a scene whose exact-path constants are staged in LDS (others: evaluated on the spot)
+#define GQ_WG_PER_CU 5   // 32 KB of LDS per workgroup (30 waypoints), <= 96 VGPRs
+
+struct GqFar {  // what the far test of one object needs (wave-uniform, SGPRs)
+    float T[12], lo[3], flo[3], fhi[3];
+    bool cullable;
+};
+
+__device__ __forceinline__ GqFar gq_load_far(ObjTablePtr ob) {
+    GqFar f;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) f.T[k] = ob->pose_inv[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { f.lo[k] = ob->lo[k]; f.flo[k] = ob->far_lo[k]; f.fhi[k] = ob->far_hi[k]; }
+    f.cullable = ob->epsilon < 1.0f && ob->clearance <= 1.0f;  // else an out-of-range lookup (value 1.0) still adds something
+    return f;
+}
+
+// dynamic LDS behind the poses (bytes, all 16-byte aligned): row masks | exact-path records | collision points | staging
+struct GqLayout {
+    int mask_off, tbl_off, pts_off, stage_off, total;
+    __host__ __device__ GqLayout(int PS, int MR, int P) {
+        mask_off = PS * 90 * 8;
+        tbl_off = mask_off + ((10 * MR * 4 + 15) & ~15);
+        pts_off = tbl_off + GQ_TBL_N * 64;
+        stage_off = pts_off + ((10 * P * 3 * 8 + 15) & ~15);
+        total = stage_off + 4 * 64 * 16;
+        const int fk = PS * 90 * 8 + PS * 14 * 8;  // the (sin, cos) table of the kinematics borrows the region behind the poses
+        if (total < fk) total = fk;
+    }
+};
+
+template <int LB, bool STAMP = false>
+__global__ __launch_bounds__(256, GQ_WG_PER_CU) void k_goalset_queue(ChunkArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double lds_pose[];  // no static LDS: 31744 B is the most a workgroup may use at 5 per CU
+    GS_WG_STAMP(0);
+    const int xcd = blockIdx.x & 7;
+    // with a trajectory layer, GS_LAYER_PARTS workgroups per scene (10 / GS_LAYER_PARTS links each) compute it; those lead the grid
+    const int nlayer = a.wp_traj ? ((a.S + 7) >> 3) * GS_LAYER_PARTS : 0;
+    const bool is_layer = (int)(blockIdx.x >> 3) < nlayer;
+    const int j = (int)(blockIdx.x >> 3) - nlayer;
+    const int sgrp = is_layer ? (int)(blockIdx.x >> 3) / GS_LAYER_PARTS : j / a.NCH;
+    const int layer_part = (int)(blockIdx.x >> 3) - sgrp * GS_LAYER_PARTS;
+    int s = sgrp * 8 + xcd;
+    int chunk = is_layer ? 0 : j - sgrp * a.NCH;
+    const bool scheduled = a.schedule && !is_layer;
+    if (scheduled) {
+        const int item = as_const(a.schedule)[(int)blockIdx.x - nlayer * 8];
+        if (item < 0 || item >= a.S * a.NCH) return;
+        s = item / a.NCH;
+        chunk = item - s * a.NCH;
+        if (a.active && as_const(a.active)[s] == 0) { if (STAMP && threadIdx.x == 0) a.work[item] = 0u; return; }
+    }
+    if (s >= a.S) return;
+    if (a.active && !scheduled) {
+        // Scenes the planner has left (planner.py:626) get no workgroups, and the remaining ones are dealt out again so that
+        // every XCD keeps an equal share: slot k = sgrp * 8 + xcd works on the k-th ACTIVE scene (ascending).  Every wave
+        // finds it by itself with ballots over the mask (S / 64 steps, wave-uniform): no barrier, no extra launch, same
+        // result in all waves.  With all scenes active this is the identity.
+        const int k = s, ln = threadIdx.x & 63;
+        int seen = 0;
+        s = -1;
+        for (int base = 0; base < a.S; base += 64) {
+            const int i = base + ln;
+            const unsigned long long bal = __ballot(i < a.S && a.active[i] != 0);
+            const int cnt = __popcll(bal);
+            if (k < seen + cnt) {
+                unsigned long long m = bal;
+                for (int q = k - seen; q > 0; --q) m &= m - 1;  // drop the k - seen lowest set bits
+                s = base + __builtin_ctzll(m);
+                break;
+            }
+            seen += cnt;
+        }
+    }
+    if (s < 0) return;  // fewer active scenes than slots
+    const int o_begin = as_const(a.scene_begin)[s], o_end = as_const(a.scene_begin)[s + 1];
+    const int P = a.P, CH = a.CH;
+    const int p = threadIdx.x & 15, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const RobotViewS rv(a.robot, P);
+    const int pstride = a.PS, MR = a.MR;
+    const GqLayout L(pstride, MR, P);
+    char* const lds_bytes = reinterpret_cast<char*>(lds_pose);
+    uint32_t* const rowmask = reinterpret_cast<uint32_t*>(lds_bytes + L.mask_off);
+    if (is_layer) {
+        waypoint_layer_block(a, s, layer_part * (10 / GS_LAYER_PARTS), (layer_part + 1) * (10 / GS_LAYER_PARTS), lds_pose, rowmask, o_begin,
+                             o_end, rv);
+        GS_WG_STAMP(4);
+        return;
+    }
+    if (a.goal_count && chunk >= as_const(a.goal_count)[s]) {  // padding of a ragged goal set
+        if (STAMP && threadIdx.x == 0) a.work[(int64_t)s * a.NCH + chunk] = 0u;
+        return;
+    }
+    const unsigned long long work_t0 = STAMP ? wall_clock64() : 0ull;
+    uint32_t* const tbl = reinterpret_cast<uint32_t*>(lds_bytes + L.tbl_off);      // [GQ_TBL_N][16]
+    double* const pts = reinterpret_cast<double*>(lds_bytes + L.pts_off);          // [10][P][3]
+    float* const stage = reinterpret_cast<float*>(lds_bytes + L.stage_off) + wave * 256;  // wave-private [64][4]
+
+    {   // Kinematics of the start + CH interpolated configurations in two stages (omg_device.h: fk_joint_sincos on
+        // (configuration, joint) lanes, fk_chain_row on (configuration, pose row) lanes); the (sin, cos) table borrows the
+        // region behind the poses, which is first written after the barriers below.
+        // cfg 0 = start itself, cfg i+1 = linspace(0,1,n+2)[1:-1][i]: numpy's linspace is i * step with step = fl(1 / (n + 1)),
+        // not i / (n + 1) — bit-identical to util.py:261-290 (interp1d)
+        const double* q0 = a.traj_start + a.ts_stride * (int64_t)s;
+        const double* qg = a.goals + ((int64_t)s * a.NCH + chunk) * 9;
+        const int ncfg = CH + 1;
+        double* sc = reinterpret_cast<double*>(rowmask);  // [ncfg][7][2]
+        auto joint = [&](int cfg, int d) { return cfg == 0 ? q0[d] : q0[d] + ((double)cfg * (1.0 / (double)(CH + 1))) * (qg[d] - q0[d]); };
+        for (int t = threadIdx.x; t < ncfg * 7; t += 256) {
+            const int cfg = t / 7, i = t - cfg * 7;
+            double sn, cs;
+            fk_joint_sincos(joint(cfg, i), sn, cs);
+            sc[2 * t] = sn; sc[2 * t + 1] = cs;
+        }
+        __syncthreads();
+        GS_WG_STAMP(1);
+        for (int t = threadIdx.x; t < ncfg * 3; t += 256) {
+            const int cfg = t / 3, rr = t - cfg * 3;
+            fk_chain_row(rv, rr, sc + 14 * cfg, joint(cfg, 7), joint(cfg, 8), [&](int l, double r0, double r1, double r2, double tr) {
+                double* dst = lds_pose + ((size_t)l * pstride + cfg) * 9;  // rows 0 and 1 of R, then t
+                if (rr < 2) { dst[3 * rr] = r0; dst[3 * rr + 1] = r1; dst[3 * rr + 2] = r2; }
+                dst[6 + rr] = tr;
+            });
+        }
+    }
+    __syncthreads();
+    GS_WG_STAMP(2);
+    const double* base = lds_pose + 9;
+
+    // ---- exact-path records of the scene's first GQ_TBL_N objects and the robot's collision points -> LDS
+    // record (16 dwords): [0..5] 1 / extent as doubles | [6..8] dims | [9,10] byte offset of the grid in the pool |
+    //                     [11] eps / 2 | [12] eps | [13] clearance | [14] padding scale | [15] 1 / (2 eps)
+    if ((int)threadIdx.x < GQ_TBL_N && o_begin + (int)threadIdx.x < o_end) {
+        const omgx_object* ob = a.objects + o_begin + threadIdx.x;
+        uint32_t* e = tbl + threadIdx.x * 16;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double rw = ob->inv_extent[k];
+            e[2 * k] = (uint32_t)__double2loint(rw); e[2 * k + 1] = (uint32_t)__double2hiint(rw);
+            e[6 + k] = (uint32_t)ob->dim[k];
+        }
+        const int64_t goffb = ob->grid_offset * 4;
+        e[9] = (uint32_t)(goffb & 0xffffffffll); e[10] = (uint32_t)(goffb >> 32);
+        e[11] = __float_as_uint(0.5f * ob->epsilon);  // exact: (double)(0.5f * eps) == 0.5 * (double)eps
+        e[12] = __float_as_uint(ob->epsilon); e[13] = __float_as_uint(ob->clearance);
+        e[14] = __float_as_uint(ob->padding_scale); e[15] = __float_as_uint(ob->inv_2eps);
+    }
+    for (int t = threadIdx.x; t < 30 * P; t += 256) pts[t] = rv.g[246 + t];
+
+    for (int row = threadIdx.x; row < 10 * CH; row += 256) {  // row-level culling (see k_sdf_chunks)
+        const int l = row / CH, ci = row - l * CH;
+        const double* A = base + ((int64_t)l * pstride + ci) * 9;
+        const float cx = (float)A[6], cy = (float)A[7], cz = (float)A[8];
+        const float rad = (float)rv.radius(l) + 1.0e-4f;
+        uint32_t m = 0;
+        for (int o = o_begin; o < o_end; ++o) {
+            ObjTablePtr ob = as_const(a.objects) + o;
+            if (ob->disabled > 0) continue;
+            const int oo = o - o_begin;
+            const uint32_t bit = 1u << (oo < 31 ? oo : 31);
+            const float ux = __builtin_fmaf(ob->pose_inv[2], cz, __builtin_fmaf(ob->pose_inv[1], cy, __builtin_fmaf(ob->pose_inv[0], cx, ob->pose_inv[3]))) - ob->lo[0];
+            const float uy = __builtin_fmaf(ob->pose_inv[6], cz, __builtin_fmaf(ob->pose_inv[5], cy, __builtin_fmaf(ob->pose_inv[4], cx, ob->pose_inv[7]))) - ob->lo[1];
+            const float uz = __builtin_fmaf(ob->pose_inv[10], cz, __builtin_fmaf(ob->pose_inv[9], cy, __builtin_fmaf(ob->pose_inv[8], cx, ob->pose_inv[11]))) - ob->lo[2];
+            const bool near = (ux >= ob->far_lo[0] - rad) & (ux <= ob->far_hi[0] + rad) & (uy >= ob->far_lo[1] - rad) &
+                              (uy <= ob->far_hi[1] + rad) & (uz >= ob->far_lo[2] - rad) & (uz <= ob->far_hi[2] + rad);
+            const bool cullable = ob->epsilon < 1.0f && ob->clearance <= 1.0f;
+            if (near || !cullable) m |= bit;
+        }
+        rowmask[row] = m;
+    }
+    __syncthreads();
+    GS_WG_STAMP(3);
+
+    // ---- the wave's queue.  q_*: pending entries, one per lane, lanes [0, pending).  f_*: the batch whose gathers are in flight.
+    float q_tx = 0.0f, q_ty = 0.0f, q_tz = 0.0f, q_w = 0.0f;
+    uint32_t q_meta = 0u;  // object index | soft << 16
+    int pending = 0;
+    F2 f_r00{0.0f, 0.0f}, f_r01{0.0f, 0.0f}, f_r10{0.0f, 0.0f}, f_r11{0.0f, 0.0f};
+    float f_fx = 0.0f, f_fy = 0.0f, f_fz = 0.0f, f_w = 0.0f;
+    uint32_t f_meta = 0u;  // object index | soft << 16 | in_c << 30 | valid << 31
+    bool inflight = false;
+    float tsum = 0.0f, tcol = 0.0f;
+
+    // CONSUME: finish the batch in flight (interpolation, hinge, weighted sums).  f_w is 0 for lanes without an entry.
+    auto consume = [&]() {
+        const float tv = trilerp(f_r00.a, f_r00.b, f_r01.a, f_r01.b, f_r10.a, f_r10.b, f_r11.a, f_r11.b, f_fx, f_fy, f_fz);
+        const uint4 h = *reinterpret_cast<const uint4*>(tbl + (f_meta & 0xffffu) * 16 + 12);
+        const float eps = __uint_as_float(h.x), clr = __uint_as_float(h.y), pad = __uint_as_float(h.z), i2eps = __uint_as_float(h.w);
+        const float heps = __uint_as_float(tbl[(f_meta & 0xffffu) * 16 + 11]);
+        const bool in_c = (f_meta & (1u << 30)) != 0, counts = (f_meta & (1u << 31)) != 0, soft = (f_meta & (1u << 16)) != 0;
+        const float value = in_c ? tv : 1.0f;                                   // .cu:49-50
+        const float p_in = (float)(-(double)value + (double)heps);              // .cu:158-160
+        const float d = value - eps;
+        const float p_band = i2eps * d * d * pad;                               // .cu:165-167
+        float pot = value <= 0.0f ? p_in : (value <= eps ? p_band : 0.0f);
+        pot = soft ? pot * 0.1f : pot;                                          // cost.py:350-353
+        tsum += pot != 0.0f ? pot * f_w : 0.0f;                                 // cost.py:260-275
+        tcol += (counts && value < clr) ? 1.0f : 0.0f;                          // .cu:150-151
+        inflight = false;
+    };
+
+    // ISSUE: grid coordinates, addresses and the four gathers of the `count` queued entries.  Lanes >= count compute on
+    // whatever their registers hold; their weight is 0, in_c false (address = the grid's first voxel) and they count nothing.
+    auto issue = [&](int count) {
+        const bool valid = lane < count;
+        const uint32_t oo = valid ? (q_meta & 0xffffu) : 0u;
+        const uint32_t* rec = tbl + oo * 16;
+        const uint4 c0 = *reinterpret_cast<const uint4*>(rec), c1 = *reinterpret_cast<const uint4*>(rec + 4), c2 = *reinterpret_cast<const uint4*>(rec + 8);
+        const double rw0 = __hiloint2double((int)c0.y, (int)c0.x), rw1 = __hiloint2double((int)c0.w, (int)c0.z);
+        const double rw2 = __hiloint2double((int)c1.y, (int)c1.x);
+        const int dx = (int)c1.z, dy = (int)c1.w, dz = (int)c2.x;
+        const uint64_t goffb = ((uint64_t)c2.z << 32) | (uint64_t)c2.y;
+        const float gx = (float)((double)q_tx * rw0) * (float)dx;  // .cu:137-142 (see pair_exact for the quotient)
+        const float gy = (float)((double)q_ty * rw1) * (float)dy;
+        const float gz = (float)((double)q_tz * rw2) * (float)dz;
+        // axis_of without its range flags: a coordinate beyond +-1e9 saturates the conversion and fails the unsigned
+        // comparison below like the oracle's explicit test; NaN converts to 0 and is rejected by the ordered comparisons
+        const float sx_ = gx - 0.5f, sy_ = gy - 0.5f, sz_ = gz - 0.5f;
+        int ix = (int)sx_, iy = (int)sy_, iz = (int)sz_;
+        float fx = sx_ - (float)ix, fy = sy_ - (float)iy, fz = sz_ - (float)iz;
+        const bool ex = (sx_ == -1.0f) && (gx > -0.5f), ey = (sy_ == -1.0f) && (gy > -0.5f), ez = (sz_ == -1.0f) && (gz > -0.5f);
+        ix = ex ? 0 : ix; iy = ey ? 0 : iy; iz = ez ? 0 : iz;
+        fx = ex ? -1.0f : fx; fy = ey ? -1.0f : fy; fz = ez ? -1.0f : fz;
+        // (axis_of's g > -1e9 && g <= 1e9; at g == -1e9 exactly the index is negative anyway)
+        const bool ordered = (__builtin_fabsf(gx) <= 1.0e9f) && (__builtin_fabsf(gy) <= 1.0e9f) && (__builtin_fabsf(gz) <= 1.0e9f);
+        const bool in_c = valid && ordered && (uint32_t)ix < (uint32_t)(dx - 1) && (uint32_t)iy < (uint32_t)(dy - 1) && (uint32_t)iz < (uint32_t)(dz - 1);
+        const uint32_t b = in_c ? (uint32_t)((ix * dy + iy) * dz + iz) : 0u;
+        const char* g0 = reinterpret_cast<const char*>(a.pool) + goffb + (uint64_t)b * 4u;
+        const uint32_t syb = (uint32_t)dz * 4u, sxb = (uint32_t)(dy * dz) * 4u;
+        f_r00 = *reinterpret_cast<const F2*>(g0);
+        f_r01 = *reinterpret_cast<const F2*>(g0 + syb);
+        f_r10 = *reinterpret_cast<const F2*>(g0 + sxb);
+        f_r11 = *reinterpret_cast<const F2*>(g0 + sxb + syb);
+        f_fx = fx; f_fy = fy; f_fz = fz;
+        f_w = valid ? q_w : 0.0f;
+        f_meta = (q_meta & 0x1ffffu) | (in_c ? 1u << 30 : 0u) | ((valid && !(q_meta & 0x10000u)) ? 1u << 31 : 0u);
+        inflight = true;
+    };
+
+    // ENQUEUE the lanes with `live` (object oo_soft = index | soft << 16): staged in LDS at their rank, picked up by the
+    // lanes behind the pending entries; a full queue is issued (after the batch in flight has been consumed)
+    auto enqueue = [&](bool live, float tx, float ty, float tz, float w, uint32_t oo_soft) {
+        const unsigned long long bal = __ballot(live);
+        const int n = __popcll(bal);
+        const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+        if (live) *reinterpret_cast<float4*>(stage + 4 * rank) = make_float4(tx, ty, tz, w);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int room = 64 - pending;
+        const int take = n < room ? n : room;
+        if (lane >= pending && lane < pending + take) {
+            const float4 e = *reinterpret_cast<const float4*>(stage + 4 * (lane - pending));
+            q_tx = e.x; q_ty = e.y; q_tz = e.z; q_w = e.w; q_meta = oo_soft;
+        }
+        pending += take;
+        if (pending == 64) {
+            if (inflight) consume();
+            issue(64);
+            pending = n - take;
+            if (lane < pending) {
+                const float4 e = *reinterpret_cast<const float4*>(stage + 4 * (take + lane));
+                q_tx = e.x; q_ty = e.y; q_tz = e.z; q_w = e.w; q_meta = oo_soft;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();  // the staging area is rewritten by the next call
+    };
+
+    // The wave's work: TILES of 4 consecutive waypoints x LB links, dealt over the 4 waves as tile (block rb, link batch lp)
+    // -> wave (rb * (10 / LB) + lp) % 4.  The pairs that survive the culling are concentrated at the goal end of the path and
+    // on the links near the hand (tests/fuzz/pair_density.py: the last waypoints carry ~20x the work of the first), so with
+    // whole blocks of waypoints per wave the busiest wave had 1.4x the mean load; dealt like this the last wave leaves the
+    // main loop 1.07x after the mean (tools/gs_phase_clock.py).  Measured and rejected: single waypoints dealt to the waves
+    // (the rows of a tile then see different objects: +2 %), a split of the tile sequence by the number of row-mask hits
+    // (a poor predictor of the exact-path work: +7 %), one link per tile (+5 %).
+    const int ntiles = ((CH + 3) >> 2) * (10 / LB);
+#pragma unroll 1
+    for (int t = wave; t < ntiles; t += 4) {  // every lane stays active: invalid items are flagged, not skipped
+        const int rb = t / (10 / LB), l0 = (t - rb * (10 / LB)) * LB;
+        {
+            const int ci = rb * 4 + (lane >> 4);
+            const bool valid = (p < P) && (ci < CH);
+            const int cic = valid ? ci : 0, pc = valid ? p : 0;
+            float px[LB], py[LB], pz[LB], w[LB];
+            uint32_t msk[LB];
+            bool wdone[LB];
+            uint32_t many = 0;
+#pragma unroll
+            for (int k = 0; k < LB; ++k) {
+                msk[k] = valid ? rowmask[(l0 + k) * CH + cic] : 0u;
+                many |= msk[k];
+                wdone[k] = false;
+                w[k] = 0.0f;
+            }
+            if (!__any(many != 0)) continue;  // nothing in reach of any row of this tile
+#pragma unroll
+            for (int k = 0; k < LB; ++k)
+                pose9_apply(base + ((int64_t)(l0 + k) * pstride + cic) * 9, pts + 3 * ((l0 + k) * P + pc), px[k], py[k], pz[k]);
+            for (int o = o_begin; o < o_end; ++o) {
+                const int oo = o - o_begin;
+                const uint32_t bit = 1u << (oo < 31 ? oo : 31);
+                if (!__any((many & bit) != 0)) continue;
+                ObjTablePtr ob = as_const(a.objects) + o;
+                if (ob->disabled > 0) continue;  // .cu:115-116
+                const GqFar fp = gq_load_far(ob);
+                const bool queued = oo < GQ_TBL_N;  // objects beyond the LDS records (rare) are evaluated on the spot
+#pragma unroll
+                for (int k = 0; k < LB; ++k) {
+                    // SE3(pose) * point (.cu:125-133) and the far test of pair_prepare
+                    const float ux = __builtin_fmaf(fp.T[2], pz[k], __builtin_fmaf(fp.T[1], py[k], __builtin_fmaf(fp.T[0], px[k], fp.T[3])));
+                    const float uy = __builtin_fmaf(fp.T[6], pz[k], __builtin_fmaf(fp.T[5], py[k], __builtin_fmaf(fp.T[4], px[k], fp.T[7])));
+                    const float uz = __builtin_fmaf(fp.T[10], pz[k], __builtin_fmaf(fp.T[9], py[k], __builtin_fmaf(fp.T[8], px[k], fp.T[11])));
+                    const float tx = ux - fp.lo[0], ty = uy - fp.lo[1], tz = uz - fp.lo[2];
+                    const bool inside = (tx >= fp.flo[0]) & (tx <= fp.fhi[0]) & (ty >= fp.flo[1]) & (ty <= fp.fhi[1]) &
+                                        (tz >= fp.flo[2]) & (tz <= fp.fhi[2]);
+                    const bool live = (msk[k] & bit) && (inside || !fp.cullable);
+                    if (!__any(live)) continue;
+                    if (!wdone[k]) {  // ||(x_i - x_{i-1}) / dt|| in float32 (config.py:162-187, cost.py:260-275), once per (row, link)
+                        const int l = l0 + k;
+                        float qx, qy, qz;
+                        pose9_apply(ci > 0 ? base + ((int64_t)l * pstride + cic - 1) * 9 : lds_pose + (int64_t)l * pstride * 9, pts + 3 * (l * P + pc), qx, qy, qz);
+                        const float vx = (px[k] - qx) * a.inv_dt, vy = (py[k] - qy) * a.inv_dt, vz = (pz[k] - qz) * a.inv_dt;
+                        w[k] = sqrtf(vx * vx + vy * vy + vz * vz);
+                        wdone[k] = true;
+                    }
+                    const uint32_t soft = (a.soften && l0 + k >= 8) ? 1u : 0u;
+                    if (queued) {
+                        enqueue(live, tx, ty, tz, w[k], (uint32_t)oo | (soft << 16));
+                    } else if (live) {
+                        const ObjParams op = load_object(ob);
+                        Accum one{0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+                        pair_exact<false>(op, a.pool + ob->grid_offset, tx, ty, tz, one);
+                        if (soft) { one.pot *= 0.1f; one.col = 0.0f; }
+                        tsum += one.pot != 0.0f ? one.pot * w[k] : 0.0f;
+                        tcol += one.col;
+                    }
+                }
+            }
+        }
+    }
+    if (inflight) consume();
+    if (pending > 0) {
+        issue(pending);
+        consume();
+    }
+#if defined(OMGX_GS_CLOCK)
+    if (lane == 0 && blockIdx.x < (1u << 16)) {  // when the first / the last wave of the workgroup left its main loop
+        const unsigned long long now = wall_clock64();
+        atomicMin(&g_gs_wg[blockIdx.x][5], now);
+        atomicMax(&g_gs_wg[blockIdx.x][6], now);
+    }
+#endif
+    {
+        const float ws_ = wave_sum(tsum), wc_ = wave_sum(tcol);
+        float* red = reinterpret_cast<float*>(lds_bytes + L.tbl_off);  // [2][4]: the records are dead once every wave has flushed its queue
+        __syncthreads();
+        if (lane == 0) { red[wave] = ws_; red[4 + wave] = wc_; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int64_t k = (int64_t)s * a.NCH + chunk;
+            if (a.chunk_cost) a.chunk_cost[k] = ((red[0] + red[1]) + red[2]) + red[3];
+            if (a.chunk_col) a.chunk_col[k] = ((red[4] + red[5]) + red[6]) + red[7];
+            if (STAMP) { const unsigned long long dt = wall_clock64() - work_t0; a.work[k] = dt < 1 ? 1u : (dt > 0xffffffffull ? 0xffffffffu : (uint32_t)dt); }
+        }
+    }
+    GS_WG_STAMP(4);
+}

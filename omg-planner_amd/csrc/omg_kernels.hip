@@ -20,6 +20,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
+
 #include "omg_device.h"
 #include "omg_host.h"
 
@@ -91,25 +93,21 @@ __global__ __launch_bounds__(256) void k_sdf_loss(RawObjects R, const float* __r
 // (2) k_fk_poses — one lane per configuration -> link poses (double [12]: R row-major, t)
 // =================================================================================================
 // Config sources:
-//   mode 0: joints[S][C][9] given                                   (omgx_fk_sdf, chomp waypoints)
-//   mode 1: joints interpolated start + (i+1)/(n+1) (goal - start)  (omgx_goalset_cost; util.py:261-290 "linear")
-//           plus one extra configuration per scene = traj_start itself, written to ws_start
-//   mode 2: joints[S][C][9] given + the extra start configuration      (omgx_fk_sdf with arc_length > 0)
+//   mode 0: joints[S][C][9] given                                    (omgx_fk_sdf)
+//   mode 2: the same + one extra configuration per scene = arc_start, written to ws_start (omgx_fk_sdf with arc_length > 0)
 // Output layout ws[S][NCH][10][CH][12]: for a fixed link the 64 configurations of a wave are contiguous
 // (6 KiB), so each link's poses are staged in LDS and stored cooperatively, fully coalesced.
 struct FkArgs {
     const double* robot;
     int P;
     int mode;
-    const double* joints;      // mode 0: [S][C][9]
-    const double* traj_start;  // mode 1/2: row s at traj_start + s * ts_stride
+    const double* joints;      // [S][C][9]
+    const double* traj_start;  // mode 2: row s at traj_start + s * ts_stride
     int64_t ts_stride;
-    const double* goals;       // mode 1: [S][G][9]
-    int S, C;                  // C configs per scene (mode 1: C = G * n)
-    int n;                     // mode 1: waypoints per goal
+    int S, C;                  // C configs per scene
     int CH;                    // configs per chunk
     double* ws;                // [S][NCH][10][CH][12]
-    double* ws_start;          // mode 1: [S][10][12]
+    double* ws_start;          // mode 2: [S][10][12]
 };
 
 __global__ __launch_bounds__(64) void k_fk_poses(FkArgs a) {
@@ -128,7 +126,7 @@ __global__ __launch_bounds__(64) void k_fk_poses(FkArgs a) {
     const int CH = a.CH;
     const int NCH = (a.C + CH - 1) / CH;
     double q[9];
-    if (a.mode == 0 || a.mode == 2) {  // explicit joints; mode 2 adds one start configuration per scene
+    {   // explicit joints; mode 2 adds one start configuration per scene
         if (a.mode == 2 && c == a.C) {
             const double* q0 = a.traj_start + a.ts_stride * (int64_t)s;
 #pragma unroll
@@ -139,22 +137,6 @@ __global__ __launch_bounds__(64) void k_fk_poses(FkArgs a) {
             const double* src = a.joints + ((int64_t)s * a.C + c) * 9;
 #pragma unroll
             for (int d = 0; d < 9; ++d) q[d] = src[d];
-            rowptr[lane] = a.ws + ((((int64_t)s * NCH + c / CH) * 10) * CH + c % CH) * 12;
-            rowstride[lane] = CH * 12;
-        }
-    } else {
-        const double* q0 = a.traj_start + a.ts_stride * (int64_t)s;
-        if (c == a.C) {  // the start configuration of the scene (ws_positions_start, cost.py:240-251)
-#pragma unroll
-            for (int d = 0; d < 9; ++d) q[d] = q0[d];
-            rowptr[lane] = a.ws_start + (int64_t)s * 120;
-            rowstride[lane] = 12;
-        } else {
-            const int g = c / a.n, i = c % a.n;
-            const double* qg = a.goals + ((int64_t)s * (a.C / a.n) + g) * 9;
-            const double t = (double)(i + 1) * (1.0 / (double)(a.n + 1));  // linspace(0,1,n+2)[1:-1] = i * step, step = fl(1 / (n + 1)) (numpy)
-#pragma unroll
-            for (int d = 0; d < 9; ++d) q[d] = q0[d] + t * (qg[d] - q0[d]);
             rowptr[lane] = a.ws + ((((int64_t)s * NCH + c / CH) * 10) * CH + c % CH) * 12;
             rowstride[lane] = CH * 12;
         }
@@ -183,8 +165,8 @@ struct ChunkArgs {
     const omgx_object* objects;
     const int32_t* scene_begin;
     const float* pool;
-    const int32_t* active;     // [S] or null (k_goalset_compact): scenes with 0 are skipped, their outputs stay as they are
-    const int32_t* goal_count; // [S] or null (k_goalset_compact): goals >= goal_count[s] of the padded goal array are skipped
+    const int32_t* active;     // [S] or null (k_goalset_queue): scenes with 0 are skipped, their outputs stay as they are
+    const int32_t* goal_count; // [S] or null (k_goalset_queue): goals >= goal_count[s] of the padded goal array are skipped
     const double* ws;        // [S][NCH][10][CH][12] link poses
     const double* ws_start;  // [S][10][12] or null
     int S, C, CH, NCH, P;
@@ -201,14 +183,14 @@ struct ChunkArgs {
     const double* traj_start;  // row s at traj_start + s * ts_stride
     int64_t ts_stride;
     const double* goals;       // [S][NCH][9]
-    // SDF layer of the current trajectories inside the goal-set launch (k_goalset_compact only): one extra workgroup per scene
+    // SDF layer of the current trajectories inside the goal-set launch (k_goalset_queue only): one extra workgroup per scene
     const double* wp_traj;     // [S][wp_n][9] or null
     int wp_n, wp_soften;
     float* wp_pot;             // [S][wp_n][10][P]
     float* wp_grad;            // [S][wp_n][10][P][3]
     float* wp_col;             // [S][wp_n][10][P]
     int PS, MR;                // LDS pose stride (configurations per link) and mask rows per link: max over both kinds of workgroup
-    // dispatch order of the goal workgroups (k_goalset_compact only).  schedule[k] = scene * NCH + goal of the k-th goal
+    // dispatch order of the goal workgroups (k_goalset_queue only).  schedule[k] = scene * NCH + goal of the k-th goal
     // workgroup in blockIdx order (< 0: nothing), normally the goals of the previous launch sorted by the time they took
     // (longest first, omgx_goalset_schedule) so that the launch does not end on a few long workgroups.  work[scene * NCH +
     // goal] receives the workgroup's duration in 10 ns ticks (0 for skipped goals).
@@ -381,21 +363,13 @@ __global__ __launch_bounds__(TPB) void k_sdf_chunks(ChunkArgs a) {
         }
     }
 }
-
 // =================================================================================================
-// (3b) k_goalset_compact — the goal-set batch with wave-level compaction of the exact path
+// (3b) waypoint_layer_block — the SDF layer of a scene's current trajectory inside the goal-set launch
 // =================================================================================================
-// Same work split as k_sdf_chunks<false, ., true> (one workgroup per (scene, goal), FK in LDS, row culling, far
-// tests per point), but the pairs that survive the far test are first PACKED: within a wave the surviving
-// (lane, link-of-batch) items are ranked with ballots, their object-space offsets go to a 1 KiB wave-private LDS
-// scratch, lanes 0..count-1 each run the exact path (grid coordinates, trilinear value, hinge) for one packed
-// item, and the owners read the results back.  The per-point far pattern left only ~49 % of the lanes useful in
-// the unpacked exact path (a link's 10 cm point cloud straddles the far box); packed, a batch of LB links needs
-// ceil(survivors / 64) exact passes instead of one per link.  Arithmetic per pair is unchanged (bit-identical).
-// The SDF layer of scene s's current trajectory (what omgx_fk_sdf computes for Optimizer.optimize: potentials,
-// gradients, collisions of wp_n x 10 x P points) as ONE extra workgroup of the goal-set launch.  The optimiser step
-// that follows on the same stream then depends on a single kernel: no side stream, no events.  Arithmetic is that of
-// k_sdf_chunks<true> (same sdf_pair calls on the same float32 points), FK as in the goal-set workgroups.
+// What omgx_fk_sdf computes for Optimizer.optimize (potentials, gradients, collisions of wp_n x 10 x P points) as
+// GS_LAYER_PARTS extra workgroups per scene of k_goalset_queue (omg_goalset_queue.h).  The optimiser step that follows on
+// the same stream then depends on a single kernel: no side stream, no events.  Arithmetic is that of k_sdf_chunks<true>
+// (same sdf_pair calls on the same float32 points); kinematics in two stages like the goal workgroups.
 __device__ __forceinline__ void waypoint_layer_block(const ChunkArgs& a, const int s, const int l_begin, const int l_end,
                                                      double* lds_pose, uint32_t* rowmask, const int o_begin, const int o_end,
                                                      const RobotViewS& rv) {
@@ -476,278 +450,23 @@ __device__ __forceinline__ void waypoint_layer_block(const ChunkArgs& a, const i
     }
 }
 
-// Debug aid (make CXXFLAGS+=-DOMGX_GS_CLOCK): every goal workgroup's waves add the shader-clock cycles they spend in each
-// phase of k_goalset_compact to g_gs_clock (tools/gs_phase_clock.py reads it).  s_memtime drains lgkmcnt, so the figures
-// are an attribution, not a timing.
+// Debug aid (make CXXFLAGS+=-DOMGX_GS_CLOCK=1; tools/gs_phase_clock.py): every workgroup of k_goalset_queue stamps the
+// 100 MHz realtime clock at its phase boundaries — entry, after each stage of the kinematics, after the row culling, when
+// its first / last wave leaves the main loop, exit — and its hardware id.  Never part of the shipped library.
 #ifdef OMGX_GS_CLOCK
-__device__ unsigned long long g_gs_clock[16];
-__device__ unsigned long long g_gs_wg[1 << 16][8];  // per workgroup: realtime at start / after the prologue / at end (100 MHz), hardware id
-// the clock read carries a fake dependency on DEP_ (a value the phase produces) and a memory clobber, so that the compiler
-// cannot move the phase's arithmetic or LDS traffic across it
-#if OMGX_GS_CLOCK > 1  // phase clocks inside the loops: s_memtime is a memory operation (~1 us each) — it slows the kernel 12x, shares only
-#define GS_CLK_DECL unsigned int clk_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long clk_t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(clk_t) :: "memory")
-#define GS_CLK_DEP(i, DEP_) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : "v"(DEP_) : "memory"); clk_acc[i] += (unsigned int)(t_ - clk_t); clk_t = t_; } while (0)
-#define GS_CLK(i) GS_CLK_DEP(i, 0)
-#define GS_CLK_FLUSH do { if ((threadIdx.x & 63) == 0) { for (int i_ = 0; i_ < 12; ++i_) atomicAdd(&g_gs_clock[i_], (unsigned long long)clk_acc[i_]); atomicAdd(&g_gs_clock[15], 1ull); } } while (0)
-#else
-#define GS_CLK_DECL
-#define GS_CLK(i)
-#define GS_CLK_DEP(i, DEP_)
-#define GS_CLK_FLUSH
-#endif
-#define GS_WG_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < (1u << 16)) { g_gs_wg[blockIdx.x][k] = wall_clock64(); if (k == 0) { unsigned hw, xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); g_gs_wg[blockIdx.x][7] = ((unsigned long long)xcc << 32) | hw; } } } while (0)
-extern "C" int omgx_debug_gs_clock(unsigned long long* h_out16, int reset) {
-    if (h_out16 && hipMemcpyFromSymbol(h_out16, HIP_SYMBOL(g_gs_clock), sizeof(unsigned long long) * 16) != hipSuccess) return -2;
-    if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_gs_clock), z, sizeof z) != hipSuccess) return -2; }
-    return 0;
-}
+__device__ unsigned long long g_gs_wg[1 << 16][8];
+#define GS_WG_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < (1u << 16)) { g_gs_wg[blockIdx.x][k] = wall_clock64(); if (k == 0) { g_gs_wg[blockIdx.x][5] = ~0ull; g_gs_wg[blockIdx.x][6] = 0ull; unsigned hw, xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); g_gs_wg[blockIdx.x][7] = ((unsigned long long)xcc << 32) | hw; } } } while (0)
 extern "C" int omgx_debug_gs_wg(unsigned long long* h_out, int n_wg) {
     if (n_wg > (1 << 16)) n_wg = 1 << 16;
     return hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_gs_wg), sizeof(unsigned long long) * 8 * n_wg) == hipSuccess ? 0 : -2;
 }
 #else
-#define GS_CLK_DECL
-#define GS_CLK(i)
-#define GS_CLK_DEP(i, DEP_)
-#define GS_CLK_FLUSH
 #define GS_WG_STAMP(k)
 #endif
 
 #define GS_LAYER_PARTS 5  // trajectory-layer workgroups per scene
-#ifndef GS_WG_PER_CU
-#define GS_WG_PER_CU 6  // 80 VGPRs; the LDS of a 30-waypoint goal (26.6 KB) allows no more
-#endif
-template <int LB, bool STAMP = false>  // STAMP: record every goal workgroup's duration in a.work (a separate instantiation: the two clock reads cost registers)
-__global__ __launch_bounds__(256, GS_WG_PER_CU) void k_goalset_compact(ChunkArgs a) {
-    extern __shared__ __attribute__((aligned(16))) double lds_pose[];
-    __shared__ float red[2][4];
-    GS_WG_STAMP(0);
-    const int xcd = blockIdx.x & 7;
-    // with a trajectory layer, the first workgroup of every scene computes it; those (longer) workgroups lead the grid
-    // (GS_LAYER_PARTS workgroups per scene, 10 / GS_LAYER_PARTS links each: a lone scene is not held up by one long workgroup)
-    const int nlayer = a.wp_traj ? ((a.S + 7) >> 3) * GS_LAYER_PARTS : 0;  // in units of 8 workgroups (one per XCD)
-    const bool is_layer = (int)(blockIdx.x >> 3) < nlayer;
-    const int j = (int)(blockIdx.x >> 3) - nlayer;
-    const int sgrp = is_layer ? (int)(blockIdx.x >> 3) / GS_LAYER_PARTS : j / a.NCH;
-    const int layer_part = (int)(blockIdx.x >> 3) - sgrp * GS_LAYER_PARTS;
-    int s = sgrp * 8 + xcd;
-    int chunk = is_layer ? 0 : j - sgrp * a.NCH;
-    const bool scheduled = a.schedule && !is_layer;
-    if (scheduled) {  // workgroup b of the goal part works on item schedule[b]
-        const int b = (int)blockIdx.x - nlayer * 8;
-        const int item = as_const(a.schedule)[b];  // [((S + 7) / 8) * 8 * NCH] = the goal part of the grid
-        if (item < 0 || item >= a.S * a.NCH) return;
-        s = item / a.NCH;  // wave-uniform, once per workgroup
-        chunk = item - s * a.NCH;
-        if (a.active && as_const(a.active)[s] == 0) { if (STAMP && threadIdx.x == 0) a.work[item] = 0u; return; }
-    }
-    if (s >= a.S) return;
-    if (a.active && !scheduled) {
-        // Scenes the planner has left (planner.py:626) get no workgroups, and the remaining ones are dealt out again so that
-        // every XCD keeps an equal share: slot k = sgrp * 8 + xcd works on the k-th ACTIVE scene (ascending).  Every wave
-        // finds it by itself with ballots over the mask (S / 64 steps, wave-uniform): no barrier, no extra launch, same
-        // result in all waves.  With all scenes active this is the identity.
-        const int k = s, ln = threadIdx.x & 63;
-        int seen = 0;
-        s = -1;
-        for (int base = 0; base < a.S; base += 64) {
-            const int i = base + ln;
-            const unsigned long long bal = __ballot(i < a.S && a.active[i] != 0);
-            const int cnt = __popcll(bal);
-            if (k < seen + cnt) {
-                unsigned long long m = bal;
-                for (int q = k - seen; q > 0; --q) m &= m - 1;  // drop the k - seen lowest set bits
-                s = base + __builtin_ctzll(m);
-                break;
-            }
-            seen += cnt;
-        }
-    }
-    if (s < 0) return;  // fewer active scenes than slots
-    const int o_begin = as_const(a.scene_begin)[s], o_end = as_const(a.scene_begin)[s + 1];
-    const int P = a.P, CH = a.CH;
-    const int nvalid = CH;
-    const int p = threadIdx.x & 15, r = threadIdx.x >> 4, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const RobotViewS rv(a.robot, P);  // chain constants and radii through scalar loads
-    const int pstride = a.PS, MR = a.MR;
-    uint32_t* rowmask = reinterpret_cast<uint32_t*>(lds_pose + (size_t)pstride * 90);  // poses: 9 doubles (see pose9_apply)
-    float* scratch = reinterpret_cast<float*>(rowmask + ((10 * MR + 3) & ~3)) + wave * 192;  // wave-private [64][3]: 12 B entries keep 6 workgroups per CU inside 160 KB
-    if (is_layer) {
-        waypoint_layer_block(a, s, layer_part * (10 / GS_LAYER_PARTS), (layer_part + 1) * (10 / GS_LAYER_PARTS), lds_pose, rowmask, o_begin,
-                             o_end, rv);
-        GS_WG_STAMP(4);
-        return;
-    }
 
-    if (a.goal_count && chunk >= as_const(a.goal_count)[s]) {  // padding of a ragged goal set
-        if (STAMP && threadIdx.x == 0) a.work[(int64_t)s * a.NCH + chunk] = 0u;
-        return;
-    }
-    const unsigned long long work_t0 = STAMP ? wall_clock64() : 0ull;  // s_memrealtime, 100 MHz
-    GS_CLK_DECL;
-    {   // FK of start + CH interpolated configurations in two stages (omg_device.h: fk_chain_row); the (sin, cos)
-        // table borrows the row-mask / scratch region, which is first written after the barriers below.
-        const double* q0 = a.traj_start + a.ts_stride * (int64_t)s;
-        const double* qg = a.goals + ((int64_t)s * a.NCH + chunk) * 9;
-        const int ncfg = CH + 1;
-        double* sc = reinterpret_cast<double*>(rowmask);  // [ncfg][7][2]
-        // cfg 0 = start itself, cfg i+1 = linspace(0,1,n+2)[1:-1][i]
-        // numpy's linspace is i * step with step = fl(1 / (n + 1)), not i / (n + 1): bit-identical to util.py:261-290 (interp1d)
-        auto joint = [&](int cfg, int d) { return cfg == 0 ? q0[d] : q0[d] + ((double)cfg * (1.0 / (double)(CH + 1))) * (qg[d] - q0[d]); };
-        for (int t = threadIdx.x; t < ncfg * 7; t += 256) {
-            const int cfg = t / 7, i = t - cfg * 7;
-            double sn, cs;
-            fk_joint_sincos(joint(cfg, i), sn, cs);
-            sc[2 * t] = sn; sc[2 * t + 1] = cs;
-        }
-        __syncthreads();
-        GS_WG_STAMP(1);
-        for (int t = threadIdx.x; t < ncfg * 3; t += 256) {
-            const int cfg = t / 3, r = t - cfg * 3;
-            fk_chain_row(rv, r, sc + 14 * cfg, joint(cfg, 7), joint(cfg, 8), [&](int l, double r0, double r1, double r2, double tr) {
-                double* dst = lds_pose + ((size_t)l * pstride + cfg) * 9;  // rows 0 and 1 of R, then t
-                if (r < 2) { dst[3 * r] = r0; dst[3 * r + 1] = r1; dst[3 * r + 2] = r2; }
-                dst[6 + r] = tr;
-            });
-        }
-    }
-    __syncthreads();
-    GS_CLK(0);
-    GS_WG_STAMP(2);
-    const double* base = lds_pose + 9;
-
-    for (int row = threadIdx.x; row < 10 * CH; row += 256) {  // phase A: row-level culling (see k_sdf_chunks)
-        const int l = row / CH, ci = row - l * CH;
-        const double* A = base + ((int64_t)l * pstride + ci) * 9;
-        const float cx = (float)A[6], cy = (float)A[7], cz = (float)A[8];
-        const float rad = (float)rv.radius(l) + 1.0e-4f;
-        uint32_t m = 0;
-        for (int o = o_begin; o < o_end; ++o) {
-            ObjTablePtr ob = as_const(a.objects) + o;
-            if (ob->disabled > 0) continue;
-            const int oo = o - o_begin;
-            const uint32_t bit = 1u << (oo < 31 ? oo : 31);
-            const float ux = __builtin_fmaf(ob->pose_inv[2], cz, __builtin_fmaf(ob->pose_inv[1], cy, __builtin_fmaf(ob->pose_inv[0], cx, ob->pose_inv[3]))) - ob->lo[0];
-            const float uy = __builtin_fmaf(ob->pose_inv[6], cz, __builtin_fmaf(ob->pose_inv[5], cy, __builtin_fmaf(ob->pose_inv[4], cx, ob->pose_inv[7]))) - ob->lo[1];
-            const float uz = __builtin_fmaf(ob->pose_inv[10], cz, __builtin_fmaf(ob->pose_inv[9], cy, __builtin_fmaf(ob->pose_inv[8], cx, ob->pose_inv[11]))) - ob->lo[2];
-            const bool near = (ux >= ob->far_lo[0] - rad) & (ux <= ob->far_hi[0] + rad) & (uy >= ob->far_lo[1] - rad) &
-                              (uy <= ob->far_hi[1] + rad) & (uz >= ob->far_lo[2] - rad) & (uz <= ob->far_hi[2] + rad);
-            const bool cullable = ob->epsilon < 1.0f && ob->clearance <= 1.0f;
-            if (near || !cullable) m |= bit;
-        }
-        rowmask[row] = m;
-    }
-    __syncthreads();
-    GS_CLK(1);
-    GS_WG_STAMP(3);
-
-    float tsum = 0.0f, tcol = 0.0f;
-    for (int ci0 = 0; ci0 < nvalid; ci0 += 16) {  // every lane stays active: invalid items are flagged, not skipped
-        const int ci = ci0 + r;
-        const bool valid = (p < P) && (ci < nvalid);
-        const int cic = valid ? ci : 0, pc = valid ? p : 0;
-#pragma unroll 1
-        for (int l0 = 0; l0 < 10; l0 += LB) {
-            float px[LB], py[LB], pz[LB];
-            uint32_t msk[LB];
-            uint32_t many = 0;
-            Accum acc[LB];
-#pragma unroll
-            for (int k = 0; k < LB; ++k) {
-                msk[k] = valid ? rowmask[(l0 + k) * CH + cic] : 0u;
-                many |= msk[k];
-                acc[k] = Accum{0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-            }
-            if (!__any(many != 0)) { GS_CLK(2); continue; }  // nothing in reach of any row of this wave: potentials stay 0
-#pragma unroll
-            for (int k = 0; k < LB; ++k)
-                pose9_apply(base + ((int64_t)(l0 + k) * pstride + cic) * 9, rv.pts(l0 + k, pc), px[k], py[k], pz[k]);
-            GS_CLK_DEP(3, (px[0] + py[0]) + (pz[LB - 1] + px[LB - 1]));
-            for (int o = o_begin; o < o_end; ++o) {
-                const int oo = o - o_begin;
-                const uint32_t bit = 1u << (oo < 31 ? oo : 31);
-                if (!__any((many & bit) != 0)) continue;
-                ObjTablePtr ob = as_const(a.objects) + o;
-                if (ob->disabled > 0) continue;
-                const ObjParams op = load_object(ob);
-                const float* grid = a.pool + ob->grid_offset;
-                GS_CLK_DEP(4, (op.T[0] + op.i2eps) + (float)op.rw[2]);
-                PairPrep pp[LB];
-                int rank[LB];
-                int total = 0;
-#pragma unroll
-                for (int k = 0; k < LB; ++k) {
-                    pp[k] = pair_prepare(op, px[k], py[k], pz[k]);
-                    const bool live = (msk[k] & bit) && !pp[k].far;
-                    const unsigned long long bal = __ballot(live);
-                    const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-                    rank[k] = live ? total + before : -1;
-                    total += __popcll(bal);
-                }
-                GS_CLK_DEP(5, total + rank[0] + rank[LB - 1]);
-                for (int b0 = 0; b0 < total; b0 += 64) {  // wave-uniform
-#pragma unroll
-                    for (int k = 0; k < LB; ++k)
-                        if (rank[k] >= b0 && rank[k] < b0 + 64) { float* e = scratch + 3 * (rank[k] - b0); e[0] = pp[k].tx; e[1] = pp[k].ty; e[2] = pp[k].tz; }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    GS_CLK(6);
-                    if (lane < total - b0) {
-                        const float tx = scratch[3 * lane], ty = scratch[3 * lane + 1], tz = scratch[3 * lane + 2];
-                        Accum one{0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-                        pair_exact<false>(op, grid, tx, ty, tz, one);
-                        scratch[3 * lane] = one.pot; scratch[3 * lane + 1] = one.col;
-                    }
-                    GS_CLK(7);
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-                    for (int k = 0; k < LB; ++k)
-                        if (rank[k] >= b0 && rank[k] < b0 + 64) {
-                            const float* e = scratch + 3 * (rank[k] - b0);
-                            acc[k].pot += e[0];
-                            acc[k].col += e[1];
-                        }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    GS_CLK(8);
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < LB; ++k) {
-                const int l = l0 + k;
-                if (a.soften && l >= 8) { acc[k].pot *= 0.1f; acc[k].col = 0.0f; }  // cost.py:350-353
-                if (acc[k].pot != 0.0f) {  // ||(x_i - x_{i-1}) / dt|| in float32 (config.py:162-187, cost.py:260-275)
-                    float qx, qy, qz;
-                    pose9_apply(ci > 0 ? base + ((int64_t)l * pstride + ci - 1) * 9 : lds_pose + (int64_t)l * pstride * 9, rv.pts(l, pc), qx, qy, qz);
-                    const float vx = (px[k] - qx) * a.inv_dt, vy = (py[k] - qy) * a.inv_dt, vz = (pz[k] - qz) * a.inv_dt;
-                    acc[k].pot = acc[k].pot * sqrtf(vx * vx + vy * vy + vz * vz);
-                }
-                if (valid && a.pot) a.pot[(((int64_t)s * a.C + chunk * CH + ci) * 10 + l) * P + p] = acc[k].pot;
-                tsum += acc[k].pot;
-                tcol += acc[k].col;
-            }
-            GS_CLK_DEP(9, tsum + tcol);
-        }
-    }
-    // a.pot must also receive the zeros of batches skipped above
-    {
-        const float ws_ = wave_sum(tsum), wc_ = wave_sum(tcol);
-        if (lane == 0) { red[0][wave] = ws_; red[1][wave] = wc_; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const int64_t k = (int64_t)s * a.NCH + chunk;
-            if (a.chunk_cost) a.chunk_cost[k] = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
-            if (a.chunk_col) a.chunk_col[k] = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
-            if (STAMP) { const unsigned long long dt = wall_clock64() - work_t0; a.work[k] = dt < 1 ? 1u : (dt > 0xffffffffull ? 0xffffffffu : (uint32_t)dt); }
-        }
-    }
-    GS_CLK(10);
-    GS_CLK_FLUSH;
-    GS_WG_STAMP(4);
-}
+#include "omg_goalset_queue.h"
 
 // =================================================================================================
 // C ABI
@@ -760,26 +479,33 @@ int omgx_set_error(const char* what, hipError_t e) {
 }
 extern "C" const char* omgx_last_error(void) { return g_err; }
 
-// ---- optional per-launch timing of the dominant kernel (k_sdf_chunks) with HIP events ----------
-// bench.py enables it around its timed region; events are recorded on the launch stream.
+// ---- optional per-launch timing of the goal-set / layer kernel with HIP events ------------------
+// A bench aid (bench.py, tools/): events are attached to the dispatch itself (hipExtLaunchKernelGGL), so they bracket
+// exactly the kernel.  One recorder per process, guarded by a mutex; the events belong to the device that was current
+// when timing was enabled and launches on another device are not recorded.
 #define OMGX_TIMING_CAP 4096
+static std::mutex g_timing_mu;
 static bool g_timing = false;
+static int g_timing_dev = -1;
 static int g_timing_stride = 1, g_timing_seen = 0;  // every g_timing_stride-th eligible launch is bracketed
 static int g_timing_n = 0;
 static hipEvent_t g_ev[OMGX_TIMING_CAP][2];
 static bool g_ev_made[OMGX_TIMING_CAP];
-static int g_ev_kind[OMGX_TIMING_CAP];  // 0 = potentials-only variant (goal-set batch), 1 = gradient variant (waypoints)
+static int g_ev_kind[OMGX_TIMING_CAP];  // 0 = goal-set launch (with or without the trajectory layer), 1 = layer-only launch
 
 extern "C" int omgx_timing_enable(int32_t on) {
+    std::lock_guard<std::mutex> lock(g_timing_mu);
     g_timing = on != 0;
     g_timing_stride = on > 1 ? on : 1;
     g_timing_seen = 0;
     g_timing_n = 0;
+    if (g_timing && hipGetDevice(&g_timing_dev) != hipSuccess) { g_timing = false; return OMGX_ERR_LAUNCH; }
     return OMGX_OK;
 }
 
 // Waits for the recorded launches and writes their durations in milliseconds; returns the count.
 extern "C" int omgx_timing_collect(float* h_ms, int32_t* h_kind, int32_t cap) {
+    std::lock_guard<std::mutex> lock(g_timing_mu);
     int n = g_timing_n < cap ? g_timing_n : cap;
     for (int i = 0; i < n; ++i) {
         if (h_kind) h_kind[i] = g_ev_kind[i];
@@ -792,15 +518,22 @@ extern "C" int omgx_timing_collect(float* h_ms, int32_t* h_kind, int32_t cap) {
     return n;
 }
 
-static inline int timing_slot() {
-    if (!g_timing || g_timing_n >= OMGX_TIMING_CAP) return -1;
-    if (g_timing_seen++ % g_timing_stride != 0) return -1;  // sampled: an event pair costs ~6 us of stream time per launch
+// Reserves an event pair for a launch of `kind` (nullptr, nullptr when this launch is not recorded).
+static void timing_events(int kind, hipEvent_t* ev0, hipEvent_t* ev1) {
+    *ev0 = *ev1 = nullptr;
+    if (!g_timing) return;  // unlocked fast path: the flag only changes between benchmark phases
+    std::lock_guard<std::mutex> lock(g_timing_mu);
+    int dev = -1;
+    if (!g_timing || g_timing_n >= OMGX_TIMING_CAP || hipGetDevice(&dev) != hipSuccess || dev != g_timing_dev) return;
+    if (g_timing_seen++ % g_timing_stride != 0) return;  // sampled: an event pair costs ~6 us of stream time per launch
     const int i = g_timing_n;
     if (!g_ev_made[i]) {
-        if (hipEventCreate(&g_ev[i][0]) != hipSuccess || hipEventCreate(&g_ev[i][1]) != hipSuccess) return -1;
+        if (hipEventCreate(&g_ev[i][0]) != hipSuccess || hipEventCreate(&g_ev[i][1]) != hipSuccess) return;
         g_ev_made[i] = true;
     }
-    return i;
+    g_ev_kind[i] = kind;
+    *ev0 = g_ev[i][0]; *ev1 = g_ev[i][1];
+    ++g_timing_n;
 }
 extern "C" int omgx_abi_version(void) { return 4; }  // 2: `active` masks; 3: ragged goal sets (goal_count, eta); 4: goal schedule + work
 extern "C" int omgx_device_arch(char* h_buf, int32_t h_len) {
@@ -903,60 +636,54 @@ extern "C" int64_t omgx_goalset_workspace_bytes(int32_t num_scenes, int32_t num_
     return poses + start;
 }
 
+// dynamic LDS and grid of a k_goalset_queue launch (goal workgroups and / or trajectory-layer workgroups)
+static int launch_goalset(ChunkArgs& ca, int timing_kind, hipStream_t st) {
+    const int scene_groups = (ca.S + 7) / 8;
+    const bool layer = ca.wp_traj != nullptr;
+    ca.PS = ca.CH + 1; ca.MR = ca.CH; ca.LPW = 10;
+    if (layer) { if (ca.wp_n > ca.PS) ca.PS = ca.wp_n; if (ca.wp_n > ca.MR) ca.MR = ca.wp_n; }
+    const int64_t grid = (int64_t)scene_groups * (ca.NCH + (layer ? GS_LAYER_PARTS : 0)) * 8;
+    if (grid > 0x7fffffff) return OMGX_ERR_UNSUPPORTED;
+    const size_t lds = (size_t)GqLayout(ca.PS, ca.MR, ca.P).total;
+    hipEvent_t ev0, ev1;
+    timing_events(timing_kind, &ev0, &ev1);
+    if (ca.work) {
+        if (ev0) hipExtLaunchKernelGGL((k_goalset_queue<2, true>), dim3((unsigned)grid), dim3(256), (uint32_t)lds, st, ev0, ev1, 0, ca);
+        else hipLaunchKernelGGL((k_goalset_queue<2, true>), dim3((unsigned)grid), dim3(256), lds, st, ca);
+    } else {
+        if (ev0) hipExtLaunchKernelGGL((k_goalset_queue<2, false>), dim3((unsigned)grid), dim3(256), (uint32_t)lds, st, ev0, ev1, 0, ca);
+        else hipLaunchKernelGGL((k_goalset_queue<2, false>), dim3((unsigned)grid), dim3(256), lds, st, ca);
+    }
+    OMGX_CHECK_LAUNCH("k_goalset_queue");
+    return OMGX_OK;
+}
+
+// k_sdf_chunks over poses in the workspace (omgx_fk_sdf beyond a trajectory-sized layer) or with its own kinematics
+// (goal-set batch with per-point potentials)
 static int launch_chunks(ChunkArgs& ca, hipStream_t st) {
     const int scene_groups = (ca.S + 7) / 8;
-    // Small batches (the S*n waypoint configurations of an optimiser step) would leave most CUs idle with one
-    // workgroup per (scene, chunk): split the 10 links over workgroups until ~4 workgroups per CU exist.
-    // Per-chunk reductions need all links in one workgroup.
+    // Small batches would leave most CUs idle with one workgroup per (scene, chunk): split the 10 links over workgroups
+    // until ~4 workgroups per CU exist.  Per-chunk reductions need all links in one workgroup.
     int lpw = 10;
     if (!ca.chunk_cost && !ca.chunk_col) {
         const int64_t wgs = (int64_t)scene_groups * ca.NCH * 8;
         if (wgs * 5 <= 1024) lpw = 2; else if (wgs * 2 <= 1024) lpw = 5;
     }
     ca.LPW = lpw;
-    const bool layer = ca.wp_traj != nullptr;  // only with k_goalset_compact (checked by the caller)
-    ca.PS = ca.CH + 1; ca.MR = ca.CH;
-    if (layer) { if (ca.wp_n > ca.PS) ca.PS = ca.wp_n; if (ca.wp_n > ca.MR) ca.MR = ca.wp_n; }
-    const int64_t grid = (int64_t)scene_groups * (ca.NCH + (layer ? GS_LAYER_PARTS : 0)) * 8 * (10 / lpw);
+    const int64_t grid = (int64_t)scene_groups * ca.NCH * 8 * (10 / lpw);
     if (grid > 0x7fffffff) return OMGX_ERR_UNSUPPORTED;
-    // Timed launches attach the start/stop events to the dispatch itself (hipExtLaunchKernelGGL): the events then
-    // bracket exactly this kernel and cost no extra packets on the stream.
-    const int slot = timing_slot();
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    if (slot >= 0) { g_ev_kind[slot] = ca.grad ? 1 : 0; ev0 = g_ev[slot][0]; ev1 = g_ev[slot][1]; ++g_timing_n; }
-#define OMGX_LAUNCH(KERNEL_, LDS_)                                                                                       \
-    do {                                                                                                                 \
-        if (ev0) hipExtLaunchKernelGGL(KERNEL_, dim3((unsigned)grid), dim3(256), (uint32_t)(LDS_), st, ev0, ev1, 0, ca); \
-        else hipLaunchKernelGGL(KERNEL_, dim3((unsigned)grid), dim3(256), (LDS_), st, ca);                               \
-    } while (0)
-    // links per batch; OMGX_LB overrides the tuned default (tuning aid).  Read once (thread-safe static initialisation).
-    static const int lb = [] { const char* e = getenv("OMGX_LB"); return e ? atoi(e) : 2; }();
-    int lbu = lb;
-    if (lpw % lbu != 0) lbu = 1;  // the link batch must divide the links of a workgroup
     const size_t mask_bytes = (size_t)10 * ca.CH * sizeof(uint32_t);
-#define OMGX_LAUNCH_CHUNKS(G_, LB_) OMGX_LAUNCH((k_sdf_chunks<G_, LB_, false>), mask_bytes)
-    // OMGX_COMPACT=0 keeps the unpacked exact path (A/B measurements)
-    static const int compact = [] { const char* e = getenv("OMGX_COMPACT"); return e ? atoi(e) : 1; }();
-    if (ca.traj_start && compact && !ca.pot) {  // goal-set batch, cost only: packed exact path
-        size_t tail = (((size_t)10 * ca.MR + 3) & ~(size_t)3) * sizeof(uint32_t) + 4 * 64 * 3 * sizeof(float);  // row masks + scratch
-        const size_t sincos = (size_t)ca.PS * 14 * sizeof(double);                                             // FK stage 1 table
-        if (tail < sincos) tail = sincos;
-        const size_t lds = (size_t)ca.PS * 90 * sizeof(double) + tail;
-        if (ca.work) OMGX_LAUNCH((k_goalset_compact<2, true>), lds);
-        else OMGX_LAUNCH((k_goalset_compact<2>), lds);
-    } else if (ca.traj_start) {  // fused FK (goal-set batch): dynamic LDS holds (CH + 1) x 10 poses
+    const int lb = lpw % 2 == 0 ? 2 : 1;  // links per batch (2 measured best); it must divide the links of a workgroup
+    if (ca.traj_start) {  // goal-set batch with potentials: the workgroup's own kinematics, (CH + 1) x 10 poses in LDS
         const size_t lds = (size_t)(ca.CH + 1) * 120 * sizeof(double) + mask_bytes;
-        if (lbu == 1) OMGX_LAUNCH((k_sdf_chunks<false, 1, true>), lds);
-        else OMGX_LAUNCH((k_sdf_chunks<false, 2, true>), lds);
+        hipLaunchKernelGGL((k_sdf_chunks<false, 2, true>), dim3((unsigned)grid), dim3(256), lds, st, ca);
     } else if (ca.grad) {
-        if (lbu == 1) OMGX_LAUNCH_CHUNKS(true, 1); else if (lbu == 2) OMGX_LAUNCH_CHUNKS(true, 2);
-        else if (lbu == 10) OMGX_LAUNCH_CHUNKS(true, 10); else OMGX_LAUNCH_CHUNKS(true, 5);
+        if (lb == 2) hipLaunchKernelGGL((k_sdf_chunks<true, 2, false>), dim3((unsigned)grid), dim3(256), mask_bytes, st, ca);
+        else hipLaunchKernelGGL((k_sdf_chunks<true, 1, false>), dim3((unsigned)grid), dim3(256), mask_bytes, st, ca);
     } else {
-        if (lbu == 1) OMGX_LAUNCH_CHUNKS(false, 1); else if (lbu == 2) OMGX_LAUNCH_CHUNKS(false, 2);
-        else if (lbu == 10) OMGX_LAUNCH_CHUNKS(false, 10); else OMGX_LAUNCH_CHUNKS(false, 5);
+        if (lb == 2) hipLaunchKernelGGL((k_sdf_chunks<false, 2, false>), dim3((unsigned)grid), dim3(256), mask_bytes, st, ca);
+        else hipLaunchKernelGGL((k_sdf_chunks<false, 1, false>), dim3((unsigned)grid), dim3(256), mask_bytes, st, ca);
     }
-#undef OMGX_LAUNCH_CHUNKS
-#undef OMGX_LAUNCH
     OMGX_CHECK_LAUNCH("k_sdf_chunks");
     return OMGX_OK;
 }
@@ -975,31 +702,15 @@ extern "C" int omgx_fk_sdf(const double* robot, int32_t n_points, const omgx_obj
         if (arc_length > OMGX_MAX_WAYPOINTS || configs_per_scene % arc_length != 0) return OMGX_ERR_UNSUPPORTED;
     }
     hipStream_t st = (hipStream_t)stream;
-    const char* fast_env = getenv("OMGX_LAYER_FAST");  // =0 keeps the two-launch path (A/B measurements, cross-check in the tests)
-    const int fast = fast_env ? atoi(fast_env) : 1;
-    if (fast && !arc && potentials && grads && collides && configs_per_scene <= OMGX_MAX_WAYPOINTS) {
-        // A trajectory-sized layer (the optimiser's input): the goal-set kernel's layer workgroups alone — FK in LDS,
-        // GS_LAYER_PARTS workgroups per scene, one launch instead of k_fk_poses + k_sdf_chunks.  Same arithmetic.
+    if (!arc && potentials && grads && collides && configs_per_scene <= OMGX_MAX_WAYPOINTS) {
+        // A trajectory-sized layer (the optimiser's input): the goal-set kernel's layer workgroups alone — kinematics in
+        // LDS, GS_LAYER_PARTS workgroups per scene, one launch instead of k_fk_poses + k_sdf_chunks.  Same arithmetic.
         ChunkArgs ca{};
         ca.robot = robot; ca.objects = objects; ca.scene_begin = scene_begin; ca.pool = sdf_pool;
         ca.S = num_scenes; ca.P = n_points; ca.NCH = 0; ca.CH = 0; ca.C = 0;
         ca.wp_traj = joints; ca.wp_n = configs_per_scene; ca.wp_soften = soften_fingers != 0;
         ca.wp_pot = potentials; ca.wp_grad = grads; ca.wp_col = collides;
-        ca.PS = configs_per_scene; ca.MR = configs_per_scene; ca.LPW = 10;
-        const int64_t grid = (int64_t)((num_scenes + 7) / 8) * GS_LAYER_PARTS * 8;
-        size_t tail = (((size_t)10 * ca.MR + 3) & ~(size_t)3) * sizeof(uint32_t) + 4 * 64 * 3 * sizeof(float);
-        const size_t sincos = (size_t)ca.PS * 14 * sizeof(double);
-        if (tail < sincos) tail = sincos;
-        const size_t lds = (size_t)ca.PS * 90 * sizeof(double) + tail;
-        const int slot = timing_slot();
-        if (slot >= 0) {
-            g_ev_kind[slot] = 1; ++g_timing_n;
-            hipExtLaunchKernelGGL((k_goalset_compact<2>), dim3((unsigned)grid), dim3(256), (uint32_t)lds, st, g_ev[slot][0], g_ev[slot][1], 0, ca);
-        } else {
-            hipLaunchKernelGGL((k_goalset_compact<2>), dim3((unsigned)grid), dim3(256), lds, st, ca);
-        }
-        OMGX_CHECK_LAUNCH("k_goalset_compact (layer only)");
-        return OMGX_OK;
+        return launch_goalset(ca, 1, st);
     }
     const int CH = arc ? arc_length : chunk_configs_fk_sdf(configs_per_scene);
     const int NCH = (configs_per_scene + CH - 1) / CH;
@@ -1075,43 +786,31 @@ static int goalset_cost_impl(const double* robot, int32_t n_points, const omgx_o
                              uint32_t* work, void* stream) {
     if (num_scenes < 0 || num_goals < 0) return OMGX_ERR_INVALID;
     if (num_scenes == 0 || num_goals == 0) return OMGX_OK;
-    if (!robot || !objects || !scene_begin || !traj_start || !goals || !goal_cost || !workspace) return OMGX_ERR_INVALID;
+    if (!robot || !objects || !scene_begin || !traj_start || !goals || !goal_cost) return OMGX_ERR_INVALID;
     if (n_points < 1 || n_points > OMGX_MAX_POINTS || n_remaining < 1 || n_remaining > OMGX_MAX_WAYPOINTS)
         return OMGX_ERR_UNSUPPORTED;
     if (!(time_interval > 0.0) || traj_start_stride < 9) return OMGX_ERR_INVALID;
     hipStream_t st = (hipStream_t)stream;
     const int n = n_remaining, C = num_goals * n;
-    double* ws = (double*)workspace;
-    double* ws_start = ws + (int64_t)num_scenes * num_goals * 10 * n * 12;
-    // OMGX_FUSED_FK=0 keeps the separate FK launch (A/B measurements)
-    static const int fused = [] { const char* e = getenv("OMGX_FUSED_FK"); return e ? atoi(e) : 1; }();
-    static const int compact = [] { const char* e = getenv("OMGX_COMPACT"); return e ? atoi(e) : 1; }();
-    if (layer_traj) {  // the trajectory layer rides on k_goalset_compact only
+    if (layer_traj) {  // the trajectory layer rides on k_goalset_queue (cost-only batch)
         if (!layer_pot || !layer_grad || !layer_col) return OMGX_ERR_INVALID;
         if (layer_n < 1 || layer_n > OMGX_MAX_WAYPOINTS) return OMGX_ERR_UNSUPPORTED;
-        if (potentials || !fused || !compact) return OMGX_ERR_UNSUPPORTED;
+        if (potentials) return OMGX_ERR_UNSUPPORTED;
     }
-    if (!fused) {
-        FkArgs fa{};
-        fa.robot = robot; fa.P = n_points; fa.mode = 1; fa.traj_start = traj_start; fa.ts_stride = traj_start_stride; fa.goals = goals; fa.S = num_scenes;
-        fa.C = C; fa.n = n; fa.CH = n; fa.ws = ws; fa.ws_start = ws_start;
-        const int64_t total = (int64_t)num_scenes * (C + 1);
-        hipLaunchKernelGGL(k_fk_poses, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, st, fa);
-        OMGX_CHECK_LAUNCH("k_fk_poses");
-    }
+    if ((active || goal_count || schedule || work) && potentials) return OMGX_ERR_UNSUPPORTED;  // masks and schedules live in k_goalset_queue
     ChunkArgs ca{};
-    ca.robot = robot; ca.objects = objects; ca.scene_begin = scene_begin; ca.pool = sdf_pool; ca.ws = ws; ca.ws_start = ws_start;
+    ca.robot = robot; ca.objects = objects; ca.scene_begin = scene_begin; ca.pool = sdf_pool;
     ca.S = num_scenes; ca.C = C; ca.CH = n; ca.NCH = num_goals; ca.P = n_points; ca.soften = soften_fingers != 0;
     ca.arc = 1; ca.inv_dt = (float)(1.0 / time_interval);
     ca.pot = potentials; ca.grad = nullptr; ca.col = nullptr; ca.chunk_cost = goal_cost; ca.chunk_col = collides;
-    if (fused) { ca.traj_start = traj_start; ca.ts_stride = traj_start_stride; ca.goals = goals; }
+    ca.traj_start = traj_start; ca.ts_stride = traj_start_stride; ca.goals = goals;  // every workgroup runs its own kinematics
     if (layer_traj) {
         ca.wp_traj = layer_traj; ca.wp_n = layer_n; ca.wp_soften = layer_soften != 0;
         ca.wp_pot = layer_pot; ca.wp_grad = layer_grad; ca.wp_col = layer_col;
     }
-    if ((active || goal_count || schedule || work) && !(fused && compact && !potentials)) return OMGX_ERR_UNSUPPORTED;  // the masks live in k_goalset_compact
     ca.active = active; ca.goal_count = goal_count; ca.schedule = schedule; ca.work = work;
-    return launch_chunks(ca, st);
+    (void)workspace;  // kept in the signature (ABI): no launch of this entry point spills poses to memory any more
+    return potentials ? launch_chunks(ca, st) : launch_goalset(ca, 0, st);
 }
 
 extern "C" int omgx_goalset_cost(const double* robot, int32_t n_points, const omgx_object* objects,
@@ -1119,10 +818,10 @@ extern "C" int omgx_goalset_cost(const double* robot, int32_t n_points, const om
                                  int64_t traj_start_stride, const double* goals, int32_t num_scenes, int32_t num_goals,
                                  int32_t n_remaining,
                                  double time_interval, int32_t soften_fingers, float* goal_cost, float* potentials,
-                                 float* collides, void* workspace, void* stream) {
+                                 float* collides, void* workspace, const int32_t* active, const int32_t* goal_count, void* stream) {
     return goalset_cost_impl(robot, n_points, objects, scene_begin, sdf_pool, traj_start, traj_start_stride, goals, num_scenes,
                              num_goals, n_remaining, time_interval, soften_fingers, goal_cost, potentials, collides, workspace,
-                             nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
+                             nullptr, 0, 0, nullptr, nullptr, nullptr, active, goal_count, nullptr, nullptr, stream);
 }
 
 extern "C" int omgx_goalset_cost_layer(const double* robot, int32_t n_points, const omgx_object* objects,

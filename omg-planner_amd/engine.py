@@ -22,8 +22,6 @@ closes the job (``gather_costs``).
 """
 from __future__ import annotations
 
-import os
-
 import numpy as np
 import torch
 
@@ -44,6 +42,12 @@ _ALL_DONE_CHECKS = frozenset((1, 2, 3, 5, 8, 13, 21, 34, 55))  # iterations afte
 
 
 class ChompEngine:
+    # learner and step of a scene in different workgroups of omgx_goal_update_optimize (None: whenever both sets are resident
+    # at once, 2 S <= CUs — beyond that the single-workgroup kernel is a little faster; True / False force it)
+    split_update = None
+    # True: iterate() goes through iterate_separate(), the five separate entry points (cross-checks)
+    separate_launches = False
+
     def __init__(self, model: PandaModel, batch: SceneBatch, cfg: Config, start: np.ndarray, goal_set: np.ndarray,
                  reach_grasps: np.ndarray | None = None, traj_init: np.ndarray | None = None, device="cuda:0",
                  ol_alg: str = "FTL", stream: "torch.cuda.Stream | None" = None, goal_counts=None):
@@ -113,11 +117,6 @@ class ChompEngine:
         self._masked = False  # becomes True with the first early_stop iteration or when `active` is assigned: launches then take the mask
         self.step_count = 0  # Optimizer.step
         self.t = 0           # Learner.t
-        # The waypoint SDF batch (omgx_fk_sdf on traj) does not depend on the goal selection, only k_chomp_optimize
-        # does: it runs on a side stream concurrently with the goal-set batch + goal update and joins before the step.
-        self.side_stream = torch.cuda.Stream(device=dev, priority=-1)  # high priority: its few workgroups slot in early
-        self._ev_fork = torch.cuda.Event()
-        self._ev_join = torch.cuda.Event()
         self._scene_flags = torch.zeros(S, dtype=torch.int32, device=dev)  # omgx_goal_update_optimize's rendezvous
         # Dispatch order of the goal-set launch.  The first launch of a plan runs in scene-major order and records every goal
         # workgroup's duration in `work`; build_schedule() turns that — on the device, no host sync — into the order of all
@@ -230,7 +229,8 @@ class ChompEngine:
                     self.schedule = self.build_schedule()
             else:
                 ops.goalset_cost(self.robot, self.P, self.scenes, traj_start, self.cv_goals, n_rem, self.cfg.time_interval,
-                                 soften_fingers=False, out=(self.goal_cost, self.goal_col))
+                                 soften_fingers=False, out=(self.goal_cost, self.goal_col), active=self._mask(),
+                                 goal_count=self.goal_count)
         elif with_layer:
             self._layer()
         if defer_update:
@@ -272,7 +272,7 @@ class ChompEngine:
         if learner_prm is not None:  # goal update + step in one launch
             # learner and step in different workgroups of the launch: pays while both sets are resident at once (one
             # 92 KB-LDS workgroup per CU); beyond that the single-workgroup kernel is a little faster (measured at 200 / 400 scenes)
-            split = not os.environ.get("OMGX_NO_SPLIT_UPDATE") and (2 * self.S <= self._num_cus or os.environ.get("OMGX_FORCE_SPLIT_UPDATE"))
+            split = 2 * self.S <= self._num_cus if self.split_update is None else bool(self.split_update)
             self._ticket += 1
             ops.goal_update_optimize(learner_prm, self.goal_set, self.reach, self.goal_cost, self.learner_state, self.goal_idx,
                                      self.robot, self._params(do_update), self.traj, self.start, self.end, self.goal_rows,
@@ -292,49 +292,48 @@ class ChompEngine:
         self._layer()
         return self._step(do_update)
 
-    def iterate(self, t: int, early_stop: bool = False, overlap: bool = True):
-        """One pass of the planner loop body (planner.py:612-621) over all scenes."""
+    def iterate(self, t: int, early_stop: bool = False):
+        """One pass of the planner loop body (planner.py:612-621) over all scenes: two launches on one stream —
+        omgx_goalset_cost_layer (goal-set batch + SDF layer of the current trajectories) and omgx_goal_update_optimize
+        (Learner.update_goal + Optimizer.optimize); once the goal is fixed (t >= optim_steps, "Proj", "Baseline") the layer
+        launch and the step."""
         if self.stream is not None and torch.cuda.current_stream(self.device) != self.stream:
             with torch.cuda.stream(self.stream):
-                return self.iterate(t, early_stop, overlap)
+                return self.iterate(t, early_stop)
+        if self.separate_launches:
+            return self.iterate_separate(t, early_stop)
         cfg = self.cfg
         # planner.py:609-618: the learner runs only for the online-learning rules; "Proj" and "Baseline" keep the goal that
         # was fixed before planning (select_initial_goal)
         select = cfg.goal_set_proj and t < cfg.optim_steps and self.ol_alg not in ("Baseline", "Proj")
-        if os.environ.get("OMGX_NO_OVERLAP"):  # profiling aid: device-wide PMC counters need kernels one at a time
-            overlap = False
-        mode = os.environ.get("OMGX_ITERATION", "fused")  # fused | streams | serial (A/B measurements)
-        if os.environ.get("OMGX_NO_OVERLAP"):  # profiling aid: device-wide PMC counters need kernels one at a time
-            mode = "serial"
         # planner.py:626-627 (a scene that terminates at t > 0 leaves the loop): the step itself clears active[s] — no extra
         # kernels between iterations; the goal-set launch, the goal update and the step skip scenes with active[s] == 0
         stop = bool(early_stop and t > 0)
         if early_stop:
             self._masked = True
-        if select and mode == "fused" and self.ol_alg != "Baseline":
-            # two launches on one stream: goal-set batch + trajectory layer, then goal update + optimiser step
+        if select:
             lprm = self.update_goal(defer_update=True, with_layer=True)
             self._schedule()
             self._step(True, lprm, stop_on_terminate=stop)
-        elif select and overlap and mode == "streams":
-            # the trajectory layer on a side stream, concurrent with the goal-set batch; joined before the step
-            main = torch.cuda.current_stream(self.device)
-            self._ev_fork.record(main)
-            self.side_stream.wait_event(self._ev_fork)
-            with torch.cuda.stream(self.side_stream):
-                self._layer()
-                self._ev_join.record(self.side_stream)
-            fuse = not os.environ.get("OMGX_NO_FUSED_UPDATE")
-            lprm = self.update_goal(defer_update=fuse)
-            self._schedule()
-            main.wait_event(self._ev_join)
-            self._step(True, lprm, stop_on_terminate=stop)
         else:
-            self._layer()  # needs only the trajectory: first, so that nothing sits between the goal-set batch and the step
-            fuse = not os.environ.get("OMGX_NO_FUSED_UPDATE")
-            lprm = self.update_goal(defer_update=fuse) if select else None
+            self._layer()
             self._schedule()
-            self._step(True, lprm, stop_on_terminate=stop)
+            self._step(True, None, stop_on_terminate=stop)
+
+    def iterate_separate(self, t: int, early_stop: bool = False):
+        """The same iteration composed from the separate entry points the drop-in classes use — omgx_goalset_cost,
+        omgx_goal_update, omgx_fk_sdf, omgx_chomp_optimize (five launches).  Same results as iterate(); kept as the
+        cross-check of the fused launches (tests) and as the reference composition for callers of the C ABI."""
+        cfg = self.cfg
+        select = cfg.goal_set_proj and t < cfg.optim_steps and self.ol_alg not in ("Baseline", "Proj")
+        stop = bool(early_stop and t > 0)
+        if early_stop:
+            self._masked = True
+        self._layer()
+        if select:
+            self.update_goal()
+        self._schedule()
+        self._step(True, None, stop_on_terminate=stop)
 
     # ---------------------------------------------------------------------------------------------
     _STATE = ("traj", "end", "goal_rows", "goal_point", "goal_idx", "learner_state", "info", "active", "goal_cost", "goal_col",

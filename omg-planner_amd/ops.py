@@ -95,9 +95,11 @@ def fk_sdf(robot: torch.Tensor, P: int, scenes: DeviceScenes, joints: torch.Tens
 
 
 def goalset_cost(robot, P, scenes: DeviceScenes, traj_start, goals, n_remaining, dt, soften_fingers=False,
-                 want_potentials=False, out=None):
+                 want_potentials=False, out=None, active=None, goal_count=None):
     """traj_start [S,9], goals [S,G,9] f64 -> goal_cost [S,G] f32, collides [S,G] f32, potentials [S,G,n,10,P] | None.
-    traj_start may be a strided row view such as traj[:, k] of a contiguous [S,n,9] tensor (no copy is made)."""
+    traj_start may be a strided row view such as traj[:, k] of a contiguous [S,n,9] tensor (no copy is made).
+    active / goal_count [S] int32 (optional, not with want_potentials): scenes with 0 and the padding goals of a ragged
+    goal set are skipped; their outputs keep their previous contents."""
     if not (traj_start.is_cuda and traj_start.dtype == torch.float64 and traj_start.dim() == 2 and traj_start.shape[1] == 9
             and traj_start.stride(1) == 1 and (traj_start.shape[0] == 1 or traj_start.stride(0) >= 9)):
         raise _lib.OmgHipError("traj_start must be a float64 device tensor [S,9] with unit inner stride")
@@ -116,7 +118,8 @@ def goalset_cost(robot, P, scenes: DeviceScenes, traj_start, goals, n_remaining,
         ws = _workspace(l.omgx_goalset_workspace_bytes(S, G, n_remaining, P), dev)
         check(l.omgx_goalset_cost(_ptr(robot), P, _ptr(scenes.objects), _ptr(scenes.scene_begin), _ptr(scenes.pool),
                                   _ptr(traj_start), ts_stride, _ptr(goals), S, G, n_remaining, float(dt), int(bool(soften_fingers)),
-                                  _ptr(cost), _ptr(pots), _ptr(col), _ptr(ws), _stream()), "omgx_goalset_cost")
+                                  _ptr(cost), _ptr(pots), _ptr(col), _ptr(ws), _ptr(_active(active, S)), _ptr(_active(goal_count, S)),
+                                  _stream()), "omgx_goalset_cost")
     return cost, col, pots
 
 

@@ -118,11 +118,9 @@ def trial(rng, k, dev):
     soft = bool(rng.rand() < 0.3)
     rp, rg, rc = orc.fk_sdf(blob, P, batch, q, soften_fingers=soft)
     STATS["layer_points"] += rp.size; STATS["layer_nonzero"] += int((rp != 0).sum()); STATS["layer_collide"] += int((rc != 0).sum())
-    for fast in ("1", "0"):
-        os.environ["OMGX_LAYER_FAST"] = fast
-        p_, g_, c_ = ops.fk_sdf(robot, P, ds, torch.as_tensor(q, device=dev), soften_fingers=soft)
-        same(f"fk_sdf[fast={fast}].pot", p_, rp); same(f"fk_sdf[fast={fast}].grad", g_, rg); same(f"fk_sdf[fast={fast}].col", c_, rc)
-    os.environ.pop("OMGX_LAYER_FAST", None)
+    # C <= 64: the layer workgroups of k_goalset_queue; C = 70: k_fk_poses + k_sdf_chunks<true>
+    p_, g_, c_ = ops.fk_sdf(robot, P, ds, torch.as_tensor(q, device=dev), soften_fingers=soft)
+    same("fk_sdf.pot", p_, rp); same("fk_sdf.grad", g_, rg); same("fk_sdf.col", c_, rc)
     # (3) goal-set batch with and without potentials
     G, n = int(rng.randint(1, 6)), int(rng.choice([1, 7, 30, 50]))
     starts, goals = rng.uniform(lo, hi, (S, 9)), rng.uniform(lo, hi, (S, G, 9))

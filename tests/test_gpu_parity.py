@@ -840,17 +840,13 @@ def test_fused_update_optimize_equals_separate_launches(dev, alg, standoff, n, m
     import copy
     outs = []
     for mode in ("split", "fused", "separate"):
-        monkeypatch.delenv("OMGX_NO_SPLIT_UPDATE", raising=False)
-        monkeypatch.delenv("OMGX_NO_FUSED_UPDATE", raising=False)
-        if mode == "split":    # two launches: goal-set batch + trajectory layer | learner and step in different workgroups
-            monkeypatch.setenv("OMGX_ITERATION", "fused")
-        elif mode == "fused":  # two launches, learner then step in one workgroup
-            monkeypatch.setenv("OMGX_ITERATION", "fused")
-            monkeypatch.setenv("OMGX_NO_SPLIT_UPDATE", "1")
-        else:                  # five launches: FK, trajectory layer, goal-set batch, goal update, step
-            monkeypatch.setenv("OMGX_NO_FUSED_UPDATE", "1")
-            monkeypatch.setenv("OMGX_ITERATION", "serial")
         eng = ChompEngine(m, batch, copy.deepcopy(cfg0), start, goals, reach_grasps=reach, device=dev, ol_alg=alg)
+        if mode == "split":    # two launches: goal-set batch + trajectory layer | learner and step in different workgroups
+            eng.split_update = True
+        elif mode == "fused":  # two launches, learner then step in one workgroup
+            eng.split_update = False
+        else:                  # five launches: trajectory layer, goal-set batch, goal update, step (iterate_separate)
+            eng.separate_launches = True
         for t in range(5):
             eng.iterate(t)
         torch.cuda.synchronize()
@@ -869,7 +865,7 @@ def test_engine_plan_matches_reference_planner_loop(dev, case, mode, monkeypatch
     evaluation; omg/planner.py:600-653), free-running for up to 70 iterations: same goal sequence, trajectories 1e-6."""
     from omg_planner_amd.config import Config
     from omg_planner_amd.engine import ChompEngine
-    monkeypatch.setenv("OMGX_ITERATION", mode)
+    monkeypatch.setattr(ChompEngine, "separate_launches", mode == "serial")
     fx = H.load(f"plan_{case}.npz")
     m, batch = H.model_from(fx), H.batch_from(fx)
     standoff = bool(int(fx["cfg_use_standoff"]))
@@ -949,7 +945,7 @@ def test_inactive_scenes_are_left_alone(dev, mode, monkeypatch):
     from omg_planner_amd.config import Config
     from omg_planner_amd.engine import ChompEngine
     import copy
-    monkeypatch.setenv("OMGX_ITERATION", mode)
+    monkeypatch.setattr(ChompEngine, "separate_launches", mode == "serial")
     S, G, n = 11, 6, 30
     m = rb.PandaModel(seed=3)
     scenes, batch = _multi_scene_batch(S)
@@ -1077,7 +1073,7 @@ def test_ragged_goal_sets_equal_single_scene_runs(dev, alg, standoff, mode, monk
     from omg_planner_amd.config import Config
     from omg_planner_amd.engine import ChompEngine
     import copy
-    monkeypatch.setenv("OMGX_ITERATION", mode)
+    monkeypatch.setattr(ChompEngine, "separate_launches", mode == "serial")
     counts = [3, 7, 1, 5, 7, 2]
     S, G, n = len(counts), max(counts), 30
     m = rb.PandaModel(seed=5)
@@ -1146,10 +1142,12 @@ def test_two_launch_entry_points_reject_bad_arguments(dev, monkeypatch):
            torch.empty((1, n, 10, P), dtype=torch.float32, device=dev))
     c1, k1 = ops.goalset_cost_layer(robot, P, ds, tt[:, 5], gg, n - 5, 0.1, tt, lay)
     c2, k2, _ = ops.goalset_cost(robot, P, ds, tt[:, 5], gg, n - 5, 0.1)
-    monkeypatch.setenv("OMGX_LAYER_FAST", "0")  # the two-launch path of omgx_fk_sdf: k_fk_poses + k_sdf_chunks<true>
-    p2, g2, o2 = ops.fk_sdf(robot, P, ds, tt)
-    monkeypatch.delenv("OMGX_LAYER_FAST")
-    p3, g3, o3 = ops.fk_sdf(robot, P, ds, tt)   # the single-launch path (layer workgroups of k_goalset_compact)
+    # omgx_fk_sdf beyond OMGX_MAX_WAYPOINTS configurations takes its two-launch path (k_fk_poses + k_sdf_chunks<true>), a
+    # trajectory-sized layer the layer workgroups of k_goalset_queue: same arithmetic, bit-identical outputs
+    big = tt.repeat(1, 6, 1)[:, :70].contiguous()
+    pb, gb, ob = ops.fk_sdf(robot, P, ds, big)
+    p2, g2, o2 = pb[:, :n].contiguous(), gb[:, :n].contiguous(), ob[:, :n].contiguous()
+    p3, g3, o3 = ops.fk_sdf(robot, P, ds, tt)
     assert torch.equal(p2, p3) and torch.equal(g2, g3) and torch.equal(o2, o3)
     assert torch.equal(c1, c2) and torch.equal(k1, k2)
     assert torch.equal(lay[0], p2.view_as(lay[0])) and torch.equal(lay[1], g2.view_as(lay[1])) and torch.equal(lay[2], o2.view_as(lay[2]))
@@ -1177,14 +1175,8 @@ def test_split_update_with_more_scenes_than_compute_units(dev, monkeypatch):
     cfg0.get_global_param(n)
     outs = []
     for split in (True, False):
-        monkeypatch.setenv("OMGX_ITERATION", "fused")
-        if split:  # the engine would not split this many scenes by itself
-            monkeypatch.delenv("OMGX_NO_SPLIT_UPDATE", raising=False)
-            monkeypatch.setenv("OMGX_FORCE_SPLIT_UPDATE", "1")
-        else:
-            monkeypatch.delenv("OMGX_FORCE_SPLIT_UPDATE", raising=False)
-            monkeypatch.setenv("OMGX_NO_SPLIT_UPDATE", "1")
         eng = ChompEngine(m, batch, copy.deepcopy(cfg0), start, goals, device=dev, ol_alg="MD")
+        eng.split_update = split  # the engine would not split this many scenes by itself
         for t in range(3):
             eng.iterate(t)
         torch.cuda.synchronize()
@@ -1280,7 +1272,9 @@ def test_goalset_full_size_properties(dev):
     # potentials of a slice of scenes: per-goal cost == sum over its [n,10,P] potentials (float32, loose order tolerance)
     sub = sc.SceneBatch(batch.objects[: batch.scene_begin[8]].copy(), batch.scene_begin[:9].copy(), batch.pool)
     c4, _, pots = ops.goalset_cost(robot, P, ops.DeviceScenes(sub, dev), _t(ts[:8], dev), _t(goals[:8], dev), n, 0.1, want_potentials=True)
-    assert torch.equal(c4, c1[:8])
+    # cost-only launch (k_goalset_queue: float32 sum of pot * weight in queue order) against the per-point path
+    # (k_sdf_chunks: per-point sums over objects, then the weight): the same pairs, a different float32 summation order
+    np.testing.assert_allclose(c4.cpu().numpy(), c1[:8].cpu().numpy(), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(pots.double().sum(dim=(2, 3, 4)).cpu().numpy(), c4.double().cpu().numpy(), rtol=2e-6, atol=1e-6)
     assert float((c1 > 0).float().mean()) > 0.9
 

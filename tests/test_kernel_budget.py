@@ -1,7 +1,8 @@
-"""Register / spill budget of the dominant kernel.  k_goalset_compact<2> runs at 6 workgroups per CU only with <= 80 VGPRs, and
-its main loop is sensitive to SGPR allocation: an innocent-looking second early exit near the top once grew the spill area from
-144 to 172 bytes and cost 25 % of the kernel's speed.  This compiles the file to assembly (no GPU
-needed) and checks the figures the measured numbers were obtained with."""
+"""Register / LDS budget of the dominant kernel.  k_goalset_queue<2> runs at 5 workgroups per CU with <= 96 VGPRs and at most
+31 744 B of LDS per workgroup (tools/lds_occupancy_probe.hip: the CU admits 5 workgroups up to that size, 4 at 32 768 B
+although the occupancy API still answers 5), and it must not spill: scratch traffic in its main loop once cost 25 % of the
+kernel's speed.  This compiles the file to assembly (no GPU needed) and checks the figures the
+measured numbers were obtained with."""
 import re
 import shutil
 import subprocess
@@ -21,10 +22,26 @@ def test_goalset_kernel_register_and_spill_budget(tmp_path):
     subprocess.run([HIPCC, *flags, str(ROOT / "omg-planner_amd" / "csrc" / "omg_kernels.hip"), "-o", str(out)], check=True,
                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     text = out.read_text()
-    start = text.index("_Z17k_goalset_compactILi2ELb0EEv9ChunkArgs:")
-    block = text[start: text.index("; Occupancy:", start) + 40]
-    vgprs = int(re.search(r"; NumVgprs: (\d+)", block).group(1))
-    scratch = int(re.search(r"; ScratchSize: (\d+)", block).group(1))
-    occupancy = int(re.search(r"; Occupancy: (\d+)", block).group(1))
-    assert vgprs <= 80 and occupancy >= 6, (vgprs, occupancy)
-    assert scratch <= 32, f"k_goalset_compact<2> spills {scratch} bytes per lane (budget 32): check the main loop's speed on the GPU"
+    for name in ("_Z15k_goalset_queueILi2ELb0EEv9ChunkArgs", "_Z15k_goalset_queueILi2ELb1EEv9ChunkArgs"):
+        start = text.index(name + ":")
+        block = text[start: text.index("; Occupancy:", start) + 40]
+        vgprs = int(re.search(r"; NumVgprs: (\d+)", block).group(1))
+        scratch = int(re.search(r"; ScratchSize: (\d+)", block).group(1))
+        occupancy = int(re.search(r"; Occupancy: (\d+)", block).group(1))
+        assert vgprs <= 96 and occupancy >= 5, (name, vgprs, occupancy)
+        assert scratch == 0, f"{name} spills {scratch} bytes per lane: the goal path must stay in registers"
+
+
+def test_goalset_kernel_lds_fits_five_workgroups_per_cu():
+    """The launcher's LDS layout for the bench shape (30 waypoints, 15 points per link) — restated from GqLayout
+    (omg_goalset_queue.h) — stays within the 31 744 B that still admit 5 workgroups per CU."""
+    src = (ROOT / "omg-planner_amd" / "csrc" / "omg_goalset_queue.h").read_text()
+    tbl_n = int(re.search(r"#define GQ_TBL_N (\d+)", src).group(1))
+    PS, MR, P = 31, 30, 15
+    mask_off = PS * 90 * 8
+    tbl_off = mask_off + ((10 * MR * 4 + 15) & ~15)
+    pts_off = tbl_off + tbl_n * 64
+    stage_off = pts_off + ((10 * P * 3 * 8 + 15) & ~15)
+    total = max(stage_off + 4 * 64 * 16, PS * 90 * 8 + PS * 14 * 8)
+    assert total <= 31744, total
+    assert "__shared__ float" not in src  # no static LDS on top of the dynamic allocation

@@ -47,7 +47,10 @@ def main():
     t = [int(x) for x in buf]
     waves, total = t[15], sum(t[:11])
     out = {"scenes": S, "goals": G, "launches": iters}
-    if waves:  # library built with -DOMGX_GS_CLOCK=2
+    if waves and sum(t[8:11]) == 0:  # k_goalset_queue's event counters
+        names = ["steps with work", "(step, object) iterations", "enqueue calls", "entries", "issues", "weight evaluations", "steps visited"]
+        out.update({"waves": waves, "per_wave": {names[i]: round(t[i] / waves, 2) for i in range(7)}})
+    elif waves:  # library built with -DOMGX_GS_CLOCK=2
         out.update({"waves": waves, "ticks_per_wave": total / waves, "share": {PHASES[i]: round(t[i] / total, 4) for i in range(11)}})
     # per-workgroup timeline of the LAST launch: 100 MHz realtime stamps at entry / after the prologue / at exit + hardware id
     import numpy as np
@@ -72,6 +75,8 @@ def main():
         "goal_wg_duration_mean/p50/p90/max": [float(x) for x in (dur[ran & ~is_layer].mean(), np.percentile(dur[ran & ~is_layer], 50), np.percentile(dur[ran & ~is_layer], 90), dur[ran & ~is_layer].max())],
         "goal_wg_prologue_mean": float((pro - st)[ran & ~is_layer].mean()),
         "goal_wg_sincos/chain/rowcull_mean": [float(x[ran & ~is_layer].mean()) for x in (t_sc - st, t_ch - t_sc, pro - t_ch)],
+        "goal_wg_first/last_wave_leaves_main_loop_after_prologue_mean": [float(((w[:, 5].astype(np.int64) - int(t0)) / 100.0 - pro)[ran & ~is_layer].mean()),
+                                                                           float(((w[:, 6].astype(np.int64) - int(t0)) / 100.0 - pro)[ran & ~is_layer].mean())],
         "layer_wg_duration_mean/max": [float(dur[ran & is_layer].mean()), float(dur[ran & is_layer].max())],
         "finish_per_xcc": {int(x): float(en[ran & (xcc == x)].max()) for x in np.unique(xcc[ran])},
         "wgs_per_xcc": {int(x): int((ran & (xcc == x)).sum()) for x in np.unique(xcc[ran])},
