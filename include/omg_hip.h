@@ -237,10 +237,13 @@ int omgx_goalset_cost(const double* robot, int32_t n_points,
  *           loop once it terminates (omg/planner.py:626) — and their outputs keep their previous contents.
  *   goal_count  optional [S] int32 (NULL = num_goals everywhere): scene s has only goal_count[s] goals, the rest of its
  *           rows in `goals` / `goal_cost` is padding that is neither read nor written (ragged goal sets in one batch).
- *   schedule  optional [ceil(S/8)*8*num_goals] int32 (NULL = scene-major order): the k-th goal workgroup of the launch (it runs
- *           on XCD k % 8) works on
- *           goal schedule[k] % num_goals of scene schedule[k] / num_goals (< 0: none).  Any permutation gives the same
- *           results; omgx_goalset_schedule derives one from `work` that starts the longest goals first (ABI 4).
+ *   schedule  optional [schedule_len] int32, schedule_len a multiple of 8 (NULL = scene-major order, scene s on XCD s % 8):
+ *           the launch has schedule_len goal workgroups, workgroup k (it runs on XCD k % 8) works on goal schedule[k] % num_goals
+ *           of scene schedule[k] / num_goals, or on nothing when schedule[k] < 0.  Every (scene, goal) that is to be
+ *           evaluated must appear exactly once; any such list gives the same results.  Keep a scene's goals on one or two
+ *           XCDs (k % 8): its SDF volumes then stay in that XCD's L2 — spread over all eight the launch takes 1.7x as long.
+ *           ChompEngine.build_schedule (engine.py) derives an order from `work` that gives every XCD the same measured
+ *           work, heaviest scenes first (ABI 4).
  *   work    optional [S*num_goals] uint32: receives how long each goal's workgroup ran, in 10 ns ticks (0 = skipped).
  * ------------------------------------------------------------------------------------------- */
 int omgx_goalset_cost_layer(const double* robot, int32_t n_points,
@@ -252,7 +255,7 @@ int omgx_goalset_cost_layer(const double* robot, int32_t n_points,
                             const double* traj, int32_t n_waypoints, int32_t layer_soften_fingers,
                             float* layer_potentials, float* layer_grads, float* layer_collides,
                             const int32_t* active, const int32_t* goal_count,
-                            const int32_t* schedule, uint32_t* work, void* stream);
+                            const int32_t* schedule, int32_t schedule_len, uint32_t* work, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * (4) omgx_chomp_optimize

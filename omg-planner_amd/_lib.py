@@ -75,7 +75,7 @@ def lib() -> C.CDLL:
         l.omgx_goalset_workspace_bytes.argtypes = [i32, i32, i32, i32]
         l.omgx_goalset_workspace_bytes.restype = i64
         l.omgx_goalset_cost.argtypes = [vp, i32, vp, vp, vp, vp, i64, vp, i32, i32, i32, f64, i32, vp, vp, vp, vp, vp, vp, vp]
-        l.omgx_goalset_cost_layer.argtypes = [vp, i32, vp, vp, vp, vp, i64, vp, i32, i32, i32, f64, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
+        l.omgx_goalset_cost_layer.argtypes = [vp, i32, vp, vp, vp, vp, i64, vp, i32, i32, i32, f64, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp]
         l.omgx_goalset_cost_layer.restype = C.c_int
         l.omgx_chomp_optimize.argtypes = [vp, C.POINTER(ChompParams)] + [vp] * 9 + [i32] + [vp] * 4 + [i32, vp]
         l.omgx_learner_state_doubles.argtypes = [i32]

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256, GQ_WG_PER_CU) void k_goalset_queue(ChunkArgs a
     int s = sgrp * 8 + xcd;
     int chunk = is_layer ? 0 : j - sgrp * a.NCH;
     const bool scheduled = a.schedule && !is_layer;
-    if (scheduled) {
+    if (scheduled) {  // goal workgroup b of the launch works on item schedule[b] (ChunkArgs)
         const int item = as_const(a.schedule)[(int)blockIdx.x - nlayer * 8];
         if (item < 0 || item >= a.S * a.NCH) return;
         s = item / a.NCH;

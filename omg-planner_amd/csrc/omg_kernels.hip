@@ -195,6 +195,7 @@ struct ChunkArgs {
     // (longest first, omgx_goalset_schedule) so that the launch does not end on a few long workgroups.  work[scene * NCH +
     // goal] receives the workgroup's duration in 10 ns ticks (0 for skipped goals).
     const int32_t* schedule;
+    int sched_len;             // entries of `schedule` = goal workgroups of the launch (a multiple of 8)
     uint32_t* work;
 };
 
@@ -642,7 +643,8 @@ static int launch_goalset(ChunkArgs& ca, int timing_kind, hipStream_t st) {
     const bool layer = ca.wp_traj != nullptr;
     ca.PS = ca.CH + 1; ca.MR = ca.CH; ca.LPW = 10;
     if (layer) { if (ca.wp_n > ca.PS) ca.PS = ca.wp_n; if (ca.wp_n > ca.MR) ca.MR = ca.wp_n; }
-    const int64_t grid = (int64_t)scene_groups * (ca.NCH + (layer ? GS_LAYER_PARTS : 0)) * 8;
+    const int64_t goal_blocks = ca.schedule ? (int64_t)ca.sched_len : (int64_t)scene_groups * ca.NCH * 8;
+    const int64_t grid = goal_blocks + (layer ? (int64_t)scene_groups * GS_LAYER_PARTS * 8 : 0);
     if (grid > 0x7fffffff) return OMGX_ERR_UNSUPPORTED;
     const size_t lds = (size_t)GqLayout(ca.PS, ca.MR, ca.P).total;
     hipEvent_t ev0, ev1;
@@ -783,7 +785,7 @@ static int goalset_cost_impl(const double* robot, int32_t n_points, const omgx_o
                              int32_t soften_fingers, float* goal_cost, float* potentials, float* collides, void* workspace,
                              const double* layer_traj, int32_t layer_n, int32_t layer_soften, float* layer_pot, float* layer_grad,
                              float* layer_col, const int32_t* active, const int32_t* goal_count, const int32_t* schedule,
-                             uint32_t* work, void* stream) {
+                             int32_t schedule_len, uint32_t* work, void* stream) {
     if (num_scenes < 0 || num_goals < 0) return OMGX_ERR_INVALID;
     if (num_scenes == 0 || num_goals == 0) return OMGX_OK;
     if (!robot || !objects || !scene_begin || !traj_start || !goals || !goal_cost) return OMGX_ERR_INVALID;
@@ -808,7 +810,8 @@ static int goalset_cost_impl(const double* robot, int32_t n_points, const omgx_o
         ca.wp_traj = layer_traj; ca.wp_n = layer_n; ca.wp_soften = layer_soften != 0;
         ca.wp_pot = layer_pot; ca.wp_grad = layer_grad; ca.wp_col = layer_col;
     }
-    ca.active = active; ca.goal_count = goal_count; ca.schedule = schedule; ca.work = work;
+    if (schedule && (schedule_len < 8 || schedule_len % 8 != 0)) return OMGX_ERR_INVALID;
+    ca.active = active; ca.goal_count = goal_count; ca.schedule = schedule; ca.sched_len = schedule ? schedule_len : 0; ca.work = work;
     (void)workspace;  // kept in the signature (ABI): no launch of this entry point spills poses to memory any more
     return potentials ? launch_chunks(ca, st) : launch_goalset(ca, 0, st);
 }
@@ -821,7 +824,7 @@ extern "C" int omgx_goalset_cost(const double* robot, int32_t n_points, const om
                                  float* collides, void* workspace, const int32_t* active, const int32_t* goal_count, void* stream) {
     return goalset_cost_impl(robot, n_points, objects, scene_begin, sdf_pool, traj_start, traj_start_stride, goals, num_scenes,
                              num_goals, n_remaining, time_interval, soften_fingers, goal_cost, potentials, collides, workspace,
-                             nullptr, 0, 0, nullptr, nullptr, nullptr, active, goal_count, nullptr, nullptr, stream);
+                             nullptr, 0, 0, nullptr, nullptr, nullptr, active, goal_count, nullptr, 0, nullptr, stream);
 }
 
 extern "C" int omgx_goalset_cost_layer(const double* robot, int32_t n_points, const omgx_object* objects,
@@ -831,10 +834,10 @@ extern "C" int omgx_goalset_cost_layer(const double* robot, int32_t n_points, co
                                        float* collides, void* workspace, const double* traj, int32_t n_waypoints,
                                        int32_t layer_soften_fingers, float* layer_potentials, float* layer_grads,
                                        float* layer_collides, const int32_t* active, const int32_t* goal_count,
-                                       const int32_t* schedule, uint32_t* work, void* stream) {
+                                       const int32_t* schedule, int32_t schedule_len, uint32_t* work, void* stream) {
     if (!traj) return OMGX_ERR_INVALID;
     return goalset_cost_impl(robot, n_points, objects, scene_begin, sdf_pool, traj_start, traj_start_stride, goals, num_scenes,
                              num_goals, n_remaining, time_interval, soften_fingers, goal_cost, nullptr, collides, workspace, traj,
                              n_waypoints, layer_soften_fingers, layer_potentials, layer_grads, layer_collides, active, goal_count, schedule,
-                             work, stream);
+                             schedule_len, work, stream);
 }

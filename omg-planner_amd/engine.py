@@ -47,6 +47,7 @@ class ChompEngine:
     split_update = None
     # True: iterate() goes through iterate_separate(), the five separate entry points (cross-checks)
     separate_launches = False
+    schedule_slack = 2  # goal workgroup slots per XCD in units of the even share (see build_schedule)
 
     def __init__(self, model: PandaModel, batch: SceneBatch, cfg: Config, start: np.ndarray, goal_set: np.ndarray,
                  reach_grasps: np.ndarray | None = None, traj_init: np.ndarray | None = None, device="cuda:0",
@@ -124,9 +125,10 @@ class ChompEngine:
         # A scene keeps all its workgroups on one XCD (its SDF volumes stay in that XCD's L2: without this affinity the
         # launch takes 1.7x as long).  Results do not depend on the order.
         self.work = torch.zeros(S * G, dtype=torch.int32, device=dev)
-        self.schedule = None
         self.auto_schedule = True
+        self.schedule = None
         self._gs_launches = 0
+        self._measured = False
         self._ticket = 0
         self._num_cus = torch.cuda.get_device_properties(dev).multi_processor_count
         self._gather_goal()
@@ -217,16 +219,20 @@ class ChompEngine:
             n_rem = self.cfg.timesteps - prm.start_idx
             traj_start = self.traj[:, prm.start_idx]  # strided view into the trajectory tensor: no copy kernel
             if with_layer:  # the SDF layer of the current trajectories rides on the goal-set launch
-                # the second launch is the measuring one (the first runs on cold caches and would distort the weights)
+                # the second launch is the measuring one (the first runs on cold caches and would distort the weights);
+                # until then the items are split evenly by count
                 self._gs_launches += 1
-                measure = self.auto_schedule and self.schedule is None and self._gs_launches >= 2
+                measure = self.auto_schedule and not self._measured and self._gs_launches >= 2
+                if self.auto_schedule and self.schedule is None:
+                    self.schedule = self.build_schedule(uniform=True)
                 ops.goalset_cost_layer(self.robot, self.P, self.scenes, traj_start, self.cv_goals, n_rem, self.cfg.time_interval,
                                        self.traj, (self.pot, self.pgrad, self.col), soften_fingers=False,
                                        layer_soften_fingers=self.cfg.uncheck_finger_collision == -1,
                                        out=(self.goal_cost, self.goal_col), active=self._mask(), goal_count=self.goal_count,
                                        schedule=self.schedule, work=self.work if measure else None)
                 if measure:
-                    self.schedule = self.build_schedule()
+                    self._measured = True
+                    self.schedule = self.build_schedule(self._mask())
             else:
                 ops.goalset_cost(self.robot, self.P, self.scenes, traj_start, self.cv_goals, n_rem, self.cfg.time_interval,
                                  soften_fingers=False, out=(self.goal_cost, self.goal_col), active=self._mask(),
@@ -240,27 +246,48 @@ class ChompEngine:
                         goal_count=self.goal_count, eta=self.eta_s)
         return None
 
-    def build_schedule(self, active: "torch.Tensor | None" = None) -> torch.Tensor:
-        """Dispatch order for omgx_goalset_cost_layer from the durations in `work` (torch ops on the device, asynchronous).
-        Block b of the goal part runs on XCD b % 8: scene number k of the weight-sorted list goes to XCD x(k) (serpentine
-        0..7,7..0) as that XCD's j-th scene; its goals, longest first, occupy blocks ((j * G + i) * 8 + x)."""
+    def build_schedule(self, active: "torch.Tensor | None" = None, uniform: bool = False) -> torch.Tensor:
+        """Dispatch order for omgx_goalset_cost_layer (torch ops on the device, asynchronous, no host sync).
+
+        The (scene, goal) items are laid out scene by scene — scenes by decreasing measured work (`work`, the durations of
+        the measuring launch), each scene's goals longest first — and this list is cut into 8 contiguous pieces of equal
+        total work, one per XCD (goal workgroup b of the launch runs on XCD b % 8).  Every XCD then holds whole scenes except
+        for at most two that it shares with a neighbour, so a scene's SDF volumes stay in one or two L2s, and all XCDs finish
+        together whatever the number of scenes (12 or 13 scenes per GPU would otherwise leave 3 of 8 XCDs with half the
+        load).  `uniform`: all items weigh the same (before anything has been measured).  `active` [S] int32: scenes
+        with 0 are left out.  An XCD has room for `schedule_slack` (2) times its share of the items; the weights are
+        clamped to a band [L, schedule_slack * L] around their mean, so no piece of the list can need more."""
         S, G, dev = self.S, self.G, self.device
-        w = self.work.view(S, G).to(torch.int64)
-        tot = w.sum(1)
-        if active is not None:
-            tot = torch.where(active != 0, tot + 1, torch.zeros_like(tot))
-        order = torch.argsort(tot, descending=True, stable=True)
-        k = torch.arange(S, device=dev)
-        r = k % 16
-        x = torch.where(r < 8, r, 15 - r)
-        j = (k // 16) * 2 + (r >= 8).to(torch.int64)
-        gorder = torch.argsort(w[order], dim=1, descending=True, stable=True)  # [S,G] goal indices of scene order[k], longest first
-        blocks = (j[:, None] * G + torch.arange(G, device=dev)[None, :]) * 8 + x[:, None]
-        items = order[:, None] * G + gorder
-        if active is not None:
-            items = torch.where((active[order] != 0)[:, None], items, torch.full_like(items, -1))
-        sched = torch.full((((S + 7) // 8) * 8 * G,), -1, dtype=torch.int32, device=dev)
-        sched[blocks.reshape(-1)] = items.reshape(-1).to(torch.int32)
+        w = torch.ones((S, G), dtype=torch.int64, device=dev) if uniform else self.work.view(S, G).to(torch.int64).clamp(min=1)
+        live = torch.ones(S, dtype=torch.bool, device=dev) if active is None else active != 0
+        if self.goal_count is not None:  # padding of ragged goal sets: never scheduled
+            keep = torch.arange(G, device=dev)[None, :] < self.goal_count[:, None]
+        else:
+            keep = torch.ones((S, G), dtype=torch.bool, device=dev)
+        keep = keep & live[:, None]
+        w = torch.where(keep, w, torch.zeros_like(w))
+        order = torch.argsort(w.sum(1), descending=True, stable=True)           # scenes, heaviest first
+        gorder = torch.argsort(w[order], dim=1, descending=True, stable=True)   # goals of scene order[k], longest first
+        items = (order[:, None] * G + gorder).reshape(-1)
+        wi = torch.gather(w[order], 1, gorder).reshape(-1)
+        valid = wi > 0                                                          # dropped items sit at the end of every scene
+        n_valid = valid.sum().clamp(min=1)
+        slack = self.schedule_slack
+        lo = ((10 * wi.sum()) // (n_valid * 14)).clamp(min=1)                   # L = mean / 1.4 (the mean sits in the middle of [L, 2 L] on a log scale)
+        wc = torch.where(valid, torch.minimum(torch.maximum(wi, lo), slack * lo), torch.zeros_like(wi))
+        cum = torch.cumsum(wc, 0)
+        total = cum[-1].clamp(min=1)
+        slots = -(-slack * S * G // 8) + 2                                      # per XCD: count <= (total / 8) / L + 1 <= slack * n / 8 + 1
+        pos = (torch.cumsum(valid.to(torch.int64), 0) - 1).clamp(min=0)         # index among the scheduled items
+        x = torch.clamp((8 * (2 * cum - wc)) // (2 * total), min=0, max=7)      # piece of the cumulative-work axis the item's centre is in
+        # rank of the item inside its piece: its index among the scheduled items minus that of the piece's first item
+        big = torch.full_like(pos, S * G)
+        firsts = torch.full((8,), S * G, dtype=torch.int64, device=dev).scatter_reduce(0, x, torch.where(valid, pos, big), reduce="amin", include_self=True)
+        rank = pos - firsts[x]
+        ok = valid & (rank >= 0) & (rank < slots)
+        block = torch.where(ok, rank * 8 + x, torch.zeros_like(rank))
+        sched = torch.full((slots * 8,), -1, dtype=torch.int32, device=dev)
+        sched[block[ok]] = items[ok].to(torch.int32)
         return sched
 
     def _layer(self):

@@ -153,7 +153,7 @@ def goalset_cost_layer(robot, P, scenes: DeviceScenes, traj_start, goals, n_rema
                                         _ptr(traj_start), ts_stride, _ptr(goals), S, G, n_remaining, float(dt),
                                         int(bool(soften_fingers)), _ptr(cost), _ptr(col), _ptr(ws), _ptr(traj), n,
                                         int(bool(layer_soften_fingers)), _ptr(lp), _ptr(lg), _ptr(lc), _ptr(_active(active, S)),
-                                        _ptr(_active(goal_count, S)), _ptr(_i32n(schedule, ((S + 7) // 8) * 8 * G, "schedule")), _ptr(_i32n(work, S * G, "work")),
+                                        _ptr(_active(goal_count, S)), _ptr(_i32n(schedule, None, "schedule")), 0 if schedule is None else schedule.numel(), _ptr(_i32n(work, S * G, "work")),
                                         _stream()),
               "omgx_goalset_cost_layer")
     return cost, col
@@ -219,8 +219,8 @@ def _eta(eta, S):
 
 def _i32n(t, n, name):
     """Optional contiguous 4-byte integer device tensor of n elements (int32 schedules, uint32-as-int32 work counters)."""
-    if t is not None and not (t.is_cuda and t.dtype == torch.int32 and t.is_contiguous() and t.numel() == n):
-        raise _lib.OmgHipError(f"{name} must be a contiguous int32 device tensor of {n} elements")
+    if t is not None and not (t.is_cuda and t.dtype == torch.int32 and t.is_contiguous() and (n is None or t.numel() == n)):
+        raise _lib.OmgHipError(f"{name} must be a contiguous int32 device tensor" + (f" of {n} elements" if n is not None else ""))
     return t
 
 

@@ -1124,7 +1124,7 @@ def test_two_launch_entry_points_reject_bad_arguments(dev, monkeypatch):
     from omg_planner_amd import _lib, ops, robot as rb, scenes as sc
     import ctypes as C
     l = _lib.lib()
-    rc = l.omgx_goalset_cost_layer(None, 15, None, None, None, None, 9, None, 1, 1, 5, 0.1, 0, None, None, None, None, 5, 0, None, None, None, None, None, None, None, None)
+    rc = l.omgx_goalset_cost_layer(None, 15, None, None, None, None, 9, None, 1, 1, 5, 0.1, 0, None, None, None, None, 5, 0, None, None, None, None, None, None, 0, None, None)
     assert rc == _lib.OMGX_ERR_INVALID
     lp, cp = _lib.LearnerParams(), _lib.ChompParams()
     rc = l.omgx_goal_update_optimize(C.byref(lp), *([None] * 6), None, C.byref(cp), *([None] * 9), 3, *([None] * 4), None, 0, 0, None, None, None)
