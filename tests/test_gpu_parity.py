@@ -8,6 +8,7 @@ and cost values."""
 import ctypes as C
 
 import numpy as np
+from pathlib import Path
 import pytest
 
 from tests import helpers as H
@@ -1403,3 +1404,50 @@ def test_engine_full_plan_runs_and_improves(dev):
     hi = torch.as_tensor(m.joint_upper_limit, device=dev) + 1e-2
     assert bool(((eng.traj >= lo) & (eng.traj <= hi)).all())       # handle_joint_limit
     assert float(info[:, 8].sum()) <= float(first[:, 8].sum())     # fewer colliding points than the initial guess
+
+
+# ------------------------------------------------------------------------------------------------
+# (10) the timed workload itself: bench.py's configuration against the oracle, and its multi-rank path on one GPU
+# ------------------------------------------------------------------------------------------------
+def test_bench_workload_matches_oracle(dev):
+    """bench.py's exact configuration — 100 scenes (4 x 64^3 + 128x96x32 private grids), 64 goals, 30 waypoints, MD, the
+    two-launch iteration with the goal-set window pinned, schedule measured on the second launch — against the oracle on three
+    of its scenes: first through the measuring launches, then three more iterations under the measured schedule."""
+    import bench
+    from omg_planner_amd.engine import ChompEngine
+    from oracle.check import engine_vs_oracle
+    cfg, model, batch, start, goals = bench.build_workload(100, 64, 30, 64, 0, False)
+    eng = ChompEngine(model, batch, cfg, start, goals, device=dev, ol_alg="MD")
+    for phase in range(2):
+        r = engine_vs_oracle(eng, batch, [0, 50, 99], steps=3, pin_window=True)
+        assert r["goal_idx_equal"], r
+        assert r["max_traj_err"] <= 1e-6 and r["max_cost_rel_err"] <= 1e-5, r  # north_star's bar is 1e-4
+    assert eng._measured and eng.schedule is not None
+
+
+def test_bench_multi_rank_costs_equal_single_process(tmp_path):
+    """bench.py --total-scenes (strong scaling: contiguous blocks of whole scenes per rank, one all-gather of the final
+    costs) with 2 ranks sharing the one GPU over gloo against the single-process run: the gathered per-scene costs are
+    bit-identical.  The ranks are fresh processes started by torch.distributed.run before they touch the GPU."""
+    import os
+    import subprocess
+    import sys
+    root = Path(__file__).resolve().parents[1]
+    common = ["--total-scenes", "6", "--goals", "8", "--grid", "24", "--steps", "4", "--warmup", "1", "--no-plan", "--no-cpu-baseline",
+              "--no-parity"]
+    env = dict(os.environ, OMGX_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    one, two = tmp_path / "one.npy", tmp_path / "two.npy"
+    r1 = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "1", *common, "--dump-costs", str(one)], env=env, capture_output=True,
+                        text=True, timeout=600)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    port = 29500 + os.getpid() % 2000
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                         "--master-port", str(port), str(root / "bench.py"), "--gpus", "2", *common, "--dump-costs", str(two)], env=env,
+                        capture_output=True, text=True, timeout=600)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    a, b = np.load(one), np.load(two)
+    assert a.shape == (6,) and np.array_equal(a, b), (a, b)
+    line = [l for l in r2.stdout.splitlines() if l.startswith("{")][-1]
+    import json
+    j = json.loads(line)
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["config"]["total_scenes"] == 6
