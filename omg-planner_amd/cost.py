@@ -188,6 +188,14 @@ class Cost(object):
                                clearance=self.cfg.clearance, target_clearance=self.cfg.target_clearance,
                                disable_collision_set=tuple(self.cfg.disable_collision_set))
 
+    def invalidate(self) -> None:
+        """Forget the cached object table and influence boxes.  They are keyed on the identity and the in-place version
+        counter of env.sdf_torch / env.sdf_limits, which a write through a raw device pointer (the C ABI, a custom kernel) does
+        not advance: call this after such a write — or bump the counter, torch.autograd.graph.increment_version(env.sdf_torch) —
+        otherwise the culling boxes of the old volume are applied to the new one."""
+        self._scenes_cache = None
+        self._pool_ref = None
+
     def _scenes(self) -> ops.DeviceScenes:
         """One-scene object table addressing env.sdf_torch IN PLACE (rebuilt per call like the reference
         rebuilds its five parameter tensors per call; object poses may have changed)."""

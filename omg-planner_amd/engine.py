@@ -425,14 +425,24 @@ class ChompEngine:
 
     def plan(self, early_stop: bool = True, initial_goal: bool = True) -> torch.Tensor:
         """Planner.plan (planner.py:600-653): up to optim_steps + extra_smooth_steps iterations, then one
-        info-only evaluation; returns the final info [S,16] (device)."""
+        info-only evaluation; returns the final info [S,16] (device).  cfg.timeout (3 s; -1: none) is the reference's
+        wall-clock budget (planner.py:629): once it is spent after an iteration t > 0, the loop ends for every scene.  The
+        engine's loop is asynchronous, so the clock the host reads is its enqueue time (a lower bound of the device's progress
+        while the launch queue is not full); a 70-iteration plan of 100 scenes takes 16 ms, the budget only matters for very
+        large batches."""
+        import time
         cfg = self.cfg
         if initial_goal and cfg.goal_set_proj:
             self.select_initial_goal()
         self.iterations_run = 0
+        self.timed_out = False
+        t_start = time.time()
         for t in range(cfg.optim_steps + cfg.extra_smooth_steps):
             self.iterate(t, early_stop)
             self.iterations_run = t + 1
+            if cfg.timeout != -1 and t > 0 and time.time() - t_start > cfg.timeout:
+                self.timed_out = True
+                break
             # Every scene may have left the loop (planner.py:626 breaks at once; a lone scene often terminates after two
             # iterations): look at the mask at a thinning set of iterations and stop launching no-ops.  Each look is a host
             # sync that drains the launch queue (measured: ~0.4 ms each with 100 scenes in flight, where it never pays), so

@@ -278,15 +278,25 @@ def goal_update_optimize(lparams: LearnerParams, goal_set, reach, goal_cost, sta
     return grad, cost_traj, info
 
 
-def point_cloud_sdf(points: torch.Tensor, grid_resolution: float = 0.02, margin: float = 0.24):
+def point_cloud_sdf(points: torch.Tensor, grid_resolution: float = 0.02, margin: float = 0.24, out: "torch.Tensor | None" = None):
     """PointEnv.compute_sdf_from_points (omg/core.py:426-457) on the device: points [N,3] f64 (robot base frame) ->
     (grid float32 [X,Y,Z] of nearest-point distances, origin [3] float64 numpy, resolution).  The workspace bounds
-    are the cloud's bounding box +- margin and the nodes np.arange(lo, hi, resolution), as in the reference."""
+    are the cloud's bounding box +- margin and the nodes np.arange(lo, hi, resolution), as in the reference.
+    out: optional contiguous float32 device tensor with X*Y*Z elements (e.g. a slice of env.sdf_torch) written IN PLACE
+    through its raw pointer; its autograd version counter is bumped so that caches keyed on it (Cost's object table and
+    influence boxes) notice.  A caller that writes such a volume through the C ABI itself must do the same
+    (torch.autograd.graph.increment_version) or call Cost.invalidate()."""
     _need(points, torch.float64, "points")
     lo = points.min(0).values.cpu().numpy() - margin
     hi = points.max(0).values.cpu().numpy() + margin
     dims = np.array([len(np.arange(lo[a], hi[a], grid_resolution)) for a in range(3)], np.int32)
-    out = torch.empty(tuple(int(d) for d in dims), dtype=torch.float32, device=points.device)
+    if out is None:
+        out = torch.empty(tuple(int(d) for d in dims), dtype=torch.float32, device=points.device)
+    else:
+        _need(out, torch.float32, "out")
+        if out.numel() != int(dims.prod()):
+            raise _lib.OmgHipError(f"out must hold {int(dims.prod())} elements (grid {tuple(int(d) for d in dims)})")
+        torch.autograd.graph.increment_version(out)
     origin = np.ascontiguousarray(lo, np.float64)
     with torch.cuda.device(points.device):
         check(_lib.lib().omgx_point_cloud_sdf(_ptr(points), points.shape[0], origin.ctypes.data_as(C.POINTER(C.c_double)),

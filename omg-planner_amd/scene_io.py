@@ -23,7 +23,7 @@ from .scenes import Scene, SceneObject, SdfGrid
 def load_sdf_pth(path: str, resize: float = 1.0) -> SdfGrid:
     """SignedDensityField.from_pth (omg/sdf_tools.py:186-193) (+ .resize, :37-45)."""
     import torch
-    d = torch.load(path, map_location="cpu", weights_only=False)
+    d = torch.load(path, map_location="cpu", weights_only=True)  # tensors and a float: no pickled code is ever executed
     data = d["sdf_torch"][0, 0].permute(1, 0, 2).contiguous().numpy().astype(np.float32)
     origin = np.asarray(d["min_coords"], dtype=np.float64).copy()
     delta = float(d["delta"])

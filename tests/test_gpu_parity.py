@@ -455,6 +455,29 @@ def test_cost_object_table_follows_the_environment(dev):
     seen.append(both())
     env.objects[0].name = "floor"                          # disabled
     seen.append(both())
+    # a write through a RAW device pointer (the C ABI, e.g. omgx_point_cloud_sdf into a slice of env.sdf_torch) does not move
+    # the version counter: the cached influence boxes of the old volume would cull the new one.  ops.point_cloud_sdf(out=...)
+    # bumps the counter itself; after any other raw write Cost.invalidate() does it.
+    from omg_planner_amd import ops
+    vol = env.sdf_torch[1]
+    cloud = torch.as_tensor(np.random.RandomState(2).uniform(0.2, 0.3, (50, 3)), dtype=torch.float64, device=dev)
+    lo = (cloud.min(0).values.cpu().numpy() - 0.24)
+    hi = (cloud.max(0).values.cpu().numpy() + 0.24)
+    dims = [len(np.arange(lo[a], hi[a], 0.02)) for a in range(3)]
+    if int(np.prod(dims)) <= vol.numel():
+        flat = vol.reshape(-1)[: int(np.prod(dims))]
+        v0 = env.sdf_torch._version
+        ops.point_cloud_sdf(cloud, out=flat)
+        assert env.sdf_torch._version > v0
+        seen.append(both())
+    ctypes_write = env.sdf_torch.data_ptr()  # what a C caller holds: emulate its write without touching the counter
+    with torch.no_grad():
+        raw = torch.empty(0, dtype=torch.float32, device=dev).set_(env.sdf_torch.untyped_storage(), 0, (env.sdf_torch.numel(),))
+        v1 = env.sdf_torch._version
+        raw.detach().mul_(0.5)
+    assert ctypes_write == env.sdf_torch.data_ptr()
+    cost.invalidate()
+    seen.append(both())
     assert len(set(seen)) == len(seen), seen
 
 

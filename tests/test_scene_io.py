@@ -24,10 +24,34 @@ def test_scene_and_sdf_files_round_trip(tmp_path):
     np.testing.assert_array_equal(got.reach_grasps, reach)
     # the .pth axis convention: stored tensor is the grid with its first two axes swapped (sdf_tools.py:189)
     import torch
-    d = torch.load(str(tmp_path / "data/objects/model_000/model_normalized_chomp.pth"), weights_only=False)
+    d = torch.load(str(tmp_path / "data/objects/model_000/model_normalized_chomp.pth"), weights_only=True)
     assert tuple(d["sdf_torch"].shape[2:]) == (scene.objects[0].sdf.data.shape[1], scene.objects[0].sdf.data.shape[0], scene.objects[0].sdf.data.shape[2])
     # identical packing either way
     b1 = sc.pack_table([scene], {})
     b2 = sc.pack_table([got.scene], {})
     np.testing.assert_array_equal(b1.pool, b2.pool)
     assert b1.objects.tobytes() == b2.objects.tobytes()
+
+
+def test_scene_file_written_like_the_reference_writes_it():
+    """tests/golden/scene_mat/: a scene .mat produced key by key like bullet/gen_data.py:21-34 (python lists of unequal-length
+    path strings -> space-padded char matrix, a plain string target_name, a list of 4x4 poses) with the extra keys of the
+    shipped demo scenes, and SDF volumes in the layout SignedDensityField.from_pth reads (checked against the reference's own
+    reader by tests/golden/make_scene_mat.py in the build container).  load_scene_mat must recover names, poses, the target
+    named by `target_name` (the LAST object here, not the first), goals, standoff tails, qualities and the volumes."""
+    from pathlib import Path
+    from omg_planner_amd import scene_io
+    root = Path(__file__).resolve().parent / "golden" / "scene_mat"
+    exp = np.load(root / "expected.npz")
+    got = scene_io.load_scene_mat(str(root / "scene_0.mat"), str(root))
+    assert [o.name for o in got.scene.objects] == [str(n) for n in exp["names"]]
+    assert got.scene.target_idx == int(exp["target_idx"]) == 2
+    np.testing.assert_array_equal(np.stack([o.pose_mat for o in got.scene.objects]), exp["pose"])
+    np.testing.assert_array_equal(got.goals, exp["goals"])
+    np.testing.assert_array_equal(got.reach_grasps, exp["reach_grasps"])
+    np.testing.assert_array_equal(got.grasp_qualities, exp["grasp_qualities"])
+    np.testing.assert_array_equal(got.grasp_potentials, exp["grasp_potentials"])
+    for k, o in enumerate(got.scene.objects):
+        np.testing.assert_array_equal(o.sdf.data, exp[f"grid{k}"])
+        np.testing.assert_allclose(o.sdf.min_coords, exp[f"origin{k}"], rtol=0, atol=0)
+        assert o.sdf.delta == float(exp["deltas"][k])

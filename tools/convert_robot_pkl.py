@@ -17,9 +17,21 @@ from pathlib import Path
 import numpy as np
 
 
+class _NumericOnly(pickle.Unpickler):
+    """The file comes from an untrusted tree: only numpy's array reconstruction and builtin containers may be unpickled."""
+    _ALLOWED = {("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"), ("numpy", "ndarray"),
+                ("numpy", "dtype"), ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"),
+                ("collections", "OrderedDict"), ("builtins", "dict"), ("builtins", "list"), ("builtins", "tuple"), ("_codecs", "encode")}
+
+    def find_class(self, module, name):
+        if (module, name) not in self._ALLOWED:
+            raise pickle.UnpicklingError(f"refusing to unpickle {module}.{name}")
+        return super().find_class(module, name)
+
+
 def main(src: str) -> None:
     with open(src, "rb") as fid:
-        info = pickle.load(fid)
+        info = _NumericOnly(fid, encoding="latin1").load()
     names = list(info["_joint_name"])
     del names[-3]  # remove the dummy hand joint, omg/core.py:154
     limits = np.array([info["_joint_limits"][n] for n in names], dtype=np.float64)  # [9,2]
