@@ -61,29 +61,17 @@ __global__ __launch_bounds__(256, GQ_WG_PER_CU) void k_goalset_queue(ChunkArgs a
     GS_WG_STAMP(0);
     const int xcd = blockIdx.x & 7;
     // with a trajectory layer, GS_LAYER_PARTS workgroups per scene (10 / GS_LAYER_PARTS links each) compute it; those lead the grid
+    // (at the end of the grid, as fillers of the launch's tail, they cost 3 %: measured)
     const int nlayer = a.wp_traj ? ((a.S + 7) >> 3) * GS_LAYER_PARTS : 0;
-#ifdef GQ_LAYER_LAST
-    const int ngoal8 = ((int)gridDim.x >> 3) - nlayer;  // goal workgroups first, the (short) layer workgroups fill the tail
-    const bool is_layer = (int)(blockIdx.x >> 3) >= ngoal8;
-    const int j = (int)(blockIdx.x >> 3);
-    const int jl = (int)(blockIdx.x >> 3) - ngoal8;
-    const int sgrp = is_layer ? jl / GS_LAYER_PARTS : j / a.NCH;
-    const int layer_part = jl - sgrp * GS_LAYER_PARTS;
-#else
     const bool is_layer = (int)(blockIdx.x >> 3) < nlayer;
     const int j = (int)(blockIdx.x >> 3) - nlayer;
     const int sgrp = is_layer ? (int)(blockIdx.x >> 3) / GS_LAYER_PARTS : j / a.NCH;
     const int layer_part = (int)(blockIdx.x >> 3) - sgrp * GS_LAYER_PARTS;
-#endif
     int s = sgrp * 8 + xcd;
     int chunk = is_layer ? 0 : j - sgrp * a.NCH;
     const bool scheduled = a.schedule && !is_layer;
     if (scheduled) {  // goal workgroup b of the launch works on item schedule[b] (ChunkArgs)
-#ifdef GQ_LAYER_LAST
-        const int item = as_const(a.schedule)[(int)blockIdx.x];
-#else
         const int item = as_const(a.schedule)[(int)blockIdx.x - nlayer * 8];
-#endif
         if (item < 0 || item >= a.S * a.NCH) return;
         s = item / a.NCH;
         chunk = item - s * a.NCH;

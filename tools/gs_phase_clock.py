@@ -1,10 +1,11 @@
-"""Where the waves of the goal-set kernel spend their cycles (attribution of the `s_waitcnt` share).
+"""Per-workgroup timeline of the goal-set kernel: where a goal workgroup's time goes (the three prologue stages, first /
+last wave leaving the main loop), how the launch fills the chip over time, when each XCD finishes.
 
 Needs the instrumented variant of the library (never the shipped one):
-    make -C omg-planner_amd/csrc BUILD=build_clk OUT=libomg_hip_clk.so EXTRA=-DOMGX_GS_CLOCK=1      (=2 adds in-loop phase clocks: 12x slower, shares only)
+    make -C omg-planner_amd/csrc BUILD=build_clk OUT=libomg_hip_clk.so EXTRA=-DOMGX_GS_CLOCK=1
 Run on the GPU box:  python tools/gs_phase_clock.py [scenes] [goals]
-Every wave of a goal workgroup adds the shader-clock ticks between phase boundaries to a device array; s_memtime drains
-lgkmcnt at each boundary, so the split is an attribution (it perturbs the schedule), not a timing of the shipped kernel.
+Every workgroup stamps the 100 MHz realtime clock at its phase boundaries (one scalar clock read each: no measurable effect on
+the kernel, unlike in-loop shader-clock reads, which cost ~1 us apiece and slowed it 12x when tried).
 """
 import ctypes as C
 import json
@@ -21,45 +22,27 @@ from omg_planner_amd import _lib  # noqa: E402
 _lib.LIB_PATH = ROOT / "omg-planner_amd" / "csrc" / "libomg_hip_clk.so"
 from omg_planner_amd.engine import ChompEngine  # noqa: E402
 
-PHASES = ["fk_prologue", "row_culling", "skipped_iterations", "masks+points(pose9_apply)", "object_record_s_load", "far_tests+ranks",
-          "compaction_write+wave_barrier", "exact_pass(loads+trilerp+hinge)", "read_back+wave_barriers", "arc_length+sums", "block_reduction"]
-
-
 def main():
     S = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     G = int(sys.argv[2]) if len(sys.argv) > 2 else 64
     cfg, model, batch, start, goals = bench.build_workload(S, G, 30, 64, 0, False)
     eng = ChompEngine(model, batch, cfg, start, goals, device="cuda:0", ol_alg="MD")
     lib = _lib.lib()
-    lib.omgx_debug_gs_clock.argtypes = [C.c_void_p, C.c_int]
-    for _ in range(3):
-        eng.t = 0
-        eng.iterate(0)
-    torch.cuda.synchronize()
-    lib.omgx_debug_gs_clock(None, 1)
     iters = 10
-    for _ in range(iters):
+    for _ in range(3 + iters):
         eng.t = 0
         eng.iterate(0)
     torch.cuda.synchronize()
-    buf = (C.c_ulonglong * 16)()
-    assert lib.omgx_debug_gs_clock(buf, 0) == 0
-    t = [int(x) for x in buf]
-    waves, total = t[15], sum(t[:11])
     out = {"scenes": S, "goals": G, "launches": iters}
-    if waves and sum(t[8:11]) == 0:  # k_goalset_queue's event counters
-        names = ["steps with work", "(step, object) iterations", "enqueue calls", "entries", "issues", "weight evaluations", "steps visited"]
-        out.update({"waves": waves, "per_wave": {names[i]: round(t[i] / waves, 2) for i in range(7)}})
-    elif waves:  # library built with -DOMGX_GS_CLOCK=2
-        out.update({"waves": waves, "ticks_per_wave": total / waves, "share": {PHASES[i]: round(t[i] / total, 4) for i in range(11)}})
     # per-workgroup timeline of the LAST launch: 100 MHz realtime stamps at entry / after the prologue / at exit + hardware id
     import numpy as np
-    nwg = ((S + 7) // 8) * (G + 5) * 8
+    nwg = ((S + 7) // 8) * 5 * 8 + max(((S + 7) // 8) * G * 8, 0 if eng.schedule is None else int(eng.schedule.numel()))
     wg = (C.c_ulonglong * (8 * nwg))()
     lib.omgx_debug_gs_wg.argtypes = [C.c_void_p, C.c_int]
     assert lib.omgx_debug_gs_wg(wg, nwg) == 0
     w = np.array(list(wg), dtype=np.uint64).reshape(nwg, 8)
-    ran = w[:, 4] > 0
+    # stamps of the LAST launch only: blocks that were empty in it may still carry an earlier launch's stamps (other schedule)
+    ran = (w[:, 4] > 0) & (w[:, 0] + np.uint64(100000) > w[:, 4].max()) & (w[:, 4] > w[:, 0])
     t0 = w[ran, 0].min()
     st, t_sc, t_ch, pro, en = [(w[:, k].astype(np.int64) - int(t0)) / 100.0 for k in range(5)]  # microseconds
     nlayer = ((S + 7) // 8) * 5 * 8
