@@ -102,7 +102,8 @@ __global__ __launch_bounds__(256, GQ_WG_PER_CU) void k_goalset_queue(ChunkArgs a
     if (s < 0) return;  // fewer active scenes than slots
     const int o_begin = as_const(a.scene_begin)[s], o_end = as_const(a.scene_begin)[s + 1];
     const int P = a.P, CH = a.CH;
-    const int p = threadIdx.x & 15, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int p = threadIdx.x & 15, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // provably wave-uniform: tile indices and their address arithmetic stay on the scalar unit
     const RobotViewS rv(a.robot, P);
     const int pstride = a.PS, MR = a.MR;
     const GqLayout L(pstride, MR, P);
@@ -302,20 +303,22 @@ __global__ __launch_bounds__(256, GQ_WG_PER_CU) void k_goalset_queue(ChunkArgs a
     // (the rows of a tile then see different objects: +2 %), a split of the tile sequence by the number of row-mask hits
     // (a poor predictor of the exact-path work: +7 %), one link per tile (+5 %).
     const int ntiles = ((CH + 3) >> 2) * (10 / LB);
+    const int pc3 = 3 * (p < P ? p : 0);  // lane part of a collision-point address (doubles)
 #pragma unroll 1
     for (int t = wave; t < ntiles; t += 4) {  // every lane stays active: invalid items are flagged, not skipped
         const int rb = t / (10 / LB), l0 = (t - rb * (10 / LB)) * LB;
         {
             const int ci = rb * 4 + (lane >> 4);
             const bool valid = (p < P) && (ci < CH);
-            const int cic = valid ? ci : 0, pc = valid ? p : 0;
+            const int cic = valid ? ci : 0;
+            const int cic9 = cic * 9;  // lane part of a pose address (doubles); base = configuration 1, lds_pose = configuration 0
             float px[LB], py[LB], pz[LB], w[LB];
             uint32_t msk[LB];
             bool wdone[LB];
             uint32_t many = 0;
 #pragma unroll
             for (int k = 0; k < LB; ++k) {
-                msk[k] = valid ? rowmask[(l0 + k) * CH + cic] : 0u;
+                msk[k] = valid ? (rowmask + (l0 + k) * CH)[cic] : 0u;  // uniform part of every address on the scalar unit
                 many |= msk[k];
                 wdone[k] = false;
                 w[k] = 0.0f;
@@ -323,7 +326,7 @@ __global__ __launch_bounds__(256, GQ_WG_PER_CU) void k_goalset_queue(ChunkArgs a
             if (!__any(many != 0)) continue;  // nothing in reach of any row of this tile
 #pragma unroll
             for (int k = 0; k < LB; ++k)
-                pose9_apply(base + ((int64_t)(l0 + k) * pstride + cic) * 9, pts + 3 * ((l0 + k) * P + pc), px[k], py[k], pz[k]);
+                pose9_apply((base + (l0 + k) * pstride * 9) + cic9, (pts + 3 * (l0 + k) * P) + pc3, px[k], py[k], pz[k]);
             for (int o = o_begin; o < o_end; ++o) {
                 const int oo = o - o_begin;
                 const uint32_t bit = 1u << (oo < 31 ? oo : 31);
@@ -346,7 +349,8 @@ __global__ __launch_bounds__(256, GQ_WG_PER_CU) void k_goalset_queue(ChunkArgs a
                     if (!wdone[k]) {  // ||(x_i - x_{i-1}) / dt|| in float32 (config.py:162-187, cost.py:260-275), once per (row, link)
                         const int l = l0 + k;
                         float qx, qy, qz;
-                        pose9_apply(ci > 0 ? base + ((int64_t)l * pstride + cic - 1) * 9 : lds_pose + (int64_t)l * pstride * 9, pts + 3 * (l * P + pc), qx, qy, qz);
+                        // the previous configuration's pose: cfg ci - 1 of the same link, i.e. one 72-byte record back (ci = 0: the start, record 0)
+                        pose9_apply((lds_pose + l * pstride * 9) + cic9, (pts + 3 * l * P) + pc3, qx, qy, qz);
                         const float vx = (px[k] - qx) * a.inv_dt, vy = (py[k] - qy) * a.inv_dt, vz = (pz[k] - qz) * a.inv_dt;
                         w[k] = sqrtf(vx * vx + vy * vy + vz * vz);
                         wdone[k] = true;
