@@ -226,9 +226,11 @@ class ChompEngine:
                 # costs more than it saves (100 scenes: 15.7 ms per plan against 12.5 ms; a device-side scheduler is future work).
                 self._gs_launches += 1
                 use_sched = self.auto_schedule and not self._masked
-                measure = use_sched and not self._measured and self._gs_launches >= 2
+                # small batches keep the even split: measuring and sorting (torch ops, ~0.3 ms once per plan) only pays
+                # when the launch has several rounds of workgroups per CU
+                measure = use_sched and not self._measured and self._gs_launches >= 2 and self.S * self.G >= 2048
                 if use_sched and self.schedule is None:
-                    self.schedule = self.build_schedule(uniform=True)
+                    self.schedule = self._uniform_schedule()
                 ops.goalset_cost_layer(self.robot, self.P, self.scenes, traj_start, self.cv_goals, n_rem, self.cfg.time_interval,
                                        self.traj, (self.pot, self.pgrad, self.col), soften_fingers=False,
                                        layer_soften_fingers=self.cfg.uncheck_finger_collision == -1,
@@ -249,6 +251,24 @@ class ChompEngine:
                         self.end, self.goal_rows, self.goal_point, self.cost_vec, active=self._mask(),
                         goal_count=self.goal_count, eta=self.eta_s)
         return None
+
+    def _uniform_schedule(self) -> torch.Tensor:
+        """The schedule before anything has been measured: the (scene, goal) items in scene-major order, cut into 8 pieces of
+        equal COUNT, one per XCD — built on the host (numpy) and uploaded once."""
+        S, G = self.S, self.G
+        if self.goal_count is not None:
+            items = np.concatenate([s * G + np.arange(int(c)) for s, c in enumerate(self._goal_counts_host)])
+        else:
+            items = np.arange(S * G)
+        n = len(items)
+        pos = np.arange(n)
+        x = np.minimum(8 * pos // max(n, 1), 7)
+        first = np.searchsorted(x, np.arange(8))
+        rank = pos - first[x]
+        slots = int(rank.max()) + 1 if n else 1
+        sched = np.full(slots * 8, -1, np.int32)
+        sched[rank * 8 + x] = items
+        return torch.as_tensor(sched, device=self.device)
 
     def build_schedule(self, active: "torch.Tensor | None" = None, uniform: bool = False) -> torch.Tensor:
         """Dispatch order for omgx_goalset_cost_layer (torch ops on the device, asynchronous, no host sync).

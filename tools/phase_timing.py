@@ -12,6 +12,8 @@ import torch
 
 import bench
 from omg_planner_amd import _lib
+from pathlib import Path
+_lib.LIB_PATH = Path(__file__).resolve().parents[1] / "omg-planner_amd" / "csrc" / "libomg_hip_pt.so"
 from omg_planner_amd.engine import ChompEngine
 
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 100
