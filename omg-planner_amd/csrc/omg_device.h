@@ -310,7 +310,7 @@ __device__ __forceinline__ Accum sdf_point(const omgx_object* __restrict__ objs,
 //   D+306+30P RAD [10]      bounding-sphere radius of each link's centred points
 // DPtr = pointer type of the derived constants: plain global memory, a copy elsewhere (LDS), or the CONSTANT address space —
 // then wave-uniform reads (the chain constants of joint i, the hand / finger rows, radii) become scalar loads into SGPRs
-// instead of per-lane vector loads of the same address (measured in k_goalset_compact's kinematics: the vector loads and
+// instead of per-lane vector loads of the same address (measured in the goal-set kernel's kinematics: the vector loads and
 // their spills were 20 of a goal workgroup's 69 us).  pts() is indexed per lane and always comes from global memory.
 template <class DPtr>
 struct RobotViewT {
@@ -403,7 +403,7 @@ __device__ __forceinline__ void fk_chain(const RV& rv, const double* __restrict_
     }
 }
 
-// The same kinematics split for a workgroup (k_goalset_compact, k_chomp_optimize), where one lane per configuration
+// The same kinematics split for a workgroup (k_goalset_queue, k_chomp_optimize), where one lane per configuration
 // leaves most of the workgroup idle behind a ~2200-instruction serial chain:
 //   stage 1, one lane per (configuration, arm joint):  fk_joint_sincos -> (sin, cos) of the round-tripped angle;
 //   stage 2, one lane per (configuration, row r < 3):  row r of every link pose.  Row r of a product A.B depends on

@@ -2,12 +2,15 @@
 //
 // Kernels in this file
 //   k_sdf_loss        points x objects SDF potential/gradient/collides, one launch (API 1)
+//   k_goalset_queue   (omg_goalset_queue.h) the goal-set batch — kinematics, culling, SDF lookups, arc-length cost per goal — and,
+//                     as extra workgroups of the same launch, the SDF layer of the current trajectories: the dominant kernel
 //   k_fk_poses        Panda FK, one lane per robot configuration -> float64 link poses
-//   k_sdf_chunks      the same SDF evaluation over the collision points of those poses, per (scene, chunk)
-//                     workgroup, optional arc-length weighting + per-chunk reduction (APIs 2 and 3)
+//   k_sdf_chunks      the same SDF evaluation with per-point outputs over the collision points of those poses (or of its own
+//                     kinematics), per (scene, chunk) workgroup, optional arc-length weighting + per-chunk reduction
+//   k_forward_kinematics, k_point_cloud_sdf
 //
 // Hot-path data layout in HBM:
-//   objects[]  128-byte omgx_object records, wave-uniform reads -> SGPRs via scalar loads
+//   objects[]  176-byte omgx_object records, wave-uniform reads -> SGPRs via scalar loads
 //   sdf pool   float32 grids, x-major, z fastest: a trilinear row (z0-1..z0+2) is one 16-byte load
 //   pose ws    [scene][chunk][link][config-in-chunk][12] float64 link poses: the 16 lanes of a row (the P
 //              points of one link at one waypoint) share one 96-byte pose; a wave = 4 consecutive
