@@ -46,12 +46,12 @@ HBM_PEAK_GBS = 8000.0
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 4.0  # 614.4 G wave-instructions/s
 
 
-def build_workload(num_scenes, num_goals, n, grid, seed0, share_grids):
+def build_workload(num_scenes, num_goals, n, grid, seed0, share_grids, num_objects=4):
     from omg_planner_amd import robot as rb, scenes as sc
     from omg_planner_amd.config import Config
     cfg = Config(timesteps=n, use_standoff=False)  # omg.core -exp sets use_standoff=False (core.py:873)
     model = rb.PandaModel(seed=0)
-    scenes = [sc.make_tabletop_scene(seed0 + s, grid=grid) for s in range(num_scenes)]
+    scenes = [sc.make_tabletop_scene(seed0 + s, num_objects=num_objects, grid=grid) for s in range(num_scenes)]
     if not share_grids:  # every scene owns private SDF volumes, like the reference's per-scene sdf_torch
         for scn in scenes:
             for ob in scn.objects:

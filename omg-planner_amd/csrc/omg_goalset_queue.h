@@ -23,8 +23,11 @@
 // the weight: equal up to float32 rounding of a sum of ~300 terms (checked against the oracle at 1e-5).
 #pragma once
 
-#define GQ_TBL_N 8       // objects of a scene whose exact-path constants are staged in LDS (others: evaluated on the spot)
+#define GQ_TBL_MAX 32    // at most this many objects of a scene have their exact-path constants staged in LDS (others: evaluated on the
+                         // spot); how many do is chosen per launch (gq_choose_layout): whatever fits the LDS of the occupancy step the launch is on
+#ifndef GQ_WG_PER_CU
 #define GQ_WG_PER_CU 5   // 32 KB of LDS per workgroup (30 waypoints), <= 96 VGPRs
+#endif
 
 struct GqFar {  // what the far test of one object needs (wave-uniform, SGPRs)
     float T[12], lo[3], flo[3], fhi[3];
@@ -44,16 +47,30 @@ __device__ __forceinline__ GqFar gq_load_far(ObjTablePtr ob) {
 // dynamic LDS behind the poses (bytes, all 16-byte aligned): row masks | exact-path records | collision points | staging
 struct GqLayout {
     int mask_off, tbl_off, pts_off, stage_off, total;
-    __host__ __device__ GqLayout(int PS, int MR, int P) {
+    __host__ __device__ GqLayout(int PS, int MR, int P, int tbl_n) {
         mask_off = PS * 90 * 8;
         tbl_off = mask_off + ((10 * MR * 4 + 15) & ~15);
-        pts_off = tbl_off + GQ_TBL_N * 64;
+        pts_off = tbl_off + tbl_n * 64;
         stage_off = pts_off + ((10 * P * 3 * 8 + 15) & ~15);
         total = stage_off + 4 * 64 * 16;
         const int fk = PS * 90 * 8 + PS * 14 * 8;  // the (sin, cos) table of the kinematics borrows the region behind the poses
         if (total < fk) total = fk;
     }
 };
+
+// How many exact-path records to stage: as many as still fit the LDS of the occupancy step the launch is on anyway.  The steps
+// are what a CU admits (tools/lds_occupancy_probe.hip: 6 workgroups up to 26 624 B, 5 up to 31 744 B, 4 up to 40 960 B — at
+// 32 768 B the occupancy API still says 5 but only 4 become resident).
+static inline int gq_choose_tbl_n(int PS, int MR, int P) {
+    static const int step[] = {26624, 31744, 40960, 53248, 80896, 163840};
+    const int base = GqLayout(PS, MR, P, 0).total;
+    for (int k = 0; k < 6; ++k)
+        if (base + 4 * 64 <= step[k]) {  // at least 4 records
+            const int n = (step[k] - base) / 64;
+            return n < GQ_TBL_MAX ? n : GQ_TBL_MAX;
+        }
+    return 0;
+}
 
 template <int LB, bool STAMP = false>
 __global__ __launch_bounds__(256, GQ_WG_PER_CU) void k_goalset_queue(ChunkArgs a) {
@@ -106,7 +123,7 @@ __global__ __launch_bounds__(256, GQ_WG_PER_CU) void k_goalset_queue(ChunkArgs a
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // provably wave-uniform: tile indices and their address arithmetic stay on the scalar unit
     const RobotViewS rv(a.robot, P);
     const int pstride = a.PS, MR = a.MR;
-    const GqLayout L(pstride, MR, P);
+    const GqLayout L(pstride, MR, P, a.tbl_n);
     char* const lds_bytes = reinterpret_cast<char*>(lds_pose);
     uint32_t* const rowmask = reinterpret_cast<uint32_t*>(lds_bytes + L.mask_off);
     if (is_layer) {
@@ -120,7 +137,7 @@ __global__ __launch_bounds__(256, GQ_WG_PER_CU) void k_goalset_queue(ChunkArgs a
         return;
     }
     const unsigned long long work_t0 = STAMP ? wall_clock64() : 0ull;
-    uint32_t* const tbl = reinterpret_cast<uint32_t*>(lds_bytes + L.tbl_off);      // [GQ_TBL_N][16]
+    uint32_t* const tbl = reinterpret_cast<uint32_t*>(lds_bytes + L.tbl_off);      // [a.tbl_n][16]
     double* const pts = reinterpret_cast<double*>(lds_bytes + L.pts_off);          // [10][P][3]
     float* const stage = reinterpret_cast<float*>(lds_bytes + L.stage_off) + wave * 256;  // wave-private [64][4]
 
@@ -155,10 +172,10 @@ __global__ __launch_bounds__(256, GQ_WG_PER_CU) void k_goalset_queue(ChunkArgs a
     GS_WG_STAMP(2);
     const double* base = lds_pose + 9;
 
-    // ---- exact-path records of the scene's first GQ_TBL_N objects and the robot's collision points -> LDS
+    // ---- exact-path records of the scene's first a.tbl_n objects and the robot's collision points -> LDS
     // record (16 dwords): [0..5] 1 / extent as doubles | [6..8] dims | [9,10] byte offset of the grid in the pool |
     //                     [11] eps / 2 | [12] eps | [13] clearance | [14] padding scale | [15] 1 / (2 eps)
-    if ((int)threadIdx.x < GQ_TBL_N && o_begin + (int)threadIdx.x < o_end) {
+    if ((int)threadIdx.x < a.tbl_n && o_begin + (int)threadIdx.x < o_end) {
         const omgx_object* ob = a.objects + o_begin + threadIdx.x;
         uint32_t* e = tbl + threadIdx.x * 16;
 #pragma unroll
@@ -334,7 +351,7 @@ __global__ __launch_bounds__(256, GQ_WG_PER_CU) void k_goalset_queue(ChunkArgs a
                 ObjTablePtr ob = as_const(a.objects) + o;
                 if (ob->disabled > 0) continue;  // .cu:115-116
                 const GqFar fp = gq_load_far(ob);
-                const bool queued = oo < GQ_TBL_N;  // objects beyond the LDS records (rare) are evaluated on the spot
+                const bool queued = oo < a.tbl_n;  // objects beyond the LDS records (rare) are evaluated on the spot
 #pragma unroll
                 for (int k = 0; k < LB; ++k) {
                     // SE3(pose) * point (.cu:125-133) and the far test of pair_prepare

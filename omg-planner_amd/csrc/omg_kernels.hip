@@ -199,6 +199,7 @@ struct ChunkArgs {
     // goal] receives the workgroup's duration in 10 ns ticks (0 for skipped goals).
     const int32_t* schedule;
     int sched_len;             // entries of `schedule` = goal workgroups of the launch (a multiple of 8)
+    int tbl_n;                 // exact-path records staged in LDS (k_goalset_queue; chosen by the launcher)
     uint32_t* work;
 };
 
@@ -649,7 +650,9 @@ static int launch_goalset(ChunkArgs& ca, int timing_kind, hipStream_t st) {
     const int64_t goal_blocks = ca.schedule ? (int64_t)ca.sched_len : (int64_t)scene_groups * ca.NCH * 8;
     const int64_t grid = goal_blocks + (layer ? (int64_t)scene_groups * GS_LAYER_PARTS * 8 : 0);
     if (grid > 0x7fffffff) return OMGX_ERR_UNSUPPORTED;
-    const size_t lds = (size_t)GqLayout(ca.PS, ca.MR, ca.P).total;
+    ca.tbl_n = gq_choose_tbl_n(ca.PS, ca.MR, ca.P);
+    const size_t lds = (size_t)GqLayout(ca.PS, ca.MR, ca.P, ca.tbl_n).total;
+    if (lds > 64 * 1024) return OMGX_ERR_UNSUPPORTED;  // cannot happen within OMGX_MAX_WAYPOINTS / OMGX_MAX_POINTS (59 KB at 64 x 16)
     hipEvent_t ev0, ev1;
     timing_events(timing_kind, &ev0, &ev1);
     if (ca.work) {

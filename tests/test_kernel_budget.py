@@ -33,15 +33,29 @@ def test_goalset_kernel_register_and_spill_budget(tmp_path):
 
 
 def test_goalset_kernel_lds_fits_five_workgroups_per_cu():
-    """The launcher's LDS layout for the bench shape (30 waypoints, 15 points per link) — restated from GqLayout
-    (omg_goalset_queue.h) — stays within the 31 744 B that still admit 5 workgroups per CU."""
+    """The launcher's LDS layout for the bench shape (30 waypoints, 15 points per link) — restated from GqLayout /
+    gq_choose_tbl_n (omg_goalset_queue.h) — stays within the 31 744 B that still admit 5 workgroups per CU, with 8
+    exact-path records staged; the largest shape the ABI accepts (64 waypoints x 16 points) stays below the 64 KB a launch may
+    ask for without opting in."""
     src = (ROOT / "omg-planner_amd" / "csrc" / "omg_goalset_queue.h").read_text()
-    tbl_n = int(re.search(r"#define GQ_TBL_N (\d+)", src).group(1))
-    PS, MR, P = 31, 30, 15
-    mask_off = PS * 90 * 8
-    tbl_off = mask_off + ((10 * MR * 4 + 15) & ~15)
-    pts_off = tbl_off + tbl_n * 64
-    stage_off = pts_off + ((10 * P * 3 * 8 + 15) & ~15)
-    total = max(stage_off + 4 * 64 * 16, PS * 90 * 8 + PS * 14 * 8)
-    assert total <= 31744, total
+    steps = [int(x) for x in re.search(r"static const int step\[\] = \{([^}]*)\}", src).group(1).split(",")]
+    tbl_max = int(re.search(r"#define GQ_TBL_MAX (\d+)", src).group(1))
+
+    def total(PS, MR, P, n):
+        mask_off = PS * 90 * 8
+        tbl_off = mask_off + ((10 * MR * 4 + 15) & ~15)
+        pts_off = tbl_off + n * 64
+        stage_off = pts_off + ((10 * P * 3 * 8 + 15) & ~15)
+        return max(stage_off + 4 * 64 * 16, PS * 90 * 8 + PS * 14 * 8)
+
+    def choose(PS, MR, P):
+        base = total(PS, MR, P, 0)
+        for st in steps:
+            if base + 4 * 64 <= st:
+                return min(tbl_max, (st - base) // 64)
+        return 0
+
+    n = choose(31, 30, 15)
+    assert n == 8 and total(31, 30, 15, n) <= 31744
+    assert total(65, 64, 16, choose(65, 64, 16)) <= 64 * 1024
     assert "__shared__ float" not in src  # no static LDS on top of the dynamic allocation

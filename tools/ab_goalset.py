@@ -25,12 +25,14 @@ def main():
     ap.add_argument("--scenes", type=int, default=100)
     ap.add_argument("--goals", type=int, default=64)
     ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--waypoints", type=int, default=30)
+    ap.add_argument("--objects", type=int, default=4, help="objects per scene besides the table")
     ap.add_argument("--tag", default="")
     args = ap.parse_args()
     if args.lib:
         _lib.LIB_PATH = Path(args.lib).resolve()
     from omg_planner_amd.engine import ChompEngine
-    cfg, model, batch, start, goals = bench.build_workload(args.scenes, args.goals, 30, 64, 0, False)
+    cfg, model, batch, start, goals = bench.build_workload(args.scenes, args.goals, args.waypoints, 64, 0, False, num_objects=args.objects)
     eng = ChompEngine(model, batch, cfg, start, goals, device="cuda:0", ol_alg="MD")
     eng.auto_schedule = args.sched == "auto"
     lib = _lib.lib()
