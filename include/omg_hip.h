@@ -242,7 +242,7 @@ int omgx_goalset_cost(const double* robot, int32_t n_points,
  *           of scene schedule[k] / num_goals, or on nothing when schedule[k] < 0.  Every (scene, goal) that is to be
  *           evaluated must appear exactly once; any such list gives the same results.  Keep a scene's goals on one or two
  *           XCDs (k % 8): its SDF volumes then stay in that XCD's L2 — spread over all eight the launch takes 1.7x as long.
- *           ChompEngine.build_schedule (engine.py) derives an order from `work` that gives every XCD the same measured
+ *           omgx_goalset_schedule (section 7) derives an order from `work` that gives every XCD the same measured
  *           work, heaviest scenes first (ABI 4).
  *   work    optional [S*num_goals] uint32: receives how long each goal's workgroup ran, in 10 ns ticks (0 = skipped).
  * ------------------------------------------------------------------------------------------- */
@@ -376,6 +376,28 @@ int omgx_point_cloud_sdf(const double* points, int32_t num_points, const double*
                          const int32_t* h_dims, float* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * (7) omgx_goalset_schedule — dispatch order for omgx_goalset_cost_layer from the durations it recorded in `work` (ABI 4)
+ * No counterpart in the reference (it plans one scene at a time); this is the engine's load balancing across the 8 XCDs.
+ * The kept (scene, goal) items — scene active, goal < goal_count[scene] — are laid out scene by scene, scenes by decreasing
+ * total work, each scene's goals longest first, and this list is cut into 8 contiguous pieces of equal (clamped) work;
+ * piece x becomes the workgroups k = 8 r + x, r = 0, 1, ... of the launch.  A scene's workgroups thus stay on one XCD (two
+ * where a cut falls inside it: its SDF volumes stay in those L2s), every XCD gets the same work.  Weights are clamped to
+ * [L, slack L], L = mean / 1.4, so that no piece needs more than slack times the even share of slots.
+ *   work      [S*G] uint32 (0 counts as 1), or NULL: all items weigh the same
+ *   active, goal_count   optional [S] int32 as above
+ *   schedule  [omgx_goalset_schedule_len(S, G, slack)] int32 out (unused slots: -1)
+ * Exact (integer) definition, restated in tests/test_gpu_schedule.py: w = work, 0 -> 1; T = sum of w over the kept items, N their
+ * number; L = max(1, 10 T / (14 N)), wc = min(max(w, L), slack L); scenes ordered by decreasing sum of w (ties: lower index
+ * first), a scene's goals by decreasing w (ties: lower goal first); an item with c = the wc of all items before it in that
+ * list belongs to piece x = min(7, 8 (2 c + wc) / (2 Tc)), Tc = sum of wc; with p its position in the list and first(x) the
+ * lowest position of piece x:  schedule[8 (p - first(x)) + x] = scene * G + goal.
+ * One workgroup; S * G <= 65536 and S <= 4096, else OMGX_ERR_UNSUPPORTED.
+ * ------------------------------------------------------------------------------------------- */
+int32_t omgx_goalset_schedule_len(int32_t num_scenes, int32_t num_goals, int32_t slack);
+int omgx_goalset_schedule(const uint32_t* work, const int32_t* active, const int32_t* goal_count, int32_t num_scenes,
+                          int32_t num_goals, int32_t slack, int32_t* schedule, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Diagnostics
  * ------------------------------------------------------------------------------------------- */
 const char* omgx_last_error(void); /* thread-local text of the last OMGX_ERR_LAUNCH               */
@@ -386,8 +408,10 @@ const char* omgx_last_error(void); /* thread-local text of the last OMGX_ERR_LAU
  * goal-set batch; 1 = with gradients, i.e. the waypoint batch; may be NULL) and returns how many;
  * not for graph capture.
  * Threads: every other entry point may be called concurrently from several host threads (on different streams); the
- * library's only process-wide state beside this hook is set-once (kernel attributes per device, tuning switches read
- * from the environment at first use).  The timing hook itself is for ONE measuring thread: enable, launch, collect. */
+ * library's only process-wide state beside this hook is set-once (kernel attributes per device); there are no
+ * environment switches.  The timing hook is a process-wide recorder for ONE device, guarded by a mutex: enable, launch, collect;
+ * launches on another device than the one current at omgx_timing_enable are not recorded.  h_kind: 0 = goal-set launch
+ * (with or without the trajectory layer), 1 = layer-only launch (omgx_fk_sdf on a trajectory-sized batch). */
 int omgx_timing_enable(int32_t on);
 int omgx_timing_collect(float* h_ms, int32_t* h_kind, int32_t cap);
 int omgx_abi_version(void);        /* bumps when a signature or struct layout changes              */

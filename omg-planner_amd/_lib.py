@@ -18,7 +18,7 @@ ABI_VERSION = 4  # omgx_abi_version() of the library these argtypes describe
 
 # every symbol include/omg_hip.h declares
 EXPORTS = ["omgx_sdf_loss_forward", "omgx_fk_sdf_workspace_bytes", "omgx_fk_sdf", "omgx_forward_kinematics",
-           "omgx_goalset_workspace_bytes", "omgx_goalset_cost", "omgx_goalset_cost_layer", "omgx_chomp_aux_doubles", "omgx_chomp_optimize",
+           "omgx_goalset_workspace_bytes", "omgx_goalset_cost", "omgx_goalset_cost_layer", "omgx_goalset_schedule_len", "omgx_goalset_schedule", "omgx_chomp_aux_doubles", "omgx_chomp_optimize",
            "omgx_learner_state_doubles", "omgx_goal_update", "omgx_goal_update_optimize", "omgx_point_cloud_sdf", "omgx_last_error", "omgx_abi_version", "omgx_device_arch",
            "omgx_timing_enable", "omgx_timing_collect"]
 
@@ -77,6 +77,10 @@ def lib() -> C.CDLL:
         l.omgx_goalset_cost.argtypes = [vp, i32, vp, vp, vp, vp, i64, vp, i32, i32, i32, f64, i32, vp, vp, vp, vp, vp, vp, vp]
         l.omgx_goalset_cost_layer.argtypes = [vp, i32, vp, vp, vp, vp, i64, vp, i32, i32, i32, f64, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp]
         l.omgx_goalset_cost_layer.restype = C.c_int
+        l.omgx_goalset_schedule_len.argtypes = [i32, i32, i32]
+        l.omgx_goalset_schedule_len.restype = i32
+        l.omgx_goalset_schedule.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp]
+        l.omgx_goalset_schedule.restype = C.c_int
         l.omgx_chomp_optimize.argtypes = [vp, C.POINTER(ChompParams)] + [vp] * 9 + [i32] + [vp] * 4 + [i32, vp]
         l.omgx_learner_state_doubles.argtypes = [i32]
         l.omgx_learner_state_doubles.restype = i64

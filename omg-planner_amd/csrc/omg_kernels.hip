@@ -833,6 +833,123 @@ extern "C" int omgx_goalset_cost(const double* robot, int32_t n_points, const om
                              nullptr, 0, 0, nullptr, nullptr, nullptr, active, goal_count, nullptr, 0, nullptr, stream);
 }
 
+// =================================================================================================
+// (7) k_goalset_schedule — dispatch order of the goal workgroups from their measured durations (include/omg_hip.h)
+// =================================================================================================
+// One workgroup of 1024.  Everything is integer arithmetic with fixed tie-breaks (index order), so the schedule is a pure
+// function of its inputs.  Per-scene arrays live in LDS; an item's position in the list is found by counting (its scene's rank
+// among the scenes, its own rank among its scene's goals) — O(S^2 + S G^2) comparisons, ~0.5 M for 100 x 64.
+#define SCH_TPB 1024
+struct SchedArgs {
+    const uint32_t* work;
+    const int32_t* active;
+    const int32_t* goal_count;
+    int S, G, slack, slots;
+    int32_t* sched;
+};
+
+__global__ __launch_bounds__(SCH_TPB) void k_goalset_schedule(SchedArgs a) {
+    extern __shared__ unsigned long long sch_lds[];
+    const int S = a.S, G = a.G, tid = threadIdx.x;
+    unsigned long long* Ws = sch_lds;                                   // [S] scene weight (unclamped)
+    unsigned long long* Wc = Ws + S;                                    // [S] scene weight (clamped)
+    unsigned long long* offw = Wc + S;                                  // [S] clamped weight of the scenes ranked before
+    uint32_t* nval = reinterpret_cast<uint32_t*>(offw + S);             // [S] kept goals
+    uint32_t* offp = nval + S;                                          // [S] items of the scenes ranked before
+    uint32_t* srank = offp + S;                                         // [S]
+    __shared__ unsigned long long tot[2];                               // total weight, total clamped weight
+    __shared__ uint32_t cnt_all;
+    __shared__ uint32_t first[8];
+    auto kept = [&](int s, int g) { return (!a.active || a.active[s] != 0) && (!a.goal_count || g < a.goal_count[s]); };
+    auto wt = [&](int s, int g) -> uint32_t { const uint32_t w = a.work ? a.work[(size_t)s * G + g] : 1u; return w ? w : 1u; };
+    if (tid == 0) { tot[0] = tot[1] = 0ull; cnt_all = 0u; }
+    if (tid < 8) first[tid] = 0xffffffffu;
+    for (int i = tid; i < a.slots * 8; i += SCH_TPB) a.sched[i] = -1;
+    __syncthreads();
+    for (int s = tid; s < S; s += SCH_TPB) {  // scene weights
+        unsigned long long w = 0;
+        uint32_t n = 0;
+        for (int g = 0; g < G; ++g)
+            if (kept(s, g)) { w += wt(s, g); ++n; }
+        Ws[s] = w; nval[s] = n;
+        atomicAdd(&tot[0], w);
+        atomicAdd(&cnt_all, n);
+    }
+    __syncthreads();
+    const unsigned long long n_all = cnt_all ? cnt_all : 1u;
+    unsigned long long lo = (10ull * tot[0]) / (14ull * n_all);
+    if (lo < 1) lo = 1;
+    const unsigned long long hi = (unsigned long long)a.slack * lo;
+    auto wclamp = [&](uint32_t w) -> unsigned long long { return w < lo ? lo : (w > hi ? hi : (unsigned long long)w); };
+    for (int s = tid; s < S; s += SCH_TPB) {  // clamped scene weights, scene ranks (heaviest first, ties by index)
+        unsigned long long w = 0;
+        for (int g = 0; g < G; ++g)
+            if (kept(s, g)) w += wclamp(wt(s, g));
+        Wc[s] = w;
+        atomicAdd(&tot[1], w);
+        uint32_t r = 0;
+        for (int q = 0; q < S; ++q) r += (Ws[q] > Ws[s] || (Ws[q] == Ws[s] && q < s)) ? 1u : 0u;
+        srank[s] = r;
+    }
+    __syncthreads();
+    for (int s = tid; s < S; s += SCH_TPB) {  // what the scenes ranked before this one hold
+        unsigned long long w = 0;
+        uint32_t n = 0;
+        for (int q = 0; q < S; ++q)
+            if (srank[q] < srank[s]) { w += Wc[q]; n += nval[q]; }
+        offw[s] = w; offp[s] = n;
+    }
+    __syncthreads();
+    const unsigned long long total_c = tot[1] ? tot[1] : 1ull;
+    auto place = [&](int s, int g, uint32_t& pos, int& x) {
+        const uint32_t w = wt(s, g);
+        uint32_t r = 0;
+        unsigned long long before = 0;
+        for (int q = 0; q < G; ++q) {
+            if (!kept(s, q)) continue;
+            const uint32_t wq = wt(s, q);
+            if (wq > w || (wq == w && q < g)) { ++r; before += wclamp(wq); }
+        }
+        pos = offp[s] + r;
+        const unsigned long long c2 = 2ull * (offw[s] + before) + wclamp(w);
+        const unsigned long long xx = (8ull * c2) / (2ull * total_c);
+        x = xx > 7 ? 7 : (int)xx;
+    };
+    for (int i = tid; i < S * G; i += SCH_TPB) {  // first position of every piece
+        const int s = i / G, g = i - s * G;
+        if (!kept(s, g)) continue;
+        uint32_t pos; int x;
+        place(s, g, pos, x);
+        atomicMin(&first[x], pos);
+    }
+    __syncthreads();
+    for (int i = tid; i < S * G; i += SCH_TPB) {
+        const int s = i / G, g = i - s * G;
+        if (!kept(s, g)) continue;
+        uint32_t pos; int x;
+        place(s, g, pos, x);
+        const uint32_t r = pos - first[x];
+        if ((int)r < a.slots) a.sched[(size_t)r * 8 + x] = i;  // always true: the clamp bounds a piece's count (include/omg_hip.h)
+    }
+}
+
+extern "C" int32_t omgx_goalset_schedule_len(int32_t num_scenes, int32_t num_goals, int32_t slack) {
+    if (num_scenes <= 0 || num_goals <= 0 || slack < 1) return 0;
+    const int64_t n = (int64_t)num_scenes * num_goals;
+    return (int32_t)(((slack * n + 7) / 8 + 2) * 8);
+}
+
+extern "C" int omgx_goalset_schedule(const uint32_t* work, const int32_t* active, const int32_t* goal_count, int32_t num_scenes,
+                                     int32_t num_goals, int32_t slack, int32_t* schedule, void* stream) {
+    if (num_scenes <= 0 || num_goals <= 0 || slack < 1 || !schedule) return OMGX_ERR_INVALID;
+    if ((int64_t)num_scenes * num_goals > 65536 || num_scenes > 4096) return OMGX_ERR_UNSUPPORTED;
+    SchedArgs a{work, active, goal_count, num_scenes, num_goals, slack, omgx_goalset_schedule_len(num_scenes, num_goals, slack) / 8, schedule};
+    const size_t lds = (size_t)num_scenes * (3 * sizeof(unsigned long long) + 3 * sizeof(uint32_t));
+    hipLaunchKernelGGL(k_goalset_schedule, dim3(1), dim3(SCH_TPB), lds, (hipStream_t)stream, a);
+    OMGX_CHECK_LAUNCH("k_goalset_schedule");
+    return OMGX_OK;
+}
+
 extern "C" int omgx_goalset_cost_layer(const double* robot, int32_t n_points, const omgx_object* objects,
                                        const int32_t* scene_begin, const float* sdf_pool, const double* traj_start,
                                        int64_t traj_start_stride, const double* goals, int32_t num_scenes, int32_t num_goals,

@@ -47,6 +47,11 @@ class ChompEngine:
     split_update = None
     # True: iterate() goes through iterate_separate(), the five separate entry points (cross-checks)
     separate_launches = False
+    # Under early stop: iterations between rebuilds of the schedule without the terminated scenes (omgx_goalset_schedule, one
+    # ~10 us launch); 0: scene-major order once scenes drop out (the kernel then deals the remaining scenes to the XCDs itself).
+    # Measured equal within 1 % for 100 and 13 scenes x 64 goals (tools/ab_plan.py: 12.5 / 6.3 ms per early-stop plan either way), so
+    # the simpler policy is the default.
+    reschedule_every = 0
     schedule_slack = 2  # goal workgroup slots per XCD in units of the even share (see build_schedule)
 
     def __init__(self, model: PandaModel, batch: SceneBatch, cfg: Config, start: np.ndarray, goal_set: np.ndarray,
@@ -129,6 +134,7 @@ class ChompEngine:
         self.schedule = None
         self._gs_launches = 0
         self._measured = False
+        self._sched_buf, self._sched_flip, self._sched_age = None, 0, None
         self._ticket = 0
         self._num_cus = torch.cuda.get_device_properties(dev).multi_processor_count
         self._gather_goal()
@@ -220,17 +226,20 @@ class ChompEngine:
             traj_start = self.traj[:, prm.start_idx]  # strided view into the trajectory tensor: no copy kernel
             if with_layer:  # the SDF layer of the current trajectories rides on the goal-set launch
                 # the second launch is the measuring one (the first runs on cold caches and would distort the weights);
-                # until then the items are split evenly by count
-                # With an active mask (early stop) the launch goes back to scene-major order, where the kernel itself deals
-                # the remaining scenes to the XCDs again at no cost; rebuilding the schedule with torch ops as scenes drop out
-                # costs more than it saves (100 scenes: 15.7 ms per plan against 12.5 ms; a device-side scheduler is future work).
+                # until then the items are split evenly by count.  Small batches keep the even split: measuring only pays
+                # when the launch has several rounds of workgroups per CU.
+                # With an active mask (early stop) the launch goes back to scene-major order, or — `reschedule_every` > 0 — the
+                # schedule is rebuilt from the same measured durations without the scenes that have terminated.
                 self._gs_launches += 1
-                use_sched = self.auto_schedule and not self._masked
-                # small batches keep the even split: measuring and sorting (torch ops, ~0.3 ms once per plan) only pays
-                # when the launch has several rounds of workgroups per CU
+                use_sched = self.auto_schedule and (not self._masked or (self._measured and bool(self.reschedule_every)))
                 measure = use_sched and not self._measured and self._gs_launches >= 2 and self.S * self.G >= 2048
+                if use_sched and self._masked:
+                    if self._sched_age is None or self._sched_age >= self.reschedule_every:
+                        self.schedule = self.build_schedule(active=self._mask())
+                        self._sched_age = 0
+                    self._sched_age += 1
                 if use_sched and self.schedule is None:
-                    self.schedule = self._uniform_schedule()
+                    self.schedule = self.build_schedule(uniform=True)
                 ops.goalset_cost_layer(self.robot, self.P, self.scenes, traj_start, self.cv_goals, n_rem, self.cfg.time_interval,
                                        self.traj, (self.pot, self.pgrad, self.col), soften_fingers=False,
                                        layer_soften_fingers=self.cfg.uncheck_finger_collision == -1,
@@ -271,48 +280,28 @@ class ChompEngine:
         return torch.as_tensor(sched, device=self.device)
 
     def build_schedule(self, active: "torch.Tensor | None" = None, uniform: bool = False) -> torch.Tensor:
-        """Dispatch order for omgx_goalset_cost_layer (torch ops on the device, asynchronous, no host sync).
+        """Dispatch order for omgx_goalset_cost_layer (omgx_goalset_schedule: one small launch on the current stream, no host
+        sync).
 
         The (scene, goal) items are laid out scene by scene — scenes by decreasing measured work (`work`, the durations of
         the measuring launch), each scene's goals longest first — and this list is cut into 8 contiguous pieces of equal
         total work, one per XCD (goal workgroup b of the launch runs on XCD b % 8).  Every XCD then holds whole scenes except
         for at most two that it shares with a neighbour, so a scene's SDF volumes stay in one or two L2s, and all XCDs finish
         together whatever the number of scenes (12 or 13 scenes per GPU would otherwise leave 3 of 8 XCDs with half the
-        load).  `uniform`: all items weigh the same (before anything has been measured).  `active` [S] int32: scenes
-        with 0 are left out.  An XCD has room for `schedule_slack` (2) times its share of the items; the weights are
-        clamped to a band [L, schedule_slack * L] around their mean, so no piece of the list can need more."""
-        S, G, dev = self.S, self.G, self.device
-        w = torch.ones((S, G), dtype=torch.int64, device=dev) if uniform else self.work.view(S, G).to(torch.int64).clamp(min=1)
-        live = torch.ones(S, dtype=torch.bool, device=dev) if active is None else active != 0
-        if self.goal_count is not None:  # padding of ragged goal sets: never scheduled
-            keep = torch.arange(G, device=dev)[None, :] < self.goal_count[:, None]
-        else:
-            keep = torch.ones((S, G), dtype=torch.bool, device=dev)
-        keep = keep & live[:, None]
-        w = torch.where(keep, w, torch.zeros_like(w))
-        order = torch.argsort(w.sum(1), descending=True, stable=True)           # scenes, heaviest first
-        gorder = torch.argsort(w[order], dim=1, descending=True, stable=True)   # goals of scene order[k], longest first
-        items = (order[:, None] * G + gorder).reshape(-1)
-        wi = torch.gather(w[order], 1, gorder).reshape(-1)
-        valid = wi > 0                                                          # dropped items sit at the end of every scene
-        n_valid = valid.sum().clamp(min=1)
-        slack = self.schedule_slack
-        lo = ((10 * wi.sum()) // (n_valid * 14)).clamp(min=1)                   # L = mean / 1.4 (the mean sits in the middle of [L, 2 L] on a log scale)
-        wc = torch.where(valid, torch.minimum(torch.maximum(wi, lo), slack * lo), torch.zeros_like(wi))
-        cum = torch.cumsum(wc, 0)
-        total = cum[-1].clamp(min=1)
-        slots = -(-slack * S * G // 8) + 2                                      # per XCD: count <= (total / 8) / L + 1 <= slack * n / 8 + 1
-        pos = (torch.cumsum(valid.to(torch.int64), 0) - 1).clamp(min=0)         # index among the scheduled items
-        x = torch.clamp((8 * (2 * cum - wc)) // (2 * total), min=0, max=7)      # piece of the cumulative-work axis the item's centre is in
-        # rank of the item inside its piece: its index among the scheduled items minus that of the piece's first item
-        big = torch.full_like(pos, S * G)
-        firsts = torch.full((8,), S * G, dtype=torch.int64, device=dev).scatter_reduce(0, x, torch.where(valid, pos, big), reduce="amin", include_self=True)
-        rank = pos - firsts[x]
-        ok = valid & (rank >= 0) & (rank < slots)
-        block = torch.where(ok, rank * 8 + x, torch.zeros_like(rank))
-        sched = torch.full((slots * 8,), -1, dtype=torch.int32, device=dev)
-        sched[block[ok]] = items[ok].to(torch.int32)
-        return sched
+        load).  `uniform`: all items weigh the same.  `active` [S] int32: scenes with 0 are left out; ragged goal sets leave
+        out their padding.  An XCD has room for `schedule_slack` (2) times its share of the items; the weights are clamped to a
+        band [L, schedule_slack * L] around their mean, so no piece of the list can need more."""
+        if self.S * self.G > 65536 or self.S > 4096:  # beyond the scheduler kernel's single workgroup: even split by count
+            return self._uniform_schedule()
+        if self._sched_buf is None:
+            self._sched_buf = [None, None]
+        # two buffers in turn: a launch that still reads the previous schedule (another stream's view of it) is never overwritten
+        self._sched_flip ^= 1
+        buf = self._sched_buf[self._sched_flip]
+        out = ops.goalset_schedule(None if uniform else self.work, self.S, self.G, active=active, goal_count=self.goal_count,
+                                   slack=self.schedule_slack, out=buf, device=self.device)
+        self._sched_buf[self._sched_flip] = out
+        return out
 
     def _layer(self):
         """SDF layer outputs of the current waypoints (first half of Cost.compute_total_loss)."""

@@ -159,6 +159,28 @@ def goalset_cost_layer(robot, P, scenes: DeviceScenes, traj_start, goals, n_rema
     return cost, col
 
 
+def goalset_schedule(work, num_scenes: int, num_goals: int, active=None, goal_count=None, slack: int = 2, out=None, device=None):
+    """Dispatch order for goalset_cost_layer (omgx_goalset_schedule): int32 device tensor [omgx_goalset_schedule_len].
+    work: int32/uint32 device tensor [S*G] of durations (None: all items weigh the same).  Asynchronous, one small launch.
+    The result lives on the device of `out`, else of the first tensor given, else `device`."""
+    l = _lib.lib()
+    n = int(l.omgx_goalset_schedule_len(num_scenes, num_goals, slack))
+    if out is None:
+        for t in (work, active, goal_count):
+            if t is not None:
+                device = t.device
+                break
+        if device is None:
+            raise _lib.OmgHipError("goalset_schedule needs a device: pass work, active, goal_count, out or device")
+        out = torch.empty(n, dtype=torch.int32, device=device)
+    _i32n(out, n, "schedule")
+    _i32n(work, num_scenes * num_goals, "work")
+    with torch.cuda.device(out.device):
+        check(l.omgx_goalset_schedule(_ptr(work), _ptr(_active(active, num_scenes)), _ptr(_active(goal_count, num_scenes)), num_scenes,
+                                      num_goals, slack, _ptr(out), _stream()), "omgx_goalset_schedule")
+    return out
+
+
 def forward_kinematics(robot, P, joints, want_joint_info=True):
     """joints [B,9] f64 -> link poses [B,10,4,4], joint origins [B,10,3] | None, joint axes [B,10,3] | None."""
     _need(joints, torch.float64, "joints")
