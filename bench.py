@@ -117,7 +117,7 @@ def cpu_baseline(cfg, model, batch, start, goals, n, budget_s=8.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--scenes", type=int, default=100, help="scenes per GPU (weak scaling)")
     ap.add_argument("--total-scenes", type=int, default=0, help="scenes in all, sharded over the GPUs (strong scaling)")

@@ -836,6 +836,9 @@ __global__ __launch_bounds__(CH_TPB) void k_update_optimize(omg_learner::Learner
 }
 
 #ifdef OMGX_PHASE_TIMING
+extern "C" int omgx_debug_learner_phase_times(unsigned long long* h_out, int n) {
+    return (int)hipMemcpyFromSymbol(h_out, HIP_SYMBOL(omg_learner::g_learner_phase), sizeof(unsigned long long) * (n < 16 ? n : 16));
+}
 extern "C" int omgx_debug_chomp_phase_times(unsigned long long* h_out, int n) {
     return (int)hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_chomp_phase), sizeof(unsigned long long) * (n < 32 ? n : 32));
 }

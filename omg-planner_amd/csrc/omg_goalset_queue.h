@@ -9,7 +9,8 @@
 //
 // What is new is what happens to a (point, object) pair that survives the far test.  It becomes a 5-dword ENTRY — the
 // object-space offset, the point's arc-length weight ||x_i - x_(i-1)|| / dt and the object's index — and joins a queue
-// that lives in the wave's registers, one entry per lane, across objects, links and waypoints.  Only when 64 entries are
+// that lives in a wave-private LDS ring (slot i = entry i; the object index in a register of lane i) across objects, links
+// and waypoints.  Only when 64 entries are
 // there does the wave run the exact path (grid coordinates, 8 voxels, trilinear value, hinge) — on 64 live lanes instead
 // of the 63 % the per-(link pair, object) batches reached — with the per-object constants read per lane from a 64-byte
 // LDS record.  The exact path is also split in two: ISSUE (coordinates, addresses, the four 8-byte gathers) and, a whole
@@ -121,6 +122,7 @@ __global__ __launch_bounds__(256, GQ_WG_PER_CU) void k_goalset_queue(ChunkArgs a
     const int P = a.P, CH = a.CH;
     const int p = threadIdx.x & 15, lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // provably wave-uniform: tile indices and their address arithmetic stay on the scalar unit
+    const int tid = (int)threadIdx.x;
     const RobotViewS rv(a.robot, P);
     const int pstride = a.PS, MR = a.MR;
     const GqLayout L(pstride, MR, P, a.tbl_n);
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(256, GQ_WG_PER_CU) void k_goalset_queue(ChunkArgs a
         return;
     }
     if (a.goal_count && chunk >= as_const(a.goal_count)[s]) {  // padding of a ragged goal set
-        if (STAMP && threadIdx.x == 0) a.work[(int64_t)s * a.NCH + chunk] = 0u;
+        if (STAMP && tid == 0) a.work[(int64_t)s * a.NCH + chunk] = 0u;
         return;
     }
     const unsigned long long work_t0 = STAMP ? wall_clock64() : 0ull;
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(256, GQ_WG_PER_CU) void k_goalset_queue(ChunkArgs a
         const int ncfg = CH + 1;
         double* sc = reinterpret_cast<double*>(rowmask);  // [ncfg][7][2]
         auto joint = [&](int cfg, int d) { return cfg == 0 ? q0[d] : q0[d] + ((double)cfg * (1.0 / (double)(CH + 1))) * (qg[d] - q0[d]); };
-        for (int t = threadIdx.x; t < ncfg * 7; t += 256) {
+        for (int t = tid; t < ncfg * 7; t += 256) {
             const int cfg = t / 7, i = t - cfg * 7;
             double sn, cs;
             fk_joint_sincos(joint(cfg, i), sn, cs);
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(256, GQ_WG_PER_CU) void k_goalset_queue(ChunkArgs a
         }
         __syncthreads();
         GS_WG_STAMP(1);
-        for (int t = threadIdx.x; t < ncfg * 3; t += 256) {
+        for (int t = tid; t < ncfg * 3; t += 256) {
             const int cfg = t / 3, rr = t - cfg * 3;
             fk_chain_row(rv, rr, sc + 14 * cfg, joint(cfg, 7), joint(cfg, 8), [&](int l, double r0, double r1, double r2, double tr) {
                 double* dst = lds_pose + ((size_t)l * pstride + cfg) * 9;  // rows 0 and 1 of R, then t
@@ -175,9 +177,9 @@ __global__ __launch_bounds__(256, GQ_WG_PER_CU) void k_goalset_queue(ChunkArgs a
     // ---- exact-path records of the scene's first a.tbl_n objects and the robot's collision points -> LDS
     // record (16 dwords): [0..5] 1 / extent as doubles | [6..8] dims | [9,10] byte offset of the grid in the pool |
     //                     [11] eps / 2 | [12] eps | [13] clearance | [14] padding scale | [15] 1 / (2 eps)
-    if ((int)threadIdx.x < a.tbl_n && o_begin + (int)threadIdx.x < o_end) {
-        const omgx_object* ob = a.objects + o_begin + threadIdx.x;
-        uint32_t* e = tbl + threadIdx.x * 16;
+    if (tid < a.tbl_n && o_begin + tid < o_end) {
+        const omgx_object* ob = a.objects + o_begin + tid;
+        uint32_t* e = tbl + tid * 16;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const double rw = ob->inv_extent[k];
@@ -190,9 +192,9 @@ __global__ __launch_bounds__(256, GQ_WG_PER_CU) void k_goalset_queue(ChunkArgs a
         e[12] = __float_as_uint(ob->epsilon); e[13] = __float_as_uint(ob->clearance);
         e[14] = __float_as_uint(ob->padding_scale); e[15] = __float_as_uint(ob->inv_2eps);
     }
-    for (int t = threadIdx.x; t < 30 * P; t += 256) pts[t] = rv.g[246 + t];
+    for (int t = tid; t < 30 * P; t += 256) pts[t] = rv.g[246 + t];
 
-    for (int row = threadIdx.x; row < 10 * CH; row += 256) {  // row-level culling (see k_sdf_chunks)
+    for (int row = tid; row < 10 * CH; row += 256) {  // row-level culling (see k_sdf_chunks)
         const int l = row / CH, ci = row - l * CH;
         const double* A = base + ((int64_t)l * pstride + ci) * 9;
         const float cx = (float)A[6], cy = (float)A[7], cz = (float)A[8];
@@ -216,9 +218,9 @@ __global__ __launch_bounds__(256, GQ_WG_PER_CU) void k_goalset_queue(ChunkArgs a
     __syncthreads();
     GS_WG_STAMP(3);
 
-    // ---- the wave's queue.  q_*: pending entries, one per lane, lanes [0, pending).  f_*: the batch whose gathers are in flight.
-    float q_tx = 0.0f, q_ty = 0.0f, q_tz = 0.0f, q_w = 0.0f;
-    uint32_t q_meta = 0u;  // object index | soft << 16
+    // ---- the wave's queue.  Pending entries (object-space offset, weight) sit in the wave's LDS ring `stage`, slot i = entry i,
+    // their object index | soft << 16 in q_meta of lane i; lanes / slots [0, pending).  f_*: the batch whose gathers are in flight.
+    uint32_t q_meta = 0u;
     int pending = 0;
     F2 f_r00{0.0f, 0.0f}, f_r01{0.0f, 0.0f}, f_r10{0.0f, 0.0f}, f_r11{0.0f, 0.0f};
     float f_fx = 0.0f, f_fy = 0.0f, f_fz = 0.0f, f_w = 0.0f;
@@ -245,9 +247,12 @@ __global__ __launch_bounds__(256, GQ_WG_PER_CU) void k_goalset_queue(ChunkArgs a
     };
 
     // ISSUE: grid coordinates, addresses and the four gathers of the `count` queued entries.  Lanes >= count compute on
-    // whatever their registers hold; their weight is 0, in_c false (address = the grid's first voxel) and they count nothing.
+    // whatever their slot holds; their weight is 0, in_c false (address = the grid's first voxel) and they count nothing.
     auto issue = [&](int count) {
+        GS_COUNT(8);
         const bool valid = lane < count;
+        const float4 qe = *reinterpret_cast<const float4*>(stage + 4 * lane);
+        const float q_tx = qe.x, q_ty = qe.y, q_tz = qe.z, q_w = qe.w;
         const uint32_t oo = valid ? (q_meta & 0xffffu) : 0u;
         const uint32_t* rec = tbl + oo * 16;
         const uint4 c0 = *reinterpret_cast<const uint4*>(rec), c1 = *reinterpret_cast<const uint4*>(rec + 4), c2 = *reinterpret_cast<const uint4*>(rec + 8);
@@ -282,34 +287,31 @@ __global__ __launch_bounds__(256, GQ_WG_PER_CU) void k_goalset_queue(ChunkArgs a
         inflight = true;
     };
 
-    // ENQUEUE the lanes with `live` (object oo_soft = index | soft << 16): staged in LDS at their rank, picked up by the
-    // lanes behind the pending entries; a full queue is issued (after the batch in flight has been consumed)
+    // ENQUEUE the lanes with `live` (object oo_soft = index | soft << 16): each writes its entry to the ring slot behind the pending
+    // ones, a write and nothing else — a wave's LDS operations execute in program order, so the ISSUE that reads the slots
+    // needs no round trip through registers.  A full ring is issued (after the batch in flight has been consumed) and the
+    // entries that did not fit start the next one.
     auto enqueue = [&](bool live, float tx, float ty, float tz, float w, uint32_t oo_soft) {
         const unsigned long long bal = __ballot(live);
         const int n = __popcll(bal);
         const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-        if (live) *reinterpret_cast<float4*>(stage + 4 * rank) = make_float4(tx, ty, tz, w);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const int room = 64 - pending;
         const int take = n < room ? n : room;
-        if (lane >= pending && lane < pending + take) {
-            const float4 e = *reinterpret_cast<const float4*>(stage + 4 * (lane - pending));
-            q_tx = e.x; q_ty = e.y; q_tz = e.z; q_w = e.w; q_meta = oo_soft;
-        }
+        if (live && rank < room) *reinterpret_cast<float4*>(stage + 4 * (pending + rank)) = make_float4(tx, ty, tz, w);
+        q_meta = (lane >= pending && lane < pending + take) ? oo_soft : q_meta;
         pending += take;
         if (pending == 64) {
             if (inflight) consume();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             issue(64);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();  // the slots have been read: the rest of this call's entries start the next ring
+            if (live && rank >= room) *reinterpret_cast<float4*>(stage + 4 * (rank - room)) = make_float4(tx, ty, tz, w);
             pending = n - take;
-            if (lane < pending) {
-                const float4 e = *reinterpret_cast<const float4*>(stage + 4 * (take + lane));
-                q_tx = e.x; q_ty = e.y; q_tz = e.z; q_w = e.w; q_meta = oo_soft;
-            }
+            q_meta = lane < pending ? oo_soft : q_meta;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();  // the staging area is rewritten by the next call
     };
 
     // The wave's work: TILES of 4 consecutive waypoints x LB links, dealt over the 4 waves as tile (block rb, link batch lp)
@@ -321,9 +323,11 @@ __global__ __launch_bounds__(256, GQ_WG_PER_CU) void k_goalset_queue(ChunkArgs a
     // (a poor predictor of the exact-path work: +7 %), one link per tile (+5 %).
     const int ntiles = ((CH + 3) >> 2) * (10 / LB);
     const int pc3 = 3 * (p < P ? p : 0);  // lane part of a collision-point address (doubles)
+    GS_COUNT(0);
 #pragma unroll 1
     for (int t = wave; t < ntiles; t += 4) {  // every lane stays active: invalid items are flagged, not skipped
         const int rb = t / (10 / LB), l0 = (t - rb * (10 / LB)) * LB;
+        GS_COUNT(1);
         {
             const int ci = rb * 4 + (lane >> 4);
             const bool valid = (p < P) && (ci < CH);
@@ -341,15 +345,18 @@ __global__ __launch_bounds__(256, GQ_WG_PER_CU) void k_goalset_queue(ChunkArgs a
                 w[k] = 0.0f;
             }
             if (!__any(many != 0)) continue;  // nothing in reach of any row of this tile
+            GS_COUNT(2);
 #pragma unroll
             for (int k = 0; k < LB; ++k)
                 pose9_apply((base + (l0 + k) * pstride * 9) + cic9, (pts + 3 * (l0 + k) * P) + pc3, px[k], py[k], pz[k]);
             for (int o = o_begin; o < o_end; ++o) {
                 const int oo = o - o_begin;
                 const uint32_t bit = 1u << (oo < 31 ? oo : 31);
+                GS_COUNT(10);
                 if (!__any((many & bit) != 0)) continue;
                 ObjTablePtr ob = as_const(a.objects) + o;
                 if (ob->disabled > 0) continue;  // .cu:115-116
+                GS_COUNT(3);
                 const GqFar fp = gq_load_far(ob);
                 const bool queued = oo < a.tbl_n;  // objects beyond the LDS records (rare) are evaluated on the spot
 #pragma unroll
@@ -362,8 +369,12 @@ __global__ __launch_bounds__(256, GQ_WG_PER_CU) void k_goalset_queue(ChunkArgs a
                     const bool inside = (tx >= fp.flo[0]) & (tx <= fp.fhi[0]) & (ty >= fp.flo[1]) & (ty <= fp.fhi[1]) &
                                         (tz >= fp.flo[2]) & (tz <= fp.fhi[2]);
                     const bool live = (msk[k] & bit) && (inside || !fp.cullable);
+                    GS_COUNT(4);
                     if (!__any(live)) continue;
-                    if (!wdone[k]) {  // ||(x_i - x_{i-1}) / dt|| in float32 (config.py:162-187, cost.py:260-275), once per (row, link)
+                    GS_COUNT(5);
+                    GS_COUNT_N(9, __popcll(__ballot(live)));
+                    if (!wdone[k]) {
+                        GS_COUNT(6);  // ||(x_i - x_{i-1}) / dt|| in float32 (config.py:162-187, cost.py:260-275), once per (row, link)
                         const int l = l0 + k;
                         float qx, qy, qz;
                         // the previous configuration's pose: cfg ci - 1 of the same link, i.e. one 72-byte record back (ci = 0: the start, record 0)
@@ -374,6 +385,7 @@ __global__ __launch_bounds__(256, GQ_WG_PER_CU) void k_goalset_queue(ChunkArgs a
                     }
                     const uint32_t soft = (a.soften && l0 + k >= 8) ? 1u : 0u;
                     if (queued) {
+                        GS_COUNT(7);
                         enqueue(live, tx, ty, tz, w[k], (uint32_t)oo | (soft << 16));
                     } else if (live) {
                         const ObjParams op = load_object(ob);
@@ -389,6 +401,9 @@ __global__ __launch_bounds__(256, GQ_WG_PER_CU) void k_goalset_queue(ChunkArgs a
     }
     if (inflight) consume();
     if (pending > 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         issue(pending);
         consume();
     }
@@ -405,7 +420,7 @@ __global__ __launch_bounds__(256, GQ_WG_PER_CU) void k_goalset_queue(ChunkArgs a
         __syncthreads();
         if (lane == 0) { red[wave] = ws_; red[4 + wave] = wc_; }
         __syncthreads();
-        if (threadIdx.x == 0) {
+        if (tid == 0) {
             const int64_t k = (int64_t)s * a.NCH + chunk;
             if (a.chunk_cost) a.chunk_cost[k] = ((red[0] + red[1]) + red[2]) + red[3];
             if (a.chunk_col) a.chunk_col[k] = ((red[4] + red[5]) + red[6]) + red[7];

@@ -469,6 +469,22 @@ extern "C" int omgx_debug_gs_wg(unsigned long long* h_out, int n_wg) {
 #define GS_WG_STAMP(k)
 #endif
 
+// Debug aid (EXTRA=-DOMGX_GS_COUNT=1; tools/gs_block_counts.py): how often each block of k_goalset_queue's main loop runs,
+// counted per wave.  Never part of the shipped library.
+#ifdef OMGX_GS_COUNT
+__device__ unsigned long long g_gs_count[16];
+#define GS_COUNT(k) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_gs_count[k], 1ull); } while (0)
+#define GS_COUNT_N(k, n) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_gs_count[k], (unsigned long long)(n)); } while (0)
+extern "C" int omgx_debug_gs_counts(unsigned long long* h_out, int reset) {
+    if (hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_gs_count), sizeof(unsigned long long) * 16) != hipSuccess) return -2;
+    if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_gs_count), z, sizeof(z)) != hipSuccess) return -2; }
+    return 0;
+}
+#else
+#define GS_COUNT(k)
+#define GS_COUNT_N(k, n)
+#endif
+
 #define GS_LAYER_PARTS 5  // trajectory-layer workgroups per scene
 
 #include "omg_goalset_queue.h"

@@ -28,6 +28,16 @@ namespace omg_learner {
 
 #define NPL 4  // goals per lane
 
+// Debug aid (EXTRA=-DOMGX_PHASE_TIMING, tools/phase_timing.py): scene 0 stamps the shader clock; wave 4 runs the slowest expert of MD.
+#ifdef OMGX_PHASE_TIMING
+static __device__ unsigned long long g_learner_phase[16];
+#define LPHASE(i, w) do { if (s == 0 && lane == 0 && wave == (w)) g_learner_phase[i] = __builtin_readcyclecounter(); } while (0)
+#define LCOUNT(i, v) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) == 4) g_learner_phase[i] = (unsigned long long)(v); } while (0)
+#else
+#define LPHASE(i, w) do { } while (0)
+#define LCOUNT(i, v) do { } while (0)
+#endif
+
 struct LearnerArgs {
     omgx_learner_params prm;
     const double* traj;
@@ -93,7 +103,7 @@ __device__ void bregman_projection(const double* x, const double* v, double delt
         if (ok) vmax = fmax(vmax, 1.0 + v[j]);
     }
     const double x1 = wmax(vmax);
-    const double L0 = (0.0 + x1) / 2.0, s0 = (x1 - 0.0) / 4.0;
+    const double L0 = (0.0 + x1) / 2.0, s0 = (x1 - 0.0) / 4.0, rx1 = 1.0 / x1;
     for (int it = 0; it < max_iter; ++it) {
         double zm = -__builtin_inf();
 #pragma unroll
@@ -106,15 +116,39 @@ __device__ void bregman_projection(const double* x, const double* v, double delt
             if (lane + 64 * j < G) { ezs[j] = exp((alpha[j] - v[j]) - zmax); partC += shiftx[j] * ezs[j]; }
         const double Csum = wsum(partC);
         const double lstar = ltarget - log(Csum);  // L + zmax at the root
-        double L = L0, sstep = s0, d = (L0 + zmax) - lstar;
+        // find_zero's sequence L_0 = x1 / 2, L_(k+1) = L_k -+ x1 / 2^(k+2) visits, at step k, the midpoint of the dyadic interval of
+        // length x1 / 2^k that holds the root Lr = lstar - zmax: L_k = x1 (2 floor(Lr / x1 2^k) + 1) / 2^(k+1) (floor clamped
+        // to [0, 2^k - 1]: a root outside [0, x1] sends the sequence to that end).  Lane k evaluates step k and the first lane
+        // inside the tolerance wins: ~20 instructions instead of ~20 dependent steps of 13.  L_k is rounded once here and k times in
+        // the sequential sums: a few ulps apart, and a step decides differently only if |d| is below the rounding of L + zmax,
+        // where it has converged anyway.  Whatever does not fit — no x1 > 0, no step below 52 inside the tolerance — takes the
+        // sequential loop below.
+        double L = L0, d = (L0 + zmax) - lstar;
         bool converged = false;
-        for (int k = 0; k < max_iter; ++k) {
-            if (d > dlo && d < dhi) { converged = true; break; }
-            if (d > 0) L -= sstep;
-            else if (d < 0) L += sstep;
-            else L = d;  // NaN: x -= s * np.sign(nan) poisons x in the reference too
-            sstep /= 2.0;
-            d = (L + zmax) - lstar;
+        {
+            const double r = (lstar - zmax) * rx1;
+            const double pk = ldexp(1.0, lane);
+            const double qf = fmin(fmax(floor(r * pk), 0.0), pk - 1.0);
+            const double Lk = ldexp(x1 * (2.0 * qf + 1.0), -(lane + 1));
+            const double dk = (Lk + zmax) - lstar;
+            const unsigned long long hit = __ballot(lane < 52 && dk > dlo && dk < dhi);
+            if (hit != 0ull && x1 > 0.0) {
+                const int k = __builtin_ctzll(hit);
+                L = lane_bcast(Lk, k);
+                d = lane_bcast(dk, k);
+                converged = true;
+            }
+        }
+        if (!converged) {
+            double sstep = s0;
+            for (int k = 0; k < max_iter; ++k) {
+                if (d > dlo && d < dhi) { converged = true; break; }
+                if (d > 0) L -= sstep;
+                else if (d < 0) L += sstep;
+                else L = d;  // NaN: x -= s * np.sign(nan) poisons x in the reference too
+                sstep /= 2.0;
+                d = (L + zmax) - lstar;
+            }
         }
         // exp(L + zmax) = exp(lstar) exp(d) = (target / Csum) exp(d)
         const double ed = converged ? 1.0 + d * (1.0 + d * (0.5 + d * (1.0 / 6.0))) : exp(d);
@@ -127,7 +161,10 @@ __device__ void bregman_projection(const double* x, const double* v, double delt
             ap[j] = ok ? fmax(0.0, v[j] - L + lds[j]) : 0.0;
             nrm += (alpha[j] - ap[j]) * (alpha[j] - ap[j]);
         }
-        if (sqrt(wsum(nrm)) < err) break;
+        LCOUNT(8, it + 1);
+        // sqrt(x) < 1e-6 (np.linalg.norm(alpha - alpha_prime) < err) <=> x < 0x1.19799812dea10p-40, the smallest double whose
+        // correctly rounded root reaches 1e-6 (sqrt is monotone; NaN fails both)
+        if (wsum(nrm) < 0x1.19799812dea10p-40) break;
 #pragma unroll
         for (int j = 0; j < NPL; ++j) alpha[j] = ap[j];
     }
@@ -144,6 +181,7 @@ __device__ void bregman_projection(const double* x, const double* v, double delt
 __device__ __forceinline__ void learner_scene(const LearnerArgs& a, int s, double (*sh_pn)[OMGX_MAX_GOALS], double (*sh_tab)[128]) {
     if (a.active && a.active[s] == 0) return;  // workgroup-uniform
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    LPHASE(0, 4);
     if (a.prm.alg != OMGX_ALG_MD && wave > 0) return;  // no barrier on these paths
     const omgx_learner_params& prm = a.prm;
     // GS: padded goal count (array strides); G: this scene's own count — every loop, sum and constant below uses G, so a scene
@@ -241,7 +279,9 @@ __device__ __forceinline__ void learner_scene(const LearnerArgs& a, int s, doubl
                     v[j] = eta * pw[wave] * cv[j];
                     epw[j] = g < G ? experts_p[(int64_t)wave * GS + g] : 0.0;
                 }
+                LPHASE(1, 4);
                 bregman_projection(epw, v, delta, G, lane, pn);
+                LPHASE(2, 4);
                 // this expert's cost (:229-230) on its own wave: sum_g cv pn + |pn - old p|; the step table is dead by now
                 double part2 = 0.0;
                 for (int j = 0; j < NPL; ++j) {
@@ -251,28 +291,32 @@ __device__ __forceinline__ void learner_scene(const LearnerArgs& a, int s, doubl
                 const double ecw = wsum(part2);
                 if (lane == 0) sh_tab[wave][0] = ecw;
             }
+            LPHASE(3, 4);
             __syncthreads();
+            LPHASE(4, 0);
             if (wave > 0) return;
             // The mixture update sits INSIDE the expert loop (:231-235): after expert i, q_k *= exp(-cost_k) for ALL k with
             // the costs as they stand (new for k <= i, last iteration's for k > i), then q is normalised.  All ten
-            // exponentials are known up front: lanes 0..4 evaluate the new ones, lanes 5..9 the old ones.  The mixture
+            // exponentials are known up front.  The mixture
             // p = sum_k q_k p_k is overwritten in every pass of the reference loop, so only the last one is formed.
+            // Lane k < 5 carries expert k through the loop (its q_k, both of its exponentials), the normalising sum is formed
+            // from lane broadcasts in the reference's order: one division per pass instead of five.
             double qv[5], ec[5], ep[5][NPL];
             for (int i = 0; i < 5; ++i) {
-                qv[i] = q[i]; ec[i] = sh_tab[i][0];
+                ec[i] = sh_tab[i][0];
                 for (int j = 0; j < NPL; ++j) { const int g = lane + 64 * j; ep[i][j] = g < G ? sh_pn[i][g] : 0.0; }
             }
-            double e_new[5], e_old[5];
             {
-                double mine = 0.0;
-                for (int k = 0; k < 5; ++k) { mine = lane == k ? ec[k] : mine; mine = lane == 5 + k ? ecost[k] : mine; }
-                const double ex = exp(-1.0 * mine);
-                for (int k = 0; k < 5; ++k) { e_new[k] = lane_bcast(ex, k); e_old[k] = lane_bcast(ex, 5 + k); }
-            }
-            for (int i = 0; i < 5; ++i) {
-                double qs = 0.0;
-                for (int k = 0; k < 5; ++k) { qv[k] = qv[k] * (k <= i ? e_new[k] : e_old[k]); qs += qv[k]; }
-                for (int k = 0; k < 5; ++k) qv[k] /= qs;
+                const int kk = lane < 5 ? lane : 0;
+                const double e_new = exp(-1.0 * sh_tab[kk][0]), e_old = exp(-1.0 * ecost[kk]);
+                double ql = q[kk];
+                for (int i = 0; i < 5; ++i) {
+                    ql = ql * (kk <= i ? e_new : e_old);
+                    double qs = 0.0;
+                    for (int k = 0; k < 5; ++k) qs += lane_bcast(ql, k);
+                    ql /= qs;
+                }
+                for (int k = 0; k < 5; ++k) qv[k] = lane_bcast(ql, k);
             }
             double pm[NPL], ps = 0.0;
             for (int j = 0; j < NPL; ++j) {
@@ -298,6 +342,7 @@ __device__ __forceinline__ void learner_scene(const LearnerArgs& a, int s, doubl
             idx = warg<false>(best, bi);
         }
     }
+    LPHASE(5, 0);
     // traj.end / goal rows (online_learner.py:243-245, optimizer.py:93-99)
     if (lane == 0) a.goal_idx[s] = idx;
     if (lane < 9) {
