@@ -19,27 +19,18 @@ from . import _lib, ops
 
 class Learner(object):
     def __init__(self, env, traj, cost):
-        self.cfg = env.config
-        self.env = env
-        self.traj = traj
-        self.cost = cost
-        self.alg_name = self.cfg.ol_alg
-        self.N = len(traj.goal_set)
-        self.T = self.cfg.optim_steps
-        self.Ti = np.zeros(self.N)
-        self.Tis = []
-        self.weights = np.ones(self.N)
-        self.t = 0.0
-        self.p = np.ones(self.N) / self.N
-        self.sum_costs = np.zeros(self.N)
-        self.last_leader = 0
-        self.eta = np.sqrt(np.log(self.N + 1) / (self.T))
-        self.etas = [self.eta * (2 ** x) for x in [-2, -1, 0, 2, 4]]
-        self.delta = np.ones(self.N) / (4 * self.N + 1)
-        self.num_experts = len(self.etas)
-        self.experts_p = [np.ones(self.N) / self.N for _ in range(len(self.etas))]
-        self.experts_costs = np.zeros(self.num_experts)
-        self.q = np.ones(self.num_experts) / self.num_experts
+        cfg, n = env.config, len(traj.goal_set)
+        eta = np.sqrt(np.log(n + 1) / cfg.optim_steps)
+        etas = [eta * 2.0 ** k for k in (-2, -1, 0, 2, 4)]
+        # The reference's attribute surface (omg/online_learner.py:67-92): planner and user code read these names, so names and
+        # initial values are the interface.  The numerical state among them (p, sum_costs, experts_p, q, experts_costs) is the
+        # host view of the device state and is refreshed after every update.
+        vars(self).update(
+            cfg=cfg, env=env, traj=traj, cost=cost, alg_name=cfg.ol_alg, N=n, T=cfg.optim_steps, t=0.0, last_leader=0,
+            Ti=np.zeros(n), Tis=[], weights=np.ones(n), p=np.full(n, 1.0) / n, sum_costs=np.zeros(n),
+            eta=eta, etas=etas, num_experts=len(etas), delta=np.ones(n) / (4 * n + 1),
+            experts_p=[np.ones(n) / n for _ in etas], experts_costs=np.zeros(len(etas)), q=np.ones(len(etas)) / len(etas),
+        )
         if self.alg_name not in _lib.ALG:
             raise ValueError(f"cfg.ol_alg = {self.alg_name!r}: the learner knows {sorted(_lib.ALG)}")
         self._dev = cost.device
