@@ -126,6 +126,7 @@ def main():
     ap.add_argument("--grid", type=int, default=64)
     ap.add_argument("--share-grids", action="store_true", help="store identical SDF volumes once (model library)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pipeline", type=int, default=0, help="parts of the engine's software pipeline (0: 2 when scenes x goals >= 4096, else 1)")
     ap.add_argument("--no-plan", action="store_true", help="skip timing a full 70-iteration plan (ms_per_plan)")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of three scenes after the timed region")
     ap.add_argument("--ol-alg", default="MD", help="goal-selection rule (reference default: MD, omg/config.py:67)")
@@ -165,6 +166,10 @@ def main():
         S, seed0, total_scenes = args.scenes, rank * args.scenes, world * args.scenes
     cfg, model, batch, start, goals = build_workload(S, G, n, args.grid, seed0=seed0, share_grids=args.share_grids)
     eng = ChompEngine(model, batch, copy.deepcopy(cfg), start, goals, device=dev, ol_alg=args.ol_alg)
+    # the engine's software pipeline: the rank's scenes as two independent halves on two streams, so that one half's update
+    # launch (and the tail / ramp-up around it) overlaps the other half's goal-set launch; same results bit for bit
+    parts = args.pipeline if args.pipeline > 0 else (2 if S * G >= ChompEngine.PIPELINE_MIN_ITEMS else 1)
+    eng.pipeline = parts
     lib = _lib.lib()
 
     # The workload must not drift with the number of steps: a trajectory that has been optimised for hundreds of iterations
@@ -266,11 +271,12 @@ def main():
         # N (32 + 128 O_active) algorithmic bytes for the N points of one launch — the goal-set batch
         # plus the S x n x 150 points of the trajectory layer.  NOT a measure of what the kernel moves: 85 % of the (point,
         # object) pairs retire in registers before any load and the rest hit L2.
-        pts_per_launch = S * G * n * 10 * P + S * n * 10 * P
+        pts_per_launch = (S * G * n * 10 * P + S * n * 10 * P) / parts  # a launch handles one part of the pipeline
         alg_bytes = pts_per_launch * (32 + 128 * O_active)
         from tools.roofline import roofline_block
         roof = roofline_block(ROOT / "profiles" / "roofline_inputs.json", avg_ms, int(len(goal_ms)), stride, alg_bytes,
-                              {"scenes": S, "goals": G, "waypoints": n, "points_per_link": P, "grid": args.grid})
+                              {"scenes": S, "goals": G, "waypoints": n, "points_per_link": P, "grid": args.grid, "pipeline": parts},
+                              launches_per_step=parts, ms_per_step=elapsed / args.steps * 1e3)
         out = {
             "metric": "CHOMP iterations/sec (batched scenes)",
             "value": total_scenes * args.steps / elapsed,
@@ -288,7 +294,8 @@ def main():
                                    f" x ({G}-goal goal-set cost + CHOMP step), Panda 9-dof, {n} waypoints",
                        "scenes_per_gpu": S, "total_scenes": total_scenes, "goals": G, "waypoints": n, "objects_per_scene": O_active,
                        "sdf_grid": f"4x{args.grid}^3 + 128x96x32 per scene, {'shared' if args.share_grids else 'private'}",
-                       "goal_selection": f"{args.ol_alg} on device (omgx_goal_update_optimize)", "launches_per_iteration": 2,
+                       "goal_selection": f"{args.ol_alg} on device (omgx_goal_update_optimize)", "launches_per_iteration": 2 * parts,
+                       "pipeline_parts": parts,
                        "top_k_collision": cfg.top_k_collision, "plan_restart_every_steps": cfg.optim_steps},
             "roofline": roof,
         }

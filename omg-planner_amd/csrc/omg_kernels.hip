@@ -856,11 +856,12 @@ extern "C" int omgx_goalset_cost(const double* robot, int32_t n_points, const om
 // function of its inputs.  Per-scene arrays live in LDS; an item's position in the list is found by counting (its scene's rank
 // among the scenes, its own rank among its scene's goals) — O(S^2 + S G^2) comparisons, ~0.5 M for 100 x 64.
 #define SCH_TPB 1024
+#define SCH_LDS_ITEMS 14336  // up to this many items have their weights staged in LDS (56 KB: no opt-in needed); beyond, the loops read global memory
 struct SchedArgs {
     const uint32_t* work;
     const int32_t* active;
     const int32_t* goal_count;
-    int S, G, slack, slots;
+    int S, G, slack, slots, staged;
     int32_t* sched;
 };
 
@@ -873,20 +874,38 @@ __global__ __launch_bounds__(SCH_TPB) void k_goalset_schedule(SchedArgs a) {
     uint32_t* nval = reinterpret_cast<uint32_t*>(offw + S);             // [S] kept goals
     uint32_t* offp = nval + S;                                          // [S] items of the scenes ranked before
     uint32_t* srank = offp + S;                                         // [S]
+    uint32_t* wl = srank + S;                                           // [S*G] weight of a kept item (>= 1), 0 = left out (a.staged)
     __shared__ unsigned long long tot[2];                               // total weight, total clamped weight
     __shared__ uint32_t cnt_all;
     __shared__ uint32_t first[8];
-    auto kept = [&](int s, int g) { return (!a.active || a.active[s] != 0) && (!a.goal_count || g < a.goal_count[s]); };
-    auto wt = [&](int s, int g) -> uint32_t { const uint32_t w = a.work ? a.work[(size_t)s * G + g] : 1u; return w ? w : 1u; };
+    // weight of item (s, g), 0 if it is left out: from LDS when staged (the loops below read every weight O(G) times)
+    auto item_w = [&](int s, int g) -> uint32_t {
+        if (a.staged) return wl[s * G + g];
+        if ((a.active && a.active[s] == 0) || (a.goal_count && g >= a.goal_count[s])) return 0u;
+        const uint32_t w = a.work ? a.work[(size_t)s * G + g] : 1u;
+        return w ? w : 1u;
+    };
     if (tid == 0) { tot[0] = tot[1] = 0ull; cnt_all = 0u; }
     if (tid < 8) first[tid] = 0xffffffffu;
     for (int i = tid; i < a.slots * 8; i += SCH_TPB) a.sched[i] = -1;
+    if (a.staged)
+        for (int i = tid; i < S * G; i += SCH_TPB) {
+            const int s = i / G, g = i - s * G;
+            uint32_t w = 0u;
+            if (!((a.active && a.active[s] == 0) || (a.goal_count && g >= a.goal_count[s]))) {
+                w = a.work ? a.work[i] : 1u;
+                w = w ? w : 1u;
+            }
+            wl[i] = w;
+        }
     __syncthreads();
     for (int s = tid; s < S; s += SCH_TPB) {  // scene weights
         unsigned long long w = 0;
         uint32_t n = 0;
-        for (int g = 0; g < G; ++g)
-            if (kept(s, g)) { w += wt(s, g); ++n; }
+        for (int g = 0; g < G; ++g) {
+            const uint32_t wi = item_w(s, g);
+            w += wi; n += wi ? 1u : 0u;
+        }
         Ws[s] = w; nval[s] = n;
         atomicAdd(&tot[0], w);
         atomicAdd(&cnt_all, n);
@@ -896,11 +915,15 @@ __global__ __launch_bounds__(SCH_TPB) void k_goalset_schedule(SchedArgs a) {
     unsigned long long lo = (10ull * tot[0]) / (14ull * n_all);
     if (lo < 1) lo = 1;
     const unsigned long long hi = (unsigned long long)a.slack * lo;
-    auto wclamp = [&](uint32_t w) -> unsigned long long { return w < lo ? lo : (w > hi ? hi : (unsigned long long)w); };
+    // clamp(w) = min(max(w, lo), hi) fits 32 bits (w does, and lo <= the largest w): one v_med3_u32 in the inner loops
+    const uint32_t lo32 = (uint32_t)lo, hi32 = hi > 0xffffffffull ? 0xffffffffu : (uint32_t)hi;
+    auto wclamp = [&](uint32_t w) -> uint32_t { return w < lo32 ? lo32 : (w > hi32 ? hi32 : w); };
     for (int s = tid; s < S; s += SCH_TPB) {  // clamped scene weights, scene ranks (heaviest first, ties by index)
         unsigned long long w = 0;
-        for (int g = 0; g < G; ++g)
-            if (kept(s, g)) w += wclamp(wt(s, g));
+        for (int g = 0; g < G; ++g) {
+            const uint32_t wi = item_w(s, g);
+            if (wi) w += wclamp(wi);
+        }
         Wc[s] = w;
         atomicAdd(&tot[1], w);
         uint32_t r = 0;
@@ -917,33 +940,41 @@ __global__ __launch_bounds__(SCH_TPB) void k_goalset_schedule(SchedArgs a) {
     }
     __syncthreads();
     const unsigned long long total_c = tot[1] ? tot[1] : 1ull;
-    auto place = [&](int s, int g, uint32_t& pos, int& x) {
-        const uint32_t w = wt(s, g);
+    auto place = [&](int s, int g, uint32_t w, uint32_t& pos, int& x) {
         uint32_t r = 0;
         unsigned long long before = 0;
+#pragma unroll 4
         for (int q = 0; q < G; ++q) {
-            if (!kept(s, q)) continue;
-            const uint32_t wq = wt(s, q);
-            if (wq > w || (wq == w && q < g)) { ++r; before += wclamp(wq); }
+            const uint32_t wq = item_w(s, q);
+            const bool ahead = wq > w || (wq == w && q < g);  // wq = 0 (left out) never ranks before a kept item
+            r += ahead ? 1u : 0u;
+            before += ahead ? wclamp(wq) : 0u;
         }
         pos = offp[s] + r;
         const unsigned long long c2 = 2ull * (offw[s] + before) + wclamp(w);
         const unsigned long long xx = (8ull * c2) / (2ull * total_c);
         x = xx > 7 ? 7 : (int)xx;
     };
+    // an item's place is computed once and kept in registers for the second pass (up to 4 items per thread: 4096 items;
+    // beyond that the second pass computes it again)
+    uint32_t kpos[4];
+    int kx[4];
+    int kept_n = 0;
     for (int i = tid; i < S * G; i += SCH_TPB) {  // first position of every piece
         const int s = i / G, g = i - s * G;
-        if (!kept(s, g)) continue;
-        uint32_t pos; int x;
-        place(s, g, pos, x);
-        atomicMin(&first[x], pos);
+        const uint32_t w = item_w(s, g);
+        uint32_t pos = 0; int x = -1;
+        if (w) { place(s, g, w, pos, x); atomicMin(&first[x], pos); }
+        if (kept_n < 4) { kpos[kept_n] = pos; kx[kept_n] = x; }
+        ++kept_n;
     }
     __syncthreads();
-    for (int i = tid; i < S * G; i += SCH_TPB) {
+    int k = 0;
+    for (int i = tid; i < S * G; i += SCH_TPB, ++k) {
         const int s = i / G, g = i - s * G;
-        if (!kept(s, g)) continue;
         uint32_t pos; int x;
-        place(s, g, pos, x);
+        if (k < 4) { pos = kpos[k]; x = kx[k]; if (x < 0) continue; }
+        else { const uint32_t w = item_w(s, g); if (!w) continue; place(s, g, w, pos, x); }
         const uint32_t r = pos - first[x];
         if ((int)r < a.slots) a.sched[(size_t)r * 8 + x] = i;  // always true: the clamp bounds a piece's count (include/omg_hip.h)
     }
@@ -959,8 +990,10 @@ extern "C" int omgx_goalset_schedule(const uint32_t* work, const int32_t* active
                                      int32_t num_goals, int32_t slack, int32_t* schedule, void* stream) {
     if (num_scenes <= 0 || num_goals <= 0 || slack < 1 || !schedule) return OMGX_ERR_INVALID;
     if ((int64_t)num_scenes * num_goals > 65536 || num_scenes > 4096) return OMGX_ERR_UNSUPPORTED;
-    SchedArgs a{work, active, goal_count, num_scenes, num_goals, slack, omgx_goalset_schedule_len(num_scenes, num_goals, slack) / 8, schedule};
-    const size_t lds = (size_t)num_scenes * (3 * sizeof(unsigned long long) + 3 * sizeof(uint32_t));
+    const int items = num_scenes * num_goals;
+    const int staged = (items <= SCH_LDS_ITEMS && num_scenes <= 128) ? 1 : 0;  // keeps the launch below 64 KB of dynamic LDS
+    SchedArgs a{work, active, goal_count, num_scenes, num_goals, slack, omgx_goalset_schedule_len(num_scenes, num_goals, slack) / 8, staged, schedule};
+    const size_t lds = (size_t)num_scenes * (3 * sizeof(unsigned long long) + 3 * sizeof(uint32_t)) + (staged ? (size_t)items * sizeof(uint32_t) : 0);
     hipLaunchKernelGGL(k_goalset_schedule, dim3(1), dim3(SCH_TPB), lds, (hipStream_t)stream, a);
     OMGX_CHECK_LAUNCH("k_goalset_schedule");
     return OMGX_OK;

@@ -38,6 +38,19 @@ def shard_range(num_items: int, rank: int, world: int) -> range:
     return range(lo, lo + base + (1 if rank < rem else 0))
 
 
+_SIDE_STREAMS: dict = {}
+
+
+def _side_stream(device: torch.device, i: int) -> "torch.cuda.Stream":
+    """Side stream i of the device, shared by all engines: the first use of a new HIP stream costs milliseconds (its
+    hardware queue is created), which a per-engine stream would pay in every plan."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), i)
+    st = _SIDE_STREAMS.get(key)
+    if st is None:
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return st
+
+
 _ALL_DONE_CHECKS = frozenset((1, 2, 3, 5, 8, 13, 21, 34, 55))  # iterations after which plan() looks at `active` (small batches only)
 
 
@@ -53,6 +66,15 @@ class ChompEngine:
     # the simpler policy is the default.
     reschedule_every = 0
     schedule_slack = 2  # goal workgroup slots per XCD in units of the even share (see build_schedule)
+    # Software pipeline over scene sub-ranges (see _iterate_pipelined): an integer k runs every iterate() as k parts on k HIP
+    # streams (1: never); None: plan() pipelines two parts when each part still fills the GPU for several rounds
+    # (S * G >= PIPELINE_MIN_ITEMS), a bare iterate() does not — its caller owns the synchronisation (join()).
+    pipeline = None
+    PIPELINE_MIN_ITEMS = 4096
+    # per-scene tensors: a part of the pipeline works on the rows [lo, hi) of each
+    _PART_TENSORS = ("start", "goal_set", "reach", "cv_goals", "goal_idx", "goal_count", "eta_s", "traj", "end", "goal_rows", "goal_point",
+                     "pot", "pgrad", "col", "grad", "cost_traj", "info", "goal_cost", "goal_col", "learner_state", "cost_vec", "_active",
+                     "_scene_flags")
 
     def __init__(self, model: PandaModel, batch: SceneBatch, cfg: Config, start: np.ndarray, goal_set: np.ndarray,
                  reach_grasps: np.ndarray | None = None, traj_init: np.ndarray | None = None, device="cuda:0",
@@ -137,6 +159,7 @@ class ChompEngine:
         self._sched_buf, self._sched_flip, self._sched_age = None, 0, None
         self._ticket = 0
         self._num_cus = torch.cuda.get_device_properties(dev).multi_processor_count
+        self._parts, self._forked, self._in_plan = None, False, False
         self._gather_goal()
 
     @property
@@ -146,8 +169,10 @@ class ChompEngine:
 
     @active.setter
     def active(self, value: torch.Tensor):
+        self.join()
         self._active = value
         self._masked = True
+        self._refresh_parts()
 
     def _mask(self):
         """The mask for a launch — None while no scene can be inactive (the goal-set kernel then skips its slot look-up)."""
@@ -213,10 +238,93 @@ class ChompEngine:
         p.eta = self.eta
         return p
 
+    # ---------------------------------------------------------------------------------------------
+    # Software pipeline.  One iteration is a goal-set launch that fills the GPU (~275 us for 100 scenes x 64 goals) followed by
+    # the update launch (2 workgroups per scene, latency-bound, ~35 us): the tail of the first, the second and the ramp-up of
+    # the next goal-set launch leave most of the GPU idle for ~80 us of every ~320.  Scenes are independent, so the batch is cut
+    # into parts (contiguous scene ranges) whose iterations are enqueued alternately on different streams: while one part
+    # is in its underused phases the other part's goal-set launch has the CUs (measured: 312 -> 284 us per iteration of 100
+    # scenes, tools/ab_pipeline.py; four parts are host-bound).  A part is a ChompEngine whose per-scene tensors are row views
+    # of this engine's — same code, same results bit for bit; its dispatch schedule, work counters and flags are its own.
+    def _make_part(self, lo: int, hi: int, stream):
+        import copy
+        part = object.__new__(ChompEngine)
+        part.__dict__.update(self.__dict__)
+        part.cfg = copy.copy(self.cfg)  # the weight schedule's fields are set per iteration (_iterate_pipelined)
+        part.S, part.stream, part._lo = hi - lo, stream, lo
+        part._parts, part._forked, part.pipeline = None, False, 1
+        sc = object.__new__(ops.DeviceScenes)
+        sc.__dict__.update(self.scenes.__dict__)
+        sc.num_scenes, sc.scene_begin = hi - lo, self.scenes.scene_begin[lo:hi + 1]  # object offsets stay absolute
+        part.scenes = sc
+        part.work = torch.zeros(part.S * self.G, dtype=torch.int32, device=self.device)
+        part.schedule, part._gs_launches, part._measured = None, 0, False
+        part._sched_buf, part._sched_flip, part._sched_age = None, 0, None
+        part._ticket = 0
+        if self.goal_count is not None:
+            part._goal_counts_host = self._goal_counts_host[lo:hi]
+        self._bind_part(part)
+        return part
+
+    def _bind_part(self, part):
+        lo, hi = part._lo, part._lo + part.S
+        for k in self._PART_TENSORS:
+            v = getattr(self, k)
+            setattr(part, k, None if v is None else v[lo:hi])
+
+    def _refresh_parts(self):
+        """After one of this engine's per-scene tensors has been REBOUND (not written in place): the parts' views follow."""
+        for part in self._parts or ():
+            self._bind_part(part)
+
+    def _get_parts(self, k: int):
+        if self._parts is None or len(self._parts) != k:
+            self.join()
+            cuts = [self.S * i // k for i in range(k + 1)]
+            self._parts = [self._make_part(cuts[i], cuts[i + 1], None if i == 0 else _side_stream(self.device, i)) for i in range(k)]
+        return self._parts
+
+    def join(self):
+        """Make the current stream wait for everything the pipeline's side streams have been given.  Whole-batch operations
+        of the engine call it themselves; a caller that reads the engine's tensors after bare pipelined iterate() calls
+        needs it too (or a device-wide synchronize)."""
+        if self._forked:
+            cur = torch.cuda.current_stream(self.device)
+            for part in self._parts[1:]:
+                cur.wait_stream(part.stream)
+            self._forked = False
+
+    _CFG_SCHEDULE = ("obstacle_weight", "smoothness_weight", "grasp_weight", "step_size")
+
+    def _iterate_pipelined(self, t: int, early_stop: bool, k: int):
+        parts = self._get_parts(k)
+        if early_stop:
+            self._masked = True
+        if not self._forked:  # the side streams start behind whatever this stream has done to the engine's tensors
+            cur = torch.cuda.current_stream(self.device)
+            for part in parts[1:]:
+                part.stream.wait_stream(cur)
+            self._forked = True
+        for part in parts:
+            part.t, part.step_count, part._masked = self.t, self.step_count, self._masked
+            for f in self._CFG_SCHEDULE:
+                setattr(part.cfg, f, getattr(self.cfg, f))
+            part.iterate(t, early_stop)
+        p0 = parts[0]
+        self.t, self.step_count = p0.t, p0.step_count
+        for f in self._CFG_SCHEDULE:
+            setattr(self.cfg, f, getattr(p0.cfg, f))
+
+    def _pipeline_parts(self) -> int:
+        if self.pipeline is not None:
+            return max(1, min(int(self.pipeline), self.S))
+        return 2 if (self._in_plan and self.S * self.G >= self.PIPELINE_MIN_ITEMS and not self.separate_launches) else 1
+
     def update_goal(self, defer_update: bool = False, with_layer: bool = False):
         """Learner.update_goal (online_learner.py:237-249): omgx_goalset_cost + omgx_goal_update, no host sync.
         defer_update=True launches only the goal-set batch and returns the learner parameters: the caller then runs
         the goal update fused with the optimiser step (omgx_goal_update_optimize)."""
+        self.join()
         self.t += 1
         if self.ol_alg == "Baseline":
             return None
@@ -328,6 +436,7 @@ class ChompEngine:
 
     def optimize(self, do_update: bool = True):
         """Optimizer.optimize(traj, force_update=True) (omg/optimizer.py:115-135) for all scenes."""
+        self.join()
         self._schedule()
         self._layer()
         return self._step(do_update)
@@ -340,6 +449,10 @@ class ChompEngine:
         if self.stream is not None and torch.cuda.current_stream(self.device) != self.stream:
             with torch.cuda.stream(self.stream):
                 return self.iterate(t, early_stop)
+        k = self._pipeline_parts()
+        if k > 1:
+            return self._iterate_pipelined(t, early_stop, k)
+        self.join()
         if self.separate_launches:
             return self.iterate_separate(t, early_stop)
         cfg = self.cfg
@@ -382,16 +495,19 @@ class ChompEngine:
     def snapshot(self) -> dict:
         """Everything a plan mutates (device tensors cloned + the host-side counters): restore() brings the engine back to
         this point — e.g. to plan the same scenes again, or to keep a benchmark's workload stationary."""
+        self.join()
         snap = {k: getattr(self, k).clone() for k in self._STATE}
         snap["_host"] = (self.step_count, self.t, self.cfg.obstacle_weight, self.cfg.smoothness_weight, self.cfg.grasp_weight, self.cfg.step_size)
         return snap
 
     def restore(self, snap: dict):
         """Device-to-device copies on the current stream, no host sync."""
+        self.join()
         for k in self._STATE:
             cur = getattr(self, k)
             if cur.shape != snap[k].shape:  # early_stop used to rebind self.active: keep one tensor
                 setattr(self, k, snap[k].clone())
+                self._refresh_parts()
             else:
                 cur.copy_(snap[k])
         (self.step_count, self.t, self.cfg.obstacle_weight, self.cfg.smoothness_weight, self.cfg.grasp_weight, self.cfg.step_size) = snap["_host"]
@@ -399,6 +515,7 @@ class ChompEngine:
     def select_initial_goal(self):
         """Learner.__init__ (online_learner.py:96-102): before planning, pick the cheapest goal by one cost_vector
         evaluation at t = 0 and re-interpolate the trajectory towards it (Trajectory.interpolate_waypoints, cubic)."""
+        self.join()
         if self.ol_alg in ("Proj", "Baseline"):
             # planner.py:200-222 (goal setup before planning): "Proj" takes the goal closest to the START in the
             # link_smooth_weight metric, "Baseline" cfg.goal_idx (>= 0: that goal; the default -2: goal 0; -1 would need the
@@ -446,21 +563,29 @@ class ChompEngine:
         self.iterations_run = 0
         self.timed_out = False
         t_start = time.time()
-        for t in range(cfg.optim_steps + cfg.extra_smooth_steps):
-            self.iterate(t, early_stop)
-            self.iterations_run = t + 1
-            if cfg.timeout != -1 and t > 0 and time.time() - t_start > cfg.timeout:
-                self.timed_out = True
-                break
-            # Every scene may have left the loop (planner.py:626 breaks at once; a lone scene often terminates after two
-            # iterations): look at the mask at a thinning set of iterations and stop launching no-ops.  Each look is a host
-            # sync that drains the launch queue (measured: ~0.4 ms each with 100 scenes in flight, where it never pays), so
-            # only small batches do it.
-            if early_stop and self.S <= 16 and t in _ALL_DONE_CHECKS and not bool(self.active.any().item()):
-                break
+        self._in_plan = True  # plan() joins the pipeline's streams itself (the final optimize below), so it may use them
+        try:
+            for t in range(cfg.optim_steps + cfg.extra_smooth_steps):
+                self.iterate(t, early_stop)
+                self.iterations_run = t + 1
+                if cfg.timeout != -1 and t > 0 and time.time() - t_start > cfg.timeout:
+                    self.timed_out = True
+                    break
+                if self._plan_all_done(early_stop, t):
+                    break
+        finally:
+            self._in_plan = False
         return self.optimize(False)
 
+    def _plan_all_done(self, early_stop: bool, t: int) -> bool:
+        """Every scene may have left the loop (planner.py:626 breaks at once; a lone scene often terminates after two
+        iterations): look at the mask at a thinning set of iterations and stop launching no-ops.  Each look is a host
+        sync that drains the launch queue (measured: ~0.4 ms each with 100 scenes in flight, where it never pays), so
+        only small batches do it."""
+        return bool(early_stop and self.S <= 16 and t in _ALL_DONE_CHECKS and not bool(self.active.any().item()))
+
     def final_costs(self) -> torch.Tensor:
+        self.join()
         return self.info[:, 0].contiguous()
 
 

@@ -1,0 +1,96 @@
+"""ChompEngine's software pipeline (two scene ranges on two HIP streams, engine.py `_iterate_pipelined`) must not change a
+bit: the parts run the same launches on row views of the engine's tensors.  Scenes are independent in the reference
+(omg/core.py:869-885 plans them one after the other), so there is nothing to compare but the engine with itself — and the
+pipelined engine with the oracle at bench.py's configuration.
+"""
+from __future__ import annotations
+
+import copy
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+STATE = ("traj", "info", "goal_idx", "learner_state", "goal_cost", "end", "goal_rows", "cost_traj", "grad", "pot", "col")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU: torch.cuda.is_available() is False")
+    return torch.device("cuda:0")
+
+
+def _engines(dev, S, G, ragged=False, grid=32):
+    import bench
+    from omg_planner_amd.engine import ChompEngine
+    cfg, model, batch, start, goals = bench.build_workload(S, G, 30, grid, 0, False)
+    counts = None
+    if ragged:
+        counts = np.random.RandomState(5).randint(G // 2, G + 1, S)
+    make = lambda: ChompEngine(model, batch, copy.deepcopy(cfg), start, goals, device=dev, ol_alg="MD", goal_counts=counts)
+    return make, batch
+
+
+def _assert_same(a, b):
+    torch.cuda.synchronize()
+    for k in STATE:
+        x, y = getattr(a, k).cpu().numpy(), getattr(b, k).cpu().numpy()
+        assert np.array_equal(x, y, equal_nan=True), k
+    assert np.array_equal(a.active.cpu().numpy(), b.active.cpu().numpy())
+
+
+@pytest.mark.parametrize("parts,ragged", [(2, False), (3, True)])
+def test_pipelined_iterations_equal_the_single_stream_engine(dev, parts, ragged):
+    make, _ = _engines(dev, 70, 64, ragged)
+    one, two = make(), make()
+    two.pipeline = parts
+    for t in range(6):  # through the uniform schedule, the measuring launch and the measured schedule of every part
+        one.iterate(t)
+        two.iterate(t)
+    assert two._parts is not None and len(two._parts) == parts
+    assert all(p._measured for p in two._parts) == (parts == 2)  # parts below 2048 items keep the even split
+    _assert_same(one, two)
+    # whole-batch operations join the side streams by themselves
+    snap = two.snapshot()
+    two.iterate(6)
+    two.restore(snap)
+    one_costs = one.final_costs().cpu().numpy()
+    assert np.array_equal(two.final_costs().cpu().numpy(), one_costs)
+    assert (one.t, one.step_count, one.cfg.obstacle_weight, one.cfg.step_size) == (two.t, two.step_count, two.cfg.obstacle_weight, two.cfg.step_size)
+
+
+def test_pipelined_plan_with_early_stop_equals_the_single_stream_plan(dev):
+    make, _ = _engines(dev, 64, 64)
+    one, two = make(), make()
+    one.pipeline = 1
+    assert two.pipeline is None  # plan() decides: 64 x 64 items -> two parts
+    i1 = one.plan(early_stop=True).cpu().numpy()
+    i2 = two.plan(early_stop=True).cpu().numpy()
+    assert two._parts is not None and len(two._parts) == 2 and one._parts is None
+    assert np.array_equal(i1, i2, equal_nan=True)
+    _assert_same(one, two)
+    assert int((two.active == 0).sum().item()) > 0, "the workload should let some scenes terminate"
+
+
+def test_small_batches_and_bare_iterate_are_not_pipelined(dev):
+    make, _ = _engines(dev, 4, 64)
+    eng = make()
+    eng.iterate(0)
+    eng.plan(early_stop=False)
+    assert eng._parts is None
+
+
+def test_pipelined_bench_workload_matches_oracle(dev):
+    """bench.py's configuration run the way bench.py runs it (two parts) against the oracle on scenes of both parts."""
+    from oracle.check import engine_vs_oracle
+    make, batch = _engines(dev, 100, 64, grid=64)
+    eng = make()
+    eng.pipeline = 2
+    for phase in range(2):
+        r = engine_vs_oracle(eng, batch, [0, 49, 50, 99], steps=3, pin_window=True)
+        assert r["goal_idx_equal"], r
+        assert r["max_traj_err"] <= 1e-6 and r["max_cost_rel_err"] <= 1e-5, r

@@ -69,6 +69,8 @@ CASES = [
     (3, 5, True, True, "ties"),
     (256, 7, True, True, "measured"),
     (40, 100, False, False, "skewed"),
+    (200, 100, True, True, "measured"),   # 20 000 items: beyond the LDS-staged path
+    (300, 40, False, False, "measured"),  # 12 000 items but more scenes than the staged path takes
 ]
 
 

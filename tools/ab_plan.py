@@ -30,24 +30,29 @@ def main():
     dev = torch.device("cuda:0")
     cfg, model, batch, start, goals = bench.build_workload(a.scenes, a.goals, 30, a.grid, 0, False)
 
-    def run(auto, every, early):
-        best = float("inf")
+    def run(auto, every, early, pipeline=1):
+        best, host = float("inf"), float("inf")
         for _ in range(a.reps):
             eng = ChompEngine(model, batch, copy.deepcopy(cfg), start, goals, device=dev, ol_alg="MD")
-            eng.auto_schedule, eng.reschedule_every = auto, every
+            eng.auto_schedule, eng.reschedule_every, eng.pipeline = auto, every, pipeline
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             eng.plan(early_stop=early)
+            host = min(host, (time.perf_counter() - t0) * 1e3)  # when the host has enqueued the whole plan
             torch.cuda.synchronize()
             best = min(best, (time.perf_counter() - t0) * 1e3)
-        return best, int((eng.active == 0).sum().item())
+        return best, int((eng.active == 0).sum().item()), host
 
     run(True, 1, True)  # warm-up: code objects, allocator
     for name, auto, every in (("none", False, 0), ("sched/0", True, 0), ("sched/1", True, 1), ("sched/2", True, 2), ("sched/4", True, 4),
                               ("sched/8", True, 8)):
-        full, _ = run(auto, every, False)
-        early, term = run(auto, every, True)
+        full, _, _ = run(auto, every, False)
+        early, term, _ = run(auto, every, True)
         print(f"{name:8s} plan {full:7.2f} ms   early-stop {early:7.2f} ms   ({term} of {a.scenes} scenes terminated)", flush=True)
+    for k in (1, 2):
+        full, _, h1 = run(True, 0, False, k)
+        early, term, h2 = run(True, 0, True, k)
+        print(f"pipeline {k}: plan {full:7.2f} ms (host enqueue {h1:6.2f})   early-stop {early:7.2f} ms (host enqueue {h2:6.2f})", flush=True)
 
 
 if __name__ == "__main__":

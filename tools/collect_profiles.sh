@@ -25,11 +25,12 @@ run_pmc FETCH_SIZE "FETCH_SIZE"
 run_pmc WRITE_SIZE "WRITE_SIZE"
 run_pmc TCC "TCC_HIT_sum TCC_MISS_sum"
 run_pmc SQ_INSTS "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU"
+run_pmc LANES "SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU"
 run_pmc SQ_WAIT "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT"
 run_pmc GRBM "GRBM_GUI_ACTIVE"
 python3 - > $O/${TAG}_workload.json <<'PY'
 import json
-print(json.dumps({"scenes": 100, "goals": 64, "waypoints": 30, "points_per_link": 15, "grid": 64}))
+print(json.dumps({"scenes": 100, "goals": 64, "waypoints": 30, "points_per_link": 15, "grid": 64, "pipeline": 2}))
 PY
 if [ -x $R/tools/_build/valu_rates ]; then
   $R/tools/_build/valu_rates > $O/${TAG}_valu_rates.txt 2>&1

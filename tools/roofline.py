@@ -70,29 +70,45 @@ def derive_inputs(tag: str, profiles: Path = ROOT / "profiles") -> dict:
     return out
 
 
-def roofline_block(inputs_file, avg_launch_ms: float, launches: int, timing_stride: int, algorithmic_bytes: float, workload: dict) -> dict:
-    """The `roofline` object of bench.py's JSON line."""
+def roofline_block(inputs_file, avg_launch_ms: float, launches: int, timing_stride: int, algorithmic_bytes: float, workload: dict,
+                   launches_per_step: int = 1, ms_per_step: float | None = None) -> dict:
+    """The `roofline` object of bench.py's JSON line.
+
+    One launch of the kernel per step (launches_per_step = 1): achieved = counts per launch / its average duration (HIP events).
+    Pipelined engine (k launches per step, in flight at the same time on k streams): a launch's duration then covers time in
+    which it shares the machine with its sibling, so the per-launch rate (still reported, `per_launch`) counts the machine k
+    times; achieved = counts of the k launches of a step / the step's wall time — the share of the chip's issue rate that
+    the kernel's instructions take over the whole timed region, update launches and gaps included."""
     inp = json.loads(Path(inputs_file).read_text()) if Path(inputs_file).exists() else {}
     same = inp.get("workload") is not None and all(inp["workload"].get(k) == v for k, v in workload.items())
     valu = inp.get("valu_wave_insts_per_launch") if same else None
     hbm = inp.get("hbm_bytes_per_launch") if same else None
     sec = avg_launch_ms * 1e-3
-    achieved = None if valu is None else valu / sec / 1e9
+    per_launch = None if valu is None else valu / sec / 1e9
+    chip = launches_per_step > 1
+    if chip and ms_per_step is None:
+        raise ValueError("ms_per_step is needed when several launches of the kernel are in flight at once")
+    sec_eff = ms_per_step * 1e-3 / launches_per_step if chip else sec  # wall time per launch of the kernel
+    achieved = None if valu is None else valu / sec_eff / 1e9
     block = {
         "bound": "valu-issue",
         "kernel": inp.get("kernel", KERNEL),
         "achieved": achieved, "peak": VALU_PEAK_GINST, "unit": "G wave-instr/s",
         "frac": None if achieved is None else achieved / VALU_PEAK_GINST,
+        "basis": (f"chip level: counts of the {launches_per_step} launches of a step / ms_per_step ({launches_per_step} launches in flight at once)"
+                  if chip else "per launch: counts of a launch / avg_launch_ms"),
+        "per_launch": {"achieved": per_launch, "frac": None if per_launch is None else per_launch / VALU_PEAK_GINST},
+        "launches_per_step": launches_per_step, "ms_per_step": ms_per_step,
         "avg_launch_ms": avg_launch_ms, "launches": launches, "timing_stride": timing_stride,
         "valu_wave_insts_per_launch": valu,
         "traffic": hbm,
-        "hbm_real": None if hbm is None else {"bytes_per_launch": hbm, "GBs": hbm / sec / 1e9, "frac_of_peak": hbm / sec / 1e9 / HBM_PEAK_GBS,
+        "hbm_real": None if hbm is None else {"bytes_per_launch": hbm, "GBs": hbm / sec_eff / 1e9, "frac_of_peak": hbm / sec_eff / 1e9 / HBM_PEAK_GBS,
                                                "peak_GBs": HBM_PEAK_GBS, "l2_hit_rate": inp.get("l2_hit_rate")},
-        "algorithmic_equiv_GBs": algorithmic_bytes / sec / 1e9,
+        "algorithmic_equiv_GBs": algorithmic_bytes / sec_eff / 1e9,
         "algorithmic_bytes_per_launch": algorithmic_bytes,
         "from_profiles_tag": inp.get("from_profiles_tag") if same else None,
         "note": "bound = VALU instruction issue (1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction); counts per launch from "
-                "profiles/<from_profiles_tag>_pmc_*.csv via tools/roofline.py, duration measured in this run; algorithmic_equiv_GBs "
+                "profiles/<from_profiles_tag>_pmc_*.csv via tools/roofline.py, durations measured in this run; algorithmic_equiv_GBs "
                 "(SURVEY 8d: 32 + 128 O bytes per point) is not a fraction of anything: the kernel retires 85 % of the pairs in "
                 "registers" + ("" if same else "; profiles/roofline_inputs.json is for another workload: counts omitted"),
     }
@@ -116,7 +132,7 @@ def main():
         b = json.loads(line)
         r = b["roofline"]
         mine = roofline_block(prof / "roofline_inputs.json", r["avg_launch_ms"], r["launches"], r["timing_stride"], r["algorithmic_bytes_per_launch"],
-                              inp["workload"] or {})
+                              inp["workload"] or {}, r.get("launches_per_step", 1), r.get("ms_per_step"))
         ok = True
         for k in ("achieved", "frac", "traffic", "algorithmic_equiv_GBs"):
             a_, b_ = mine[k], r.get(k)
