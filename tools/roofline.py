@@ -123,15 +123,18 @@ def main():
     args = ap.parse_args()
     prof = ROOT / "profiles"
     inp = derive_inputs(args.tag, prof)
-    if not args.no_write:
-        (prof / "roofline_inputs.json").write_text(json.dumps(inp, indent=1) + "\n")
+    import tempfile
+    inputs_path = prof / "roofline_inputs.json"
+    if args.no_write:  # recompute an older tag's bench line from that tag's own CSVs without touching the tracked inputs
+        inputs_path = Path(tempfile.mkdtemp()) / "roofline_inputs.json"
+    inputs_path.write_text(json.dumps(inp, indent=1) + "\n")
     print(json.dumps(inp, indent=1))
     bench = Path(args.bench) if args.bench else prof / f"{args.tag}_bench.json"
     if bench.exists():
         line = [l for l in bench.read_text().splitlines() if l.startswith("{")][-1]
         b = json.loads(line)
         r = b["roofline"]
-        mine = roofline_block(prof / "roofline_inputs.json", r["avg_launch_ms"], r["launches"], r["timing_stride"], r["algorithmic_bytes_per_launch"],
+        mine = roofline_block(inputs_path, r["avg_launch_ms"], r["launches"], r["timing_stride"], r["algorithmic_bytes_per_launch"],
                               inp["workload"] or {}, r.get("launches_per_step", 1), r.get("ms_per_step"))
         ok = True
         for k in ("achieved", "frac", "traffic", "algorithmic_equiv_GBs"):
