@@ -126,7 +126,7 @@ def main():
     ap.add_argument("--grid", type=int, default=64)
     ap.add_argument("--share-grids", action="store_true", help="store identical SDF volumes once (model library)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--pipeline", type=int, default=0, help="parts of the engine's software pipeline (0: 2 when scenes x goals >= 4096, else 1)")
+    ap.add_argument("--pipeline", type=int, default=0, help="parts of the engine's software pipeline (0: 2 when scenes x goals >= ChompEngine.PIPELINE_MIN_ITEMS, else 1)")
     ap.add_argument("--no-plan", action="store_true", help="skip timing a full 70-iteration plan (ms_per_plan)")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of three scenes after the timed region")
     ap.add_argument("--ol-alg", default="MD", help="goal-selection rule (reference default: MD, omg/config.py:67)")

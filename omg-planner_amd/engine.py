@@ -67,10 +67,12 @@ class ChompEngine:
     reschedule_every = 0
     schedule_slack = 2  # goal workgroup slots per XCD in units of the even share (see build_schedule)
     # Software pipeline over scene sub-ranges (see _iterate_pipelined): an integer k runs every iterate() as k parts on k HIP
-    # streams (1: never); None: plan() pipelines two parts when each part still fills the GPU for several rounds
-    # (S * G >= PIPELINE_MIN_ITEMS), a bare iterate() does not — its caller owns the synchronisation (join()).
+    # streams (1: never); None: plan() pipelines two parts from PIPELINE_MIN_ITEMS (scene, goal) items on — below, the host's
+    # four launches per iteration (~95 us) take longer than the GPU needs (tools/ab_pipeline.py: 8 x 64: 90 -> 96 us,
+    # 16 x 64: 109 -> 95, 13 x 128: 139 -> 112, 50 x 64: 191 -> 172, 100 x 64: 312 -> 285) — a bare iterate() does not: its
+    # caller owns the synchronisation (join()).
     pipeline = None
-    PIPELINE_MIN_ITEMS = 4096
+    PIPELINE_MIN_ITEMS = 768
     # per-scene tensors: a part of the pipeline works on the rows [lo, hi) of each
     _PART_TENSORS = ("start", "goal_set", "reach", "cv_goals", "goal_idx", "goal_count", "eta_s", "traj", "end", "goal_rows", "goal_point",
                      "pot", "pgrad", "col", "grad", "cost_traj", "info", "goal_cost", "goal_col", "learner_state", "cost_vec", "_active",
@@ -160,6 +162,7 @@ class ChompEngine:
         self._ticket = 0
         self._num_cus = torch.cuda.get_device_properties(dev).multi_processor_count
         self._parts, self._forked, self._in_plan = None, False, False
+        self._hot = None
         self._gather_goal()
 
     @property
@@ -253,6 +256,7 @@ class ChompEngine:
         part.cfg = copy.copy(self.cfg)  # the weight schedule's fields are set per iteration (_iterate_pipelined)
         part.S, part.stream, part._lo = hi - lo, stream, lo
         part._parts, part._forked, part.pipeline = None, False, 1
+        part._hot = None
         sc = object.__new__(ops.DeviceScenes)
         sc.__dict__.update(self.scenes.__dict__)
         sc.num_scenes, sc.scene_begin = hi - lo, self.scenes.scene_begin[lo:hi + 1]  # object offsets stay absolute
@@ -446,12 +450,21 @@ class ChompEngine:
         omgx_goalset_cost_layer (goal-set batch + SDF layer of the current trajectories) and omgx_goal_update_optimize
         (Learner.update_goal + Optimizer.optimize); once the goal is fixed (t >= optim_steps, "Proj", "Baseline") the layer
         launch and the step."""
-        if self.stream is not None and torch.cuda.current_stream(self.device) != self.stream:
-            with torch.cuda.stream(self.stream):
-                return self.iterate(t, early_stop)
         k = self._pipeline_parts()
         if k > 1:
             return self._iterate_pipelined(t, early_stop, k)
+        cfg = self.cfg
+        if not self.separate_launches and cfg.goal_set_proj and t < cfg.optim_steps and not self._forked:
+            if early_stop:
+                self._masked = True
+            if self._iterate_hot(bool(early_stop and t > 0)):
+                return None
+        if self.stream is not None and torch.cuda.current_stream(self.device) != self.stream:
+            with torch.cuda.stream(self.stream):
+                return self._iterate_general(t, early_stop)
+        return self._iterate_general(t, early_stop)
+
+    def _iterate_general(self, t: int, early_stop: bool):
         self.join()
         if self.separate_launches:
             return self.iterate_separate(t, early_stop)
@@ -472,6 +485,43 @@ class ChompEngine:
             self._layer()
             self._schedule()
             self._step(True, None, stop_on_terminate=stop)
+
+    _HOT_TENSORS = ("robot", "cv_goals", "traj", "pot", "pgrad", "col", "goal_cost", "goal_col", "goal_set", "reach", "learner_state",
+                    "goal_idx", "start", "end", "goal_rows", "goal_point", "grad", "cost_traj", "info", "cost_vec", "_active",
+                    "goal_count", "eta_s", "_scene_flags")
+
+    def _iterate_hot(self, stop: bool) -> bool:
+        """A goal-selecting iteration in its steady state — schedule settled (or none), nothing to measure — through
+        ops.IterationCalls: the same two launches with argument lists prepared once, on this engine's stream without
+        switching torch's current stream.  Returns False when the general path has to run (first launches of a plan, schedule
+        rebuilds, the rules without a goal-set batch)."""
+        if self.ol_alg in ("Baseline", "Proj"):
+            return False
+        use_sched = self.auto_schedule and not self._masked
+        if self._masked and self.auto_schedule and self._measured and self.reschedule_every:
+            return False
+        if use_sched and (self.schedule is None or (not self._measured and self._gs_launches >= 1 and self.S * self.G >= 2048)):
+            return False
+        key = tuple(id(getattr(self, k)) for k in self._HOT_TENSORS) + (id(self.scenes.scene_begin),)
+        hot = self._hot
+        if hot is None or hot[0] != key:
+            calls = ops.IterationCalls(self.robot, self.P, self.scenes, self.cv_goals, self.cfg.time_interval, self.traj,
+                                       (self.pot, self.pgrad, self.col), (self.goal_cost, self.goal_col), self.goal_set, self.reach,
+                                       self.learner_state, self.goal_idx, self.start, self.end, self.goal_rows, self.goal_point,
+                                       (self.grad, self.cost_traj, self.info), self.cost_vec, self._active, self.goal_count, self.eta_s,
+                                       self._scene_flags, layer_soften_fingers=self.cfg.uncheck_finger_collision == -1)
+            hot = self._hot = (key, calls)
+        calls = hot[1]
+        stream = (self.stream if self.stream is not None else torch.cuda.current_stream(self.device)).cuda_stream
+        self.t += 1
+        prm = self._learner_params()
+        self._gs_launches += 1
+        calls.goalset_layer(prm.start_idx, self._masked, self.schedule if use_sched else None, None, stream)
+        self._schedule()
+        self._ticket += 1
+        split = 2 * self.S <= self._num_cus if self.split_update is None else bool(self.split_update)
+        calls.update(prm, self._params(True), split, self._ticket, stop, stream)
+        return True
 
     def iterate_separate(self, t: int, early_stop: bool = False):
         """The same iteration composed from the separate entry points the drop-in classes use — omgx_goalset_cost,

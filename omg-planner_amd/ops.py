@@ -300,6 +300,79 @@ def goal_update_optimize(lparams: LearnerParams, goal_set, reach, goal_cost, sta
     return grad, cost_traj, info
 
 
+class IterationCalls:
+    """The two launches of a planner iteration (omgx_goalset_cost_layer with traj_start = traj[:, k], then
+    omgx_goal_update_optimize) with their tensor arguments checked and converted ONCE: a steady-state iteration passes ~60
+    pointers whose values never change, and re-checking / re-wrapping them costs the host more than the launches
+    themselves (48 -> 27 us per iteration; it matters when the iteration is short: small batches, the late iterations of a
+    plan, the engine's two-stream pipeline).  Same entry points, same argument meaning as goalset_cost_layer() and
+    goal_update_optimize(); whoever rebinds one of the tensors builds a new object (ChompEngine keys it on their identities)."""
+
+    def __init__(self, robot, P, scenes: DeviceScenes, goals, dt, traj, layer_out, goal_out, goal_set, reach, state, goal_idx,
+                 start, end, goal_rows, goal_point, step_out, cost_vector, active, goal_count=None, eta=None, scene_flags=None,
+                 layer_soften_fingers=False):
+        lp, lg, lc = layer_out
+        cost, col = goal_out
+        grad, cost_traj, info = step_out
+        for n_, t in (("goals", goals), ("traj", traj), ("goal_set", goal_set), ("state", state), ("start", start), ("end", end),
+                      ("goal", goal_rows), ("goal_point", goal_point), ("grad", grad), ("cost_traj", cost_traj), ("info", info),
+                      ("cost_vector", cost_vector)):
+            _need(t, torch.float64, n_)
+        if reach is not None:
+            _need(reach, torch.float64, "reach")
+        for n_, t in (("layer potentials", lp), ("layer grads", lg), ("layer collides", lc), ("goal_cost", cost), ("goal collides", col)):
+            _need(t, torch.float32, n_)
+        S, G, n = goals.shape[0], goals.shape[1], traj.shape[1]
+        if traj.shape[0] != S or lp.numel() != S * n * 10 * P or lg.numel() != 3 * lp.numel() or lc.numel() != lp.numel():
+            raise _lib.OmgHipError("layer outputs must be [S,n,10,P], [S,n,10,P,3], [S,n,10,P]")
+        if goal_idx.dtype != torch.int32 or not goal_idx.is_cuda or goal_idx.numel() != S:
+            raise _lib.OmgHipError("goal_idx must be an int32 device tensor [S]")
+        if scene_flags is not None and (scene_flags.dtype != torch.int32 or scene_flags.numel() < S or not scene_flags.is_cuda):
+            raise _lib.OmgHipError("scene_flags must be an int32 device tensor [S]")
+        _active(active, S); _active(goal_count, S); _eta(eta, S)
+        self.S, self.G, self.n, self.P, self.dt = S, G, n, int(P), float(dt)
+        self.device = traj.device
+        self._dev_index = traj.device.index if traj.device.index is not None else torch.cuda.current_device()
+        self._traj_addr = traj.data_ptr()
+        l = _lib.lib()
+        self._f_gs, self._f_up = l.omgx_goalset_cost_layer, l.omgx_goal_update_optimize
+        self._layer_soft = int(bool(layer_soften_fingers))
+        p = _ptr
+        self._gs_head = (p(robot), self.P, p(scenes.objects), p(scenes.scene_begin), p(scenes.pool))
+        self._gs_mid = (p(cost), p(col), None, p(traj), n, self._layer_soft, p(lp), p(lg), p(lc))
+        self._goals, self._active_p, self._goal_count = p(goals), p(active), p(goal_count)
+        self._up_a = (p(goal_set), p(reach), p(cost), p(state), p(goal_idx), p(cost_vector), p(robot))
+        self._up_b = (p(traj), p(start), p(end), p(goal_rows), p(goal_point), p(lp), p(lg), p(lc), p(active), S, p(grad), p(cost_traj),
+                      p(info), None)
+        self._flags, self._eta = p(scene_flags), p(eta)
+
+    def _on_device(self):
+        return torch.cuda.current_device() == self._dev_index
+
+    def goalset_layer(self, start_idx: int, masked: bool, schedule, work, stream):
+        """omgx_goalset_cost_layer for traj_start = traj[:, start_idx], n_remaining = n - start_idx.  schedule / work: checked
+        int32 device tensors or None; stream: a HIP stream handle (int)."""
+        args = (*self._gs_head, C.c_void_p(self._traj_addr + 72 * start_idx), self.n * 9, self._goals, self.S, self.G,
+                self.n - start_idx, self.dt, 0, *self._gs_mid, self._active_p if masked else None, self._goal_count,
+                _ptr(_i32n(schedule, None, "schedule")), 0 if schedule is None else schedule.numel(), _ptr(_i32n(work, self.S * self.G, "work")),
+                C.c_void_p(stream))
+        if self._on_device():
+            check(self._f_gs(*args), "omgx_goalset_cost_layer")
+        else:
+            with torch.cuda.device(self.device):
+                check(self._f_gs(*args), "omgx_goalset_cost_layer")
+
+    def update(self, lparams: LearnerParams, params: ChompParams, split: bool, ticket: int, stop_on_terminate: bool, stream):
+        """omgx_goal_update_optimize."""
+        args = (C.byref(lparams), *self._up_a, C.byref(params), *self._up_b, self._flags if split else None, int(ticket),
+                int(bool(stop_on_terminate)), self._goal_count, self._eta, C.c_void_p(stream))
+        if self._on_device():
+            check(self._f_up(*args), "omgx_goal_update_optimize")
+        else:
+            with torch.cuda.device(self.device):
+                check(self._f_up(*args), "omgx_goal_update_optimize")
+
+
 def point_cloud_sdf(points: torch.Tensor, grid_resolution: float = 0.02, margin: float = 0.24, out: "torch.Tensor | None" = None):
     """PointEnv.compute_sdf_from_points (omg/core.py:426-457) on the device: points [N,3] f64 (robot base frame) ->
     (grid float32 [X,Y,Z] of nearest-point distances, origin [3] float64 numpy, resolution).  The workspace bounds
