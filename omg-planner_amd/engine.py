@@ -22,6 +22,8 @@ closes the job (``gather_costs``).
 """
 from __future__ import annotations
 
+import operator
+
 import numpy as np
 import torch
 
@@ -502,9 +504,10 @@ class ChompEngine:
             return False
         if use_sched and (self.schedule is None or (not self._measured and self._gs_launches >= 1 and self.S * self.G >= 2048)):
             return False
-        key = tuple(id(getattr(self, k)) for k in self._HOT_TENSORS) + (id(self.scenes.scene_begin),)
+        # the prepared calls belong to these very tensor objects (held here, so none of them can be freed and its identity reused)
+        key = [getattr(self, k) for k in self._HOT_TENSORS] + [self.scenes.scene_begin]
         hot = self._hot
-        if hot is None or hot[0] != key:
+        if hot is None or not all(map(operator.is_, hot[0], key)):
             calls = ops.IterationCalls(self.robot, self.P, self.scenes, self.cv_goals, self.cfg.time_interval, self.traj,
                                        (self.pot, self.pgrad, self.col), (self.goal_cost, self.goal_col), self.goal_set, self.reach,
                                        self.learner_state, self.goal_idx, self.start, self.end, self.goal_rows, self.goal_point,
