@@ -196,9 +196,9 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    # every 4th launch of the dominant kernel is bracketed by HIP events attached to the dispatch (all of them would cost
-    # 1.7 % of the step time, a quarter 0.4 %)
-    stride = 4
+    # every 5th launch of the dominant kernel is bracketed by HIP events attached to the dispatch (all of them would cost
+    # 1.7 % of the step time, a fifth 0.3 %); an odd stride, so that the samples alternate between the pipeline's parts
+    stride = 5
     lib.omgx_timing_enable(stride)
     t0 = time.perf_counter()
     for _ in range(args.steps):
