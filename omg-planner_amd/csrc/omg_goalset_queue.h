@@ -139,6 +139,7 @@ __global__ __launch_bounds__(256, GQ_WG_PER_CU) void k_goalset_queue(ChunkArgs a
         return;
     }
     const unsigned long long work_t0 = STAMP ? wall_clock64() : 0ull;
+    GS_FREQ_BEGIN();
     uint32_t* const tbl = reinterpret_cast<uint32_t*>(lds_bytes + L.tbl_off);      // [a.tbl_n][16]
     double* const pts = reinterpret_cast<double*>(lds_bytes + L.pts_off);          // [10][P][3]
     float* const stage = reinterpret_cast<float*>(lds_bytes + L.stage_off) + wave * 256;  // wave-private [64][4]
@@ -427,5 +428,6 @@ __global__ __launch_bounds__(256, GQ_WG_PER_CU) void k_goalset_queue(ChunkArgs a
             if (STAMP) { const unsigned long long dt = wall_clock64() - work_t0; a.work[k] = dt < 1 ? 1u : (dt > 0xffffffffull ? 0xffffffffu : (uint32_t)dt); }
         }
     }
+    GS_FREQ_END();
     GS_WG_STAMP(4);
 }

@@ -65,6 +65,14 @@ def main():
         "wgs_per_xcc": {int(x): int((ran & (xcc == x)).sum()) for x in np.unique(xcc[ran])},
         "blockidx_mod8_equals_xcc": float((xcc[ran] == (np.arange(nwg)[ran] & 7)).mean()),
     }
+    # the clock the CUs really ran at during the launch: shader-clock cycles per 100 MHz tick over each goal workgroup's lifetime
+    fr = (C.c_ulonglong * (2 * nwg))()
+    lib.omgx_debug_gs_freq.argtypes = [C.c_void_p, C.c_int]
+    if lib.omgx_debug_gs_freq(fr, nwg) == 0:
+        f = np.array(list(fr), dtype=np.float64).reshape(nwg, 2)
+        ok = ran & ~is_layer & (f[:, 1] > 1000)
+        ghz = f[ok, 0] / f[ok, 1] * 0.1
+        out["shader_clock_ghz_p10/p50/p90"] = [round(float(np.percentile(ghz, q)), 3) for q in (10, 50, 90)]
     # resident workgroups over time (all CUs): fraction of the 1536 slots in use, in 10 slices of the span
     span = en[ran].max()
     edges = np.linspace(0, span, 11)
