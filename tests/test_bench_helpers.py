@@ -18,3 +18,35 @@ def test_workload_and_cpu_baseline():
     assert np.linalg.norm(pos - sc.make_tabletop_scene(0, grid=16).objects[0].pose_mat[:3, 3], axis=1).max() < 0.45
     out = bench.cpu_baseline(cfg, model, batch, start, goals, 30, budget_s=0.5)
     assert out["kind"] == "port" and out["unit"] == "iterations/s" and out["value"] > 0 and out["cores"] >= 1
+
+
+def test_roofline_block_per_launch_and_chip_level(tmp_path):
+    """tools/roofline.py: one launch per step -> counts / launch duration; k launches in flight at once (pipelined engine) ->
+    counts of a step's launches / the step's wall time, the per-launch figure beside it; counts are dropped when the tracked
+    inputs belong to another workload; the committed inputs reproduce the committed bench line."""
+    import json
+    import pytest
+    from tools.roofline import ROOT, VALU_PEAK_GINST, roofline_block
+    wl = {"scenes": 100, "goals": 64, "pipeline": 2}
+    inp = tmp_path / "inputs.json"
+    inp.write_text(json.dumps({"from_profiles_tag": "t", "workload": wl, "valu_wave_insts_per_launch": 60.0e6, "hbm_bytes_per_launch": 1.0e8,
+                               "l2_hit_rate": 0.95}))
+    one = roofline_block(inp, 0.25, 40, 5, 1.0e10, wl)
+    assert one["basis"].startswith("per launch") and one["achieved"] == pytest.approx(60.0e6 / 0.25e-3 / 1e9)
+    assert one["frac"] == pytest.approx(one["achieved"] / VALU_PEAK_GINST) and one["per_launch"]["achieved"] == pytest.approx(one["achieved"])
+    two = roofline_block(inp, 0.25, 40, 5, 1.0e10, wl, launches_per_step=2, ms_per_step=0.30)
+    assert two["basis"].startswith("chip level") and two["achieved"] == pytest.approx(2 * 60.0e6 / 0.30e-3 / 1e9)
+    assert two["per_launch"]["achieved"] == pytest.approx(60.0e6 / 0.25e-3 / 1e9) and two["frac"] <= 1.0
+    assert two["hbm_real"]["GBs"] == pytest.approx(2 * 1.0e8 / 0.30e-3 / 1e9)
+    with pytest.raises(ValueError):
+        roofline_block(inp, 0.25, 40, 5, 1.0e10, wl, launches_per_step=2)
+    other = roofline_block(inp, 0.25, 40, 5, 1.0e10, dict(wl, goals=128))
+    assert other["achieved"] is None and other["frac"] is None and other["from_profiles_tag"] is None
+    # the tracked inputs and the bench line they belong to
+    tracked = json.loads((ROOT / "profiles" / "roofline_inputs.json").read_text())
+    bench = ROOT / "profiles" / f"{tracked['from_profiles_tag']}_bench.json"
+    line = json.loads([l for l in bench.read_text().splitlines() if l.startswith("{")][-1])
+    r = line["roofline"]
+    again = roofline_block(ROOT / "profiles" / "roofline_inputs.json", r["avg_launch_ms"], r["launches"], r["timing_stride"],
+                           r["algorithmic_bytes_per_launch"], tracked["workload"], r.get("launches_per_step", 1), r.get("ms_per_step"))
+    assert again["frac"] == pytest.approx(r["frac"], rel=1e-6) and 0.0 < again["frac"] <= 1.0

@@ -94,3 +94,42 @@ def test_pipelined_bench_workload_matches_oracle(dev):
         r = engine_vs_oracle(eng, batch, [0, 49, 50, 99], steps=3, pin_window=True)
         assert r["goal_idx_equal"], r
         assert r["max_traj_err"] <= 1e-6 and r["max_cost_rel_err"] <= 1e-5, r
+
+
+def test_prepared_iteration_calls_check_their_tensors(dev):
+    """ops.IterationCalls validates once what goalset_cost_layer / goal_update_optimize validate per call."""
+    from omg_planner_amd import _lib, ops
+    make, _ = _engines(dev, 3, 8)
+    e = make()
+
+    def build(**over):
+        a = dict(robot=e.robot, P=e.P, scenes=e.scenes, goals=e.cv_goals, dt=e.cfg.time_interval, traj=e.traj, layer_out=(e.pot, e.pgrad, e.col),
+                 goal_out=(e.goal_cost, e.goal_col), goal_set=e.goal_set, reach=e.reach, state=e.learner_state, goal_idx=e.goal_idx, start=e.start,
+                 end=e.end, goal_rows=e.goal_rows, goal_point=e.goal_point, step_out=(e.grad, e.cost_traj, e.info), cost_vector=e.cost_vec,
+                 active=e._active, goal_count=e.goal_count, eta=e.eta_s, scene_flags=e._scene_flags)
+        a.update(over)
+        return ops.IterationCalls(**a)
+
+    build()
+    with pytest.raises(_lib.OmgHipError):
+        build(traj=e.traj.float())
+    with pytest.raises(_lib.OmgHipError):
+        build(traj=e.traj.cpu())
+    with pytest.raises(_lib.OmgHipError):
+        build(layer_out=(e.pot[:, :-1], e.pgrad, e.col))
+    with pytest.raises(_lib.OmgHipError):
+        build(goal_idx=e.goal_idx.long())
+    with pytest.raises(_lib.OmgHipError):
+        build(active=e._active[:-1])
+    # the engine builds new calls when one of its tensors is rebound, and the result stays that of the general path
+    ref = make()
+    for t in range(5):
+        e.iterate(t)
+        ref.separate_launches = True
+        ref.iterate(t)
+    first = e._hot[1]
+    e.traj = e.traj.clone()
+    e.iterate(5)
+    ref.iterate(5)
+    assert e._hot[1] is not first
+    _assert_same(e, ref)
