@@ -230,7 +230,7 @@ def main():
         eng.restore(snap)
         parity = engine_vs_oracle(eng, batch, sorted({0, S // 2, S - 1}), steps=3, pin_window=True)
 
-    ms_per_plan = ms_plan_early = ms_single = terminated = None
+    ms_per_plan = ms_plan_early = ms_single = terminated = ms_graph_early = ms_graph_single = None
     if not args.no_plan and rank == 0:
         ms_per_plan = float("inf")
         for _ in range(2):  # best of 2: the first plan pays one-off costs (code-object load of the 30 window sizes)
@@ -260,6 +260,22 @@ def main():
             e1.plan(early_stop=False)
             torch.cuda.synchronize()
             ms_single = min(ms_single, (time.perf_counter() - tp) * 1e3)
+
+        # the same plans as ONE HIP graph each (ChompEngine.capture_plan: no host in the loop), replayed from the fresh state
+        def graph_ms(e):
+            fresh = e.snapshot()
+            pg = e.capture_plan(early_stop=True)
+            best = float("inf")
+            for _ in range(3):
+                e.restore(fresh)
+                torch.cuda.synchronize()
+                tp_ = time.perf_counter()
+                pg.replay()
+                torch.cuda.synchronize()
+                best = min(best, (time.perf_counter() - tp_) * 1e3)
+            return best
+        ms_graph_early = graph_ms(ChompEngine(model, batch, copy.deepcopy(cfg), start, goals, device=dev, ol_alg=args.ol_alg))
+        ms_graph_single = graph_ms(ChompEngine(model, one, copy.deepcopy(cfg), start[:1], goals[:1], device=dev, ol_alg=args.ol_alg))
 
     if rank == 0:
         durs = np.array([buf[i] for i in range(nrec)], dtype=np.float64)
@@ -307,6 +323,8 @@ def main():
             out["ms_per_plan_early_stop"] = ms_plan_early  # with the reference's break on `terminate` (informational)
             out["scenes_terminated_early"] = terminated
             out["ms_per_plan_single_scene"] = ms_single  # one scene alone (launch-latency bound), best of 3
+            out["ms_per_plan_early_stop_graph"] = ms_graph_early  # the early-stop plan replayed as one HIP graph (capture_plan)
+            out["ms_per_plan_single_scene_graph"] = ms_graph_single
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, model, batch, start, goals, n)
         print(json.dumps(out))

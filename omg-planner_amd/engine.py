@@ -165,6 +165,7 @@ class ChompEngine:
         self._num_cus = torch.cuda.get_device_properties(dev).multi_processor_count
         self._parts, self._forked, self._in_plan = None, False, False
         self._hot = None
+        self._capturing = False
         self._gather_goal()
 
     @property
@@ -621,7 +622,7 @@ class ChompEngine:
             for t in range(cfg.optim_steps + cfg.extra_smooth_steps):
                 self.iterate(t, early_stop)
                 self.iterations_run = t + 1
-                if cfg.timeout != -1 and t > 0 and time.time() - t_start > cfg.timeout:
+                if cfg.timeout != -1 and t > 0 and not self._capturing and time.time() - t_start > cfg.timeout:
                     self.timed_out = True
                     break
                 if self._plan_all_done(early_stop, t):
@@ -635,11 +636,57 @@ class ChompEngine:
         iterations): look at the mask at a thinning set of iterations and stop launching no-ops.  Each look is a host
         sync that drains the launch queue (measured: ~0.4 ms each with 100 scenes in flight, where it never pays), so
         only small batches do it."""
+        if self._capturing:  # a graph has no host in its loop
+            return False
         return bool(early_stop and self.S <= 16 and t in _ALL_DONE_CHECKS and not bool(self.active.any().item()))
+
+    def capture_plan(self, early_stop: bool = True, initial_goal: bool = True) -> "PlanGraph":
+        """plan() as ONE HIP graph: the initial goal pick, all optim_steps + extra_smooth_steps iterations (on both streams of the
+        pipeline where it applies) and the final evaluation are recorded once and replayed with a single launch — the planner
+        loop of planner.py:600-653 without the host in it.  Everything the host decides per iteration is frozen at capture: the
+        weight schedule (Optimizer.update), the goal-set window, the iteration count; what depends on the data stays on the
+        device — a scene that terminates (`early_stop`) is skipped by every later launch through its `active` flag, but the
+        launches themselves remain, and cfg.timeout has no meaning.  Replays compute exactly what plan() computes from the
+        same state (tests/test_gpu_pipeline.py).  The engine's state after this call is its state before it.
+
+            fresh = eng.snapshot(); graph = eng.capture_plan()
+            for problem in problems:                       # same shapes, same scenes
+                eng.restore(fresh); eng.start.copy_(...); eng.goal_set.copy_(...); eng.traj.copy_(...)
+                info = graph.replay()
+        """
+        state = self.snapshot()
+        self.plan(early_stop, initial_goal)  # warm-up: workspaces, dispatch schedules, pipeline parts and their streams exist afterwards
+        self.restore(state)
+        torch.cuda.synchronize(self.device)
+        graph = torch.cuda.CUDAGraph()
+        self._capturing = True
+        try:
+            with torch.cuda.graph(graph):
+                info = self.plan(early_stop, initial_goal)
+                self.join()
+        finally:
+            self._capturing = False
+        self.restore(state)  # nothing has run, but the host-side counters went through a plan
+        torch.cuda.synchronize(self.device)
+        return PlanGraph(self, graph, info)
 
     def final_costs(self) -> torch.Tensor:
         self.join()
         return self.info[:, 0].contiguous()
+
+
+class PlanGraph:
+    """A captured ChompEngine.plan (ChompEngine.capture_plan)."""
+
+    def __init__(self, engine: ChompEngine, graph: "torch.cuda.CUDAGraph", info: torch.Tensor):
+        self.engine, self.graph, self.info = engine, graph, info
+
+    def replay(self) -> torch.Tensor:
+        """Run the plan from the engine's current device state on the current stream: one launch, no host sync.  Returns the
+        engine's info tensor [S,16] (valid once the stream has caught up)."""
+        self.engine.join()
+        self.graph.replay()
+        return self.info
 
 
 def gather_costs_equal(local_costs: torch.Tensor, world: int) -> torch.Tensor:

@@ -133,3 +133,27 @@ def test_prepared_iteration_calls_check_their_tensors(dev):
     ref.iterate(5)
     assert e._hot[1] is not first
     _assert_same(e, ref)
+
+
+@pytest.mark.parametrize("S,early", [(3, True), (48, True), (48, False)])
+def test_captured_plan_replays_to_the_same_bits(dev, S, early):
+    """ChompEngine.capture_plan: the whole plan as one HIP graph (with 48 x 64 items also its two-stream pipeline) against
+    plan(), twice from the same fresh state and once after the state was disturbed in between."""
+    make, _ = _engines(dev, S, 64)
+    ref = make()
+    ref.plan(early_stop=early)
+    eng = make()
+    fresh = eng.snapshot()
+    graph = eng.capture_plan(early_stop=early)
+    assert (eng.t, eng.step_count) == (0, 0) and np.array_equal(eng.traj.cpu().numpy(), fresh["traj"].cpu().numpy())
+    for rep in range(2):
+        eng.restore(fresh)
+        if rep == 1:
+            eng.iterate(0)        # something else happened on the engine in between
+            eng.restore(fresh)
+        info = graph.replay()
+        torch.cuda.synchronize()
+        assert info is eng.info
+        for k in ("traj", "info", "goal_idx", "learner_state", "end", "goal_rows"):
+            assert np.array_equal(getattr(eng, k).cpu().numpy(), getattr(ref, k).cpu().numpy(), equal_nan=True), (rep, k)
+        assert np.array_equal(eng.active.cpu().numpy(), ref.active.cpu().numpy())

@@ -1,32 +1,61 @@
-"""Experiment: how much would hipGraph replay of one planner iteration save? (weights frozen at capture)"""
-import sys, time, copy
-sys.path.insert(0, '.')
-import torch, bench
+"""Experiment: a whole ChompEngine.plan captured as ONE HIP graph (torch.cuda.CUDAGraph) against the eager plan.
+    python tools/graph_experiment.py [scenes] [goals] [early_stop 0|1]
+Replaying the graph re-runs the plan from whatever state the engine's tensors hold (kernel arguments are frozen at capture)."""
+import copy
+import sys
+import time
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import torch
+
+import bench
 from omg_planner_amd.engine import ChompEngine
-cfg, model, batch, start, goals = bench.build_workload(100, 64, 30, 64, 0, False)
-eng = ChompEngine(model, batch, copy.deepcopy(cfg), start, goals, device="cuda:0", ol_alg="MD")
-def step():
-    eng.t = 0; eng.iterate(0)
-for _ in range(5): step()
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-for _ in range(50): step()
-torch.cuda.synchronize(); print("eager ms/step", (time.perf_counter() - t0) / 50 * 1e3)
-g = torch.cuda.CUDAGraph()
-s = torch.cuda.Stream()
-s.wait_stream(torch.cuda.current_stream())
-with torch.cuda.stream(s):
-    step()
-torch.cuda.current_stream().wait_stream(s)
-torch.cuda.synchronize()
-try:
-    with torch.cuda.graph(g, stream=s):
-        step()
-    torch.cuda.synchronize()
-    for _ in range(5): g.replay()
+
+S = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+G = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+early = bool(int(sys.argv[3])) if len(sys.argv) > 3 else False
+cfg, model, batch, start, goals = bench.build_workload(S, G, 30, 64, 0, False)
+
+
+def fresh():
+    return ChompEngine(model, batch, copy.deepcopy(cfg), start, goals, device="cuda:0", ol_alg="MD")
+
+
+best = float("inf")
+for _ in range(3):
+    e = fresh()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(50): g.replay()
-    torch.cuda.synchronize(); print("graph ms/step", (time.perf_counter() - t0) / 50 * 1e3)
-except Exception as e:
-    print("graph capture failed:", repr(e)[:300])
+    e.plan(early_stop=early)
+    torch.cuda.synchronize()
+    best = min(best, (time.perf_counter() - t0) * 1e3)
+ref = e.info.cpu().numpy().copy()
+print(f"eager plan {best:.2f} ms")
+
+eng = fresh()
+snap0 = eng.snapshot()
+eng.plan(early_stop=early)          # warm-up: workspaces, schedules, parts, side streams
+eng.restore(snap0)
+torch.cuda.synchronize()
+if early and S <= 16:
+    eng._plan_all_done = lambda *a: False  # the host-side look at the mask cannot be captured
+g = torch.cuda.CUDAGraph()
+try:
+    with torch.cuda.graph(g):
+        eng.plan(early_stop=early)
+        eng.join()
+    torch.cuda.synchronize()
+    times = []
+    for _ in range(4):
+        eng.restore(snap0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        g.replay()
+        torch.cuda.synchronize()
+        times.append((time.perf_counter() - t0) * 1e3)
+    import numpy as np
+    same = np.array_equal(eng.info.cpu().numpy(), ref, equal_nan=True)
+    print(f"graph replay {min(times):.2f} ms (all: {[round(x, 2) for x in times]}), results equal to the eager plan: {same}")
+except Exception as ex:  # noqa: BLE001
+    print("graph capture failed:", repr(ex)[:400])
