@@ -4,7 +4,7 @@
 # Writes into gpurun_out/ (copy what is to be judged into profiles/, then `python tools/roofline.py --tag <tag>`):
 #   <tag>_bench.json            the unprofiled default bench.py line
 #   <tag>_kernel_stats.csv      rocprofv3 --kernel-trace --stats of the same command
-#   <tag>_pmc_<SET>.csv         per-kernel means of every counter set (separate --pmc passes, kernel-trace only)
+#   <tag>_pmc_<SET>.csv         per-kernel means of every counter set (separate --pmc passes, kernel-trace only; MEM_* = TA / TCP / TD)
 #   <tag>_workload.json         the workload the counts belong to
 #   <tag>_valu_rates.txt        tools/valu_rates.hip: cycles per wave64 VALU instruction per SIMD (calibration of the bound)
 #   <tag>_valu_rates_pmc.csv    the same kernels under SQ_ACTIVE_INST_VALU / GRBM_GUI_ACTIVE (what "VALU busy" can reach)
@@ -28,6 +28,12 @@ run_pmc SQ_INSTS "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INST
 run_pmc LANES "SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU"
 run_pmc SQ_WAIT "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT"
 run_pmc GRBM "GRBM_GUI_ACTIVE"
+# the vector-memory path of the gathers: address unit, L1, data return (how busy each is next to the VALU)
+if [ -z "$SKIP_MEMPIPE" ]; then
+run_pmc MEM_TA "TA_TA_BUSY_sum TA_BUSY_avr GRBM_GUI_ACTIVE TA_FLAT_READ_WAVEFRONTS_sum"
+run_pmc MEM_TCP "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_GATE_EN1_sum"
+run_pmc MEM_TD "TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TD_TD_BUSY_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum"
+fi
 python3 - > $O/${TAG}_workload.json <<'PY'
 import json
 print(json.dumps({"scenes": 100, "goals": 64, "waypoints": 30, "points_per_link": 15, "grid": 64, "pipeline": 2}))
