@@ -124,6 +124,7 @@ def main():
     ap.add_argument("--goals", type=int, default=64)
     ap.add_argument("--waypoints", type=int, default=30)
     ap.add_argument("--grid", type=int, default=64)
+    ap.add_argument("--objects", type=int, default=4, help="obstacles per scene besides the table (BASELINE config 5's clutter: 12 with --waypoints 50)")
     ap.add_argument("--share-grids", action="store_true", help="store identical SDF volumes once (model library)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pipeline", type=int, default=0, help="parts of the engine's software pipeline (0: 2 when scenes x goals >= ChompEngine.PIPELINE_MIN_ITEMS, else 1)")
@@ -164,7 +165,7 @@ def main():
         S, seed0, total_scenes = len(mine), mine.start, args.total_scenes
     else:
         S, seed0, total_scenes = args.scenes, rank * args.scenes, world * args.scenes
-    cfg, model, batch, start, goals = build_workload(S, G, n, args.grid, seed0=seed0, share_grids=args.share_grids)
+    cfg, model, batch, start, goals = build_workload(S, G, n, args.grid, seed0=seed0, share_grids=args.share_grids, num_objects=args.objects)
     eng = ChompEngine(model, batch, copy.deepcopy(cfg), start, goals, device=dev, ol_alg=args.ol_alg)
     # the engine's software pipeline: the rank's scenes as two independent halves on two streams, so that one half's update
     # launch (and the tail / ramp-up around it) overlaps the other half's goal-set launch; same results bit for bit
@@ -283,7 +284,7 @@ def main():
         goal_ms = durs[kind == 0]  # the goal-set launch (goal-set batch + trajectory layer) = the dominant kernel
         avg_ms = float(goal_ms.mean()) if len(goal_ms) else float("nan")
         P = model.points_per_link
-        O_active = 5
+        O_active = args.objects + 1
         # N (32 + 128 O_active) algorithmic bytes for the N points of one launch — the goal-set batch
         # plus the S x n x 150 points of the trajectory layer.  NOT a measure of what the kernel moves: 85 % of the (point,
         # object) pairs retire in registers before any load and the rest hit L2.
@@ -306,10 +307,10 @@ def main():
             "vs_baseline": None,
             "dtype": "f32 SDF / f64 kinematics+update",
             "data": "synthetic",
-            "config": {"workload": (f"{total_scenes} table-top scenes sharded over {world} GPU(s)" if strong else "100 table-top scenes/GPU") +
+            "config": {"workload": (f"{total_scenes} table-top scenes sharded over {world} GPU(s)" if strong else f"{S} table-top scenes/GPU") +
                                    f" x ({G}-goal goal-set cost + CHOMP step), Panda 9-dof, {n} waypoints",
                        "scenes_per_gpu": S, "total_scenes": total_scenes, "goals": G, "waypoints": n, "objects_per_scene": O_active,
-                       "sdf_grid": f"4x{args.grid}^3 + 128x96x32 per scene, {'shared' if args.share_grids else 'private'}",
+                       "sdf_grid": f"{args.objects}x{args.grid}^3 + 128x96x32 per scene, {'shared' if args.share_grids else 'private'}",
                        "goal_selection": f"{args.ol_alg} on device (omgx_goal_update_optimize)", "launches_per_iteration": 2 * parts,
                        "pipeline_parts": parts,
                        "top_k_collision": cfg.top_k_collision, "plan_restart_every_steps": cfg.optim_steps},

@@ -638,7 +638,10 @@ class ChompEngine:
         only small batches do it."""
         if self._capturing:  # a graph has no host in its loop
             return False
-        return bool(early_stop and self.S <= 16 and t in _ALL_DONE_CHECKS and not bool(self.active.any().item()))
+        if not (early_stop and self.S <= 16 and t in _ALL_DONE_CHECKS):
+            return False
+        self.join()  # the mask rows of a pipelined engine's side stream
+        return not self._active.cpu().numpy().any()  # a plain copy: a torch reduction would load its kernel (~10 ms) on first use
 
     def capture_plan(self, early_stop: bool = True, initial_goal: bool = True) -> "PlanGraph":
         """plan() as ONE HIP graph: the initial goal pick, all optim_steps + extra_smooth_steps iterations (on both streams of the
