@@ -77,6 +77,9 @@ struct ChompArgs {
 };
 
 // wrap_joint(l+1) (omg/util.py:213-220): k-th joint index (into the 10-joint tables) of link l; count via njoints().
+// k_update_optimize_split hands the end configuration's 10 x 12 pose doubles from the learner's workgroup to the step's through the
+// scene's grad rows [n][9]: possible from 14 waypoints on
+__device__ __forceinline__ bool end_pose_fits(int n) { return n * 9 >= 120; }
 __device__ __forceinline__ int njoints(int l) { return l < 7 ? l + 1 : (l == 7 ? 7 : 8); }
 __device__ __forceinline__ int joint_of(int l, int k) { return k < 7 ? k : l; /* k==7: finger joint 8 or 9 == link index */ }
 // wrap_index(l+1) (omg/util.py:205-210): trajectory column of slot k of link l.
@@ -578,7 +581,13 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
         }
         __syncthreads();
         PHASE_MARK_T(24, 0);
-        fk_configs(ncfg - 1, ncfg, L.red + 8);  // the end configuration; red[8..21] is free scratch
+        if (end_pose_fits(n)) {  // the learner's workgroup has left the end configuration's poses in this scene's grad rows
+            const double* src = a.grad + (size_t)s * n * 9;
+            for (int e = tid; e < 120; e += blockDim.x) L.pose[(size_t)(ncfg - 1) * 120 + e] = src[e];
+            __syncthreads();
+        } else {
+            fk_configs(ncfg - 1, ncfg, L.red + 8);  // red[8..21] is free scratch
+        }
         PHASE_MARK_T(28, 0);
         if (topk_mode) {
             for (int grp = i_defer * 10 + tid; grp < n * 10; grp += blockDim.x) winner_gradient(grp);
@@ -812,6 +821,29 @@ __global__ __launch_bounds__(CH_TPB) void k_update_optimize_split(omg_learner::L
         omg_learner::learner_scene(la, blockIdx.x, reinterpret_cast<double (*)[OMGX_MAX_GOALS]>(shl),
                                    reinterpret_cast<double (*)[128]>(shl + 5 * OMGX_MAX_GOALS));
         __syncthreads();
+        // The kinematics of the chosen end configuration (a 3-lane serial chain, ~7 K cycles) run HERE, where nothing waits for
+        // them, instead of in the step's workgroup right after its wait.  The 10 x 12 doubles travel in the scene's `grad`
+        // rows, which the step's workgroup overwrites with the gradient only after it has taken the pose (chomp_scene).
+        if (end_pose_fits(a.prm.n_waypoints) && !(a.active && a.active[blockIdx.x] == 0)) {
+            const RobotView rv(a.robot, a.prm.n_points);
+            const double* q = a.end + 9 * (size_t)blockIdx.x;
+            double* out = a.grad + (size_t)blockIdx.x * a.prm.n_waypoints * 9;
+            if (threadIdx.x < 7) {
+                double sn, cs;
+                fk_joint_sincos(q[threadIdx.x], sn, cs);
+                shl[2 * threadIdx.x] = sn; shl[2 * threadIdx.x + 1] = cs;
+            }
+            __syncthreads();
+            if (threadIdx.x < 3) {
+                const int r = threadIdx.x;
+                fk_chain_row(rv, r, shl, q[7], q[8], [&](int l, double r0, double r1, double r2, double tr) {
+                    double* dst = out + 12 * l + 3 * r;
+                    dst[0] = r0; dst[1] = r1; dst[2] = r2;
+                    dst[9 - 2 * r] = tr;  // element 9 + r of the pose
+                });
+            }
+            __syncthreads();
+        }
         if (threadIdx.x == 0) __hip_atomic_store(goal_flags + blockIdx.x, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef OMGX_PHASE_TIMING
         if (blockIdx.x == 0 && threadIdx.x == 0) g_chomp_phase[27] = __builtin_readcyclecounter();
