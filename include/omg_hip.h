@@ -348,6 +348,8 @@ int omgx_goal_update(const omgx_learner_params* h_params, const double* traj, co
  *                goal-independent part of the step (FK, top-k, per-point costs, most gradients) run in different
  *                workgroups of the launch and meet through scene_flags[s] == ticket; `ticket` must differ from every
  *                value still stored there (use 1, 2, 3, ... per call).  NULL: one workgroup per scene does both in turn.
+ *                In this mode a scene's `grad` rows also carry the end configuration's link poses from the learner's workgroup
+ *                to the step's (from 14 waypoints on) before the gradient is written over them: `grad` must not alias anything.
  *   stop_on_terminate  non-zero: a scene whose info says `terminate` after this step gets active[s] = 0 (active must be
  *                given), i.e. it leaves the planner loop like `if self.info[-1]["terminate"] and t > 0: break`
  *                (omg/planner.py:626) — later launches that take the mask skip it.
