@@ -232,6 +232,7 @@ __device__ __forceinline__ void apply_ainv(const double* in, double* out, int n,
 // wait_goal != nullptr (k_update_optimize_split): the goal (end, goal rows, goal point) is being written by ANOTHER
 // workgroup; everything that does not need it — FK of start and waypoints, top-k, per-point costs, the winners'
 // gradients of all but the last waypoint — runs first, then thread 0 waits for *wait_goal == ticket.
+template <int MAXIT>  // items (16-lane groups of potentials) per thread the prefetch loops are unrolled for: ceil(n * 160 / CH_TPB) <= MAXIT
 __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* smem, const int s, const uint32_t* wait_goal = nullptr,
                                             const uint32_t ticket = 0) {
     if (a.active && a.active[s] == 0) return;
@@ -264,7 +265,6 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
     // This thread's potentials / collision flags: all loads are issued back to back (one memory latency instead of
     // one per item) and stay in flight while the FK waves work; first use is after the FK.
     // Items it = r * CH_TPB + tid, item = (i*10 + l)*16 + p.
-    constexpr int MAXIT = (OMGX_MAX_WAYPOINTS * 160 + CH_TPB - 1) / CH_TPB;
     float pv[MAXIT], cv[MAXIT];
     if (L.potl) {
 #pragma unroll
@@ -799,9 +799,14 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
     PHASE_MARK(8);
 }
 
+// MI: see chomp_scene — MI_SMALL serves up to 32 waypoints (every configuration of BASELINE.json but the 50-waypoint one) with half the
+// unrolled prefetch / count loops and 20 fewer VGPRs, MI_FULL up to OMGX_MAX_WAYPOINTS; same results.
+#define MI_SMALL 10
+#define MI_FULL ((OMGX_MAX_WAYPOINTS * 160 + CH_TPB - 1) / CH_TPB)
+template <int MI>
 __global__ __launch_bounds__(CH_TPB) void k_chomp_optimize(ChompArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    chomp_scene(a, smem, blockIdx.x);
+    chomp_scene<MI>(a, smem, blockIdx.x);
 }
 
 // The same pair with the goal update in its own workgroup: workgroups [0, S) run the learner of scene b and publish
@@ -809,6 +814,7 @@ __global__ __launch_bounds__(CH_TPB) void k_chomp_optimize(ChompArgs a) {
 // (FK, top-k, per-point costs, winners' gradients) overlap the learner; they wait for the flag only before the part that
 // uses the goal.  Learner workgroups come first in the grid, so a waiting workgroup's producer has always been
 // dispatched already (no deadlock); the wait is bounded anyway.
+template <int MI>
 __global__ __launch_bounds__(CH_TPB) void k_update_optimize_split(omg_learner::LearnerArgs la, ChompArgs a, uint32_t* goal_flags,
                                                                   uint32_t ticket) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -851,20 +857,21 @@ __global__ __launch_bounds__(CH_TPB) void k_update_optimize_split(omg_learner::L
         return;
     }
     const int s = (int)blockIdx.x - S;
-    chomp_scene(a, smem, s, goal_flags + s, ticket);
+    chomp_scene<MI>(a, smem, s, goal_flags + s, ticket);
 }
 
 // Learner.update_goal followed by Optimizer.optimize for the same scene in one workgroup (planner.py:612-621 calls them
 // back to back): one launch and no stream round trip between the goal choice and the step that uses it.  The
 // learner's LDS (5 x 256 + 5 x 128 doubles) borrows the front of the dynamic region, which chomp_scene initialises
 // itself after the barrier.
+template <int MI>
 __global__ __launch_bounds__(CH_TPB) void k_update_optimize(omg_learner::LearnerArgs la, ChompArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* shl = reinterpret_cast<double*>(smem);
     omg_learner::learner_scene(la, blockIdx.x, reinterpret_cast<double (*)[OMGX_MAX_GOALS]>(shl),
                                reinterpret_cast<double (*)[128]>(shl + 5 * OMGX_MAX_GOALS));
     __syncthreads();  // the goal written by wave 0 (global memory) is visible to the whole workgroup
-    chomp_scene(a, smem, blockIdx.x);
+    chomp_scene<MI>(a, smem, blockIdx.x);
 }
 
 #ifdef OMGX_PHASE_TIMING
@@ -876,6 +883,7 @@ extern "C" int omgx_debug_chomp_phase_times(unsigned long long* h_out, int n) {
 }
 #endif
 
+static bool fits_small(int n) { return n * 160 <= MI_SMALL * CH_TPB; }
 static size_t host_lds_bytes(int n, int P) {
     size_t d = (size_t)(n + 2) * 120 + 60 + (size_t)n * 80 + (size_t)n * 10 + (size_t)n * 9 * 6 + (n + 1) + 30 * P + 64 + 246;
     size_t i = (size_t)n * 10 + 256 + (n * 160 + 31) / 32 + 16;
@@ -911,7 +919,7 @@ static int chomp_make_args(const double* robot, const omgx_chomp_params* h_param
 
 // Once per (kernel, device): the attribute belongs to the device's copy of the function, and entry points may be called from
 // several host threads (one bit per device in an atomic word; a lost race only repeats the idempotent call).
-template <class K>
+template <int TAG, class K>  // TAG: one flag word per kernel instantiation (instantiations of one template share the type K)
 static int allow_big_lds(K kernel, const char* what) {
     static std::atomic<unsigned long long> done{0ull};
     int dev = 0;
@@ -939,8 +947,13 @@ extern "C" int omgx_chomp_optimize(const double* robot, const omgx_chomp_params*
         if (!active) return OMGX_ERR_INVALID;
         a.deactivate = active;
     }
-    if ((rc = allow_big_lds(k_chomp_optimize, "hipFuncSetAttribute(k_chomp_optimize)")) != OMGX_OK) return rc;
-    hipLaunchKernelGGL(k_chomp_optimize, dim3(num_scenes), dim3(CH_TPB), lds, (hipStream_t)stream, a);
+    if (fits_small(a.prm.n_waypoints)) {
+        if ((rc = allow_big_lds<0>(k_chomp_optimize<MI_SMALL>, "hipFuncSetAttribute(k_chomp_optimize)")) != OMGX_OK) return rc;
+        hipLaunchKernelGGL(k_chomp_optimize<MI_SMALL>, dim3(num_scenes), dim3(CH_TPB), lds, (hipStream_t)stream, a);
+    } else {
+        if ((rc = allow_big_lds<1>(k_chomp_optimize<MI_FULL>, "hipFuncSetAttribute(k_chomp_optimize)")) != OMGX_OK) return rc;
+        hipLaunchKernelGGL(k_chomp_optimize<MI_FULL>, dim3(num_scenes), dim3(CH_TPB), lds, (hipStream_t)stream, a);
+    }
     OMGX_CHECK_LAUNCH("k_chomp_optimize");
     return OMGX_OK;
 }
@@ -970,15 +983,27 @@ extern "C" int omgx_goal_update_optimize(const omgx_learner_params* h_learner, c
     }
     const size_t learner_lds = (size_t)(5 * OMGX_MAX_GOALS + 5 * 128) * sizeof(double);
     if (lds < learner_lds) lds = learner_lds;
-    if ((rc = allow_big_lds(k_update_optimize, "hipFuncSetAttribute(k_update_optimize)")) != OMGX_OK) return rc;
-    if ((rc = allow_big_lds(k_update_optimize_split, "hipFuncSetAttribute(k_update_optimize_split)")) != OMGX_OK) return rc;
+    const bool small = fits_small(a.prm.n_waypoints);
     if (scene_flags) {
-        hipLaunchKernelGGL(k_update_optimize_split, dim3(2 * num_scenes), dim3(CH_TPB), lds, (hipStream_t)stream, la, a,
-                           reinterpret_cast<uint32_t*>(scene_flags), (uint32_t)ticket);
+        if (small) {
+            if ((rc = allow_big_lds<2>(k_update_optimize_split<MI_SMALL>, "hipFuncSetAttribute(k_update_optimize_split)")) != OMGX_OK) return rc;
+            hipLaunchKernelGGL(k_update_optimize_split<MI_SMALL>, dim3(2 * num_scenes), dim3(CH_TPB), lds, (hipStream_t)stream, la, a,
+                               reinterpret_cast<uint32_t*>(scene_flags), (uint32_t)ticket);
+        } else {
+            if ((rc = allow_big_lds<3>(k_update_optimize_split<MI_FULL>, "hipFuncSetAttribute(k_update_optimize_split)")) != OMGX_OK) return rc;
+            hipLaunchKernelGGL(k_update_optimize_split<MI_FULL>, dim3(2 * num_scenes), dim3(CH_TPB), lds, (hipStream_t)stream, la, a,
+                               reinterpret_cast<uint32_t*>(scene_flags), (uint32_t)ticket);
+        }
         OMGX_CHECK_LAUNCH("k_update_optimize_split");
         return OMGX_OK;
     }
-    hipLaunchKernelGGL(k_update_optimize, dim3(num_scenes), dim3(CH_TPB), lds, (hipStream_t)stream, la, a);
+    if (small) {
+        if ((rc = allow_big_lds<4>(k_update_optimize<MI_SMALL>, "hipFuncSetAttribute(k_update_optimize)")) != OMGX_OK) return rc;
+        hipLaunchKernelGGL(k_update_optimize<MI_SMALL>, dim3(num_scenes), dim3(CH_TPB), lds, (hipStream_t)stream, la, a);
+    } else {
+        if ((rc = allow_big_lds<5>(k_update_optimize<MI_FULL>, "hipFuncSetAttribute(k_update_optimize)")) != OMGX_OK) return rc;
+        hipLaunchKernelGGL(k_update_optimize<MI_FULL>, dim3(num_scenes), dim3(CH_TPB), lds, (hipStream_t)stream, la, a);
+    }
     OMGX_CHECK_LAUNCH("k_update_optimize");
     return OMGX_OK;
 }
