@@ -127,7 +127,7 @@ def main():
     ap.add_argument("--objects", type=int, default=4, help="obstacles per scene besides the table (BASELINE config 5's clutter: 12 with --waypoints 50)")
     ap.add_argument("--share-grids", action="store_true", help="store identical SDF volumes once (model library)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--pipeline", type=int, default=0, help="parts of the engine's software pipeline (0: 2 when scenes x goals >= ChompEngine.PIPELINE_MIN_ITEMS, else 1)")
+    ap.add_argument("--pipeline", type=int, default=0, help="parts of the engine's software pipeline (0: ChompEngine.auto_parts)")
     ap.add_argument("--no-plan", action="store_true", help="skip timing a full 70-iteration plan (ms_per_plan)")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of three scenes after the timed region")
     ap.add_argument("--ol-alg", default="MD", help="goal-selection rule (reference default: MD, omg/config.py:67)")
@@ -169,7 +169,7 @@ def main():
     eng = ChompEngine(model, batch, copy.deepcopy(cfg), start, goals, device=dev, ol_alg=args.ol_alg)
     # the engine's software pipeline: the rank's scenes as two independent halves on two streams, so that one half's update
     # launch (and the tail / ramp-up around it) overlaps the other half's goal-set launch; same results bit for bit
-    parts = args.pipeline if args.pipeline > 0 else (2 if S * G >= ChompEngine.PIPELINE_MIN_ITEMS else 1)
+    parts = args.pipeline if args.pipeline > 0 else ChompEngine.auto_parts(S, G)
     eng.pipeline = parts
     lib = _lib.lib()
 

@@ -75,6 +75,18 @@ class ChompEngine:
     # caller owns the synchronisation (join()).
     pipeline = None
     PIPELINE_MIN_ITEMS = 768
+    # Between PIPELINE_MIN_ITEMS and this many items three parts beat two: a part is then a single partial round of workgroups,
+    # the step is bound by the latency of a part's launch chain rather than by the GPU's capacity, and a third chain in flight
+    # fills it (13 x 128: 0.136 / 0.114 / 0.107 ms per step with 1 / 2 / 3 parts, 25 x 64: 0.134 / 0.120 / 0.108; from 35 x 64
+    # on two parts win: 0.142 vs 0.147, 100 x 64: 0.290 vs 0.300).
+    PIPELINE_THREE_BELOW = 2048
+
+    @classmethod
+    def auto_parts(cls, num_scenes: int, num_goals: int) -> int:
+        items = num_scenes * num_goals
+        if items < cls.PIPELINE_MIN_ITEMS:
+            return 1
+        return min(num_scenes, 3 if items < cls.PIPELINE_THREE_BELOW else 2)
     # per-scene tensors: a part of the pipeline works on the rows [lo, hi) of each
     _PART_TENSORS = ("start", "goal_set", "reach", "cv_goals", "goal_idx", "goal_count", "eta_s", "traj", "end", "goal_rows", "goal_point",
                      "pot", "pgrad", "col", "grad", "cost_traj", "info", "goal_cost", "goal_col", "learner_state", "cost_vec", "_active",
@@ -325,7 +337,7 @@ class ChompEngine:
     def _pipeline_parts(self) -> int:
         if self.pipeline is not None:
             return max(1, min(int(self.pipeline), self.S))
-        return 2 if (self._in_plan and self.S * self.G >= self.PIPELINE_MIN_ITEMS and not self.separate_launches) else 1
+        return self.auto_parts(self.S, self.G) if (self._in_plan and not self.separate_launches) else 1
 
     def update_goal(self, defer_update: bool = False, with_layer: bool = False):
         """Learner.update_goal (online_learner.py:237-249): omgx_goalset_cost + omgx_goal_update, no host sync.
@@ -634,11 +646,11 @@ class ChompEngine:
     def _plan_all_done(self, early_stop: bool, t: int) -> bool:
         """Every scene may have left the loop (planner.py:626 breaks at once; a lone scene often terminates after two
         iterations): look at the mask at a thinning set of iterations and stop launching no-ops.  Each look is a host
-        sync that drains the launch queue (measured: ~0.4 ms each with 100 scenes in flight, where it never pays), so
-        only small batches do it."""
+        sync that drains the launch queue (measured: ~0.4 ms each with 100 scenes in flight, where it never pays; 13 scenes:
+        6.5 ms per plan with the looks, 5.9 without), so only the smallest batches do it — where all scenes often ARE done early."""
         if self._capturing:  # a graph has no host in its loop
             return False
-        if not (early_stop and self.S <= 16 and t in _ALL_DONE_CHECKS):
+        if not (early_stop and self.S <= 4 and t in _ALL_DONE_CHECKS):
             return False
         self.join()  # the mask rows of a pipelined engine's side stream
         return not self._active.cpu().numpy().any()  # a plain copy: a torch reduction would load its kernel (~10 ms) on first use
