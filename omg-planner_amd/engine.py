@@ -647,7 +647,7 @@ class ChompEngine:
         """Every scene may have left the loop (planner.py:626 breaks at once; a lone scene often terminates after two
         iterations): look at the mask at a thinning set of iterations and stop launching no-ops.  Each look is a host
         sync that drains the launch queue (measured: ~0.4 ms each with 100 scenes in flight, where it never pays; 13 scenes:
-        6.5 ms per plan with the looks, 5.9 without), so only the smallest batches do it — where all scenes often ARE done early."""
+        6.5 ms per plan with the looks, 6.3 without), so only the smallest batches do it — where all scenes often ARE done early."""
         if self._capturing:  # a graph has no host in its loop
             return False
         if not (early_stop and self.S <= 4 and t in _ALL_DONE_CHECKS):
