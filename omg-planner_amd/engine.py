@@ -260,10 +260,11 @@ class ChompEngine:
     # Software pipeline.  One iteration is a goal-set launch that fills the GPU (~275 us for 100 scenes x 64 goals) followed by
     # the update launch (2 workgroups per scene, latency-bound, ~35 us): the tail of the first, the second and the ramp-up of
     # the next goal-set launch leave most of the GPU idle for ~80 us of every ~320.  Scenes are independent, so the batch is cut
-    # into parts (contiguous scene ranges) whose iterations are enqueued alternately on different streams: while one part
-    # is in its underused phases the other part's goal-set launch has the CUs (measured: 312 -> 284 us per iteration of 100
-    # scenes, tools/ab_pipeline.py; four parts are host-bound).  A part is a ChompEngine whose per-scene tensors are row views
-    # of this engine's — same code, same results bit for bit; its dispatch schedule, work counters and flags are its own.
+    # into parts (contiguous scene ranges) whose iterations are enqueued alternately on different streams with no dependency
+    # between them.  The parts mostly run in step — their goal-set launches at once, ramp-ups and tails overlapping, then their
+    # update launches at once (DESIGN.md section 4 item 8 has the kernel trace) — which packs the same work into less time (measured:
+    # 312 -> 285-290 us per iteration of 100 scenes; tools/ab_pipeline.py).  A part is a ChompEngine whose per-scene tensors are
+    # row views of this engine's — same code, same results bit for bit; its dispatch schedule, work counters and flags are its own.
     def _make_part(self, lo: int, hi: int, stream):
         import copy
         part = object.__new__(ChompEngine)
