@@ -167,8 +167,8 @@ def main():
         S, seed0, total_scenes = args.scenes, rank * args.scenes, world * args.scenes
     cfg, model, batch, start, goals = build_workload(S, G, n, args.grid, seed0=seed0, share_grids=args.share_grids, num_objects=args.objects)
     eng = ChompEngine(model, batch, copy.deepcopy(cfg), start, goals, device=dev, ol_alg=args.ol_alg)
-    # the engine's software pipeline: the rank's scenes as two independent halves on two streams, so that one half's update
-    # launch (and the tail / ramp-up around it) overlaps the other half's goal-set launch; same results bit for bit
+    # the engine's software pipeline: the rank's scenes as two independent halves on two streams — the two half launches run
+    # concurrently and pack their ramp-ups and tails into less time than one launch after the other; same results bit for bit
     parts = args.pipeline if args.pipeline > 0 else ChompEngine.auto_parts(S, G)
     eng.pipeline = parts
     lib = _lib.lib()
