@@ -77,3 +77,13 @@ def test_sharded_costs_gathered_over_gloo_equal_single_process(tmp_path):
         got = np.load(tmp_path / f"rank{r}.npy")
         np.testing.assert_allclose(got, ref, rtol=0, atol=1e-12)  # scenes are independent: sharding changes nothing
         np.testing.assert_array_equal(np.load(tmp_path / f"eq{r}.npy"), np.repeat(np.arange(world, dtype=np.float64), 3))
+
+
+def test_pipeline_parts_by_batch_size():
+    """ChompEngine.auto_parts (host logic, no GPU): no pipeline below 768 (scene, goal) items, three parts up to 2048, two beyond —
+    never more parts than scenes."""
+    from omg_planner_amd.engine import ChompEngine
+    assert ChompEngine.auto_parts(1, 64) == 1 and ChompEngine.auto_parts(8, 64) == 1 and ChompEngine.auto_parts(11, 64) == 1
+    assert ChompEngine.auto_parts(12, 64) == 3 and ChompEngine.auto_parts(13, 128) == 3 and ChompEngine.auto_parts(25, 64) == 3
+    assert ChompEngine.auto_parts(32, 64) == 2 and ChompEngine.auto_parts(100, 64) == 2 and ChompEngine.auto_parts(100, 128) == 2
+    assert ChompEngine.auto_parts(2, 512) == 2 and ChompEngine.auto_parts(1, 1024) == 1  # bounded by the number of scenes
