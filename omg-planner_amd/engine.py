@@ -520,14 +520,15 @@ class ChompEngine:
             return False
         # the prepared calls belong to these very tensor objects (held here, so none of them can be freed and its identity reused)
         key = [getattr(self, k) for k in self._HOT_TENSORS] + [self.scenes.scene_begin]
+        baked = (float(self.cfg.time_interval), self.cfg.uncheck_finger_collision == -1)  # the scalars the calls carry
         hot = self._hot
-        if hot is None or not all(map(operator.is_, hot[0], key)):
+        if hot is None or hot[2] != baked or not all(map(operator.is_, hot[0], key)):
             calls = ops.IterationCalls(self.robot, self.P, self.scenes, self.cv_goals, self.cfg.time_interval, self.traj,
                                        (self.pot, self.pgrad, self.col), (self.goal_cost, self.goal_col), self.goal_set, self.reach,
                                        self.learner_state, self.goal_idx, self.start, self.end, self.goal_rows, self.goal_point,
                                        (self.grad, self.cost_traj, self.info), self.cost_vec, self._active, self.goal_count, self.eta_s,
                                        self._scene_flags, layer_soften_fingers=self.cfg.uncheck_finger_collision == -1)
-            hot = self._hot = (key, calls)
+            hot = self._hot = (key, calls, baked)
         calls = hot[1]
         stream = (self.stream if self.stream is not None else torch.cuda.current_stream(self.device)).cuda_stream
         self.t += 1
