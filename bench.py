@@ -196,6 +196,8 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    gather_warm = gather_costs if strong else gather_costs_equal
+    _ = gather_warm(eng.final_costs() if backend == "nccl" else eng.final_costs().cpu(), world)  # the epilogue's kernels / collective are loaded too
     barrier()
     # every 5th launch of the dominant kernel is bracketed by HIP events attached to the dispatch (all of them would cost
     # 1.7 % of the step time, a fifth 0.3 %); an odd stride, so that the samples alternate between the pipeline's parts
