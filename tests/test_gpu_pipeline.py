@@ -157,3 +157,17 @@ def test_captured_plan_replays_to_the_same_bits(dev, S, early):
         for k in ("traj", "info", "goal_idx", "learner_state", "end", "goal_rows"):
             assert np.array_equal(getattr(eng, k).cpu().numpy(), getattr(ref, k).cpu().numpy(), equal_nan=True), (rep, k)
         assert np.array_equal(eng.active.cpu().numpy(), ref.active.cpu().numpy())
+
+
+def test_whole_plan_at_bench_size_follows_the_oracle(dev):
+    """All 70 iterations of a plan (50 goal-selecting + 20 smoothing, shrinking goal-set window, weight schedule) on bench.py's 100
+    scenes with the pipelined engine, two of the scenes followed by the oracle-driven loop from the same state: the bar is
+    north_star's 1e-4 on trajectory states and costs, with the same goal choices all the way."""
+    from oracle.check import engine_vs_oracle
+    make, batch = _engines(dev, 100, 64, grid=64)
+    eng = make()
+    eng.pipeline = 2
+    eng.select_initial_goal()
+    r = engine_vs_oracle(eng, batch, [3, 96], steps=eng.cfg.optim_steps + eng.cfg.extra_smooth_steps, pin_window=False)
+    assert r["goal_idx_equal"], r
+    assert r["max_traj_err"] <= 1e-4 and r["max_cost_rel_err"] <= 1e-4, r
