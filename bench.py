@@ -39,11 +39,7 @@ import numpy as np
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-# MI355X_MICROARCH.md: 8.0 TB/s HBM3E spec; 256 CUs x 4 SIMDs at <= 2.4 GHz; a wave64 VALU instruction occupies its SIMD's
-# issue for 4 cycles whatever its type (tools/valu_rates.hip on this pool: 4.1-5.0 cycles per instruction per SIMD with 8
-# waves per SIMD; the PMC-derived VALU-busy fraction of a pure-VALU kernel reaches 0.85-1.05)
-HBM_PEAK_GBS = 8000.0
-VALU_PEAK_GINST = 256 * 4 * 2.4 / 4.0  # 614.4 G wave-instructions/s
+# the roofline's constants and its one formula live in tools/roofline.py (bound: VALU instruction issue, priced by tools/valu_peak.hip)
 
 
 def build_workload(num_scenes, num_goals, n, grid, seed0, share_grids, num_objects=4):
@@ -63,12 +59,31 @@ def build_workload(num_scenes, num_goals, n, grid, seed0, share_grids, num_objec
     return cfg, model, batch, start, goals
 
 
-def cpu_baseline(cfg, model, batch, start, goals, n, budget_s=8.0):
-    """The oracle (CPU port) timed on a bounded sample of the same step: all host threads (OpenMP over scenes / goals) and
-    one thread.  A reported baseline, not the target (see `roofline`)."""
+def cpu_quota():
+    """CPUs' worth of time the container may use (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited."""
+    try:
+        f = Path("/sys/fs/cgroup/cpu.max")
+        if f.exists():
+            q, per = f.read_text().split()[:2]
+            return None if q == "max" else float(q) / float(per)
+        q = float(Path("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read_text())
+        per = float(Path("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read_text())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
+def cpu_baseline(cfg, model, batch, start, goals, n, budget_s=10.0):
+    """The oracle (CPU port) timed on a bounded sample of the same step with 1, 16, 64 and all hardware threads (and the
+    container's CPU quota, if it has one): `value` is the BEST of them, with the thread count that gave it and its efficiency
+    against the single-thread figure.  The step's work is the 64-goal goal-set cost, an OpenMP loop over (scene, goal) items
+    with schedule(dynamic, 1) — embarrassingly parallel (tools/cpu_scaling_probe.py: 72x on 128 threads in a 2 ms burst); what
+    limits a sustained run on the GPU boxes of this pool is the cgroup quota (cpu.max = 16 CPUs), which throttles any larger
+    team.  A reported baseline, not the target (see `roofline`)."""
     from oracle import oracle as orc
     from omg_planner_amd import scenes as sc
     cores = os.cpu_count() or 1
+    quota = cpu_quota()
     P = model.points_per_link
     blob = model.blob()
 
@@ -97,17 +112,30 @@ def cpu_baseline(cfg, model, batch, start, goals, n, budget_s=8.0):
         per_scene = one_step(k) / k  # pilot
         k2 = int(max(1, min(len(start), budget / max(per_scene, 1e-6))))
         total, reps = 0.0, 0
-        while reps < 1 or (total < 0.6 * budget and reps < 5):
+        while reps < 1 or (total < 0.8 * budget and reps < 8):  # sustained: a burst would not see the quota's throttling
             total += one_step(k2)
             reps += 1
         return k2 / (total / reps), k2, reps
 
-    v_all, k_all, r_all = timed(cores, budget_s)
-    v_one, k_one, r_one = timed(1, budget_s)
+    teams = sorted({1, min(16, cores), min(64, cores), cores} | ({max(1, min(cores, int(quota)))} if quota else set()))
+    share = budget_s / (len(teams) + 1)
+    v_one, k_one, r_one = timed(1, 2.0 * share)
+    tried = {1: v_one}
+    best = (v_one, 1, k_one, r_one)
+    for th in teams[1:]:
+        v, k, r = timed(th, share)
+        tried[th] = v
+        if v > best[0]:
+            best = (v, th, k, r)
     orc.set_threads(cores)
-    return {"value": v_all, "unit": "iterations/s", "cores": cores, "kind": "port",
-            "sample": f"{k_all} scenes x 1 planner iteration (64-goal goal-set cost + optimize step), mean of {r_all} run(s), "
-                      f"oracle/omg_oracle.c with OpenMP on {cores} threads",
+    v_best, th_best, k_best, r_best = best
+    return {"value": v_best, "unit": "iterations/s", "cores": th_best, "kind": "port",
+            "sample": f"{k_best} scenes x 1 planner iteration (64-goal goal-set cost + optimize step), mean of {r_best} run(s), "
+                      f"oracle/omg_oracle.c with OpenMP on {th_best} threads (the best of the teams tried)",
+            "threads_tried": {str(k): v for k, v in tried.items()},
+            "efficiency_vs_single_thread": v_best / (v_one * th_best),
+            "host": {"hardware_threads": cores, "cgroup_cpu_quota": quota,
+                     "note": "the container's cgroup quota caps sustained CPU time; teams larger than the quota are throttled" if quota else "no cgroup quota"},
             "single_thread": {"value": v_one, "unit": "iterations/s", "cores": 1,
                               "sample": f"{k_one} scene(s) x 1 planner iteration, mean of {r_one} run(s), same code on 1 thread"},
             "reference_python": "the reference's own numpy path (omg/cost.py, omg/optimizer.py, omg/online_learner.py) cannot travel to the GPU "
@@ -147,7 +175,10 @@ def main():
     local_dev = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
-    if world > 1:
+    # Launched by torch.distributed.run (RANK in the environment) the process group is created even for ONE rank, so that a
+    # one-GPU box runs the same RCCL initialisation and the same all-gather on device tensors as a node (tests/test_gpu_round3.py)
+    dist_on = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
+    if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -189,15 +220,18 @@ def main():
         eng.iterate(0)
 
     def barrier():
-        if world > 1:
+        if dist_on:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
 
+    def gather(c):  # the job's one collective: sizes follow from shard_range on every rank, nothing else is exchanged
+        c = c if backend == "nccl" else c.cpu()  # RCCL all-gather over xGMI on device tensors; host tensors under the gloo test backend
+        return gather_costs(c, world, total_scenes) if strong else gather_costs_equal(c, world)
+
     for _ in range(args.warmup):
         step()
-    gather_warm = gather_costs if strong else gather_costs_equal
-    _ = gather_warm(eng.final_costs() if backend == "nccl" else eng.final_costs().cpu(), world)  # the epilogue's kernels / collective are loaded too
+    _ = gather(eng.final_costs())  # the epilogue's kernels / collective are loaded too
     barrier()
     # every 5th launch of the dominant kernel is bracketed by HIP events attached to the dispatch (all of them would cost
     # 1.7 % of the step time, a fifth 0.3 %); an odd stride, so that the samples alternate between the pipeline's parts
@@ -207,9 +241,7 @@ def main():
     for _ in range(args.steps):
         step()
     costs = eng.final_costs()  # enqueued behind the last step: no host sync before the collective
-    # the job's one collective (RCCL all-gather over xGMI; host tensors under the gloo test backend)
-    gather = gather_costs if strong else gather_costs_equal
-    allc = gather(costs if backend == "nccl" else costs.cpu(), world)
+    allc = gather(costs)
     assert allc.numel() == total_scenes
     barrier()
     elapsed = time.perf_counter() - t0
@@ -219,12 +251,38 @@ def main():
     kinds = (C.c_int32 * 4096)()
     nrec = lib.omgx_timing_collect(buf, kinds, 4096)
     lib.omgx_timing_enable(0)
-    if world > 1:
+    elapsed_local = elapsed
+    if dist_on:
         import torch.distributed as dist
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    # every rank's own roofline block: its launch durations (HIP events), its scenes, its wall time — gathered so that an N-GPU
+    # line carries the achieved rates per GPU (north_star: "achieved ... vs roofline reported at 1/2/4/8")
+    durs = np.array([buf[i] for i in range(nrec)], dtype=np.float64)
+    kind = np.array([kinds[i] for i in range(nrec)])
+    goal_ms = durs[kind == 0]  # the goal-set launch (goal-set batch + trajectory layer) = the dominant kernel
+    avg_ms = float(goal_ms.mean()) if len(goal_ms) else elapsed_local / args.steps * 1e3  # no goal-set launch recorded (rules without a goal-set batch)
+    P = model.points_per_link
+    O_active = args.objects + 1
+    # N (32 + 128 O_active) algorithmic bytes for the N points of one launch — the goal-set batch
+    # plus the S x n x 150 points of the trajectory layer.  NOT a measure of what the kernel moves: 85 % of the (point,
+    # object) pairs retire in registers before any load and the rest hit L2.
+    pts_per_launch = (S * G * n * 10 * P + S * n * 10 * P) / parts  # a launch handles one part of the pipeline
+    alg_bytes = pts_per_launch * (32 + 128 * O_active)
+    from tools.roofline import roofline_block
+    roof = roofline_block(ROOT / "profiles" / "roofline_inputs.json", avg_ms, int(len(goal_ms)), stride, alg_bytes,
+                          {"scenes": S, "goals": G, "waypoints": n, "points_per_link": P, "grid": args.grid, "pipeline": parts},
+                          launches_per_step=parts, ms_per_step=elapsed_local / args.steps * 1e3)
+    per_rank = None
+    if dist_on:
+        import torch.distributed as dist
+        mine = {"rank": rank, "scenes": S, "ms_per_step": elapsed_local / args.steps * 1e3, "avg_launch_ms": avg_ms, "launches": int(len(goal_ms)),
+                "achieved": roof["achieved"], "frac": roof["frac"], "hbm_GBs": None if roof["hbm_real"] is None else roof["hbm_real"]["GBs"],
+                "algorithmic_equiv_GBs": roof["algorithmic_equiv_GBs"]}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     parity = None
     if not args.no_parity and rank == 0:
         # the timed workload against the oracle: three scenes of this rank, the first three iterations of the plan the timed
@@ -281,21 +339,11 @@ def main():
         ms_graph_single = graph_ms(ChompEngine(model, one, copy.deepcopy(cfg), start[:1], goals[:1], device=dev, ol_alg=args.ol_alg))
 
     if rank == 0:
-        durs = np.array([buf[i] for i in range(nrec)], dtype=np.float64)
-        kind = np.array([kinds[i] for i in range(nrec)])
-        goal_ms = durs[kind == 0]  # the goal-set launch (goal-set batch + trajectory layer) = the dominant kernel
-        avg_ms = float(goal_ms.mean()) if len(goal_ms) else elapsed / args.steps * 1e3  # no goal-set launch recorded (rules without a goal-set batch)
-        P = model.points_per_link
-        O_active = args.objects + 1
-        # N (32 + 128 O_active) algorithmic bytes for the N points of one launch — the goal-set batch
-        # plus the S x n x 150 points of the trajectory layer.  NOT a measure of what the kernel moves: 85 % of the (point,
-        # object) pairs retire in registers before any load and the rest hit L2.
-        pts_per_launch = (S * G * n * 10 * P + S * n * 10 * P) / parts  # a launch handles one part of the pipeline
-        alg_bytes = pts_per_launch * (32 + 128 * O_active)
-        from tools.roofline import roofline_block
-        roof = roofline_block(ROOT / "profiles" / "roofline_inputs.json", avg_ms, int(len(goal_ms)), stride, alg_bytes,
-                              {"scenes": S, "goals": G, "waypoints": n, "points_per_link": P, "grid": args.grid, "pipeline": parts},
-                              launches_per_step=parts, ms_per_step=elapsed / args.steps * 1e3)
+        if per_rank is not None:
+            roof["per_rank"] = per_rank
+            roof["all_ranks"] = {"achieved": None if any(r["achieved"] is None for r in per_rank) else sum(r["achieved"] for r in per_rank),
+                                 "hbm_GBs": None if any(r["hbm_GBs"] is None for r in per_rank) else sum(r["hbm_GBs"] for r in per_rank),
+                                 "note": "sums over the ranks' own figures (each GPU against its own peak: per_rank[i].frac)"}
         out = {
             "metric": "CHOMP iterations/sec (batched scenes) + ms/plan, Panda 7-DoF 30-wp",  # BASELINE.json's metric: `value` is the first half, ms_per_plan* the second
             "value": total_scenes * args.steps / elapsed,
@@ -331,7 +379,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, model, batch, start, goals, n)
         print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         import torch.distributed as dist
         dist.destroy_process_group()
     if parity is not None and not parity["ok"]:

@@ -313,6 +313,7 @@ int omgx_chomp_optimize(const double* robot, const omgx_chomp_params* h_params,
  * the scene's own goals, so the scene computes exactly what it would compute alone.
  * ------------------------------------------------------------------------------------------- */
 #define OMGX_MAX_GOALS 256
+#define OMGX_SCHEDULE_MAX_SCENES 1792  /* omgx_goalset_schedule: per-scene arrays of 36 bytes in < 64 KB of LDS */
 #define OMGX_ALG_FTL 0
 #define OMGX_ALG_FTC 1
 #define OMGX_ALG_EXP 2
@@ -393,7 +394,8 @@ int omgx_point_cloud_sdf(const double* points, int32_t num_points, const double*
  * first), a scene's goals by decreasing w (ties: lower goal first); an item with c = the wc of all items before it in that
  * list belongs to piece x = min(7, 8 (2 c + wc) / (2 Tc)), Tc = sum of wc; with p its position in the list and first(x) the
  * lowest position of piece x:  schedule[8 (p - first(x)) + x] = scene * G + goal.
- * One workgroup; S * G <= 65536 and S <= 4096, else OMGX_ERR_UNSUPPORTED.
+ * One workgroup; S * G <= 65536 and S <= OMGX_SCHEDULE_MAX_SCENES (1792: its per-scene arrays stay below 64 KB of LDS), else
+ * OMGX_ERR_UNSUPPORTED.
  * ------------------------------------------------------------------------------------------- */
 int32_t omgx_goalset_schedule_len(int32_t num_scenes, int32_t num_goals, int32_t slack);
 int omgx_goalset_schedule(const uint32_t* work, const int32_t* active, const int32_t* goal_count, int32_t num_scenes,

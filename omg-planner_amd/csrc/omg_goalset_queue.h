@@ -231,6 +231,10 @@ __global__ __launch_bounds__(256, GQ_WG_PER_CU) void k_goalset_queue(ChunkArgs a
 
     // CONSUME: finish the batch in flight (interpolation, hinge, weighted sums).  f_w is 0 for lanes without an entry.
     auto consume = [&]() {
+#ifdef OMGX_GS_NO_EXACT  // measurement build (tools/collect_profiles.sh): the exact path compiled out, what remains is the triage
+        inflight = false;
+        return;
+#endif
         const float tv = trilerp(f_r00.a, f_r00.b, f_r01.a, f_r01.b, f_r10.a, f_r10.b, f_r11.a, f_r11.b, f_fx, f_fy, f_fz);
         const uint4 h = *reinterpret_cast<const uint4*>(tbl + (f_meta & 0xffffu) * 16 + 12);
         const float eps = __uint_as_float(h.x), clr = __uint_as_float(h.y), pad = __uint_as_float(h.z), i2eps = __uint_as_float(h.w);
@@ -244,6 +248,7 @@ __global__ __launch_bounds__(256, GQ_WG_PER_CU) void k_goalset_queue(ChunkArgs a
         pot = soft ? pot * 0.1f : pot;                                          // cost.py:350-353
         tsum += pot != 0.0f ? pot * f_w : 0.0f;                                 // cost.py:260-275
         tcol += (counts && value < clr) ? 1.0f : 0.0f;                          // .cu:150-151
+        GS_COUNT_N(11, __popcll(__ballot(f_w != 0.0f ? (pot != 0.0f || value < clr) : false)));  // entries that contribute anything
         inflight = false;
     };
 
@@ -251,6 +256,11 @@ __global__ __launch_bounds__(256, GQ_WG_PER_CU) void k_goalset_queue(ChunkArgs a
     // whatever their slot holds; their weight is 0, in_c false (address = the grid's first voxel) and they count nothing.
     auto issue = [&](int count) {
         GS_COUNT(8);
+#ifdef OMGX_GS_NO_EXACT
+        tsum += (float)count * 1.0e-30f;  // keeps the queue bookkeeping alive
+        inflight = true;
+        return;
+#endif
         const bool valid = lane < count;
         const float4 qe = *reinterpret_cast<const float4*>(stage + 4 * lane);
         const float q_tx = qe.x, q_ty = qe.y, q_tz = qe.z, q_w = qe.w;

@@ -484,7 +484,7 @@ extern "C" int omgx_debug_gs_wg(unsigned long long* h_out, int n_wg) {
 #ifdef OMGX_GS_COUNT
 __device__ unsigned long long g_gs_count[16];
 #define GS_COUNT(k) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_gs_count[k], 1ull); } while (0)
-#define GS_COUNT_N(k, n) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_gs_count[k], (unsigned long long)(n)); } while (0)
+#define GS_COUNT_N(k, n) do { const unsigned long long n_ = (unsigned long long)(n); if ((threadIdx.x & 63) == 0) atomicAdd(&g_gs_count[k], n_); } while (0)  /* n may hold a ballot: evaluated by all lanes */
 extern "C" int omgx_debug_gs_counts(unsigned long long* h_out, int reset) {
     if (hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_gs_count), sizeof(unsigned long long) * 16) != hipSuccess) return -2;
     if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_gs_count), z, sizeof(z)) != hipSuccess) return -2; }
@@ -999,7 +999,8 @@ extern "C" int32_t omgx_goalset_schedule_len(int32_t num_scenes, int32_t num_goa
 extern "C" int omgx_goalset_schedule(const uint32_t* work, const int32_t* active, const int32_t* goal_count, int32_t num_scenes,
                                      int32_t num_goals, int32_t slack, int32_t* schedule, void* stream) {
     if (num_scenes <= 0 || num_goals <= 0 || slack < 1 || !schedule) return OMGX_ERR_INVALID;
-    if ((int64_t)num_scenes * num_goals > 65536 || num_scenes > 4096) return OMGX_ERR_UNSUPPORTED;
+    // per-scene arrays in dynamic LDS: 36 bytes per scene; 1792 scenes = 63 KB, below the 64 KB a launch gets without opting in
+    if ((int64_t)num_scenes * num_goals > 65536 || num_scenes > OMGX_SCHEDULE_MAX_SCENES) return OMGX_ERR_UNSUPPORTED;
     const int items = num_scenes * num_goals;
     const int staged = (items <= SCH_LDS_ITEMS && num_scenes <= 128) ? 1 : 0;  // keeps the launch below 64 KB of dynamic LDS
     SchedArgs a{work, active, goal_count, num_scenes, num_goals, slack, omgx_goalset_schedule_len(num_scenes, num_goals, slack) / 8, staged, schedule};

@@ -173,7 +173,11 @@ class ChompEngine:
         self._gs_launches = 0
         self._measured = False
         self._sched_buf, self._sched_flip, self._sched_age = None, 0, None
-        self._ticket = 0
+        self._uniform_cache = None
+        # ONE ticket source for this engine and every pipeline part made from it (the parts' flags are slices of _scene_flags):
+        # a ticket must differ from every value still stored in the flags it is compared with (include/omg_hip.h), whoever
+        # launched last — the whole engine, a part, parts of an earlier split.  A one-element list, shared by reference.
+        self._ticket_src = [0]
         self._num_cus = torch.cuda.get_device_properties(dev).multi_processor_count
         self._parts, self._forked, self._in_plan = None, False, False
         self._hot = None
@@ -191,6 +195,13 @@ class ChompEngine:
         self._active = value
         self._masked = True
         self._refresh_parts()
+
+    def _next_ticket(self) -> int:
+        """The next rendezvous ticket of omgx_goal_update_optimize: monotonically increasing over the engine AND its pipeline
+        parts, never 0 (the flags start at 0), wrapping inside int32 long before any flag could still hold the value."""
+        src = self._ticket_src
+        src[0] = src[0] + 1 if src[0] < 0x7ffffff0 else 1
+        return src[0]
 
     def _mask(self):
         """The mask for a launch — None while no scene can be inactive (the goal-set kernel then skips its slot look-up)."""
@@ -280,7 +291,7 @@ class ChompEngine:
         part.work = torch.zeros(part.S * self.G, dtype=torch.int32, device=self.device)
         part.schedule, part._gs_launches, part._measured = None, 0, False
         part._sched_buf, part._sched_flip, part._sched_age = None, 0, None
-        part._ticket = 0
+        part._uniform_cache = None
         if self.goal_count is not None:
             part._goal_counts_host = self._goal_counts_host[lo:hi]
         self._bind_part(part)
@@ -336,8 +347,16 @@ class ChompEngine:
             setattr(self.cfg, f, getattr(p0.cfg, f))
 
     def _pipeline_parts(self) -> int:
+        # The pipeline forks from and joins into torch's CURRENT stream.  An engine bound to a stream of its own keeps every
+        # launch on that stream — switching between the two modes would leave the streams unordered — so it never pipelines
+        # by itself and refuses an explicit request.
         if self.pipeline is not None:
-            return max(1, min(int(self.pipeline), self.S))
+            k = max(1, min(int(self.pipeline), self.S))
+            if k > 1 and self.stream is not None:
+                raise ValueError("ChompEngine(stream=...) cannot be pipelined: the pipeline's parts run on the current stream and the shared side streams")
+            return k
+        if self.stream is not None:
+            return 1
         return self.auto_parts(self.S, self.G) if (self._in_plan and not self.separate_launches) else 1
 
     def update_goal(self, defer_update: bool = False, with_layer: bool = False):
@@ -419,8 +438,10 @@ class ChompEngine:
         load).  `uniform`: all items weigh the same.  `active` [S] int32: scenes with 0 are left out; ragged goal sets leave
         out their padding.  An XCD has room for `schedule_slack` (2) times its share of the items; the weights are clamped to a
         band [L, schedule_slack * L] around their mean, so no piece of the list can need more."""
-        if self.S * self.G > 65536 or self.S > 4096:  # beyond the scheduler kernel's single workgroup: even split by count
-            return self._uniform_schedule()
+        if self.S * self.G > 65536 or self.S > _lib.SCHEDULE_MAX_SCENES:  # beyond the scheduler kernel's single workgroup: even split by count
+            if self._uniform_cache is None:  # built once: the upload is a host-to-device copy, which a graph capture could not record
+                self._uniform_cache = self._uniform_schedule()
+            return self._uniform_cache
         if self._sched_buf is None:
             self._sched_buf = [None, None]
         # two buffers in turn: a launch that still reads the previous schedule (another stream's view of it) is never overwritten
@@ -441,12 +462,12 @@ class ChompEngine:
             # learner and step in different workgroups of the launch: pays while both sets are resident at once (one
             # 92 KB-LDS workgroup per CU); beyond that the single-workgroup kernel is a little faster (measured at 200 / 400 scenes)
             split = 2 * self.S <= self._num_cus if self.split_update is None else bool(self.split_update)
-            self._ticket += 1
+            ticket = self._next_ticket()
             ops.goal_update_optimize(learner_prm, self.goal_set, self.reach, self.goal_cost, self.learner_state, self.goal_idx,
                                      self.robot, self._params(do_update), self.traj, self.start, self.end, self.goal_rows,
                                      self.goal_point, self.pot, self.pgrad, self.col, active=self.active,
                                      out=(self.grad, self.cost_traj, self.info), cost_vector=self.cost_vec,
-                                     scene_flags=self._scene_flags if split else None, ticket=self._ticket,
+                                     scene_flags=self._scene_flags if split else None, ticket=ticket,
                                      stop_on_terminate=stop_on_terminate, goal_count=self.goal_count, eta=self.eta_s)
             return self.info
         ops.chomp_optimize(self.robot, self._params(do_update), self.traj, self.start, self.end, self.goal_rows,
@@ -536,9 +557,8 @@ class ChompEngine:
         self._gs_launches += 1
         calls.goalset_layer(prm.start_idx, self._masked, self.schedule if use_sched else None, None, stream)
         self._schedule()
-        self._ticket += 1
         split = 2 * self.S <= self._num_cus if self.split_update is None else bool(self.split_update)
-        calls.update(prm, self._params(True), split, self._ticket, stop, stream)
+        calls.update(prm, self._params(True), split, self._next_ticket(), stop, stream)
         return True
 
     def iterate_separate(self, t: int, early_stop: bool = False):
@@ -566,6 +586,7 @@ class ChompEngine:
         self.join()
         snap = {k: getattr(self, k).clone() for k in self._STATE}
         snap["_host"] = (self.step_count, self.t, self.cfg.obstacle_weight, self.cfg.smoothness_weight, self.cfg.grasp_weight, self.cfg.step_size)
+        snap["_masked"] = self._masked
         return snap
 
     def restore(self, snap: dict):
@@ -579,6 +600,9 @@ class ChompEngine:
             else:
                 cur.copy_(snap[k])
         (self.step_count, self.t, self.cfg.obstacle_weight, self.cfg.smoothness_weight, self.cfg.grasp_weight, self.cfg.step_size) = snap["_host"]
+        # the mask goes back with the flags it guards: a snapshot taken before any early stop has every scene active, and the
+        # launches after the restore run unmasked again (dispatch schedule in use, no mask look-up in the goal-set kernel)
+        self._masked = bool(snap.get("_masked", self._masked))
 
     def select_initial_goal(self):
         """Learner.__init__ (online_learner.py:96-102): before planning, pick the cheapest goal by one cost_vector
@@ -621,9 +645,12 @@ class ChompEngine:
         """Planner.plan (planner.py:600-653): up to optim_steps + extra_smooth_steps iterations, then one
         info-only evaluation; returns the final info [S,16] (device).  cfg.timeout (3 s; -1: none) is the reference's
         wall-clock budget (planner.py:629): once it is spent after an iteration t > 0, the loop ends for every scene.  The
-        engine's loop is asynchronous, so the clock the host reads is its enqueue time (a lower bound of the device's progress
-        while the launch queue is not full); a 70-iteration plan of 100 scenes takes 16 ms, the budget only matters for very
-        large batches."""
+        engine's loop is asynchronous, so with a budget set the host keeps at most PLAN_LOOKAHEAD iterations ahead of the
+        device (an event every fourth iteration; the host waits for the one PLAN_LOOKAHEAD iterations back — the launch queue stays full, nothing
+        is lost) and the clock it reads is the device's progress to within those few iterations.  A captured plan
+        (capture_plan) has no host in its loop and no budget.
+        A plan started with early_stop=False on an engine whose mask is already in use (an earlier early-stop plan that was
+        not restore()d, or `active` assigned) keeps skipping the scenes that are switched off."""
         import time
         cfg = self.cfg
         if initial_goal and cfg.goal_set_proj:
@@ -631,19 +658,41 @@ class ChompEngine:
         self.iterations_run = 0
         self.timed_out = False
         t_start = time.time()
+        budget = cfg.timeout != -1 and not self._capturing
+        marks = []
         self._in_plan = True  # plan() joins the pipeline's streams itself (the final optimize below), so it may use them
         try:
             for t in range(cfg.optim_steps + cfg.extra_smooth_steps):
                 self.iterate(t, early_stop)
                 self.iterations_run = t + 1
-                if cfg.timeout != -1 and t > 0 and not self._capturing and time.time() - t_start > cfg.timeout:
-                    self.timed_out = True
-                    break
+                if budget:
+                    if t % 4 == 3:  # a mark every 4 iterations, PLAN_LOOKAHEAD / 4 of them outstanding
+                        marks.append(self._record_progress())
+                        if len(marks) > self.PLAN_LOOKAHEAD // 4:
+                            for ev in marks.pop(0):
+                                ev.synchronize()
+                    if t > 0 and time.time() - t_start > cfg.timeout:
+                        self.timed_out = True
+                        break
                 if self._plan_all_done(early_stop, t):
                     break
         finally:
             self._in_plan = False
         return self.optimize(False)
+
+    PLAN_LOOKAHEAD = 8  # iterations the host may be ahead of the device while plan() watches cfg.timeout
+
+    def _record_progress(self) -> list:
+        """Events behind everything enqueued so far: one on this engine's stream and one on every side stream the pipeline is
+        using (no cross-stream waits: the parts stay independent)."""
+        main = self.stream if self.stream is not None else torch.cuda.current_stream(self.device)
+        streams = [main] + ([part.stream for part in self._parts[1:]] if self._forked else [])
+        evs = []
+        for st in streams:
+            ev = torch.cuda.Event()
+            ev.record(st)
+            evs.append(ev)
+        return evs
 
     def _plan_all_done(self, early_stop: bool, t: int) -> bool:
         """Every scene may have left the loop (planner.py:626 breaks at once; a lone scene often terminates after two
@@ -706,9 +755,18 @@ class PlanGraph:
         return self.info
 
 
+def _collective_on(world: int) -> bool:
+    """A process group exists (launched by torch.distributed.run): the collective runs even for a single rank, so that a
+    one-GPU box exercises the same RCCL path as a node."""
+    if world > 1:
+        return True
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized()
+
+
 def gather_costs_equal(local_costs: torch.Tensor, world: int) -> torch.Tensor:
     """All-gather for equal-sized shards (bench.py's weak-scaling layout): one collective, no host sync."""
-    if world == 1:
+    if not _collective_on(world):
         return local_costs
     import torch.distributed as dist
     out = torch.empty(world * local_costs.numel(), dtype=local_costs.dtype, device=local_costs.device)
@@ -716,18 +774,25 @@ def gather_costs_equal(local_costs: torch.Tensor, world: int) -> torch.Tensor:
     return out
 
 
-def gather_costs(local_costs: torch.Tensor, world: int) -> torch.Tensor:
-    """The one collective of the job: all-gather of per-scene final costs over RCCL (backend "nccl")
-    or gloo.  Ragged shards are padded to the largest shard with NaN."""
-    if world == 1:
+def gather_costs(local_costs: torch.Tensor, world: int, total: int | None = None) -> torch.Tensor:
+    """The one collective of the job: all-gather of per-scene final costs over RCCL (backend "nccl") or gloo.
+    `total`: number of scenes in all — rank r then holds the block shard_range(total, r, world), whose size every rank knows:
+    the (at most one scene) shorter shards are padded to the longest with NaN, ONE all_gather_into_tensor moves them and the
+    padding is cut away by index, without any host synchronisation.  Without `total` the shards are taken to be equal."""
+    if not _collective_on(world):
         return local_costs
     import torch.distributed as dist
-    n = torch.tensor([local_costs.numel()], device=local_costs.device)
-    sizes = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(sizes, n)
-    mx = int(max(int(s.item()) for s in sizes))
+    if total is None:
+        return gather_costs_equal(local_costs, world)
+    sizes = [len(shard_range(total, r, world)) for r in range(world)]
+    mx = max(sizes)
+    if local_costs.numel() != sizes[dist.get_rank()]:
+        raise ValueError(f"rank {dist.get_rank()} holds {local_costs.numel()} costs, shard_range says {sizes[dist.get_rank()]}")
     pad = torch.full((mx,), float("nan"), dtype=local_costs.dtype, device=local_costs.device)
     pad[: local_costs.numel()] = local_costs
-    out = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(out, pad)
-    return torch.cat([o[: int(s.item())] for o, s in zip(out, sizes)])
+    out = torch.empty(world * mx, dtype=local_costs.dtype, device=local_costs.device)
+    dist.all_gather_into_tensor(out, pad)
+    if all(n == mx for n in sizes):
+        return out
+    keep = torch.as_tensor([r * mx + k for r in range(world) for k in range(sizes[r])], device=out.device)  # built from host-known sizes
+    return out.index_select(0, keep)

@@ -59,7 +59,7 @@ def _worker(rank, world, port, total, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     mine = list(shard_range(total, rank, world))
     local = torch.from_numpy(_scene_costs(mine))
-    allc = gather_costs(local, world)
+    allc = gather_costs(local, world, total)  # sizes from shard_range: one collective, no size exchange
     np.save(os.path.join(out_dir, f"rank{rank}.npy"), allc.numpy())
     eq = gather_costs_equal(torch.full((3,), float(rank), dtype=torch.float64), world)  # bench.py's equal-shard path
     np.save(os.path.join(out_dir, f"eq{rank}.npy"), eq.numpy())
@@ -77,6 +77,32 @@ def test_sharded_costs_gathered_over_gloo_equal_single_process(tmp_path):
         got = np.load(tmp_path / f"rank{r}.npy")
         np.testing.assert_allclose(got, ref, rtol=0, atol=1e-12)  # scenes are independent: sharding changes nothing
         np.testing.assert_array_equal(np.load(tmp_path / f"eq{r}.npy"), np.repeat(np.arange(world, dtype=np.float64), 3))
+
+
+def test_single_rank_process_group_runs_the_collective(tmp_path):
+    """Launched by torch.distributed.run with ONE rank (the GPU box has one GPU), bench.py still goes through the process group:
+    gather_costs / gather_costs_equal run their collective for world == 1 whenever a group exists."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(1, port, 3, str(tmp_path)), nprocs=1, join=True)
+    np.testing.assert_allclose(np.load(tmp_path / "rank0.npy"), _scene_costs([0, 1, 2]), rtol=0, atol=1e-12)
+    np.testing.assert_array_equal(np.load(tmp_path / "eq0.npy"), np.zeros(3))
+
+
+def test_gather_costs_rejects_a_shard_of_the_wrong_size():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        with pytest.raises(ValueError):
+            gather_costs(torch.zeros(4, dtype=torch.float64), 1, total=5)
+        out = gather_costs(torch.arange(5, dtype=torch.float64), 1, total=5)
+        assert out.tolist() == [0.0, 1.0, 2.0, 3.0, 4.0]
+    finally:
+        dist.destroy_process_group()
 
 
 def test_pipeline_parts_by_batch_size():

@@ -6,8 +6,11 @@
 #   <tag>_kernel_stats.csv      rocprofv3 --kernel-trace --stats of the same command
 #   <tag>_pmc_<SET>.csv         per-kernel means of every counter set (separate --pmc passes, kernel-trace only; MEM_* = TA / TCP / TD)
 #   <tag>_workload.json         the workload the counts belong to
-#   <tag>_valu_rates.txt        tools/valu_rates.hip: cycles per wave64 VALU instruction per SIMD (calibration of the bound)
-#   <tag>_valu_rates_pmc.csv    the same kernels under SQ_ACTIVE_INST_VALU / GRBM_GUI_ACTIVE (what "VALU busy" can reach)
+#   <tag>_pmc_MIX{1,2}.csv      the kernel's dynamic VALU mix (SQ_INSTS_VALU_* classes: what tools/roofline.py prices)
+#   <tag>_pmc_NOEXACT.csv       SQ_INSTS_VALU of the build without the exact path (libomg_hip_noexact.so) -> <tag>_useful.json
+#   <tag>_block_counts.json     tools/gs_block_counts.py --json (libomg_hip_cnt.so): block counts per goal workgroup, pair statistics
+#   <tag>_valu_peak.{txt,csv}   tools/valu_peak.hip: cycles per wave64 VALU instruction per SIMD (calibration of the bound), with
+#   <tag>_valu_peak_pmc.csv     the same kernels under GRBM_GUI_ACTIVE / SQ_INSTS_VALU (set VALU_PEAK=1: the table only changes with the hardware)
 TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
@@ -38,23 +41,20 @@ python3 - > $O/${TAG}_workload.json <<'PY'
 import json
 print(json.dumps({"scenes": 100, "goals": 64, "waypoints": 30, "points_per_link": 15, "grid": 64, "pipeline": 2}))
 PY
-if [ -x $R/tools/_build/valu_rates ]; then
-  $R/tools/_build/valu_rates > $O/${TAG}_valu_rates.txt 2>&1
-  rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $T/vr -o vr -- $R/tools/_build/valu_rates pmc > $O/${TAG}_valu_rates_pmc.log 2>&1
-  python3 - $T/vr $O/${TAG}_valu_rates_pmc.csv <<'PY'
-import csv, glob, sys, collections
-d, out = sys.argv[1], sys.argv[2]
-rows = collections.OrderedDict()
-for f in glob.glob(d + "/**/*counter_collection*.csv", recursive=True):
-    for r in csv.DictReader(open(f)):
-        rows.setdefault((r["Dispatch_Id"], r["Kernel_Name"][:40], r["Grid_Size"]), {})[r["Counter_Name"]] = float(r["Counter_Value"])
-w = csv.writer(open(out, "w"))
-names = ["SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY", "GRBM_GUI_ACTIVE"]
-w.writerow(["dispatch", "kernel", "grid"] + names + ["valu_busy = 4*ACTIVE_INST_VALU/(1024*GUI_ACTIVE/8)"])
-for k, v in rows.items():
-    busy = 4.0 * v.get("SQ_ACTIVE_INST_VALU", 0) / (1024.0 * v["GRBM_GUI_ACTIVE"] / 8.0) if v.get("GRBM_GUI_ACTIVE") else ""
-    w.writerow(list(k) + [v.get(n, "") for n in names] + [busy])
-PY
+run_pmc MIX1 "SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64"
+run_pmc MIX2 "SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64"
+if [ -f $R/omg-planner_amd/csrc/libomg_hip_noexact.so ]; then
+  rocprofv3 --pmc SQ_INSTS_VALU --output-format csv -d $T/pmc_NOEXACT -o $TAG -- python3 $R/tools/bench_variant.py libomg_hip_noexact.so --steps 5 --warmup 1 --no-cpu-baseline --no-plan --no-parity > $O/${TAG}_pmc_NOEXACT.log 2>&1
+  python3 $R/tools/pmc_summary.py $T/pmc_NOEXACT $O/${TAG}_pmc_NOEXACT.csv
+fi
+if [ -f $R/omg-planner_amd/csrc/libomg_hip_cnt.so ]; then
+  (cd $R && python3 tools/gs_block_counts.py 100 --json $O/${TAG}_block_counts.json > $O/${TAG}_block_counts.txt 2>&1)
+fi
+python3 $R/tools/make_useful.py $TAG $O > /dev/null 2>&1
+if [ -n "$VALU_PEAK" ] && [ -x $R/tools/_build/valu_peak ]; then
+  $R/tools/_build/valu_peak $O/${TAG}_valu_peak.csv > $O/${TAG}_valu_peak.txt 2>&1
+  rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $T/vp -o vp -- $R/tools/_build/valu_peak pmc > $O/${TAG}_valu_peak_pmc.txt 2>&1
+  find $T/vp -name "*counter_collection*.csv" -exec cp {} $O/${TAG}_valu_peak_pmc_raw.csv \;
 fi
 head -4 $O/${TAG}_kernel_stats.csv | cut -c1-160
 grep goalset $O/${TAG}_pmc_*.csv | cut -c1-200
