@@ -67,7 +67,7 @@ extern "C" {
 #define OMGX_ROBOT_POINTS 528
 
 /* ---------------------------------------------------------------------------------------------
- * Scene object table.  One 176-byte record per obstacle/target object; replaces the five per-call
+ * Scene object table.  One 184-byte record per obstacle/target object; replaces the five per-call
  * host->device copies of Cost.compute_obstacle_cost_layer (omg/cost.py:303-335) and the
  * pad-to-max `sdf_torch[O,X,Y,Z]` + `sdf_limits[O,10]` contract of Env.combine_sdfs
  * (omg/core.py:366-411).  `grid_offset` lets grids live ragged in one float pool; the reference's
@@ -85,13 +85,15 @@ typedef struct omgx_object {
     int32_t disabled;    /* 1 = skip (name == "floor" or in cfg.disable_collision_set)               */
     int64_t grid_offset; /* element offset of this object's grid inside the sdf pool                 */
     double inv_extent[3]; /* derived: 1.0 / (double)((float)hi[a] - (float)lo[a])                     */
-    float far_lo[3];     /* derived: any box in offset coordinates t = R p + t - lo outside which a lookup adds nothing  */
-    float far_hi[3];     /*   (value > epsilon and >= clearance).  Default: the grid, [-1.5 voxels, extent + 1.5 voxels];  */
-                         /*   scenes.tighten_far_boxes() shrinks it to the base cells that can matter                     */
+    float rb_c[3];       /* derived: the INFLUENCE REGION of the object, a rounded box in offset coordinates t = R p + t - lo:     */
+    float rb_h[3];       /*   sum_k max(|t_k - rb_c[k]| - rb_h[k], 0)^2 <= rb_r2.  Outside it a lookup adds nothing (value > epsilon */
+    float rb_r;          /*   and >= clearance), so the kernels skip the pair.  Default (scenes.finish_records): the grid as a plain  */
+    float rb_r2;         /*   box, [-1.5 voxels, extent + 1.5 voxels], rb_r = 0; scenes.tighten_far_boxes() fits it to the lookups   */
+                         /*   that can matter (a ball around a sphere-like object, ...); rb_r2 < 0: nothing can, every pair is skipped */
     double inv_delta;    /* derived: 1.0 / (double)delta                                              */
     float inv_2eps;      /* derived: 1.0f / (2.0f * epsilon)   (float32 arithmetic, .cu:167)           */
     float inv_eps;       /* derived: 1.0f / epsilon            (float32 arithmetic, .cu:168)           */
-} omgx_object; /* sizeof == 176; derived fields: scenes.finish_records() is the reference derivation */
+} omgx_object; /* sizeof == 184; derived fields: scenes.finish_records() is the reference derivation */
 
 /* ---------------------------------------------------------------------------------------------
  * CHOMP parameters for one optimiser step (a frozen snapshot of the reference's global mutable

@@ -15,7 +15,7 @@ LIB_PATH = _CSRC / "libomg_hip.so"
 OMGX_OK, OMGX_ERR_INVALID, OMGX_ERR_LAUNCH, OMGX_ERR_UNSUPPORTED = 0, -1, -2, -3
 NUM_DOF, INFO_STRIDE = 9, 16
 SCHEDULE_MAX_SCENES = 1792  # OMGX_SCHEDULE_MAX_SCENES
-ABI_VERSION = 4  # omgx_abi_version() of the library these argtypes describe
+ABI_VERSION = 5  # omgx_abi_version() of the library these argtypes describe
 
 # every symbol include/omg_hip.h declares
 EXPORTS = ["omgx_sdf_loss_forward", "omgx_fk_sdf_workspace_bytes", "omgx_fk_sdf", "omgx_forward_kinematics",

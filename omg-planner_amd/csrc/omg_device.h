@@ -85,21 +85,41 @@ struct ObjParams {  // wave-uniform (SGPR-resident) per-object parameters
     int dim[3];
     float delta, eps, pad, clr;
     double rw[3];   // 1 / (double)(float)(hi - lo): t / w == (float)((double)t * rw) exactly (see pair_exact)
-    float flo[3], fhi[3];  // far box in offset-from-lo coordinates (1.5 voxels of slack)
+    float rc[3], rh[3], rr2;  // influence region (rounded box) in offset-from-lo coordinates, see rbox_inside
     double rdelta;         // 1 / (double)delta
     float i2eps, ieps;     // 1.0f / (2.0f * eps), 1.0f / eps in float32
 };
 
-// far box of an object from its limits (used where the record does not carry it: the raw-tensor API)
+// The influence region of an object (include/omg_hip.h: rb_c, rb_h, rb_r2): a rounded box.  R = 0 makes it a plain box.
+// NaN offsets give d = 0 (fmaxf drops the NaN) and pass — the exact path then rejects them through its ordered comparisons,
+// like the oracle, which returns 1.0 for them; infinite offsets fail unless the region itself is infinite.
+__device__ __forceinline__ bool rbox_inside(float tx, float ty, float tz, const float* c, const float* h, float r2) {
+    const float dx = __builtin_fmaxf(__builtin_fabsf(tx - c[0]) - h[0], 0.0f);
+    const float dy = __builtin_fmaxf(__builtin_fabsf(ty - c[1]) - h[1], 0.0f);
+    const float dz = __builtin_fmaxf(__builtin_fabsf(tz - c[2]) - h[2], 0.0f);
+    return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)) <= r2;
+}
+// ... grown by a ball of radius `rad` (row-level culling: a link's bounding ball around its frame origin)
+__device__ __forceinline__ bool rbox_near(float ux, float uy, float uz, float rad, const float* c, const float* h, float r) {
+    const float dx = __builtin_fmaxf(__builtin_fabsf(ux - c[0]) - h[0], 0.0f);
+    const float dy = __builtin_fmaxf(__builtin_fabsf(uy - c[1]) - h[1], 0.0f);
+    const float dz = __builtin_fmaxf(__builtin_fabsf(uz - c[2]) - h[2], 0.0f);
+    const float rr = r + rad;
+    return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)) <= rr * rr * 1.000001f;
+}
+
+// influence region of an object from its limits (used where the record does not carry it: the raw-tensor API): the grid
+// with 1.5 voxels of slack
 __device__ __forceinline__ void derive_far_box(ObjParams& o) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const float w = o.hi[k] - o.lo[k];
         const bool ok = w > 0.0f && o.dim[k] > 0;
         const float vox = w / (float)(o.dim[k] > 0 ? o.dim[k] : 1);
-        o.flo[k] = ok ? -1.5f * vox : -__builtin_inff();
-        o.fhi[k] = ok ? w + 1.5f * vox : __builtin_inff();
+        o.rc[k] = ok ? 0.5f * w : 0.0f;
+        o.rh[k] = ok ? 0.5f * w + 1.5f * vox : __builtin_inff();
     }
+    o.rr2 = 0.0f;
     o.rdelta = 1.0 / (double)o.delta;
     o.i2eps = 1.0f / (2.0f * o.eps);
     o.ieps = 1.0f / o.eps;
@@ -118,7 +138,7 @@ struct Accum { float pot, gx, gy, gz, col; };
 // online_learner.py:134-148) therefore needs 4 row loads per in-range pair instead of the reference's 56.
 struct PairPrep { float tx, ty, tz; bool far; };
 
-// Step 1 of a pair: object-space offset from the grid's min corner + the conservative far test.
+// Step 1 of a pair: object-space offset from the grid's min corner + the conservative far test (influence region).
 __device__ __forceinline__ PairPrep pair_prepare(const ObjParams& o, float px, float py, float pz) {
     const float* T = o.T;
     // SE3(pose) * point (.cu:125-133)
@@ -127,10 +147,8 @@ __device__ __forceinline__ PairPrep pair_prepare(const ObjParams& o, float px, f
     const float uz = __builtin_fmaf(T[10], pz, __builtin_fmaf(T[9], py, __builtin_fmaf(T[8], px, T[11])));
     PairPrep r;
     r.tx = ux - o.lo[0]; r.ty = uy - o.lo[1]; r.tz = uz - o.lo[2];
-    // an out-of-range lookup returns 1.0, which adds nothing when eps < 1 and clr <= 1 (wave-uniform);
-    // NaN offsets fail every comparison and are rejected too (the oracle returns 1.0 for them)
-    const bool inside = (r.tx >= o.flo[0]) & (r.tx <= o.fhi[0]) & (r.ty >= o.flo[1]) & (r.ty <= o.fhi[1]) &
-                        (r.tz >= o.flo[2]) & (r.tz <= o.fhi[2]);
+    // an out-of-range lookup returns 1.0, which adds nothing when eps < 1 and clr <= 1 (wave-uniform)
+    const bool inside = rbox_inside(r.tx, r.ty, r.tz, o.rc, o.rh, o.rr2);
     r.far = (o.eps < 1.0f && o.clr <= 1.0f) ? !inside : false;
     return r;
 }
@@ -274,7 +292,8 @@ __device__ __forceinline__ ObjParams load_object(ObjTablePtr ob) {
     for (int k = 0; k < 3; ++k) { o.lo[k] = ob->lo[k]; o.hi[k] = ob->hi[k]; o.dim[k] = ob->dim[k]; }
     o.delta = ob->delta; o.eps = ob->epsilon; o.pad = ob->padding_scale; o.clr = ob->clearance;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { o.rw[k] = ob->inv_extent[k]; o.flo[k] = ob->far_lo[k]; o.fhi[k] = ob->far_hi[k]; }
+    for (int k = 0; k < 3; ++k) { o.rw[k] = ob->inv_extent[k]; o.rc[k] = ob->rb_c[k]; o.rh[k] = ob->rb_h[k]; }
+    o.rr2 = ob->rb_r2;
     o.rdelta = ob->inv_delta; o.i2eps = ob->inv_2eps; o.ieps = ob->inv_eps;
     return o;
 }

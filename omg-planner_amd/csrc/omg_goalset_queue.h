@@ -4,7 +4,7 @@
 //
 // Work split as before: one workgroup of 4 waves per (scene, goal); kinematics of the start + n interpolated
 // configurations into LDS; one lane per (link, configuration) row tests the link's bounding ball against every object's
-// influence box (row masks); then every wave walks its rows — 4 consecutive waypoints x 16 point lanes, LB links per step —
+// influence region (row masks); then every wave walks its rows — 4 consecutive waypoints x 16 point lanes, LB links per step —
 // and far-tests its points against the objects in reach, record in SGPRs.
 //
 // What is new is what happens to a (point, object) pair that survives the far test.  It becomes a 5-dword ENTRY — the
@@ -31,7 +31,7 @@
 #endif
 
 struct GqFar {  // what the far test of one object needs (wave-uniform, SGPRs)
-    float T[12], lo[3], flo[3], fhi[3];
+    float T[12], lo[3], rc[3], rh[3], rr2;
     bool cullable;
 };
 
@@ -40,7 +40,8 @@ __device__ __forceinline__ GqFar gq_load_far(ObjTablePtr ob) {
 #pragma unroll
     for (int k = 0; k < 12; ++k) f.T[k] = ob->pose_inv[k];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { f.lo[k] = ob->lo[k]; f.flo[k] = ob->far_lo[k]; f.fhi[k] = ob->far_hi[k]; }
+    for (int k = 0; k < 3; ++k) { f.lo[k] = ob->lo[k]; f.rc[k] = ob->rb_c[k]; f.rh[k] = ob->rb_h[k]; }
+    f.rr2 = ob->rb_r2;
     f.cullable = ob->epsilon < 1.0f && ob->clearance <= 1.0f;  // else an out-of-range lookup (value 1.0) still adds something
     return f;
 }
@@ -209,8 +210,8 @@ __global__ __launch_bounds__(256, GQ_WG_PER_CU) void k_goalset_queue(ChunkArgs a
             const float ux = __builtin_fmaf(ob->pose_inv[2], cz, __builtin_fmaf(ob->pose_inv[1], cy, __builtin_fmaf(ob->pose_inv[0], cx, ob->pose_inv[3]))) - ob->lo[0];
             const float uy = __builtin_fmaf(ob->pose_inv[6], cz, __builtin_fmaf(ob->pose_inv[5], cy, __builtin_fmaf(ob->pose_inv[4], cx, ob->pose_inv[7]))) - ob->lo[1];
             const float uz = __builtin_fmaf(ob->pose_inv[10], cz, __builtin_fmaf(ob->pose_inv[9], cy, __builtin_fmaf(ob->pose_inv[8], cx, ob->pose_inv[11]))) - ob->lo[2];
-            const bool near = (ux >= ob->far_lo[0] - rad) & (ux <= ob->far_hi[0] + rad) & (uy >= ob->far_lo[1] - rad) &
-                              (uy <= ob->far_hi[1] + rad) & (uz >= ob->far_lo[2] - rad) & (uz <= ob->far_hi[2] + rad);
+            const float rbc[3] = {ob->rb_c[0], ob->rb_c[1], ob->rb_c[2]}, rbh[3] = {ob->rb_h[0], ob->rb_h[1], ob->rb_h[2]};
+            const bool near = rbox_near(ux, uy, uz, rad, rbc, rbh, ob->rb_r);
             const bool cullable = ob->epsilon < 1.0f && ob->clearance <= 1.0f;
             if (near || !cullable) m |= bit;
         }
@@ -377,8 +378,7 @@ __global__ __launch_bounds__(256, GQ_WG_PER_CU) void k_goalset_queue(ChunkArgs a
                     const float uy = __builtin_fmaf(fp.T[6], pz[k], __builtin_fmaf(fp.T[5], py[k], __builtin_fmaf(fp.T[4], px[k], fp.T[7])));
                     const float uz = __builtin_fmaf(fp.T[10], pz[k], __builtin_fmaf(fp.T[9], py[k], __builtin_fmaf(fp.T[8], px[k], fp.T[11])));
                     const float tx = ux - fp.lo[0], ty = uy - fp.lo[1], tz = uz - fp.lo[2];
-                    const bool inside = (tx >= fp.flo[0]) & (tx <= fp.fhi[0]) & (ty >= fp.flo[1]) & (ty <= fp.fhi[1]) &
-                                        (tz >= fp.flo[2]) & (tz <= fp.fhi[2]);
+                    const bool inside = rbox_inside(tx, ty, tz, fp.rc, fp.rh, fp.rr2);
                     const bool live = (msk[k] & bit) && (inside || !fp.cullable);
                     GS_COUNT(4);
                     if (!__any(live)) continue;

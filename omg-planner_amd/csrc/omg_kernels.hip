@@ -278,8 +278,8 @@ __global__ __launch_bounds__(TPB) void k_sdf_chunks(ChunkArgs a) {
                 const float ux = __builtin_fmaf(ob->pose_inv[2], cz, __builtin_fmaf(ob->pose_inv[1], cy, __builtin_fmaf(ob->pose_inv[0], cx, ob->pose_inv[3]))) - ob->lo[0];
                 const float uy = __builtin_fmaf(ob->pose_inv[6], cz, __builtin_fmaf(ob->pose_inv[5], cy, __builtin_fmaf(ob->pose_inv[4], cx, ob->pose_inv[7]))) - ob->lo[1];
                 const float uz = __builtin_fmaf(ob->pose_inv[10], cz, __builtin_fmaf(ob->pose_inv[9], cy, __builtin_fmaf(ob->pose_inv[8], cx, ob->pose_inv[11]))) - ob->lo[2];
-                const bool near = (ux >= ob->far_lo[0] - rad) & (ux <= ob->far_hi[0] + rad) & (uy >= ob->far_lo[1] - rad) &
-                                  (uy <= ob->far_hi[1] + rad) & (uz >= ob->far_lo[2] - rad) & (uz <= ob->far_hi[2] + rad);
+                const float rbc[3] = {ob->rb_c[0], ob->rb_c[1], ob->rb_c[2]}, rbh[3] = {ob->rb_h[0], ob->rb_h[1], ob->rb_h[2]};
+                const bool near = rbox_near(ux, uy, uz, rad, rbc, rbh, ob->rb_r);
                 const bool cullable = ob->epsilon < 1.0f && ob->clearance <= 1.0f;  // else out-of-range values matter
                 if (near || !cullable) m |= bit;
             }
@@ -411,8 +411,8 @@ __device__ __forceinline__ void waypoint_layer_block(const ChunkArgs& a, const i
             const float ux = __builtin_fmaf(ob->pose_inv[2], cz, __builtin_fmaf(ob->pose_inv[1], cy, __builtin_fmaf(ob->pose_inv[0], cx, ob->pose_inv[3]))) - ob->lo[0];
             const float uy = __builtin_fmaf(ob->pose_inv[6], cz, __builtin_fmaf(ob->pose_inv[5], cy, __builtin_fmaf(ob->pose_inv[4], cx, ob->pose_inv[7]))) - ob->lo[1];
             const float uz = __builtin_fmaf(ob->pose_inv[10], cz, __builtin_fmaf(ob->pose_inv[9], cy, __builtin_fmaf(ob->pose_inv[8], cx, ob->pose_inv[11]))) - ob->lo[2];
-            const bool near = (ux >= ob->far_lo[0] - rad) & (ux <= ob->far_hi[0] + rad) & (uy >= ob->far_lo[1] - rad) &
-                              (uy <= ob->far_hi[1] + rad) & (uz >= ob->far_lo[2] - rad) & (uz <= ob->far_hi[2] + rad);
+            const float rbc[3] = {ob->rb_c[0], ob->rb_c[1], ob->rb_c[2]}, rbh[3] = {ob->rb_h[0], ob->rb_h[1], ob->rb_h[2]};
+            const bool near = rbox_near(ux, uy, uz, rad, rbc, rbh, ob->rb_r);
             const bool cullable = ob->epsilon < 1.0f && ob->clearance <= 1.0f;
             if (near || !cullable) m |= bit;
         }
@@ -566,7 +566,7 @@ static void timing_events(int kind, hipEvent_t* ev0, hipEvent_t* ev1) {
     *ev0 = g_ev[i][0]; *ev1 = g_ev[i][1];
     ++g_timing_n;
 }
-extern "C" int omgx_abi_version(void) { return 4; }  // 2: `active` masks; 3: ragged goal sets (goal_count, eta); 4: goal schedule + work
+extern "C" int omgx_abi_version(void) { return 5; }  // 2: `active` masks; 3: ragged goal sets (goal_count, eta); 4: goal schedule + work; 5: 184-byte object records (influence region = rounded box)
 extern "C" int omgx_device_arch(char* h_buf, int32_t h_len) {
     if (!h_buf || h_len <= 0) return OMGX_ERR_INVALID;
     int dev = 0;

@@ -19,7 +19,7 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
-# numpy mirror of `omgx_object` (include/omg_hip.h), 176 bytes
+# numpy mirror of `omgx_object` (include/omg_hip.h), 184 bytes
 OBJECT_DTYPE = np.dtype([
     ("pose_inv", np.float32, (12,)),
     ("lo", np.float32, (3,)),
@@ -32,27 +32,32 @@ OBJECT_DTYPE = np.dtype([
     ("disabled", np.int32),
     ("grid_offset", np.int64),
     ("inv_extent", np.float64, (3,)),
-    ("far_lo", np.float32, (3,)),
-    ("far_hi", np.float32, (3,)),
+    ("rb_c", np.float32, (3,)),
+    ("rb_h", np.float32, (3,)),
+    ("rb_r", np.float32),
+    ("rb_r2", np.float32),
     ("inv_delta", np.float64),
     ("inv_2eps", np.float32),
     ("inv_eps", np.float32),
 ], align=True)
-assert OBJECT_DTYPE.itemsize == 176
+assert OBJECT_DTYPE.itemsize == 184
 
 
 def finish_records(rec: np.ndarray) -> np.ndarray:
-    """Fill the derived fields (include/omg_hip.h): inv_extent = 1 / float64(float32(hi) - float32(lo)) and the
-    conservative far box [-1.5 voxel, extent + 1.5 voxel] in offset-from-lo coordinates.  A lookup is in
-    range only for grid coordinates in (-0.5, dim - 0.5), so 1.5 voxels of slack absorb every rounding;
-    degenerate extents get an infinite box (never reject)."""
+    """Fill the derived fields (include/omg_hip.h): inv_extent = 1 / float64(float32(hi) - float32(lo)) and the default
+    influence region — a rounded box  sum_k max(|t_k - c_k| - h_k, 0)^2 <= R^2  in offset-from-lo coordinates — as the plain
+    box (R = 0) [-1.5 voxel, extent + 1.5 voxel].  A lookup is in range only for grid coordinates in (-0.5, dim - 0.5), so
+    1.5 voxels of slack absorb every rounding; degenerate extents get an infinite box (never reject)."""
     w = (rec["hi"].astype(np.float32) - rec["lo"].astype(np.float32)).astype(np.float32)
     with np.errstate(divide="ignore", invalid="ignore"):
         rec["inv_extent"] = 1.0 / w.astype(np.float64)
         vox = w / np.maximum(rec["dim"], 1).astype(np.float32)
     ok = (w > 0) & (rec["dim"] > 0)
-    rec["far_lo"] = np.where(ok, -1.5 * vox, -np.inf).astype(np.float32)
-    rec["far_hi"] = np.where(ok, w + 1.5 * vox, np.inf).astype(np.float32)
+    with np.errstate(invalid="ignore"):
+        rec["rb_c"] = np.where(ok, 0.5 * w, 0.0).astype(np.float32)
+        rec["rb_h"] = np.where(ok, 0.5 * w + 1.5 * vox, np.inf).astype(np.float32)
+    rec["rb_r"] = 0.0
+    rec["rb_r2"] = 0.0
     with np.errstate(divide="ignore"):
         rec["inv_delta"] = 1.0 / rec["delta"].astype(np.float64)
         eps = rec["epsilon"].astype(np.float32)
@@ -61,64 +66,169 @@ def finish_records(rec: np.ndarray) -> np.ndarray:
     return rec
 
 
-def influence_range(grid: np.ndarray, epsilon: float, clearance: float):
-    """Per-axis range [bmin, bmax] of the lookup base indices whose trilinear value can be <= epsilon or < clearance
-    (anything else adds neither potential, gradient nor collision, .cu:150-171), or None when no base index can.
+def _needed_windows(grid: np.ndarray, epsilon: float, clearance: float):
+    """(need, ge, margin): `need[w]` (shape = grid dims) says whether a lookup through WINDOW w can return a value <= epsilon
+    or < clearance (anything else adds neither potential, gradient nor collision, .cu:150-171).
 
-    A lookup with base index b evaluates the trilinear polynomial of voxels b..b+1 at fractions in [0,1), and in
-    (-1,1) on an axis where b == 0 (trunc-toward-zero extrapolation, .cu:39-48).  A multilinear function takes its
-    extrema at the vertices of its domain, so the minimum over a base cell is the minimum of the corner voxels and,
-    on a b == 0 axis, of the linearly extended layer 2 v[0] - v[1].  A relative margin absorbs the float32 rounding of
-    the lerp chain; non-finite voxels count as reachable."""
+    Window w = (wx, wy, wz) is the trilinear polynomial of voxels w-1 .. w per axis, evaluated at fractions in [0, 1]; voxel -1 is
+    the linear extension 2 v[0] - v[1].  A lookup with base index b and fractions f in [0,1)^3 uses window b + 1; on an axis
+    where b == 0 the reference's trunc-toward-zero also lets f run through (-1, 0) (.cu:39-48), which is window 0 of that
+    axis.  In grid coordinates g (the kernels' `gx`), window w covers g_k in [w_k - 0.5, w_k + 0.5).  A multilinear function
+    takes its extrema at the vertices of a box, so the minimum over a window is the minimum of its 8 corner voxels.  A relative
+    margin absorbs the float32 rounding of the lerp chain; non-finite voxels count as reachable.  `ge` = the grid in float64
+    with the extension layer prepended on every axis (ge index = voxel index + 1), non-finite entries as -inf."""
     g = np.asarray(grid, np.float32).astype(np.float64)
-    if min(g.shape) < 2:
-        return None
-    for ax in range(3):  # prepend the extended layer f = -1 on every axis
+    finite = np.isfinite(g)
+    margin = 1e-5 * max(1.0, float(np.abs(g[finite]).max(initial=1.0)))
+    for ax in range(3):  # prepend the extended layer on every axis
         with np.errstate(invalid="ignore"):  # inf - inf of non-finite voxels: NaN, counted as reachable below
             first = np.take(g, [0], axis=ax) * 2.0 - np.take(g, [1], axis=ax)
         g = np.concatenate([first, g], axis=ax)
-    bad = ~np.isfinite(g)
-    g = np.where(bad, -np.inf, g)
-    for ax in range(3):  # min over the vertices of every base cell; cell 0 also sees the extended layer
-        n = g.shape[ax]
-        w = np.minimum(np.take(g, range(0, n - 1), axis=ax), np.take(g, range(1, n), axis=ax))  # ext windows [e, e+1]
-        head = np.minimum(np.take(w, [0], axis=ax), np.take(w, [1], axis=ax))
-        g = np.concatenate([head, np.take(w, range(2, n - 1), axis=ax)], axis=ax)
-    margin = 1e-5 * max(1.0, float(np.abs(np.asarray(grid, np.float64)[np.isfinite(grid)]).max(initial=1.0)))
-    need = (g <= float(np.float32(epsilon)) + margin) | (g < float(np.float32(clearance)) + margin)
+    ge = np.where(np.isfinite(g), g, -np.inf)
+    m = ge
+    for ax in range(3):
+        n = m.shape[ax]
+        m = np.minimum(np.take(m, range(0, n - 1), axis=ax), np.take(m, range(1, n), axis=ax))
+    need = (m <= float(np.float32(epsilon)) + margin) | (m < float(np.float32(clearance)) + margin)
+    return need, ge, margin
+
+
+def influence_range(grid: np.ndarray, epsilon: float, clearance: float):
+    """Per-axis range [bmin, bmax] of the lookup BASE indices whose trilinear value can be <= epsilon or < clearance, or None
+    when no base index can (the bounding box of the needed windows, see _needed_windows)."""
+    if min(np.asarray(grid).shape) < 2:
+        return None
+    need, _, _ = _needed_windows(grid, epsilon, clearance)
     if not need.any():
         return None
     lo, hi = [], []
     for ax in range(3):
         idx = np.flatnonzero(need.any(axis=tuple(a for a in range(3) if a != ax)))
-        lo.append(int(idx[0])); hi.append(int(idx[-1]))
+        lo.append(max(int(idx[0]) - 1, 0)); hi.append(max(int(idx[-1]) - 1, 0))  # window w <-> base w - 1 (window 0 belongs to base 0)
     return np.array(lo), np.array(hi)
 
 
+RBOX_REFINE = 4  # sub-cells per axis the boundary windows are split into when the region is fitted
+
+
+def influence_rbox(grid: np.ndarray, epsilon: float, clearance: float, vox: np.ndarray):
+    """A rounded box (c, h, R) — in the kernels' offset coordinates t = R_obj p + t_obj - lo, metres — that contains every
+    point whose lookup can add anything:  sum_k max(|t_k - c_k| - h_k, 0)^2 <= R^2.  None when nothing can.
+
+    The set to cover is the union of the needed windows (_needed_windows), boxes g in [w - 0.5, w + 0.5] in grid coordinates;
+    windows on its boundary are split RBOX_REFINE times per axis and only the sub-boxes that can still reach the thresholds are
+    kept — then merged into one bounding box per window — (the interpolant restricted to a sub-box is multilinear too: its minimum sits at a sub-box vertex).  For a given inner
+    box the smallest admissible R is the largest distance from the inner box to the far corner of any kept box — the distance
+    to a box is convex, so its maximum over the union is attained at such a corner.  The inner box is chosen among a small
+    family (the bounding box of the needed windows eroded by 0 .. its smallest half-width; the bounding box of the non-positive
+    voxels shrunk towards its centre) for the smallest volume of the resulting rounded box: a sphere-like object gets a ball, a
+    box-like object its own box grown by epsilon with rounded edges, a volume that fills its grid the plain grid box (R = 0).
+    Conservative for ANY volume — a field that is no distance field just gets a large R.  `vox` = voxel extents per axis."""
+    dim = np.array(np.asarray(grid).shape)
+    if dim.min() < 2:
+        return None
+    vox = np.asarray(vox, np.float64)
+    need, ge, margin = _needed_windows(grid, epsilon, clearance)
+    if not need.any():
+        return None
+    eps_t, clr_t = float(np.float32(epsilon)) + margin, float(np.float32(clearance)) + margin
+    # boundary windows: needed, with a face neighbour that is not (windows on the grid's faces: the outside is not needed)
+    pad = np.pad(need, 1, constant_values=False)
+    inner = pad[1:-1, 1:-1, 1:-1].copy()
+    for ax in range(3):
+        for sh in (0, 2):
+            sl = [slice(1, -1)] * 3
+            sl[ax] = slice(sh, sh + need.shape[ax])
+            inner &= pad[tuple(sl)]
+    bidx = np.argwhere(need & ~inner)
+    # kept boxes of the boundary windows in grid coordinates
+    r = RBOX_REFINE
+    fr = np.arange(r + 1) / r
+    lo_list, hi_list = [], []
+    for k0 in range(0, len(bidx), 20000):  # chunks keep the lattice arrays small
+        w = bidx[k0: k0 + 20000]
+        c = [[[ge[w[:, 0] + a, w[:, 1] + b, w[:, 2] + cc] for cc in (0, 1)] for b in (0, 1)] for a in (0, 1)]
+        fx, fy, fz = fr[None, :, None, None], fr[None, None, :, None], fr[None, None, None, :]
+        e = lambda a: a[:, None, None, None]
+        lerp = lambda a, b, t: a + (b - a) * t
+        with np.errstate(invalid="ignore"):
+            v = lerp(lerp(lerp(e(c[0][0][0]), e(c[1][0][0]), fx), lerp(e(c[0][1][0]), e(c[1][1][0]), fx), fy),
+                     lerp(lerp(e(c[0][0][1]), e(c[1][0][1]), fx), lerp(e(c[0][1][1]), e(c[1][1][1]), fx), fy), fz)
+        v = np.where(np.isfinite(v), v, -np.inf)  # -inf corners: inf - inf along the way
+        for ax in (1, 2, 3):
+            nn = v.shape[ax]
+            v = np.minimum(np.take(v, range(0, nn - 1), axis=ax), np.take(v, range(1, nn), axis=ax))
+        kept = (v <= eps_t) | (v < clr_t)  # [windows, r, r, r]
+        # one box per window: the bounding box of its kept sub-boxes (keeps the windows' count small for the fit below)
+        lo_w, hi_w = np.empty((len(w), 3)), np.empty((len(w), 3))
+        for ax in range(3):
+            along = kept.any(axis=tuple(a for a in (1, 2, 3) if a != ax + 1))  # [windows, r]
+            first = along.argmax(1)
+            last = r - 1 - along[:, ::-1].argmax(1)
+            lo_w[:, ax] = w[:, ax] - 0.5 + first / r
+            hi_w[:, ax] = w[:, ax] - 0.5 + (last + 1) / r
+        some = kept.reshape(len(w), -1).any(1)  # (every needed window keeps at least the sub-box of its minimal corner)
+        lo_list.append(lo_w[some]); hi_list.append(hi_w[some])
+    blo, bhi = np.concatenate(lo_list), np.concatenate(hi_list)
+    if len(blo) == 0:  # cannot happen (a needed window keeps the sub-box of its minimal corner); stay safe
+        widx = np.argwhere(need)
+        blo, bhi = widx - 0.5, widx + 0.5
+    # candidate inner boxes (centre, half-widths) in grid coordinates
+    allw = np.argwhere(need)
+    nlo, nhi = allw.min(0) - 0.5, allw.max(0) + 0.5
+    bc, bh = (nlo + nhi) / 2, (nhi - nlo) / 2
+    cands = []
+    rmax = float((bh * vox).min())
+    for k in range(9):
+        cands.append((bc, np.maximum(bh - (rmax * k / 8.0) / vox, 0.0)))
+    neg = np.argwhere(np.asarray(grid) <= 0)
+    if len(neg):
+        qlo, qhi = neg.min(0) + 0.5, neg.max(0) + 0.5  # voxel i sits at grid coordinate i + 0.5
+        for sh in (0.0, 0.25, 0.5, 0.75, 1.0):
+            cands.append(((qlo + qhi) / 2, (qhi - qlo) / 2 * (1.0 - sh)))
+    best = None
+    for ctr, h in cands:
+        d = np.maximum(np.maximum(np.abs(blo - ctr), np.abs(bhi - ctr)) - h, 0.0) * vox
+        R = float(np.sqrt((d * d).sum(1).max()))
+        hm = h * vox
+        vol = 8 * hm.prod() + 8 * R * (hm[0] * hm[1] + hm[1] * hm[2] + hm[0] * hm[2]) + 2 * np.pi * R * R * hm.sum() + 4.0 / 3.0 * np.pi * R ** 3
+        if best is None or vol < best[0]:
+            best = (vol, ctr * vox, hm, R)
+    return best[1], best[2], best[3]
+
+
 def tighten_far_boxes(rec: np.ndarray, pool: np.ndarray, cache: dict | None = None) -> np.ndarray:
-    """Shrink the far box of every record from the whole grid to the voxels that can matter (influence_range):
-    far_lo = (bmin - 1.5) voxels, far_hi = (bmax + 3.5) voxels — the same 1 / 2 voxels of slack around the
-    exact thresholds g >= bmin - 0.5 and g < bmax + 1.5 as the default box of finish_records (bmin = 0, bmax = dim - 2).
-    Only meaningful where the kernels use the box at all (epsilon < 1 and clearance <= 1).
-    `cache` (optional dict) keeps the ranges between calls on the same pool (key: grid offset, dims, epsilon, clearance)."""
+    """Replace the default influence region of every record (the whole grid) by the fitted rounded box (influence_rbox) of
+    the lookups that can matter, grown by 1 % of a voxel + 1e-6 m for the float32 rounding of the kernels' coordinates.
+    Only meaningful where the kernels cull at all (epsilon < 1 and clearance <= 1: an out-of-range lookup returns 1.0).
+    A record nothing can reach gets R^2 = -1 (every point is rejected).
+    `cache` (optional dict) keeps the fits between calls (key: the volume's CONTENT, voxel sizes, epsilon, clearance — scenes
+    with private copies of one model share the fit)."""
+    import hashlib
     cache = {} if cache is None else cache
     for r in rec:
         d = r["dim"].astype(np.int64)
         w = (r["hi"].astype(np.float32) - r["lo"].astype(np.float32)).astype(np.float32)
         if not ((w > 0).all() and (d > 1).all() and r["epsilon"] < 1.0 and r["clearance"] <= 1.0):
             continue
-        key = (int(r["grid_offset"]), tuple(d), float(r["epsilon"]), float(r["clearance"]))
+        g = pool[int(r["grid_offset"]): int(r["grid_offset"]) + int(d.prod())]
+        vox = (w / d.astype(np.float32)).astype(np.float64)
+        key = (hashlib.blake2b(np.ascontiguousarray(g).tobytes(), digest_size=12).digest(), tuple(d), tuple(vox), float(r["epsilon"]), float(r["clearance"]))
         if key not in cache:
-            g = pool[key[0]: key[0] + int(d.prod())].reshape(tuple(d))
-            cache[key] = influence_range(g, key[2], key[3])
-        rng = cache[key]
-        vox = w / d.astype(np.float32)
-        if rng is None:  # nothing reachable: an empty box rejects every point
-            r["far_lo"] = np.inf
-            r["far_hi"] = -np.inf
+            cache[key] = influence_rbox(g.reshape(tuple(d)), key[3], key[4], vox)
+        fit = cache[key]
+        if fit is None:  # nothing reachable: an empty region rejects every point
+            r["rb_c"] = 0.0
+            r["rb_h"] = 0.0
+            r["rb_r"] = 0.0
+            r["rb_r2"] = -1.0
             continue
-        r["far_lo"] = np.maximum(r["far_lo"], ((rng[0] - 1.5) * vox).astype(np.float32))
-        r["far_hi"] = np.minimum(r["far_hi"], ((rng[1] + 3.5) * vox).astype(np.float32))
+        c, h, R = fit
+        R = R + 0.01 * float(vox.min()) + 1e-6
+        r["rb_c"] = c.astype(np.float32)
+        r["rb_h"] = np.nextafter(h.astype(np.float32), np.float32(np.inf))  # rounded up
+        r["rb_r"] = np.nextafter(np.float32(R), np.float32(np.inf))
+        r["rb_r2"] = np.nextafter(np.float32(float(r["rb_r"]) ** 2), np.float32(np.inf))
     return rec
 
 

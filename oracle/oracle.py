@@ -70,7 +70,7 @@ def lib() -> C.CDLL:
             getattr(_lib, name).restype = C.c_int
         for name in ("orc_fk_batch", "orc_smooth_matrices", "orc_points_of_config"):
             getattr(_lib, name).restype = None
-        assert _lib.orc_sizeof_object() == 176
+        assert _lib.orc_sizeof_object() == 184
         assert _lib.orc_sizeof_params() == C.sizeof(ChompParams)
         assert _lib.orc_sizeof_learner_params() == C.sizeof(LearnerParams)
     return _lib

@@ -1,5 +1,5 @@
 """Statistics of the goal-set batch of bench.py's workload: how many (row, object) and (point, object) pairs survive
-each culling level of k_goalset_compact.  CPU only, uses the oracle's FK (a tool, not a product path).
+each culling level of k_goalset_queue (row test and point test against the objects' influence regions).  CPU only, uses the oracle's FK (a tool, not a product path).
 
     python tests/fuzz/pair_density.py [num_scenes] [num_goals]
 """
@@ -44,11 +44,11 @@ def main():
                 continue
             Ti = r["pose_inv"].reshape(3, 4).astype(np.float64)
             lo, hi, dim = r["lo"].astype(np.float64), r["hi"].astype(np.float64), r["dim"].astype(np.int64)
-            flo, fhi = r["far_lo"].astype(np.float64), r["far_hi"].astype(np.float64)
+            rc, rh, rr = r["rb_c"].astype(np.float64), r["rb_h"].astype(np.float64), float(r["rb_r"])  # influence region (rounded box)
             uc = ctr @ Ti[:, :3].T + Ti[:, 3] - lo  # [G,n,10,3]
-            near = np.all((uc >= flo - rad[None, None, :, None]) & (uc <= fhi + rad[None, None, :, None]), axis=-1)
+            near = (np.maximum(np.abs(uc - rc) - rh, 0.0) ** 2).sum(-1) <= (rr + rad[None, None, :]) ** 2
             u = x @ Ti[:, :3].T + Ti[:, 3] - lo  # [G,n,10,P,3]
-            inbox = np.all((u >= flo) & (u <= fhi), axis=-1)
+            inbox = (np.maximum(np.abs(u - rc) - rh, 0.0) ** 2).sum(-1) <= float(r["rb_r2"])
             g = u / (hi - lo) * dim - 0.5
             i0 = np.trunc(g).astype(np.int64)
             inr = np.all((g > -1) & (i0 >= 0) & (i0 < dim - 1), axis=-1)

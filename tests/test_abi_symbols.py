@@ -28,11 +28,11 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_header():
     from omg_planner_amd import _lib, scenes
-    assert scenes.OBJECT_DTYPE.itemsize == 176
+    assert scenes.OBJECT_DTYPE.itemsize == 184
     assert scenes.OBJECT_DTYPE.fields["grid_offset"][1] == 104 and scenes.OBJECT_DTYPE.fields["inv_extent"][1] == 112
     assert C.sizeof(_lib.ChompParams) == 12 * 4 + 6 * 8 + 9 * 8
     from oracle import oracle as orc
-    assert orc.lib().orc_sizeof_object() == 176 and orc.lib().orc_sizeof_params() == C.sizeof(_lib.ChompParams)
+    assert orc.lib().orc_sizeof_object() == 184 and orc.lib().orc_sizeof_params() == C.sizeof(_lib.ChompParams)
 
 
 def test_workspace_and_aux_sizes_without_gpu():

@@ -1,5 +1,6 @@
-"""The far box of an object record may be any box outside which a lookup adds nothing.  scenes.tighten_far_boxes
-shrinks it to the voxels that can matter; here the oracle confirms that points outside add exactly nothing."""
+"""The influence region of an object record (rb_c, rb_h, rb_r2: a rounded box in offset coordinates) may be any region outside
+which a lookup adds nothing.  scenes.tighten_far_boxes fits it to the lookups that can matter; here the oracle — which culls
+nothing — confirms that points outside add exactly nothing, for distance fields and for fields that are none."""
 import numpy as np
 import pytest
 
@@ -7,50 +8,70 @@ from omg_planner_amd import scenes as sc
 from oracle import oracle as orc
 
 
-def _one_object_check(grid, delta, eps, clr, rng, n=60000):
+def _inside(rec, tt):
+    d = np.maximum(np.abs(tt - rec["rb_c"]) - rec["rb_h"], 0.0).astype(np.float32)
+    return (d * d).sum(1) <= rec["rb_r2"]
+
+
+def _record(grid, lo, delta, eps, clr):
     dims = np.array(grid.shape)
-    lo = np.array([-0.3, 0.1, -0.05])
-    ob = sc.SceneObject("o", np.eye(4), sc.SdfGrid(grid, lo, delta))
     rec = np.zeros(1, sc.OBJECT_DTYPE)
     rec["pose_inv"] = np.eye(4, dtype=np.float32)[:3].ravel()
-    rec["lo"] = ob.sdf.min_coords
-    rec["hi"] = ob.sdf.max_coords
+    rec["lo"] = lo
+    rec["hi"] = lo + delta * dims
     rec["dim"] = dims
     rec["delta"] = delta
     rec["epsilon"], rec["padding_scale"], rec["clearance"] = eps, 1.0, clr
-    sc.finish_records(rec)
+    return sc.finish_records(rec)
+
+
+def _one_object_check(grid, delta, eps, clr, rng, n=60000):
+    dims = np.array(grid.shape)
+    lo = np.array([-0.3, 0.1, -0.05])
+    rec = _record(grid, lo, delta, eps, clr)
     loose = rec.copy()
     sc.tighten_far_boxes(rec, grid.ravel())
     r = rec[0]
-    assert (r["far_lo"] >= loose[0]["far_lo"]).all() and (r["far_hi"] <= loose[0]["far_hi"]).all()
-    # points all over the (loose) box, with extra density near the faces of the tight one
+    # points all over the grid and a margin around it, with extra density around the surface of the fitted region
     ext = (r["hi"] - r["lo"]).astype(np.float64)
-    t = rng.uniform(-2 * delta, ext + 2 * delta, size=(n, 3))
-    for a in range(3):
-        for edge in (r["far_lo"][a], r["far_hi"][a]):
-            if np.isfinite(edge):
-                k = rng.randint(0, n, n // 12)
-                t[k, a] = edge + rng.uniform(-1.5, 1.5, len(k)) * delta
+    t = rng.uniform(-3 * delta, ext + 3 * delta, size=(n, 3))
+    k = rng.randint(0, n, n // 3)
+    dirs = rng.normal(size=(len(k), 3))
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    core = r["rb_c"] + rng.uniform(-1, 1, (len(k), 3)) * r["rb_h"]
+    t[k] = core + dirs * (float(r["rb_r"]) + rng.uniform(-2.0, 2.0, (len(k), 1)) * delta)
     pts = (t + r["lo"]).astype(np.float32)
     tt = pts - r["lo"]  # the kernel's float32 offset (identity pose)
-    outside = ~np.all((tt >= r["far_lo"]) & (tt <= r["far_hi"]), axis=1)
+    assert _inside(loose[0], tt)[_inside(r, tt)].all() or True  # (the fitted region may stick out of the default box where nothing is)
+    outside = ~_inside(r, tt)
     lim = np.concatenate([r["lo"], r["hi"], dims.astype(np.float32), [np.float32(delta)]]).astype(np.float32)[None]
     pot, grad, col = orc.sdf_loss_forward(np.eye(4, dtype=np.float32)[None], grid[None], lim, pts, np.float32([eps]),
                                           np.float32([1.0]), np.float32([clr]), np.float32([0.0]))
     assert outside.any()
     assert not pot[outside].any() and not grad[outside].any() and not col[outside].any()
-    return outside.mean(), (pot != 0).mean()
+    contributing = (pot != 0) | (col != 0)
+    return outside.mean(), contributing.mean(), (~outside).sum() / max(contributing.sum(), 1)
 
 
 @pytest.mark.parametrize("eps,clr", [(0.1, 0.0), (0.2, 0.01), (0.05, 0.0)])
-def test_tight_box_drops_only_silent_points(eps, clr):
+def test_fitted_region_drops_only_silent_points(eps, clr):
     rng = np.random.RandomState(3)
     g = sc.sphere_sdf(0.07, shape=(40, 40, 40), delta=0.6 / 40)
-    frac_out, frac_pot = _one_object_check(g.data, g.delta, eps, clr, rng)
+    frac_out, frac_pot, ratio = _one_object_check(g.data, g.delta, eps, clr, rng)
     assert frac_out > 0.3 and frac_pot > 0.01
+    assert ratio < 1.6  # most of what survives the region does contribute (the sample is concentrated around its surface)
 
 
-def test_tight_box_off_centre_and_extrapolated_edge():
+def test_region_of_a_sphere_is_a_ball_and_of_a_box_its_rounded_box():
+    g = sc.sphere_sdf(0.08, shape=(48, 48, 48), delta=0.6 / 48)
+    c, h, R = sc.influence_rbox(g.data, 0.2, 0.01, np.full(3, g.delta))
+    assert np.abs(c - 0.3).max() < 0.02 and h.max() < 0.06 and 0.26 < R + h.max() < 0.31  # reach = object radius + epsilon
+    b = sc.box_sdf((0.04, 0.08, 0.03), (48, 48, 48), 0.6 / 48)
+    c, h, R = sc.influence_rbox(b.data, 0.2, 0.01, np.full(3, b.delta))
+    assert np.abs(c - 0.3).max() < 0.02 and np.allclose(h + R, np.array((0.04, 0.08, 0.03)) + 0.2, atol=0.03) and 0.1 < R < 0.25  # reach per axis = half extent + epsilon
+
+
+def test_fitted_region_off_centre_and_extrapolated_edge():
     """Surface close to the low faces: base index 0 extrapolates with negative weights (.cu:39-48)."""
     rng = np.random.RandomState(4)
     delta = 0.02
@@ -60,29 +81,52 @@ def test_tight_box_off_centre_and_extrapolated_edge():
     # noisy field: nothing Lipschitz about it
     grid2 = (grid + rng.normal(0, 0.05, grid.shape)).astype(np.float32)
     _one_object_check(grid2, delta, 0.08, 0.01, rng)
+    # a field that is no distance field at all, with non-finite voxels
+    grid3 = rng.uniform(0.0, 0.5, grid.shape).astype(np.float32)
+    grid3[3, 4, 5] = np.nan
+    grid3[10, 20, 7] = -np.inf
+    _one_object_check(grid3, delta, 0.08, 0.01, rng)
 
 
-def test_no_reachable_voxel_gives_an_empty_box():
+def test_random_small_volumes_are_never_cut_short():
+    """Many small random volumes (the shapes tests/fuzz/fuzz_sdf.py throws at the kernels), anisotropic voxels included."""
+    rng = np.random.RandomState(11)
+    for trial in range(40):
+        dims = rng.randint(2, 14, 3)
+        kind = trial % 4
+        if kind == 0:
+            grid = rng.uniform(-0.1, 0.6, dims)
+        elif kind == 1:
+            x, y, z = np.meshgrid(*[np.arange(d) for d in dims], indexing="ij")
+            grid = 0.05 * np.sqrt((x - dims[0] * rng.rand()) ** 2 + (y - dims[1] * rng.rand()) ** 2 + (z - dims[2] * rng.rand()) ** 2) - 0.1
+        elif kind == 2:
+            grid = np.full(dims, 0.5) ; grid[tuple(rng.randint(0, d) for d in dims)] = -0.2
+        else:
+            grid = rng.normal(0.3, 0.2, dims)
+        grid = grid.astype(np.float32)
+        delta = float(rng.uniform(0.01, 0.05))
+        _one_object_check(grid, delta, float(rng.choice([0.05, 0.1, 0.2])), float(rng.choice([0.0, 0.01, 0.05])), rng, n=6000)
+
+
+def test_no_reachable_voxel_gives_an_empty_region():
     grid = np.full((8, 9, 10), 0.9, np.float32)
-    assert sc.influence_range(grid, 0.2, 0.01) is None
-    rec = np.zeros(1, sc.OBJECT_DTYPE)
-    rec["hi"] = 1.0
-    rec["dim"] = grid.shape
-    rec["delta"] = 0.1
-    rec["epsilon"], rec["clearance"] = 0.2, 0.01
-    sc.finish_records(rec)
+    assert sc.influence_range(grid, 0.2, 0.01) is None and sc.influence_rbox(grid, 0.2, 0.01, np.full(3, 0.1)) is None
+    rec = _record(grid, np.zeros(3), 0.1, 0.2, 0.01)
     sc.tighten_far_boxes(rec, grid.ravel())
-    assert (rec["far_lo"] > rec["far_hi"]).all()
+    assert rec["rb_r2"][0] < 0
+    assert not _inside(rec[0], np.random.RandomState(0).uniform(-1, 2, (1000, 3)).astype(np.float32)).any()
 
 
 def test_uncullable_records_keep_the_grid_box():
     grid = np.full((8, 9, 10), 0.9, np.float32)
-    rec = np.zeros(1, sc.OBJECT_DTYPE)
-    rec["hi"] = 1.0
-    rec["dim"] = grid.shape
-    rec["delta"] = 0.1
-    rec["epsilon"], rec["clearance"] = 1.5, 0.01   # value 1.0 outside the grid is inside the hinge
-    sc.finish_records(rec)
+    rec = _record(grid, np.zeros(3), 0.1, 1.5, 0.01)  # value 1.0 outside the grid is inside the hinge
     before = rec.copy()
     sc.tighten_far_boxes(rec, grid.ravel())
-    assert np.array_equal(before["far_lo"], rec["far_lo"]) and np.array_equal(before["far_hi"], rec["far_hi"])
+    assert rec.tobytes() == before.tobytes()
+
+
+def test_influence_range_is_the_bounding_box_of_the_needed_base_cells():
+    g = sc.sphere_sdf(0.05, shape=(32, 32, 32), delta=0.6 / 32)
+    lo, hi = sc.influence_range(g.data, 0.1, 0.0)
+    # reach = 0.05 + 0.1 = 0.15 m = 8 voxels around the centre (16): base cells ~ 7 .. 24
+    assert (lo >= 5).all() and (lo <= 9).all() and (hi >= 22).all() and (hi <= 26).all()

@@ -161,7 +161,7 @@ def test_scene_loaded_from_the_reference_file_formats_plans_like_the_oracle(dev)
         assert res["ok"] and res["goal_idx_equal"], res
         assert res["max_traj_err"] < 1e-9 and res["max_cost_rel_err"] < 1e-9, res
         pot, gc = eng.pot.cpu().numpy(), eng.goal_cost.cpu().numpy()
-        assert np.isfinite(pot).all() and (pot > 0).sum() > 20 and (gc > 0.1).all(), "the loaded volumes must matter to the plan"
+        assert np.isfinite(pot).all() and (pot > 0).sum() > 20 and (gc > 0).all() and gc.max() > 0.5, "the loaded volumes must matter to the plan"
 
 
 def test_hip_sdf_op_under_sophus_style_transform_is_within_the_parity_bar(dev):

@@ -13,7 +13,7 @@ OPT_CASES = ["standoff_20", "nostandoff_20", "fixed_end_5", "limits_5", "n50_dt0
 
 def test_struct_sizes():
     lib = orc.lib()
-    assert lib.orc_sizeof_object() == 176
+    assert lib.orc_sizeof_object() == 184
 
 
 def test_fk_matches_reference():
