@@ -55,7 +55,9 @@ struct GqLayout {
         pts_off = tbl_off + tbl_n * 64;
         stage_off = pts_off + ((10 * P * 3 * 8 + 15) & ~15);
         total = stage_off + 4 * 64 * 16;
-        const int fk = PS * 90 * 8 + PS * 14 * 8;  // the (sin, cos) table of the kinematics borrows the region behind the poses
+        // the (sin, cos) table of the kinematics [PS][7][2] doubles borrows the queues' region (first used in the main loop), so
+        // that the records and collision points can be staged while the kinematics run
+        const int fk = stage_off + PS * 14 * 8;
         if (total < fk) total = fk;
     }
 };
@@ -153,7 +155,9 @@ __global__ __launch_bounds__(256, GQ_WG_PER_CU) void k_goalset_queue(ChunkArgs a
         const double* q0 = a.traj_start + a.ts_stride * (int64_t)s;
         const double* qg = a.goals + ((int64_t)s * a.NCH + chunk) * 9;
         const int ncfg = CH + 1;
-        double* sc = reinterpret_cast<double*>(rowmask);  // [ncfg][7][2]
+        double* sc = reinterpret_cast<double*>(lds_bytes + L.stage_off);  // [ncfg][7][2]: the queues' region, first used in the main loop
+        // the robot's collision points -> LDS: the loads are issued here and land while the (sin, cos) stage runs
+        const double pv0 = tid < 30 * P ? rv.g[246 + tid] : 0.0, pv1 = tid + 256 < 30 * P ? rv.g[246 + tid + 256] : 0.0;
         auto joint = [&](int cfg, int d) { return cfg == 0 ? q0[d] : q0[d] + ((double)cfg * (1.0 / (double)(CH + 1))) * (qg[d] - q0[d]); };
         for (int t = tid; t < ncfg * 7; t += 256) {
             const int cfg = t / 7, i = t - cfg * 7;
@@ -163,6 +167,26 @@ __global__ __launch_bounds__(256, GQ_WG_PER_CU) void k_goalset_queue(ChunkArgs a
         }
         __syncthreads();
         GS_WG_STAMP(1);
+        if (tid < 30 * P) pts[tid] = pv0;
+        if (tid + 256 < 30 * P) pts[tid + 256] = pv1;
+        // ---- exact-path records of the scene's first a.tbl_n objects -> LDS, by lanes of wave 2 (idle during the chain stage)
+        // record (16 dwords): [0..5] 1 / extent as doubles | [6..8] dims | [9,10] byte offset of the grid in the pool |
+        //                     [11] eps / 2 | [12] eps | [13] clearance | [14] padding scale | [15] 1 / (2 eps)
+        if (tid >= 128 && tid - 128 < a.tbl_n && o_begin + tid - 128 < o_end) {
+            const omgx_object* ob = a.objects + o_begin + (tid - 128);
+            uint32_t* e = tbl + (tid - 128) * 16;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const double rw = ob->inv_extent[k];
+                e[2 * k] = (uint32_t)__double2loint(rw); e[2 * k + 1] = (uint32_t)__double2hiint(rw);
+                e[6 + k] = (uint32_t)ob->dim[k];
+            }
+            const int64_t goffb = ob->grid_offset * 4;
+            e[9] = (uint32_t)(goffb & 0xffffffffll); e[10] = (uint32_t)(goffb >> 32);
+            e[11] = __float_as_uint(0.5f * ob->epsilon);  // exact: (double)(0.5f * eps) == 0.5 * (double)eps
+            e[12] = __float_as_uint(ob->epsilon); e[13] = __float_as_uint(ob->clearance);
+            e[14] = __float_as_uint(ob->padding_scale); e[15] = __float_as_uint(ob->inv_2eps);
+        }
         for (int t = tid; t < ncfg * 3; t += 256) {
             const int cfg = t / 3, rr = t - cfg * 3;
             fk_chain_row(rv, rr, sc + 14 * cfg, joint(cfg, 7), joint(cfg, 8), [&](int l, double r0, double r1, double r2, double tr) {
@@ -175,26 +199,6 @@ __global__ __launch_bounds__(256, GQ_WG_PER_CU) void k_goalset_queue(ChunkArgs a
     __syncthreads();
     GS_WG_STAMP(2);
     const double* base = lds_pose + 9;
-
-    // ---- exact-path records of the scene's first a.tbl_n objects and the robot's collision points -> LDS
-    // record (16 dwords): [0..5] 1 / extent as doubles | [6..8] dims | [9,10] byte offset of the grid in the pool |
-    //                     [11] eps / 2 | [12] eps | [13] clearance | [14] padding scale | [15] 1 / (2 eps)
-    if (tid < a.tbl_n && o_begin + tid < o_end) {
-        const omgx_object* ob = a.objects + o_begin + tid;
-        uint32_t* e = tbl + tid * 16;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const double rw = ob->inv_extent[k];
-            e[2 * k] = (uint32_t)__double2loint(rw); e[2 * k + 1] = (uint32_t)__double2hiint(rw);
-            e[6 + k] = (uint32_t)ob->dim[k];
-        }
-        const int64_t goffb = ob->grid_offset * 4;
-        e[9] = (uint32_t)(goffb & 0xffffffffll); e[10] = (uint32_t)(goffb >> 32);
-        e[11] = __float_as_uint(0.5f * ob->epsilon);  // exact: (double)(0.5f * eps) == 0.5 * (double)eps
-        e[12] = __float_as_uint(ob->epsilon); e[13] = __float_as_uint(ob->clearance);
-        e[14] = __float_as_uint(ob->padding_scale); e[15] = __float_as_uint(ob->inv_2eps);
-    }
-    for (int t = tid; t < 30 * P; t += 256) pts[t] = rv.g[246 + t];
 
     for (int row = tid; row < 10 * CH; row += 256) {  // row-level culling (see k_sdf_chunks)
         const int l = row / CH, ci = row - l * CH;
@@ -373,6 +377,7 @@ __global__ __launch_bounds__(256, GQ_WG_PER_CU) void k_goalset_queue(ChunkArgs a
                 const bool queued = oo < a.tbl_n;  // objects beyond the LDS records (rare) are evaluated on the spot
 #pragma unroll
                 for (int k = 0; k < LB; ++k) {
+                    if (!__any((msk[k] & bit) != 0)) continue;  // none of this link's four rows reaches the object
                     // SE3(pose) * point (.cu:125-133) and the far test of pair_prepare
                     const float ux = __builtin_fmaf(fp.T[2], pz[k], __builtin_fmaf(fp.T[1], py[k], __builtin_fmaf(fp.T[0], px[k], fp.T[3])));
                     const float uy = __builtin_fmaf(fp.T[6], pz[k], __builtin_fmaf(fp.T[5], py[k], __builtin_fmaf(fp.T[4], px[k], fp.T[7])));

@@ -925,3 +925,30 @@ void orc_points_of_config(const double* robot, int32_t P, const double* q, doubl
 int orc_sizeof_object(void) { return (int)sizeof(omgx_object); }
 int orc_sizeof_params(void) { return (int)sizeof(omgx_chomp_params); }
 int orc_sizeof_learner_params(void) { return (int)sizeof(omgx_learner_params); }
+
+/* =============================================================================================
+ * Checker of an arithmetic identity the HIP kernels rely on (omg_device.h: div_by_const): for a constant c,
+ *   q = x * RN(1/c);  r = fma(-q, c, x);  q' = fma(r, RN(1/c), q)
+ * is the IEEE quotient x / c.  Returns how many of n pseudo-random arguments (joint-angle, degree and wide exponent
+ * ranges) it is not.  The oracle itself divides (orc_fk); this function only counts.
+ * =========================================================================================== */
+int64_t orc_div_by_const_mismatches(double c, int64_t n, uint64_t seed) {
+    const double rc = 1.0 / c;
+    uint64_t s = seed ? seed : 88172645463325252ull;
+    int64_t bad = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+        const double u = (double)(s >> 11) / 9007199254740992.0;
+        double x;
+        switch (i & 3) {
+            case 0: x = (u - 0.5) * 14.0; break;
+            case 1: x = (u - 0.5) * 2000.0; break;
+            case 2: x = ldexp(1.0 + u, (int)(s % 60) - 30) * (((s >> 3) & 1) ? 1.0 : -1.0); break;
+            default: x = (u - 0.5) * 0.1;
+        }
+        const double q = x * rc;
+        const double r = fma(-q, c, x);
+        if (fma(r, rc, q) != x / c) ++bad;
+    }
+    return bad;
+}

@@ -140,3 +140,16 @@ def test_optimize_without_force_update_leaves_a_terminated_trajectory_alone():
         out[mode] = traj[0]
     np.testing.assert_array_equal(out[2], xi)
     assert np.abs(out[1] - xi).max() > 0
+
+
+def test_division_by_constant_through_fma_equals_the_quotient():
+    """omg_device.h: div_by_const — the kernels' rad -> deg -> rad round trip (omg/util.py:194-202, robot_pykdl.py:164) divides by
+    pi and by 180 with a multiplication and one FMA correction step instead of the IEEE division sequence; the two agree on
+    every sampled argument."""
+    import ctypes as C
+    import math
+    lib = orc.lib()
+    lib.orc_div_by_const_mismatches.restype = C.c_int64
+    lib.orc_div_by_const_mismatches.argtypes = [C.c_double, C.c_int64, C.c_uint64]
+    for c in (math.pi, 180.0):
+        assert lib.orc_div_by_const_mismatches(c, 20_000_000, 12345) == 0
