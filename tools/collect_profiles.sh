@@ -2,7 +2,7 @@
 # Collect the rocprofv3 evidence for bench.py on the GPU box (run through gpurun from the repo root):
 #   gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh r02h'
 # Writes into gpurun_out/ (copy what is to be judged into profiles/, then `python tools/roofline.py --tag <tag>`):
-#   <tag>_bench.json            the unprofiled default bench.py line
+#   <tag>_bench.json            the unprofiled default bench.py line (run LAST: its roofline block uses this collection's counts)
 #   <tag>_kernel_stats.csv      rocprofv3 --kernel-trace --stats of the same command
 #   <tag>_pmc_<SET>.csv         per-kernel means of every counter set (separate --pmc passes, kernel-trace only; MEM_* = TA / TCP / TD)
 #   <tag>_workload.json         the workload the counts belong to
@@ -17,7 +17,6 @@ O=$R/gpurun_out
 T=/tmp/prof_$TAG
 mkdir -p $O $T
 cd /tmp && export TMPDIR=/tmp
-python3 $R/bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.log
 rocprofv3 --kernel-trace --stats --output-format csv -d $T/stats -o $TAG -- python3 $R/bench.py --no-cpu-baseline --no-plan --no-parity > $O/${TAG}_bench_under_rocprof.log 2>&1
 cp $T/stats/*kernel_stats*.csv $O/${TAG}_kernel_stats.csv
 run_pmc() {  # name, counters
@@ -56,6 +55,10 @@ if [ -n "$VALU_PEAK" ] && [ -x $R/tools/_build/valu_peak ]; then
   rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $T/vp -o vp -- $R/tools/_build/valu_peak pmc > $O/${TAG}_valu_peak_pmc.txt 2>&1
   find $T/vp -name "*counter_collection*.csv" -exec cp {} $O/${TAG}_valu_peak_pmc_raw.csv \;
 fi
+# the unprofiled bench line LAST, with the per-launch counts of THIS collection behind its roofline block
+cp $O/${TAG}_*.csv $O/${TAG}_*.json $R/profiles/ 2>/dev/null
+(cd $R && python3 tools/roofline.py --tag $TAG > $O/${TAG}_roofline_inputs.log 2>&1; cp profiles/roofline_inputs.json $O/${TAG}_roofline_inputs.json)
+python3 $R/bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.log
 head -4 $O/${TAG}_kernel_stats.csv | cut -c1-160
 grep goalset $O/${TAG}_pmc_*.csv | cut -c1-200
 cut -c1-1200 $O/${TAG}_bench.json

@@ -73,13 +73,13 @@ def main():
         ok = ran & ~is_layer & (f[:, 1] > 1000)
         ghz = f[ok, 0] / f[ok, 1] * 0.1
         out["shader_clock_ghz_p10/p50/p90"] = [round(float(np.percentile(ghz, q)), 3) for q in (10, 50, 90)]
-    # resident workgroups over time (all CUs): fraction of the 1536 slots in use, in 10 slices of the span
+    # resident workgroups over time (all CUs): fraction of the 1280 slots (5 workgroups per CU) in use, in 10 slices of the span
     span = en[ran].max()
     edges = np.linspace(0, span, 11)
     occ = []
     for a, b in zip(edges[:-1], edges[1:]):
         overlap = np.clip(np.minimum(en[ran], b) - np.maximum(st[ran], a), 0, None).sum() / (b - a)
-        occ.append(round(float(overlap) / 1536.0, 3))
+        occ.append(round(float(overlap) / 1280.0, 3))
     out["timeline_us"]["slot_occupancy_by_tenth"] = occ
     np.save(str(ROOT / "gpurun_out" / "gs_wg_timeline.npy"), w)
     print(json.dumps(out, indent=1))
