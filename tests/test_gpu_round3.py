@@ -208,6 +208,43 @@ def test_hip_sdf_op_under_sophus_style_transform_is_within_the_parity_bar(dev):
     assert flips <= 2e-4 * total, (flips, total)
 
 
+def test_fitted_influence_regions_change_no_result(dev):
+    """The influence region only decides which (point, object) pairs are skipped.  Against the same table with the default
+    region (the whole grid): every per-point output of the layer — a sum over the objects in index order, to which a skipped
+    pair would have added 0 — is bit-identical, with and without per-point potentials of the goal-set batch; a goal's cost is a
+    float32 sum in the order its pairs were queued, so it moves by that sum's rounding only (1e-6) and stays within the tests'
+    1e-5 of the oracle, which culls nothing."""
+    import bench
+    from omg_planner_amd import ops, scenes as sc
+    from oracle import oracle as orc
+    S, G, n = 6, 16, 30
+    cfg, model, _, start, goals = bench.build_workload(S, G, n, 32, 0, True)
+    scenes = [sc.make_tabletop_scene(s, grid=32) for s in range(S)]
+    tight = sc.pack_table(scenes, cfg.layer_kwargs(), tight=True)
+    loose = sc.pack_table(scenes, cfg.layer_kwargs(), tight=False)
+    assert (loose.objects["rb_r2"] == 0).all() and (tight.objects["rb_r2"] > 0).any()
+    P = model.points_per_link
+    robot = ops.robot_blob(model, dev)
+    dt, dl = ops.DeviceScenes(tight, dev), ops.DeviceScenes(loose, dev)
+    traj = torch.as_tensor(np.stack([sc.cubic_init(start[s], goals[s, 0], n) for s in range(S)]), device=dev)
+    a, b = ops.fk_sdf(robot, P, dt, traj), ops.fk_sdf(robot, P, dl, traj)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    assert float((a[0] > 0).float().mean()) > 0.02
+    g = torch.as_tensor(goals, device=dev)
+    ts = traj[:, 0]
+    ct, colt, pt = ops.goalset_cost(robot, P, dt, ts, g, n, cfg.time_interval, want_potentials=True)
+    cl, coll, pl = ops.goalset_cost(robot, P, dl, ts, g, n, cfg.time_interval, want_potentials=True)
+    assert torch.equal(pt, pl) and torch.equal(ct, cl) and torch.equal(colt, coll)  # per-point path: sums in a fixed per-point order
+    qt, qcolt, _ = ops.goalset_cost(robot, P, dt, ts, g, n, cfg.time_interval)
+    ql, qcoll, _ = ops.goalset_cost(robot, P, dl, ts, g, n, cfg.time_interval)
+    torch.cuda.synchronize()
+    assert torch.equal(qcolt, qcoll)  # collision counts are sums of 0 / 1: exact in any order
+    np.testing.assert_allclose(qt.cpu().numpy(), ql.cpu().numpy(), rtol=2e-6, atol=1e-7)
+    ref, _ = orc.goalset_cost(model.blob(), P, tight, traj[:, 0].cpu().numpy(), goals, n, cfg.time_interval)
+    np.testing.assert_allclose(qt.cpu().numpy(), ref, rtol=1e-5, atol=1e-6)
+
+
 def test_bench_collective_path_runs_over_rccl_with_one_rank(tmp_path):
     """bench.py under torch.distributed.run with ONE rank and the default backend: RCCL initialisation, the barrier, the
     all_gather_into_tensor of the final costs on DEVICE tensors and the MAX all-reduce of the timing all run for real (the
