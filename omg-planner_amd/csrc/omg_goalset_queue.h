@@ -363,8 +363,11 @@ __global__ __launch_bounds__(256, GQ_WG_PER_CU) void k_goalset_queue(ChunkArgs a
             if (!__any(many != 0)) continue;  // nothing in reach of any row of this tile
             GS_COUNT(2);
 #pragma unroll
-            for (int k = 0; k < LB; ++k)
-                pose9_apply((base + (l0 + k) * pstride * 9) + cic9, (pts + 3 * (l0 + k) * P) + pc3, px[k], py[k], pz[k]);
+            for (int k = 0; k < LB; ++k) {
+                px[k] = py[k] = pz[k] = 0.0f;
+                if (__any(msk[k] != 0))  // a link none of whose four rows reaches anything needs no points (its far tests are skipped too)
+                    pose9_apply((base + (l0 + k) * pstride * 9) + cic9, (pts + 3 * (l0 + k) * P) + pc3, px[k], py[k], pz[k]);
+            }
             for (int o = o_begin; o < o_end; ++o) {
                 const int oo = o - o_begin;
                 const uint32_t bit = 1u << (oo < 31 ? oo : 31);

@@ -19,7 +19,8 @@ import torch  # noqa: E402
 import bench  # noqa: E402
 from omg_planner_amd import _lib  # noqa: E402
 
-_lib.LIB_PATH = ROOT / "omg-planner_amd" / "csrc" / "libomg_hip_clk.so"
+import os
+_lib.LIB_PATH = ROOT / "omg-planner_amd" / "csrc" / os.environ.get("OMGX_CLK_LIB", "libomg_hip_clk.so")  # experiment variants of the instrumented build
 from omg_planner_amd.engine import ChompEngine  # noqa: E402
 
 def main():
