@@ -57,7 +57,7 @@ struct GqLayout {
         total = stage_off + 4 * 64 * 16;
         // the (sin, cos) table of the kinematics [PS][7][2] doubles borrows the queues' region (first used in the main loop), so
         // that the records and collision points can be staged while the kinematics run
-        const int fk = stage_off + PS * 14 * 8;
+        const int fk = stage_off + PS * 14 * 8 + 16;  // + the chain waves' progress flags (4 words)
         if (total < fk) total = fk;
     }
 };
@@ -147,6 +147,34 @@ __global__ __launch_bounds__(256, GQ_WG_PER_CU) void k_goalset_queue(ChunkArgs a
     double* const pts = reinterpret_cast<double*>(lds_bytes + L.pts_off);          // [10][P][3]
     float* const stage = reinterpret_cast<float*>(lds_bytes + L.stage_off) + wave * 256;  // wave-private [64][4]
 
+    // Row-level culling of row (link l, configuration ci): the link's bounding ball against every object's influence region
+    // -> bit mask of the objects in reach (objects >= 31 share the last bit).
+    auto cull_row = [&](int l, int ci) {
+        const double* A = lds_pose + 9 + ((int64_t)l * pstride + ci) * 9;
+        const float cx = (float)A[6], cy = (float)A[7], cz = (float)A[8];
+        const float rad = (float)rv.radius(l) + 1.0e-4f;
+        uint32_t m = 0;
+        for (int o = o_begin; o < o_end; ++o) {
+            ObjTablePtr ob = as_const(a.objects) + o;
+            if (ob->disabled > 0) continue;
+            const int oo = o - o_begin;
+            const uint32_t bit = 1u << (oo < 31 ? oo : 31);
+            const float ux = __builtin_fmaf(ob->pose_inv[2], cz, __builtin_fmaf(ob->pose_inv[1], cy, __builtin_fmaf(ob->pose_inv[0], cx, ob->pose_inv[3]))) - ob->lo[0];
+            const float uy = __builtin_fmaf(ob->pose_inv[6], cz, __builtin_fmaf(ob->pose_inv[5], cy, __builtin_fmaf(ob->pose_inv[4], cx, ob->pose_inv[7]))) - ob->lo[1];
+            const float uz = __builtin_fmaf(ob->pose_inv[10], cz, __builtin_fmaf(ob->pose_inv[9], cy, __builtin_fmaf(ob->pose_inv[8], cx, ob->pose_inv[11]))) - ob->lo[2];
+            const float rbc[3] = {ob->rb_c[0], ob->rb_c[1], ob->rb_c[2]}, rbh[3] = {ob->rb_h[0], ob->rb_h[1], ob->rb_h[2]};
+            const bool near = rbox_near(ux, uy, uz, rad, rbc, rbh, ob->rb_r);
+            const bool cullable = ob->epsilon < 1.0f && ob->clearance <= 1.0f;
+            if (near || !cullable) m |= bit;
+        }
+        rowmask[l * CH + ci] = m;
+    };
+    // The chain stage of the kinematics keeps ceil(3 (CH + 1) / 64) waves busy (one lane per (configuration, pose row)) and
+    // produces the links' poses in order; the other waves cull the rows of a link as soon as every chain wave has published
+    // it (a progress word per chain wave in LDS, release / acquire at workgroup scope): the culling stage disappears behind
+    // the chain.  With 64 waypoints all four waves run the chain and the rows are culled afterwards.
+    const int chain_waves = (3 * (CH + 1) + 63) >> 6;
+    const bool cull_beside_chain = chain_waves < 4;
     {   // Kinematics of the start + CH interpolated configurations in two stages (omg_device.h: fk_joint_sincos on
         // (configuration, joint) lanes, fk_chain_row on (configuration, pose row) lanes); the (sin, cos) table borrows the
         // region behind the poses, which is first written after the barriers below.
@@ -156,6 +184,8 @@ __global__ __launch_bounds__(256, GQ_WG_PER_CU) void k_goalset_queue(ChunkArgs a
         const double* qg = a.goals + ((int64_t)s * a.NCH + chunk) * 9;
         const int ncfg = CH + 1;
         double* sc = reinterpret_cast<double*>(lds_bytes + L.stage_off);  // [ncfg][7][2]: the queues' region, first used in the main loop
+        int* const progress = reinterpret_cast<int*>(lds_bytes + L.stage_off + pstride * 14 * 8);  // [4] links a chain wave has published
+        if (tid < 4) progress[tid] = tid < chain_waves ? 0 : 99;
         // the robot's collision points -> LDS: the loads are issued here and land while the (sin, cos) stage runs
         const double pv0 = tid < 30 * P ? rv.g[246 + tid] : 0.0, pv1 = tid + 256 < 30 * P ? rv.g[246 + tid + 256] : 0.0;
         auto joint = [&](int cfg, int d) { return cfg == 0 ? q0[d] : q0[d] + ((double)cfg * (1.0 / (double)(CH + 1))) * (qg[d] - q0[d]); };
@@ -193,35 +223,34 @@ __global__ __launch_bounds__(256, GQ_WG_PER_CU) void k_goalset_queue(ChunkArgs a
                 double* dst = lds_pose + ((size_t)l * pstride + cfg) * 9;  // rows 0 and 1 of R, then t
                 if (rr < 2) { dst[3 * rr] = r0; dst[3 * rr + 1] = r1; dst[3 * rr + 2] = r2; }
                 dst[6 + rr] = tr;
+                // link l of this wave's configurations is in LDS (a wave's LDS operations execute in order; the release keeps the
+                // compiler from moving the flag ahead of the pose)
+                if (lane == 0) __hip_atomic_store(progress + wave, l + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             });
+        }
+        if (cull_beside_chain && wave >= chain_waves) {
+            for (int l = wave - chain_waves; l < 10; l += 4 - chain_waves) {
+                for (;;) {  // every lane reads the same words: broadcast
+                    int done = 99;
+                    for (int w = 0; w < chain_waves; ++w) {
+                        const int d = __hip_atomic_load(progress + w, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        done = d < done ? d : done;
+                    }
+                    if (done > l) break;
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                for (int ci = lane; ci < CH; ci += 64) cull_row(l, ci);
+            }
         }
     }
     __syncthreads();
     GS_WG_STAMP(2);
     const double* base = lds_pose + 9;
 
-    for (int row = tid; row < 10 * CH; row += 256) {  // row-level culling (see k_sdf_chunks)
-        const int l = row / CH, ci = row - l * CH;
-        const double* A = base + ((int64_t)l * pstride + ci) * 9;
-        const float cx = (float)A[6], cy = (float)A[7], cz = (float)A[8];
-        const float rad = (float)rv.radius(l) + 1.0e-4f;
-        uint32_t m = 0;
-        for (int o = o_begin; o < o_end; ++o) {
-            ObjTablePtr ob = as_const(a.objects) + o;
-            if (ob->disabled > 0) continue;
-            const int oo = o - o_begin;
-            const uint32_t bit = 1u << (oo < 31 ? oo : 31);
-            const float ux = __builtin_fmaf(ob->pose_inv[2], cz, __builtin_fmaf(ob->pose_inv[1], cy, __builtin_fmaf(ob->pose_inv[0], cx, ob->pose_inv[3]))) - ob->lo[0];
-            const float uy = __builtin_fmaf(ob->pose_inv[6], cz, __builtin_fmaf(ob->pose_inv[5], cy, __builtin_fmaf(ob->pose_inv[4], cx, ob->pose_inv[7]))) - ob->lo[1];
-            const float uz = __builtin_fmaf(ob->pose_inv[10], cz, __builtin_fmaf(ob->pose_inv[9], cy, __builtin_fmaf(ob->pose_inv[8], cx, ob->pose_inv[11]))) - ob->lo[2];
-            const float rbc[3] = {ob->rb_c[0], ob->rb_c[1], ob->rb_c[2]}, rbh[3] = {ob->rb_h[0], ob->rb_h[1], ob->rb_h[2]};
-            const bool near = rbox_near(ux, uy, uz, rad, rbc, rbh, ob->rb_r);
-            const bool cullable = ob->epsilon < 1.0f && ob->clearance <= 1.0f;
-            if (near || !cullable) m |= bit;
-        }
-        rowmask[row] = m;
+    if (!cull_beside_chain) {
+        for (int row = tid; row < 10 * CH; row += 256) cull_row(row / CH, row - (row / CH) * CH);
+        __syncthreads();
     }
-    __syncthreads();
     GS_WG_STAMP(3);
 
     // ---- the wave's queue.  Pending entries (object-space offset, weight) sit in the wave's LDS ring `stage`, slot i = entry i,
