@@ -260,6 +260,43 @@ int omgx_goalset_cost_layer(const double* robot, int32_t n_points,
                             const int32_t* schedule, int32_t schedule_len, uint32_t* work, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * (3c) omgx_goalset_cost_layer_tiled — the same launch cut into more, smaller workgroups: LATENCY mode (ABI 6)
+ * For one or a few scenes (BASELINE configs 1-2: one scene x 64 goals, omg/planner.py:600-653 one plan at a time) the batch
+ * layout of (3b) — one workgroup per goal, five per trajectory layer, a scene per XCD — leaves most of the chip idle behind a
+ * few long workgroups.  This entry point runs the same arithmetic per (point, object) pair with
+ *   goal_parts          1, 2, 4 or 8: a goal's TILES (4 waypoints x 2 links) are dealt over NP = omgx_goalset_parts(n_remaining,
+ *                       goal_parts) workgroups — the largest power of two <= goal_parts that leaves each at least 4 of the
+ *                       ceil(n_remaining / 4) x 5 tiles; part p takes the tiles t with t % NP == p, so the heavy ones (last waypoints,
+ *                       hand links) spread evenly — each running the kinematics of all configurations (the chain's latency does not
+ *                       depend on their number).  goal_cost / collides are then [S][G][NP] PARTIAL sums and the goal's cost is
+ *                       their float32 sum in part order — omgx_goal_update(_optimize) adds them when
+ *                       omgx_learner_params.cost_parts = NP.  A goal's cost differs from (3b)'s by the rounding of a float32 sum
+ *                       taken in another order (~1e-7 relative); everything else is bit-identical.  More than one part needs `spread`.
+ *   layer_link_groups   1, 2, 5 or 10 and
+ *   layer_config_block  b >= 0: the trajectory layer of a scene is computed by layer_link_groups x ceil(n_waypoints / b)
+ *                       workgroups (10 / layer_link_groups links x b waypoints each; 0 = all waypoints).  Layer outputs do not
+ *                       depend on the split (every element is computed on its own).
+ *   spread              non-zero: the latency-mode kernel — workgroups in plain (scene, item) order over all XCDs instead of a scene
+ *                       per XCD, the kinematic chain's constants staged in LDS (a workgroup alone on a cold CU otherwise pays a
+ *                       scalar-cache miss per joint).
+ * num_goals = 0 (goals, traj_start, goal_cost NULL): only the trajectory layer (what omgx_fk_sdf computes for the step);
+ * traj = NULL: only the goal-set batch (what omgx_goalset_cost computes, as partial sums).
+ * No dispatch schedule / work counters here (they order whole goals, a scene per XCD).
+ * ------------------------------------------------------------------------------------------- */
+int32_t omgx_goalset_parts(int32_t n_remaining, int32_t goal_parts);
+int omgx_goalset_cost_layer_tiled(const double* robot, int32_t n_points,
+                                  const omgx_object* objects, const int32_t* scene_begin, const float* sdf_pool,
+                                  const double* traj_start, int64_t traj_start_stride, const double* goals,
+                                  int32_t num_scenes, int32_t num_goals, int32_t n_remaining,
+                                  double time_interval, int32_t soften_fingers,
+                                  float* goal_cost, float* collides,
+                                  const double* traj, int32_t n_waypoints, int32_t layer_soften_fingers,
+                                  float* layer_potentials, float* layer_grads, float* layer_collides,
+                                  const int32_t* active, const int32_t* goal_count,
+                                  int32_t goal_parts, int32_t layer_link_groups, int32_t layer_config_block,
+                                  int32_t spread, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * (4) omgx_chomp_optimize
  * Replaces one Optimizer.optimize step (omg/optimizer.py:115-135) for S independent trajectories:
  * Cost.compute_total_loss (omg/cost.py:451-532) = compute_smooth_loss (425-449) +
@@ -329,7 +366,7 @@ typedef struct omgx_learner_params {
     int32_t constraint_num;  /* c rows of goal_rows: reach_tail_length if use_standoff else 1        */
     int32_t use_standoff;    /* goal_rows from `reach` instead of goal_set                           */
     int32_t normalize_cost;  /* cfg.normalize_cost                                                  */
-    int32_t reserved;
+    int32_t cost_parts;      /* goal_cost holds this many partial sums per goal, [S][G][cost_parts] (omgx_goalset_cost_layer_tiled); 0 or 1: one */
     double base_obstacle_weight; /* cfg.base_obstacle_weight                                        */
     double smooth_weight;        /* cfg.smoothness_base_weight * cfg.dist_eps                       */
     double eta;                  /* sqrt(log(G + 1) / optim_steps), online_learner.py:80            */

@@ -15,11 +15,11 @@ LIB_PATH = _CSRC / "libomg_hip.so"
 OMGX_OK, OMGX_ERR_INVALID, OMGX_ERR_LAUNCH, OMGX_ERR_UNSUPPORTED = 0, -1, -2, -3
 NUM_DOF, INFO_STRIDE = 9, 16
 SCHEDULE_MAX_SCENES = 1792  # OMGX_SCHEDULE_MAX_SCENES
-ABI_VERSION = 5  # omgx_abi_version() of the library these argtypes describe
+ABI_VERSION = 6  # omgx_abi_version() of the library these argtypes describe
 
 # every symbol include/omg_hip.h declares
 EXPORTS = ["omgx_sdf_loss_forward", "omgx_fk_sdf_workspace_bytes", "omgx_fk_sdf", "omgx_forward_kinematics",
-           "omgx_goalset_workspace_bytes", "omgx_goalset_cost", "omgx_goalset_cost_layer", "omgx_goalset_schedule_len", "omgx_goalset_schedule", "omgx_chomp_aux_doubles", "omgx_chomp_optimize",
+           "omgx_goalset_workspace_bytes", "omgx_goalset_cost", "omgx_goalset_cost_layer", "omgx_goalset_parts", "omgx_goalset_cost_layer_tiled", "omgx_goalset_schedule_len", "omgx_goalset_schedule", "omgx_chomp_aux_doubles", "omgx_chomp_optimize",
            "omgx_learner_state_doubles", "omgx_goal_update", "omgx_goal_update_optimize", "omgx_point_cloud_sdf", "omgx_last_error", "omgx_abi_version", "omgx_device_arch",
            "omgx_timing_enable", "omgx_timing_collect"]
 
@@ -41,7 +41,7 @@ class ChompParams(C.Structure):
 class LearnerParams(C.Structure):
     """Mirror of `omgx_learner_params` (include/omg_hip.h)."""
     _fields_ = [(n, C.c_int32) for n in ("alg", "num_goals", "n_waypoints", "start_idx", "constraint_num", "use_standoff",
-                                          "normalize_cost", "reserved")] + [(n, C.c_double) for n in (
+                                          "normalize_cost", "cost_parts")] + [(n, C.c_double) for n in (
         "base_obstacle_weight", "smooth_weight", "eta")]
 
 
@@ -78,6 +78,10 @@ def lib() -> C.CDLL:
         l.omgx_goalset_cost.argtypes = [vp, i32, vp, vp, vp, vp, i64, vp, i32, i32, i32, f64, i32, vp, vp, vp, vp, vp, vp, vp]
         l.omgx_goalset_cost_layer.argtypes = [vp, i32, vp, vp, vp, vp, i64, vp, i32, i32, i32, f64, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp]
         l.omgx_goalset_cost_layer.restype = C.c_int
+        l.omgx_goalset_parts.argtypes = [i32, i32]
+        l.omgx_goalset_parts.restype = i32
+        l.omgx_goalset_cost_layer_tiled.argtypes = [vp, i32, vp, vp, vp, vp, i64, vp, i32, i32, i32, f64, i32, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+        l.omgx_goalset_cost_layer_tiled.restype = C.c_int
         l.omgx_goalset_schedule_len.argtypes = [i32, i32, i32]
         l.omgx_goalset_schedule_len.restype = i32
         l.omgx_goalset_schedule.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp]

@@ -327,6 +327,25 @@ __device__ __forceinline__ Accum sdf_point(const omgx_object* __restrict__ objs,
 //   D+246+30P AX [10][3]    tip2joint[l][:3,:3] . joint_axis[l]                  (:190-197)
 //   D+276+30P OG [10][3]    tip2joint[l][:3,3]
 //   D+306+30P RAD [10]      bounding-sphere radius of each link's centred points
+// Latency mode: a workgroup alone on a cold CU takes its scalar-cache misses one after the other — the culling stage's object loop
+// needs two dependent round trips per object (the `disabled` flag, then the record): 5 objects = 7 us of an 8 us stage, measured.
+// gq_warm_scalar_cache requests every 64-byte line of up to 8 object records and of the links' radii through the scalar cache AT ONCE
+// and waits for them (one round trip, taken while the workgroup's first vector loads are in flight anyway).  One asm statement:
+// the loads' throw-away targets are clobbers, and nothing of it is in flight when it ends (the compiler neither tracks inline-asm
+// loads nor knows when a scalar load lands).
+__device__ __forceinline__ void gq_warm_scalar_cache(const omgx_object* objects, int o_begin, int o_end, const double* radii) {
+    const omgx_object* ob[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ob[k] = objects + (o_begin + k < o_end ? o_begin + k : o_end - 1);  // fewer than 8: the last one again (a hit)
+#define OMG_WARM_OBJ(N) "s_load_dword s96, %" #N ", 0x0\n\ts_load_dword s97, %" #N ", 0x40\n\ts_load_dword s98, %" #N ", 0x80\n\ts_load_dword s99, %" #N ", 0xb4\n\t"
+    asm volatile(OMG_WARM_OBJ(0) OMG_WARM_OBJ(1) OMG_WARM_OBJ(2) OMG_WARM_OBJ(3) OMG_WARM_OBJ(4) OMG_WARM_OBJ(5) OMG_WARM_OBJ(6) OMG_WARM_OBJ(7)
+                 "s_load_dword s96, %8, 0x0\n\ts_load_dword s97, %8, 0x4c\n\ts_waitcnt lgkmcnt(0)"
+                 :
+                 : "s"(ob[0]), "s"(ob[1]), "s"(ob[2]), "s"(ob[3]), "s"(ob[4]), "s"(ob[5]), "s"(ob[6]), "s"(ob[7]), "s"(radii)
+                 : "s96", "s97", "s98", "s99", "memory");
+#undef OMG_WARM_OBJ
+}
+
 // DPtr = pointer type of the derived constants: plain global memory, a copy elsewhere (LDS), or the CONSTANT address space —
 // then wave-uniform reads (the chain constants of joint i, the hand / finger rows, radii) become scalar loads into SGPRs
 // instead of per-lane vector loads of the same address (measured in the goal-set kernel's kinematics: the vector loads and

@@ -48,8 +48,8 @@ __device__ __forceinline__ GqFar gq_load_far(ObjTablePtr ob) {
 
 // dynamic LDS behind the poses (bytes, all 16-byte aligned): row masks | exact-path records | collision points | staging
 struct GqLayout {
-    int mask_off, tbl_off, pts_off, stage_off, total;
-    __host__ __device__ GqLayout(int PS, int MR, int P, int tbl_n) {
+    int mask_off, tbl_off, pts_off, stage_off, fkc_off, total;
+    __host__ __device__ GqLayout(int PS, int MR, int P, int tbl_n, bool with_fkc = false) {
         mask_off = PS * 90 * 8;
         tbl_off = mask_off + ((10 * MR * 4 + 15) & ~15);
         pts_off = tbl_off + tbl_n * 64;
@@ -59,15 +59,18 @@ struct GqLayout {
         // that the records and collision points can be staged while the kinematics run
         const int fk = stage_off + PS * 14 * 8 + 16;  // + the chain waves' progress flags (4 words)
         if (total < fk) total = fk;
+        total = (total + 15) & ~15;
+        fkc_off = total;  // latency mode: the kinematic chain's 246 constants (RobotViewT::uvw .. rf)
+        if (with_fkc) total += 246 * 8;
     }
 };
 
 // How many exact-path records to stage: as many as still fit the LDS of the occupancy step the launch is on anyway.  The steps
 // are what a CU admits (tools/lds_occupancy_probe.hip: 6 workgroups up to 26 624 B, 5 up to 31 744 B, 4 up to 40 960 B — at
 // 32 768 B the occupancy API still says 5 but only 4 become resident).
-static inline int gq_choose_tbl_n(int PS, int MR, int P) {
+static inline int gq_choose_tbl_n(int PS, int MR, int P, bool with_fkc = false) {
     static const int step[] = {26624, 31744, 40960, 53248, 80896, 163840};
-    const int base = GqLayout(PS, MR, P, 0).total;
+    const int base = GqLayout(PS, MR, P, 0, with_fkc).total;
     for (int k = 0; k < 6; ++k)
         if (base + 4 * 64 <= step[k]) {  // at least 4 records
             const int n = (step[k] - base) / 64;
@@ -76,30 +79,74 @@ static inline int gq_choose_tbl_n(int PS, int MR, int P) {
     return 0;
 }
 
-template <int LB, bool STAMP = false>
+struct GqTblRec { double rw[3]; int32_t dim[3]; int64_t goffb; float eps, clr, pad, i2e; };
+__device__ __forceinline__ GqTblRec gq_tbl_load(const omgx_object* ob) {
+    GqTblRec r;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { r.rw[k] = ob->inv_extent[k]; r.dim[k] = ob->dim[k]; }
+    r.goffb = ob->grid_offset * 4;
+    r.eps = ob->epsilon; r.clr = ob->clearance; r.pad = ob->padding_scale; r.i2e = ob->inv_2eps;
+    return r;
+}
+// record (16 dwords): [0..5] 1 / extent as doubles | [6..8] dims | [9,10] byte offset of the grid in the pool |
+//                     [11] eps / 2 | [12] eps | [13] clearance | [14] padding scale | [15] 1 / (2 eps)
+__device__ __forceinline__ void gq_tbl_store(uint32_t* e, const GqTblRec& r) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        e[2 * k] = (uint32_t)__double2loint(r.rw[k]); e[2 * k + 1] = (uint32_t)__double2hiint(r.rw[k]);
+        e[6 + k] = (uint32_t)r.dim[k];
+    }
+    e[9] = (uint32_t)(r.goffb & 0xffffffffll); e[10] = (uint32_t)(r.goffb >> 32);
+    e[11] = __float_as_uint(0.5f * r.eps);  // exact: (double)(0.5f * eps) == 0.5 * (double)eps
+    e[12] = __float_as_uint(r.eps); e[13] = __float_as_uint(r.clr);
+    e[14] = __float_as_uint(r.pad); e[15] = __float_as_uint(r.i2e);
+}
+
+// LAT: the latency-mode variant (omgx_goalset_cost_layer_tiled with `spread`): workgroups in plain (scene, item) order over all
+// XCDs, a goal's tiles dealt over a.NP workgroups, the kinematic chain's constants staged in LDS (a workgroup alone on a cold
+// CU pays a scalar-cache miss per joint otherwise: 6.5 us of chain for 9 configurations, measured).  LAT = false compiles to
+// exactly the batch kernel.
+template <int LB, bool STAMP = false, bool LAT = false>
 __global__ __launch_bounds__(256, GQ_WG_PER_CU) void k_goalset_queue(ChunkArgs a) {
     extern __shared__ __attribute__((aligned(16))) double lds_pose[];  // no static LDS: 31744 B is the most a workgroup may use at 5 per CU
     GS_WG_STAMP(0);
     const int xcd = blockIdx.x & 7;
-    // with a trajectory layer, GS_LAYER_PARTS workgroups per scene (10 / GS_LAYER_PARTS links each) compute it; those lead the grid
+    // with a trajectory layer, a.layer_parts workgroups per scene compute it (a.layer_lg link groups x a.layer_nb blocks of a.layer_cb
+    // configurations: 5 x 1 in a batch, finer in latency mode); those lead the grid
     // (at the end of the grid, as fillers of the launch's tail, they cost 3 %: measured)
-    const int nlayer = a.wp_traj ? ((a.S + 7) >> 3) * GS_LAYER_PARTS : 0;
-    const bool is_layer = (int)(blockIdx.x >> 3) < nlayer;
-    const int j = (int)(blockIdx.x >> 3) - nlayer;
-    const int sgrp = is_layer ? (int)(blockIdx.x >> 3) / GS_LAYER_PARTS : j / a.NCH;
-    const int layer_part = (int)(blockIdx.x >> 3) - sgrp * GS_LAYER_PARTS;
-    int s = sgrp * 8 + xcd;
-    int chunk = is_layer ? 0 : j - sgrp * a.NCH;
-    const bool scheduled = a.schedule && !is_layer;
-    if (scheduled) {  // goal workgroup b of the launch works on item schedule[b] (ChunkArgs)
-        const int item = as_const(a.schedule)[(int)blockIdx.x - nlayer * 8];
-        if (item < 0 || item >= a.S * a.NCH) return;
-        s = item / a.NCH;
-        chunk = item - s * a.NCH;
-        if (a.active && as_const(a.active)[s] == 0) { if (STAMP && threadIdx.x == 0) a.work[item] = 0u; return; }
+    const int LPARTS = a.layer_parts;
+    const bool spread = LAT;
+    const int NP = LAT ? a.NP : 1;
+    bool is_layer;
+    int s, chunk, layer_part;
+    bool scheduled = false;
+    if (spread) {
+        // latency mode (a handful of scenes): workgroup b -> (scene, item) in plain order, the scene's workgroups spread over all XCDs
+        const int nl = a.wp_traj ? a.S * LPARTS : 0;
+        is_layer = (int)blockIdx.x < nl;
+        const int j = (int)blockIdx.x - nl;
+        s = is_layer ? (int)blockIdx.x / LPARTS : j / a.NCH;
+        layer_part = (int)blockIdx.x - s * LPARTS;
+        chunk = is_layer ? 0 : j - s * a.NCH;
+    } else {
+        const int nlayer = a.wp_traj ? ((a.S + 7) >> 3) * LPARTS : 0;
+        is_layer = (int)(blockIdx.x >> 3) < nlayer;
+        const int j = (int)(blockIdx.x >> 3) - nlayer;
+        const int sgrp = is_layer ? (int)(blockIdx.x >> 3) / LPARTS : j / a.NCH;
+        layer_part = (int)(blockIdx.x >> 3) - sgrp * LPARTS;
+        s = sgrp * 8 + xcd;
+        chunk = is_layer ? 0 : j - sgrp * a.NCH;
+        scheduled = a.schedule && !is_layer;
+        if (scheduled) {  // goal workgroup b of the launch works on item schedule[b] (ChunkArgs)
+            const int item = as_const(a.schedule)[(int)blockIdx.x - nlayer * 8];
+            if (item < 0 || item >= a.S * a.NCH) return;
+            s = item / a.NCH;
+            chunk = item - s * a.NCH;
+            if (a.active && as_const(a.active)[s] == 0) { if (STAMP && threadIdx.x == 0) a.work[item] = 0u; return; }
+        }
     }
     if (s >= a.S) return;
-    if (a.active && !scheduled) {
+    if (a.active && !scheduled && !spread) {
         // Scenes the planner has left (planner.py:626) get no workgroups, and the remaining ones are dealt out again so that
         // every XCD keeps an equal share: slot k = sgrp * 8 + xcd works on the k-th ACTIVE scene (ascending).  Every wave
         // finds it by itself with ballots over the mask (S / 64 steps, wave-uniform): no barrier, no extra launch, same
@@ -121,23 +168,35 @@ __global__ __launch_bounds__(256, GQ_WG_PER_CU) void k_goalset_queue(ChunkArgs a
         }
     }
     if (s < 0) return;  // fewer active scenes than slots
+    if (spread && a.active && as_const(a.active)[s] == 0) return;
     const int o_begin = as_const(a.scene_begin)[s], o_end = as_const(a.scene_begin)[s + 1];
-    const int P = a.P, CH = a.CH;
+    const int P = a.P;
+    // LAT: the scene's object records and the links' radii into the scalar cache, asynchronously (consumed after the (sin, cos) stage)
+    const bool warming = LAT && o_end > o_begin;
+    // A goal's TILES may be dealt over a.NP workgroups (latency mode): chunk = goal * NP + part, part takes the tiles t with
+    // t % NP == part — (waypoint block + link pair) % NP for NP = 2, 4: the heavy tiles (last waypoints, hand links) are spread
+    // evenly — and runs the kinematics of all configurations itself (the chain's latency does not depend on their number).
+    const int goal = NP > 1 ? chunk / NP : chunk;
+    const int part = NP > 1 ? chunk - goal * NP : 0;
+    const int CH = a.CH;
     const int p = threadIdx.x & 15, lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // provably wave-uniform: tile indices and their address arithmetic stay on the scalar unit
     const int tid = (int)threadIdx.x;
     const RobotViewS rv(a.robot, P);
     const int pstride = a.PS, MR = a.MR;
-    const GqLayout L(pstride, MR, P, a.tbl_n);
+    const GqLayout L(pstride, MR, P, a.tbl_n, LAT);
     char* const lds_bytes = reinterpret_cast<char*>(lds_pose);
     uint32_t* const rowmask = reinterpret_cast<uint32_t*>(lds_bytes + L.mask_off);
     if (is_layer) {
-        waypoint_layer_block(a, s, layer_part * (10 / GS_LAYER_PARTS), (layer_part + 1) * (10 / GS_LAYER_PARTS), lds_pose, rowmask, o_begin,
-                             o_end, rv);
+        const int lgi = a.layer_nb > 1 ? layer_part / a.layer_nb : layer_part, cbi = layer_part - lgi * a.layer_nb;
+        const int lpg = 10 / a.layer_lg, c_begin = cbi * a.layer_cb;
+        const int c_end = c_begin + a.layer_cb < a.wp_n ? c_begin + a.layer_cb : a.wp_n;
+        waypoint_layer_block<LAT>(a, s, lgi * lpg, (lgi + 1) * lpg, c_begin, c_end, lds_pose, rowmask, o_begin, o_end, rv,
+                                  reinterpret_cast<double*>(lds_bytes + L.fkc_off), warming);
         GS_WG_STAMP(4);
         return;
     }
-    if (a.goal_count && chunk >= as_const(a.goal_count)[s]) {  // padding of a ragged goal set
+    if (a.goal_count && goal >= as_const(a.goal_count)[s]) {  // padding of a ragged goal set
         if (STAMP && tid == 0) a.work[(int64_t)s * a.NCH + chunk] = 0u;
         return;
     }
@@ -174,20 +233,26 @@ __global__ __launch_bounds__(256, GQ_WG_PER_CU) void k_goalset_queue(ChunkArgs a
     // it (a progress word per chain wave in LDS, release / acquire at workgroup scope): the culling stage disappears behind
     // the chain.  With 64 waypoints all four waves run the chain and the rows are culled afterwards.
     const int chain_waves = (3 * (CH + 1) + 63) >> 6;
-    const bool cull_beside_chain = chain_waves < 4;
+    const bool cull_beside_chain = !LAT && chain_waves < 4;  // LAT: every wave culls the rows of its own tiles after the chain (below)
     {   // Kinematics of the start + CH interpolated configurations in two stages (omg_device.h: fk_joint_sincos on
         // (configuration, joint) lanes, fk_chain_row on (configuration, pose row) lanes); the (sin, cos) table borrows the
         // region behind the poses, which is first written after the barriers below.
         // cfg 0 = start itself, cfg i+1 = linspace(0,1,n+2)[1:-1][i]: numpy's linspace is i * step with step = fl(1 / (n + 1)),
         // not i / (n + 1) — bit-identical to util.py:261-290 (interp1d)
         const double* q0 = a.traj_start + a.ts_stride * (int64_t)s;
-        const double* qg = a.goals + ((int64_t)s * a.NCH + chunk) * 9;
+        const double* qg = a.goals + ((int64_t)s * a.NG + goal) * 9;
         const int ncfg = CH + 1;
         double* sc = reinterpret_cast<double*>(lds_bytes + L.stage_off);  // [ncfg][7][2]: the queues' region, first used in the main loop
         int* const progress = reinterpret_cast<int*>(lds_bytes + L.stage_off + pstride * 14 * 8);  // [4] links a chain wave has published
         if (tid < 4) progress[tid] = tid < chain_waves ? 0 : 99;
         // the robot's collision points -> LDS: the loads are issued here and land while the (sin, cos) stage runs
         const double pv0 = tid < 30 * P ? rv.g[246 + tid] : 0.0, pv1 = tid + 256 < 30 * P ? rv.g[246 + tid + 256] : 0.0;
+        double* const fkc = reinterpret_cast<double*>(lds_bytes + L.fkc_off);  // LAT: the chain's constants, one coalesced load
+        const double fkv = (LAT && tid < 246) ? rv.g[tid] : 0.0;
+        const bool tbl_lane = tid >= 128 && tid - 128 < a.tbl_n && o_begin + tid - 128 < o_end;  // lanes of wave 2: idle during the chain stage
+        GqTblRec trec{};
+        if (LAT && tbl_lane) trec = gq_tbl_load(a.objects + o_begin + (tid - 128));  // LAT: requested here, stored after the barrier
+        if (warming) gq_warm_scalar_cache(a.objects, o_begin, o_end, a.robot + OMGX_ROBOT_POINTS + 30 * P + 306 + 30 * P);
         auto joint = [&](int cfg, int d) { return cfg == 0 ? q0[d] : q0[d] + ((double)cfg * (1.0 / (double)(CH + 1))) * (qg[d] - q0[d]); };
         for (int t = tid; t < ncfg * 7; t += 256) {
             const int cfg = t / 7, i = t - cfg * 7;
@@ -195,39 +260,31 @@ __global__ __launch_bounds__(256, GQ_WG_PER_CU) void k_goalset_queue(ChunkArgs a
             fk_joint_sincos(joint(cfg, i), sn, cs);
             sc[2 * t] = sn; sc[2 * t + 1] = cs;
         }
+        if (LAT && tid < 246) fkc[tid] = fkv;
         __syncthreads();
         GS_WG_STAMP(1);
         if (tid < 30 * P) pts[tid] = pv0;
         if (tid + 256 < 30 * P) pts[tid + 256] = pv1;
         // ---- exact-path records of the scene's first a.tbl_n objects -> LDS, by lanes of wave 2 (idle during the chain stage)
-        // record (16 dwords): [0..5] 1 / extent as doubles | [6..8] dims | [9,10] byte offset of the grid in the pool |
-        //                     [11] eps / 2 | [12] eps | [13] clearance | [14] padding scale | [15] 1 / (2 eps)
-        if (tid >= 128 && tid - 128 < a.tbl_n && o_begin + tid - 128 < o_end) {
-            const omgx_object* ob = a.objects + o_begin + (tid - 128);
-            uint32_t* e = tbl + (tid - 128) * 16;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const double rw = ob->inv_extent[k];
-                e[2 * k] = (uint32_t)__double2loint(rw); e[2 * k + 1] = (uint32_t)__double2hiint(rw);
-                e[6 + k] = (uint32_t)ob->dim[k];
+        if (tbl_lane) {
+            if (!LAT) trec = gq_tbl_load(a.objects + o_begin + (tid - 128));
+            gq_tbl_store(tbl + (tid - 128) * 16, trec);
+        }
+        auto run_chain = [&](const auto& view) {
+            for (int t = tid; t < ncfg * 3; t += 256) {
+                const int cfg = t / 3, rr = t - cfg * 3;
+                fk_chain_row(view, rr, sc + 14 * cfg, joint(cfg, 7), joint(cfg, 8), [&](int l, double r0, double r1, double r2, double tr) {
+                    double* dst = lds_pose + ((size_t)l * pstride + cfg) * 9;  // rows 0 and 1 of R, then t
+                    if (rr < 2) { dst[3 * rr] = r0; dst[3 * rr + 1] = r1; dst[3 * rr + 2] = r2; }
+                    dst[6 + rr] = tr;
+                    // link l of this wave's configurations is in LDS (a wave's LDS operations execute in order; the release keeps the
+                    // compiler from moving the flag ahead of the pose)
+                    if (lane == 0) __hip_atomic_store(progress + wave, l + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                });
             }
-            const int64_t goffb = ob->grid_offset * 4;
-            e[9] = (uint32_t)(goffb & 0xffffffffll); e[10] = (uint32_t)(goffb >> 32);
-            e[11] = __float_as_uint(0.5f * ob->epsilon);  // exact: (double)(0.5f * eps) == 0.5 * (double)eps
-            e[12] = __float_as_uint(ob->epsilon); e[13] = __float_as_uint(ob->clearance);
-            e[14] = __float_as_uint(ob->padding_scale); e[15] = __float_as_uint(ob->inv_2eps);
-        }
-        for (int t = tid; t < ncfg * 3; t += 256) {
-            const int cfg = t / 3, rr = t - cfg * 3;
-            fk_chain_row(rv, rr, sc + 14 * cfg, joint(cfg, 7), joint(cfg, 8), [&](int l, double r0, double r1, double r2, double tr) {
-                double* dst = lds_pose + ((size_t)l * pstride + cfg) * 9;  // rows 0 and 1 of R, then t
-                if (rr < 2) { dst[3 * rr] = r0; dst[3 * rr + 1] = r1; dst[3 * rr + 2] = r2; }
-                dst[6 + rr] = tr;
-                // link l of this wave's configurations is in LDS (a wave's LDS operations execute in order; the release keeps the
-                // compiler from moving the flag ahead of the pose)
-                if (lane == 0) __hip_atomic_store(progress + wave, l + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            });
-        }
+        };
+        if constexpr (LAT) run_chain(RobotView(a.robot, P, fkc));  // constants from LDS
+        else run_chain(rv);                                          // constants through the scalar cache (warm in a batch)
         if (cull_beside_chain && wave >= chain_waves) {
             for (int l = wave - chain_waves; l < 10; l += 4 - chain_waves) {
                 for (;;) {  // every lane reads the same words: broadcast
@@ -247,7 +304,20 @@ __global__ __launch_bounds__(256, GQ_WG_PER_CU) void k_goalset_queue(ChunkArgs a
     GS_WG_STAMP(2);
     const double* base = lds_pose + 9;
 
-    if (!cull_beside_chain) {
+    static_assert(LB == 2 || !LAT, "the latency-mode culling maps 8 lanes to a tile of 4 waypoints x 2 links");
+    if (LAT) {
+        // A pass over a link's rows costs the latency of its object loop whatever the number of lanes in it (~1 us for a lone wave:
+        // beside the chain, 5 links per culling wave were the longest thing in the prologue).  Here every wave culls exactly the rows
+        // its own tiles will read — lane -> (tile slot, link of the pair, waypoint of the block), normally one pass — and goes on
+        // to its main loop without a barrier (its own LDS writes, in order).
+        const int ntl = ((CH + 3) >> 2) * (10 / LB);
+        for (int j0 = 0;; j0 += 8) {
+            const int t = part + NP * (wave + 4 * (j0 + (lane >> 3)));
+            if (part + NP * (wave + 4 * j0) >= ntl) break;  // the pass's first tile slot: wave-uniform
+            const int rb = t / (10 / LB), l = (t - rb * (10 / LB)) * LB + ((lane >> 2) & 1), ci = rb * 4 + (lane & 3);
+            if (t < ntl && ci < CH) cull_row(l, ci);
+        }
+    } else if (!cull_beside_chain) {
         for (int row = tid; row < 10 * CH; row += 256) cull_row(row / CH, row - (row / CH) * CH);
         __syncthreads();
     }
@@ -370,7 +440,7 @@ __global__ __launch_bounds__(256, GQ_WG_PER_CU) void k_goalset_queue(ChunkArgs a
     const int pc3 = 3 * (p < P ? p : 0);  // lane part of a collision-point address (doubles)
     GS_COUNT(0);
 #pragma unroll 1
-    for (int t = wave; t < ntiles; t += 4) {  // every lane stays active: invalid items are flagged, not skipped
+    for (int t = LAT ? part + NP * wave : wave; t < ntiles; t += LAT ? 4 * NP : 4) {  // every lane stays active: invalid items are flagged, not skipped
         const int rb = t / (10 / LB), l0 = (t - rb * (10 / LB)) * LB;
         GS_COUNT(1);
         {

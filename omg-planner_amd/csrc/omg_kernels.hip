@@ -200,6 +200,12 @@ struct ChunkArgs {
     const int32_t* schedule;
     int sched_len;             // entries of `schedule` = goal workgroups of the launch (a multiple of 8)
     int tbl_n;                 // exact-path records staged in LDS (k_goalset_queue; chosen by the launcher)
+    // work decomposition of k_goalset_queue (set by launch_goalset).  Batch: one workgroup per goal (NP = 1), 5 layer workgroups per
+    // scene (2 links x all waypoints each), a scene's workgroups on one XCD.  Latency mode (a few scenes): a goal's tiles dealt over
+    // NP workgroups (chunk = goal * NP + part; NCH = NG * NP chunks per scene), layer_lg x layer_nb layer workgroups per scene
+    // (10 / layer_lg links x layer_cb waypoints), workgroups in plain order over all XCDs (spread).
+    int NG, NP;
+    int layer_parts, layer_lg, layer_nb, layer_cb, spread;
     uint32_t* work;
 };
 
@@ -372,33 +378,45 @@ __global__ __launch_bounds__(TPB) void k_sdf_chunks(ChunkArgs a) {
 // (3b) waypoint_layer_block — the SDF layer of a scene's current trajectory inside the goal-set launch
 // =================================================================================================
 // What omgx_fk_sdf computes for Optimizer.optimize (potentials, gradients, collisions of wp_n x 10 x P points) as
-// GS_LAYER_PARTS extra workgroups per scene of k_goalset_queue (omg_goalset_queue.h).  The optimiser step that follows on
+// extra workgroups per scene (ChunkArgs::layer_parts) of k_goalset_queue (omg_goalset_queue.h).  The optimiser step that follows on
 // the same stream then depends on a single kernel: no side stream, no events.  Arithmetic is that of k_sdf_chunks<true>
 // (same sdf_pair calls on the same float32 points); kinematics in two stages like the goal workgroups.
+template <bool LAT>  // the chain's constants from LDS (fkc, filled here) instead of through the scalar cache: see k_goalset_queue
 __device__ __forceinline__ void waypoint_layer_block(const ChunkArgs& a, const int s, const int l_begin, const int l_end,
-                                                     double* lds_pose, uint32_t* rowmask, const int o_begin, const int o_end,
-                                                     const RobotViewS& rv) {
+                                                     const int c_begin, const int c_end, double* lds_pose, uint32_t* rowmask,
+                                                     const int o_begin, const int o_end, const RobotViewS& rv, double* fkc,
+                                                     const bool warming) {
+    // links [l_begin, l_end) at the waypoint configurations [c_begin, c_end): every output element is computed on its own, so any
+    // split of the (link, configuration) grid over workgroups writes the same bits
     const int n = a.wp_n, P = a.P, PS = a.PS, MR = a.MR;
-    const double* tr = a.wp_traj + (int64_t)s * n * 9;
-    double* sc = reinterpret_cast<double*>(rowmask);  // [n][7][2], dead before the masks are written
-    for (int t = threadIdx.x; t < n * 7; t += 256) {
+    const int nloc = c_end - c_begin;
+    const double* tr = a.wp_traj + ((int64_t)s * n + c_begin) * 9;
+    double* sc = reinterpret_cast<double*>(rowmask);  // [nloc][7][2], dead before the masks are written
+    const double fkv = (LAT && threadIdx.x < 246) ? rv.g[threadIdx.x] : 0.0;
+    if (warming) gq_warm_scalar_cache(a.objects, o_begin, o_end, a.robot + OMGX_ROBOT_POINTS + 30 * P + 306 + 30 * P);
+    for (int t = threadIdx.x; t < nloc * 7; t += 256) {
         const int cfg = t / 7, i = t - cfg * 7;
         double sn, cs;
         fk_joint_sincos(tr[cfg * 9 + i], sn, cs);
         sc[2 * t] = sn; sc[2 * t + 1] = cs;
     }
+    if (LAT && threadIdx.x < 246) fkc[threadIdx.x] = fkv;
     __syncthreads();
-    for (int t = threadIdx.x; t < n * 3; t += 256) {
-        const int cfg = t / 3, r = t - cfg * 3;
-        fk_chain_row(rv, r, sc + 14 * cfg, tr[cfg * 9 + 7], tr[cfg * 9 + 8], [&](int l, double r0, double r1, double r2, double tt) {
-            double* dst = lds_pose + ((size_t)l * PS + cfg) * 9;
-            if (r < 2) { dst[3 * r] = r0; dst[3 * r + 1] = r1; dst[3 * r + 2] = r2; }
-            dst[6 + r] = tt;
-        });
-    }
+    auto run_chain = [&](const auto& view) {
+        for (int t = threadIdx.x; t < nloc * 3; t += 256) {
+            const int cfg = t / 3, r = t - cfg * 3;
+            fk_chain_row(view, r, sc + 14 * cfg, tr[cfg * 9 + 7], tr[cfg * 9 + 8], [&](int l, double r0, double r1, double r2, double tt) {
+                double* dst = lds_pose + ((size_t)l * PS + cfg) * 9;
+                if (r < 2) { dst[3 * r] = r0; dst[3 * r + 1] = r1; dst[3 * r + 2] = r2; }
+                dst[6 + r] = tt;
+            });
+        }
+    };
+    if constexpr (LAT) run_chain(RobotView(a.robot, P, fkc));
+    else run_chain(rv);
     __syncthreads();
-    for (int row = l_begin * n + threadIdx.x; row < l_end * n; row += 256) {  // row-level culling of this workgroup's links
-        const int l = row / n, ci = row - l * n;
+    for (int row = l_begin * nloc + threadIdx.x; row < l_end * nloc; row += 256) {  // row-level culling of this workgroup's links
+        const int l = row / nloc, ci = row - l * nloc;
         const double* A = lds_pose + ((int64_t)l * PS + ci) * 9;
         const float cx = (float)A[6], cy = (float)A[7], cz = (float)A[8];
         const float rad = (float)rv.radius(l) + 1.0e-4f;
@@ -420,9 +438,9 @@ __device__ __forceinline__ void waypoint_layer_block(const ChunkArgs& a, const i
     }
     __syncthreads();
     const int p = threadIdx.x & 15, r = threadIdx.x >> 4;
-    for (int ci0 = 0; ci0 < n; ci0 += 16) {
+    for (int ci0 = 0; ci0 < nloc; ci0 += 16) {
         const int ci = ci0 + r;
-        const bool valid = (p < P) && (ci < n);
+        const bool valid = (p < P) && (ci < nloc);
         const int cic = valid ? ci : 0, pc = valid ? p : 0;
 #pragma unroll 1
         for (int l = l_begin; l < l_end; ++l) {
@@ -446,7 +464,7 @@ __device__ __forceinline__ void waypoint_layer_block(const ChunkArgs& a, const i
                 acc.pot *= 0.1f; acc.gx *= 0.1f; acc.gy *= 0.1f; acc.gz *= 0.1f; acc.col = 0.0f;
             }
             if (valid) {
-                const int64_t kk = (((int64_t)s * n + ci) * 10 + l) * P + p;
+                const int64_t kk = (((int64_t)s * n + c_begin + ci) * 10 + l) * P + p;
                 a.wp_pot[kk] = acc.pot;
                 a.wp_col[kk] = acc.col;
                 a.wp_grad[3 * kk] = acc.gx; a.wp_grad[3 * kk + 1] = acc.gy; a.wp_grad[3 * kk + 2] = acc.gz;
@@ -495,7 +513,6 @@ extern "C" int omgx_debug_gs_counts(unsigned long long* h_out, int reset) {
 #define GS_COUNT_N(k, n)
 #endif
 
-#define GS_LAYER_PARTS 5  // trajectory-layer workgroups per scene
 
 #include "omg_goalset_queue.h"
 
@@ -566,7 +583,7 @@ static void timing_events(int kind, hipEvent_t* ev0, hipEvent_t* ev1) {
     *ev0 = g_ev[i][0]; *ev1 = g_ev[i][1];
     ++g_timing_n;
 }
-extern "C" int omgx_abi_version(void) { return 5; }  // 2: `active` masks; 3: ragged goal sets (goal_count, eta); 4: goal schedule + work; 5: 184-byte object records (influence region = rounded box)
+extern "C" int omgx_abi_version(void) { return 6; }  // 2: `active` masks; 3: ragged goal sets (goal_count, eta); 4: goal schedule + work; 5: 184-byte object records (influence region = rounded box); 6: omgx_goalset_cost_layer_tiled, omgx_learner_params.cost_parts
 extern "C" int omgx_device_arch(char* h_buf, int32_t h_len) {
     if (!h_buf || h_len <= 0) return OMGX_ERR_INVALID;
     int dev = 0;
@@ -667,21 +684,55 @@ extern "C" int64_t omgx_goalset_workspace_bytes(int32_t num_scenes, int32_t num_
     return poses + start;
 }
 
+// How a k_goalset_queue launch is cut into workgroups (ChunkArgs: NP, layer_*, spread).  The default is the batch layout.
+struct GsTiling {
+    int goal_parts = 1;  // workgroups per goal (1, 2, 4 or 8) at most: omgx_goalset_parts picks the count for a window
+    int layer_lg = 5;    // link groups of the trajectory layer (1, 2, 5 or 10)
+    int layer_cb = 0;    // waypoints per layer workgroup; 0: all
+    int spread = 0;      // latency mode: workgroups in plain (scene, item) order over all XCDs instead of a scene per XCD
+};
+
+// Workgroups per goal for a window of n_remaining configurations: the largest power of two <= max_parts that still leaves every
+// workgroup at least 4 tiles (one per wave) of the ceil(n / 4) x 5.
+static inline int gs_parts(int n_remaining, int max_parts) {
+    const int ntiles = ((n_remaining + 3) / 4) * 5;
+    int np = 1;
+    while (np * 2 <= max_parts && ntiles / (np * 2) >= 4) np *= 2;
+    return np;
+}
+
 // dynamic LDS and grid of a k_goalset_queue launch (goal workgroups and / or trajectory-layer workgroups)
-static int launch_goalset(ChunkArgs& ca, int timing_kind, hipStream_t st) {
+static int launch_goalset(ChunkArgs& ca, int timing_kind, hipStream_t st, const GsTiling& tl = GsTiling()) {
     const int scene_groups = (ca.S + 7) / 8;
     const bool layer = ca.wp_traj != nullptr;
+    if (tl.goal_parts < 1 || tl.goal_parts > 8 || tl.layer_lg < 1 || tl.layer_lg > 10 || 10 % tl.layer_lg != 0 || tl.layer_cb < 0) return OMGX_ERR_INVALID;
+    ca.spread = tl.spread != 0;
+    if (tl.goal_parts > 1 && !ca.spread) return OMGX_ERR_UNSUPPORTED;  // parts of a goal exist in the latency-mode kernel only
+    ca.NG = ca.NCH;
+    ca.NP = ca.NG > 0 ? gs_parts(ca.CH, tl.goal_parts) : 1;
+    ca.NCH = ca.NG * ca.NP;
+    if (ca.spread && (ca.schedule || ca.work)) return OMGX_ERR_UNSUPPORTED;  // a dispatch schedule orders whole goals, a scene per XCD
+    ca.layer_lg = tl.layer_lg;
+    ca.layer_cb = layer ? ((tl.layer_cb > 0 && tl.layer_cb < ca.wp_n) ? tl.layer_cb : ca.wp_n) : 1;
+    ca.layer_nb = layer ? (ca.wp_n + ca.layer_cb - 1) / ca.layer_cb : 1;
+    ca.layer_parts = ca.layer_lg * ca.layer_nb;
     ca.PS = ca.CH + 1; ca.MR = ca.CH; ca.LPW = 10;
-    if (layer) { if (ca.wp_n > ca.PS) ca.PS = ca.wp_n; if (ca.wp_n > ca.MR) ca.MR = ca.wp_n; }
-    const int64_t goal_blocks = ca.schedule ? (int64_t)ca.sched_len : (int64_t)scene_groups * ca.NCH * 8;
-    const int64_t grid = goal_blocks + (layer ? (int64_t)scene_groups * GS_LAYER_PARTS * 8 : 0);
+    if (layer) { if (ca.layer_cb > ca.PS) ca.PS = ca.layer_cb; if (ca.layer_cb > ca.MR) ca.MR = ca.layer_cb; }
+    const int64_t per_scene = (int64_t)ca.NCH + (layer ? ca.layer_parts : 0);
+    const int64_t grid = ca.spread ? (int64_t)ca.S * per_scene
+                                   : (ca.schedule ? (int64_t)ca.sched_len : (int64_t)scene_groups * ca.NCH * 8) +
+                                         (layer ? (int64_t)scene_groups * ca.layer_parts * 8 : 0);
     if (grid > 0x7fffffff) return OMGX_ERR_UNSUPPORTED;
-    ca.tbl_n = gq_choose_tbl_n(ca.PS, ca.MR, ca.P);
-    const size_t lds = (size_t)GqLayout(ca.PS, ca.MR, ca.P, ca.tbl_n).total;
-    if (lds > 64 * 1024) return OMGX_ERR_UNSUPPORTED;  // cannot happen within OMGX_MAX_WAYPOINTS / OMGX_MAX_POINTS (59 KB at 64 x 16)
+    if (grid == 0) return OMGX_OK;
+    ca.tbl_n = gq_choose_tbl_n(ca.PS, ca.MR, ca.P, ca.spread);
+    const size_t lds = (size_t)GqLayout(ca.PS, ca.MR, ca.P, ca.tbl_n, ca.spread).total;
+    if (lds > 64 * 1024) return OMGX_ERR_UNSUPPORTED;  // cannot happen within OMGX_MAX_WAYPOINTS / OMGX_MAX_POINTS (61 KB at 64 x 16)
     hipEvent_t ev0, ev1;
     timing_events(timing_kind, &ev0, &ev1);
-    if (ca.work) {
+    if (ca.spread) {
+        if (ev0) hipExtLaunchKernelGGL((k_goalset_queue<2, false, true>), dim3((unsigned)grid), dim3(256), (uint32_t)lds, st, ev0, ev1, 0, ca);
+        else hipLaunchKernelGGL((k_goalset_queue<2, false, true>), dim3((unsigned)grid), dim3(256), lds, st, ca);
+    } else if (ca.work) {
         if (ev0) hipExtLaunchKernelGGL((k_goalset_queue<2, true>), dim3((unsigned)grid), dim3(256), (uint32_t)lds, st, ev0, ev1, 0, ca);
         else hipLaunchKernelGGL((k_goalset_queue<2, true>), dim3((unsigned)grid), dim3(256), lds, st, ca);
     } else {
@@ -738,7 +789,7 @@ extern "C" int omgx_fk_sdf(const double* robot, int32_t n_points, const omgx_obj
     hipStream_t st = (hipStream_t)stream;
     if (!arc && potentials && grads && collides && configs_per_scene <= OMGX_MAX_WAYPOINTS) {
         // A trajectory-sized layer (the optimiser's input): the goal-set kernel's layer workgroups alone — kinematics in
-        // LDS, GS_LAYER_PARTS workgroups per scene, one launch instead of k_fk_poses + k_sdf_chunks.  Same arithmetic.
+        // LDS, 5 workgroups per scene, one launch instead of k_fk_poses + k_sdf_chunks.  Same arithmetic.
         ChunkArgs ca{};
         ca.robot = robot; ca.objects = objects; ca.scene_begin = scene_begin; ca.pool = sdf_pool;
         ca.S = num_scenes; ca.P = n_points; ca.NCH = 0; ca.CH = 0; ca.C = 0;
@@ -817,15 +868,16 @@ static int goalset_cost_impl(const double* robot, int32_t n_points, const omgx_o
                              int32_t soften_fingers, float* goal_cost, float* potentials, float* collides, void* workspace,
                              const double* layer_traj, int32_t layer_n, int32_t layer_soften, float* layer_pot, float* layer_grad,
                              float* layer_col, const int32_t* active, const int32_t* goal_count, const int32_t* schedule,
-                             int32_t schedule_len, uint32_t* work, void* stream) {
+                             int32_t schedule_len, uint32_t* work, void* stream, const GsTiling& tiling = GsTiling()) {
     if (num_scenes < 0 || num_goals < 0) return OMGX_ERR_INVALID;
-    if (num_scenes == 0 || num_goals == 0) return OMGX_OK;
-    if (!robot || !objects || !scene_begin || !traj_start || !goals || !goal_cost) return OMGX_ERR_INVALID;
+    if (num_scenes == 0 || (num_goals == 0 && !layer_traj)) return OMGX_OK;
+    if (!robot || !objects || !scene_begin) return OMGX_ERR_INVALID;
+    if (num_goals > 0 && (!traj_start || !goals || !goal_cost)) return OMGX_ERR_INVALID;
     if (n_points < 1 || n_points > OMGX_MAX_POINTS || n_remaining < 1 || n_remaining > OMGX_MAX_WAYPOINTS)
         return OMGX_ERR_UNSUPPORTED;
-    if (!(time_interval > 0.0) || traj_start_stride < 9) return OMGX_ERR_INVALID;
+    if (!(time_interval > 0.0) || (num_goals > 0 && traj_start_stride < 9)) return OMGX_ERR_INVALID;
     hipStream_t st = (hipStream_t)stream;
-    const int n = n_remaining, C = num_goals * n;
+    const int n = num_goals > 0 ? n_remaining : 0, C = num_goals * n;
     if (layer_traj) {  // the trajectory layer rides on k_goalset_queue (cost-only batch)
         if (!layer_pot || !layer_grad || !layer_col) return OMGX_ERR_INVALID;
         if (layer_n < 1 || layer_n > OMGX_MAX_WAYPOINTS) return OMGX_ERR_UNSUPPORTED;
@@ -845,7 +897,7 @@ static int goalset_cost_impl(const double* robot, int32_t n_points, const omgx_o
     if (schedule && (schedule_len < 8 || schedule_len % 8 != 0)) return OMGX_ERR_INVALID;
     ca.active = active; ca.goal_count = goal_count; ca.schedule = schedule; ca.sched_len = schedule ? schedule_len : 0; ca.work = work;
     (void)workspace;  // kept in the signature (ABI): no launch of this entry point spills poses to memory any more
-    return potentials ? launch_chunks(ca, st) : launch_goalset(ca, 0, st);
+    return potentials ? launch_chunks(ca, st) : launch_goalset(ca, 0, st, tiling);
 }
 
 extern "C" int omgx_goalset_cost(const double* robot, int32_t n_points, const omgx_object* objects,
@@ -1023,4 +1075,26 @@ extern "C" int omgx_goalset_cost_layer(const double* robot, int32_t n_points, co
                              num_goals, n_remaining, time_interval, soften_fingers, goal_cost, nullptr, collides, workspace, traj,
                              n_waypoints, layer_soften_fingers, layer_potentials, layer_grads, layer_collides, active, goal_count, schedule,
                              schedule_len, work, stream);
+}
+
+extern "C" int32_t omgx_goalset_parts(int32_t n_remaining, int32_t goal_parts) {
+    if (n_remaining < 1 || goal_parts < 1 || goal_parts > 8) return 0;
+    return gs_parts(n_remaining, goal_parts);
+}
+
+extern "C" int omgx_goalset_cost_layer_tiled(const double* robot, int32_t n_points, const omgx_object* objects,
+                                             const int32_t* scene_begin, const float* sdf_pool, const double* traj_start,
+                                             int64_t traj_start_stride, const double* goals, int32_t num_scenes, int32_t num_goals,
+                                             int32_t n_remaining, double time_interval, int32_t soften_fingers, float* goal_cost,
+                                             float* collides, const double* traj, int32_t n_waypoints, int32_t layer_soften_fingers,
+                                             float* layer_potentials, float* layer_grads, float* layer_collides,
+                                             const int32_t* active, const int32_t* goal_count, int32_t goal_parts,
+                                             int32_t layer_link_groups, int32_t layer_config_block, int32_t spread, void* stream) {
+    if (!traj && num_goals <= 0) return OMGX_ERR_INVALID;
+    GsTiling tl;
+    tl.goal_parts = goal_parts; tl.layer_lg = layer_link_groups; tl.layer_cb = layer_config_block; tl.spread = spread;
+    return goalset_cost_impl(robot, n_points, objects, scene_begin, sdf_pool, traj_start, traj_start_stride, goals, num_scenes,
+                             num_goals, num_goals > 0 ? n_remaining : 1, time_interval, soften_fingers, goal_cost, nullptr, collides, nullptr, traj,
+                             n_waypoints, layer_soften_fingers, layer_potentials, layer_grads, layer_collides, active, goal_count, nullptr,
+                             0, nullptr, stream, tl);
 }

@@ -222,7 +222,12 @@ __device__ __forceinline__ void learner_scene(const LearnerArgs& a, int s, doubl
                     s2 += e * e;
                 }
                 const double nr = sqrt(s2);
-                const float wc = (float)prm.base_obstacle_weight * a.goal_cost[(int64_t)s * GS + g];  // float32 product
+                // the goal's cost: one float32, or (latency mode) the cost_parts partial sums of its parts added in part order
+                const int NPc = prm.cost_parts > 1 ? prm.cost_parts : 1;
+                const float* gc = a.goal_cost + ((int64_t)s * GS + g) * NPc;
+                float gcost = gc[0];
+                for (int k = 1; k < NPc; ++k) gcost += gc[k];
+                const float wc = (float)prm.base_obstacle_weight * gcost;  // float32 product
                 cv[j] = (double)wc + prm.smooth_weight * (nr * nr);
                 part += cv[j] * cv[j];
             }

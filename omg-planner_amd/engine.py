@@ -92,15 +92,27 @@ class ChompEngine:
                      "pot", "pgrad", "col", "grad", "cost_traj", "info", "goal_cost", "goal_col", "learner_state", "cost_vec", "_active",
                      "_scene_flags")
 
+    # Latency mode (ChompEngine(latency_mode=True); omgx_goalset_cost_layer_tiled): a goal's tiles dealt over up to LAT_GOAL_PARTS
+    # workgroups, the trajectory layer in LAT_LAYER_LINK_GROUPS x ceil(n / LAT_LAYER_BLOCK) workgroups, all spread over the XCDs.
+    LAT_GOAL_PARTS = 4
+    LAT_LAYER_LINK_GROUPS = 10
+    LAT_LAYER_BLOCK = 16
+
     def __init__(self, model: PandaModel, batch: SceneBatch, cfg: Config, start: np.ndarray, goal_set: np.ndarray,
                  reach_grasps: np.ndarray | None = None, traj_init: np.ndarray | None = None, device="cuda:0",
-                 ol_alg: str = "FTL", stream: "torch.cuda.Stream | None" = None, goal_counts=None):
+                 ol_alg: str = "FTL", stream: "torch.cuda.Stream | None" = None, goal_counts=None, latency_mode: bool = False):
         """start [S,9]; goal_set [S,G,9]; reach_grasps [S,G,c,9] (needed when cfg.use_standoff).
         `stream`: run every launch of this engine on that HIP stream (several engines holding disjoint scene
         subsets on different streams overlap each other's latency-bound kernels).
         `goal_counts` [S]: ragged goal sets — scene s uses goal_set[s, :goal_counts[s]] (and the matching reach_grasps); the
-        rest of its rows is padding that no launch reads.  Each scene then computes exactly what it would compute alone."""
+        rest of its rows is padding that no launch reads.  Each scene then computes exactly what it would compute alone.
+        `latency_mode`: for ONE or a few scenes (BASELINE configs 1-2) — the goal-set batch and the trajectory layer are cut
+        into many small workgroups spread over the whole chip instead of one workgroup per goal on the scene's XCD (a third
+        of the launch's latency).  A goal's cost is then the float32 sum of its parts' sums — another summation order
+        than the batch layout's (~1e-7 relative), everything else is bit-identical; `goal_cost` / `goal_col` hold the partial
+        sums (goal_cost_total() adds them).  No pipeline, no dispatch schedule in this mode."""
         self.cfg = cfg
+        self.latency = bool(latency_mode)
         self.stream = stream
         self.model = model
         self.device = torch.device(device)
@@ -152,8 +164,11 @@ class ChompEngine:
         self.grad = torch.empty((S, n, 9), **f64)
         self.cost_traj = torch.empty((S, n), **f64)
         self.info = torch.zeros((S, _lib.INFO_STRIDE), **f64)
-        self.goal_cost = torch.zeros((S, G), **f32)
-        self.goal_col = torch.zeros((S, G), **f32)
+        # latency mode: [S][G][parts] partial sums, parts = ceil(window / LAT_GOAL_PARTS) shrinking with the window (flat buffer)
+        self._parts_max = ops.goalset_parts(n, self.LAT_GOAL_PARTS) if self.latency else 1
+        self._parts_last = 1
+        self.goal_cost = torch.zeros((S, G * self._parts_max), **f32)
+        self.goal_col = torch.zeros((S, G * self._parts_max), **f32)
         self.learner_state = ops.learner_state(S, G, dev, goal_counts)  # sum_costs | p | experts_p | q | experts_costs
         self.cost_vec = torch.zeros((S, G), **f64)
         self.eta = float(np.sqrt(np.log(G + 1) / cfg.optim_steps))  # online_learner.py:80
@@ -265,7 +280,24 @@ class ChompEngine:
         p.base_obstacle_weight = float(cfg.base_obstacle_weight)
         p.smooth_weight = float(cfg.smoothness_base_weight * cfg.dist_eps)
         p.eta = self.eta
+        p.cost_parts = ops.goalset_parts(cfg.timesteps - p.start_idx, self.LAT_GOAL_PARTS) if self.latency else 0
         return p
+
+    def _tiling(self):
+        return (self.LAT_GOAL_PARTS, self.LAT_LAYER_LINK_GROUPS, self.LAT_LAYER_BLOCK, 1)
+
+    def goal_cost_total(self) -> torch.Tensor:
+        """[S,G] float32 goal costs of the last goal-set launch (latency mode: the parts' sums added in part order, as the
+        learner adds them)."""
+        self.join()
+        if not self.latency:
+            return self.goal_cost
+        k = self._parts_last
+        parts = self.goal_cost.reshape(-1)[: self.S * self.G * k].reshape(self.S, self.G, k)
+        tot = parts[:, :, 0].clone()
+        for j in range(1, k):
+            tot += parts[:, :, j]
+        return tot
 
     # ---------------------------------------------------------------------------------------------
     # Software pipeline.  One iteration is a goal-set launch that fills the GPU (~275 us for 100 scenes x 64 goals) followed by
@@ -350,6 +382,8 @@ class ChompEngine:
         # The pipeline forks from and joins into torch's CURRENT stream.  An engine bound to a stream of its own keeps every
         # launch on that stream — switching between the two modes would leave the streams unordered — so it never pipelines
         # by itself and refuses an explicit request.
+        if self.latency:
+            return 1
         if self.pipeline is not None:
             k = max(1, min(int(self.pipeline), self.S))
             if k > 1 and self.stream is not None:
@@ -371,7 +405,15 @@ class ChompEngine:
         if self.ol_alg != "Proj":  # cost_vector's obstacle batch (online_learner.py:128-148)
             n_rem = self.cfg.timesteps - prm.start_idx
             traj_start = self.traj[:, prm.start_idx]  # strided view into the trajectory tensor: no copy kernel
-            if with_layer:  # the SDF layer of the current trajectories rides on the goal-set launch
+            if self.latency:
+                self._gs_launches += 1
+                self._parts_last = ops.goalset_cost_layer_tiled(
+                    self.robot, self.P, self.scenes, traj_start, self.cv_goals, n_rem, self.cfg.time_interval,
+                    self.traj if with_layer else None, (self.pot, self.pgrad, self.col), (self.goal_cost, self.goal_col),
+                    soften_fingers=False, layer_soften_fingers=self.cfg.uncheck_finger_collision == -1, active=self._mask(),
+                    goal_count=self.goal_count, goal_parts=self.LAT_GOAL_PARTS, layer_link_groups=self.LAT_LAYER_LINK_GROUPS,
+                    layer_config_block=self.LAT_LAYER_BLOCK, spread=True)
+            elif with_layer:  # the SDF layer of the current trajectories rides on the goal-set launch
                 # the second launch is the measuring one (the first runs on cold caches and would distort the weights);
                 # until then the items are split evenly by count.  Small batches keep the even split: measuring only pays
                 # when the launch has several rounds of workgroups per CU.
@@ -454,6 +496,12 @@ class ChompEngine:
 
     def _layer(self):
         """SDF layer outputs of the current waypoints (first half of Cost.compute_total_loss)."""
+        if self.latency:
+            ops.goalset_cost_layer_tiled(self.robot, self.P, self.scenes, None, None, 1, self.cfg.time_interval, self.traj,
+                                         (self.pot, self.pgrad, self.col), None, layer_soften_fingers=self.cfg.uncheck_finger_collision == -1,
+                                         layer_link_groups=self.LAT_LAYER_LINK_GROUPS,
+                                         layer_config_block=self.LAT_LAYER_BLOCK, spread=True)
+            return
         ops.fk_sdf(self.robot, self.P, self.scenes, self.traj, soften_fingers=self.cfg.uncheck_finger_collision == -1,
                    out=(self.pot, self.pgrad, self.col))
 
@@ -534,8 +582,8 @@ class ChompEngine:
         rebuilds, the rules without a goal-set batch)."""
         if self.ol_alg in ("Baseline", "Proj"):
             return False
-        use_sched = self.auto_schedule and not self._masked
-        if self._masked and self.auto_schedule and self._measured and self.reschedule_every:
+        use_sched = self.auto_schedule and not self._masked and not self.latency
+        if not self.latency and self._masked and self.auto_schedule and self._measured and self.reschedule_every:
             return False
         if use_sched and (self.schedule is None or (not self._measured and self._gs_launches >= 1 and self.S * self.G >= 2048)):
             return False
@@ -548,13 +596,15 @@ class ChompEngine:
                                        (self.pot, self.pgrad, self.col), (self.goal_cost, self.goal_col), self.goal_set, self.reach,
                                        self.learner_state, self.goal_idx, self.start, self.end, self.goal_rows, self.goal_point,
                                        (self.grad, self.cost_traj, self.info), self.cost_vec, self._active, self.goal_count, self.eta_s,
-                                       self._scene_flags, layer_soften_fingers=self.cfg.uncheck_finger_collision == -1)
+                                       self._scene_flags, layer_soften_fingers=self.cfg.uncheck_finger_collision == -1,
+                                       tiling=self._tiling() if self.latency else None)
             hot = self._hot = (key, calls, baked)
         calls = hot[1]
         stream = (self.stream if self.stream is not None else torch.cuda.current_stream(self.device)).cuda_stream
         self.t += 1
         prm = self._learner_params()
         self._gs_launches += 1
+        self._parts_last = max(1, int(prm.cost_parts))
         calls.goalset_layer(prm.start_idx, self._masked, self.schedule if use_sched else None, None, stream)
         self._schedule()
         split = 2 * self.S <= self._num_cus if self.split_update is None else bool(self.split_update)

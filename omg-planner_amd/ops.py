@@ -159,6 +159,57 @@ def goalset_cost_layer(robot, P, scenes: DeviceScenes, traj_start, goals, n_rema
     return cost, col
 
 
+def goalset_parts(n_remaining: int, goal_parts: int) -> int:
+    """Workgroups per goal of goalset_cost_layer_tiled for a window of n_remaining configurations (omgx_goalset_parts)."""
+    return int(_lib.lib().omgx_goalset_parts(int(n_remaining), int(goal_parts)))
+
+
+def goalset_cost_layer_tiled(robot, P, scenes: DeviceScenes, traj_start, goals, n_remaining, dt, traj, layer_out, out,
+                             soften_fingers=False, layer_soften_fingers=False, active=None, goal_count=None, goal_parts=4,
+                             layer_link_groups=10, layer_config_block=16, spread=True):
+    """The goal-set batch and / or the trajectory layer cut into many small workgroups (omgx_goalset_cost_layer_tiled: latency
+    mode for one or a few scenes).  goals None: only the layer; traj None: only the batch.  out = (cost, collides): float32
+    device tensors with at least S * G * goalset_parts(n_remaining, goal_parts) elements, written as [S][G][parts] PARTIAL sums
+    (the learner adds them: LearnerParams.cost_parts).  Returns the number of parts per goal."""
+    dev = (goals if goals is not None else traj).device
+    S = (goals if goals is not None else traj).shape[0]
+    G, ts_stride, parts = 0, 9, 1
+    cost = col = None
+    if goals is not None:
+        if not (traj_start.is_cuda and traj_start.dtype == torch.float64 and traj_start.dim() == 2 and traj_start.shape[1] == 9
+                and traj_start.stride(1) == 1 and (traj_start.shape[0] == 1 or traj_start.stride(0) >= 9)):
+            raise _lib.OmgHipError("traj_start must be a float64 device tensor [S,9] with unit inner stride")
+        ts_stride = traj_start.stride(0) if traj_start.shape[0] > 1 else 9
+        _need(goals, torch.float64, "goals")
+        G = goals.shape[1]
+        parts = goalset_parts(n_remaining, goal_parts)
+        if parts < 1:
+            raise _lib.OmgHipError("goal_parts must be 1, 2, 4 or 8")
+        cost, col = out
+        for n_, t in (("goal_cost", cost), ("goal collides", col)):
+            _need(t, torch.float32, n_)
+            if t.numel() < S * G * parts:
+                raise _lib.OmgHipError(f"{n_} must hold S * G * parts = {S * G * parts} elements")
+    lp = lg = lc = None
+    n = 0
+    if traj is not None:
+        _need(traj, torch.float64, "traj")
+        lp, lg, lc = layer_out
+        for n_, t in (("layer potentials", lp), ("layer grads", lg), ("layer collides", lc)):
+            _need(t, torch.float32, n_)
+        n = traj.shape[1]
+        if traj.shape[0] != S or lp.numel() != S * n * 10 * P or lg.numel() != 3 * lp.numel() or lc.numel() != lp.numel():
+            raise _lib.OmgHipError("layer outputs must be [S,n,10,P], [S,n,10,P,3], [S,n,10,P]")
+    with torch.cuda.device(dev):
+        check(_lib.lib().omgx_goalset_cost_layer_tiled(
+            _ptr(robot), P, _ptr(scenes.objects), _ptr(scenes.scene_begin), _ptr(scenes.pool), _ptr(traj_start) if goals is not None else None,
+            ts_stride, _ptr(goals), S, G, int(n_remaining) if goals is not None else 1, float(dt), int(bool(soften_fingers)), _ptr(cost), _ptr(col),
+            _ptr(traj), n, int(bool(layer_soften_fingers)), _ptr(lp), _ptr(lg), _ptr(lc), _ptr(_active(active, S)),
+            _ptr(_active(goal_count, S)), int(goal_parts), int(layer_link_groups), int(layer_config_block), int(bool(spread)), _stream()),
+            "omgx_goalset_cost_layer_tiled")
+    return parts
+
+
 def goalset_schedule(work, num_scenes: int, num_goals: int, active=None, goal_count=None, slack: int = 2, out=None, device=None):
     """Dispatch order for goalset_cost_layer (omgx_goalset_schedule): int32 device tensor [omgx_goalset_schedule_len].
     work: int32/uint32 device tensor [S*G] of durations (None: all items weigh the same).  Asynchronous, one small launch.
@@ -310,7 +361,7 @@ class IterationCalls:
 
     def __init__(self, robot, P, scenes: DeviceScenes, goals, dt, traj, layer_out, goal_out, goal_set, reach, state, goal_idx,
                  start, end, goal_rows, goal_point, step_out, cost_vector, active, goal_count=None, eta=None, scene_flags=None,
-                 layer_soften_fingers=False):
+                 layer_soften_fingers=False, tiling=None):
         lp, lg, lc = layer_out
         cost, col = goal_out
         grad, cost_traj, info = step_out
@@ -325,6 +376,13 @@ class IterationCalls:
         S, G, n = goals.shape[0], goals.shape[1], traj.shape[1]
         if traj.shape[0] != S or lp.numel() != S * n * 10 * P or lg.numel() != 3 * lp.numel() or lc.numel() != lp.numel():
             raise _lib.OmgHipError("layer outputs must be [S,n,10,P], [S,n,10,P,3], [S,n,10,P]")
+        # tiling = (goal_parts, layer_link_groups, layer_config_block, spread): the launches go through omgx_goalset_cost_layer_tiled
+        # (latency mode), goal_cost / collides then hold [S][G][parts] partial sums
+        self._tiling = None if tiling is None else tuple(int(v) for v in tiling)
+        if self._tiling is not None:
+            need = S * G * goalset_parts(n, self._tiling[0])
+            if cost.numel() < need or col.numel() < need:
+                raise _lib.OmgHipError(f"goal_cost / collides must hold S * G * parts = {need} elements")
         if goal_idx.dtype != torch.int32 or not goal_idx.is_cuda or goal_idx.numel() != S:
             raise _lib.OmgHipError("goal_idx must be an int32 device tensor [S]")
         if scene_flags is not None and (scene_flags.dtype != torch.int32 or scene_flags.numel() < S or not scene_flags.is_cuda):
@@ -336,6 +394,7 @@ class IterationCalls:
         self._traj_addr = traj.data_ptr()
         l = _lib.lib()
         self._f_gs, self._f_up = l.omgx_goalset_cost_layer, l.omgx_goal_update_optimize
+        self._f_gst = l.omgx_goalset_cost_layer_tiled
         self._layer_soft = int(bool(layer_soften_fingers))
         p = _ptr
         self._gs_head = (p(robot), self.P, p(scenes.objects), p(scenes.scene_begin), p(scenes.pool))
@@ -352,6 +411,19 @@ class IterationCalls:
     def goalset_layer(self, start_idx: int, masked: bool, schedule, work, stream):
         """omgx_goalset_cost_layer for traj_start = traj[:, start_idx], n_remaining = n - start_idx.  schedule / work: checked
         int32 device tensors or None; stream: a HIP stream handle (int)."""
+        if self._tiling is not None:
+            if schedule is not None or work is not None:
+                raise _lib.OmgHipError("a tiled goal-set launch takes no dispatch schedule")
+            cost, col, _ws, traj, n, soft, lp, lg, lc = self._gs_mid
+            args = (*self._gs_head, C.c_void_p(self._traj_addr + 72 * start_idx), self.n * 9, self._goals, self.S, self.G,
+                    self.n - start_idx, self.dt, 0, cost, col, traj, n, soft, lp, lg, lc, self._active_p if masked else None,
+                    self._goal_count, *self._tiling, C.c_void_p(stream))
+            if self._on_device():
+                check(self._f_gst(*args), "omgx_goalset_cost_layer_tiled")
+            else:
+                with torch.cuda.device(self.device):
+                    check(self._f_gst(*args), "omgx_goalset_cost_layer_tiled")
+            return
         args = (*self._gs_head, C.c_void_p(self._traj_addr + 72 * start_idx), self.n * 9, self._goals, self.S, self.G,
                 self.n - start_idx, self.dt, 0, *self._gs_mid, self._active_p if masked else None, self._goal_count,
                 _ptr(_i32n(schedule, None, "schedule")), 0 if schedule is None else schedule.numel(), _ptr(_i32n(work, self.S * self.G, "work")),

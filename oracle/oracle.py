@@ -33,7 +33,7 @@ class ChompParams(C.Structure):
 class LearnerParams(C.Structure):
     """Mirror of `omgx_learner_params` (include/omg_hip.h)."""
     _fields_ = [(n, C.c_int32) for n in ("alg", "num_goals", "n_waypoints", "start_idx", "constraint_num", "use_standoff",
-                                          "normalize_cost", "reserved")] + [(n, C.c_double) for n in (
+                                          "normalize_cost", "cost_parts")] + [(n, C.c_double) for n in (
         "base_obstacle_weight", "smooth_weight", "eta")]
 
 

@@ -1,0 +1,158 @@
+"""Latency mode (ChompEngine(latency_mode=True), omgx_goalset_cost_layer_tiled): one or a few scenes — BASELINE configs 1-2, the
+shape of the reference's own Planner.plan (omg/planner.py:600-653: one scene, one plan) — with the goal-set batch and the trajectory
+layer cut into many small workgroups.  What has to hold: layer outputs bit for bit whatever the split; a goal's cost = the
+float32 sum of its parts' sums, within summation rounding of the batch layout and at the oracle's tolerance; plans like the batch
+layout's and like the oracle's; the error paths of the new entry point."""
+from __future__ import annotations
+
+import copy
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU: torch.cuda.is_available() is False")
+    return torch.device("cuda:0")
+
+
+def _workload(S, G, grid=32, seed=0):
+    import bench
+    return bench.build_workload(S, G, 30, grid, seed, False)
+
+
+def _make(dev, S, G, latency, counts=None, grid=32, alg="MD"):
+    from omg_planner_amd.engine import ChompEngine
+    cfg, model, batch, start, goals = _workload(S, G, grid)
+    return ChompEngine(model, batch, copy.deepcopy(cfg), start, goals, device=dev, ol_alg=alg, goal_counts=counts, latency_mode=latency), batch
+
+
+@pytest.mark.parametrize("lg,cb", [(1, 0), (2, 7), (5, 16), (10, 16), (10, 4)])
+def test_layer_outputs_do_not_depend_on_the_split(dev, lg, cb):
+    """Every element of the trajectory layer is computed on its own: 10 / lg links x cb waypoints per workgroup, spread or not,
+    against omgx_fk_sdf's five workgroups per scene."""
+    from omg_planner_amd import ops
+    eng, _ = _make(dev, 3, 8, False)
+    ref = ops.fk_sdf(eng.robot, eng.P, eng.scenes, eng.traj)
+    for spread in (False, True):
+        out = tuple(torch.full_like(t, float("nan")) for t in ref)
+        ops.goalset_cost_layer_tiled(eng.robot, eng.P, eng.scenes, None, None, 1, eng.cfg.time_interval, eng.traj, out, None,
+                                     layer_link_groups=lg, layer_config_block=cb, spread=spread, goal_parts=1)
+        torch.cuda.synchronize()
+        for a, b in zip(ref, out):
+            assert torch.equal(a, b), (lg, cb, spread)
+
+
+@pytest.mark.parametrize("parts", [1, 2, 4, 8])
+@pytest.mark.parametrize("n_rem", [30, 17, 5, 1])
+def test_goal_cost_parts_add_up_to_the_batch_cost_and_the_oracle(dev, parts, n_rem):
+    """[S][G][NP] partial sums: their float32 sum in part order against the batch layout (another summation order: 1e-6) and the
+    oracle (1e-5, the bar of the batch layout); collision counts are integers and add up exactly."""
+    from omg_planner_amd import ops
+    from oracle import oracle as orc
+    eng, batch = _make(dev, 2, 24, False)
+    ts = eng.traj[:, 30 - n_rem]
+    cost, col, _ = ops.goalset_cost(eng.robot, eng.P, eng.scenes, ts, eng.cv_goals, n_rem, eng.cfg.time_interval)
+    NP = ops.goalset_parts(n_rem, parts)
+    assert 1 <= NP <= parts and (NP == 1 or ((n_rem + 3) // 4) * 5 // NP >= 4)
+    pc = torch.full((2, 24 * NP), float("nan"), dtype=torch.float32, device=dev)
+    pl = torch.full_like(pc, float("nan"))
+    got = ops.goalset_cost_layer_tiled(eng.robot, eng.P, eng.scenes, ts, eng.cv_goals, n_rem, eng.cfg.time_interval, None, None, (pc, pl),
+                                       goal_parts=parts, spread=True)
+    assert got == NP
+    torch.cuda.synchronize()
+    tot = pc.reshape(2, 24, NP)[:, :, 0].clone()
+    for k in range(1, NP):
+        tot += pc.reshape(2, 24, NP)[:, :, k]
+    np.testing.assert_allclose(tot.cpu().numpy(), cost.cpu().numpy(), rtol=2e-6, atol=1e-7)
+    assert torch.equal(pl.reshape(2, 24, NP).sum(-1), col)
+    for s in range(2):
+        gc, _ = orc.goalset_cost(eng.model.blob(), eng.P, batch.subset(s, s + 1), ts[s:s + 1].cpu().numpy(), eng.cv_goals[s:s + 1].cpu().numpy(),
+                                 n_rem, eng.cfg.time_interval)
+        np.testing.assert_allclose(tot[s].cpu().numpy(), np.asarray(gc).reshape(-1), rtol=1e-5, atol=1e-6)
+
+
+def test_latency_engine_follows_the_batch_engine_and_the_oracle(dev):
+    """Three scenes, ragged goal sets: iterations of a plan in both modes — layer outputs equal bit for bit, goal costs within
+    summation rounding, the same goals chosen, trajectories equal (the learner's distribution only enters through its arg-max) —
+    and the latency engine against the oracle-driven loop."""
+    from oracle.check import engine_vs_oracle
+    counts = np.array([20, 13, 7])
+    a, _ = _make(dev, 3, 20, False, counts)
+    b, _ = _make(dev, 3, 20, True, counts)
+    for e in (a, b):
+        e.select_initial_goal()
+    assert torch.equal(a.goal_idx, b.goal_idx) and torch.equal(a.traj, b.traj)
+    for t in (0, 1, 2, 20, 35, 49, 50, 55):
+        for e in (a, b):
+            e.t = t
+            e.iterate(t, early_stop=t > 1)
+        torch.cuda.synchronize()
+        for k in ("pot", "pgrad", "col"):
+            assert torch.equal(getattr(a, k), getattr(b, k)), (t, k)
+        if t < 50:
+            ga, gb = a.goal_cost_total().cpu().numpy(), b.goal_cost_total().cpu().numpy()
+            for s in range(3):
+                np.testing.assert_allclose(gb[s, :counts[s]], ga[s, :counts[s]], rtol=2e-6, atol=1e-7)
+        assert torch.equal(a.goal_idx, b.goal_idx), t
+        np.testing.assert_allclose(b.traj.cpu().numpy(), a.traj.cpu().numpy(), rtol=0, atol=1e-9)
+    c, batch = _make(dev, 2, 16, True)
+    c.select_initial_goal()
+    r = engine_vs_oracle(c, batch, [0, 1], steps=12, pin_window=False)
+    assert r["goal_idx_equal"] and r["max_traj_err"] <= 1e-6 and r["max_cost_rel_err"] <= 1e-5, r
+
+
+@pytest.mark.parametrize("early", [True, False])
+def test_latency_plan_equals_the_batch_plan_and_its_graph(dev, early):
+    """A whole plan of one scene x 64 goals (BASELINE config 2) in latency mode: the same goals and trajectories as the batch
+    layout (1e-9), and captured as one HIP graph it replays to the bits of plan()."""
+    a, _ = _make(dev, 1, 64, False, grid=64)
+    b, _ = _make(dev, 1, 64, True, grid=64)
+    a.plan(early_stop=early)
+    b.plan(early_stop=early)
+    torch.cuda.synchronize()
+    assert torch.equal(a.goal_idx, b.goal_idx) and torch.equal(a.active, b.active)
+    np.testing.assert_allclose(b.traj.cpu().numpy(), a.traj.cpu().numpy(), rtol=0, atol=1e-9)
+    np.testing.assert_allclose(b.info.cpu().numpy(), a.info.cpu().numpy(), rtol=1e-9, atol=1e-12)
+    c, _ = _make(dev, 1, 64, True, grid=64)
+    fresh = c.snapshot()
+    graph = c.capture_plan(early_stop=early)
+    c.restore(fresh)
+    graph.replay()
+    torch.cuda.synchronize()
+    for k in ("traj", "info", "goal_idx", "learner_state", "end", "goal_rows"):
+        assert np.array_equal(getattr(c, k).cpu().numpy(), getattr(b, k).cpu().numpy(), equal_nan=True), k
+    assert c._pipeline_parts() == 1 and c.schedule is None  # no pipeline, no dispatch schedule in this mode
+
+
+def test_tiled_entry_point_rejects_bad_arguments(dev):
+    import ctypes as C
+    from omg_planner_amd import _lib, ops
+    eng, _ = _make(dev, 1, 8, False)
+    l = _lib.lib()
+    p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    cost = torch.zeros(8 * 8, dtype=torch.float32, device=dev)
+
+    def call(goal_parts=4, lg=10, cb=16, spread=1, goals=eng.cv_goals, traj=eng.traj, G=8):
+        return l.omgx_goalset_cost_layer_tiled(p(eng.robot), eng.P, p(eng.scenes.objects), p(eng.scenes.scene_begin), p(eng.scenes.pool),
+                                               p(eng.traj), 270, p(goals), 1, G, 30, 0.1, 0, p(cost), p(cost), p(traj), 30, 0,
+                                               p(eng.pot), p(eng.pgrad), p(eng.col), None, None, goal_parts, lg, cb, spread, None)
+    assert call() == _lib.OMGX_OK
+    assert call(goal_parts=0) == _lib.OMGX_ERR_INVALID and call(goal_parts=9) == _lib.OMGX_ERR_INVALID
+    assert call(lg=3) == _lib.OMGX_ERR_INVALID and call(lg=0) == _lib.OMGX_ERR_INVALID and call(cb=-1) == _lib.OMGX_ERR_INVALID
+    assert call(goal_parts=4, spread=0) == _lib.OMGX_ERR_UNSUPPORTED  # parts of a goal exist in the latency-mode kernel only
+    assert call(goal_parts=1, spread=0) == _lib.OMGX_OK
+    assert call(goals=None, traj=None, G=0) == _lib.OMGX_ERR_INVALID   # nothing to do
+    assert call(goals=None, G=8) == _lib.OMGX_ERR_INVALID
+    assert l.omgx_goalset_parts(30, 4) == 4 and l.omgx_goalset_parts(30, 8) == 8 and l.omgx_goalset_parts(12, 8) == 2
+    assert l.omgx_goalset_parts(4, 8) == 1 and l.omgx_goalset_parts(0, 4) == 0 and l.omgx_goalset_parts(30, 9) == 0
+    torch.cuda.synchronize()
+    with pytest.raises(_lib.OmgHipError):  # the partial sums need S * G * parts elements
+        ops.goalset_cost_layer_tiled(eng.robot, eng.P, eng.scenes, eng.traj[:, 0], eng.cv_goals, 30, 0.1, None, None,
+                                     (cost[:8], cost[:8]), goal_parts=4)

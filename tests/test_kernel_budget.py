@@ -22,7 +22,8 @@ def test_goalset_kernel_register_and_spill_budget(tmp_path):
     subprocess.run([HIPCC, *flags, str(ROOT / "omg-planner_amd" / "csrc" / "omg_kernels.hip"), "-o", str(out)], check=True,
                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     text = out.read_text()
-    for name in ("_Z15k_goalset_queueILi2ELb0EEv9ChunkArgs", "_Z15k_goalset_queueILi2ELb1EEv9ChunkArgs"):
+    for name in ("_Z15k_goalset_queueILi2ELb0ELb0EEv9ChunkArgs", "_Z15k_goalset_queueILi2ELb1ELb0EEv9ChunkArgs",
+                 "_Z15k_goalset_queueILi2ELb0ELb1EEv9ChunkArgs"):  # batch, measuring, latency mode
         start = text.index(name + ":")
         block = text[start: text.index("; Occupancy:", start) + 40]
         vgprs = int(re.search(r"; NumVgprs: (\d+)", block).group(1))
