@@ -108,6 +108,7 @@ struct Lds {
     uint32_t* hist;  // [256]
     uint32_t* tie;   // [(n*10*16+31)/32] tie bit mask
     int* iscr;       // [16] int scalars
+    int* wlist;      // [n*10] groups that have a winner (phase 3)
     float* potl;     // [n*160] this trajectory's potentials by item (0 in the padding lanes), or null when LDS is short
     double* fkc;     // [246] kinematic-chain constants of the robot blob (UVW, TP, H, LF, RF)
 };
@@ -134,6 +135,7 @@ __device__ __forceinline__ Lds carve(unsigned char* base, int n, int P, bool pot
     L.hist = reinterpret_cast<uint32_t*>(ip); ip += 256;
     L.tie = reinterpret_cast<uint32_t*>(ip); ip += (n * 160 + 31) / 32;
     L.iscr = ip; ip += 16;
+    L.wlist = ip; ip += n * 10;
     L.potl = pot_in_lds ? reinterpret_cast<float*>(ip) : nullptr;
     return L;
 }
@@ -355,9 +357,17 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
                 __syncthreads();
                 for (int e = tid; e < 256; e += blockDim.x) L.hist[e] = 0;
                 __syncthreads();
-                for (int f = tid; f < total; f += blockDim.x) {
-                    const uint32_t key = float_key(pot[f]);
-                    if (key > key0 && (key & mask) == prefix) atomicAdd(&L.hist[(key >> shift) & 255u], 1u);
+                if (L.potl) {  // the keys are in registers already (padding lanes hold 0.0f = key0: never counted)
+#pragma unroll
+                    for (int r = 0; r < MAXIT; ++r) {
+                        const uint32_t key = float_key(pv[r]);
+                        if (key > key0 && (key & mask) == prefix) atomicAdd(&L.hist[(key >> shift) & 255u], 1u);
+                    }
+                } else {
+                    for (int f = tid; f < total; f += blockDim.x) {
+                        const uint32_t key = float_key(pot[f]);
+                        if (key > key0 && (key & mask) == prefix) atomicAdd(&L.hist[(key >> shift) & 255u], 1u);
+                    }
                 }
                 __syncthreads();
                 if (tid < 64) {  // wave 0: locate the bin holding the `want`-th largest key (suffix sums over 256 bins)
@@ -406,8 +416,16 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
     // Ties at a non-zero threshold: the reference keeps whichever numpy's unstable argsort placed last;
     // this build (like the oracle) defines it as the highest flat indices.  Mark them in a bit mask.
     if (topk_mode && K < total && !tau_is_zero) {
-        for (int f = tid; f < total; f += blockDim.x)
-            if (float_key(pot[f]) == tau) atomicOr(&L.tie[f >> 5], 1u << (f & 31));
+        if (L.potl) {  // from the registers; a non-zero threshold never matches a padding lane's 0.0f
+#pragma unroll
+            for (int r = 0; r < MAXIT; ++r) {
+                const int it = r * CH_TPB + tid, f = (it >> 4) * P + (it & 15);
+                if (float_key(pv[r]) == tau) atomicOr(&L.tie[f >> 5], 1u << (f & 31));
+            }
+        } else {
+            for (int f = tid; f < total; f += blockDim.x)
+                if (float_key(pot[f]) == tau) atomicOr(&L.tie[f >> 5], 1u << (f & 31));
+        }
         __syncthreads();
     }
 
@@ -500,26 +518,39 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
 
     // ---------------------------------------------------------------- phase 3: winners' gradients (top-k branch)
     PHASE_MARK(3);
-    auto winner_gradient = [&](const int grp) {
-        const int l = grp % 10, i = grp / 10;
-        const int p = L.gwin[grp];
-        double out[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (p >= 0) {
+    // Few of the n x 10 (waypoint, link) groups have a winner, and a winner's J_k . g for its up to 8 joints are independent: the
+    // groups with a winner are compacted into L.wlist (order irrelevant: every (group, k) element is computed on its own) and
+    // then served by 8 lanes each, lane k -> joint slot k, instead of one lane walking the 8 slots of its group (a chain of
+    // ~200 dependent LDS reads: 13 K of the step's 68 K cycles).  Same arithmetic per element, same bits.
+    auto winners_gradients = [&](const int g_begin, const int g_end) {  // two barriers inside: call from all threads
+        if (tid == 0) L.iscr[3] = 0;
+        __syncthreads();
+        for (int grp = g_begin + tid; grp < g_end; grp += blockDim.x) {
+            if (L.gwin[grp] >= 0) L.wlist[atomicAdd(&L.iscr[3], 1)] = grp;
+            else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) L.gl[(size_t)grp * 8 + k] = 0.0;
+            }
+        }
+        __syncthreads();
+        const int cnt = L.iscr[3];
+        for (int idx = tid >> 3; idx < cnt; idx += blockDim.x >> 3) {
+            const int grp = L.wlist[idx], k = tid & 7;
+            const int l = grp % 10, i = grp / 10;
+            const int p = L.gwin[grp];
             const int f = (i * 10 + l) * P + p;
             double x[3], v[3], acc[3], g[3];
             point_kinematics(L, i, l, p, P, dt, x, v, acc);
             const double dc[3] = {(double)pgrad[3 * f], (double)pgrad[3 * f + 1], (double)pgrad[3 * f + 2]};
             functional_g(v, acc, (double)(L.potl ? L.potl[(grp << 4) + p] : pot[f]), dc, g);
-            const int nk = njoints(l);
-            for (int k = 0; k < nk; ++k) out[k] = jacobian_dot(L, i, l, k, x, g);
+            L.gl[(size_t)grp * 8 + k] = k < njoints(l) ? jacobian_dot(L, i, l, k, x, g) : 0.0;
         }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) L.gl[(size_t)grp * 8 + k] = out[k];
     };
     if (topk_mode) {
-        for (int grp = tid; grp < i_defer * 10; grp += blockDim.x) winner_gradient(grp);
+        winners_gradients(0, i_defer * 10);
         __syncthreads();
     }
+    PHASE_MARK_T(9, 0);
     const double* w = prm.link_smooth_weight;
     auto obstacle_rows = [&](const int e_begin, const int e_end) {  // obstacle gradient [n][9] from the groups' J.g
         for (int e = e_begin + tid; e < e_end; e += blockDim.x) {
@@ -545,14 +576,23 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
             else sm = free_end ? (xc - xm) / dt2 : (2.0 * xc - xm - end[d]) / dt2;
             L.sg[e] = sm * w[d];
         }
-        for (int i = tid; i <= n; i += blockDim.x) {  // smoothness loss rows 0..n (cost.py:430-445)
+        // smoothness loss rows 0..n (cost.py:430-445).  The 9 weighted velocities of a row (two divisions each) are computed by 9
+        // lanes — one lane per row walked them in turn: 6 K of the step's 68 K cycles — and parked in L.tv (+ the first row of
+        // L.tvs behind it: both are free until phase 5); the row's lane then adds their squares in joint order, as before.
+        double* const evs = L.tv;  // [(n + 1)][9]
+        for (int e = tid; e < (n + 1) * 9; e += blockDim.x) {
+            const int i = e / 9, d = e % 9;
+            double vel;
+            if (i == 0) vel = L.xi[d] / dt + (-1.0 * start[d] / dt);
+            else if (i < n) vel = (L.xi[i * 9 + d] - L.xi[(i - 1) * 9 + d]) / dt;
+            else vel = free_end ? 0.0 : (-L.xi[(n - 1) * 9 + d] / dt + end[d] / dt);
+            evs[e] = vel * w[d];
+        }
+        __syncthreads();
+        for (int i = tid; i <= n; i += blockDim.x) {
             double s2 = 0.0;
             for (int d = 0; d < 9; ++d) {
-                double vel;
-                if (i == 0) vel = L.xi[d] / dt + (-1.0 * start[d] / dt);
-                else if (i < n) vel = (L.xi[i * 9 + d] - L.xi[(i - 1) * 9 + d]) / dt;
-                else vel = free_end ? 0.0 : (-L.xi[(n - 1) * 9 + d] / dt + end[d] / dt);
-                const double ev = vel * w[d];
+                const double ev = evs[i * 9 + d];
                 s2 += ev * ev;
             }
             const double nrm = sqrt(s2);
@@ -561,7 +601,9 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
     };
     if (wait_goal) {
         obstacle_rows(0, i_defer * 9);  // everything that does not involve the goal, before waiting for it
+        PHASE_MARK_T(10, 0);
         if (free_end) smooth_terms();
+        PHASE_MARK_T(11, 0);
         // ------------------------------------------------------------ the goal: wait for the learner's workgroup
         PHASE_MARK_T(23, 0);
         if (tid == 0) {
@@ -590,7 +632,7 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
         }
         PHASE_MARK_T(28, 0);
         if (topk_mode) {
-            for (int grp = i_defer * 10 + tid; grp < n * 10; grp += blockDim.x) winner_gradient(grp);
+            winners_gradients(i_defer * 10, n * 10);
         } else {
             for (int it0 = i_defer * 160; it0 < nitems; it0 += blockDim.x) phase2_item(it0 + tid, true);
         }
@@ -638,6 +680,7 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
         if (lowv) L.red[50] = 1.0;   // benign same-value races; both were zeroed in phase 0
         if (highv) L.red[51] = 1.0;
     }
+    PHASE_MARK_T(12, 0);
     __syncthreads();
     // The independent block sums run on different waves at once, each in wave_allsum's fixed order.
     {
@@ -653,11 +696,23 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
             // top-k branch: each link's summed cost is broadcast to every waypoint (cost.py:416)
             double cl = 0.0;
             bool any = false;
-            for (int i = 0; i < n; ++i) { cl += L.gcost[i * 10 + ln]; any = any || (L.gwin[i * 10 + ln] >= 0); }
+            for (int i0 = 0; i0 < n; i0 += 8) {  // the LDS reads of 8 waypoints at once, then the additions in waypoint order
+                double gv[8];
+                int wv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int i = i0 + j < n ? i0 + j : n - 1;
+                    gv[j] = L.gcost[i * 10 + ln]; wv[j] = L.gwin[i * 10 + ln];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (i0 + j < n) { cl += gv[j]; any = any || (wv[j] >= 0); }
+            }
             L.red[32 + ln] = (ln < mlinks && any) ? cl : 0.0;
         }
     }
     __syncthreads();
+    PHASE_MARK_T(13, 0);
     double obs_sum;
     if (topk_mode) {
         double per_wp = 0.0;
@@ -719,6 +774,7 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
         info[OMGX_INFO_LIMIT_STEPS] = 0.0;
         L.red[52] = terminate ? 1.0 : 0.0;
     }
+    PHASE_MARK_T(14, 0);
     if (!prm.do_update) return;
     if (prm.do_update == 2) {  // Optimizer.optimize without force_update: a terminated trajectory is left alone
         __syncthreads();
@@ -730,6 +786,7 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
     __syncthreads();
     apply_ainv(L.g, L.tvs, n, free_end, dt2);  // Ag = Ainv g
     __syncthreads();
+    PHASE_MARK_T(15, 0);
     const double eta = prm.step_size;
     const double* goal = a.goal + (size_t)s * c * 9;
     for (int e = tid; e < n * 9; e += blockDim.x) {
@@ -816,7 +873,7 @@ __global__ __launch_bounds__(CH_TPB) void k_chomp_optimize(ChompArgs a) {
 // dispatched already (no deadlock); the wait is bounded anyway.
 template <int MI>
 __global__ __launch_bounds__(CH_TPB) void k_update_optimize_split(omg_learner::LearnerArgs la, ChompArgs a, uint32_t* goal_flags,
-                                                                  uint32_t ticket) {
+                                                                  uint32_t ticket, uint32_t publish /* == ticket (test hook: see omgx_debug_drop_ticket) */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int S = la.S;
     if ((int)blockIdx.x < S) {
@@ -850,7 +907,7 @@ __global__ __launch_bounds__(CH_TPB) void k_update_optimize_split(omg_learner::L
             }
             __syncthreads();
         }
-        if (threadIdx.x == 0) __hip_atomic_store(goal_flags + blockIdx.x, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) __hip_atomic_store(goal_flags + blockIdx.x, publish, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef OMGX_PHASE_TIMING
         if (blockIdx.x == 0 && threadIdx.x == 0) g_chomp_phase[27] = __builtin_readcyclecounter();
 #endif
@@ -886,7 +943,7 @@ extern "C" int omgx_debug_chomp_phase_times(unsigned long long* h_out, int n) {
 static bool fits_small(int n) { return n * 160 <= MI_SMALL * CH_TPB; }
 static size_t host_lds_bytes(int n, int P) {
     size_t d = (size_t)(n + 2) * 120 + 60 + (size_t)n * 80 + (size_t)n * 10 + (size_t)n * 9 * 6 + (n + 1) + 30 * P + 64 + 246;
-    size_t i = (size_t)n * 10 + 256 + (n * 160 + 31) / 32 + 16;
+    size_t i = (size_t)n * 10 + 256 + (n * 160 + 31) / 32 + 16 + (size_t)n * 10;
     return d * 8 + i * 4;
 }
 static const size_t kLdsLimit = 160 * 1024;  // gfx950: 160 KB per workgroup
@@ -958,6 +1015,11 @@ extern "C" int omgx_chomp_optimize(const double* robot, const omgx_chomp_params*
     return OMGX_OK;
 }
 
+// Test hook for the bounded wait of k_update_optimize_split: while on, the learner workgroups publish a WRONG ticket, so every step
+// workgroup runs into its 2 s bound and reports a NaN cost instead of hanging the device (tests/test_gpu_round3.py).  Not part of the ABI.
+static std::atomic<int> g_drop_ticket{0};
+extern "C" int omgx_debug_drop_ticket(int32_t on) { g_drop_ticket.store(on ? 1 : 0, std::memory_order_relaxed); return OMGX_OK; }
+
 extern "C" int omgx_goal_update_optimize(const omgx_learner_params* h_learner, const double* goal_set, const double* reach,
                                          const float* goal_cost, double* learner_state, int32_t* goal_idx, double* cost_vector,
                                          const double* robot, const omgx_chomp_params* h_params, double* traj,
@@ -985,14 +1047,15 @@ extern "C" int omgx_goal_update_optimize(const omgx_learner_params* h_learner, c
     if (lds < learner_lds) lds = learner_lds;
     const bool small = fits_small(a.prm.n_waypoints);
     if (scene_flags) {
+        const uint32_t publish = g_drop_ticket.load(std::memory_order_relaxed) ? (uint32_t)ticket ^ 0x40000000u : (uint32_t)ticket;
         if (small) {
             if ((rc = allow_big_lds<2>(k_update_optimize_split<MI_SMALL>, "hipFuncSetAttribute(k_update_optimize_split)")) != OMGX_OK) return rc;
             hipLaunchKernelGGL(k_update_optimize_split<MI_SMALL>, dim3(2 * num_scenes), dim3(CH_TPB), lds, (hipStream_t)stream, la, a,
-                               reinterpret_cast<uint32_t*>(scene_flags), (uint32_t)ticket);
+                               reinterpret_cast<uint32_t*>(scene_flags), (uint32_t)ticket, publish);
         } else {
             if ((rc = allow_big_lds<3>(k_update_optimize_split<MI_FULL>, "hipFuncSetAttribute(k_update_optimize_split)")) != OMGX_OK) return rc;
             hipLaunchKernelGGL(k_update_optimize_split<MI_FULL>, dim3(2 * num_scenes), dim3(CH_TPB), lds, (hipStream_t)stream, la, a,
-                               reinterpret_cast<uint32_t*>(scene_flags), (uint32_t)ticket);
+                               reinterpret_cast<uint32_t*>(scene_flags), (uint32_t)ticket, publish);
         }
         OMGX_CHECK_LAUNCH("k_update_optimize_split");
         return OMGX_OK;

@@ -73,6 +73,36 @@ def test_bare_iterate_then_pipelined_iterate_draws_fresh_tickets(dev):
     _assert_same(one, two)
 
 
+def test_a_goal_that_never_arrives_ends_in_nan_not_in_a_hang(dev):
+    """k_update_optimize_split: a step workgroup waits for its scene's learner workgroup through a ticket.  Forward progress rests
+    on the learner workgroups leading the grid; the wait is bounded all the same (2 s), and a goal that never arrives must show
+    as a NaN cost — never as a hung device and never as a plausible number.  omgx_debug_drop_ticket makes the learner workgroups
+    publish a wrong ticket (test hook, not part of the ABI)."""
+    import time
+    from omg_planner_amd import _lib
+    eng = _make(dev, 2, 8)()
+    eng.split_update = True
+    snap = eng.snapshot()
+    eng.iterate(0)
+    torch.cuda.synchronize()
+    assert np.isfinite(eng.info.cpu().numpy()[:, 0]).all()
+    lib = _lib.lib()
+    lib.omgx_debug_drop_ticket(1)
+    try:
+        t0 = time.perf_counter()
+        eng.iterate(1)
+        torch.cuda.synchronize()
+        waited = time.perf_counter() - t0
+    finally:
+        lib.omgx_debug_drop_ticket(0)
+    assert 1.5 < waited < 10.0, waited                      # the 2 s bound of the wait, not forever
+    assert np.isnan(eng.info.cpu().numpy()[:, 0]).all()      # fail loudly
+    eng.restore(snap)                                        # and the device is as usable as before
+    eng.iterate(0)
+    torch.cuda.synchronize()
+    assert np.isfinite(eng.info.cpu().numpy()[:, 0]).all()
+
+
 def test_engine_bound_to_a_stream_does_not_pipeline(dev):
     side = torch.cuda.Stream(device=dev)
     make = _make(dev, 16, 64, stream=side)

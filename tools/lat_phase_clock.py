@@ -36,6 +36,8 @@ def main():
     n_rem = 30 - min(int((t / cfg.optim_steps) * 30), 29)
     NP = ops.goalset_parts(n_rem, eng.LAT_GOAL_PARTS)
     LP = eng.LAT_LAYER_LINK_GROUPS * ((30 + eng.LAT_LAYER_BLOCK - 1) // eng.LAT_LAYER_BLOCK)
+    if t >= cfg.optim_steps:
+        G = 0
     nwg = S * (LP + G * NP)
     wg = (C.c_ulonglong * (8 * nwg))()
     lib.omgx_debug_gs_wg.argtypes = [C.c_void_p, C.c_int]
@@ -47,13 +49,18 @@ def main():
     is_layer = np.arange(nwg) < S * LP
     g = ~is_layer
     out = {"scenes": S, "goals": G, "parts": NP, "workgroups": nwg, "kernel_span_us": float(en.max()), "last_start_us": float(st.max()),
+           "layer_wg sincos/chain+cull mean": [float(x[is_layer].mean()) for x in (t_sc - st, t_ch - t_sc)] if False else None,
+           "layer_wg_life all": [round(float(v), 2) for v in (en - st)[is_layer]]}
+    if G == 0:
+        print(json.dumps(out)); return
+    out.update({
            "goal_wg_life mean/max": [float((en - st)[g].mean()), float((en - st)[g].max())],
            "goal_wg sincos/chain/cull mean": [float(x[g].mean()) for x in (t_sc - st, t_ch - t_sc, pro - t_ch)],
            "goal_wg main loop first/last wave mean": [float((first - pro)[g].mean()), float((last - pro)[g].mean())],
            "goal_wg main loop last wave max": float((last - pro)[g].max()),
            "goal_wg epilogue mean": float((en - last)[g].mean()),
            "layer_wg_life mean/max": [float((en - st)[is_layer].mean()), float((en - st)[is_layer].max())],
-           "layer_end_max": float(en[is_layer].max()), "goal_end_max": float(en[g].max())}
+           "layer_end_max": float(en[is_layer].max()), "goal_end_max": float(en[g].max())})
     print(json.dumps(out))
 
 
