@@ -121,6 +121,13 @@ typedef struct omgx_chomp_params {
     double clip_grad_scale;           /* cfg.clip_grad_scale                                        */
     double terminate_smooth_loss;     /* cfg.terminate_smooth_loss                                  */
     double link_smooth_weight[OMGX_NUM_DOF]; /* cfg.link_smooth_weight                              */
+    /* Optional link poses the step would otherwise compute itself (ABI 7; NULL = compute).  Pose layout: omgx_pose_table.  The
+     * caller vouches that they belong to the configurations the step sees (same kinematics code: same bits, nothing else changes). */
+    const double* waypoint_poses; /* [S][n][10][12] device: poses of the CURRENT trajectory, as omgx_goalset_cost_layer_tiled's
+                                     layer workgroups leave them in `layer_poses`                                              */
+    const double* start_poses;    /* [S][10][12] device: omgx_pose_table(start)                                                */
+    const double* end_poses;      /* [S][10][12] device: poses of `end` (the goal); omgx_goal_update_optimize's learner keeps it
+                                     current when omgx_learner_params.end_poses_out points at the same buffer                  */
 } omgx_chomp_params;
 
 /* info record layout (doubles), one per trajectory: the numeric keys of Cost.compute_total_loss's
@@ -201,6 +208,15 @@ int omgx_forward_kinematics(const double* robot, int32_t n_points, const double*
                             double* link_poses, double* joint_origins, double* joint_axes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * (2c) omgx_pose_table (ABI 7)
+ * Link poses of N configurations in the layout the optimiser step keeps them in: per configuration 10 links x 12 doubles —
+ * rotation row-major [9], translation [3], BEFORE center_offset (robot_pykdl output_pose; omgx_forward_kinematics applies it).
+ * Same kinematics code as inside the step / learner kernels, so a tabulated pose carries the bits they would compute:
+ * omgx_chomp_params.start_poses / end_poses, omgx_learner_params.goal_pose_table.
+ * ------------------------------------------------------------------------------------------- */
+int omgx_pose_table(const double* robot, int32_t n_points, const double* configs, int64_t num_configs, double* poses, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * (3) omgx_goalset_cost
  * Replaces Learner.cost_vector's device work (omg/online_learner.py:104-148):
  * multi_interpolate_waypoints(..., "linear") (omg/util.py:261-290) -> Cost.batch_obstacle_cost with
@@ -279,6 +295,8 @@ int omgx_goalset_cost_layer(const double* robot, int32_t n_points,
  *   spread              non-zero: the latency-mode kernel — workgroups in plain (scene, item) order over all XCDs instead of a scene
  *                       per XCD, the kinematic chain's constants staged in LDS (a workgroup alone on a cold CU otherwise pays a
  *                       scalar-cache miss per joint).
+ * layer_poses  optional [S][n_waypoints][10][12] (ABI 7): the layer workgroups of link group 0 leave the waypoint configurations'
+ *              link poses there (layout: omgx_pose_table) for the step that follows (omgx_chomp_params.waypoint_poses).
  * num_goals = 0 (goals, traj_start, goal_cost NULL): only the trajectory layer (what omgx_fk_sdf computes for the step);
  * traj = NULL: only the goal-set batch (what omgx_goalset_cost computes, as partial sums).
  * No dispatch schedule / work counters here (they order whole goals, a scene per XCD).
@@ -294,7 +312,7 @@ int omgx_goalset_cost_layer_tiled(const double* robot, int32_t n_points,
                                   float* layer_potentials, float* layer_grads, float* layer_collides,
                                   const int32_t* active, const int32_t* goal_count,
                                   int32_t goal_parts, int32_t layer_link_groups, int32_t layer_config_block,
-                                  int32_t spread, void* stream);
+                                  int32_t spread, double* layer_poses, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * (4) omgx_chomp_optimize
@@ -370,6 +388,10 @@ typedef struct omgx_learner_params {
     double base_obstacle_weight; /* cfg.base_obstacle_weight                                        */
     double smooth_weight;        /* cfg.smoothness_base_weight * cfg.dist_eps                       */
     double eta;                  /* sqrt(log(G + 1) / optim_steps), online_learner.py:80            */
+    /* Optional (ABI 7; NULL = compute / skip): the goal configurations' link poses, tabulated once per plan (the goals are fixed),
+     * so that omgx_goal_update_optimize copies the chosen goal's poses instead of running its kinematics */
+    const double* goal_pose_table; /* [S][G][10][12] device: omgx_pose_table(goal_set)                                        */
+    double* end_poses_out;         /* [S][10][12] device: receives the chosen goal's poses (for later steps' end_poses)       */
 } omgx_learner_params;
 int64_t omgx_learner_state_doubles(int32_t num_goals);
 int omgx_goal_update(const omgx_learner_params* h_params, const double* traj, const double* goal_set, const double* reach,

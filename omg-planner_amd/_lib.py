@@ -15,10 +15,10 @@ LIB_PATH = _CSRC / "libomg_hip.so"
 OMGX_OK, OMGX_ERR_INVALID, OMGX_ERR_LAUNCH, OMGX_ERR_UNSUPPORTED = 0, -1, -2, -3
 NUM_DOF, INFO_STRIDE = 9, 16
 SCHEDULE_MAX_SCENES = 1792  # OMGX_SCHEDULE_MAX_SCENES
-ABI_VERSION = 6  # omgx_abi_version() of the library these argtypes describe
+ABI_VERSION = 7  # omgx_abi_version() of the library these argtypes describe
 
 # every symbol include/omg_hip.h declares
-EXPORTS = ["omgx_sdf_loss_forward", "omgx_fk_sdf_workspace_bytes", "omgx_fk_sdf", "omgx_forward_kinematics",
+EXPORTS = ["omgx_sdf_loss_forward", "omgx_fk_sdf_workspace_bytes", "omgx_fk_sdf", "omgx_forward_kinematics", "omgx_pose_table",
            "omgx_goalset_workspace_bytes", "omgx_goalset_cost", "omgx_goalset_cost_layer", "omgx_goalset_parts", "omgx_goalset_cost_layer_tiled", "omgx_goalset_schedule_len", "omgx_goalset_schedule", "omgx_chomp_aux_doubles", "omgx_chomp_optimize",
            "omgx_learner_state_doubles", "omgx_goal_update", "omgx_goal_update_optimize", "omgx_point_cloud_sdf", "omgx_last_error", "omgx_abi_version", "omgx_device_arch",
            "omgx_timing_enable", "omgx_timing_collect"]
@@ -35,14 +35,15 @@ class ChompParams(C.Structure):
         "use_standoff", "uncheck_finger_collision", "joint_limit_max_steps", "allow_collision_point",
         "pre_terminate", "do_update")] + [(n, C.c_double) for n in (
         "time_interval", "obstacle_weight", "smoothness_weight", "step_size", "clip_grad_scale",
-        "terminate_smooth_loss")] + [("link_smooth_weight", C.c_double * NUM_DOF)]
+        "terminate_smooth_loss")] + [("link_smooth_weight", C.c_double * NUM_DOF)] + [(n, C.c_void_p) for n in (
+        "waypoint_poses", "start_poses", "end_poses")]
 
 
 class LearnerParams(C.Structure):
     """Mirror of `omgx_learner_params` (include/omg_hip.h)."""
     _fields_ = [(n, C.c_int32) for n in ("alg", "num_goals", "n_waypoints", "start_idx", "constraint_num", "use_standoff",
                                           "normalize_cost", "cost_parts")] + [(n, C.c_double) for n in (
-        "base_obstacle_weight", "smooth_weight", "eta")]
+        "base_obstacle_weight", "smooth_weight", "eta")] + [(n, C.c_void_p) for n in ("goal_pose_table", "end_poses_out")]
 
 
 ALG = {"FTL": 0, "FTC": 1, "Exp": 2, "MD": 3, "Proj": 4}
@@ -80,7 +81,9 @@ def lib() -> C.CDLL:
         l.omgx_goalset_cost_layer.restype = C.c_int
         l.omgx_goalset_parts.argtypes = [i32, i32]
         l.omgx_goalset_parts.restype = i32
-        l.omgx_goalset_cost_layer_tiled.argtypes = [vp, i32, vp, vp, vp, vp, i64, vp, i32, i32, i32, f64, i32, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+        l.omgx_goalset_cost_layer_tiled.argtypes = [vp, i32, vp, vp, vp, vp, i64, vp, i32, i32, i32, f64, i32, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]
+        l.omgx_pose_table.argtypes = [vp, i32, vp, i64, vp, vp]
+        l.omgx_pose_table.restype = C.c_int
         l.omgx_goalset_cost_layer_tiled.restype = C.c_int
         l.omgx_goalset_schedule_len.argtypes = [i32, i32, i32]
         l.omgx_goalset_schedule_len.restype = i32
@@ -100,7 +103,7 @@ def lib() -> C.CDLL:
         l.omgx_device_arch.argtypes = [C.c_char_p, i32]
         l.omgx_timing_enable.argtypes = [i32]
         l.omgx_timing_collect.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_int32), i32]
-        for name in ("omgx_sdf_loss_forward", "omgx_fk_sdf", "omgx_forward_kinematics", "omgx_goalset_cost", "omgx_chomp_optimize",
+        for name in ("omgx_sdf_loss_forward", "omgx_fk_sdf", "omgx_forward_kinematics", "omgx_pose_table", "omgx_goalset_cost", "omgx_chomp_optimize",
                      "omgx_abi_version", "omgx_device_arch", "omgx_timing_enable", "omgx_timing_collect"):
             getattr(l, name).restype = C.c_int
         if l.omgx_abi_version() != ABI_VERSION:

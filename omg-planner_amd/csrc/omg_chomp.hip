@@ -307,8 +307,23 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
         }
         __syncthreads();
     };
-    fk_configs(0, wait_goal ? ncfg - 1 : ncfg, sc);  // the end configuration is the goal: later, if it is not known yet
-
+    // Poses the caller hands over (omgx_chomp_params: the layer launch's waypoint poses, the tabulated start / end poses) are copied,
+    // the rest is computed here: same code either way, same bits.  The end configuration is the goal: later, if it is not known yet.
+    {
+        const double* wp = prm.waypoint_poses ? prm.waypoint_poses + (size_t)s * n * 120 : nullptr;
+        const double* sp = prm.start_poses ? prm.start_poses + (size_t)s * 120 : nullptr;
+        const double* ep = (!wait_goal && prm.end_poses) ? prm.end_poses + (size_t)s * 120 : nullptr;
+        if (wp) for (int e = tid; e < n * 120; e += blockDim.x) L.pose[120 + e] = wp[e];
+        if (sp) for (int e = tid; e < 120; e += blockDim.x) L.pose[e] = sp[e];
+        if (ep) for (int e = tid; e < 120; e += blockDim.x) L.pose[(size_t)(ncfg - 1) * 120 + e] = ep[e];
+        const bool need_end = !wait_goal && !ep;
+        if (!wp) fk_configs(sp ? 1 : 0, (need_end ? ncfg : ncfg - 1), sc);  // start (unless given) + waypoints (+ end)
+        else {
+            if (!sp) fk_configs(0, 1, sc);
+            if (need_end) fk_configs(ncfg - 1, ncfg, sc);
+            if (sp && !need_end) __syncthreads();  // the copies
+        }
+    }
     PHASE_MARK_T(17, CH_TPB - 128);
     PHASE_MARK_T(20, 0);
     double colsum = 0.0;
@@ -888,9 +903,19 @@ __global__ __launch_bounds__(CH_TPB) void k_update_optimize_split(omg_learner::L
         // them, instead of in the step's workgroup right after its wait.  The 10 x 12 doubles travel in the scene's `grad`
         // rows, which the step's workgroup overwrites with the gradient only after it has taken the pose (chomp_scene).
         if (end_pose_fits(a.prm.n_waypoints) && !(a.active && a.active[blockIdx.x] == 0)) {
+            double* out = a.grad + (size_t)blockIdx.x * a.prm.n_waypoints * 9;
+            if (la.prm.goal_pose_table) {
+                // the goals' poses were tabulated for the plan (omgx_pose_table): the chosen goal's 120 doubles are copied
+                const double* src = la.prm.goal_pose_table + ((size_t)blockIdx.x * la.prm.num_goals + la.goal_idx[blockIdx.x]) * 120;
+                if (threadIdx.x < 120) {
+                    const double v = src[threadIdx.x];
+                    out[threadIdx.x] = v;
+                    if (la.prm.end_poses_out) la.prm.end_poses_out[(size_t)blockIdx.x * 120 + threadIdx.x] = v;
+                }
+                __syncthreads();
+            } else {
             const RobotView rv(a.robot, a.prm.n_points);
             const double* q = a.end + 9 * (size_t)blockIdx.x;
-            double* out = a.grad + (size_t)blockIdx.x * a.prm.n_waypoints * 9;
             if (threadIdx.x < 7) {
                 double sn, cs;
                 fk_joint_sincos(q[threadIdx.x], sn, cs);
@@ -906,6 +931,7 @@ __global__ __launch_bounds__(CH_TPB) void k_update_optimize_split(omg_learner::L
                 });
             }
             __syncthreads();
+            }
         }
         if (threadIdx.x == 0) __hip_atomic_store(goal_flags + blockIdx.x, publish, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef OMGX_PHASE_TIMING
@@ -928,6 +954,11 @@ __global__ __launch_bounds__(CH_TPB) void k_update_optimize(omg_learner::Learner
     omg_learner::learner_scene(la, blockIdx.x, reinterpret_cast<double (*)[OMGX_MAX_GOALS]>(shl),
                                reinterpret_cast<double (*)[128]>(shl + 5 * OMGX_MAX_GOALS));
     __syncthreads();  // the goal written by wave 0 (global memory) is visible to the whole workgroup
+    if (la.prm.goal_pose_table && la.prm.end_poses_out && !(la.active && la.active[blockIdx.x] == 0)) {  // keep the end pose current
+        const double* src = la.prm.goal_pose_table + ((size_t)blockIdx.x * la.prm.num_goals + la.goal_idx[blockIdx.x]) * 120;
+        if (threadIdx.x < 120) la.prm.end_poses_out[(size_t)blockIdx.x * 120 + threadIdx.x] = src[threadIdx.x];
+        __syncthreads();
+    }
     chomp_scene<MI>(a, smem, blockIdx.x);
 }
 

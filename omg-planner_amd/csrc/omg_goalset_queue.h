@@ -232,6 +232,16 @@ __global__ __launch_bounds__(256, GQ_WG_PER_CU) void k_goalset_queue(ChunkArgs a
     // produces the links' poses in order; the other waves cull the rows of a link as soon as every chain wave has published
     // it (a progress word per chain wave in LDS, release / acquire at workgroup scope): the culling stage disappears behind
     // the chain.  With 64 waypoints all four waves run the chain and the rows are culled afterwards.
+    // LAT: the q-th tile of this wave.  The part's tiles (t = part + NP j) are dealt to the four waves heaviest first — the work grows
+    // with the waypoint block and towards the hand, i.e. with j — in a serpentine (ranks 0 1 2 3 | 3 2 1 0 | 0 1 ...), so the wave that
+    // gets the heaviest tile gets the lightest ones with it; dealt in plain order (j mod 4) the waves with three tiles also held
+    // the two heaviest.  < 0: no such tile.
+    auto lat_tile = [&](int q) {
+        const int ntl = ((CH + 3) >> 2) * (10 / LB);
+        const int ntp = ntl > part ? (ntl - part + NP - 1) / NP : 0;  // tiles of this part
+        const int r = 4 * q + ((q & 1) ? 3 - wave : wave);             // rank by weight, heaviest = 0
+        return r < ntp ? part + NP * (ntp - 1 - r) : -1;
+    };
     const int chain_waves = (3 * (CH + 1) + 63) >> 6;
     const bool cull_beside_chain = !LAT && chain_waves < 4;  // LAT: every wave culls the rows of its own tiles after the chain (below)
     {   // Kinematics of the start + CH interpolated configurations in two stages (omg_device.h: fk_joint_sincos on
@@ -310,12 +320,10 @@ __global__ __launch_bounds__(256, GQ_WG_PER_CU) void k_goalset_queue(ChunkArgs a
         // beside the chain, 5 links per culling wave were the longest thing in the prologue).  Here every wave culls exactly the rows
         // its own tiles will read — lane -> (tile slot, link of the pair, waypoint of the block), normally one pass — and goes on
         // to its main loop without a barrier (its own LDS writes, in order).
-        const int ntl = ((CH + 3) >> 2) * (10 / LB);
-        for (int j0 = 0;; j0 += 8) {
-            const int t = part + NP * (wave + 4 * (j0 + (lane >> 3)));
-            if (part + NP * (wave + 4 * j0) >= ntl) break;  // the pass's first tile slot: wave-uniform
+        for (int q0 = 0; lat_tile(q0) >= 0; q0 += 8) {  // the pass's first tile slot: wave-uniform
+            const int t = lat_tile(q0 + (lane >> 3));
             const int rb = t / (10 / LB), l = (t - rb * (10 / LB)) * LB + ((lane >> 2) & 1), ci = rb * 4 + (lane & 3);
-            if (t < ntl && ci < CH) cull_row(l, ci);
+            if (t >= 0 && ci < CH) cull_row(l, ci);
         }
     } else if (!cull_beside_chain) {
         for (int row = tid; row < 10 * CH; row += 256) cull_row(row / CH, row - (row / CH) * CH);
@@ -440,7 +448,7 @@ __global__ __launch_bounds__(256, GQ_WG_PER_CU) void k_goalset_queue(ChunkArgs a
     const int pc3 = 3 * (p < P ? p : 0);  // lane part of a collision-point address (doubles)
     GS_COUNT(0);
 #pragma unroll 1
-    for (int t = LAT ? part + NP * wave : wave; t < ntiles; t += LAT ? 4 * NP : 4) {  // every lane stays active: invalid items are flagged, not skipped
+    for (int q = 0, t = LAT ? lat_tile(0) : wave; LAT ? t >= 0 : t < ntiles; t = LAT ? lat_tile(++q) : t + 4) {  // every lane stays active: invalid items are flagged, not skipped
         const int rb = t / (10 / LB), l0 = (t - rb * (10 / LB)) * LB;
         GS_COUNT(1);
         {

@@ -206,6 +206,7 @@ struct ChunkArgs {
     // (10 / layer_lg links x layer_cb waypoints), workgroups in plain order over all XCDs (spread).
     int NG, NP;
     int layer_parts, layer_lg, layer_nb, layer_cb, spread;
+    double* wp_pose_out;       // [S][wp_n][10][12] or null: the layer workgroups of link group 0 leave the waypoints' poses here
     uint32_t* work;
 };
 
@@ -402,6 +403,8 @@ __device__ __forceinline__ void waypoint_layer_block(const ChunkArgs& a, const i
     }
     if (LAT && threadIdx.x < 246) fkc[threadIdx.x] = fkv;
     __syncthreads();
+    // (the step that follows can take the waypoints' poses from here instead of running the same kinematics again: omgx_chomp_params)
+    double* const gpose = (a.wp_pose_out && l_begin == 0) ? a.wp_pose_out + ((int64_t)s * n + c_begin) * 120 : nullptr;
     auto run_chain = [&](const auto& view) {
         for (int t = threadIdx.x; t < nloc * 3; t += 256) {
             const int cfg = t / 3, r = t - cfg * 3;
@@ -409,6 +412,10 @@ __device__ __forceinline__ void waypoint_layer_block(const ChunkArgs& a, const i
                 double* dst = lds_pose + ((size_t)l * PS + cfg) * 9;
                 if (r < 2) { dst[3 * r] = r0; dst[3 * r + 1] = r1; dst[3 * r + 2] = r2; }
                 dst[6 + r] = tt;
+                if (gpose) {
+                    double* g = gpose + ((size_t)cfg * 10 + l) * 12;
+                    g[3 * r] = r0; g[3 * r + 1] = r1; g[3 * r + 2] = r2; g[9 + r] = tt;
+                }
             });
         }
     };
@@ -583,7 +590,7 @@ static void timing_events(int kind, hipEvent_t* ev0, hipEvent_t* ev1) {
     *ev0 = g_ev[i][0]; *ev1 = g_ev[i][1];
     ++g_timing_n;
 }
-extern "C" int omgx_abi_version(void) { return 6; }  // 2: `active` masks; 3: ragged goal sets (goal_count, eta); 4: goal schedule + work; 5: 184-byte object records (influence region = rounded box); 6: omgx_goalset_cost_layer_tiled, omgx_learner_params.cost_parts
+extern "C" int omgx_abi_version(void) { return 7; }  // 2: `active` masks; 3: ragged goal sets (goal_count, eta); 4: goal schedule + work; 5: 184-byte object records (influence region = rounded box); 6: omgx_goalset_cost_layer_tiled, omgx_learner_params.cost_parts; 7: pose tables (omgx_pose_table, pointer fields at the end of both parameter blocks, layer_poses)
 extern "C" int omgx_device_arch(char* h_buf, int32_t h_len) {
     if (!h_buf || h_len <= 0) return OMGX_ERR_INVALID;
     int dev = 0;
@@ -690,6 +697,7 @@ struct GsTiling {
     int layer_lg = 5;    // link groups of the trajectory layer (1, 2, 5 or 10)
     int layer_cb = 0;    // waypoints per layer workgroup; 0: all
     int spread = 0;      // latency mode: workgroups in plain (scene, item) order over all XCDs instead of a scene per XCD
+    double* wp_pose_out = nullptr;  // the waypoints' poses for the step that follows (ChunkArgs)
 };
 
 // Workgroups per goal for a window of n_remaining configurations: the largest power of two <= max_parts that still leaves every
@@ -712,6 +720,7 @@ static int launch_goalset(ChunkArgs& ca, int timing_kind, hipStream_t st, const 
     ca.NP = ca.NG > 0 ? gs_parts(ca.CH, tl.goal_parts) : 1;
     ca.NCH = ca.NG * ca.NP;
     if (ca.spread && (ca.schedule || ca.work)) return OMGX_ERR_UNSUPPORTED;  // a dispatch schedule orders whole goals, a scene per XCD
+    ca.wp_pose_out = layer ? tl.wp_pose_out : nullptr;
     ca.layer_lg = tl.layer_lg;
     ca.layer_cb = layer ? ((tl.layer_cb > 0 && tl.layer_cb < ca.wp_n) ? tl.layer_cb : ca.wp_n) : 1;
     ca.layer_nb = layer ? (ca.wp_n + ca.layer_cb - 1) / ca.layer_cb : 1;
@@ -859,6 +868,38 @@ extern "C" int omgx_forward_kinematics(const double* robot, int32_t n_points, co
     hipLaunchKernelGGL(k_forward_kinematics, dim3((unsigned)((num_configs + 63) / 64)), dim3(64), 0, (hipStream_t)stream,
                        robot, n_points, joints, num_configs, link_poses, joint_origins, joint_axes);
     OMGX_CHECK_LAUNCH("k_forward_kinematics");
+    return OMGX_OK;
+}
+
+// (2c) link poses of N configurations as the step keeps them ([10][12] doubles each): one lane per (configuration, pose row), the
+// same fk_joint_sincos / fk_chain_row as inside k_chomp_optimize and the learner's workgroup
+__global__ __launch_bounds__(192) void k_pose_table(const double* __restrict__ robot, int P, const double* __restrict__ configs,
+                                                    int64_t N, double* __restrict__ poses) {
+    const int64_t e = (int64_t)blockIdx.x * 64 + threadIdx.x / 3;  // 64 configurations per workgroup
+    const int r = threadIdx.x % 3;
+    if (e >= N) return;
+    const RobotView rv(robot, P);
+    const double* q = configs + 9 * e;
+    double sc[14];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) fk_joint_sincos(q[i], sc[2 * i], sc[2 * i + 1]);
+    double* out = poses + e * 120;
+    fk_chain_row(rv, r, sc, q[7], q[8], [&](int l, double r0, double r1, double r2, double tr) {
+        double* dst = out + 12 * l + 3 * r;
+        dst[0] = r0; dst[1] = r1; dst[2] = r2;
+        dst[9 - 2 * r] = tr;  // element 9 + r of the pose
+    });
+}
+
+extern "C" int omgx_pose_table(const double* robot, int32_t n_points, const double* configs, int64_t num_configs, double* poses,
+                               void* stream) {
+    if (num_configs < 0) return OMGX_ERR_INVALID;
+    if (num_configs == 0) return OMGX_OK;
+    if (!robot || !configs || !poses) return OMGX_ERR_INVALID;
+    if (n_points < 1 || n_points > OMGX_MAX_POINTS) return OMGX_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(k_pose_table, dim3((unsigned)((num_configs + 63) / 64)), dim3(192), 0, (hipStream_t)stream, robot, n_points,
+                       configs, num_configs, poses);
+    OMGX_CHECK_LAUNCH("k_pose_table");
     return OMGX_OK;
 }
 
@@ -1089,10 +1130,12 @@ extern "C" int omgx_goalset_cost_layer_tiled(const double* robot, int32_t n_poin
                                              float* collides, const double* traj, int32_t n_waypoints, int32_t layer_soften_fingers,
                                              float* layer_potentials, float* layer_grads, float* layer_collides,
                                              const int32_t* active, const int32_t* goal_count, int32_t goal_parts,
-                                             int32_t layer_link_groups, int32_t layer_config_block, int32_t spread, void* stream) {
+                                             int32_t layer_link_groups, int32_t layer_config_block, int32_t spread, double* layer_poses,
+                                             void* stream) {
     if (!traj && num_goals <= 0) return OMGX_ERR_INVALID;
     GsTiling tl;
     tl.goal_parts = goal_parts; tl.layer_lg = layer_link_groups; tl.layer_cb = layer_config_block; tl.spread = spread;
+    tl.wp_pose_out = traj ? layer_poses : nullptr;
     return goalset_cost_impl(robot, n_points, objects, scene_begin, sdf_pool, traj_start, traj_start_stride, goals, num_scenes,
                              num_goals, num_goals > 0 ? n_remaining : 1, time_interval, soften_fingers, goal_cost, nullptr, collides, nullptr, traj,
                              n_waypoints, layer_soften_fingers, layer_potentials, layer_grads, layer_collides, active, goal_count, nullptr,

@@ -97,6 +97,7 @@ class ChompEngine:
     LAT_GOAL_PARTS = 4
     LAT_LAYER_LINK_GROUPS = 10
     LAT_LAYER_BLOCK = 16
+    LAT_HAND_OVER_POSES = True  # inside plan(): link poses handed between the launches (False: every kernel runs its own kinematics; same bits)
 
     def __init__(self, model: PandaModel, batch: SceneBatch, cfg: Config, start: np.ndarray, goal_set: np.ndarray,
                  reach_grasps: np.ndarray | None = None, traj_init: np.ndarray | None = None, device="cuda:0",
@@ -167,6 +168,15 @@ class ChompEngine:
         # latency mode: [S][G][parts] partial sums, parts = ceil(window / LAT_GOAL_PARTS) shrinking with the window (flat buffer)
         self._parts_max = ops.goalset_parts(n, self.LAT_GOAL_PARTS) if self.latency else 1
         self._parts_last = 1
+        # latency mode, inside plan(): link poses handed between the launches instead of being recomputed (omgx_pose_table, ABI 7)
+        # — the waypoints' poses from the layer workgroups to the step, the start's and the goals' poses tabulated per plan
+        self._poses_on = False
+        if self.latency:
+            self.wp_pose = torch.empty((S, n, 10, 12), **f64)
+            self.start_pose = torch.empty((S, 10, 12), **f64)
+            self.end_pose = torch.zeros((S, 10, 12), **f64)
+            self.goal_pose_tab = torch.empty((S, G, 10, 12), **f64)
+            self._STATE = ChompEngine._STATE + ("end_pose",)
         self.goal_cost = torch.zeros((S, G * self._parts_max), **f32)
         self.goal_col = torch.zeros((S, G * self._parts_max), **f32)
         self.learner_state = ops.learner_state(S, G, dev, goal_counts)  # sum_costs | p | experts_p | q | experts_costs
@@ -245,6 +255,8 @@ class ChompEngine:
         p.terminate_smooth_loss = float(cfg.terminate_smooth_loss)
         for d in range(9):
             p.link_smooth_weight[d] = float(cfg.link_smooth_weight[d])
+        if self._poses_on:
+            p.waypoint_poses, p.start_poses, p.end_poses = self.wp_pose.data_ptr(), self.start_pose.data_ptr(), self.end_pose.data_ptr()
         return p
 
     def _schedule(self):
@@ -281,7 +293,18 @@ class ChompEngine:
         p.smooth_weight = float(cfg.smoothness_base_weight * cfg.dist_eps)
         p.eta = self.eta
         p.cost_parts = ops.goalset_parts(cfg.timesteps - p.start_idx, self.LAT_GOAL_PARTS) if self.latency else 0
+        if self._poses_on:
+            p.goal_pose_table, p.end_poses_out = self.goal_pose_tab.data_ptr(), self.end_pose.data_ptr()
         return p
+
+    def _refresh_pose_tables(self):
+        """Latency mode, at the start of a plan (after the initial goal pick): the start configurations' and all goal
+        configurations' link poses (two small launches) and the current goal's poses — from then on the fused launches keep
+        `end_pose` current themselves.  Valid while start, goal_set and goal_idx are only changed by the plan's own launches."""
+        ops.pose_table(self.robot, self.P, self.start, out=self.start_pose)
+        ops.pose_table(self.robot, self.P, self.goal_set, out=self.goal_pose_tab)
+        ar = torch.arange(self.S, device=self.device)
+        torch.index_select(self.goal_pose_tab.view(self.S * self.G, 120), 0, ar * self.G + self.goal_idx.long(), out=self.end_pose.view(self.S, 120))
 
     def _tiling(self):
         return (self.LAT_GOAL_PARTS, self.LAT_LAYER_LINK_GROUPS, self.LAT_LAYER_BLOCK, 1)
@@ -412,7 +435,8 @@ class ChompEngine:
                     self.traj if with_layer else None, (self.pot, self.pgrad, self.col), (self.goal_cost, self.goal_col),
                     soften_fingers=False, layer_soften_fingers=self.cfg.uncheck_finger_collision == -1, active=self._mask(),
                     goal_count=self.goal_count, goal_parts=self.LAT_GOAL_PARTS, layer_link_groups=self.LAT_LAYER_LINK_GROUPS,
-                    layer_config_block=self.LAT_LAYER_BLOCK, spread=True)
+                    layer_config_block=self.LAT_LAYER_BLOCK, spread=True,
+                    layer_poses=self.wp_pose if (self._poses_on and with_layer) else None)
             elif with_layer:  # the SDF layer of the current trajectories rides on the goal-set launch
                 # the second launch is the measuring one (the first runs on cold caches and would distort the weights);
                 # until then the items are split evenly by count.  Small batches keep the even split: measuring only pays
@@ -500,7 +524,8 @@ class ChompEngine:
             ops.goalset_cost_layer_tiled(self.robot, self.P, self.scenes, None, None, 1, self.cfg.time_interval, self.traj,
                                          (self.pot, self.pgrad, self.col), None, layer_soften_fingers=self.cfg.uncheck_finger_collision == -1,
                                          layer_link_groups=self.LAT_LAYER_LINK_GROUPS,
-                                         layer_config_block=self.LAT_LAYER_BLOCK, spread=True)
+                                         layer_config_block=self.LAT_LAYER_BLOCK, spread=True,
+                                         layer_poses=self.wp_pose if self._poses_on else None)
             return
         ops.fk_sdf(self.robot, self.P, self.scenes, self.traj, soften_fingers=self.cfg.uncheck_finger_collision == -1,
                    out=(self.pot, self.pgrad, self.col))
@@ -597,7 +622,8 @@ class ChompEngine:
                                        self.learner_state, self.goal_idx, self.start, self.end, self.goal_rows, self.goal_point,
                                        (self.grad, self.cost_traj, self.info), self.cost_vec, self._active, self.goal_count, self.eta_s,
                                        self._scene_flags, layer_soften_fingers=self.cfg.uncheck_finger_collision == -1,
-                                       tiling=self._tiling() if self.latency else None)
+                                       tiling=self._tiling() if self.latency else None,
+                                       layer_poses=self.wp_pose if self.latency else None)
             hot = self._hot = (key, calls, baked)
         calls = hot[1]
         stream = (self.stream if self.stream is not None else torch.cuda.current_stream(self.device)).cuda_stream
@@ -605,6 +631,7 @@ class ChompEngine:
         prm = self._learner_params()
         self._gs_launches += 1
         self._parts_last = max(1, int(prm.cost_parts))
+        calls.use_layer_poses = self._poses_on
         calls.goalset_layer(prm.start_idx, self._masked, self.schedule if use_sched else None, None, stream)
         self._schedule()
         split = 2 * self.S <= self._num_cus if self.split_update is None else bool(self.split_update)
@@ -705,6 +732,9 @@ class ChompEngine:
         cfg = self.cfg
         if initial_goal and cfg.goal_set_proj:
             self.select_initial_goal()
+        if self.latency and self.LAT_HAND_OVER_POSES and not self.separate_launches:
+            self._refresh_pose_tables()
+            self._poses_on = True
         self.iterations_run = 0
         self.timed_out = False
         t_start = time.time()
@@ -726,9 +756,15 @@ class ChompEngine:
                         break
                 if self._plan_all_done(early_stop, t):
                     break
+        except BaseException:
+            self._poses_on = False
+            raise
         finally:
             self._in_plan = False
-        return self.optimize(False)
+        try:
+            return self.optimize(False)
+        finally:
+            self._poses_on = False
 
     PLAN_LOOKAHEAD = 8  # iterations the host may be ahead of the device while plan() watches cfg.timeout
 

@@ -166,11 +166,12 @@ def goalset_parts(n_remaining: int, goal_parts: int) -> int:
 
 def goalset_cost_layer_tiled(robot, P, scenes: DeviceScenes, traj_start, goals, n_remaining, dt, traj, layer_out, out,
                              soften_fingers=False, layer_soften_fingers=False, active=None, goal_count=None, goal_parts=4,
-                             layer_link_groups=10, layer_config_block=16, spread=True):
+                             layer_link_groups=10, layer_config_block=16, spread=True, layer_poses=None):
     """The goal-set batch and / or the trajectory layer cut into many small workgroups (omgx_goalset_cost_layer_tiled: latency
     mode for one or a few scenes).  goals None: only the layer; traj None: only the batch.  out = (cost, collides): float32
     device tensors with at least S * G * goalset_parts(n_remaining, goal_parts) elements, written as [S][G][parts] PARTIAL sums
-    (the learner adds them: LearnerParams.cost_parts).  Returns the number of parts per goal."""
+    (the learner adds them: LearnerParams.cost_parts).  layer_poses: optional float64 [S,n,10,12] receiving the waypoints' link
+    poses (ChompParams.waypoint_poses of the step that follows).  Returns the number of parts per goal."""
     dev = (goals if goals is not None else traj).device
     S = (goals if goals is not None else traj).shape[0]
     G, ts_stride, parts = 0, 9, 1
@@ -192,6 +193,10 @@ def goalset_cost_layer_tiled(robot, P, scenes: DeviceScenes, traj_start, goals, 
                 raise _lib.OmgHipError(f"{n_} must hold S * G * parts = {S * G * parts} elements")
     lp = lg = lc = None
     n = 0
+    if layer_poses is not None:
+        _need(layer_poses, torch.float64, "layer_poses")
+        if traj is None or layer_poses.numel() != S * traj.shape[1] * 120:
+            raise _lib.OmgHipError("layer_poses must be [S,n,10,12] and needs the trajectory layer")
     if traj is not None:
         _need(traj, torch.float64, "traj")
         lp, lg, lc = layer_out
@@ -205,7 +210,8 @@ def goalset_cost_layer_tiled(robot, P, scenes: DeviceScenes, traj_start, goals, 
             _ptr(robot), P, _ptr(scenes.objects), _ptr(scenes.scene_begin), _ptr(scenes.pool), _ptr(traj_start) if goals is not None else None,
             ts_stride, _ptr(goals), S, G, int(n_remaining) if goals is not None else 1, float(dt), int(bool(soften_fingers)), _ptr(cost), _ptr(col),
             _ptr(traj), n, int(bool(layer_soften_fingers)), _ptr(lp), _ptr(lg), _ptr(lc), _ptr(_active(active, S)),
-            _ptr(_active(goal_count, S)), int(goal_parts), int(layer_link_groups), int(layer_config_block), int(bool(spread)), _stream()),
+            _ptr(_active(goal_count, S)), int(goal_parts), int(layer_link_groups), int(layer_config_block), int(bool(spread)),
+            _ptr(layer_poses), _stream()),
             "omgx_goalset_cost_layer_tiled")
     return parts
 
@@ -243,6 +249,22 @@ def forward_kinematics(robot, P, joints, want_joint_info=True):
         check(_lib.lib().omgx_forward_kinematics(_ptr(robot), P, _ptr(joints), B, _ptr(poses), _ptr(org), _ptr(ax), _stream()),
               "omgx_forward_kinematics")
     return poses, org, ax
+
+
+def pose_table(robot, P, configs: torch.Tensor, out: "torch.Tensor | None" = None) -> torch.Tensor:
+    """configs [..., 9] f64 -> link poses [..., 10, 12] f64 in the step's own layout (omgx_pose_table: rotation rows, translation;
+    before center_offset): what ChompParams.start_poses / end_poses and LearnerParams.goal_pose_table point at."""
+    _need(configs, torch.float64, "configs")
+    N = configs.numel() // 9
+    if out is None:
+        out = torch.empty(tuple(configs.shape[:-1]) + (10, 12), dtype=torch.float64, device=configs.device)
+    else:
+        _need(out, torch.float64, "poses")
+        if out.numel() != N * 120:
+            raise _lib.OmgHipError("poses must hold 120 doubles per configuration")
+    with torch.cuda.device(configs.device):
+        check(_lib.lib().omgx_pose_table(_ptr(robot), P, _ptr(configs), N, _ptr(out), _stream()), "omgx_pose_table")
+    return out
 
 
 def chomp_optimize(robot, params: ChompParams, traj, start, end, goal, goal_point, pot, pgrad, col, active=None, out=None,
@@ -361,7 +383,7 @@ class IterationCalls:
 
     def __init__(self, robot, P, scenes: DeviceScenes, goals, dt, traj, layer_out, goal_out, goal_set, reach, state, goal_idx,
                  start, end, goal_rows, goal_point, step_out, cost_vector, active, goal_count=None, eta=None, scene_flags=None,
-                 layer_soften_fingers=False, tiling=None):
+                 layer_soften_fingers=False, tiling=None, layer_poses=None):
         lp, lg, lc = layer_out
         cost, col = goal_out
         grad, cost_traj, info = step_out
@@ -379,6 +401,11 @@ class IterationCalls:
         # tiling = (goal_parts, layer_link_groups, layer_config_block, spread): the launches go through omgx_goalset_cost_layer_tiled
         # (latency mode), goal_cost / collides then hold [S][G][parts] partial sums
         self._tiling = None if tiling is None else tuple(int(v) for v in tiling)
+        if layer_poses is not None:
+            _need(layer_poses, torch.float64, "layer_poses")
+            if self._tiling is None or layer_poses.numel() != S * n * 120:
+                raise _lib.OmgHipError("layer_poses must be [S,n,10,12] and needs a tiled launch")
+        self._layer_poses = _ptr(layer_poses)
         if self._tiling is not None:
             need = S * G * goalset_parts(n, self._tiling[0])
             if cost.numel() < need or col.numel() < need:
@@ -404,6 +431,7 @@ class IterationCalls:
         self._up_b = (p(traj), p(start), p(end), p(goal_rows), p(goal_point), p(lp), p(lg), p(lc), p(active), S, p(grad), p(cost_traj),
                       p(info), None)
         self._flags, self._eta = p(scene_flags), p(eta)
+        self.use_layer_poses = False  # set per launch by the owner: only while the step that follows takes the poses
 
     def _on_device(self):
         return torch.cuda.current_device() == self._dev_index
@@ -417,7 +445,7 @@ class IterationCalls:
             cost, col, _ws, traj, n, soft, lp, lg, lc = self._gs_mid
             args = (*self._gs_head, C.c_void_p(self._traj_addr + 72 * start_idx), self.n * 9, self._goals, self.S, self.G,
                     self.n - start_idx, self.dt, 0, cost, col, traj, n, soft, lp, lg, lc, self._active_p if masked else None,
-                    self._goal_count, *self._tiling, C.c_void_p(stream))
+                    self._goal_count, *self._tiling, self._layer_poses if self.use_layer_poses else None, C.c_void_p(stream))
             if self._on_device():
                 check(self._f_gst(*args), "omgx_goalset_cost_layer_tiled")
             else:

@@ -27,14 +27,15 @@ class ChompParams(C.Structure):
         "use_standoff", "uncheck_finger_collision", "joint_limit_max_steps", "allow_collision_point",
         "pre_terminate", "do_update")] + [(n, C.c_double) for n in (
         "time_interval", "obstacle_weight", "smoothness_weight", "step_size", "clip_grad_scale",
-        "terminate_smooth_loss")] + [("link_smooth_weight", C.c_double * NUM_DOF)]
+        "terminate_smooth_loss")] + [("link_smooth_weight", C.c_double * NUM_DOF)] + [(n, C.c_void_p) for n in (
+        "waypoint_poses", "start_poses", "end_poses")]
 
 
 class LearnerParams(C.Structure):
     """Mirror of `omgx_learner_params` (include/omg_hip.h)."""
     _fields_ = [(n, C.c_int32) for n in ("alg", "num_goals", "n_waypoints", "start_idx", "constraint_num", "use_standoff",
                                           "normalize_cost", "cost_parts")] + [(n, C.c_double) for n in (
-        "base_obstacle_weight", "smooth_weight", "eta")]
+        "base_obstacle_weight", "smooth_weight", "eta")] + [(n, C.c_void_p) for n in ("goal_pose_table", "end_poses_out")]
 
 
 ALG = {"FTL": 0, "FTC": 1, "Exp": 2, "MD": 3, "Proj": 4}

@@ -95,13 +95,20 @@ def one_trial(rng, trial, dev, dry=False):
             e_goals[s_, counts[s_]:] = np.nan
             if e_reach is not None:
                 e_reach[s_, counts[s_]:] = np.nan
-    eng = ChompEngine(m, batch, copy.deepcopy(cfg), start, e_goals, reach_grasps=e_reach, device=dev, ol_alg=alg,
-                      goal_counts=None if counts is None else counts)
     # the engine's software pipeline (scene ranges on several streams): forced in a third of the trials with at least two scenes
-    # (same separate random stream); the comparisons below then need eng.join() before they read the engine's tensors
+    # (same separate random stream); the comparisons below then need eng.join() before they read the engine's tensors.
+    # Latency mode (omgx_goalset_cost_layer_tiled: goals in parts, layer in 20 workgroups per scene) in a third of the others.
+    pipe = None
     if S >= 2 and r2.rand() < 0.35:
-        eng.pipeline = int(min(S, r2.choice([2, 2, 3])))
+        pipe = int(min(S, r2.choice([2, 2, 3])))
         STATS["pipelined"] = STATS.get("pipelined", 0) + 1
+    lat = pipe is None and r2.rand() < 0.33
+    if lat:
+        STATS["latency"] = STATS.get("latency", 0) + 1
+    eng = ChompEngine(m, batch, copy.deepcopy(cfg), start, e_goals, reach_grasps=e_reach, device=dev, ol_alg=alg,
+                      goal_counts=None if counts is None else counts, latency_mode=lat)
+    if pipe is not None:
+        eng.pipeline = pipe
     traj = eng.traj.cpu().numpy().copy()
     state = orc.learner_state_init(S, G)
     states_r = None if counts is None else [orc.learner_state_init(1, int(k_)) for k_ in counts]
@@ -214,7 +221,7 @@ def main(trials=None, seed=None):
             print(f"trial {k}: ok, max |traj - oracle| {worst:.2e}", flush=True)
     print(f"{trials - bad}/{trials} trials agree; worst trajectory difference {worst_all:.2e}; joint-limit projection steps "
           f"{STATS['limit_steps']}, limit-violation flags {STATS['violations']}, scene-iterations skipped after termination {STATS['stopped']}, "
-          f"{STATS.get('ragged', 0)} trials with ragged goal sets, {STATS.get('pipelined', 0)} with a pipelined engine; {time.time() - t0:.0f} s")
+          f"{STATS.get('ragged', 0)} trials with ragged goal sets, {STATS.get('pipelined', 0)} with a pipelined engine, {STATS.get('latency', 0)} in latency mode; {time.time() - t0:.0f} s")
     return 1 if bad else 0
 
 

@@ -30,7 +30,8 @@ def test_struct_layouts_match_header():
     from omg_planner_amd import _lib, scenes
     assert scenes.OBJECT_DTYPE.itemsize == 184
     assert scenes.OBJECT_DTYPE.fields["grid_offset"][1] == 104 and scenes.OBJECT_DTYPE.fields["inv_extent"][1] == 112
-    assert C.sizeof(_lib.ChompParams) == 12 * 4 + 6 * 8 + 9 * 8
+    assert C.sizeof(_lib.ChompParams) == 12 * 4 + 6 * 8 + 9 * 8 + 3 * 8   # ABI 7: three optional pose pointers at the end
+    assert C.sizeof(_lib.LearnerParams) == 8 * 4 + 3 * 8 + 2 * 8          # ABI 7: goal pose table, end poses out
     from oracle import oracle as orc
     assert orc.lib().orc_sizeof_object() == 184 and orc.lib().orc_sizeof_params() == C.sizeof(_lib.ChompParams)
 

@@ -142,7 +142,7 @@ def test_tiled_entry_point_rejects_bad_arguments(dev):
     def call(goal_parts=4, lg=10, cb=16, spread=1, goals=eng.cv_goals, traj=eng.traj, G=8):
         return l.omgx_goalset_cost_layer_tiled(p(eng.robot), eng.P, p(eng.scenes.objects), p(eng.scenes.scene_begin), p(eng.scenes.pool),
                                                p(eng.traj), 270, p(goals), 1, G, 30, 0.1, 0, p(cost), p(cost), p(traj), 30, 0,
-                                               p(eng.pot), p(eng.pgrad), p(eng.col), None, None, goal_parts, lg, cb, spread, None)
+                                               p(eng.pot), p(eng.pgrad), p(eng.col), None, None, goal_parts, lg, cb, spread, None, None)
     assert call() == _lib.OMGX_OK
     assert call(goal_parts=0) == _lib.OMGX_ERR_INVALID and call(goal_parts=9) == _lib.OMGX_ERR_INVALID
     assert call(lg=3) == _lib.OMGX_ERR_INVALID and call(lg=0) == _lib.OMGX_ERR_INVALID and call(cb=-1) == _lib.OMGX_ERR_INVALID
@@ -156,3 +156,44 @@ def test_tiled_entry_point_rejects_bad_arguments(dev):
     with pytest.raises(_lib.OmgHipError):  # the partial sums need S * G * parts elements
         ops.goalset_cost_layer_tiled(eng.robot, eng.P, eng.scenes, eng.traj[:, 0], eng.cv_goals, 30, 0.1, None, None,
                                      (cost[:8], cost[:8]), goal_parts=4)
+
+
+@pytest.mark.parametrize("alg,split", [("MD", None), ("FTL", False), ("Proj", None)])
+def test_pose_hand_over_changes_no_bit(dev, alg, split, monkeypatch):
+    """Inside a latency-mode plan the launches hand link poses to each other (ABI 7: the layer workgroups' waypoint poses, the
+    tabulated start / goal poses) instead of running the same kinematics again: every result bit for bit what the kernels compute
+    on their own — learner and step in two workgroups or in one, early stop, ragged goal sets."""
+    from omg_planner_amd.engine import ChompEngine
+    counts = np.array([16, 9, 12])
+    out = []
+    for on in (True, False):
+        monkeypatch.setattr(ChompEngine, "LAT_HAND_OVER_POSES", on)
+        e, _ = _make(dev, 3, 16, True, counts, alg=alg)
+        e.split_update = split
+        e.plan(early_stop=True)
+        torch.cuda.synchronize()
+        assert not e._poses_on
+        out.append({k: getattr(e, k).cpu().numpy().copy() for k in ("traj", "info", "goal_idx", "learner_state", "grad", "cost_traj", "end", "goal_rows")})
+        out[-1]["active"] = e.active.cpu().numpy().copy()
+    for k in out[0]:
+        assert np.array_equal(out[0][k], out[1][k], equal_nan=True), k
+
+
+def test_pose_table_is_the_forward_kinematics_before_the_centre_offset(dev):
+    """omgx_pose_table against omgx_forward_kinematics (pinned to the reference's robot_pykdl by tests/golden/fk.npz): the 4 x 4
+    link pose is the tabulated pose times the link's centre offset (robot_pykdl.py:203-204)."""
+    from omg_planner_amd import ops
+    from omg_planner_amd.robot import PandaModel
+    m = PandaModel(points_per_link=15)
+    robot = ops.robot_blob(m, dev)
+    rng = np.random.RandomState(3)
+    q = torch.as_tensor(rng.uniform(-2.5, 2.5, (37, 9)) * np.array([1] * 7 + [0.016, 0.016]), dtype=torch.float64, device=dev).contiguous()
+    tab = ops.pose_table(robot, 15, q).cpu().numpy()           # [37,10,12]
+    full, _, _ = ops.forward_kinematics(robot, 15, q, want_joint_info=False)
+    full = full.cpu().numpy()                                    # [37,10,4,4]
+    co = m.center_offset.reshape(10, 4, 4)
+    P4 = np.zeros((37, 10, 4, 4))
+    P4[:, :, :3, :3] = tab[:, :, :9].reshape(37, 10, 3, 3)
+    P4[:, :, :3, 3] = tab[:, :, 9:]
+    P4[:, :, 3, 3] = 1.0
+    np.testing.assert_allclose(P4 @ co[None], full, rtol=0, atol=1e-12)

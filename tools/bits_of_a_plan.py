@@ -24,10 +24,13 @@ def main():
     ap.add_argument("--alg", default="MD")
     ap.add_argument("--latency", type=int, default=0)
     ap.add_argument("--standoff", type=int, default=0)
+    ap.add_argument("--no-poses", action="store_true", help="latency mode without the pose hand-over between the launches")
     args = ap.parse_args()
     if args.lib:
         _lib.LIB_PATH = Path(args.lib).resolve()
     from omg_planner_amd.engine import ChompEngine
+    if args.no_poses:
+        ChompEngine.LAT_HAND_OVER_POSES = False
     cfg, model, batch, start, goals = bench.build_workload(args.scenes, args.goals, 30, 32, 0, False)
     out = {"lib": Path(_lib.LIB_PATH).name}
     for split in (None, False):

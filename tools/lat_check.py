@@ -14,6 +14,8 @@ import bench  # noqa: E402
 from omg_planner_amd.engine import ChompEngine  # noqa: E402
 
 import os as _os
+if _os.environ.get("OMGX_LAT_NO_POSES"):
+    ChompEngine.LAT_HAND_OVER_POSES = False
 if _os.environ.get("OMGX_LAT_PARTS"):
     ChompEngine.LAT_GOAL_PARTS = int(_os.environ["OMGX_LAT_PARTS"])  # experiments
 
