@@ -48,7 +48,7 @@ __device__ __forceinline__ GqFar gq_load_far(ObjTablePtr ob) {
 
 // dynamic LDS behind the poses (bytes, all 16-byte aligned): row masks | exact-path records | collision points | staging
 struct GqLayout {
-    int mask_off, tbl_off, pts_off, stage_off, fkc_off, total;
+    int mask_off, tbl_off, pts_off, stage_off, fkc_off, objc_off, total;
     __host__ __device__ GqLayout(int PS, int MR, int P, int tbl_n, bool with_fkc = false) {
         mask_off = PS * 90 * 8;
         tbl_off = mask_off + ((10 * MR * 4 + 15) & ~15);
@@ -62,6 +62,8 @@ struct GqLayout {
         total = (total + 15) & ~15;
         fkc_off = total;  // latency mode: the kinematic chain's 246 constants (RobotViewT::uvw .. rf)
         if (with_fkc) total += 246 * 8;
+        objc_off = total;  // latency mode: per-object contributions of the layer's object-parallel evaluation, [8][64][5] floats
+        if (with_fkc) total += 8 * 64 * 5 * 4;
     }
 };
 
@@ -107,7 +109,7 @@ __device__ __forceinline__ void gq_tbl_store(uint32_t* e, const GqTblRec& r) {
 // CU pays a scalar-cache miss per joint otherwise: 6.5 us of chain for 9 configurations, measured).  LAT = false compiles to
 // exactly the batch kernel.
 template <int LB, bool STAMP = false, bool LAT = false>
-__global__ __launch_bounds__(256, GQ_WG_PER_CU) void k_goalset_queue(ChunkArgs a) {
+__global__ __launch_bounds__(256, LAT ? 2 : GQ_WG_PER_CU) void k_goalset_queue(ChunkArgs a) {  // LAT: a workgroup per CU or two, registers are free
     extern __shared__ __attribute__((aligned(16))) double lds_pose[];  // no static LDS: 31744 B is the most a workgroup may use at 5 per CU
     GS_WG_STAMP(0);
     const int xcd = blockIdx.x & 7;
@@ -192,7 +194,8 @@ __global__ __launch_bounds__(256, GQ_WG_PER_CU) void k_goalset_queue(ChunkArgs a
         const int lpg = 10 / a.layer_lg, c_begin = cbi * a.layer_cb;
         const int c_end = c_begin + a.layer_cb < a.wp_n ? c_begin + a.layer_cb : a.wp_n;
         waypoint_layer_block<LAT>(a, s, lgi * lpg, (lgi + 1) * lpg, c_begin, c_end, lds_pose, rowmask, o_begin, o_end, rv,
-                                  reinterpret_cast<double*>(lds_bytes + L.fkc_off), warming);
+                                  reinterpret_cast<double*>(lds_bytes + L.fkc_off), warming,
+                                  reinterpret_cast<float*>(lds_bytes + L.objc_off));
         GS_WG_STAMP(4);
         return;
     }

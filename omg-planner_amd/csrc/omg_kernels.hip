@@ -386,7 +386,7 @@ template <bool LAT>  // the chain's constants from LDS (fkc, filled here) instea
 __device__ __forceinline__ void waypoint_layer_block(const ChunkArgs& a, const int s, const int l_begin, const int l_end,
                                                      const int c_begin, const int c_end, double* lds_pose, uint32_t* rowmask,
                                                      const int o_begin, const int o_end, const RobotViewS& rv, double* fkc,
-                                                     const bool warming) {
+                                                     const bool warming, float* objc) {
     // links [l_begin, l_end) at the waypoint configurations [c_begin, c_end): every output element is computed on its own, so any
     // split of the (link, configuration) grid over workgroups writes the same bits
     const int n = a.wp_n, P = a.P, PS = a.PS, MR = a.MR;
@@ -444,6 +444,60 @@ __device__ __forceinline__ void waypoint_layer_block(const ChunkArgs& a, const i
         rowmask[l * MR + ci] = m;
     }
     __syncthreads();
+    if (LAT && nloc <= 4 && l_end - l_begin == 1) {
+        // Latency mode, one link x at most 4 waypoints per workgroup: the rows fit ONE wave, so the four waves take the scene's
+        // OBJECTS side by side (wave w: objects w, w + 4 of each group of 8) instead of one wave walking them one gather round
+        // trip (two, with a gradient) after the other — the finger links near the goal, in reach of everything, took 14 us where
+        // the other workgroups took 6.  An object's contribution starts from zero and is parked in LDS (objc [8][64][5]); wave 0
+        // adds the contributions in object order: the same sequence of float32 additions as the walk, bit for bit.
+        const int l = l_begin, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int p = lane & 15, ci = lane >> 4;
+        const bool valid = (p < P) && (ci < nloc);
+        const int cic = valid ? ci : 0, pc = valid ? p : 0;
+        const uint32_t msk = valid ? rowmask[l * MR + cic] : 0u;
+        Accum acc{0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        if (__any(msk != 0)) {  // the same in all four waves
+            float px, py, pz;
+            pose9_apply(lds_pose + ((int64_t)l * PS + cic) * 9, rv.pts(l, pc), px, py, pz);
+            for (int og = o_begin; og < o_end; og += 8) {
+                for (int o = og + wave; o < og + 8 && o < o_end; o += 4) {
+                    const int oo = o - o_begin;
+                    const uint32_t bit = 1u << (oo < 31 ? oo : 31);
+                    Accum c{0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+                    if (__any((msk & bit) != 0)) {
+                        ObjTablePtr ob = as_const(a.objects) + o;
+                        if (!(ob->disabled > 0)) {
+                            const ObjParams op = load_object(ob);
+                            const PairPrep pp = pair_prepare(op, px, py, pz);
+                            if ((msk & bit) && !pp.far) pair_exact<true>(op, a.pool + ob->grid_offset, pp.tx, pp.ty, pp.tz, c);
+                        }
+                    }
+                    float* dst = objc + ((o - og) * 64 + lane) * 5;
+                    dst[0] = c.pot; dst[1] = c.gx; dst[2] = c.gy; dst[3] = c.gz; dst[4] = c.col;
+                }
+                __syncthreads();
+                if (wave == 0) {
+                    for (int o = og; o < og + 8 && o < o_end; ++o) {
+                        const float* src = objc + ((o - og) * 64 + lane) * 5;
+                        acc.pot += src[0]; acc.gx += src[1]; acc.gy += src[2]; acc.gz += src[3]; acc.col += src[4];
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        if (wave == 0) {
+            if (a.wp_soften && l >= 8) {  // cost.py:350-353
+                acc.pot *= 0.1f; acc.gx *= 0.1f; acc.gy *= 0.1f; acc.gz *= 0.1f; acc.col = 0.0f;
+            }
+            if (valid) {
+                const int64_t kk = (((int64_t)s * n + c_begin + ci) * 10 + l) * P + p;
+                a.wp_pot[kk] = acc.pot;
+                a.wp_col[kk] = acc.col;
+                a.wp_grad[3 * kk] = acc.gx; a.wp_grad[3 * kk + 1] = acc.gy; a.wp_grad[3 * kk + 2] = acc.gz;
+            }
+        }
+        return;
+    }
     const int p = threadIdx.x & 15, r = threadIdx.x >> 4;
     for (int ci0 = 0; ci0 < nloc; ci0 += 16) {
         const int ci = ci0 + r;

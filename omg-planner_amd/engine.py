@@ -96,7 +96,7 @@ class ChompEngine:
     # workgroups, the trajectory layer in LAT_LAYER_LINK_GROUPS x ceil(n / LAT_LAYER_BLOCK) workgroups, all spread over the XCDs.
     LAT_GOAL_PARTS = 4
     LAT_LAYER_LINK_GROUPS = 10
-    LAT_LAYER_BLOCK = 16
+    LAT_LAYER_BLOCK = 4   # one link x 4 waypoints per layer workgroup: its four waves take the objects side by side
     LAT_HAND_OVER_POSES = True  # inside plan(): link poses handed between the launches (False: every kernel runs its own kinematics; same bits)
 
     def __init__(self, model: PandaModel, batch: SceneBatch, cfg: Config, start: np.ndarray, goal_set: np.ndarray,
