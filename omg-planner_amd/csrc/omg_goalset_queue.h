@@ -299,17 +299,23 @@ __global__ __launch_bounds__(256, LAT ? 2 : GQ_WG_PER_CU) void k_goalset_queue(C
         if constexpr (LAT) run_chain(RobotView(a.robot, P, fkc));  // constants from LDS
         else run_chain(rv);                                          // constants through the scalar cache (warm in a batch)
         if (cull_beside_chain && wave >= chain_waves) {
-            for (int l = wave - chain_waves; l < 10; l += 4 - chain_waves) {
+            // a culling wave takes two consecutive links per pass when their rows fit one wave (CH <= 32: lanes 0-31 link l, lanes
+            // 32-63 link l + 1) — one link per pass left half the lanes idle and doubled the stage's wave-instructions
+            const bool two = CH <= 32;
+            const int lstep = two ? 2 : 1;
+            for (int l = (wave - chain_waves) * lstep; l < 10; l += (4 - chain_waves) * lstep) {
+                const int need = two ? l + 1 : l;  // the later link of the pair
                 for (;;) {  // every lane reads the same words: broadcast
                     int done = 99;
                     for (int w = 0; w < chain_waves; ++w) {
                         const int d = __hip_atomic_load(progress + w, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
                         done = d < done ? d : done;
                     }
-                    if (done > l) break;
-                    __builtin_amdgcn_s_sleep(2);
+                    if (done > need) break;
+                    __builtin_amdgcn_s_sleep(4);
                 }
-                for (int ci = lane; ci < CH; ci += 64) cull_row(l, ci);
+                if (two) { if ((lane & 31) < CH) cull_row(l + (lane >> 5), lane & 31); }
+                else for (int ci = lane; ci < CH; ci += 64) cull_row(l, ci);
             }
         }
     }

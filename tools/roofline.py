@@ -41,7 +41,7 @@ ROOT = Path(__file__).resolve().parents[1]
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 SIMDS = 256 * 4
 CLOCK_GHZ = 2.4           # data-sheet maximum
-KERNEL = "k_goalset_queue<2, false>"
+KERNEL = "k_goalset_queue<2, false, false>"  # LB = 2, no work stamps, batch layout (the latency-mode instantiation is <2, false, true>)
 CALIBRATION_TAG = "r03d"  # profiles/<tag>_valu_peak.csv
 
 # SQ_INSTS_VALU_* class -> the calibration row that prices it (cheapest member of the class: lower bound of the issue time)
@@ -123,7 +123,7 @@ def derive_inputs(tag: str, profiles: Path = ROOT / "profiles") -> dict:
     out = {
         "from_profiles_tag": tag,
         "calibration_tag": CALIBRATION_TAG,
-        "kernel": "k_goalset_queue<2, false> (goal-set batch + trajectory layer: kinematics, culling, SDF lookups, arc-length cost)",
+        "kernel": "k_goalset_queue<2, false, false> (goal-set batch + trajectory layer: kinematics, culling, SDF lookups, arc-length cost)",
         "workload": json.loads(cfg_file.read_text()) if cfg_file.exists() else None,
         "valu_wave_insts_per_launch": valu,
         "valu_issue_cycles_per_launch": cycles,   # summed over the SIMDs; a lower bound (module docstring)
