@@ -383,7 +383,29 @@ __global__ __launch_bounds__(256, LAT ? 2 : GQ_WG_PER_CU) void k_goalset_queue(C
         return;
 #endif
         const bool valid = lane < count;
+#ifdef OMGX_GS_SORT  // experiment (verdict item 3, DESIGN appendix A): the ring's entries grouped by object before the gathers
+        int src = lane;
+        uint32_t q_meta_s = q_meta;
+        {
+            const uint32_t key = q_meta & 0xffffu;
+            int pos = lane, base = 0;
+            unsigned long long todo = __ballot(valid);
+            while (todo) {  // one round per object present in the ring (wave-uniform)
+                const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)key, __builtin_ctzll(todo));
+                const unsigned long long m = __ballot(valid && key == k);
+                const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                if (valid && key == k) pos = base + rank;
+                base += __popcll(m);
+                todo &= ~m;
+            }
+            src = __builtin_amdgcn_ds_permute(pos * 4, lane);             // lane pos receives the entry of this lane
+            q_meta_s = (uint32_t)__builtin_amdgcn_ds_permute(pos * 4, (int)q_meta);
+        }
+#define q_meta q_meta_s
+        const float4 qe = *reinterpret_cast<const float4*>(stage + 4 * src);
+#else
         const float4 qe = *reinterpret_cast<const float4*>(stage + 4 * lane);
+#endif
         const float q_tx = qe.x, q_ty = qe.y, q_tz = qe.z, q_w = qe.w;
         const uint32_t oo = valid ? (q_meta & 0xffffu) : 0u;
         const uint32_t* rec = tbl + oo * 16;
@@ -416,6 +438,9 @@ __global__ __launch_bounds__(256, LAT ? 2 : GQ_WG_PER_CU) void k_goalset_queue(C
         f_fx = fx; f_fy = fy; f_fz = fz;
         f_w = valid ? q_w : 0.0f;
         f_meta = (q_meta & 0x1ffffu) | (in_c ? 1u << 30 : 0u) | ((valid && !(q_meta & 0x10000u)) ? 1u << 31 : 0u);
+#ifdef OMGX_GS_SORT
+#undef q_meta
+#endif
         inflight = true;
     };
 
