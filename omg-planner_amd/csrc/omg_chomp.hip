@@ -1005,21 +1005,6 @@ static int chomp_make_args(const double* robot, const omgx_chomp_params* h_param
     return OMGX_OK;
 }
 
-// Once per (kernel, device): the attribute belongs to the device's copy of the function, and entry points may be called from
-// several host threads (one bit per device in an atomic word; a lost race only repeats the idempotent call).
-template <int TAG, class K>  // TAG: one flag word per kernel instantiation (instantiations of one template share the type K)
-static int allow_big_lds(K kernel, const char* what) {
-    static std::atomic<unsigned long long> done{0ull};
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return omgx_set_error("hipGetDevice", e);
-    if (dev >= 0 && dev < 64 && ((done.load(std::memory_order_acquire) >> dev) & 1ull)) return OMGX_OK;
-    e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return omgx_set_error(what, e);
-    if (dev >= 0 && dev < 64) done.fetch_or(1ull << dev, std::memory_order_release);
-    return OMGX_OK;
-}
-
 extern "C" int omgx_chomp_optimize(const double* robot, const omgx_chomp_params* h_params, double* traj,
                                    const double* start, const double* end, const double* goal,
                                    const double* goal_point, const float* potentials, const float* grads,

@@ -789,7 +789,13 @@ static int launch_goalset(ChunkArgs& ca, int timing_kind, hipStream_t st, const 
     if (grid == 0) return OMGX_OK;
     ca.tbl_n = gq_choose_tbl_n(ca.PS, ca.MR, ca.P, ca.spread);
     const size_t lds = (size_t)GqLayout(ca.PS, ca.MR, ca.P, ca.tbl_n, ca.spread).total;
-    if (lds > 64 * 1024) return OMGX_ERR_UNSUPPORTED;  // cannot happen within OMGX_MAX_WAYPOINTS / OMGX_MAX_POINTS (61 KB at 64 x 16)
+    if (lds > 64 * 1024) {
+        // the batch layout stays below (61 KB at 64 waypoints x 16 points); the latency-mode kernel adds the chain constants and the
+        // layer's per-object contributions (73 KB at 64 waypoints) and opts in
+        if (!ca.spread) return OMGX_ERR_UNSUPPORTED;
+        const int rc = allow_big_lds<10>(k_goalset_queue<2, false, true>, "hipFuncSetAttribute(k_goalset_queue)");
+        if (rc != OMGX_OK) return rc;
+    }
     hipEvent_t ev0, ev1;
     timing_events(timing_kind, &ev0, &ev1);
     if (ca.spread) {

@@ -197,3 +197,35 @@ def test_pose_table_is_the_forward_kinematics_before_the_centre_offset(dev):
     P4[:, :, :3, 3] = tab[:, :, 9:]
     P4[:, :, 3, 3] = 1.0
     np.testing.assert_allclose(P4 @ co[None], full, rtol=0, atol=1e-12)
+
+
+def test_latency_mode_at_the_waypoint_limit(dev):
+    """64 waypoints (OMGX_MAX_WAYPOINTS): the latency-mode kernel then needs 73 KB of LDS (poses of 65 configurations + the chain
+    constants + the layer's per-object contributions) and opts in beyond the 64 KB default; a window of 64 configurations has
+    16 x 5 tiles.  Against the batch layout on the same scenes."""
+    import bench
+    from omg_planner_amd.engine import ChompEngine
+    cfg, model, batch, start, goals = bench.build_workload(2, 24, 64, 32, 1, False)
+    mk = lambda lat: ChompEngine(model, batch, copy.deepcopy(cfg), start, goals, device=dev, ol_alg="MD", latency_mode=lat)
+    a, b = mk(False), mk(True)
+    for e in (a, b):
+        e.select_initial_goal()
+    assert torch.equal(a.goal_idx, b.goal_idx)
+    for t in (0, 1, 30, 49, 50):
+        for e in (a, b):
+            e.t = t
+            e.iterate(t)
+        torch.cuda.synchronize()
+        for k in ("pot", "pgrad", "col"):
+            assert torch.equal(getattr(a, k), getattr(b, k)), (t, k)
+        if t < 50:
+            np.testing.assert_allclose(b.goal_cost_total().cpu().numpy(), a.goal_cost_total().cpu().numpy(), rtol=2e-6, atol=1e-7)
+        assert torch.equal(a.goal_idx, b.goal_idx), t
+        np.testing.assert_allclose(b.traj.cpu().numpy(), a.traj.cpu().numpy(), rtol=0, atol=1e-9)
+    c = mk(True)
+    c.plan(early_stop=True)  # with the pose hand-over
+    d = mk(False)
+    d.plan(early_stop=True)
+    torch.cuda.synchronize()
+    assert torch.equal(c.goal_idx, d.goal_idx)
+    np.testing.assert_allclose(c.traj.cpu().numpy(), d.traj.cpu().numpy(), rtol=0, atol=1e-9)
