@@ -229,3 +229,26 @@ def test_latency_mode_at_the_waypoint_limit(dev):
     torch.cuda.synchronize()
     assert torch.equal(c.goal_idx, d.goal_idx)
     np.testing.assert_allclose(c.traj.cpu().numpy(), d.traj.cpu().numpy(), rtol=0, atol=1e-9)
+
+
+def test_latency_mode_with_a_dozen_objects(dev):
+    """BASELINE config 5's shape (50 waypoints, 12 obstacle volumes + table): the layer's object-parallel evaluation walks the
+    objects in groups of 8 (two rounds here), the scalar-cache warm-up covers the first 8 records only."""
+    import bench
+    from omg_planner_amd.engine import ChompEngine
+    cfg, model, batch, start, goals = bench.build_workload(2, 16, 50, 32, 2, False, num_objects=12)
+    mk = lambda lat: ChompEngine(model, batch, copy.deepcopy(cfg), start, goals, device=dev, ol_alg="MD", latency_mode=lat)
+    a, b = mk(False), mk(True)
+    for e in (a, b):
+        e.select_initial_goal()
+    for t in (0, 3, 40, 50, 51):
+        for e in (a, b):
+            e.t = t
+            e.iterate(t)
+        torch.cuda.synchronize()
+        for k in ("pot", "pgrad", "col"):
+            assert torch.equal(getattr(a, k), getattr(b, k)), (t, k)
+        if t < 50:
+            np.testing.assert_allclose(b.goal_cost_total().cpu().numpy(), a.goal_cost_total().cpu().numpy(), rtol=2e-6, atol=1e-7)
+        assert torch.equal(a.goal_idx, b.goal_idx), t
+        np.testing.assert_allclose(b.traj.cpu().numpy(), a.traj.cpu().numpy(), rtol=0, atol=1e-9)
