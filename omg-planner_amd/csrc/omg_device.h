@@ -493,6 +493,44 @@ __device__ __forceinline__ void fk_chain_row(const RV& rv, int r, const double* 
       h0 * Rf[3] + h1 * (Rf[7] - deg_round_trip(q8)) + h2 * Rf[11] + ht);
 }
 
+// The same chain with the joints' matrices B_i = c_i U_i + s_i V_i + W_i computed beforehand by one lane per (configuration, joint)
+// (fk_joint_matrix: the expression of fk_chain_row, so the same bits) and read from Bt [7][9]: the chain's lanes then do 12 instead
+// of 30 multiply-adds and read 12 instead of 30 constants per joint.  Latency mode only: the table costs 504 B of LDS per configuration.
+template <class RV>
+__device__ __forceinline__ void fk_joint_matrix(const RV& rv, int i, double s, double c, double* __restrict__ B) {
+#pragma clang fp contract(fast)
+    const auto uvw = rv.uvw(i);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) B[k] = c * uvw[k] + s * uvw[9 + k] + uvw[18 + k];
+}
+
+template <class RV, class F>
+__device__ __forceinline__ void fk_chain_row_B(const RV& rv, int r, const double* __restrict__ Bt /* [7][9] */, double q7, double q8, F&& f) {
+#pragma clang fp contract(fast)
+    double a0 = r == 0 ? 1.0 : 0.0, a1 = r == 1 ? 1.0 : 0.0, a2 = r == 2 ? 1.0 : 0.0, at = 0.0;
+#pragma unroll 1
+    for (int i = 0; i < 7; ++i) {
+        const double* B = Bt + 9 * i;
+        const auto tp = rv.tp(i);
+        const double n0 = a0 * B[0] + a1 * B[3] + a2 * B[6];
+        const double n1 = a0 * B[1] + a1 * B[4] + a2 * B[7];
+        const double n2 = a0 * B[2] + a1 * B[5] + a2 * B[8];
+        at = a0 * tp[0] + a1 * tp[1] + a2 * tp[2] + at;
+        a0 = n0; a1 = n1; a2 = n2;
+        f(i, a0, a1, a2, at);
+    }
+    const auto H = rv.hand();
+    const double h0 = a0 * H[0] + a1 * H[4] + a2 * H[8], h1 = a0 * H[1] + a1 * H[5] + a2 * H[9], h2 = a0 * H[2] + a1 * H[6] + a2 * H[10];
+    const double ht = a0 * H[3] + a1 * H[7] + a2 * H[11] + at;
+    f(7, h0, h1, h2, ht);
+    const auto Lf = rv.lf();
+    f(8, h0 * Lf[0] + h1 * Lf[4] + h2 * Lf[8], h0 * Lf[1] + h1 * Lf[5] + h2 * Lf[9], h0 * Lf[2] + h1 * Lf[6] + h2 * Lf[10],
+      h0 * Lf[3] + h1 * (Lf[7] + deg_round_trip(q7)) + h2 * Lf[11] + ht);
+    const auto Rf = rv.rf();
+    f(9, h0 * Rf[0] + h1 * Rf[4] + h2 * Rf[8], h0 * Rf[1] + h1 * Rf[5] + h2 * Rf[9], h0 * Rf[2] + h1 * Rf[6] + h2 * Rf[10],
+      h0 * Rf[3] + h1 * (Rf[7] - deg_round_trip(q8)) + h2 * Rf[11] + ht);
+}
+
 __device__ __forceinline__ void pose_apply(const Pose& A, const double* __restrict__ p, double& x, double& y, double& z) {
 #pragma clang fp contract(fast)
     x = A.R[0] * p[0] + A.R[1] * p[1] + A.R[2] * p[2] + A.t[0];

@@ -48,7 +48,7 @@ __device__ __forceinline__ GqFar gq_load_far(ObjTablePtr ob) {
 
 // dynamic LDS behind the poses (bytes, all 16-byte aligned): row masks | exact-path records | collision points | staging
 struct GqLayout {
-    int mask_off, tbl_off, pts_off, stage_off, fkc_off, objc_off, total;
+    int mask_off, tbl_off, pts_off, stage_off, fkc_off, objc_off, btab_off, total;
     __host__ __device__ GqLayout(int PS, int MR, int P, int tbl_n, bool with_fkc = false) {
         mask_off = PS * 90 * 8;
         tbl_off = mask_off + ((10 * MR * 4 + 15) & ~15);
@@ -64,6 +64,8 @@ struct GqLayout {
         if (with_fkc) total += 246 * 8;
         objc_off = total;  // latency mode: per-object contributions of the layer's object-parallel evaluation, [8][64][5] floats
         if (with_fkc) total += 8 * 64 * 5 * 4;
+        btab_off = total;  // latency mode: the joints' matrices of every configuration, [PS][7][9] doubles (fk_chain_row_B)
+        if (with_fkc) total += PS * 7 * 9 * 8;
     }
 };
 
@@ -195,7 +197,7 @@ __global__ __launch_bounds__(256, LAT ? 2 : GQ_WG_PER_CU) void k_goalset_queue(C
         const int c_end = c_begin + a.layer_cb < a.wp_n ? c_begin + a.layer_cb : a.wp_n;
         waypoint_layer_block<LAT>(a, s, lgi * lpg, (lgi + 1) * lpg, c_begin, c_end, lds_pose, rowmask, o_begin, o_end, rv,
                                   reinterpret_cast<double*>(lds_bytes + L.fkc_off), warming,
-                                  reinterpret_cast<float*>(lds_bytes + L.objc_off));
+                                  reinterpret_cast<float*>(lds_bytes + L.objc_off), reinterpret_cast<double*>(lds_bytes + L.btab_off));
         GS_WG_STAMP(4);
         return;
     }
@@ -296,8 +298,22 @@ __global__ __launch_bounds__(256, LAT ? 2 : GQ_WG_PER_CU) void k_goalset_queue(C
                 });
             }
         };
-        if constexpr (LAT) run_chain(RobotView(a.robot, P, fkc));  // constants from LDS
-        else run_chain(rv);                                          // constants through the scalar cache (warm in a batch)
+        if constexpr (LAT) {
+            // the joints' matrices first, one lane per (configuration, joint) like the (sin, cos) stage (whose table they read), then
+            // the chain over the tabulated matrices: its 7 dependent steps shrink from 30 + 30 to 12 + 12 reads / multiply-adds each
+            const RobotView rvl(a.robot, P, fkc);
+            double* const btab = reinterpret_cast<double*>(lds_bytes + L.btab_off);
+            for (int t = tid; t < ncfg * 7; t += 256) fk_joint_matrix(rvl, t - (t / 7) * 7, sc[2 * t], sc[2 * t + 1], btab + 9 * t);
+            __syncthreads();
+            for (int t = tid; t < ncfg * 3; t += 256) {
+                const int cfg = t / 3, rr = t - cfg * 3;
+                fk_chain_row_B(rvl, rr, btab + 63 * cfg, joint(cfg, 7), joint(cfg, 8), [&](int l, double r0, double r1, double r2, double tr) {
+                    double* dst = lds_pose + ((size_t)l * pstride + cfg) * 9;  // rows 0 and 1 of R, then t
+                    if (rr < 2) { dst[3 * rr] = r0; dst[3 * rr + 1] = r1; dst[3 * rr + 2] = r2; }
+                    dst[6 + rr] = tr;
+                });
+            }
+        } else run_chain(rv);                                          // constants through the scalar cache (warm in a batch)
         if (cull_beside_chain && wave >= chain_waves) {
             // a culling wave takes two consecutive links per pass when their rows fit one wave (CH <= 32: lanes 0-31 link l, lanes
             // 32-63 link l + 1) — one link per pass left half the lanes idle and doubled the stage's wave-instructions

@@ -386,7 +386,7 @@ template <bool LAT>  // the chain's constants from LDS (fkc, filled here) instea
 __device__ __forceinline__ void waypoint_layer_block(const ChunkArgs& a, const int s, const int l_begin, const int l_end,
                                                      const int c_begin, const int c_end, double* lds_pose, uint32_t* rowmask,
                                                      const int o_begin, const int o_end, const RobotViewS& rv, double* fkc,
-                                                     const bool warming, float* objc) {
+                                                     const bool warming, float* objc, double* btab) {
     // links [l_begin, l_end) at the waypoint configurations [c_begin, c_end): every output element is computed on its own, so any
     // split of the (link, configuration) grid over workgroups writes the same bits
     const int n = a.wp_n, P = a.P, PS = a.PS, MR = a.MR;
@@ -419,8 +419,23 @@ __device__ __forceinline__ void waypoint_layer_block(const ChunkArgs& a, const i
             });
         }
     };
-    if constexpr (LAT) run_chain(RobotView(a.robot, P, fkc));
-    else run_chain(rv);
+    if constexpr (LAT) {  // the joints' matrices tabulated first (fk_chain_row_B; see k_goalset_queue)
+        const RobotView rvl(a.robot, P, fkc);
+        for (int t = threadIdx.x; t < nloc * 7; t += 256) fk_joint_matrix(rvl, t - (t / 7) * 7, sc[2 * t], sc[2 * t + 1], btab + 9 * t);
+        __syncthreads();
+        for (int t = threadIdx.x; t < nloc * 3; t += 256) {
+            const int cfg = t / 3, r = t - cfg * 3;
+            fk_chain_row_B(rvl, r, btab + 63 * cfg, tr[cfg * 9 + 7], tr[cfg * 9 + 8], [&](int l, double r0, double r1, double r2, double tt) {
+                double* dst = lds_pose + ((size_t)l * PS + cfg) * 9;
+                if (r < 2) { dst[3 * r] = r0; dst[3 * r + 1] = r1; dst[3 * r + 2] = r2; }
+                dst[6 + r] = tt;
+                if (gpose) {
+                    double* g = gpose + ((size_t)cfg * 10 + l) * 12;
+                    g[3 * r] = r0; g[3 * r + 1] = r1; g[3 * r + 2] = r2; g[9 + r] = tt;
+                }
+            });
+        }
+    } else run_chain(rv);
     __syncthreads();
     for (int row = l_begin * nloc + threadIdx.x; row < l_end * nloc; row += 256) {  // row-level culling of this workgroup's links
         const int l = row / nloc, ci = row - l * nloc;
