@@ -22,6 +22,14 @@
 // SDFdistanceForward (layers/sdf_matching_loss_kernel.cu:111-171).  A goal's cost is the float32 sum of pot * weight over
 // its pairs in queue order (fixed by the program: deterministic, no atomics) instead of per-point sums over objects times
 // the weight: equal up to float32 rounding of a sum of ~300 terms (checked against the oracle at 1e-5).
+//
+// Two instantiations share this source.  k_goalset_queue<2, STAMP, false> is the batch kernel (one workgroup per goal, five per
+// trajectory layer, a scene per XCD, five workgroups per CU).  k_goalset_queue<2, false, true> is the LATENCY-MODE kernel for one or
+// a few scenes (omgx_goalset_cost_layer_tiled): workgroups in plain order over all XCDs, a goal's tiles dealt over up to 8 of them,
+// layer workgroups of one link x 4 waypoints whose waves take the objects side by side, the chain's constants and the joints'
+// matrices in LDS, the object records pulled into the scalar cache at the top, every wave culling the rows of its own tiles; a
+// goal's cost is then the sum of its parts' sums.  Everything LAT-specific is behind `if constexpr (LAT)` / constant-folded
+// conditions: the batch kernel's code does not change with it (tests/test_kernel_budget.py watches its registers).
 #pragma once
 
 #define GQ_TBL_MAX 32    // at most this many objects of a scene have their exact-path constants staged in LDS (others: evaluated on the

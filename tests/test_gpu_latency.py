@@ -76,6 +76,13 @@ def test_goal_cost_parts_add_up_to_the_batch_cost_and_the_oracle(dev, parts, n_r
         gc, _ = orc.goalset_cost(eng.model.blob(), eng.P, batch.subset(s, s + 1), ts[s:s + 1].cpu().numpy(), eng.cv_goals[s:s + 1].cpu().numpy(),
                                  n_rem, eng.cfg.time_interval)
         np.testing.assert_allclose(tot[s].cpu().numpy(), np.asarray(gc).reshape(-1), rtol=1e-5, atol=1e-6)
+    if parts == 1:  # one part per goal and a scene per XCD: the tiled entry point launches the batch kernel — the same bits
+        bc = torch.full((2, 24), float("nan"), dtype=torch.float32, device=dev)
+        bl = torch.full_like(bc, float("nan"))
+        ops.goalset_cost_layer_tiled(eng.robot, eng.P, eng.scenes, ts, eng.cv_goals, n_rem, eng.cfg.time_interval, None, None, (bc, bl),
+                                     goal_parts=1, spread=False)
+        torch.cuda.synchronize()
+        assert torch.equal(bc, cost) and torch.equal(bl, col)
 
 
 def test_latency_engine_follows_the_batch_engine_and_the_oracle(dev):
