@@ -207,6 +207,7 @@ class ChompEngine:
         self._parts, self._forked, self._in_plan = None, False, False
         self._hot = None
         self._capturing = False
+        self._scratch_state = self._cubic_h = self._cubic_tmp = self._cubic_diff = None
         self._gather_goal()
 
     @property
@@ -702,21 +703,33 @@ class ChompEngine:
                 if self.goal_count is not None:  # a scene with fewer goals than cfg.goal_idx falls back to goal 0, never to padding
                     self.goal_idx.copy_(torch.where(self.goal_idx < self.goal_count, self.goal_idx, torch.zeros_like(self.goal_idx)))
             self._gather_goal()
-            tt = (torch.arange(1, self.n + 1, device=self.device, dtype=torch.float64) / (self.n + 1.0))[None, :, None]
-            h = 3.0 * tt * tt - 2.0 * tt * tt * tt
-            self.traj.copy_(self.start[:, None, :] + h * (self.end - self.start)[:, None, :])
+            self._cubic_to_end()
             return
         saved_t, saved_alg = self.t, self.ol_alg
-        scratch = self.learner_state.clone()
+        if self._scratch_state is None:
+            self._scratch_state = torch.empty_like(self.learner_state)
+        scratch = self._scratch_state  # (no allocation per plan)
+        scratch.copy_(self.learner_state)
         keep = self.learner_state
         try:
             self.t, self.ol_alg, self.learner_state = -1, "FTC", scratch  # update_goal increments t to 0: start_idx 0, argmin(costs)
             self.update_goal()
         finally:
             self.t, self.ol_alg, self.learner_state = saved_t, saved_alg, keep
-        tt = (torch.arange(1, self.n + 1, device=self.device, dtype=torch.float64) / (self.n + 1.0))[None, :, None]
-        h = 3.0 * tt * tt - 2.0 * tt * tt * tt  # clamped cubic through (0,start),(1,end)
-        self.traj.copy_(self.start[:, None, :] + h * (self.end - self.start)[:, None, :])
+        self._cubic_to_end()
+
+    def _cubic_to_end(self):
+        """Trajectory.interpolate_waypoints towards the chosen end: the clamped cubic through (0, start), (1, end).  The weights are
+        computed once per engine; the same three elementwise operations (difference, product, sum) as before, into preallocated
+        tensors."""
+        if self._cubic_h is None:
+            tt = (torch.arange(1, self.n + 1, device=self.device, dtype=torch.float64) / (self.n + 1.0))[None, :, None]
+            self._cubic_h = 3.0 * tt * tt - 2.0 * tt * tt * tt
+            self._cubic_tmp = torch.empty_like(self.traj)
+            self._cubic_diff = torch.empty_like(self.start)
+        torch.sub(self.end, self.start, out=self._cubic_diff)
+        torch.mul(self._cubic_h, self._cubic_diff[:, None, :], out=self._cubic_tmp)
+        torch.add(self.start[:, None, :], self._cubic_tmp, out=self.traj)
 
     def plan(self, early_stop: bool = True, initial_goal: bool = True) -> torch.Tensor:
         """Planner.plan (planner.py:600-653): up to optim_steps + extra_smooth_steps iterations, then one
