@@ -317,8 +317,13 @@ def main():
         # comparison, the batch layout a 100-scene run uses (one workgroup per goal on the scene's XCD)
         ms_single, ms_single_batch_layout = float("inf"), float("inf")
         for lat in (True, False):
+            # one engine per mode, planned again and again from the same fresh state (restore(): device-to-device copies, untimed) —
+            # the first plan pays the engine's one-off host work (argument lists checked and prepared once) and is not timed
+            e1 = ChompEngine(model, one, copy.deepcopy(cfg), start[:1], goals[:1], device=dev, ol_alg=args.ol_alg, latency_mode=lat)
+            fresh1 = e1.snapshot()
+            e1.plan(early_stop=False)
             for _ in range(3):
-                e1 = ChompEngine(model, one, copy.deepcopy(cfg), start[:1], goals[:1], device=dev, ol_alg=args.ol_alg, latency_mode=lat)
+                e1.restore(fresh1)
                 torch.cuda.synchronize()
                 tp = time.perf_counter()
                 e1.plan(early_stop=False)
@@ -328,7 +333,6 @@ def main():
                     ms_single = min(ms_single, dt_)
                 else:
                     ms_single_batch_layout = min(ms_single_batch_layout, dt_)
-
         # the same plans as ONE HIP graph each (ChompEngine.capture_plan: no host in the loop), replayed from the fresh state
         def graph_ms(e):
             fresh = e.snapshot()
@@ -380,7 +384,7 @@ def main():
             out["ms_per_plan_per_scene"] = ms_per_plan / S
             out["ms_per_plan_early_stop"] = ms_plan_early  # with the reference's break on `terminate` (informational)
             out["scenes_terminated_early"] = terminated
-            out["ms_per_plan_single_scene"] = ms_single  # one scene alone in latency mode (latency-bound), best of 3
+            out["ms_per_plan_single_scene"] = ms_single  # one scene alone in latency mode (latency-bound): a warm engine, best of 3 plans
             out["ms_per_plan_single_scene_batch_layout"] = ms_single_batch_layout  # the same plan with the launches of the batched path
             out["ms_per_plan_early_stop_graph"] = ms_graph_early  # the early-stop plan replayed as one HIP graph (capture_plan)
             out["ms_per_plan_single_scene_graph"] = ms_graph_single
