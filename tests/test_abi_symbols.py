@@ -59,3 +59,30 @@ def test_robot_blob_layout():
     q = 0.37
     Rz = np.array([[np.cos(q), -np.sin(q), 0], [np.sin(q), np.cos(q), 0], [0, 0, 1]])
     np.testing.assert_allclose(np.cos(q) * U + np.sin(q) * V + W, m.pose_0[0][:3, :3] @ Rz, atol=1e-15)
+
+
+def test_goalset_parts_and_tiled_argument_checks_without_gpu():
+    """Host logic of the latency-mode launch (no GPU needed: argument errors are reported before anything is launched).
+    omgx_goalset_parts: the largest power of two <= goal_parts that leaves every workgroup at least 4 of the window's
+    ceil(n / 4) x 5 tiles."""
+    from omg_planner_amd import _lib
+    lib = _lib.lib()
+    want = {(30, 4): 4, (30, 8): 8, (30, 1): 1, (30, 2): 2, (12, 8): 2, (13, 4): 4, (8, 4): 2, (5, 8): 2, (4, 8): 1, (1, 8): 1, (64, 8): 8}
+    for (n, p), np_ in want.items():
+        assert lib.omgx_goalset_parts(n, p) == np_, (n, p)
+        tiles = ((n + 3) // 4) * 5
+        assert np_ == 1 or tiles // np_ >= 4
+    assert lib.omgx_goalset_parts(0, 4) == 0 and lib.omgx_goalset_parts(30, 0) == 0 and lib.omgx_goalset_parts(30, 9) == 0
+    d = C.c_void_p(4096)  # never dereferenced: every call below fails its checks first
+
+    def call(goal_parts=4, lg=10, cb=4, spread=1, goals=d, traj=d, G=64, n_rem=30):
+        return lib.omgx_goalset_cost_layer_tiled(d, 15, d, d, d, d, 270, goals, 1, G, n_rem, 0.1, 0, d, d, traj, 30, 0, d, d, d, None, None,
+                                                 goal_parts, lg, cb, spread, None, None)
+    assert call(goal_parts=0) == _lib.OMGX_ERR_INVALID and call(goal_parts=9) == _lib.OMGX_ERR_INVALID
+    assert call(lg=3) == _lib.OMGX_ERR_INVALID and call(lg=11) == _lib.OMGX_ERR_INVALID and call(cb=-1) == _lib.OMGX_ERR_INVALID
+    assert call(goal_parts=2, spread=0) == _lib.OMGX_ERR_UNSUPPORTED
+    assert call(goals=None, traj=None, G=0) == _lib.OMGX_ERR_INVALID
+    assert call(goals=None) == _lib.OMGX_ERR_INVALID
+    assert call(n_rem=0) == _lib.OMGX_ERR_UNSUPPORTED and call(n_rem=65) == _lib.OMGX_ERR_UNSUPPORTED
+    assert lib.omgx_pose_table(None, 15, d, 4, d, None) == _lib.OMGX_ERR_INVALID and lib.omgx_pose_table(d, 15, d, 0, d, None) == _lib.OMGX_OK
+    assert lib.omgx_pose_table(d, 99, d, 4, d, None) == _lib.OMGX_ERR_UNSUPPORTED and lib.omgx_pose_table(d, 15, d, -1, d, None) == _lib.OMGX_ERR_INVALID
