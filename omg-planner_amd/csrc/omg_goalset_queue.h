@@ -256,7 +256,10 @@ __global__ __launch_bounds__(256, LAT ? 2 : GQ_WG_PER_CU) void k_goalset_queue(C
         return r < ntp ? part + NP * (ntp - 1 - r) : -1;
     };
     const int chain_waves = (3 * (CH + 1) + 63) >> 6;
-    const bool cull_beside_chain = !LAT && chain_waves < 4;  // LAT: every wave culls the rows of its own tiles after the chain (below)
+    // Only while two waves are free and a link pair's rows fit one pass (CH <= 32): with 50 waypoints a single free wave walked the 10
+    // links one pass each and the prologue got LONGER (0.49 instead of 0.41 ms per step at 50 waypoints: measured) — there all four
+    // waves cull after the chain as before.  LAT: every wave culls the rows of its own tiles after the chain (below).
+    const bool cull_beside_chain = !LAT && chain_waves <= 2 && CH <= 32;
     {   // Kinematics of the start + CH interpolated configurations in two stages (omg_device.h: fk_joint_sincos on
         // (configuration, joint) lanes, fk_chain_row on (configuration, pose row) lanes); the (sin, cos) table borrows the
         // region behind the poses, which is first written after the barriers below.
