@@ -191,6 +191,9 @@ __global__ __launch_bounds__(256, LAT ? 2 : GQ_WG_PER_CU) void k_goalset_queue(C
     const int goal = NP > 1 ? chunk / NP : chunk;
     const int part = NP > 1 ? chunk - goal * NP : 0;
     const int CH = a.CH;
+    // The blocks of 4 waypoints are aligned with the END of the window: when CH is no multiple of 4 the short block is the first one
+    // (far from the goal, mostly culled as a whole) instead of the last one — the heaviest tiles, which then ran at half their lanes.
+    const int blk_shift = (4 - (CH & 3)) & 3;
     const int p = threadIdx.x & 15, lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // provably wave-uniform: tile indices and their address arithmetic stay on the scalar unit
     const int tid = (int)threadIdx.x;
@@ -358,8 +361,8 @@ __global__ __launch_bounds__(256, LAT ? 2 : GQ_WG_PER_CU) void k_goalset_queue(C
         // to its main loop without a barrier (its own LDS writes, in order).
         for (int q0 = 0; lat_tile(q0) >= 0; q0 += 8) {  // the pass's first tile slot: wave-uniform
             const int t = lat_tile(q0 + (lane >> 3));
-            const int rb = t / (10 / LB), l = (t - rb * (10 / LB)) * LB + ((lane >> 2) & 1), ci = rb * 4 + (lane & 3);
-            if (t >= 0 && ci < CH) cull_row(l, ci);
+            const int rb = t / (10 / LB), l = (t - rb * (10 / LB)) * LB + ((lane >> 2) & 1), ci = rb * 4 + (lane & 3) - blk_shift;
+            if (t >= 0 && ci >= 0 && ci < CH) cull_row(l, ci);
         }
     } else if (!cull_beside_chain) {
         for (int row = tid; row < 10 * CH; row += 256) cull_row(row / CH, row - (row / CH) * CH);
@@ -513,8 +516,8 @@ __global__ __launch_bounds__(256, LAT ? 2 : GQ_WG_PER_CU) void k_goalset_queue(C
         const int rb = t / (10 / LB), l0 = (t - rb * (10 / LB)) * LB;
         GS_COUNT(1);
         {
-            const int ci = rb * 4 + (lane >> 4);
-            const bool valid = (p < P) && (ci < CH);
+            const int ci = rb * 4 + (lane >> 4) - blk_shift;
+            const bool valid = (p < P) && (ci >= 0) && (ci < CH);
             const int cic = valid ? ci : 0;
             const int cic9 = cic * 9;  // lane part of a pose address (doubles); base = configuration 1, lds_pose = configuration 0
             float px[LB], py[LB], pz[LB], w[LB];
