@@ -902,7 +902,15 @@ __global__ __launch_bounds__(CH_TPB) void k_update_optimize_split(omg_learner::L
         // The kinematics of the chosen end configuration (a 3-lane serial chain, ~7 K cycles) run HERE, where nothing waits for
         // them, instead of in the step's workgroup right after its wait.  The 10 x 12 doubles travel in the scene's `grad`
         // rows, which the step's workgroup overwrites with the gradient only after it has taken the pose (chomp_scene).
-        if (end_pose_fits(a.prm.n_waypoints) && !(a.active && a.active[blockIdx.x] == 0)) {
+        const bool scene_on = !(a.active && a.active[blockIdx.x] == 0);
+        if (!end_pose_fits(a.prm.n_waypoints) && scene_on && la.prm.goal_pose_table && la.prm.end_poses_out) {
+            // Fewer than 14 waypoints: the pose does not travel through the grad rows (the step's workgroup runs the end
+            // configuration's kinematics itself), but `end_poses_out` must still follow the goal — the launches of the plan that
+            // come after the goal-selecting iterations (k_chomp_optimize) take their end pose from it.
+            const double* src = la.prm.goal_pose_table + ((size_t)blockIdx.x * la.prm.num_goals + la.goal_idx[blockIdx.x]) * 120;
+            if (threadIdx.x < 120) la.prm.end_poses_out[(size_t)blockIdx.x * 120 + threadIdx.x] = src[threadIdx.x];
+        }
+        if (end_pose_fits(a.prm.n_waypoints) && scene_on) {
             double* out = a.grad + (size_t)blockIdx.x * a.prm.n_waypoints * 9;
             if (la.prm.goal_pose_table) {
                 // the goals' poses were tabulated for the plan (omgx_pose_table): the chosen goal's 120 doubles are copied

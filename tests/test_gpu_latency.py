@@ -22,14 +22,14 @@ def dev():
     return torch.device("cuda:0")
 
 
-def _workload(S, G, grid=32, seed=0):
+def _workload(S, G, grid=32, seed=0, n=30):
     import bench
-    return bench.build_workload(S, G, 30, grid, seed, False)
+    return bench.build_workload(S, G, n, grid, seed, False)
 
 
-def _make(dev, S, G, latency, counts=None, grid=32, alg="MD"):
+def _make(dev, S, G, latency, counts=None, grid=32, alg="MD", n=30):
     from omg_planner_amd.engine import ChompEngine
-    cfg, model, batch, start, goals = _workload(S, G, grid)
+    cfg, model, batch, start, goals = _workload(S, G, grid, n=n)
     return ChompEngine(model, batch, copy.deepcopy(cfg), start, goals, device=dev, ol_alg=alg, goal_counts=counts, latency_mode=latency), batch
 
 
@@ -182,6 +182,34 @@ def test_pose_hand_over_changes_no_bit(dev, alg, split, monkeypatch):
         assert not e._poses_on
         out.append({k: getattr(e, k).cpu().numpy().copy() for k in ("traj", "info", "goal_idx", "learner_state", "grad", "cost_traj", "end", "goal_rows")})
         out[-1]["active"] = e.active.cpu().numpy().copy()
+    for k in out[0]:
+        assert np.array_equal(out[0][k], out[1][k], equal_nan=True), k
+
+
+@pytest.mark.parametrize("n", [6, 13])
+@pytest.mark.parametrize("alg", ["MD", "FTL"])
+def test_pose_hand_over_below_14_waypoints_keeps_the_end_pose_current(dev, n, alg, monkeypatch):
+    """Below 14 waypoints the end pose does not fit the grad rows the split update launch hands it over in (end_pose_fits): the
+    learner's workgroup must still keep `end_pose` on the chosen goal, because the plan's later launches — the smoothing
+    iterations and the final evaluation (k_chomp_optimize) — read it.  A plan whose goal changes on the way, learner and step in
+    two workgroups: every bit as without the hand-over."""
+    from omg_planner_amd.engine import ChompEngine
+    out = []
+    for on in (True, False):
+        monkeypatch.setattr(ChompEngine, "LAT_HAND_OVER_POSES", on)
+        e, _ = _make(dev, 2, 16, True, alg=alg, n=n)
+        e.split_update = True
+        first = None
+        e.select_initial_goal()
+        first = e.goal_idx.cpu().numpy().copy()
+        e.plan(early_stop=False, initial_goal=False)
+        torch.cuda.synchronize()
+        out.append({k: getattr(e, k).cpu().numpy().copy() for k in ("traj", "info", "goal_idx", "grad", "cost_traj", "end", "goal_rows")})
+        out[-1]["first"] = first
+        if on:  # the end pose the plan left behind is the chosen goal's
+            from omg_planner_amd import ops
+            want = ops.pose_table(e.robot, e.P, e.end).cpu().numpy()
+            assert np.array_equal(e.end_pose.cpu().numpy(), want)
     for k in out[0]:
         assert np.array_equal(out[0][k], out[1][k], equal_nan=True), k
 
