@@ -287,7 +287,8 @@ int omgx_goalset_cost_layer(const double* robot, int32_t n_points,
  *                       depend on their number).  goal_cost / collides are then [S][G][NP] PARTIAL sums and the goal's cost is
  *                       their float32 sum in part order — omgx_goal_update(_optimize) adds them when
  *                       omgx_learner_params.cost_parts = NP.  A goal's cost differs from (3b)'s by the rounding of a float32 sum
- *                       taken in another order (~1e-7 relative); everything else is bit-identical.  More than one part needs `spread`.
+ *                       taken in another order (~1e-7 relative); everything else is bit-identical.  (Without `spread`, more than one
+ *                       part runs the batch kernel with split goals: (3d).)
  *   layer_link_groups   1, 2, 5 or 10 and
  *   layer_config_block  b >= 0: the trajectory layer of a scene is computed by layer_link_groups x ceil(n_waypoints / b)
  *                       workgroups (10 / layer_link_groups links x b waypoints each; 0 = all waypoints).  Layer outputs do not
@@ -313,6 +314,35 @@ int omgx_goalset_cost_layer_tiled(const double* robot, int32_t n_points,
                                   const int32_t* active, const int32_t* goal_count,
                                   int32_t goal_parts, int32_t layer_link_groups, int32_t layer_config_block,
                                   int32_t spread, double* layer_poses, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * (3d) omgx_goalset_cost_layer_parts — (3b) with a goal's tiles dealt over several workgroups of the BATCH kernel (ABI 8)
+ * Mid-size batches — a launch of about half a round to a few rounds of the chip's 1280 workgroup slots: one GPU's share of
+ * BASELINE config 4 on 8 GPUs (13 scenes x 128 goals), 25 x 64 — are bound by the latency of one goal workgroup, not by the
+ * chip's capacity.  goal_parts (1, 2, 4, 8) deals a goal's tiles over NP = omgx_goalset_parts(n_remaining, goal_parts)
+ * workgroups exactly as (3c) does — part p takes the tiles t with t % NP == p and runs the kinematics of all configurations —
+ * but keeps the batch layout: a scene's workgroups on one XCD, five workgroups per CU, the dispatch schedule.
+ *   goal_cost / collides  [S][G][NP] PARTIAL sums (omgx_learner_params.cost_parts = NP adds them in part order): a goal's
+ *                         cost differs from (3b)'s by the rounding of a float32 sum taken in another order; the layer outputs
+ *                         are (3b)'s bit for bit.
+ *   schedule / work       over the S * G * NP items (scene, goal, part): schedule[k] = (scene * G + goal) * NP + part;
+ *                         omgx_goalset_schedule_parts builds it (goal_count still counts GOALS).
+ *   layer_poses           optional, as in (3c).
+ * goal_parts = 1 is (3b).
+ * ------------------------------------------------------------------------------------------- */
+int omgx_goalset_cost_layer_parts(const double* robot, int32_t n_points,
+                                  const omgx_object* objects, const int32_t* scene_begin, const float* sdf_pool,
+                                  const double* traj_start, int64_t traj_start_stride, const double* goals,
+                                  int32_t num_scenes, int32_t num_goals, int32_t n_remaining,
+                                  double time_interval, int32_t soften_fingers,
+                                  float* goal_cost, float* collides,
+                                  const double* traj, int32_t n_waypoints, int32_t layer_soften_fingers,
+                                  float* layer_potentials, float* layer_grads, float* layer_collides,
+                                  const int32_t* active, const int32_t* goal_count,
+                                  const int32_t* schedule, int32_t schedule_len, uint32_t* work,
+                                  int32_t goal_parts, double* layer_poses, void* stream);
+int omgx_goalset_schedule_parts(const uint32_t* work, const int32_t* active, const int32_t* goal_count, int32_t num_scenes,
+                                int32_t num_goals, int32_t parts, int32_t slack, int32_t* schedule, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * (4) omgx_chomp_optimize

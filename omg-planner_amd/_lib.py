@@ -15,11 +15,11 @@ LIB_PATH = _CSRC / "libomg_hip.so"
 OMGX_OK, OMGX_ERR_INVALID, OMGX_ERR_LAUNCH, OMGX_ERR_UNSUPPORTED = 0, -1, -2, -3
 NUM_DOF, INFO_STRIDE = 9, 16
 SCHEDULE_MAX_SCENES = 1792  # OMGX_SCHEDULE_MAX_SCENES
-ABI_VERSION = 7  # omgx_abi_version() of the library these argtypes describe
+ABI_VERSION = 8  # omgx_abi_version() of the library these argtypes describe
 
 # every symbol include/omg_hip.h declares
 EXPORTS = ["omgx_sdf_loss_forward", "omgx_fk_sdf_workspace_bytes", "omgx_fk_sdf", "omgx_forward_kinematics", "omgx_pose_table",
-           "omgx_goalset_workspace_bytes", "omgx_goalset_cost", "omgx_goalset_cost_layer", "omgx_goalset_parts", "omgx_goalset_cost_layer_tiled", "omgx_goalset_schedule_len", "omgx_goalset_schedule", "omgx_chomp_aux_doubles", "omgx_chomp_optimize",
+           "omgx_goalset_workspace_bytes", "omgx_goalset_cost", "omgx_goalset_cost_layer", "omgx_goalset_parts", "omgx_goalset_cost_layer_tiled", "omgx_goalset_cost_layer_parts", "omgx_goalset_schedule_len", "omgx_goalset_schedule", "omgx_goalset_schedule_parts", "omgx_chomp_aux_doubles", "omgx_chomp_optimize",
            "omgx_learner_state_doubles", "omgx_goal_update", "omgx_goal_update_optimize", "omgx_point_cloud_sdf", "omgx_last_error", "omgx_abi_version", "omgx_device_arch",
            "omgx_timing_enable", "omgx_timing_collect"]
 
@@ -82,6 +82,10 @@ def lib() -> C.CDLL:
         l.omgx_goalset_parts.argtypes = [i32, i32]
         l.omgx_goalset_parts.restype = i32
         l.omgx_goalset_cost_layer_tiled.argtypes = [vp, i32, vp, vp, vp, vp, i64, vp, i32, i32, i32, f64, i32, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]
+        l.omgx_goalset_cost_layer_parts.argtypes = [vp, i32, vp, vp, vp, vp, i64, vp, i32, i32, i32, f64, i32, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp]
+        l.omgx_goalset_cost_layer_parts.restype = C.c_int
+        l.omgx_goalset_schedule_parts.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp]
+        l.omgx_goalset_schedule_parts.restype = C.c_int
         l.omgx_pose_table.argtypes = [vp, i32, vp, i64, vp, vp]
         l.omgx_pose_table.restype = C.c_int
         l.omgx_goalset_cost_layer_tiled.restype = C.c_int

@@ -118,7 +118,10 @@ __device__ __forceinline__ void gq_tbl_store(uint32_t* e, const GqTblRec& r) {
 // XCDs, a goal's tiles dealt over a.NP workgroups, the kinematic chain's constants staged in LDS (a workgroup alone on a cold
 // CU pays a scalar-cache miss per joint otherwise: 6.5 us of chain for 9 configurations, measured).  LAT = false compiles to
 // exactly the batch kernel.
-template <int LB, bool STAMP = false, bool LAT = false>
+// SPLIT: the batch kernel with a goal's tiles dealt over a.NP workgroups (omgx_goalset_cost_layer_parts; mid-size batches whose launch
+// is a round or two of the chip's workgroup slots: half as long a workgroup, the kinematics run in every part).  Everything else —
+// scene per XCD, dispatch schedule over (scene, goal, part) items, five workgroups per CU — is the batch kernel's.
+template <int LB, bool STAMP = false, bool LAT = false, bool SPLIT = false>
 __global__ __launch_bounds__(256, LAT ? 2 : GQ_WG_PER_CU) void k_goalset_queue(ChunkArgs a) {  // LAT: a workgroup per CU or two, registers are free
     extern __shared__ __attribute__((aligned(16))) double lds_pose[];  // no static LDS: 31744 B is the most a workgroup may use at 5 per CU
     GS_WG_STAMP(0);
@@ -128,7 +131,8 @@ __global__ __launch_bounds__(256, LAT ? 2 : GQ_WG_PER_CU) void k_goalset_queue(C
     // (at the end of the grid, as fillers of the launch's tail, they cost 3 %: measured)
     const int LPARTS = a.layer_parts;
     const bool spread = LAT;
-    const int NP = LAT ? a.NP : 1;
+    static_assert(!(LAT && SPLIT), "latency mode has its parts already");
+    const int NP = (LAT || SPLIT) ? a.NP : 1;
     bool is_layer;
     int s, chunk, layer_part;
     bool scheduled = false;
@@ -511,8 +515,9 @@ __global__ __launch_bounds__(256, LAT ? 2 : GQ_WG_PER_CU) void k_goalset_queue(C
     const int ntiles = ((CH + 3) >> 2) * (10 / LB);
     const int pc3 = 3 * (p < P ? p : 0);  // lane part of a collision-point address (doubles)
     GS_COUNT(0);
+    constexpr bool PARTS = LAT || SPLIT;  // this workgroup holds one part of a goal's tiles: the wave's q-th tile is lat_tile(q)
 #pragma unroll 1
-    for (int q = 0, t = LAT ? lat_tile(0) : wave; LAT ? t >= 0 : t < ntiles; t = LAT ? lat_tile(++q) : t + 4) {  // every lane stays active: invalid items are flagged, not skipped
+    for (int q = 0, t = PARTS ? lat_tile(0) : wave; PARTS ? t >= 0 : t < ntiles; t = PARTS ? lat_tile(++q) : t + 4) {  // every lane stays active: invalid items are flagged, not skipped
         const int rb = t / (10 / LB), l0 = (t - rb * (10 / LB)) * LB;
         GS_COUNT(1);
         {

@@ -659,7 +659,7 @@ static void timing_events(int kind, hipEvent_t* ev0, hipEvent_t* ev1) {
     *ev0 = g_ev[i][0]; *ev1 = g_ev[i][1];
     ++g_timing_n;
 }
-extern "C" int omgx_abi_version(void) { return 7; }  // 2: `active` masks; 3: ragged goal sets (goal_count, eta); 4: goal schedule + work; 5: 184-byte object records (influence region = rounded box); 6: omgx_goalset_cost_layer_tiled, omgx_learner_params.cost_parts; 7: pose tables (omgx_pose_table, pointer fields at the end of both parameter blocks, layer_poses)
+extern "C" int omgx_abi_version(void) { return 8; }  // 8: omgx_goalset_cost_layer_parts, omgx_goalset_schedule_parts (a goal's tiles over several workgroups of the batch kernel); 2: `active` masks; 3: ragged goal sets (goal_count, eta); 4: goal schedule + work; 5: 184-byte object records (influence region = rounded box); 6: omgx_goalset_cost_layer_tiled, omgx_learner_params.cost_parts; 7: pose tables (omgx_pose_table, pointer fields at the end of both parameter blocks, layer_poses)
 extern "C" int omgx_device_arch(char* h_buf, int32_t h_len) {
     if (!h_buf || h_len <= 0) return OMGX_ERR_INVALID;
     int dev = 0;
@@ -784,11 +784,11 @@ static int launch_goalset(ChunkArgs& ca, int timing_kind, hipStream_t st, const 
     const bool layer = ca.wp_traj != nullptr;
     if (tl.goal_parts < 1 || tl.goal_parts > 8 || tl.layer_lg < 1 || tl.layer_lg > 10 || 10 % tl.layer_lg != 0 || tl.layer_cb < 0) return OMGX_ERR_INVALID;
     ca.spread = tl.spread != 0;
-    if (tl.goal_parts > 1 && !ca.spread) return OMGX_ERR_UNSUPPORTED;  // parts of a goal exist in the latency-mode kernel only
     ca.NG = ca.NCH;
     ca.NP = ca.NG > 0 ? gs_parts(ca.CH, tl.goal_parts) : 1;
     ca.NCH = ca.NG * ca.NP;
-    if (ca.spread && (ca.schedule || ca.work)) return OMGX_ERR_UNSUPPORTED;  // a dispatch schedule orders whole goals, a scene per XCD
+    const bool split = !ca.spread && ca.NP > 1;  // the batch kernel with a goal's tiles dealt over NP workgroups (omgx_goalset_cost_layer_parts)
+    if (ca.spread && (ca.schedule || ca.work)) return OMGX_ERR_UNSUPPORTED;  // a dispatch schedule belongs to the batch layout: a scene per XCD
     ca.wp_pose_out = layer ? tl.wp_pose_out : nullptr;
     ca.layer_lg = tl.layer_lg;
     ca.layer_cb = layer ? ((tl.layer_cb > 0 && tl.layer_cb < ca.wp_n) ? tl.layer_cb : ca.wp_n) : 1;
@@ -816,6 +816,12 @@ static int launch_goalset(ChunkArgs& ca, int timing_kind, hipStream_t st, const 
     if (ca.spread) {
         if (ev0) hipExtLaunchKernelGGL((k_goalset_queue<2, false, true>), dim3((unsigned)grid), dim3(256), (uint32_t)lds, st, ev0, ev1, 0, ca);
         else hipLaunchKernelGGL((k_goalset_queue<2, false, true>), dim3((unsigned)grid), dim3(256), lds, st, ca);
+    } else if (split && ca.work) {
+        if (ev0) hipExtLaunchKernelGGL((k_goalset_queue<2, true, false, true>), dim3((unsigned)grid), dim3(256), (uint32_t)lds, st, ev0, ev1, 0, ca);
+        else hipLaunchKernelGGL((k_goalset_queue<2, true, false, true>), dim3((unsigned)grid), dim3(256), lds, st, ca);
+    } else if (split) {
+        if (ev0) hipExtLaunchKernelGGL((k_goalset_queue<2, false, false, true>), dim3((unsigned)grid), dim3(256), (uint32_t)lds, st, ev0, ev1, 0, ca);
+        else hipLaunchKernelGGL((k_goalset_queue<2, false, false, true>), dim3((unsigned)grid), dim3(256), lds, st, ca);
     } else if (ca.work) {
         if (ev0) hipExtLaunchKernelGGL((k_goalset_queue<2, true>), dim3((unsigned)grid), dim3(256), (uint32_t)lds, st, ev0, ev1, 0, ca);
         else hipLaunchKernelGGL((k_goalset_queue<2, true>), dim3((unsigned)grid), dim3(256), lds, st, ca);
@@ -1041,6 +1047,7 @@ struct SchedArgs {
     const int32_t* goal_count;
     int S, G, slack, slots, staged;
     int32_t* sched;
+    int np;  // items per goal (omgx_goalset_schedule_parts): G counts items, item g of a scene belongs to its goal g / np
 };
 
 __global__ __launch_bounds__(SCH_TPB) void k_goalset_schedule(SchedArgs a) {
@@ -1059,7 +1066,7 @@ __global__ __launch_bounds__(SCH_TPB) void k_goalset_schedule(SchedArgs a) {
     // weight of item (s, g), 0 if it is left out: from LDS when staged (the loops below read every weight O(G) times)
     auto item_w = [&](int s, int g) -> uint32_t {
         if (a.staged) return wl[s * G + g];
-        if ((a.active && a.active[s] == 0) || (a.goal_count && g >= a.goal_count[s])) return 0u;
+        if ((a.active && a.active[s] == 0) || (a.goal_count && g / a.np >= a.goal_count[s])) return 0u;
         const uint32_t w = a.work ? a.work[(size_t)s * G + g] : 1u;
         return w ? w : 1u;
     };
@@ -1070,7 +1077,7 @@ __global__ __launch_bounds__(SCH_TPB) void k_goalset_schedule(SchedArgs a) {
         for (int i = tid; i < S * G; i += SCH_TPB) {
             const int s = i / G, g = i - s * G;
             uint32_t w = 0u;
-            if (!((a.active && a.active[s] == 0) || (a.goal_count && g >= a.goal_count[s]))) {
+            if (!((a.active && a.active[s] == 0) || (a.goal_count && g / a.np >= a.goal_count[s]))) {
                 w = a.work ? a.work[i] : 1u;
                 w = w ? w : 1u;
             }
@@ -1164,14 +1171,32 @@ extern "C" int32_t omgx_goalset_schedule_len(int32_t num_scenes, int32_t num_goa
     return (int32_t)(((slack * n + 7) / 8 + 2) * 8);
 }
 
+static int goalset_schedule_impl(const uint32_t* work, const int32_t* active, const int32_t* goal_count, int32_t num_scenes,
+                                 int32_t num_goals, int32_t parts, int32_t slack, int32_t* schedule, void* stream);
+
 extern "C" int omgx_goalset_schedule(const uint32_t* work, const int32_t* active, const int32_t* goal_count, int32_t num_scenes,
                                      int32_t num_goals, int32_t slack, int32_t* schedule, void* stream) {
-    if (num_scenes <= 0 || num_goals <= 0 || slack < 1 || !schedule) return OMGX_ERR_INVALID;
+    return goalset_schedule_impl(work, active, goal_count, num_scenes, num_goals, 1, slack, schedule, stream);
+}
+
+extern "C" int omgx_goalset_schedule_parts(const uint32_t* work, const int32_t* active, const int32_t* goal_count, int32_t num_scenes,
+                                           int32_t num_goals, int32_t parts, int32_t slack, int32_t* schedule, void* stream) {
+    if (parts != 1 && parts != 2 && parts != 4 && parts != 8) return OMGX_ERR_INVALID;
+    return goalset_schedule_impl(work, active, goal_count, num_scenes, num_goals, parts, slack, schedule, stream);
+}
+
+// items per scene = goals x parts; everything below counts items
+static int goalset_schedule_impl(const uint32_t* work, const int32_t* active, const int32_t* goal_count, int32_t num_scenes,
+                                 int32_t num_goals_, int32_t parts, int32_t slack, int32_t* schedule, void* stream) {
+    if (num_scenes <= 0 || num_goals_ <= 0 || slack < 1 || !schedule) return OMGX_ERR_INVALID;
+    const int64_t items64 = (int64_t)num_goals_ * parts;
+    if (items64 > 65536) return OMGX_ERR_UNSUPPORTED;
+    const int32_t num_goals = (int32_t)items64;
     // per-scene arrays in dynamic LDS: 36 bytes per scene; 1792 scenes = 63 KB, below the 64 KB a launch gets without opting in
     if ((int64_t)num_scenes * num_goals > 65536 || num_scenes > OMGX_SCHEDULE_MAX_SCENES) return OMGX_ERR_UNSUPPORTED;
     const int items = num_scenes * num_goals;
     const int staged = (items <= SCH_LDS_ITEMS && num_scenes <= 128) ? 1 : 0;  // keeps the launch below 64 KB of dynamic LDS
-    SchedArgs a{work, active, goal_count, num_scenes, num_goals, slack, omgx_goalset_schedule_len(num_scenes, num_goals, slack) / 8, staged, schedule};
+    SchedArgs a{work, active, goal_count, num_scenes, num_goals, slack, omgx_goalset_schedule_len(num_scenes, num_goals, slack) / 8, staged, schedule, parts};
     const size_t lds = (size_t)num_scenes * (3 * sizeof(unsigned long long) + 3 * sizeof(uint32_t)) + (staged ? (size_t)items * sizeof(uint32_t) : 0);
     hipLaunchKernelGGL(k_goalset_schedule, dim3(1), dim3(SCH_TPB), lds, (hipStream_t)stream, a);
     OMGX_CHECK_LAUNCH("k_goalset_schedule");
@@ -1191,6 +1216,25 @@ extern "C" int omgx_goalset_cost_layer(const double* robot, int32_t n_points, co
                              num_goals, n_remaining, time_interval, soften_fingers, goal_cost, nullptr, collides, workspace, traj,
                              n_waypoints, layer_soften_fingers, layer_potentials, layer_grads, layer_collides, active, goal_count, schedule,
                              schedule_len, work, stream);
+}
+
+extern "C" int omgx_goalset_cost_layer_parts(const double* robot, int32_t n_points, const omgx_object* objects,
+                                             const int32_t* scene_begin, const float* sdf_pool, const double* traj_start,
+                                             int64_t traj_start_stride, const double* goals, int32_t num_scenes, int32_t num_goals,
+                                             int32_t n_remaining, double time_interval, int32_t soften_fingers, float* goal_cost,
+                                             float* collides, const double* traj, int32_t n_waypoints,
+                                             int32_t layer_soften_fingers, float* layer_potentials, float* layer_grads,
+                                             float* layer_collides, const int32_t* active, const int32_t* goal_count,
+                                             const int32_t* schedule, int32_t schedule_len, uint32_t* work, int32_t goal_parts,
+                                             double* layer_poses, void* stream) {
+    if (!traj) return OMGX_ERR_INVALID;
+    GsTiling tl;
+    tl.goal_parts = goal_parts;
+    tl.wp_pose_out = layer_poses;
+    return goalset_cost_impl(robot, n_points, objects, scene_begin, sdf_pool, traj_start, traj_start_stride, goals, num_scenes,
+                             num_goals, n_remaining, time_interval, soften_fingers, goal_cost, nullptr, collides, nullptr, traj,
+                             n_waypoints, layer_soften_fingers, layer_potentials, layer_grads, layer_collides, active, goal_count, schedule,
+                             schedule_len, work, stream, tl);
 }
 
 extern "C" int32_t omgx_goalset_parts(int32_t n_remaining, int32_t goal_parts) {

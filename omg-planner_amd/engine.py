@@ -87,6 +87,52 @@ class ChompEngine:
         if items < cls.PIPELINE_MIN_ITEMS:
             return 1
         return min(num_scenes, 3 if items < cls.PIPELINE_THREE_BELOW else 2)
+
+    # ---------------------------------------------------------------------------------------------
+    # The size-aware layout: ONE documented rule, a pure function of the shape, so that every rank of a job picks the same one
+    # (a goal's cost is a float32 sum whose order depends on goal_parts / latency mode: shards computed under different layouts
+    # would not be bit-comparable).  Measured on MI355X (tools/ab_parts_graph.py, profiles/r04a_layout_sweep.json), ms per step
+    # of bench.py's step, best (goal_parts, pipeline parts) against the plain batch layout:
+    #   1 x 64   latency mode 0.050          plain 0.065      |   6 x 64   (2, 3) 0.067   plain 0.073
+    #   2 x 64   (4, 1) 0.059                plain 0.068      |  10 x 64   (2, 2) 0.070   plain 0.075
+    #   4 x 64   (4, 2) 0.060                plain 0.068      |   6 x 128  (2, 2) 0.071   plain 0.078
+    #   2 x 128  (4, 2) 0.060                plain 0.070      |  16 x 64   (2, 2) 0.078   plain 0.079
+    #   5 x 64   (4, 2) 0.066                plain 0.072      |  20 x 64 and beyond: plain (split goals cost 6-30 % there)
+    # A goal workgroup's life is a latency-bound prologue (kinematics of the window) + its tiles; splitting a goal shortens the
+    # launch only while the chip has idle workgroup slots — every part repeats the prologue — i.e. below about 0.7 rounds of the
+    # 1280 slots.  Beyond that the batch is bound by the chip's capacity and the plain layout wins.
+    @classmethod
+    def layout(cls, num_scenes: int, num_goals: int, n_waypoints: int = 30) -> dict:
+        """-> {"latency_mode", "goal_parts", "pipeline"} for a rank that plans num_scenes x num_goals goals over n_waypoints.
+        The work of a goal workgroup grows with the window, so the thresholds count (scene, goal) items scaled by n / 30."""
+        load = num_scenes * num_goals * max(n_waypoints, 1) / 30.0
+        if num_scenes == 1:
+            return {"latency_mode": True, "goal_parts": 1, "pipeline": 1}
+        if load <= 320:
+            gp, pipe = 4, 2
+        elif load <= 896:
+            gp, pipe = 2, 2
+        elif load < 2048:
+            gp, pipe = 1, 3
+        else:
+            gp, pipe = 1, 2
+        return {"latency_mode": False, "goal_parts": gp, "pipeline": max(1, min(pipe, num_scenes))}
+
+    @classmethod
+    def auto(cls, model, batch, cfg, start, goal_set, layout_scenes: "int | None" = None, **kw) -> "ChompEngine":
+        """An engine laid out by ChompEngine.layout for its shape.  `layout_scenes`: the scene count the RULE is evaluated for —
+        in a multi-rank job every rank passes the same number (the largest shard, ceil(total / world)), so that shards of 13 and
+        12 scenes run the same layout and stay bit-comparable with each other and with a single-process run given that number."""
+        S, G = goal_set.shape[0], goal_set.shape[1]
+        lay = cls.layout(S if layout_scenes is None else int(layout_scenes), G, cfg.timesteps)
+        if lay["latency_mode"] and S > 4:  # the latency-mode kernel runs two workgroups per CU: a rule evaluated for another size must not force it on a batch
+            lay = dict(lay, latency_mode=False, goal_parts=4)
+        eng = cls(model, batch, cfg, start, goal_set, latency_mode=lay["latency_mode"], goal_parts=lay["goal_parts"], **kw)
+        if not lay["latency_mode"] and eng.stream is None:
+            eng.pipeline = max(1, min(lay["pipeline"], S))
+        eng.layout_used = lay
+        return eng
+
     # per-scene tensors: a part of the pipeline works on the rows [lo, hi) of each
     _PART_TENSORS = ("start", "goal_set", "reach", "cv_goals", "goal_idx", "goal_count", "eta_s", "traj", "end", "goal_rows", "goal_point",
                      "pot", "pgrad", "col", "grad", "cost_traj", "info", "goal_cost", "goal_col", "learner_state", "cost_vec", "_active",
@@ -101,7 +147,8 @@ class ChompEngine:
 
     def __init__(self, model: PandaModel, batch: SceneBatch, cfg: Config, start: np.ndarray, goal_set: np.ndarray,
                  reach_grasps: np.ndarray | None = None, traj_init: np.ndarray | None = None, device="cuda:0",
-                 ol_alg: str = "FTL", stream: "torch.cuda.Stream | None" = None, goal_counts=None, latency_mode: bool = False):
+                 ol_alg: str = "FTL", stream: "torch.cuda.Stream | None" = None, goal_counts=None, latency_mode: bool = False,
+                 goal_parts: int = 1):
         """start [S,9]; goal_set [S,G,9]; reach_grasps [S,G,c,9] (needed when cfg.use_standoff).
         `stream`: run every launch of this engine on that HIP stream (several engines holding disjoint scene
         subsets on different streams overlap each other's latency-bound kernels).
@@ -111,9 +158,15 @@ class ChompEngine:
         into many small workgroups spread over the whole chip instead of one workgroup per goal on the scene's XCD (a third
         of the launch's latency).  A goal's cost is then the float32 sum of its parts' sums — another summation order
         than the batch layout's (~1e-7 relative), everything else is bit-identical; `goal_cost` / `goal_col` hold the partial
-        sums (goal_cost_total() adds them).  No pipeline, no dispatch schedule in this mode."""
+        sums (goal_cost_total() adds them).  No pipeline, no dispatch schedule in this mode.
+        `goal_parts` (1, 2, 4, 8; batch layout only): MID-SIZE batches — a goal's tiles dealt over up to that many workgroups of
+        the batch kernel (omgx_goalset_cost_layer_parts), scene per XCD, dispatch schedule and pipeline as usual; goal costs are
+        partial sums as in latency mode.  ChompEngine.layout() names the rule that picks all of this from the shape."""
         self.cfg = cfg
         self.latency = bool(latency_mode)
+        self.goal_parts = 1 if self.latency else int(goal_parts)
+        if self.goal_parts not in (1, 2, 4, 8):
+            raise ValueError("goal_parts must be 1, 2, 4 or 8")
         self.stream = stream
         self.model = model
         self.device = torch.device(device)
@@ -166,7 +219,7 @@ class ChompEngine:
         self.cost_traj = torch.empty((S, n), **f64)
         self.info = torch.zeros((S, _lib.INFO_STRIDE), **f64)
         # latency mode: [S][G][parts] partial sums, parts = ceil(window / LAT_GOAL_PARTS) shrinking with the window (flat buffer)
-        self._parts_max = ops.goalset_parts(n, self.LAT_GOAL_PARTS) if self.latency else 1
+        self._parts_max = ops.goalset_parts(n, self.LAT_GOAL_PARTS) if self.latency else (ops.goalset_parts(n, self.goal_parts) if self.goal_parts > 1 else 1)
         self._parts_last = 1
         # latency mode, inside plan(): link poses handed between the launches instead of being recomputed (omgx_pose_table, ABI 7)
         # — the waypoints' poses from the layer workgroups to the step, the start's and the goals' poses tabulated per plan
@@ -192,9 +245,10 @@ class ChompEngine:
         # later launches: scenes dealt to the 8 XCDs by weight (heaviest first, serpentine), each scene's goals longest first.
         # A scene keeps all its workgroups on one XCD (its SDF volumes stay in that XCD's L2: without this affinity the
         # launch takes 1.7x as long).  Results do not depend on the order.
-        self.work = torch.zeros(S * G, dtype=torch.int32, device=dev)
+        self.work = torch.zeros(S * G * (1 if self.latency else self._parts_max), dtype=torch.int32, device=dev)  # one counter per (scene, goal, part) workgroup
         self.auto_schedule = True
         self.schedule = None
+        self._sched_np = 1  # parts per goal the current schedule's items count
         self._gs_launches = 0
         self._measured = False
         self._sched_buf, self._sched_flip, self._sched_age = None, 0, None
@@ -293,7 +347,7 @@ class ChompEngine:
         p.base_obstacle_weight = float(cfg.base_obstacle_weight)
         p.smooth_weight = float(cfg.smoothness_base_weight * cfg.dist_eps)
         p.eta = self.eta
-        p.cost_parts = ops.goalset_parts(cfg.timesteps - p.start_idx, self.LAT_GOAL_PARTS) if self.latency else 0
+        p.cost_parts = ops.goalset_parts(cfg.timesteps - p.start_idx, self.LAT_GOAL_PARTS) if self.latency else (self._np(cfg.timesteps - p.start_idx) if self.goal_parts > 1 else 0)
         if self._poses_on:
             p.goal_pose_table, p.end_poses_out = self.goal_pose_tab.data_ptr(), self.end_pose.data_ptr()
         return p
@@ -310,11 +364,15 @@ class ChompEngine:
     def _tiling(self):
         return (self.LAT_GOAL_PARTS, self.LAT_LAYER_LINK_GROUPS, self.LAT_LAYER_BLOCK, 1)
 
+    def _np(self, n_remaining: int) -> int:
+        """Workgroups per goal of a batch-layout goal-set launch over a window of n_remaining configurations."""
+        return ops.goalset_parts(n_remaining, self.goal_parts) if self.goal_parts > 1 else 1
+
     def goal_cost_total(self) -> torch.Tensor:
         """[S,G] float32 goal costs of the last goal-set launch (latency mode: the parts' sums added in part order, as the
         learner adds them)."""
         self.join()
-        if not self.latency:
+        if not self.latency and self.goal_parts == 1:
             return self.goal_cost
         k = self._parts_last
         parts = self.goal_cost.reshape(-1)[: self.S * self.G * k].reshape(self.S, self.G, k)
@@ -344,8 +402,8 @@ class ChompEngine:
         sc.__dict__.update(self.scenes.__dict__)
         sc.num_scenes, sc.scene_begin = hi - lo, self.scenes.scene_begin[lo:hi + 1]  # object offsets stay absolute
         part.scenes = sc
-        part.work = torch.zeros(part.S * self.G, dtype=torch.int32, device=self.device)
-        part.schedule, part._gs_launches, part._measured = None, 0, False
+        part.work = torch.zeros(part.S * self.G * (1 if self.latency else self._parts_max), dtype=torch.int32, device=self.device)
+        part.schedule, part._gs_launches, part._measured, part._sched_np = None, 0, False, 1
         part._sched_buf, part._sched_flip, part._sched_age = None, 0, None
         part._uniform_cache = None
         if self.goal_count is not None:
@@ -445,23 +503,33 @@ class ChompEngine:
                 # With an active mask (early stop) the launch goes back to scene-major order, or — `reschedule_every` > 0 — the
                 # schedule is rebuilt from the same measured durations without the scenes that have terminated.
                 self._gs_launches += 1
+                NP = self._np(n_rem)
+                self._parts_last = NP
                 use_sched = self.auto_schedule and (not self._masked or (self._measured and bool(self.reschedule_every)))
-                measure = use_sched and not self._measured and self._gs_launches >= 2 and self.S * self.G >= 2048
+                measure = use_sched and not self._measured and self._gs_launches >= 2 and self.S * self.G * NP >= 2048 and NP == self._parts_max
                 if use_sched and self._masked:
-                    if self._sched_age is None or self._sched_age >= self.reschedule_every:
-                        self.schedule = self.build_schedule(active=self._mask())
+                    if self._sched_age is None or self._sched_age >= self.reschedule_every or self._sched_np != NP:
+                        self.schedule = self.build_schedule(active=self._mask(), parts=NP, uniform=(NP != self._parts_max or not self._measured))
                         self._sched_age = 0
                     self._sched_age += 1
-                if use_sched and self.schedule is None:
-                    self.schedule = self.build_schedule(uniform=True)
+                if use_sched and (self.schedule is None or self._sched_np != NP):
+                    # nothing measured yet, or the window has shrunk to another number of parts per goal (the last few iterations
+                    # of a plan): the items in scene-major order, equal counts per XCD
+                    self.schedule = self.build_schedule(uniform=True, parts=NP)
                 ops.goalset_cost_layer(self.robot, self.P, self.scenes, traj_start, self.cv_goals, n_rem, self.cfg.time_interval,
                                        self.traj, (self.pot, self.pgrad, self.col), soften_fingers=False,
                                        layer_soften_fingers=self.cfg.uncheck_finger_collision == -1,
                                        out=(self.goal_cost, self.goal_col), active=self._mask(), goal_count=self.goal_count,
-                                       schedule=self.schedule if use_sched else None, work=self.work if measure else None)
+                                       schedule=self.schedule if use_sched else None, work=self.work[: self.S * self.G * NP] if measure else None,
+                                       goal_parts=self.goal_parts)
                 if measure:
                     self._measured = True
-                    self.schedule = self.build_schedule()
+                    self.schedule = self.build_schedule(parts=NP)
+            elif self.goal_parts > 1:  # the batch alone, split goals: the same partial sums as the fused launch writes
+                self._parts_last = ops.goalset_cost_layer_tiled(
+                    self.robot, self.P, self.scenes, traj_start, self.cv_goals, n_rem, self.cfg.time_interval, None, None,
+                    (self.goal_cost, self.goal_col), soften_fingers=False, active=self._mask(), goal_count=self.goal_count,
+                    goal_parts=self.goal_parts, layer_link_groups=5, layer_config_block=0, spread=False)
             else:
                 ops.goalset_cost(self.robot, self.P, self.scenes, traj_start, self.cv_goals, n_rem, self.cfg.time_interval,
                                  soften_fingers=False, out=(self.goal_cost, self.goal_col), active=self._mask(),
@@ -475,12 +543,12 @@ class ChompEngine:
                         goal_count=self.goal_count, eta=self.eta_s)
         return None
 
-    def _uniform_schedule(self) -> torch.Tensor:
-        """The schedule before anything has been measured: the (scene, goal) items in scene-major order, cut into 8 pieces of
-        equal COUNT, one per XCD — built on the host (numpy) and uploaded once."""
-        S, G = self.S, self.G
+    def _uniform_schedule(self, parts: int = 1) -> torch.Tensor:
+        """The schedule before anything has been measured: the (scene, goal[, part]) items in scene-major order, cut into 8 pieces
+        of equal COUNT, one per XCD — built on the host (numpy) and uploaded once."""
+        S, G = self.S, self.G * parts
         if self.goal_count is not None:
-            items = np.concatenate([s * G + np.arange(int(c)) for s, c in enumerate(self._goal_counts_host)])
+            items = np.concatenate([s * G + np.arange(int(c) * parts) for s, c in enumerate(self._goal_counts_host)])
         else:
             items = np.arange(S * G)
         n = len(items)
@@ -493,7 +561,7 @@ class ChompEngine:
         sched[rank * 8 + x] = items
         return torch.as_tensor(sched, device=self.device)
 
-    def build_schedule(self, active: "torch.Tensor | None" = None, uniform: bool = False) -> torch.Tensor:
+    def build_schedule(self, active: "torch.Tensor | None" = None, uniform: bool = False, parts: int = 1) -> torch.Tensor:
         """Dispatch order for omgx_goalset_cost_layer (omgx_goalset_schedule: one small launch on the current stream, no host
         sync).
 
@@ -504,19 +572,23 @@ class ChompEngine:
         together whatever the number of scenes (12 or 13 scenes per GPU would otherwise leave 3 of 8 XCDs with half the
         load).  `uniform`: all items weigh the same.  `active` [S] int32: scenes with 0 are left out; ragged goal sets leave
         out their padding.  An XCD has room for `schedule_slack` (2) times its share of the items; the weights are clamped to a
-        band [L, schedule_slack * L] around their mean, so no piece of the list can need more."""
-        if self.S * self.G > 65536 or self.S > _lib.SCHEDULE_MAX_SCENES:  # beyond the scheduler kernel's single workgroup: even split by count
-            if self._uniform_cache is None:  # built once: the upload is a host-to-device copy, which a graph capture could not record
-                self._uniform_cache = self._uniform_schedule()
-            return self._uniform_cache
+        band [L, schedule_slack * L] around their mean, so no piece of the list can need more.
+        `parts`: the launch deals every goal over that many workgroups (goal_parts): the items are (scene, goal, part)."""
+        self._sched_np = parts
+        if self.S * self.G * parts > 65536 or self.S > _lib.SCHEDULE_MAX_SCENES:  # beyond the scheduler kernel's single workgroup: even split by count
+            if self._uniform_cache is None:
+                self._uniform_cache = {}
+            if parts not in self._uniform_cache:  # built once: the upload is a host-to-device copy, which a graph capture could not record
+                self._uniform_cache[parts] = self._uniform_schedule(parts)
+            return self._uniform_cache[parts]
         if self._sched_buf is None:
-            self._sched_buf = [None, None]
-        # two buffers in turn: a launch that still reads the previous schedule (another stream's view of it) is never overwritten
+            self._sched_buf = {}
+        # two buffers (per item count) in turn: a launch that still reads the previous schedule (another stream's view of it) is never overwritten
         self._sched_flip ^= 1
-        buf = self._sched_buf[self._sched_flip]
-        out = ops.goalset_schedule(None if uniform else self.work, self.S, self.G, active=active, goal_count=self.goal_count,
-                                   slack=self.schedule_slack, out=buf, device=self.device)
-        self._sched_buf[self._sched_flip] = out
+        key = (parts, self._sched_flip)
+        out = ops.goalset_schedule(None if uniform else self.work[: self.S * self.G * parts], self.S, self.G, active=active, goal_count=self.goal_count,
+                                   slack=self.schedule_slack, out=self._sched_buf.get(key), device=self.device, parts=parts)
+        self._sched_buf[key] = out
         return out
 
     def _layer(self):
@@ -611,8 +683,11 @@ class ChompEngine:
         use_sched = self.auto_schedule and not self._masked and not self.latency
         if not self.latency and self._masked and self.auto_schedule and self._measured and self.reschedule_every:
             return False
-        if use_sched and (self.schedule is None or (not self._measured and self._gs_launches >= 1 and self.S * self.G >= 2048)):
-            return False
+        if use_sched:
+            cfg = self.cfg
+            NP = self._np(cfg.timesteps - min(int(((self.t + 1) / cfg.optim_steps) * cfg.timesteps), cfg.timesteps - 1))  # the window of the launch to come
+            if self.schedule is None or self._sched_np != NP or (not self._measured and self._gs_launches >= 1 and self.S * self.G * self._parts_max >= 2048):
+                return False
         # the prepared calls belong to these very tensor objects (held here, so none of them can be freed and its identity reused)
         key = [getattr(self, k) for k in self._HOT_TENSORS] + [self.scenes.scene_begin]
         baked = (float(self.cfg.time_interval), self.cfg.uncheck_finger_collision == -1)  # the scalars the calls carry
@@ -624,7 +699,7 @@ class ChompEngine:
                                        (self.grad, self.cost_traj, self.info), self.cost_vec, self._active, self.goal_count, self.eta_s,
                                        self._scene_flags, layer_soften_fingers=self.cfg.uncheck_finger_collision == -1,
                                        tiling=self._tiling() if self.latency else None,
-                                       layer_poses=self.wp_pose if self.latency else None)
+                                       layer_poses=self.wp_pose if self.latency else None, goal_parts=self.goal_parts)
             hot = self._hot = (key, calls, baked)
         calls = hot[1]
         stream = (self.stream if self.stream is not None else torch.cuda.current_stream(self.device)).cuda_stream
@@ -632,7 +707,7 @@ class ChompEngine:
         prm = self._learner_params()
         self._gs_launches += 1
         self._parts_last = max(1, int(prm.cost_parts))
-        calls.use_layer_poses = self._poses_on
+        calls.use_layer_poses = self._poses_on and self.latency
         calls.goalset_layer(prm.start_idx, self._masked, self.schedule if use_sched else None, None, stream)
         self._schedule()
         split = 2 * self.S <= self._num_cus if self.split_update is None else bool(self.split_update)

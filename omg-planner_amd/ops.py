@@ -124,10 +124,14 @@ def goalset_cost(robot, P, scenes: DeviceScenes, traj_start, goals, n_remaining,
 
 
 def goalset_cost_layer(robot, P, scenes: DeviceScenes, traj_start, goals, n_remaining, dt, traj, layer_out, soften_fingers=False,
-                       layer_soften_fingers=False, out=None, active=None, goal_count=None, schedule=None, work=None):
+                       layer_soften_fingers=False, out=None, active=None, goal_count=None, schedule=None, work=None, goal_parts=1,
+                       layer_poses=None):
     """goalset_cost (cost only) + fk_sdf(traj) in one launch (omgx_goalset_cost_layer).  traj [S,n,9] f64;
     layer_out = (potentials [S,n,10,P], grads [S,n,10,P,3], collides [S,n,10,P]) float32, written in place.
-    active [S] int32 (optional): scenes with 0 are skipped, their outputs keep their previous contents."""
+    active [S] int32 (optional): scenes with 0 are skipped, their outputs keep their previous contents.
+    goal_parts > 1 (omgx_goalset_cost_layer_parts): a goal's tiles dealt over NP = goalset_parts(n_remaining, goal_parts) workgroups
+    of the batch kernel; `out` must then hold S * G * NP elements each and receives [S][G][NP] PARTIAL sums, schedule / work count
+    the S * G * NP (scene, goal, part) items.  Returns (cost, collides) as given / allocated."""
     if not (traj_start.is_cuda and traj_start.dtype == torch.float64 and traj_start.dim() == 2 and traj_start.shape[1] == 9
             and traj_start.stride(1) == 1 and (traj_start.shape[0] == 1 or traj_start.stride(0) >= 9)):
         raise _lib.OmgHipError("traj_start must be a float64 device tensor [S,9] with unit inner stride")
@@ -141,12 +145,34 @@ def goalset_cost_layer(robot, P, scenes: DeviceScenes, traj_start, goals, n_rema
     if traj.shape[0] != S or lp.numel() != S * n * 10 * P or lg.numel() != 3 * lp.numel() or lc.numel() != lp.numel():
         raise _lib.OmgHipError("layer outputs must be [S,n,10,P], [S,n,10,P,3], [S,n,10,P]")
     dev = goals.device
+    NP = goalset_parts(n_remaining, goal_parts) if int(goal_parts) != 1 else 1
+    if NP < 1:
+        raise _lib.OmgHipError("goal_parts must be 1, 2, 4 or 8")
     if out is None:
-        cost = torch.empty((S, G), dtype=torch.float32, device=dev)
-        col = torch.empty((S, G), dtype=torch.float32, device=dev)
+        cost = torch.empty((S, G) if NP == 1 else (S, G, NP), dtype=torch.float32, device=dev)
+        col = torch.empty((S, G) if NP == 1 else (S, G, NP), dtype=torch.float32, device=dev)
     else:
         cost, col = out
     l = _lib.lib()
+    if int(goal_parts) != 1 or layer_poses is not None:
+        for n_, t in (("goal_cost", cost), ("goal collides", col)):
+            _need(t, torch.float32, n_)
+            if t.numel() < S * G * NP:
+                raise _lib.OmgHipError(f"{n_} must hold S * G * parts = {S * G * NP} elements")
+        if layer_poses is not None:
+            _need(layer_poses, torch.float64, "layer_poses")
+            if layer_poses.numel() != S * n * 120:
+                raise _lib.OmgHipError("layer_poses must be [S,n,10,12]")
+        with torch.cuda.device(dev):
+            check(l.omgx_goalset_cost_layer_parts(_ptr(robot), P, _ptr(scenes.objects), _ptr(scenes.scene_begin), _ptr(scenes.pool),
+                                                  _ptr(traj_start), ts_stride, _ptr(goals), S, G, n_remaining, float(dt),
+                                                  int(bool(soften_fingers)), _ptr(cost), _ptr(col), _ptr(traj), n,
+                                                  int(bool(layer_soften_fingers)), _ptr(lp), _ptr(lg), _ptr(lc), _ptr(_active(active, S)),
+                                                  _ptr(_active(goal_count, S)), _ptr(_i32n(schedule, None, "schedule")),
+                                                  0 if schedule is None else schedule.numel(), _ptr(_i32n(work, S * G * NP, "work")),
+                                                  int(goal_parts), _ptr(layer_poses), _stream()),
+                  "omgx_goalset_cost_layer_parts")
+        return cost, col
     with torch.cuda.device(dev):
         ws = _workspace(l.omgx_goalset_workspace_bytes(S, G, n_remaining, P), dev)
         check(l.omgx_goalset_cost_layer(_ptr(robot), P, _ptr(scenes.objects), _ptr(scenes.scene_begin), _ptr(scenes.pool),
@@ -216,12 +242,16 @@ def goalset_cost_layer_tiled(robot, P, scenes: DeviceScenes, traj_start, goals, 
     return parts
 
 
-def goalset_schedule(work, num_scenes: int, num_goals: int, active=None, goal_count=None, slack: int = 2, out=None, device=None):
+def goalset_schedule(work, num_scenes: int, num_goals: int, active=None, goal_count=None, slack: int = 2, out=None, device=None,
+                     parts: int = 1):
     """Dispatch order for goalset_cost_layer (omgx_goalset_schedule): int32 device tensor [omgx_goalset_schedule_len].
     work: int32/uint32 device tensor [S*G] of durations (None: all items weigh the same).  Asynchronous, one small launch.
-    The result lives on the device of `out`, else of the first tensor given, else `device`."""
+    The result lives on the device of `out`, else of the first tensor given, else `device`.
+    parts > 1 (omgx_goalset_schedule_parts): the items are the S * G * parts (scene, goal, part) workgroups of a launch with
+    split goals; work [S*G*parts]; goal_count still counts goals."""
     l = _lib.lib()
-    n = int(l.omgx_goalset_schedule_len(num_scenes, num_goals, slack))
+    parts = int(parts)
+    n = int(l.omgx_goalset_schedule_len(num_scenes, num_goals * parts, slack))
     if out is None:
         for t in (work, active, goal_count):
             if t is not None:
@@ -231,10 +261,14 @@ def goalset_schedule(work, num_scenes: int, num_goals: int, active=None, goal_co
             raise _lib.OmgHipError("goalset_schedule needs a device: pass work, active, goal_count, out or device")
         out = torch.empty(n, dtype=torch.int32, device=device)
     _i32n(out, n, "schedule")
-    _i32n(work, num_scenes * num_goals, "work")
+    _i32n(work, num_scenes * num_goals * parts, "work")
     with torch.cuda.device(out.device):
-        check(l.omgx_goalset_schedule(_ptr(work), _ptr(_active(active, num_scenes)), _ptr(_active(goal_count, num_scenes)), num_scenes,
-                                      num_goals, slack, _ptr(out), _stream()), "omgx_goalset_schedule")
+        if parts != 1:
+            check(l.omgx_goalset_schedule_parts(_ptr(work), _ptr(_active(active, num_scenes)), _ptr(_active(goal_count, num_scenes)),
+                                                num_scenes, num_goals, parts, slack, _ptr(out), _stream()), "omgx_goalset_schedule_parts")
+        else:
+            check(l.omgx_goalset_schedule(_ptr(work), _ptr(_active(active, num_scenes)), _ptr(_active(goal_count, num_scenes)), num_scenes,
+                                          num_goals, slack, _ptr(out), _stream()), "omgx_goalset_schedule")
     return out
 
 
@@ -383,7 +417,7 @@ class IterationCalls:
 
     def __init__(self, robot, P, scenes: DeviceScenes, goals, dt, traj, layer_out, goal_out, goal_set, reach, state, goal_idx,
                  start, end, goal_rows, goal_point, step_out, cost_vector, active, goal_count=None, eta=None, scene_flags=None,
-                 layer_soften_fingers=False, tiling=None, layer_poses=None):
+                 layer_soften_fingers=False, tiling=None, layer_poses=None, goal_parts=1):
         lp, lg, lc = layer_out
         cost, col = goal_out
         grad, cost_traj, info = step_out
@@ -401,13 +435,15 @@ class IterationCalls:
         # tiling = (goal_parts, layer_link_groups, layer_config_block, spread): the launches go through omgx_goalset_cost_layer_tiled
         # (latency mode), goal_cost / collides then hold [S][G][parts] partial sums
         self._tiling = None if tiling is None else tuple(int(v) for v in tiling)
+        # goal_parts > 1 without a tiling: the batch kernel with split goals (omgx_goalset_cost_layer_parts), schedules over (scene, goal, part)
+        self._goal_parts = int(goal_parts) if self._tiling is None else 1
         if layer_poses is not None:
             _need(layer_poses, torch.float64, "layer_poses")
-            if self._tiling is None or layer_poses.numel() != S * n * 120:
-                raise _lib.OmgHipError("layer_poses must be [S,n,10,12] and needs a tiled launch")
+            if layer_poses.numel() != S * n * 120:
+                raise _lib.OmgHipError("layer_poses must be [S,n,10,12]")
         self._layer_poses = _ptr(layer_poses)
-        if self._tiling is not None:
-            need = S * G * goalset_parts(n, self._tiling[0])
+        if self._tiling is not None or self._goal_parts > 1:
+            need = S * G * goalset_parts(n, self._tiling[0] if self._tiling is not None else self._goal_parts)
             if cost.numel() < need or col.numel() < need:
                 raise _lib.OmgHipError(f"goal_cost / collides must hold S * G * parts = {need} elements")
         if goal_idx.dtype != torch.int32 or not goal_idx.is_cuda or goal_idx.numel() != S:
@@ -422,6 +458,7 @@ class IterationCalls:
         l = _lib.lib()
         self._f_gs, self._f_up = l.omgx_goalset_cost_layer, l.omgx_goal_update_optimize
         self._f_gst = l.omgx_goalset_cost_layer_tiled
+        self._f_gsp = l.omgx_goalset_cost_layer_parts
         self._layer_soft = int(bool(layer_soften_fingers))
         p = _ptr
         self._gs_head = (p(robot), self.P, p(scenes.objects), p(scenes.scene_begin), p(scenes.pool))
@@ -451,6 +488,20 @@ class IterationCalls:
             else:
                 with torch.cuda.device(self.device):
                     check(self._f_gst(*args), "omgx_goalset_cost_layer_tiled")
+            return
+        if self._goal_parts > 1 or self.use_layer_poses:
+            cost, col, _ws, traj, n, soft, lp, lg, lc = self._gs_mid
+            NP = goalset_parts(self.n - start_idx, self._goal_parts) if self._goal_parts > 1 else 1
+            args = (*self._gs_head, C.c_void_p(self._traj_addr + 72 * start_idx), self.n * 9, self._goals, self.S, self.G,
+                    self.n - start_idx, self.dt, 0, cost, col, traj, n, soft, lp, lg, lc, self._active_p if masked else None,
+                    self._goal_count, _ptr(_i32n(schedule, None, "schedule")), 0 if schedule is None else schedule.numel(),
+                    _ptr(_i32n(work, self.S * self.G * NP, "work")), self._goal_parts, self._layer_poses if self.use_layer_poses else None,
+                    C.c_void_p(stream))
+            if self._on_device():
+                check(self._f_gsp(*args), "omgx_goalset_cost_layer_parts")
+            else:
+                with torch.cuda.device(self.device):
+                    check(self._f_gsp(*args), "omgx_goalset_cost_layer_parts")
             return
         args = (*self._gs_head, C.c_void_p(self._traj_addr + 72 * start_idx), self.n * 9, self._goals, self.S, self.G,
                 self.n - start_idx, self.dt, 0, *self._gs_mid, self._active_p if masked else None, self._goal_count,

@@ -80,7 +80,15 @@ def test_goalset_parts_and_tiled_argument_checks_without_gpu():
                                                  goal_parts, lg, cb, spread, None, None)
     assert call(goal_parts=0) == _lib.OMGX_ERR_INVALID and call(goal_parts=9) == _lib.OMGX_ERR_INVALID
     assert call(lg=3) == _lib.OMGX_ERR_INVALID and call(lg=11) == _lib.OMGX_ERR_INVALID and call(cb=-1) == _lib.OMGX_ERR_INVALID
-    assert call(goal_parts=2, spread=0) == _lib.OMGX_ERR_UNSUPPORTED
+    # (goal_parts > 1 without `spread` is the batch kernel with split goals since ABI 8: omgx_goalset_cost_layer_parts)
+
+    def parts(goal_parts=2, traj=d, sched=None, slen=0):
+        return lib.omgx_goalset_cost_layer_parts(d, 15, d, d, d, d, 270, d, 1, 64, 30, 0.1, 0, d, d, traj, 30, 0, d, d, d, None, None,
+                                                 sched, slen, None, goal_parts, None, None)
+    assert parts(traj=None) == _lib.OMGX_ERR_INVALID and parts(goal_parts=0) == _lib.OMGX_ERR_INVALID and parts(goal_parts=16) == _lib.OMGX_ERR_INVALID
+    assert parts(sched=d, slen=12) == _lib.OMGX_ERR_INVALID  # a schedule's length is a multiple of 8
+    assert lib.omgx_goalset_schedule_parts(None, None, None, 4, 64, 3, 2, d, None) == _lib.OMGX_ERR_INVALID
+    assert lib.omgx_goalset_schedule_parts(None, None, None, 4, 64, 2, 2, None, None) == _lib.OMGX_ERR_INVALID
     assert call(goals=None, traj=None, G=0) == _lib.OMGX_ERR_INVALID
     assert call(goals=None) == _lib.OMGX_ERR_INVALID
     assert call(n_rem=0) == _lib.OMGX_ERR_UNSUPPORTED and call(n_rem=65) == _lib.OMGX_ERR_UNSUPPORTED

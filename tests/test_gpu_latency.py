@@ -153,7 +153,7 @@ def test_tiled_entry_point_rejects_bad_arguments(dev):
     assert call() == _lib.OMGX_OK
     assert call(goal_parts=0) == _lib.OMGX_ERR_INVALID and call(goal_parts=9) == _lib.OMGX_ERR_INVALID
     assert call(lg=3) == _lib.OMGX_ERR_INVALID and call(lg=0) == _lib.OMGX_ERR_INVALID and call(cb=-1) == _lib.OMGX_ERR_INVALID
-    assert call(goal_parts=4, spread=0) == _lib.OMGX_ERR_UNSUPPORTED  # parts of a goal exist in the latency-mode kernel only
+    assert call(goal_parts=4, spread=0) == _lib.OMGX_OK  # since ABI 8: the batch kernel with split goals (tests/test_gpu_parts.py)
     assert call(goal_parts=1, spread=0) == _lib.OMGX_OK
     assert call(goals=None, traj=None, G=0) == _lib.OMGX_ERR_INVALID   # nothing to do
     assert call(goals=None, G=8) == _lib.OMGX_ERR_INVALID

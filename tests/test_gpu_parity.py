@@ -882,7 +882,7 @@ def test_fused_update_optimize_equals_separate_launches(dev, alg, standoff, n, m
 
 
 @pytest.mark.parametrize("case", ["md_switch_70", "exp_standoff_41", "md_early_2"])
-@pytest.mark.parametrize("mode", ["fused", "serial", "latency"])
+@pytest.mark.parametrize("mode", ["fused", "serial", "latency", "split2", "split4"])
 def test_engine_plan_matches_reference_planner_loop(dev, case, mode, monkeypatch):
     """ChompEngine on ONE scene against the reference's own planner run (tests/golden/plan_*.npz: Learner.__init__'s goal
     pick, then Learner.update_goal + Optimizer.optimize per iteration with the break on `terminate`, then the info-only
@@ -896,7 +896,8 @@ def test_engine_plan_matches_reference_planner_loop(dev, case, mode, monkeypatch
     cfg = Config(timesteps=30, use_standoff=standoff)
     assert cfg.optim_steps == int(fx["optim_steps"]) and cfg.extra_smooth_steps == int(fx["extra_smooth_steps"])
     eng = ChompEngine(m, batch, cfg, fx["start"][None], fx["goal_set"][None], reach_grasps=fx["reach_grasps"][None] if standoff else None,
-                      device=dev, ol_alg=str(fx["alg"]), latency_mode=mode == "latency")  # latency: omgx_goalset_cost_layer_tiled
+                      device=dev, ol_alg=str(fx["alg"]), latency_mode=mode == "latency",  # latency: omgx_goalset_cost_layer_tiled
+                      goal_parts=int(mode[5:]) if mode.startswith("split") else 1)     # split: omgx_goalset_cost_layer_parts
     eng.select_initial_goal()
     assert int(eng.goal_idx[0]) == int(fx["init_goal_idx"])
     np.testing.assert_allclose(eng.traj[0].cpu().numpy(), fx["init_traj"], rtol=0, atol=1e-12)

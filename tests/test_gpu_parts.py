@@ -1,0 +1,162 @@
+"""Split goals in the BATCH layout (ChompEngine(goal_parts=...), omgx_goalset_cost_layer_parts / omgx_goalset_schedule_parts, ABI 8):
+mid-size batches — one GPU's share of BASELINE config 4 on 8 GPUs (13 scenes x 128 goals), 25 x 64 — whose goal-set launch is a round
+or two of the chip's workgroup slots and therefore bound by the latency of one goal workgroup.  What has to hold: the partial sums
+add up to the one-workgroup cost (another float32 summation order) and to the oracle's; collision counts add up exactly; layer outputs
+bit for bit; any dispatch schedule over the (scene, goal, part) items gives the same bits; plans like the unsplit engine's and the
+oracle's, pipelined or not, ragged or not; the reference's own planner runs through it."""
+from __future__ import annotations
+
+import copy
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU: torch.cuda.is_available() is False")
+    return torch.device("cuda:0")
+
+
+def _make(dev, S, G, goal_parts, counts=None, grid=32, alg="MD", n=30):
+    import bench
+    from omg_planner_amd.engine import ChompEngine
+    cfg, model, batch, start, goals = bench.build_workload(S, G, n, grid, 0, False)
+    return ChompEngine(model, batch, copy.deepcopy(cfg), start, goals, device=dev, ol_alg=alg, goal_counts=counts, goal_parts=goal_parts), batch
+
+
+def _total(buf, S, G, NP):
+    parts = buf.reshape(-1)[: S * G * NP].reshape(S, G, NP)
+    tot = parts[:, :, 0].clone()
+    for k in range(1, NP):
+        tot += parts[:, :, k]
+    return tot
+
+
+@pytest.mark.parametrize("parts", [2, 4, 8])
+@pytest.mark.parametrize("n_rem", [30, 17, 5, 1])
+def test_split_goal_costs_add_up_and_the_layer_keeps_its_bits(dev, parts, n_rem):
+    from omg_planner_amd import ops
+    from oracle import oracle as orc
+    S, G = 3, 24
+    counts = np.array([24, 11, 17])
+    eng, batch = _make(dev, S, G, 1, counts)
+    ts = eng.traj[:, 30 - n_rem]
+    lay = tuple(torch.full_like(t, float("nan")) for t in (eng.pot, eng.pgrad, eng.col))
+    cost, col = ops.goalset_cost_layer(eng.robot, eng.P, eng.scenes, ts, eng.cv_goals, n_rem, eng.cfg.time_interval, eng.traj, lay,
+                                       goal_count=eng.goal_count)
+    NP = ops.goalset_parts(n_rem, parts)
+    pc = torch.full((S, G * NP), float("nan"), dtype=torch.float32, device=dev)
+    pl = torch.full_like(pc, float("nan"))
+    lay2 = tuple(torch.full_like(t, float("nan")) for t in lay)
+    poses = torch.full((S, 30, 10, 12), float("nan"), dtype=torch.float64, device=dev)
+    ops.goalset_cost_layer(eng.robot, eng.P, eng.scenes, ts, eng.cv_goals, n_rem, eng.cfg.time_interval, eng.traj, lay2, out=(pc, pl),
+                           goal_count=eng.goal_count, goal_parts=parts, layer_poses=poses)
+    torch.cuda.synchronize()
+    for a, b in zip(lay, lay2):
+        assert torch.equal(a, b)
+    np.testing.assert_array_equal(poses.cpu().numpy(), ops.pose_table(eng.robot, eng.P, eng.traj).cpu().numpy())
+    tot, tcol = _total(pc, S, G, NP).cpu().numpy(), _total(pl, S, G, NP).cpu().numpy()
+    for s in range(S):
+        k = counts[s]
+        np.testing.assert_allclose(tot[s, :k], cost[s, :k].cpu().numpy(), rtol=2e-6, atol=1e-7)
+        assert np.array_equal(tcol[s, :k], col[s, :k].cpu().numpy())
+        assert np.isnan(pc.reshape(S, G, NP)[s, k:].cpu().numpy()).all()  # the padding of a ragged goal set is never written
+        gc, _ = orc.goalset_cost(eng.model.blob(), eng.P, batch.subset(s, s + 1), ts[s:s + 1].cpu().numpy(), eng.cv_goals[s:s + 1, :k].cpu().numpy(),
+                                 n_rem, eng.cfg.time_interval)
+        np.testing.assert_allclose(tot[s, :k], np.asarray(gc).reshape(-1), rtol=1e-5, atol=1e-6)
+    # any dispatch schedule over the (scene, goal, part) items: the same bits; the measuring launch stamps every item that ran
+    work = torch.zeros(S * G * NP, dtype=torch.int32, device=dev)
+    sched = ops.goalset_schedule(None, S, G, goal_count=eng.goal_count, parts=NP, device=dev)
+    pc2, pl2 = torch.full_like(pc, float("nan")), torch.full_like(pl, float("nan"))
+    ops.goalset_cost_layer(eng.robot, eng.P, eng.scenes, ts, eng.cv_goals, n_rem, eng.cfg.time_interval, eng.traj, lay2, out=(pc2, pl2),
+                           goal_count=eng.goal_count, goal_parts=parts, schedule=sched, work=work)
+    sched2 = ops.goalset_schedule(work, S, G, goal_count=eng.goal_count, parts=NP)
+    pc3, pl3 = torch.full_like(pc, float("nan")), torch.full_like(pl, float("nan"))
+    ops.goalset_cost_layer(eng.robot, eng.P, eng.scenes, ts, eng.cv_goals, n_rem, eng.cfg.time_interval, eng.traj, lay2, out=(pc3, pl3),
+                           goal_count=eng.goal_count, goal_parts=parts, schedule=sched2)
+    torch.cuda.synchronize()
+    for x in (pc2, pc3):
+        assert np.array_equal(x.cpu().numpy(), pc.cpu().numpy(), equal_nan=True)
+    for x in (pl2, pl3):
+        assert np.array_equal(x.cpu().numpy(), pl.cpu().numpy(), equal_nan=True)
+    w = work.cpu().numpy().reshape(S, G, NP)
+    sc = sched2.cpu().numpy()
+    items = np.sort(sc[sc >= 0])
+    want = np.concatenate([(s * G + np.arange(counts[s]))[:, None] * NP + np.arange(NP)[None, :] for s in range(S)]).reshape(-1)
+    assert np.array_equal(items, np.sort(want))  # every item exactly once, no padding
+    for s in range(S):
+        assert (w[s, :counts[s]] > 0).all() and (w[s, counts[s]:] == 0).all()
+
+
+@pytest.mark.parametrize("parts,alg", [(2, "MD"), (4, "FTL"), (2, "Exp")])
+def test_split_engine_follows_the_unsplit_engine_and_the_oracle(dev, parts, alg):
+    """Iterations of a plan with and without split goals: layer outputs equal bit for bit, goal costs within summation rounding,
+    the same goals, trajectories equal; the fused launches against the five separate ones bit for bit; and against the oracle."""
+    from oracle.check import engine_vs_oracle
+    counts = np.array([20, 13, 7])
+    a, _ = _make(dev, 3, 20, 1, counts, alg=alg)
+    b, _ = _make(dev, 3, 20, parts, counts, alg=alg)
+    c, _ = _make(dev, 3, 20, parts, counts, alg=alg)
+    c.separate_launches = True
+    for e in (a, b, c):
+        e.select_initial_goal()
+    assert torch.equal(a.goal_idx, b.goal_idx) and torch.equal(a.traj, b.traj)
+    for t in (0, 1, 2, 20, 35, 46, 49, 50, 55):
+        for e in (a, b, c):
+            e.t = t
+            e.iterate(t, early_stop=t > 1)
+        torch.cuda.synchronize()
+        for k in ("pot", "pgrad", "col"):
+            assert torch.equal(getattr(a, k), getattr(b, k)), (t, k)
+        if t < 50:
+            ga, gb = a.goal_cost_total().cpu().numpy(), b.goal_cost_total().cpu().numpy()
+            for s in range(3):
+                np.testing.assert_allclose(gb[s, :counts[s]], ga[s, :counts[s]], rtol=2e-6, atol=1e-7)
+        assert torch.equal(a.goal_idx, b.goal_idx), t
+        np.testing.assert_allclose(b.traj.cpu().numpy(), a.traj.cpu().numpy(), rtol=0, atol=1e-9)
+        for k in ("traj", "goal_idx", "learner_state", "info", "pot", "col"):
+            assert np.array_equal(getattr(b, k).cpu().numpy(), getattr(c, k).cpu().numpy(), equal_nan=True), (t, k)
+    d, batch = _make(dev, 2, 16, parts, alg=alg)
+    d.select_initial_goal()
+    r = engine_vs_oracle(d, batch, [0, 1], steps=12, pin_window=False)
+    assert r["goal_idx_equal"] and r["max_traj_err"] <= 1e-6 and r["max_cost_rel_err"] <= 1e-5, r
+
+
+@pytest.mark.parametrize("early", [True, False])
+def test_split_plan_pipelined_equals_unpipelined_and_its_graph(dev, early):
+    """13 scenes x 128 goals (one GPU's share of BASELINE config 4 on 8 GPUs) with split goals: the plan on three pipeline parts, on
+    one stream, and replayed as one HIP graph — the same bits; against the unsplit plan: same goals, trajectories at 1e-9."""
+    S, G = 13, 128
+    a, _ = _make(dev, S, G, 1)
+    a.plan(early_stop=early)
+    out = []
+    for pipe in (None, 1):
+        b, _ = _make(dev, S, G, 2)
+        b.pipeline = pipe
+        b.plan(early_stop=early)
+        torch.cuda.synchronize()
+        out.append({k: getattr(b, k).cpu().numpy().copy() for k in ("traj", "info", "goal_idx", "learner_state", "end", "goal_rows", "active")})
+    assert ChompEngineParts(S, G) >= 2
+    for k in out[0]:
+        assert np.array_equal(out[0][k], out[1][k], equal_nan=True), k
+    assert np.array_equal(out[0]["goal_idx"], a.goal_idx.cpu().numpy()) and np.array_equal(out[0]["active"], a.active.cpu().numpy())
+    np.testing.assert_allclose(out[0]["traj"], a.traj.cpu().numpy(), rtol=0, atol=1e-9)
+    c, _ = _make(dev, S, G, 2)
+    fresh = c.snapshot()
+    graph = c.capture_plan(early_stop=early)
+    c.restore(fresh)
+    graph.replay()
+    torch.cuda.synchronize()
+    for k in ("traj", "info", "goal_idx", "learner_state", "end", "goal_rows"):
+        assert np.array_equal(getattr(c, k).cpu().numpy(), out[0][k], equal_nan=True), k
+
+
+def ChompEngineParts(S, G):
+    from omg_planner_amd.engine import ChompEngine
+    return ChompEngine.auto_parts(S, G)
