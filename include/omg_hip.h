@@ -341,8 +341,6 @@ int omgx_goalset_cost_layer_parts(const double* robot, int32_t n_points,
                                   const int32_t* active, const int32_t* goal_count,
                                   const int32_t* schedule, int32_t schedule_len, uint32_t* work,
                                   int32_t goal_parts, double* layer_poses, void* stream);
-int omgx_goalset_schedule_parts(const uint32_t* work, const int32_t* active, const int32_t* goal_count, int32_t num_scenes,
-                                int32_t num_goals, int32_t parts, int32_t slack, int32_t* schedule, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * (4) omgx_chomp_optimize
@@ -491,6 +489,34 @@ int omgx_point_cloud_sdf(const double* points, int32_t num_points, const double*
 int32_t omgx_goalset_schedule_len(int32_t num_scenes, int32_t num_goals, int32_t slack);
 int omgx_goalset_schedule(const uint32_t* work, const int32_t* active, const int32_t* goal_count, int32_t num_scenes,
                           int32_t num_goals, int32_t slack, int32_t* schedule, void* stream);
+
+int omgx_goalset_schedule_parts(const uint32_t* work, const int32_t* active, const int32_t* goal_count, int32_t num_scenes,
+                                int32_t num_goals, int32_t parts, int32_t slack, int32_t* schedule, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * (8) Scenes that change while resident in HBM (ABI 8)
+ * The reference rebuilds the per-object parameters on every call (Cost.compute_obstacle_cost_layer, omg/cost.py:296-335) and
+ * a perception frame replaces an obstacle's volume (PointEnv.compute_sdf_from_points, omg/core.py:426-457).  With the object
+ * table and the SDF pool on the device a change is:
+ *   a new pose    12 floats at offset 0 of the object's record (rows of se3_inverse(pose_mat), float32) — a 48-byte copy; the
+ *                 influence region lives in object coordinates and survives;
+ *   a new volume  the grid (already on the device, e.g. written by omgx_point_cloud_sdf straight into the pool), then
+ *     omgx_object_set_grid       lo / hi / dim / delta / grid_offset of the record and what is derived from them (inv_extent,
+ *                                inv_delta) + the LOOSE influence region (the grid with 1.5 voxels of slack), one 1-thread launch;
+ *     omgx_fit_influence_region  the fitted rounded box (rb_c, rb_h, rb_r, rb_r2) of the lookups that can add anything, computed
+ *                                ON THE DEVICE from the volume: the algorithm of scenes.influence_rbox + tighten_far_boxes
+ *                                (omg-planner_amd/scenes.py is the specification; float64, the same expressions), six small
+ *                                launches on `stream`, no host pass over the voxels, no synchronisation.  epsilon / clearance =
+ *                                the record's (host copies).  A record the kernels do not cull with (epsilon >= 1 or
+ *                                clearance > 1) or a grid without interior keeps the loose region.
+ *   scratch  device memory of omgx_region_scratch_bytes(dims) bytes, owned by the caller until the launches have run.
+ * Everything is ordered on `stream`: a plan enqueued behind these calls sees the new scene.
+ * ------------------------------------------------------------------------------------------- */
+int64_t omgx_region_scratch_bytes(int32_t dx, int32_t dy, int32_t dz);
+int omgx_object_set_grid(omgx_object* object, const float* h_lo, const float* h_hi, const int32_t* h_dims, float delta,
+                         int64_t grid_offset, void* stream);
+int omgx_fit_influence_region(omgx_object* object, const float* grid, const int32_t* h_dims, const float* h_lo, const float* h_hi,
+                              float epsilon, float clearance, void* scratch, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Diagnostics

@@ -180,7 +180,7 @@ class ChompEngine:
         dev = self.device
         f64 = dict(dtype=torch.float64, device=dev)
         self.robot = ops.robot_blob(model, dev)
-        self.scenes = ops.DeviceScenes(batch, dev)
+        self.scenes = batch if isinstance(batch, ops.DeviceScenes) else ops.DeviceScenes(batch, dev)  # a DeviceScenes: shared, and changeable between plans (set_object_pose, replace_grid)
         self.start = torch.as_tensor(start, **f64).contiguous()
         self.goal_set = torch.as_tensor(goal_set, **f64).contiguous()
         self.use_standoff = bool(cfg.use_standoff)

@@ -56,14 +56,126 @@ def sdf_loss_forward(pose_init, sdf_grids, sdf_limits, points, epsilons, padding
 
 
 class DeviceScenes:
-    """Scene table resident in HBM: object records, scene_begin, SDF pool (see scenes.SceneBatch)."""
+    """Scene table resident in HBM: object records, scene_begin, SDF pool (see scenes.SceneBatch) — and the ways to change it
+    while it stays there (include/omg_hip.h section 8): `set_object_pose` (a 48-byte write), `replace_grid` (a volume that is
+    already on the device, its influence region fitted on the device), `grid_slot` (where omgx_point_cloud_sdf can write a new
+    volume directly).  Every change is ordered on torch's current stream; launches enqueued behind it see the new scene, and a
+    ChompEngine built on these scenes plans again without being rebuilt (it holds pointers, not copies).
+    `reserve_voxels`: spare float32 elements at the end of the pool for volumes that outgrow their slot (the pool is never
+    reallocated: engines and prepared launches keep its address)."""
 
-    def __init__(self, batch, device="cuda:0"):
+    def __init__(self, batch, device="cuda:0", reserve_voxels: int = 0):
+        from . import scenes as _sc
         self.device = torch.device(device)
         self.num_scenes = batch.num_scenes
-        self.objects = torch.from_numpy(np.ascontiguousarray(batch.objects).view(np.uint8).copy()).to(self.device)
-        self.scene_begin = torch.from_numpy(np.ascontiguousarray(batch.scene_begin, np.int32)).to(self.device)
-        self.pool = torch.from_numpy(np.ascontiguousarray(batch.pool, np.float32)).to(self.device)
+        self.host_objects = np.ascontiguousarray(batch.objects).copy()          # host mirror of the records (the region fields of a
+        self.host_scene_begin = np.ascontiguousarray(batch.scene_begin, np.int32)  # device-fitted object are stale until sync_host())
+        assert self.host_objects.dtype == _sc.OBJECT_DTYPE
+        self.objects = torch.from_numpy(self.host_objects.view(np.uint8).copy()).to(self.device)
+        self.scene_begin = torch.from_numpy(self.host_scene_begin).to(self.device)
+        used = int(np.asarray(batch.pool).size)
+        pool = np.ascontiguousarray(batch.pool, np.float32)
+        if reserve_voxels > 0:
+            self.pool = torch.empty(used + int(reserve_voxels), dtype=torch.float32, device=self.device)
+            self.pool[:used].copy_(torch.from_numpy(pool))
+        else:
+            self.pool = torch.from_numpy(pool).to(self.device)
+        self.pool_used = used
+        sizes = self.host_objects["dim"].astype(np.int64).prod(axis=1)
+        self._slot_cap = {i: int(sizes[i]) for i in range(len(sizes))}  # elements object i may use at its grid_offset
+        self._scratch = None
+
+    def _index(self, scene: int, obj: int) -> int:
+        lo, hi = int(self.host_scene_begin[scene]), int(self.host_scene_begin[scene + 1])
+        if not 0 <= obj < hi - lo:
+            raise IndexError(f"scene {scene} has {hi - lo} objects")
+        return lo + obj
+
+    def _record_ptr(self, idx: int) -> C.c_void_p:
+        return C.c_void_p(self.objects.data_ptr() + idx * self.host_objects.dtype.itemsize)
+
+    def set_object_pose(self, scene: int, obj: int, pose_mat) -> None:
+        """Move an object: pose_mat [4,4] (object -> world; numpy or a device tensor).  The record's pose rows become
+        se3_inverse(pose_mat) in float32 (omg/util.py:129-135, what Cost.compute_obstacle_cost_layer rebuilds per call,
+        omg/cost.py:303-316); its influence region lives in object coordinates and stays."""
+        from . import scenes as _sc
+        idx = self._index(scene, obj)
+        if isinstance(pose_mat, torch.Tensor):
+            P = pose_mat.to(device=self.device, dtype=torch.float64)
+            R, t = P[:3, :3], P[:3, 3]
+            inv = torch.cat([R.T, -(R.T @ t)[:, None]], dim=1).to(torch.float32).contiguous()  # [3,4]
+            self.host_objects[idx]["pose_inv"] = inv.cpu().numpy().ravel()
+        else:
+            inv_h = _sc.se3_inverse(np.asarray(pose_mat, np.float64))[:3, :4]
+            self.host_objects[idx]["pose_inv"] = inv_h.ravel()
+            inv = torch.from_numpy(np.ascontiguousarray(inv_h, np.float32)).to(self.device, non_blocking=True)
+        off = idx * self.host_objects.dtype.itemsize
+        self.objects[off: off + 48].copy_(inv.reshape(-1).view(torch.uint8))
+
+    def grid_slot(self, scene: int, obj: int, shape) -> torch.Tensor:
+        """A float32 [X,Y,Z] view into the pool where the object's NEXT volume can be written in place (e.g. by
+        point_cloud_sdf(out=...)): the object's own slot if the shape fits, else fresh space from the reserve.  Pass it to
+        replace_grid afterwards."""
+        idx = self._index(scene, obj)
+        n = int(np.prod(shape))
+        off = int(self.host_objects[idx]["grid_offset"])
+        if n > self._slot_cap[idx]:
+            if self.pool_used + n > self.pool.numel():
+                raise _lib.OmgHipError(f"the SDF pool has no room for {n} more voxels: build DeviceScenes with reserve_voxels")
+            off = self.pool_used
+            self.pool_used += n
+            self._slot_cap[idx] = n
+            self.host_objects[idx]["grid_offset"] = off
+        return self.pool[off: off + n].view(tuple(int(d) for d in shape))
+
+    def replace_grid(self, scene: int, obj: int, grid: torch.Tensor, origin, delta: float, fit: str = "device") -> None:
+        """Give an object a new volume that is already on the device: grid [X,Y,Z] float32 (a view from grid_slot: used in place;
+        anything else is copied into the pool, device to device), origin = min corner [3], delta = voxel size.  The record's
+        limits follow like scenes.pack_table writes them; the influence region is fitted ON THE DEVICE (fit="device":
+        omgx_fit_influence_region, the algorithm of scenes.influence_rbox) or left loose (fit="loose": the grid with 1.5 voxels
+        of slack — same results, more exact lookups)."""
+        if fit not in ("device", "loose"):
+            raise ValueError("fit must be 'device' or 'loose'")
+        _need(grid, torch.float32, "grid")
+        if grid.dim() != 3:
+            raise _lib.OmgHipError("grid must be [X,Y,Z]")
+        idx = self._index(scene, obj)
+        shape = tuple(int(d) for d in grid.shape)
+        slot = self.grid_slot(scene, obj, shape)
+        if slot.data_ptr() != grid.data_ptr():
+            slot.copy_(grid)
+        rec = self.host_objects[idx]
+        mn = np.asarray(origin, np.float64)
+        mxc = mn + float(delta) * np.array(shape)
+        lo = mn.astype(np.float32)
+        hi = np.array([mn[a] + (mxc[a] - mn[a]) * 1.0 for a in range(3)], np.float32)  # scenes.pack_table (ragged)
+        dims = np.array(shape, np.int32)
+        rec["lo"], rec["hi"], rec["dim"], rec["delta"] = lo, hi, dims, np.float32(delta)
+        one = self.host_objects[idx: idx + 1]
+        from . import scenes as _sc
+        _sc.finish_records(one)  # host mirror: derived constants + the loose region
+        l = _lib.lib()
+        fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int32)
+        with torch.cuda.device(self.device):
+            check(l.omgx_object_set_grid(self._record_ptr(idx), lo.ctypes.data_as(fp), hi.ctypes.data_as(fp), dims.ctypes.data_as(ip),
+                                         float(np.float32(delta)), int(rec["grid_offset"]), _stream()), "omgx_object_set_grid")
+            if fit == "device":
+                need = int(l.omgx_region_scratch_bytes(*shape))
+                if self._scratch is None or self._scratch.numel() < need:
+                    self._scratch = torch.empty(need, dtype=torch.uint8, device=self.device)
+                check(l.omgx_fit_influence_region(self._record_ptr(idx), C.c_void_p(slot.data_ptr()), dims.ctypes.data_as(ip),
+                                                  lo.ctypes.data_as(fp), hi.ctypes.data_as(fp), float(rec["epsilon"]), float(rec["clearance"]),
+                                                  _ptr(self._scratch), _stream()), "omgx_fit_influence_region")
+
+    def sync_host(self) -> np.ndarray:
+        """Bring the host mirror of the records up to date with the device (one small copy; tests, oracle comparisons)."""
+        self.host_objects = self.objects.cpu().numpy().view(self.host_objects.dtype).copy()
+        return self.host_objects
+
+    def host_batch(self):
+        """The scenes as they are on the device now, as a host SceneBatch (records + pool copied back): for oracle checks."""
+        from . import scenes as _sc
+        return _sc.SceneBatch(self.sync_host(), self.host_scene_begin.copy(), self.pool[: self.pool_used].cpu().numpy())
 
 
 def robot_blob(model, device="cuda:0") -> torch.Tensor:

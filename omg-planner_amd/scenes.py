@@ -169,6 +169,22 @@ def influence_rbox(grid: np.ndarray, epsilon: float, clearance: float, vox: np.n
             hi_w[:, ax] = w[:, ax] - 0.5 + (last + 1) / r
         some = kept.reshape(len(w), -1).any(1)  # (every needed window keeps at least the sub-box of its minimal corner)
         lo_list.append(lo_w[some]); hi_list.append(hi_w[some])
+    # ... and, whole, the needed windows NEXT to the boundary (inner windows with a boundary window as a face neighbour).  Once the
+    # boundary windows have been shrunk to their kept sub-boxes they no longer enclose what lies behind them, and a far corner of
+    # such an inner window can be the farthest point of the union.  Deeper windows cannot: along every axis a deeper window lies
+    # between two windows of this layer, so none of its corners is an extreme point of the union (omgx_fit_influence_region,
+    # the device version of this fit, simply feeds every inner window: the same maximum).
+    bnd = need & ~inner
+    padb = np.pad(bnd, 1, constant_values=False)
+    adj = np.zeros_like(need)
+    for ax in range(3):
+        for sh in (0, 2):
+            sl = [slice(1, -1)] * 3
+            sl[ax] = slice(sh, sh + need.shape[ax])
+            adj |= padb[tuple(sl)]
+    sidx = np.argwhere(inner & adj).astype(np.float64)
+    if len(sidx):
+        lo_list.append(sidx - 0.5); hi_list.append(sidx + 0.5)
     blo, bhi = np.concatenate(lo_list), np.concatenate(hi_list)
     if len(blo) == 0:  # cannot happen (a needed window keeps the sub-box of its minimal corner); stay safe
         widx = np.argwhere(need)

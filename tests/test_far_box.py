@@ -42,14 +42,14 @@ def _one_object_check(grid, delta, eps, clr, rng, n=60000):
     t[k] = core + dirs * (float(r["rb_r"]) + rng.uniform(-2.0, 2.0, (len(k), 1)) * delta)
     pts = (t + r["lo"]).astype(np.float32)
     tt = pts - r["lo"]  # the kernel's float32 offset (identity pose)
-    assert _inside(loose[0], tt)[_inside(r, tt)].all() or True  # (the fitted region may stick out of the default box where nothing is)
-    outside = ~_inside(r, tt)
+    outside = ~_inside(r, tt)  # (the fitted region may stick out of the default box `loose` where nothing is: no invariant there)
     lim = np.concatenate([r["lo"], r["hi"], dims.astype(np.float32), [np.float32(delta)]]).astype(np.float32)[None]
     pot, grad, col = orc.sdf_loss_forward(np.eye(4, dtype=np.float32)[None], grid[None], lim, pts, np.float32([eps]),
                                           np.float32([1.0]), np.float32([clr]), np.float32([0.0]))
     assert outside.any()
     assert not pot[outside].any() and not grad[outside].any() and not col[outside].any()
     contributing = (pot != 0) | (col != 0)
+    assert _inside(r, tt)[contributing].all() and _inside(loose[0], tt)[contributing].all()  # every point that adds anything lies in both regions
     return outside.mean(), contributing.mean(), (~outside).sum() / max(contributing.sum(), 1)
 
 
