@@ -42,7 +42,9 @@ sys.path.insert(0, str(ROOT))
 # the roofline's constants and its one formula live in tools/roofline.py (bound: VALU instruction issue, priced by tools/valu_peak.hip)
 
 
-def build_workload(num_scenes, num_goals, n, grid, seed0, share_grids, num_objects=4):
+def build_workload(num_scenes, num_goals, n, grid, seed0, share_grids, num_objects=4, timing=None):
+    """timing: optional dict that receives the host time of scenes.pack_table (object records + SDF pool + the fitted influence
+    regions: the set-up a batch pays once, outside every timed region)."""
     from omg_planner_amd import robot as rb, scenes as sc
     from omg_planner_amd.config import Config
     cfg = Config(timesteps=n, use_standoff=False)  # omg.core -exp sets use_standoff=False (core.py:873)
@@ -52,7 +54,10 @@ def build_workload(num_scenes, num_goals, n, grid, seed0, share_grids, num_objec
         for scn in scenes:
             for ob in scn.objects:
                 ob.sdf = sc.SdfGrid(ob.sdf.data.copy(), ob.sdf.origin, ob.sdf.delta)
+    t0 = time.perf_counter()
     batch = sc.pack_table(scenes, cfg.layer_kwargs(), ragged=True, share_grids=share_grids)
+    if timing is not None:
+        timing["pack_table_ms"] = (time.perf_counter() - t0) * 1e3
     start = np.tile(rb.HOME_CONFIG, (num_scenes, 1))
     # grasp-like goal sets: the hand ends 10-16 cm from the target, approach axis towards it
     goals = np.stack([sc.make_reach_goals(scenes[s], model, num_goals, seed0 + s) for s in range(num_scenes)])
@@ -142,6 +147,86 @@ def cpu_baseline(cfg, model, batch, start, goals, n, budget_s=10.0):
                                 "box; timed in the build container by tools/time_reference_cpu.py: BASELINE.md section 3.1"}
 
 
+def rank_share_config4(dev, ol_alg, steps=100, regions=3):
+    """ms per step of ONE GPU's share of BASELINE config 4 on 8 GPUs (100 scenes x 128 goals -> 13 scenes x 128 goals), laid out
+    by ChompEngine.layout like any rank of that job would be: what the 8-GPU strong-scaling ceiling hangs on."""
+    import torch
+    from omg_planner_amd.engine import ChompEngine
+    cfg, model, batch, start, goals = build_workload(13, 128, 30, 64, seed0=0, share_grids=False)
+    eng = ChompEngine.auto(model, batch, copy.deepcopy(cfg), start, goals, layout_scenes=13, device=dev, ol_alg=ol_alg)
+    snap = eng.snapshot()
+    count = [0]
+
+    def step():
+        if count[0] and count[0] % cfg.optim_steps == 0:
+            eng.restore(snap)
+        count[0] += 1
+        eng.t = 0
+        eng.iterate(0)
+
+    for _ in range(20):
+        step()
+    out = []
+    for _ in range(regions):
+        eng.join()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        eng.join()
+        torch.cuda.synchronize()
+        out.append((time.perf_counter() - t0) / steps * 1e3)
+    return sorted(out)[len(out) // 2], dict(eng.layout_used)
+
+
+def scene_update_timing(dev, cfg, model, batch, start, goals, ol_alg):
+    """One perception frame's scene change on the device, for ONE scene of the workload (include/omg_hip.h section 8): two objects
+    moved (48-byte writes), one obstacle's volume replaced by a fresh point-cloud SDF (4096 points -> a ~45^3 grid written
+    straight into the pool, omg/core.py:426-457) with its influence region fitted on the device — wall time incl. the final
+    synchronisation — and, beside it, what the same change costs through the host (volume back to the host + scenes.pack_table's
+    fit).  Then the SAME engine plans the changed scene; its result against an engine packed afresh is part of the line."""
+    import torch
+    from omg_planner_amd import ops, scenes as sc
+    from omg_planner_amd.engine import ChompEngine
+    one = batch.subset(0, 1)
+    ds = ops.DeviceScenes(one, dev, reserve_voxels=400_000)
+    eng = ChompEngine.auto(model, ds, copy.deepcopy(cfg), start[:1], goals[:1], device=dev, ol_alg=ol_alg)
+    fresh = eng.snapshot()
+    eng.plan(early_stop=False)
+    rng = np.random.RandomState(7)
+    cloud = rng.uniform([0.35, -0.2, 0.05], [0.65, 0.2, 0.35], size=(4096, 3))
+    pts = torch.as_tensor(cloud, dtype=torch.float64, device=dev)
+    lo, hi = cloud.min(0) - 0.24, cloud.max(0) + 0.24
+    shape = tuple(len(np.arange(lo[a], hi[a], 0.02)) for a in range(3))
+    best = float("inf")
+    for rep in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ds.set_object_pose(0, 0, sc._yaw_pose(0.5, 0.1 + 0.01 * rep, 0.15, 0.3))
+        ds.set_object_pose(0, 1, sc._yaw_pose(0.6, -0.15, 0.16, -0.8))
+        slot = ds.grid_slot(0, 2, shape)
+        grid, origin, res = ops.point_cloud_sdf(pts, 0.02, 0.24, out=slot)
+        ds.replace_grid(0, 2, grid, origin, res, fit="device")
+        ds.set_object_pose(0, 2, np.eye(4))
+        torch.cuda.synchronize()
+        best = min(best, (time.perf_counter() - t0) * 1e3)
+    t0 = time.perf_counter()
+    g_host = grid.cpu().numpy()
+    obj = sc.SceneObject("cloud", np.eye(4), sc.SdfGrid(g_host, origin, res))
+    sc.pack_table([sc.Scene([obj], 0)], cfg.layer_kwargs())
+    host_ms = (time.perf_counter() - t0) * 1e3
+    eng.restore(fresh)
+    info = eng.plan(early_stop=False)
+    torch.cuda.synchronize()
+    hb = ds.host_batch()
+    eng2 = ChompEngine.auto(model, sc.SceneBatch(hb.objects, hb.scene_begin, hb.pool), copy.deepcopy(cfg), start[:1], goals[:1], device=dev, ol_alg=ol_alg)
+    info2 = eng2.plan(early_stop=False)
+    torch.cuda.synchronize()
+    same = bool(torch.equal(eng.traj, eng2.traj) and torch.equal(info, info2))
+    return {"scene_update_ms": best, "what": f"2 poses + a {shape[0]}x{shape[1]}x{shape[2]} point-cloud SDF of 4096 points built, placed and region-fitted on the device (best of 3, incl. synchronize)",
+            "same_change_through_the_host_ms": host_ms, "replan_equals_fresh_engine": same}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -155,7 +240,11 @@ def main():
     ap.add_argument("--objects", type=int, default=4, help="obstacles per scene besides the table (BASELINE config 5's clutter: 12 with --waypoints 50)")
     ap.add_argument("--share-grids", action="store_true", help="store identical SDF volumes once (model library)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--pipeline", type=int, default=0, help="parts of the engine's software pipeline (0: ChompEngine.auto_parts)")
+    ap.add_argument("--pipeline", type=int, default=0, help="parts of the engine's software pipeline (0: ChompEngine.layout's choice)")
+    ap.add_argument("--layout-scenes", type=int, default=0, help="scene count ChompEngine.layout is evaluated for (0: the largest shard, ceil(total / world)); "
+                    "a single-process run given a multi-rank job's number computes the same bits as that job")
+    ap.add_argument("--goal-parts", type=int, default=0, help="workgroups per goal in the batch layout (0: the layout rule's choice)")
+    ap.add_argument("--regions", type=int, default=0, help="timed regions of --steps steps each (0: 1, or 5 when a region is shorter than 50 ms); ms_per_step is their median")
     ap.add_argument("--no-plan", action="store_true", help="skip timing a full 70-iteration plan (ms_per_plan)")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of three scenes after the timed region")
     ap.add_argument("--ol-alg", default="MD", help="goal-selection rule (reference default: MD, omg/config.py:67)")
@@ -196,12 +285,26 @@ def main():
         S, seed0, total_scenes = len(mine), mine.start, args.total_scenes
     else:
         S, seed0, total_scenes = args.scenes, rank * args.scenes, world * args.scenes
-    cfg, model, batch, start, goals = build_workload(S, G, n, args.grid, seed0=seed0, share_grids=args.share_grids, num_objects=args.objects)
-    eng = ChompEngine(model, batch, copy.deepcopy(cfg), start, goals, device=dev, ol_alg=args.ol_alg)
-    # the engine's software pipeline: the rank's scenes as two independent halves on two streams — the two half launches run
-    # concurrently and pack their ramp-ups and tails into less time than one launch after the other; same results bit for bit
-    parts = args.pipeline if args.pipeline > 0 else ChompEngine.auto_parts(S, G)
-    eng.pipeline = parts
+    setup = {}
+    cfg, model, batch, start, goals = build_workload(S, G, n, args.grid, seed0=seed0, share_grids=args.share_grids, num_objects=args.objects, timing=setup)
+    # The layout — latency mode, split goals, pipeline parts — follows ONE rule of the shape (ChompEngine.layout), evaluated on every
+    # rank for the same scene count (the largest shard), so that all shards of a job compute comparable bits
+    S_max = len(shard_range(args.total_scenes, 0, world)) if strong else S
+    layout_scenes = args.layout_scenes if args.layout_scenes > 0 else S_max
+    t_init = time.perf_counter()
+    eng = ChompEngine.auto(model, batch, copy.deepcopy(cfg), start, goals, layout_scenes=layout_scenes, device=dev, ol_alg=args.ol_alg)
+    if args.goal_parts > 0 and not eng.latency and args.goal_parts != eng.goal_parts:
+        eng = ChompEngine(model, batch, copy.deepcopy(cfg), start, goals, device=dev, ol_alg=args.ol_alg, goal_parts=args.goal_parts)
+        eng.pipeline = ChompEngine.layout(layout_scenes, G, n)["pipeline"]
+        eng.layout_used = {"latency_mode": False, "goal_parts": args.goal_parts, "pipeline": eng.pipeline}
+    torch.cuda.synchronize()
+    setup["engine_init_ms"] = (time.perf_counter() - t_init) * 1e3  # uploads (records, SDF pool, goals) + allocations
+    # the engine's software pipeline: the rank's scenes as independent parts on their own streams — their launches run concurrently
+    # and pack ramp-ups and tails into less time than one launch after the other; same results bit for bit
+    if args.pipeline > 0 and not eng.latency:
+        eng.pipeline = min(args.pipeline, S)
+    parts = 1 if eng.latency else max(1, int(eng.pipeline or 1))
+    layout = dict(eng.layout_used, pipeline=parts, evaluated_for_scenes=layout_scenes)
     lib = _lib.lib()
 
     # The workload must not drift with the number of steps: a trajectory that has been optimised for hundreds of iterations
@@ -237,26 +340,43 @@ def main():
     # 1.7 % of the step time, a fifth 0.3 %); an odd stride, so that the samples alternate between the pipeline's parts
     stride = 5 if args.steps * parts >= 25 else 1  # a very short run still gets its launches timed
     lib.omgx_timing_enable(stride)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    costs = eng.final_costs()  # enqueued behind the last step: no host sync before the collective
-    allc = gather(costs)
-    assert allc.numel() == total_scenes
-    barrier()
-    elapsed = time.perf_counter() - t0
+
+    def region():
+        """EXACTLY --steps steps + the job's one collective, bracketed by barrier + synchronize on both sides; -> (this rank's
+        seconds, MAX over ranks)."""
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        costs = eng.final_costs()  # enqueued behind the last step: no host sync before the collective
+        allc = gather(costs)
+        assert allc.numel() == total_scenes
+        barrier()
+        el = time.perf_counter() - t0
+        mx = el
+        if dist_on:
+            import torch.distributed as dist
+            tmax = torch.tensor([el], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            mx = float(tmax.item())
+        return el, mx, allc
+
+    # A region of the driver's size (20 steps of ~0.2 ms) is a few milliseconds: one such interval says little.  When the first
+    # region is shorter than 50 ms, four more of the same --steps are timed and ms_per_step is the MEDIAN region (the spread is
+    # reported beside it); `steps` stays what was asked for.
+    first = region()
+    n_regions = args.regions if args.regions > 0 else (5 if first[1] < 0.050 else 1)
+    regs = [first] + [region() for _ in range(n_regions - 1)]
+    order = sorted(range(len(regs)), key=lambda i: regs[i][1])
+    mid = order[len(order) // 2]
+    elapsed_local, elapsed, allc = regs[mid]
+    region_ms = [r[1] / args.steps * 1e3 for r in regs]
     if args.dump_costs and rank == 0:
-        np.save(args.dump_costs, allc.cpu().numpy())
+        np.save(args.dump_costs, regs[0][2].cpu().numpy())  # the FIRST region's costs: which region is the median depends on the clock
     buf = (C.c_float * 4096)()
     kinds = (C.c_int32 * 4096)()
     nrec = lib.omgx_timing_collect(buf, kinds, 4096)
     lib.omgx_timing_enable(0)
-    elapsed_local = elapsed
-    if dist_on:
-        import torch.distributed as dist
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
 
     # every rank's own roofline block: its launch durations (HIP events), its scenes, its wall time — gathered so that an N-GPU
     # line carries the achieved rates per GPU (north_star: "achieved ... vs roofline reported at 1/2/4/8")
@@ -292,10 +412,14 @@ def main():
         parity = engine_vs_oracle(eng, batch, sorted({0, S // 2, S - 1}), steps=3, pin_window=True)
 
     ms_per_plan = ms_plan_early = ms_single = ms_single_batch_layout = terminated = ms_graph_early = ms_graph_single = None
+    share4 = scene_upd = None
+    if not args.no_plan and rank == 0 and world == 1:
+        share4 = rank_share_config4(dev, args.ol_alg)
+        scene_upd = scene_update_timing(dev, cfg, model, batch, start, goals, args.ol_alg)
     if not args.no_plan and rank == 0:
         ms_per_plan = float("inf")
         for _ in range(2):  # best of 2: the first plan pays one-off costs (code-object load of the 30 window sizes)
-            eng2 = ChompEngine(model, batch, copy.deepcopy(cfg), start, goals, device=dev, ol_alg=args.ol_alg)
+            eng2 = ChompEngine.auto(model, batch, copy.deepcopy(cfg), start, goals, layout_scenes=layout_scenes, device=dev, ol_alg=args.ol_alg)
             torch.cuda.synchronize()
             tp = time.perf_counter()
             eng2.plan(early_stop=False)
@@ -304,7 +428,7 @@ def main():
             del eng2
         # the same plan as the reference runs it: a scene that terminates leaves the loop (planner.py:626) — its goal-set
         # batch, goal update and step are skipped from then on (active mask)
-        eng3 = ChompEngine(model, batch, copy.deepcopy(cfg), start, goals, device=dev, ol_alg=args.ol_alg)
+        eng3 = ChompEngine.auto(model, batch, copy.deepcopy(cfg), start, goals, layout_scenes=layout_scenes, device=dev, ol_alg=args.ol_alg)
         torch.cuda.synchronize()
         tp = time.perf_counter()
         eng3.plan(early_stop=True)
@@ -346,7 +470,7 @@ def main():
                 torch.cuda.synchronize()
                 best = min(best, (time.perf_counter() - tp_) * 1e3)
             return best
-        ms_graph_early = graph_ms(ChompEngine(model, batch, copy.deepcopy(cfg), start, goals, device=dev, ol_alg=args.ol_alg))
+        ms_graph_early = graph_ms(ChompEngine.auto(model, batch, copy.deepcopy(cfg), start, goals, layout_scenes=layout_scenes, device=dev, ol_alg=args.ol_alg))
         ms_graph_single = graph_ms(ChompEngine(model, one, copy.deepcopy(cfg), start[:1], goals[:1], device=dev, ol_alg=args.ol_alg, latency_mode=True))
 
     if rank == 0:
@@ -363,6 +487,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step_spread": [min(region_ms), max(region_ms)],  # over the timed regions of --steps steps each; ms_per_step / value = the median region
+            "regions": len(region_ms),
             "higher_is_better": True,
             "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
@@ -373,13 +499,21 @@ def main():
                        "scenes_per_gpu": S, "total_scenes": total_scenes, "goals": G, "waypoints": n, "objects_per_scene": O_active,
                        "sdf_grid": f"{args.objects}x{args.grid}^3 + 128x96x32 per scene, {'shared' if args.share_grids else 'private'}",
                        "goal_selection": f"{args.ol_alg} on device (omgx_goal_update_optimize)", "launches_per_iteration": 2 * parts,
-                       "pipeline_parts": parts,
+                       "pipeline_parts": parts, "layout": layout,
                        "top_k_collision": cfg.top_k_collision, "plan_restart_every_steps": cfg.optim_steps},
             "roofline": roof,
         }
         if parity is not None:
             out["parity_sample"] = parity
+        out["setup_ms"] = dict(setup, what="host: scenes.pack_table (records, pool, fitted influence regions) / engine_init: uploads + allocations; once per batch, outside the timed regions")
+        if share4 is not None:
+            out["ms_per_step_rank_share_config4"] = share4[0]  # 13 scenes x 128 goals on this GPU: one rank's share of BASELINE config 4 on 8 GPUs
+            out["rank_share_config4_layout"] = share4[1]
+        if scene_upd is not None:
+            out["scene_update_ms"] = scene_upd["scene_update_ms"]
+            out["scene_update"] = scene_upd
         if ms_per_plan is not None:
+            out["plan_timing_version"] = 2  # since round 3: single-scene plans on a WARM engine restored from a snapshot, best of 3 (round 1-2: first plan of a fresh batch-layout engine); round 4: the batch's engines laid out by ChompEngine.layout
             out["ms_per_plan"] = ms_per_plan  # Planner.plan for all scenes of rank 0: initial goal pick + 50 + 20 iterations + final info
             out["ms_per_plan_per_scene"] = ms_per_plan / S
             out["ms_per_plan_early_stop"] = ms_plan_early  # with the reference's break on `terminate` (informational)
