@@ -1461,8 +1461,9 @@ def test_bench_multi_rank_costs_equal_single_process(tmp_path):
               "--no-parity"]
     env = dict(os.environ, OMGX_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     one, two = tmp_path / "one.npy", tmp_path / "two.npy"
-    r1 = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "1", *common, "--dump-costs", str(one)], env=env, capture_output=True,
-                        text=True, timeout=600)
+    # (--layout-scenes 3: the single process lays its engine out like a rank of the 2-rank job, see ChompEngine.layout)
+    r1 = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "1", *common, "--layout-scenes", "3", "--dump-costs", str(one)], env=env,
+                        capture_output=True, text=True, timeout=600)
     assert r1.returncode == 0, r1.stderr[-2000:]
     port = 29500 + os.getpid() % 2000
     r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
@@ -1475,3 +1476,40 @@ def test_bench_multi_rank_costs_equal_single_process(tmp_path):
     import json
     j = json.loads(line)
     assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["config"]["total_scenes"] == 6
+
+
+def test_bench_two_ranks_on_the_config4_share_shape(tmp_path):
+    """BASELINE config 4's per-rank shape: 25 scenes x 128 goals over 2 ranks = shards of 13 + 12 scenes (what ranks of the
+    8-GPU job hold), launched by torch.distributed.run with 2 ranks on the one GPU over gloo.  Every rank picks its layout from
+    the LARGEST shard (ChompEngine.layout(13, 128)), so the two shards — and the single-process run told the same number — compute
+    the same bits: gathered per-scene costs bit-identical; the line carries a complete per-rank roofline list."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = Path(__file__).resolve().parents[1]
+    common = ["--total-scenes", "25", "--goals", "128", "--steps", "6", "--warmup", "2", "--no-plan", "--no-cpu-baseline", "--no-parity"]
+    env = dict(os.environ, OMGX_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    one, two = tmp_path / "one.npy", tmp_path / "two.npy"
+    r1 = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "1", *common, "--layout-scenes", "13", "--dump-costs", str(one)], env=env,
+                        capture_output=True, text=True, timeout=900)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    port = 31500 + os.getpid() % 2000
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                         "--master-port", str(port), str(root / "bench.py"), "--gpus", "2", *common, "--dump-costs", str(two)], env=env,
+                        capture_output=True, text=True, timeout=900)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    a, b = np.load(one), np.load(two)
+    assert a.shape == (25,) and np.isfinite(a).all() and np.array_equal(a, b), (a, b)
+    j1 = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][-1])
+    j = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["config"]["total_scenes"] == 25 and j["steps"] == 6
+    assert j["config"]["layout"]["evaluated_for_scenes"] == 13 and j1["config"]["layout"]["evaluated_for_scenes"] == 13
+    assert j["config"]["layout"]["goal_parts"] == j1["config"]["layout"]["goal_parts"]
+    pr = j["roofline"]["per_rank"]
+    assert [r["rank"] for r in pr] == [0, 1] and [r["scenes"] for r in pr] == [13, 12]
+    for r in pr:
+        assert set(r) >= {"rank", "scenes", "ms_per_step", "avg_launch_ms", "launches", "achieved", "frac", "hbm_GBs", "algorithmic_equiv_GBs"}
+        # (achieved / frac need the instruction counts of profiles/roofline_inputs.json, which are for the 100 x 64 workload: None here)
+        assert r["launches"] > 0 and r["avg_launch_ms"] > 0 and r["ms_per_step"] > 0 and r["algorithmic_equiv_GBs"] > 0
+    assert "cpu_baseline" not in j  # an N = 1 field
