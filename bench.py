@@ -305,6 +305,9 @@ def main():
         eng.pipeline = min(args.pipeline, S)
     parts = 1 if eng.latency else max(1, int(eng.pipeline or 1))
     layout = dict(eng.layout_used, pipeline=parts, evaluated_for_scenes=layout_scenes)
+    # the step is an iteration INSIDE a plan: like plan() itself, the launches hand link poses to each other (the start's and the
+    # goals' poses tabulated once, the waypoints' poses left by the layer workgroups) instead of running the same kinematics again
+    eng.pose_hand_over(True)
     lib = _lib.lib()
 
     # The workload must not drift with the number of steps: a trajectory that has been optimised for hundreds of iterations

@@ -136,14 +136,14 @@ class ChompEngine:
     # per-scene tensors: a part of the pipeline works on the rows [lo, hi) of each
     _PART_TENSORS = ("start", "goal_set", "reach", "cv_goals", "goal_idx", "goal_count", "eta_s", "traj", "end", "goal_rows", "goal_point",
                      "pot", "pgrad", "col", "grad", "cost_traj", "info", "goal_cost", "goal_col", "learner_state", "cost_vec", "_active",
-                     "_scene_flags")
+                     "_scene_flags", "wp_pose", "start_pose", "end_pose", "goal_pose_tab")
 
     # Latency mode (ChompEngine(latency_mode=True); omgx_goalset_cost_layer_tiled): a goal's tiles dealt over up to LAT_GOAL_PARTS
     # workgroups, the trajectory layer in LAT_LAYER_LINK_GROUPS x ceil(n / LAT_LAYER_BLOCK) workgroups, all spread over the XCDs.
     LAT_GOAL_PARTS = 4
     LAT_LAYER_LINK_GROUPS = 10
     LAT_LAYER_BLOCK = 4   # one link x 4 waypoints per layer workgroup: its four waves take the objects side by side
-    LAT_HAND_OVER_POSES = True  # inside plan(): link poses handed between the launches (False: every kernel runs its own kinematics; same bits)
+    LAT_HAND_OVER_POSES = True  # inside plan(), both layouts: link poses handed between the launches (False: every kernel runs its own kinematics; same bits)
 
     def __init__(self, model: PandaModel, batch: SceneBatch, cfg: Config, start: np.ndarray, goal_set: np.ndarray,
                  reach_grasps: np.ndarray | None = None, traj_init: np.ndarray | None = None, device="cuda:0",
@@ -224,12 +224,10 @@ class ChompEngine:
         # latency mode, inside plan(): link poses handed between the launches instead of being recomputed (omgx_pose_table, ABI 7)
         # — the waypoints' poses from the layer workgroups to the step, the start's and the goals' poses tabulated per plan
         self._poses_on = False
-        if self.latency:
-            self.wp_pose = torch.empty((S, n, 10, 12), **f64)
-            self.start_pose = torch.empty((S, 10, 12), **f64)
-            self.end_pose = torch.zeros((S, 10, 12), **f64)
-            self.goal_pose_tab = torch.empty((S, G, 10, 12), **f64)
-            self._STATE = ChompEngine._STATE + ("end_pose",)
+        self.wp_pose = torch.empty((S, n, 10, 12), **f64)
+        self.start_pose = torch.empty((S, 10, 12), **f64)
+        self.end_pose = torch.zeros((S, 10, 12), **f64)
+        self.goal_pose_tab = torch.empty((S, G, 10, 12), **f64)
         self.goal_cost = torch.zeros((S, G * self._parts_max), **f32)
         self.goal_col = torch.zeros((S, G * self._parts_max), **f32)
         self.learner_state = ops.learner_state(S, G, dev, goal_counts)  # sum_costs | p | experts_p | q | experts_costs
@@ -361,6 +359,17 @@ class ChompEngine:
         ar = torch.arange(self.S, device=self.device)
         torch.index_select(self.goal_pose_tab.view(self.S * self.G, 120), 0, ar * self.G + self.goal_idx.long(), out=self.end_pose.view(self.S, 120))
 
+    def pose_hand_over(self, on: bool = True):
+        """Outside plan() (bench.py's step, callers that drive iterate() themselves): switch the hand-over of link poses between
+        the launches on or off.  On: the start's and all goals' poses are tabulated now (two small launches) — valid while start,
+        goal_set and goal_idx are only changed by the engine's own launches or restore(); every result keeps its bits."""
+        self.join()
+        if on and not self.separate_launches:
+            self._refresh_pose_tables()
+            self._poses_on = True
+        else:
+            self._poses_on = False
+
     def _tiling(self):
         return (self.LAT_GOAL_PARTS, self.LAT_LAYER_LINK_GROUPS, self.LAT_LAYER_BLOCK, 1)
 
@@ -451,7 +460,7 @@ class ChompEngine:
                 part.stream.wait_stream(cur)
             self._forked = True
         for part in parts:
-            part.t, part.step_count, part._masked = self.t, self.step_count, self._masked
+            part.t, part.step_count, part._masked, part._poses_on = self.t, self.step_count, self._masked, self._poses_on
             for f in self._CFG_SCHEDULE:
                 setattr(part.cfg, f, getattr(self.cfg, f))
             part.iterate(t, early_stop)
@@ -521,7 +530,7 @@ class ChompEngine:
                                        layer_soften_fingers=self.cfg.uncheck_finger_collision == -1,
                                        out=(self.goal_cost, self.goal_col), active=self._mask(), goal_count=self.goal_count,
                                        schedule=self.schedule if use_sched else None, work=self.work[: self.S * self.G * NP] if measure else None,
-                                       goal_parts=self.goal_parts)
+                                       goal_parts=self.goal_parts, layer_poses=self.wp_pose if self._poses_on else None)
                 if measure:
                     self._measured = True
                     self.schedule = self.build_schedule(parts=NP)
@@ -599,6 +608,11 @@ class ChompEngine:
                                          layer_link_groups=self.LAT_LAYER_LINK_GROUPS,
                                          layer_config_block=self.LAT_LAYER_BLOCK, spread=True,
                                          layer_poses=self.wp_pose if self._poses_on else None)
+            return
+        if self._poses_on:  # the same five layer workgroups per scene as omgx_fk_sdf launches, leaving the waypoints' poses for the step
+            ops.goalset_cost_layer_tiled(self.robot, self.P, self.scenes, None, None, 1, self.cfg.time_interval, self.traj,
+                                         (self.pot, self.pgrad, self.col), None, layer_soften_fingers=self.cfg.uncheck_finger_collision == -1,
+                                         goal_parts=1, layer_link_groups=5, layer_config_block=0, spread=False, layer_poses=self.wp_pose)
             return
         ops.fk_sdf(self.robot, self.P, self.scenes, self.traj, soften_fingers=self.cfg.uncheck_finger_collision == -1,
                    out=(self.pot, self.pgrad, self.col))
@@ -699,7 +713,7 @@ class ChompEngine:
                                        (self.grad, self.cost_traj, self.info), self.cost_vec, self._active, self.goal_count, self.eta_s,
                                        self._scene_flags, layer_soften_fingers=self.cfg.uncheck_finger_collision == -1,
                                        tiling=self._tiling() if self.latency else None,
-                                       layer_poses=self.wp_pose if self.latency else None, goal_parts=self.goal_parts)
+                                       layer_poses=self.wp_pose, goal_parts=self.goal_parts)
             hot = self._hot = (key, calls, baked)
         calls = hot[1]
         stream = (self.stream if self.stream is not None else torch.cuda.current_stream(self.device)).cuda_stream
@@ -707,7 +721,7 @@ class ChompEngine:
         prm = self._learner_params()
         self._gs_launches += 1
         self._parts_last = max(1, int(prm.cost_parts))
-        calls.use_layer_poses = self._poses_on and self.latency
+        calls.use_layer_poses = self._poses_on
         calls.goalset_layer(prm.start_idx, self._masked, self.schedule if use_sched else None, None, stream)
         self._schedule()
         split = 2 * self.S <= self._num_cus if self.split_update is None else bool(self.split_update)
@@ -731,7 +745,7 @@ class ChompEngine:
 
     # ---------------------------------------------------------------------------------------------
     _STATE = ("traj", "end", "goal_rows", "goal_point", "goal_idx", "learner_state", "info", "active", "goal_cost", "goal_col",
-              "cost_vec", "grad", "cost_traj", "pot", "pgrad", "col")
+              "cost_vec", "grad", "cost_traj", "pot", "pgrad", "col", "end_pose")
 
     def snapshot(self) -> dict:
         """Everything a plan mutates (device tensors cloned + the host-side counters): restore() brings the engine back to
@@ -820,7 +834,7 @@ class ChompEngine:
         cfg = self.cfg
         if initial_goal and cfg.goal_set_proj:
             self.select_initial_goal()
-        if self.latency and self.LAT_HAND_OVER_POSES and not self.separate_launches:
+        if self.LAT_HAND_OVER_POSES and not self.separate_launches:
             self._refresh_pose_tables()
             self._poses_on = True
         self.iterations_run = 0

@@ -160,3 +160,35 @@ def test_split_plan_pipelined_equals_unpipelined_and_its_graph(dev, early):
 def ChompEngineParts(S, G):
     from omg_planner_amd.engine import ChompEngine
     return ChompEngine.auto_parts(S, G)
+
+
+@pytest.mark.parametrize("goal_parts,alg,split,pipe", [(1, "MD", None, None), (2, "FTL", False, 1), (1, "Exp", True, 2), (4, "MD", None, 2)])
+def test_pose_hand_over_in_the_batch_layout_changes_no_bit(dev, goal_parts, alg, split, pipe, monkeypatch):
+    """plan() hands link poses between its launches in the batch layout too (since round 4): the layer workgroups' waypoint poses
+    to the step, the tabulated start / goal poses to the learner and the step — every result bit for bit what the kernels
+    compute on their own; learner and step in two workgroups or in one, pipelined or not, early stop, ragged goal sets."""
+    from omg_planner_amd.engine import ChompEngine
+    counts = np.array([16, 9, 12, 16, 5])
+    out = []
+    for on in (True, False):
+        monkeypatch.setattr(ChompEngine, "LAT_HAND_OVER_POSES", on)
+        e, _ = _make(dev, 5, 16, goal_parts, counts, alg=alg)
+        e.split_update, e.pipeline = split, pipe
+        e.plan(early_stop=True)
+        torch.cuda.synchronize()
+        assert not e._poses_on
+        out.append({k: getattr(e, k).cpu().numpy().copy() for k in ("traj", "info", "goal_idx", "learner_state", "grad", "cost_traj", "end", "goal_rows", "pot", "col")})
+        out[-1]["active"] = e.active.cpu().numpy().copy()
+    for k in out[0]:
+        assert np.array_equal(out[0][k], out[1][k], equal_nan=True), k
+    # outside plan(): the switch bench.py uses around its steps
+    a, _ = _make(dev, 3, 16, goal_parts, alg=alg)
+    b, _ = _make(dev, 3, 16, goal_parts, alg=alg)
+    a.pose_hand_over(True)
+    for t in (0, 1, 2, 30):
+        for e in (a, b):
+            e.t = t
+            e.iterate(t)
+    torch.cuda.synchronize()
+    for k in ("traj", "info", "goal_idx", "learner_state", "grad"):
+        assert np.array_equal(getattr(a, k).cpu().numpy(), getattr(b, k).cpu().numpy(), equal_nan=True), k
