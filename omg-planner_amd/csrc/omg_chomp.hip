@@ -218,32 +218,31 @@ __device__ __forceinline__ double ainv_entry(int i, int k, int n, bool free_end,
     return free_end ? dt2 * (double)(lo + 1) : dt2 * (double)(lo + 1) * (double)(n - hi) / (double)(n + 1);
 }
 
-// out[i][d] = sum_k Ainv[i][k] in[k][d]   (cfg.Ainv.dot(.), optimizer.py:109,132,156) as two running sums per column instead of n terms
-// per element (O(n) instead of O(n^2): 4.0 K of the step's 64 K cycles at 30 waypoints, four times that at 64):
+// out[i][d] = sum_k Ainv[i][k] in[k][d]   (cfg.Ainv.dot(.), optimizer.py:109,132,156) with the closed-form entries factored:
 //   sum_k Ainv[i][k] x_k = c [ u_i sum_(k<=i) (k + 1) x_k  +  (i + 1) sum_(k>i) w_k x_k ]
 //   free end : u_i = 1,     w_k = 1,     c = dt^2              (Ainv[i][k] = dt^2 (min + 1))
 //   fixed end: u_i = n - i, w_k = n - k, c = dt^2 / (n + 1)    (Ainv[i][k] = dt^2 (min + 1)(n - max) / (n + 1))
-// The prefix runs forward, the suffix backward (no difference of large sums), one lane per (column, direction), each in a fixed
-// order.  Another association of the same sum than the dense product: ~1e-16 relative (fixture tolerances: 1e-9).
-// scr: 2 n 9 doubles of LDS scratch.  Two barriers inside: call from all threads.
-__device__ __forceinline__ void apply_ainv(const double* in, double* out, double* scr, int n, bool free_end, double dt2) {
-    const int tid = threadIdx.x;
-    if (tid < 18) {
-        const int d = tid % 9;
-        double acc = 0.0;
-        if (tid < 9) {
-            for (int i = 0; i < n; ++i) { acc += (double)(i + 1) * in[i * 9 + d]; scr[i * 9 + d] = acc; }
-        } else {
-            double* suf = scr + n * 9;
-            for (int i = n - 1; i >= 0; --i) { suf[i * 9 + d] = acc; acc += (free_end ? 1.0 : (double)(n - i)) * in[i * 9 + d]; }
-        }
-    }
-    __syncthreads();
+// One thread per element, its two sums in ascending k: per term one conversion and one multiply-add instead of the ~10 instructions
+// of the entry's closed form (min / max, two conversions, a division for the fixed end), and the LDS reads of a column are independent
+// of the arithmetic (4.0 K -> of the step's 64 K cycles at 30 waypoints).  Another association of the same sum than the dense product:
+// ~1e-16 relative (fixture tolerances: 1e-9).  (Running sums per column — O(n) — were tried first: 18 serial lanes, each step a dependent
+// LDS round trip: 6.2 K cycles, slower than the dense product.)
+__device__ __forceinline__ void apply_ainv(const double* __restrict__ in, double* __restrict__ out, int n, bool free_end, double dt2) {
     const double c = free_end ? dt2 : dt2 / (double)(n + 1);
-    for (int e = tid; e < n * 9; e += blockDim.x) {
-        const int i = e / 9;
-        const double u = free_end ? 1.0 : (double)(n - i);
-        out[e] = c * (u * scr[e] + (double)(i + 1) * scr[n * 9 + e]);
+    for (int e = threadIdx.x; e < n * 9; e += blockDim.x) {
+        const int i = e / 9, d = e - 9 * i;
+        const double* col = in + d;
+        double pre = 0.0, suf = 0.0;
+#pragma unroll 4
+        for (int k = 0; k <= i; ++k) pre += (double)(k + 1) * col[9 * k];
+        if (free_end) {
+#pragma unroll 4
+            for (int k = i + 1; k < n; ++k) suf += col[9 * k];
+        } else {
+#pragma unroll 4
+            for (int k = i + 1; k < n; ++k) suf += (double)(n - k) * col[9 * k];
+        }
+        out[e] = c * ((free_end ? 1.0 : (double)(n - i)) * pre + (double)(i + 1) * suf);
     }
 }
 
@@ -468,6 +467,7 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
     const int mlinks = topk_mode ? (prm.consider_finger ? 10 : 8) : 10;  // cost.py:401-404
     const int i_defer = wait_goal ? n - 1 : n;  // waypoints >= i_defer need the end pose (acceleration): second pass
     double* const goalc = reinterpret_cast<double*>(L.hist);  // [9 + c * 9] goal point | goal rows; the histogram is dead after phase 1 (c <= 8: 81 of its 128 doubles)
+    double* const limc = goalc + 96;                          // [18] joint limits (lower | upper): LDS reads in the totals and the limit loop instead of global loads
     auto phase2_item = [&](const int it, const bool second_pass) {
         const bool inb = it < nitems;
         const int p = it & 15, grp = it >> 4, l = grp % 10, i = grp / 10;
@@ -558,6 +558,26 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
     // then served by 8 lanes each, lane k -> joint slot k, instead of one lane walking the 8 slots of its group (a chain of
     // ~200 dependent LDS reads: 13 K of the step's 68 K cycles).  Same arithmetic per element, same bits.
     auto winners_gradients = [&](const int g_begin, const int g_end) {  // two barriers inside: call from all threads
+        if ((g_end - g_begin) * 8 <= (int)blockDim.x) {
+            // a range that fits the workgroup at 8 lanes per group (the last waypoint's ten groups, after the goal has arrived): no
+            // compaction — the same element by the same arithmetic, without the counter and its two barriers
+            const int grp = g_begin + (tid >> 3), k = tid & 7;
+            if (grp < g_end) {
+                const int p = L.gwin[grp];
+                double val = 0.0;
+                if (p >= 0) {
+                    const int l = grp % 10, i = grp / 10;
+                    const int f = (i * 10 + l) * P + p;
+                    double x[3], v[3], acc[3], g[3];
+                    point_kinematics(L, i, l, p, P, dt, x, v, acc);
+                    const double dc[3] = {(double)pgrad[3 * f], (double)pgrad[3 * f + 1], (double)pgrad[3 * f + 2]};
+                    functional_g(v, acc, (double)(L.potl ? L.potl[(grp << 4) + p] : pot[f]), dc, g);
+                    val = k < njoints(l) ? jacobian_dot(L, i, l, k, x, g) : 0.0;
+                }
+                L.gl[(size_t)grp * 8 + k] = val;
+            }
+            return;
+        }
         if (tid == 0) L.iscr[3] = 0;
         __syncthreads();
         for (int grp = g_begin + tid; grp < g_end; grp += blockDim.x) {
@@ -664,6 +684,7 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
             const int e = tid - 128;
             goalc[e] = e < 9 ? a.goal_point[9 * (size_t)s + e] : a.goal[(size_t)s * c * 9 + (e - 9)];
         }
+        if (tid >= 256 && tid < 256 + 18) limc[tid - 256] = tid < 265 ? rv.lower()[tid - 256] : rv.upper()[tid - 265];
         if (end_pose_fits(n)) {  // the learner's workgroup has left the end configuration's poses in this scene's grad rows
             const double* src = a.grad + (size_t)s * n * 9;
             for (int e = tid; e < 120; e += blockDim.x) L.pose[(size_t)(ncfg - 1) * 120 + e] = src[e];
@@ -688,6 +709,7 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
         const int e = tid - 128;
         goalc[e] = e < 9 ? a.goal_point[9 * (size_t)s + e] : a.goal[(size_t)s * c * 9 + (e - 9)];
     }
+    if (!wait_goal && tid >= 256 && tid < 256 + 18) limc[tid - 256] = tid < 265 ? rv.lower()[tid - 256] : rv.upper()[tid - 265];
     if (wait_goal) {  // only what the goal-dependent passes above produced is still missing
         obstacle_rows(i_defer * 9, n * 9);
         if (!free_end) smooth_terms();
@@ -713,8 +735,8 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
         a.grad[(size_t)s * n * 9 + e] = gt;
     }
     // check_joint_limit (optimizer.py:166-174): flags only when a low AND a high violation exist
-    const double* lower = rv.lower();
-    const double* upper = rv.upper();
+    const double* lower = limc;
+    const double* upper = limc + 9;
     {
         bool lowv = false, highv = false;
         for (int e = tid; e < n * 9; e += blockDim.x) {
@@ -829,7 +851,7 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
     // ---------------------------------------------------------------- phase 6: covariant (projected) step
     PHASE_MARK(6);
     __syncthreads();
-    apply_ainv(L.g, L.tvs, L.gl, n, free_end, dt2);  // Ag = Ainv g (L.gl: dead since the obstacle-gradient rows were formed)
+    apply_ainv(L.g, L.tvs, n, free_end, dt2);  // Ag = Ainv g
     __syncthreads();
     PHASE_MARK_T(15, 0);
     const double eta = prm.step_size;
@@ -874,7 +896,7 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
         }
         const double nrm2 = block_sum(L, L.g, n * 9, 5);
         if (!(sqrt(nrm2) > 1e-2) || cnt >= prm.joint_limit_max_steps) break;
-        apply_ainv(L.tv, L.tvs, L.gl, n, free_end, dt2);
+        apply_ainv(L.tv, L.tvs, n, free_end, dt2);
         __syncthreads();
         if (tid < 64) {  // np.abs(traj_v).argmax(): first maximum in flat order
             double best = -__builtin_inf();  // numpy order: first occurrence, NaN wins (omg::np_arg_better)

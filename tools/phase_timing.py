@@ -15,7 +15,8 @@ import torch
 
 import bench
 from omg_planner_amd import _lib
-_lib.LIB_PATH = Path(__file__).resolve().parents[1] / "omg-planner_amd" / "csrc" / "libomg_hip_pt.so"
+import os
+_lib.LIB_PATH = Path(__file__).resolve().parents[1] / "omg-planner_amd" / "csrc" / os.environ.get("OMGX_PT_LIB", "libomg_hip_pt.so")
 from omg_planner_amd.engine import ChompEngine
 
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 100
