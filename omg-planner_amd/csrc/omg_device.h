@@ -504,13 +504,15 @@ __device__ __forceinline__ void fk_joint_matrix(const RV& rv, int i, double s, d
     for (int k = 0; k < 9; ++k) B[k] = c * uvw[k] + s * uvw[9 + k] + uvw[18 + k];
 }
 
+// bstride: doubles between the matrices of consecutive joints (9: a [7][9] table per configuration; the batch kernel keeps joint i's
+// matrices where link i's poses will be written: one link block apart).  Bt is NOT restrict there: f() overwrites what was read.
 template <class RV, class F>
-__device__ __forceinline__ void fk_chain_row_B(const RV& rv, int r, const double* __restrict__ Bt /* [7][9] */, double q7, double q8, F&& f) {
+__device__ __forceinline__ void fk_chain_row_B(const RV& rv, int r, const double* Bt /* [7][bstride] */, double q7, double q8, F&& f, int bstride = 9) {
 #pragma clang fp contract(fast)
     double a0 = r == 0 ? 1.0 : 0.0, a1 = r == 1 ? 1.0 : 0.0, a2 = r == 2 ? 1.0 : 0.0, at = 0.0;
 #pragma unroll 1
     for (int i = 0; i < 7; ++i) {
-        const double* B = Bt + 9 * i;
+        const double* B = Bt + bstride * i;
         const auto tp = rv.tp(i);
         const double n0 = a0 * B[0] + a1 * B[3] + a2 * B[6];
         const double n1 = a0 * B[1] + a1 * B[4] + a2 * B[7];

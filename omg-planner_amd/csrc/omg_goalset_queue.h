@@ -262,7 +262,18 @@ __global__ __launch_bounds__(256, LAT ? 2 : GQ_WG_PER_CU) void k_goalset_queue(C
         const int r = 4 * q + ((q & 1) ? 3 - wave : wave);             // rank by weight, heaviest = 0
         return r < ntp ? part + NP * (ntp - 1 - r) : -1;
     };
-    const int chain_waves = (3 * (CH + 1) + 63) >> 6;
+#ifndef OMGX_GS_BTAB_IN_PLACE
+#define OMGX_GS_BTAB_IN_PLACE 1  // batch kernel: the joints' matrices tabulated IN the pose array before the chain (see below)
+#endif
+    // Batch kernel: the chain's lanes are (configuration, pose row) with a configuration's three rows in ONE wave (21 configurations
+    // per wave) — joint i's matrix B_i = c U + s V + W of a configuration is tabulated beforehand (one lane per configuration, the
+    // joint wave-uniform: its 27 constants are scalar operands) into the 9 doubles that will hold link i's pose of that configuration,
+    // and the chain step reads it, multiplies (12 multiply-adds instead of 27 + 12 and 60 dwords of scalar loads per joint on the
+    // stage's critical wave) and writes the pose over it: a wave's LDS operations execute in order, so all three row lanes have read
+    // the matrix before any of them writes.  No extra LDS; same expressions, same bits (fk_joint_matrix).  (Requesting joint i + 1's
+    // matrix before the arithmetic of joint i and dropping the flag's release wait changed nothing: 4.2 us for the chain either way.)
+    constexpr bool BTAB = !LAT && OMGX_GS_BTAB_IN_PLACE != 0;
+    const int chain_waves = BTAB ? (CH + 1 + 20) / 21 : (3 * (CH + 1) + 63) >> 6;
     // Only while two waves are free and a link pair's rows fit one pass (CH <= 32): with 50 waypoints a single free wave walked the 10
     // links one pass each and the prologue got LONGER (0.49 instead of 0.41 ms per step at 50 waypoints: measured) — there all four
     // waves cull after the chain as before.  LAT: every wave culls the rows of its own tiles after the chain (below).
@@ -277,7 +288,7 @@ __global__ __launch_bounds__(256, LAT ? 2 : GQ_WG_PER_CU) void k_goalset_queue(C
         const int ncfg = CH + 1;
         double* sc = reinterpret_cast<double*>(lds_bytes + L.stage_off);  // [ncfg][7][2]: the queues' region, first used in the main loop
         int* const progress = reinterpret_cast<int*>(lds_bytes + L.stage_off + pstride * 14 * 8);  // [4] links a chain wave has published
-        if (tid < 4) progress[tid] = tid < chain_waves ? 0 : 99;
+        if (tid < 4) progress[tid] = (tid < chain_waves || (cull_beside_chain && tid == 3)) ? 0 : 99;  // [3]: the culling's pair counter when two waves are free
         // the robot's collision points -> LDS: the loads are issued here and land while the (sin, cos) stage runs
         const double pv0 = tid < 30 * P ? rv.g[246 + tid] : 0.0, pv1 = tid + 256 < 30 * P ? rv.g[246 + tid + 256] : 0.0;
         double* const fkc = reinterpret_cast<double*>(lds_bytes + L.fkc_off);  // LAT: the chain's constants, one coalesced load
@@ -331,14 +342,37 @@ __global__ __launch_bounds__(256, LAT ? 2 : GQ_WG_PER_CU) void k_goalset_queue(C
                     dst[6 + rr] = tr;
                 });
             }
+        } else if constexpr (BTAB) {
+            for (int j = wave; j < 7; j += 4)  // wave-uniform joint: U, V, W of the joint are scalar operands
+                for (int cfg = lane; cfg < ncfg; cfg += 64)
+                    fk_joint_matrix(rv, j, sc[2 * (cfg * 7 + j)], sc[2 * (cfg * 7 + j) + 1], lds_pose + ((size_t)j * pstride + cfg) * 9);
+            __syncthreads();
+            GS_WAVE_STAMP(4 + wave);
+            if (wave < chain_waves && lane < 63) {
+                const int cfg = 21 * wave + lane / 3, rr = lane - 3 * (lane / 3);
+                if (cfg < ncfg)
+                    fk_chain_row_B(rv, rr, lds_pose + (size_t)cfg * 9, joint(cfg, 7), joint(cfg, 8), [&](int l, double r0, double r1, double r2, double tr) {
+                        double* dst = lds_pose + ((size_t)l * pstride + cfg) * 9;  // rows 0 and 1 of R, then t
+                        if (rr < 2) { dst[3 * rr] = r0; dst[3 * rr + 1] = r1; dst[3 * rr + 2] = r2; }
+                        dst[6 + rr] = tr;
+                        if (lane == 0) __hip_atomic_store(progress + wave, l + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }, pstride * 9);
+                GS_WAVE_STAMP(6 + wave);  // (instrumented build: when this chain wave finished the chain; overwrites the entry stamps of waves 2, 3)
+            }
         } else run_chain(rv);                                          // constants through the scalar cache (warm in a batch)
-        if (cull_beside_chain && wave >= chain_waves) {
-            // a culling wave takes two consecutive links per pass when their rows fit one wave (CH <= 32: lanes 0-31 link l, lanes
-            // 32-63 link l + 1) — one link per pass left half the lanes idle and doubled the stage's wave-instructions
-            const bool two = CH <= 32;
-            const int lstep = two ? 2 : 1;
-            for (int l = (wave - chain_waves) * lstep; l < 10; l += (4 - chain_waves) * lstep) {
-                const int need = two ? l + 1 : l;  // the later link of the pair
+        if (cull_beside_chain) {
+            // The rows of a link PAIR fit one wave (CH <= 32: lanes 0-31 link l, lanes 32-63 link l + 1).  The five pairs are claimed
+            // from a counter in LDS, in order: the waves that do not run the chain start at once (a pair is culled as soon as every
+            // chain wave has published its later link), the chain waves join when they are done — two waves walking 3 + 2 passes were
+            // the longest thing in the prologue (8 us beside a 4 us chain: tools/gs_wave_clock.py).  Who culls a row does not change
+            // its mask.
+            int* const next_pair = progress + 3;  // (chain_waves <= 2 here: the word is no progress flag)
+            for (;;) {
+                int pr = 0;
+                if (lane == 0) pr = __hip_atomic_fetch_add(next_pair, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                pr = __builtin_amdgcn_readfirstlane(pr);
+                if (pr >= 5) break;
+                const int l = 2 * pr, need = l + 1;  // the later link of the pair
                 for (;;) {  // every lane reads the same words: broadcast
                     int done = 99;
                     for (int w = 0; w < chain_waves; ++w) {
@@ -348,10 +382,10 @@ __global__ __launch_bounds__(256, LAT ? 2 : GQ_WG_PER_CU) void k_goalset_queue(C
                     if (done > need) break;
                     __builtin_amdgcn_s_sleep(4);
                 }
-                if (two) { if ((lane & 31) < CH) cull_row(l + (lane >> 5), lane & 31); }
-                else for (int ci = lane; ci < CH; ci += 64) cull_row(l, ci);
+                if ((lane & 31) < CH) cull_row(l + (lane >> 5), lane & 31);
             }
         }
+        GS_WAVE_STAMP(wave);
     }
     __syncthreads();
     GS_WG_STAMP(2);

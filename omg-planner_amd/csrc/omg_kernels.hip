@@ -555,6 +555,12 @@ __device__ __forceinline__ void waypoint_layer_block(const ChunkArgs& a, const i
 #ifdef OMGX_GS_CLOCK
 __device__ unsigned long long g_gs_wg[1 << 16][8];
 #define GS_WG_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < (1u << 16)) { g_gs_wg[blockIdx.x][k] = wall_clock64(); if (k == 0) { g_gs_wg[blockIdx.x][5] = ~0ull; g_gs_wg[blockIdx.x][6] = 0ull; unsigned hw, xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); g_gs_wg[blockIdx.x][7] = ((unsigned long long)xcc << 32) | hw; } } } while (0)
+__device__ unsigned long long g_gs_wave[1 << 16][8];  // per wave: [w] when wave w finished its part of the chain / culling stage; [4 + w] when it entered it
+#define GS_WAVE_STAMP(k) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < (1u << 16)) g_gs_wave[blockIdx.x][k] = wall_clock64(); } while (0)
+extern "C" int omgx_debug_gs_wave(unsigned long long* h_out, int n_wg) {
+    if (n_wg > (1 << 16)) n_wg = 1 << 16;
+    return hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_gs_wave), sizeof(unsigned long long) * 8 * n_wg) == hipSuccess ? 0 : -2;
+}
 // shader-clock cycles and 100 MHz ticks a goal workgroup lived: their ratio is the clock the CUs really ran at under this load
 __device__ unsigned long long g_gs_freq[1 << 16][2];
 #define GS_FREQ_BEGIN() unsigned long long gs_f0 = 0, gs_f1 = 0; if (threadIdx.x == 0) { gs_f0 = __builtin_readcyclecounter(); gs_f1 = wall_clock64(); }
@@ -569,6 +575,7 @@ extern "C" int omgx_debug_gs_wg(unsigned long long* h_out, int n_wg) {
 }
 #else
 #define GS_WG_STAMP(k)
+#define GS_WAVE_STAMP(k)
 #define GS_FREQ_BEGIN()
 #define GS_FREQ_END()
 #endif
