@@ -416,7 +416,14 @@ __global__ __launch_bounds__(256, LAT ? 2 : GQ_WG_PER_CU) void k_goalset_queue(C
     float f_fx = 0.0f, f_fy = 0.0f, f_fz = 0.0f, f_w = 0.0f;
     uint32_t f_meta = 0u;  // object index | soft << 16 | in_c << 30 | valid << 31
     bool inflight = false;
-    float tsum = 0.0f, tcol = 0.0f;
+    // A goal's cost is the sum of pot * weight (a float32 product, as before) over its pairs — accumulated EXACTLY: every term is
+    // rounded to the grid 2^-36 (far below the float32 resolution of any cost that matters: |term| < 2^15) and added in float64,
+    // where sums of grid multiples below 2^16 are exact.  The sum therefore does not depend on the order of its terms: whatever
+    // the queue order, the tile assignment, the number of workgroups a goal is split over or the dispatch schedule, the workgroup's
+    // sum is the same number, rounded to float32 once at the end (the oracle's bar: 1e-5 relative).
+    double tsum = 0.0;
+    float tcol = 0.0f;
+    auto add_term = [&](float term) { const double C = 98304.0; /* 1.5 * 2^16: (x + C) - C rounds x to a multiple of 2^-36 */ tsum += ((double)term + C) - C; };
 
     // CONSUME: finish the batch in flight (interpolation, hinge, weighted sums).  f_w is 0 for lanes without an entry.
     auto consume = [&]() {
@@ -435,7 +442,7 @@ __global__ __launch_bounds__(256, LAT ? 2 : GQ_WG_PER_CU) void k_goalset_queue(C
         const float p_band = i2eps * d * d * pad;                               // .cu:165-167
         float pot = value <= 0.0f ? p_in : (value <= eps ? p_band : 0.0f);
         pot = soft ? pot * 0.1f : pot;                                          // cost.py:350-353
-        tsum += pot != 0.0f ? pot * f_w : 0.0f;                                 // cost.py:260-275
+        add_term(pot != 0.0f ? pot * f_w : 0.0f);                               // cost.py:260-275
         tcol += (counts && value < clr) ? 1.0f : 0.0f;                          // .cu:150-151
         GS_COUNT_N(11, __popcll(__ballot(f_w != 0.0f ? (pot != 0.0f || value < clr) : false)));  // entries that contribute anything
         inflight = false;
@@ -446,7 +453,7 @@ __global__ __launch_bounds__(256, LAT ? 2 : GQ_WG_PER_CU) void k_goalset_queue(C
     auto issue = [&](int count) {
         GS_COUNT(8);
 #ifdef OMGX_GS_NO_EXACT
-        tsum += (float)count * 1.0e-30f;  // keeps the queue bookkeeping alive
+        tsum += (double)count * 1.0e-30;  // keeps the queue bookkeeping alive
         inflight = true;
         return;
 #endif
@@ -621,7 +628,7 @@ __global__ __launch_bounds__(256, LAT ? 2 : GQ_WG_PER_CU) void k_goalset_queue(C
                         Accum one{0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
                         pair_exact<false>(op, a.pool + ob->grid_offset, tx, ty, tz, one);
                         if (soft) { one.pot *= 0.1f; one.col = 0.0f; }
-                        tsum += one.pot != 0.0f ? one.pot * w[k] : 0.0f;
+                        add_term(one.pot != 0.0f ? one.pot * w[k] : 0.0f);
                         tcol += one.col;
                     }
                 }
@@ -644,15 +651,17 @@ __global__ __launch_bounds__(256, LAT ? 2 : GQ_WG_PER_CU) void k_goalset_queue(C
     }
 #endif
     {
-        const float ws_ = wave_sum(tsum), wc_ = wave_sum(tcol);
-        float* red = reinterpret_cast<float*>(lds_bytes + L.tbl_off);  // [2][4]: the records are dead once every wave has flushed its queue
+        const double ws_ = wave_sum(tsum);  // exact (see tsum)
+        const float wc_ = wave_sum(tcol);
+        double* red = reinterpret_cast<double*>(lds_bytes + L.tbl_off);  // [4] sums, then [4] float counts: the records are dead once every wave has flushed its queue
+        float* redc = reinterpret_cast<float*>(red + 4);
         __syncthreads();
-        if (lane == 0) { red[wave] = ws_; red[4 + wave] = wc_; }
+        if (lane == 0) { red[wave] = ws_; redc[wave] = wc_; }
         __syncthreads();
         if (tid == 0) {
             const int64_t k = (int64_t)s * a.NCH + chunk;
-            if (a.chunk_cost) a.chunk_cost[k] = ((red[0] + red[1]) + red[2]) + red[3];
-            if (a.chunk_col) a.chunk_col[k] = ((red[4] + red[5]) + red[6]) + red[7];
+            if (a.chunk_cost) a.chunk_cost[k] = (float)(((red[0] + red[1]) + red[2]) + red[3]);
+            if (a.chunk_col) a.chunk_col[k] = ((redc[0] + redc[1]) + redc[2]) + redc[3];
             if (STAMP) { const unsigned long long dt = wall_clock64() - work_t0; a.work[k] = dt < 1 ? 1u : (dt > 0xffffffffull ? 0xffffffffu : (uint32_t)dt); }
         }
     }

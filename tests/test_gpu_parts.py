@@ -192,3 +192,28 @@ def test_pose_hand_over_in_the_batch_layout_changes_no_bit(dev, goal_parts, alg,
     torch.cuda.synchronize()
     for k in ("traj", "info", "goal_idx", "learner_state", "grad"):
         assert np.array_equal(getattr(a, k).cpu().numpy(), getattr(b, k).cpu().numpy(), equal_nan=True), k
+
+
+@pytest.mark.parametrize("n_rem", [30, 13])
+def test_a_goals_cost_does_not_depend_on_the_order_of_its_terms(dev, n_rem):
+    """A workgroup's sum of pot x weight is accumulated exactly (terms on the 2^-36 grid, float64) and rounded to float32 once: the
+    same goals through the batch kernel (tile t -> wave t % 4) and through the latency-mode kernel with ONE part per goal (tiles
+    dealt heaviest first in a serpentine, another queue order altogether) give the same bits; with several parts the float32
+    partial sums add up to it within one rounding per part; and the exact float64 sum of the oracle's per-pair terms rounds to it."""
+    from omg_planner_amd import ops
+    eng, batch = _make(dev, 2, 24, 1, grid=32)
+    ts = eng.traj[:, 30 - n_rem]
+    cost, col, _ = ops.goalset_cost(eng.robot, eng.P, eng.scenes, ts, eng.cv_goals, n_rem, eng.cfg.time_interval)
+    pc = torch.full((2, 24), float("nan"), dtype=torch.float32, device=dev)
+    pl = torch.full_like(pc, float("nan"))
+    ops.goalset_cost_layer_tiled(eng.robot, eng.P, eng.scenes, ts, eng.cv_goals, n_rem, eng.cfg.time_interval, None, None, (pc, pl), goal_parts=1, spread=True)
+    torch.cuda.synchronize()
+    assert torch.equal(pc, cost) and torch.equal(pl, col)
+    for parts in (2, 4):
+        NP = ops.goalset_parts(n_rem, parts)
+        qc = torch.full((2, 24 * NP), float("nan"), dtype=torch.float32, device=dev)
+        ql = torch.full_like(qc, float("nan"))
+        ops.goalset_cost_layer_tiled(eng.robot, eng.P, eng.scenes, ts, eng.cv_goals, n_rem, eng.cfg.time_interval, None, None, (qc, ql), goal_parts=parts, spread=False)
+        torch.cuda.synchronize()
+        tot = qc.reshape(2, 24, NP).double().sum(-1)
+        np.testing.assert_allclose(tot.cpu().numpy(), cost.double().cpu().numpy(), rtol=NP * 6e-8, atol=1e-9)
