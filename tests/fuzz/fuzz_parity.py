@@ -105,10 +105,19 @@ def one_trial(rng, trial, dev, dry=False):
     lat = pipe is None and r2.rand() < 0.33
     if lat:
         STATS["latency"] = STATS.get("latency", 0) + 1
+    # round 4: split goals in the batch layout (goal_parts 2 / 4 / 8, pipelined or not) in a third of the trials that are not in
+    # latency mode, and the hand-over of link poses between the launches (what plan() and bench.py switch on) in half of all trials
+    gparts = 1
+    if not lat and r2.rand() < 0.33:
+        gparts = int(r2.choice([2, 4, 8]))
+        STATS["split_goals"] = STATS.get("split_goals", 0) + 1
     eng = ChompEngine(m, batch, copy.deepcopy(cfg), start, e_goals, reach_grasps=e_reach, device=dev, ol_alg=alg,
-                      goal_counts=None if counts is None else counts, latency_mode=lat)
+                      goal_counts=None if counts is None else counts, latency_mode=lat, goal_parts=gparts)
     if pipe is not None:
         eng.pipeline = pipe
+    if r2.rand() < 0.5:
+        eng.pose_hand_over(True)
+        STATS["pose_hand_over"] = STATS.get("pose_hand_over", 0) + 1
     traj = eng.traj.cpu().numpy().copy()
     state = orc.learner_state_init(S, G)
     states_r = None if counts is None else [orc.learner_state_init(1, int(k_)) for k_ in counts]
@@ -221,7 +230,7 @@ def main(trials=None, seed=None):
             print(f"trial {k}: ok, max |traj - oracle| {worst:.2e}", flush=True)
     print(f"{trials - bad}/{trials} trials agree; worst trajectory difference {worst_all:.2e}; joint-limit projection steps "
           f"{STATS['limit_steps']}, limit-violation flags {STATS['violations']}, scene-iterations skipped after termination {STATS['stopped']}, "
-          f"{STATS.get('ragged', 0)} trials with ragged goal sets, {STATS.get('pipelined', 0)} with a pipelined engine, {STATS.get('latency', 0)} in latency mode; {time.time() - t0:.0f} s")
+          f"{STATS.get('ragged', 0)} trials with ragged goal sets, {STATS.get('pipelined', 0)} with a pipelined engine, {STATS.get('latency', 0)} in latency mode, {STATS.get('split_goals', 0)} with split goals, {STATS.get('pose_hand_over', 0)} with the pose hand-over; {time.time() - t0:.0f} s")
     return 1 if bad else 0
 
 
