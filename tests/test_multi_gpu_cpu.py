@@ -113,3 +113,24 @@ def test_pipeline_parts_by_batch_size():
     assert ChompEngine.auto_parts(12, 64) == 3 and ChompEngine.auto_parts(13, 128) == 3 and ChompEngine.auto_parts(25, 64) == 3
     assert ChompEngine.auto_parts(32, 64) == 2 and ChompEngine.auto_parts(100, 64) == 2 and ChompEngine.auto_parts(100, 128) == 2
     assert ChompEngine.auto_parts(2, 512) == 2 and ChompEngine.auto_parts(1, 1024) == 1  # bounded by the number of scenes
+
+
+def test_layout_rule_is_a_pure_function_of_the_shape():
+    """ChompEngine.layout (host logic, no GPU): ONE rule by shape — latency mode for one scene, a goal's tiles over 4 / 2 workgroups of
+    the batch kernel up to ~320 / ~896 (scene, goal) items (scaled by waypoints / 30), whole goals beyond; pipeline parts 2 / 3 / 2 —
+    and what the ranks of a strong-scaling job rely on: every shard is laid out for the LARGEST shard."""
+    from omg_planner_amd.engine import ChompEngine, shard_range
+    L = ChompEngine.layout
+    assert L(1, 64) == {"latency_mode": True, "goal_parts": 1, "pipeline": 1}
+    assert L(2, 64)["goal_parts"] == 4 and L(5, 64)["goal_parts"] == 4 and L(2, 128)["goal_parts"] == 4
+    assert L(6, 64)["goal_parts"] == 2 and L(14, 64)["goal_parts"] == 2 and L(6, 128)["goal_parts"] == 2
+    for shape in ((13, 128), (25, 64), (16, 64), (50, 64), (100, 64), (100, 128), (400, 64)):
+        assert L(*shape)["goal_parts"] == 1 and not L(*shape)["latency_mode"], shape
+    assert L(13, 128)["pipeline"] == 3 and L(25, 64)["pipeline"] == 3 and L(100, 64)["pipeline"] == 2 and L(2, 64)["pipeline"] == 2
+    assert L(16, 12, 50)["goal_parts"] == 4 and L(16, 64, 50)["goal_parts"] == 1  # the load grows with the window
+    assert all(L(s, g)["pipeline"] <= s for s in (1, 2, 3) for g in (8, 64, 512))
+    assert L(13, 128) == L(13, 128)  # no hidden state
+    # BASELINE config 4 on 8 ranks: shards of 13 and 12 scenes, one layout
+    sizes = [len(shard_range(100, r, 8)) for r in range(8)]
+    assert sorted(set(sizes)) == [12, 13] and sum(sizes) == 100
+    assert len({str(L(max(sizes), 128))}) == 1 and L(max(sizes), 128) == L(13, 128)
