@@ -408,6 +408,17 @@ __global__ __launch_bounds__(256, LAT ? 2 : GQ_WG_PER_CU) void k_goalset_queue(C
     }
     GS_WG_STAMP(3);
 
+    // The main loop's wave-uniform inputs as copies of their own (an empty asm the compiler cannot see through): the kernel's
+    // arguments arrive as 4- and 8-dword tuples of neighbouring fields, and a tuple that stays live for ONE field is spilled and
+    // restored whole — lane moves on the VALU, per tile, per far test, per ring-fill.
+    int h_CH, h_P, h_ps, h_ob, h_oe, h_tbl, h_soft;
+    float h_idt;
+    const omgx_object* h_objects;
+    const float* h_pool;
+    asm volatile("s_mov_b32 %0, %10\n\ts_mov_b32 %1, %11\n\ts_mov_b32 %2, %12\n\ts_mov_b32 %3, %13\n\ts_mov_b32 %4, %14\n\ts_mov_b32 %5, %15\n\t"
+                 "s_mov_b32 %6, %16\n\ts_mov_b32 %7, %17\n\ts_mov_b64 %8, %18\n\ts_mov_b64 %9, %19"
+                 : "=&s"(h_CH), "=&s"(h_P), "=&s"(h_ps), "=&s"(h_ob), "=&s"(h_oe), "=&s"(h_tbl), "=&s"(h_soft), "=&s"(h_idt), "=&s"(h_objects), "=&s"(h_pool)
+                 : "s"(CH), "s"(P), "s"(pstride), "s"(o_begin), "s"(o_end), "s"(a.tbl_n), "s"(a.soften), "s"(a.inv_dt), "s"(a.objects), "s"(a.pool));
     // ---- the wave's queue.  Pending entries (object-space offset, weight) sit in the wave's LDS ring `stage`, slot i = entry i,
     // their object index | soft << 16 in q_meta of lane i; lanes / slots [0, pending).  f_*: the batch whose gathers are in flight.
     uint32_t q_meta = 0u;
@@ -504,7 +515,7 @@ __global__ __launch_bounds__(256, LAT ? 2 : GQ_WG_PER_CU) void k_goalset_queue(C
         const bool ordered = (__builtin_fabsf(gx) <= 1.0e9f) && (__builtin_fabsf(gy) <= 1.0e9f) && (__builtin_fabsf(gz) <= 1.0e9f);
         const bool in_c = valid && ordered && (uint32_t)ix < (uint32_t)(dx - 1) && (uint32_t)iy < (uint32_t)(dy - 1) && (uint32_t)iz < (uint32_t)(dz - 1);
         const uint32_t b = in_c ? (uint32_t)((ix * dy + iy) * dz + iz) : 0u;
-        const char* g0 = reinterpret_cast<const char*>(a.pool) + goffb + (uint64_t)b * 4u;
+        const char* g0 = reinterpret_cast<const char*>(h_pool) + goffb + (uint64_t)b * 4u;
         const uint32_t syb = (uint32_t)dz * 4u, sxb = (uint32_t)(dy * dz) * 4u;
         f_r00 = *reinterpret_cast<const F2*>(g0);
         f_r01 = *reinterpret_cast<const F2*>(g0 + syb);
@@ -553,8 +564,8 @@ __global__ __launch_bounds__(256, LAT ? 2 : GQ_WG_PER_CU) void k_goalset_queue(C
     // main loop 1.07x after the mean (tools/gs_phase_clock.py).  Measured and rejected: single waypoints dealt to the waves
     // (the rows of a tile then see different objects: +2 %), a split of the tile sequence by the number of row-mask hits
     // (a poor predictor of the exact-path work: +7 %), one link per tile (+5 %).
-    const int ntiles = ((CH + 3) >> 2) * (10 / LB);
-    const int pc3 = 3 * (p < P ? p : 0);  // lane part of a collision-point address (doubles)
+    const int ntiles = ((h_CH + 3) >> 2) * (10 / LB);
+    const int pc3 = 3 * (p < h_P ? p : 0);  // lane part of a collision-point address (doubles)
     GS_COUNT(0);
     constexpr bool PARTS = LAT || SPLIT;  // this workgroup holds one part of a goal's tiles: the wave's q-th tile is lat_tile(q)
 #pragma unroll 1
@@ -563,7 +574,7 @@ __global__ __launch_bounds__(256, LAT ? 2 : GQ_WG_PER_CU) void k_goalset_queue(C
         GS_COUNT(1);
         {
             const int ci = rb * 4 + (lane >> 4) - blk_shift;
-            const bool valid = (p < P) && (ci >= 0) && (ci < CH);
+            const bool valid = (p < h_P) && (ci >= 0) && (ci < h_CH);
             const int cic = valid ? ci : 0;
             const int cic9 = cic * 9;  // lane part of a pose address (doubles); base = configuration 1, lds_pose = configuration 0
             float px[LB], py[LB], pz[LB], w[LB];
@@ -572,7 +583,7 @@ __global__ __launch_bounds__(256, LAT ? 2 : GQ_WG_PER_CU) void k_goalset_queue(C
             uint32_t many = 0;
 #pragma unroll
             for (int k = 0; k < LB; ++k) {
-                msk[k] = valid ? (rowmask + (l0 + k) * CH)[cic] : 0u;  // uniform part of every address on the scalar unit
+                msk[k] = valid ? (rowmask + (l0 + k) * h_CH)[cic] : 0u;  // uniform part of every address on the scalar unit
                 many |= msk[k];
                 wdone[k] = false;
                 w[k] = 0.0f;
@@ -583,18 +594,18 @@ __global__ __launch_bounds__(256, LAT ? 2 : GQ_WG_PER_CU) void k_goalset_queue(C
             for (int k = 0; k < LB; ++k) {
                 px[k] = py[k] = pz[k] = 0.0f;
                 if (__any(msk[k] != 0))  // a link none of whose four rows reaches anything needs no points (its far tests are skipped too)
-                    pose9_apply((base + (l0 + k) * pstride * 9) + cic9, (pts + 3 * (l0 + k) * P) + pc3, px[k], py[k], pz[k]);
+                    pose9_apply((base + (l0 + k) * h_ps * 9) + cic9, (pts + 3 * (l0 + k) * h_P) + pc3, px[k], py[k], pz[k]);
             }
-            for (int o = o_begin; o < o_end; ++o) {
-                const int oo = o - o_begin;
+            for (int o = h_ob; o < h_oe; ++o) {
+                const int oo = o - h_ob;
                 const uint32_t bit = 1u << (oo < 31 ? oo : 31);
                 GS_COUNT(10);
                 if (!__any((many & bit) != 0)) continue;
-                ObjTablePtr ob = as_const(a.objects) + o;
+                ObjTablePtr ob = as_const(h_objects) + o;
                 if (ob->disabled > 0) continue;  // .cu:115-116
                 GS_COUNT(3);
                 const GqFar fp = gq_load_far(ob);
-                const bool queued = oo < a.tbl_n;  // objects beyond the LDS records (rare) are evaluated on the spot
+                const bool queued = oo < h_tbl;  // objects beyond the LDS records (rare) are evaluated on the spot
 #pragma unroll
                 for (int k = 0; k < LB; ++k) {
                     if (!__any((msk[k] & bit) != 0)) continue;  // none of this link's four rows reaches the object
@@ -614,19 +625,19 @@ __global__ __launch_bounds__(256, LAT ? 2 : GQ_WG_PER_CU) void k_goalset_queue(C
                         const int l = l0 + k;
                         float qx, qy, qz;
                         // the previous configuration's pose: cfg ci - 1 of the same link, i.e. one 72-byte record back (ci = 0: the start, record 0)
-                        pose9_apply((lds_pose + l * pstride * 9) + cic9, (pts + 3 * l * P) + pc3, qx, qy, qz);
-                        const float vx = (px[k] - qx) * a.inv_dt, vy = (py[k] - qy) * a.inv_dt, vz = (pz[k] - qz) * a.inv_dt;
+                        pose9_apply((lds_pose + l * h_ps * 9) + cic9, (pts + 3 * l * h_P) + pc3, qx, qy, qz);
+                        const float vx = (px[k] - qx) * h_idt, vy = (py[k] - qy) * h_idt, vz = (pz[k] - qz) * h_idt;
                         w[k] = sqrtf(vx * vx + vy * vy + vz * vz);
                         wdone[k] = true;
                     }
-                    const uint32_t soft = (a.soften && l0 + k >= 8) ? 1u : 0u;
+                    const uint32_t soft = (h_soft && l0 + k >= 8) ? 1u : 0u;
                     if (queued) {
                         GS_COUNT(7);
                         enqueue(live, tx, ty, tz, w[k], (uint32_t)oo | (soft << 16));
                     } else if (live) {
                         const ObjParams op = load_object(ob);
                         Accum one{0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-                        pair_exact<false>(op, a.pool + ob->grid_offset, tx, ty, tz, one);
+                        pair_exact<false>(op, h_pool + ob->grid_offset, tx, ty, tz, one);
                         if (soft) { one.pot *= 0.1f; one.col = 0.0f; }
                         add_term(one.pot != 0.0f ? one.pot * w[k] : 0.0f);
                         tcol += one.col;
