@@ -460,10 +460,41 @@ __device__ __forceinline__ void fk_chain(const RV& rv, const double* __restrict_
 // f(l, R_r0, R_r1, R_r2, t_r) receives row r of link l's pose (before center_offset, like fk_chain).
 __device__ __forceinline__ void fk_joint_sincos(double q, double& s, double& c) { sincos(deg_round_trip(q), &s, &c); }
 
+// The rounding sequence of the workgroup kinematics, fixed in SOURCE: the three code shapes below — fk_chain_row,
+// fk_joint_matrix + fk_chain_row_B — must produce the same bits (the launches hand poses to each other), which under
+// `fp contract(fast)` depended on the backend fusing the same multiply-adds in each.  Here every fused operation is an explicit fma and
+// contraction is off: a 3-term dot product is fma(a2, b2, fma(a1, b1, a0 b0)).  (The backend had fused differently: the plan digests of
+// tools/bits_of_a_plan.py changed once with this rewrite — last-bit differences of the poses, inside every parity tolerance — and
+// are now a property of this file, not of the compiler version.)
+__device__ __forceinline__ double fk_dot3(double a0, double a1, double a2, double b0, double b1, double b2) {
+#pragma clang fp contract(off)
+    return __builtin_fma(a2, b2, __builtin_fma(a1, b1, a0 * b0));
+}
+// joint matrix entry: c U + s V + W
+__device__ __forceinline__ double fk_bentry(double c, double s, double U, double V, double W) {
+#pragma clang fp contract(off)
+    return __builtin_fma(s, V, c * U) + W;
+}
+// hand = link7 . pose_0[7]; fingers = hand . pose_0[8|9] with y -+ q (robot_pykdl.py:181-188): the tail of every chain
+template <class RV, class F>
+__device__ __forceinline__ void fk_chain_tail(const RV& rv, double a0, double a1, double a2, double at, double q7, double q8, F&& f) {
+#pragma clang fp contract(off)
+    const auto H = rv.hand();
+    const double h0 = fk_dot3(a0, a1, a2, H[0], H[4], H[8]), h1 = fk_dot3(a0, a1, a2, H[1], H[5], H[9]), h2 = fk_dot3(a0, a1, a2, H[2], H[6], H[10]);
+    const double ht = fk_dot3(a0, a1, a2, H[3], H[7], H[11]) + at;
+    f(7, h0, h1, h2, ht);
+    const auto Lf = rv.lf();
+    f(8, fk_dot3(h0, h1, h2, Lf[0], Lf[4], Lf[8]), fk_dot3(h0, h1, h2, Lf[1], Lf[5], Lf[9]), fk_dot3(h0, h1, h2, Lf[2], Lf[6], Lf[10]),
+      fk_dot3(h0, h1, h2, Lf[3], Lf[7] + deg_round_trip(q7), Lf[11]) + ht);
+    const auto Rf = rv.rf();
+    f(9, fk_dot3(h0, h1, h2, Rf[0], Rf[4], Rf[8]), fk_dot3(h0, h1, h2, Rf[1], Rf[5], Rf[9]), fk_dot3(h0, h1, h2, Rf[2], Rf[6], Rf[10]),
+      fk_dot3(h0, h1, h2, Rf[3], Rf[7] - deg_round_trip(q8), Rf[11]) + ht);
+}
+
 template <class RV, class F>
 __device__ __forceinline__ void fk_chain_row(const RV& rv, int r, const double* __restrict__ sc /* [7][2] sin, cos */,
                                              double q7, double q8, F&& f) {
-#pragma clang fp contract(fast)
+#pragma clang fp contract(off)
     double a0 = r == 0 ? 1.0 : 0.0, a1 = r == 1 ? 1.0 : 0.0, a2 = r == 2 ? 1.0 : 0.0, at = 0.0;
 #pragma unroll 1  // unrolled, the 7 x 27 wave-uniform constants are hoisted into (spilled) SGPRs all at once
     for (int i = 0; i < 7; ++i) {
@@ -472,25 +503,15 @@ __device__ __forceinline__ void fk_chain_row(const RV& rv, int r, const double* 
         const auto tp = rv.tp(i);
         double B[9];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) B[k] = c * uvw[k] + s * uvw[9 + k] + uvw[18 + k];
-        const double n0 = a0 * B[0] + a1 * B[3] + a2 * B[6];
-        const double n1 = a0 * B[1] + a1 * B[4] + a2 * B[7];
-        const double n2 = a0 * B[2] + a1 * B[5] + a2 * B[8];
-        at = a0 * tp[0] + a1 * tp[1] + a2 * tp[2] + at;
+        for (int k = 0; k < 9; ++k) B[k] = fk_bentry(c, s, uvw[k], uvw[9 + k], uvw[18 + k]);
+        const double n0 = fk_dot3(a0, a1, a2, B[0], B[3], B[6]);
+        const double n1 = fk_dot3(a0, a1, a2, B[1], B[4], B[7]);
+        const double n2 = fk_dot3(a0, a1, a2, B[2], B[5], B[8]);
+        at = fk_dot3(a0, a1, a2, tp[0], tp[1], tp[2]) + at;
         a0 = n0; a1 = n1; a2 = n2;
         f(i, a0, a1, a2, at);
     }
-    // hand = link7 . pose_0[7]; fingers = hand . pose_0[8|9] with y -+ q (robot_pykdl.py:181-188)
-    const auto H = rv.hand();
-    const double h0 = a0 * H[0] + a1 * H[4] + a2 * H[8], h1 = a0 * H[1] + a1 * H[5] + a2 * H[9], h2 = a0 * H[2] + a1 * H[6] + a2 * H[10];
-    const double ht = a0 * H[3] + a1 * H[7] + a2 * H[11] + at;
-    f(7, h0, h1, h2, ht);
-    const auto Lf = rv.lf();
-    f(8, h0 * Lf[0] + h1 * Lf[4] + h2 * Lf[8], h0 * Lf[1] + h1 * Lf[5] + h2 * Lf[9], h0 * Lf[2] + h1 * Lf[6] + h2 * Lf[10],
-      h0 * Lf[3] + h1 * (Lf[7] + deg_round_trip(q7)) + h2 * Lf[11] + ht);
-    const auto Rf = rv.rf();
-    f(9, h0 * Rf[0] + h1 * Rf[4] + h2 * Rf[8], h0 * Rf[1] + h1 * Rf[5] + h2 * Rf[9], h0 * Rf[2] + h1 * Rf[6] + h2 * Rf[10],
-      h0 * Rf[3] + h1 * (Rf[7] - deg_round_trip(q8)) + h2 * Rf[11] + ht);
+    fk_chain_tail(rv, a0, a1, a2, at, q7, q8, f);
 }
 
 // The same chain with the joints' matrices B_i = c_i U_i + s_i V_i + W_i computed beforehand by one lane per (configuration, joint)
@@ -498,39 +519,29 @@ __device__ __forceinline__ void fk_chain_row(const RV& rv, int r, const double* 
 // of 30 multiply-adds and read 12 instead of 30 constants per joint.  Latency mode only: the table costs 504 B of LDS per configuration.
 template <class RV>
 __device__ __forceinline__ void fk_joint_matrix(const RV& rv, int i, double s, double c, double* __restrict__ B) {
-#pragma clang fp contract(fast)
     const auto uvw = rv.uvw(i);
 #pragma unroll
-    for (int k = 0; k < 9; ++k) B[k] = c * uvw[k] + s * uvw[9 + k] + uvw[18 + k];
+    for (int k = 0; k < 9; ++k) B[k] = fk_bentry(c, s, uvw[k], uvw[9 + k], uvw[18 + k]);
 }
 
 // bstride: doubles between the matrices of consecutive joints (9: a [7][9] table per configuration; the batch kernel keeps joint i's
 // matrices where link i's poses will be written: one link block apart).  Bt is NOT restrict there: f() overwrites what was read.
 template <class RV, class F>
 __device__ __forceinline__ void fk_chain_row_B(const RV& rv, int r, const double* Bt /* [7][bstride] */, double q7, double q8, F&& f, int bstride = 9) {
-#pragma clang fp contract(fast)
+#pragma clang fp contract(off)
     double a0 = r == 0 ? 1.0 : 0.0, a1 = r == 1 ? 1.0 : 0.0, a2 = r == 2 ? 1.0 : 0.0, at = 0.0;
 #pragma unroll 1
     for (int i = 0; i < 7; ++i) {
         const double* B = Bt + bstride * i;
         const auto tp = rv.tp(i);
-        const double n0 = a0 * B[0] + a1 * B[3] + a2 * B[6];
-        const double n1 = a0 * B[1] + a1 * B[4] + a2 * B[7];
-        const double n2 = a0 * B[2] + a1 * B[5] + a2 * B[8];
-        at = a0 * tp[0] + a1 * tp[1] + a2 * tp[2] + at;
+        const double n0 = fk_dot3(a0, a1, a2, B[0], B[3], B[6]);
+        const double n1 = fk_dot3(a0, a1, a2, B[1], B[4], B[7]);
+        const double n2 = fk_dot3(a0, a1, a2, B[2], B[5], B[8]);
+        at = fk_dot3(a0, a1, a2, tp[0], tp[1], tp[2]) + at;
         a0 = n0; a1 = n1; a2 = n2;
         f(i, a0, a1, a2, at);
     }
-    const auto H = rv.hand();
-    const double h0 = a0 * H[0] + a1 * H[4] + a2 * H[8], h1 = a0 * H[1] + a1 * H[5] + a2 * H[9], h2 = a0 * H[2] + a1 * H[6] + a2 * H[10];
-    const double ht = a0 * H[3] + a1 * H[7] + a2 * H[11] + at;
-    f(7, h0, h1, h2, ht);
-    const auto Lf = rv.lf();
-    f(8, h0 * Lf[0] + h1 * Lf[4] + h2 * Lf[8], h0 * Lf[1] + h1 * Lf[5] + h2 * Lf[9], h0 * Lf[2] + h1 * Lf[6] + h2 * Lf[10],
-      h0 * Lf[3] + h1 * (Lf[7] + deg_round_trip(q7)) + h2 * Lf[11] + ht);
-    const auto Rf = rv.rf();
-    f(9, h0 * Rf[0] + h1 * Rf[4] + h2 * Rf[8], h0 * Rf[1] + h1 * Rf[5] + h2 * Rf[9], h0 * Rf[2] + h1 * Rf[6] + h2 * Rf[10],
-      h0 * Rf[3] + h1 * (Rf[7] - deg_round_trip(q8)) + h2 * Rf[11] + ht);
+    fk_chain_tail(rv, a0, a1, a2, at, q7, q8, f);
 }
 
 __device__ __forceinline__ void pose_apply(const Pose& A, const double* __restrict__ p, double& x, double& y, double& z) {
