@@ -493,6 +493,18 @@ int omgx_goalset_schedule(const uint32_t* work, const int32_t* active, const int
 int omgx_goalset_schedule_parts(const uint32_t* work, const int32_t* active, const int32_t* goal_count, int32_t num_scenes,
                                 int32_t num_goals, int32_t parts, int32_t slack, int32_t* schedule, void* stream);
 
+/* ABI 9: the order INSIDE an XCD.  OMGX_SCHEDULE_SCENE_MAJOR is the list above.  OMGX_SCHEDULE_LONGEST_FIRST keeps every item on
+ * the XCD the list above gives it (whole scenes per XCD, equal work) and runs an XCD's items by decreasing w across its scenes
+ * (ties: lower item index first): schedule[8 r + x] = item, r = the number of items of piece x that run before it.  For launches of
+ * a round or two of the chip's workgroup slots (13 scenes x 128 goals, 25 x 64), whose span is set by what starts LAST; a launch
+ * of many rounds is faster scene by scene (a scene's volumes stay in L2: +16 % longest first at 100 x 64).  Above
+ * OMGX_SCHEDULE_LONGEST_FIRST_MAX_ITEMS items (S * G * parts) the call falls back to the scene-major order. */
+#define OMGX_SCHEDULE_SCENE_MAJOR 0
+#define OMGX_SCHEDULE_LONGEST_FIRST 1
+#define OMGX_SCHEDULE_LONGEST_FIRST_MAX_ITEMS 8192
+int omgx_goalset_schedule_ordered(const uint32_t* work, const int32_t* active, const int32_t* goal_count, int32_t num_scenes,
+                                  int32_t num_goals, int32_t parts, int32_t slack, int32_t order, int32_t* schedule, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * (8) Scenes that change while resident in HBM (ABI 8)
  * The reference rebuilds the per-object parameters on every call (Cost.compute_obstacle_cost_layer, omg/cost.py:296-335) and

@@ -606,6 +606,22 @@ __global__ __launch_bounds__(256, LAT ? 2 : GQ_WG_PER_CU) void k_goalset_queue(C
                 GS_COUNT(3);
                 const GqFar fp = gq_load_far(ob);
                 const bool queued = oo < h_tbl;  // objects beyond the LDS records (rare) are evaluated on the spot
+#ifdef OMGX_GS_COUNT  // what tiles of 2 waypoints x 2 links would do here (verdict round 3, item 2 i): far tests and enqueue calls per half wave
+                if (LB == 2) {
+                    bool lv = false;
+#pragma unroll
+                    for (int k = 0; k < LB; ++k) {
+                        const float ux = __builtin_fmaf(fp.T[2], pz[k], __builtin_fmaf(fp.T[1], py[k], __builtin_fmaf(fp.T[0], px[k], fp.T[3])));
+                        const float uy = __builtin_fmaf(fp.T[6], pz[k], __builtin_fmaf(fp.T[5], py[k], __builtin_fmaf(fp.T[4], px[k], fp.T[7])));
+                        const float uz = __builtin_fmaf(fp.T[10], pz[k], __builtin_fmaf(fp.T[9], py[k], __builtin_fmaf(fp.T[8], px[k], fp.T[11])));
+                        const bool inside = rbox_inside(ux - fp.lo[0], uy - fp.lo[1], uz - fp.lo[2], fp.rc, fp.rh, fp.rr2);
+                        lv = lv || ((msk[k] & bit) && (inside || !fp.cullable));
+                    }
+                    const unsigned long long hb = __ballot(((msk[0] | msk[1]) & bit) != 0), lb_ = __ballot(lv);
+                    GS_COUNT_N(12, ((hb & 0xffffffffull) ? 1 : 0) + ((hb >> 32) ? 1 : 0));
+                    GS_COUNT_N(13, ((lb_ & 0xffffffffull) ? 1 : 0) + ((lb_ >> 32) ? 1 : 0));
+                }
+#endif
 #pragma unroll
                 for (int k = 0; k < LB; ++k) {
                     if (!__any((msk[k] & bit) != 0)) continue;  // none of this link's four rows reaches the object
@@ -657,8 +673,8 @@ __global__ __launch_bounds__(256, LAT ? 2 : GQ_WG_PER_CU) void k_goalset_queue(C
 #if defined(OMGX_GS_CLOCK)
     if (lane == 0 && blockIdx.x < (1u << 16)) {  // when the first / the last wave of the workgroup left its main loop
         const unsigned long long now = wall_clock64();
-        atomicMin(&g_gs_wg[blockIdx.x][5], now);
-        atomicMax(&g_gs_wg[blockIdx.x][6], now);
+        atomicMin(&g_gs_wg[GS_WG_IDX][5], now);
+        atomicMax(&g_gs_wg[GS_WG_IDX][6], now);
     }
 #endif
     {

@@ -554,7 +554,9 @@ __device__ __forceinline__ void waypoint_layer_block(const ChunkArgs& a, const i
 // its first / last wave leaves the main loop, exit — and its hardware id.  Never part of the shipped library.
 #ifdef OMGX_GS_CLOCK
 __device__ unsigned long long g_gs_wg[1 << 16][8];
-#define GS_WG_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < (1u << 16)) { g_gs_wg[blockIdx.x][k] = wall_clock64(); if (k == 0) { g_gs_wg[blockIdx.x][5] = ~0ull; g_gs_wg[blockIdx.x][6] = 0ull; unsigned hw, xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); g_gs_wg[blockIdx.x][7] = ((unsigned long long)xcc << 32) | hw; } } } while (0)
+// two launches that run at once (tools/gs_two_queue_clock.py) keep their stamps apart when one has an odd number of scenes
+#define GS_WG_IDX ((blockIdx.x + (((unsigned)a.S & 1u) << 14)) & 0xffffu)
+#define GS_WG_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < (1u << 16)) { g_gs_wg[GS_WG_IDX][k] = wall_clock64(); if (k == 0) { g_gs_wg[GS_WG_IDX][5] = ~0ull; g_gs_wg[GS_WG_IDX][6] = 0ull; unsigned hw, xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); g_gs_wg[GS_WG_IDX][7] = ((unsigned long long)xcc << 32) | hw; } } } while (0)
 __device__ unsigned long long g_gs_wave[1 << 16][8];  // per wave: [w] when wave w finished its part of the chain / culling stage; [4 + w] when it entered it
 #define GS_WAVE_STAMP(k) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < (1u << 16)) g_gs_wave[blockIdx.x][k] = wall_clock64(); } while (0)
 extern "C" int omgx_debug_gs_wave(unsigned long long* h_out, int n_wg) {
@@ -666,7 +668,7 @@ static void timing_events(int kind, hipEvent_t* ev0, hipEvent_t* ev1) {
     *ev0 = g_ev[i][0]; *ev1 = g_ev[i][1];
     ++g_timing_n;
 }
-extern "C" int omgx_abi_version(void) { return 8; }  // 8: omgx_goalset_cost_layer_parts, omgx_goalset_schedule_parts (a goal's tiles over several workgroups of the batch kernel); 2: `active` masks; 3: ragged goal sets (goal_count, eta); 4: goal schedule + work; 5: 184-byte object records (influence region = rounded box); 6: omgx_goalset_cost_layer_tiled, omgx_learner_params.cost_parts; 7: pose tables (omgx_pose_table, pointer fields at the end of both parameter blocks, layer_poses)
+extern "C" int omgx_abi_version(void) { return 9; }  // 9: omgx_goalset_schedule_ordered (longest first inside an XCD); 8: omgx_goalset_cost_layer_parts, omgx_goalset_schedule_parts (a goal's tiles over several workgroups of the batch kernel); 2: `active` masks; 3: ragged goal sets (goal_count, eta); 4: goal schedule + work; 5: 184-byte object records (influence region = rounded box); 6: omgx_goalset_cost_layer_tiled, omgx_learner_params.cost_parts; 7: pose tables (omgx_pose_table, pointer fields at the end of both parameter blocks, layer_poses)
 extern "C" int omgx_device_arch(char* h_buf, int32_t h_len) {
     if (!h_buf || h_len <= 0) return OMGX_ERR_INVALID;
     int dev = 0;
@@ -1055,6 +1057,7 @@ struct SchedArgs {
     int S, G, slack, slots, staged;
     int32_t* sched;
     int np;  // items per goal (omgx_goalset_schedule_parts): G counts items, item g of a scene belongs to its goal g / np
+    int longest_first;  // omgx_goalset_schedule_ordered: inside an XCD the items run longest first across its scenes (staged only)
 };
 
 __global__ __launch_bounds__(SCH_TPB) void k_goalset_schedule(SchedArgs a) {
@@ -1067,6 +1070,7 @@ __global__ __launch_bounds__(SCH_TPB) void k_goalset_schedule(SchedArgs a) {
     uint32_t* offp = nval + S;                                          // [S] items of the scenes ranked before
     uint32_t* srank = offp + S;                                         // [S]
     uint32_t* wl = srank + S;                                           // [S*G] weight of a kept item (>= 1), 0 = left out (a.staged)
+    unsigned char* xs = reinterpret_cast<unsigned char*>(wl + S * G);   // [S*G] the item's XCD, 255 = left out (a.longest_first)
     __shared__ unsigned long long tot[2];                               // total weight, total clamped weight
     __shared__ uint32_t cnt_all;
     __shared__ uint32_t first[8];
@@ -1159,8 +1163,24 @@ __global__ __launch_bounds__(SCH_TPB) void k_goalset_schedule(SchedArgs a) {
         if (w) { place(s, g, w, pos, x); atomicMin(&first[x], pos); }
         if (kept_n < 4) { kpos[kept_n] = pos; kx[kept_n] = x; }
         ++kept_n;
+        if (a.longest_first) xs[i] = (unsigned char)(w ? x : 255);
     }
     __syncthreads();
+    if (a.longest_first) {
+        // The XCD of every item as above (whole scenes per XCD, equal work); its place inside the XCD by weight alone — longest first
+        // across the XCD's scenes, ties by index.  For launches of a round or two of the chip's workgroup slots, whose span is set by
+        // what starts last (tools/ab_schedule_order.py; with many rounds the scene-major order keeps a scene's volumes in L2 and wins).
+        for (int i = tid; i < S * G; i += SCH_TPB) {
+            const uint32_t w = wl[i];
+            if (!w) continue;
+            const unsigned char x = xs[i];
+            uint32_t r = 0;
+#pragma unroll 4
+            for (int j = 0; j < S * G; ++j) r += (xs[j] == x && (wl[j] > w || (wl[j] == w && j < i))) ? 1u : 0u;
+            if ((int)r < a.slots) a.sched[(size_t)r * 8 + x] = i;
+        }
+        return;
+    }
     int k = 0;
     for (int i = tid; i < S * G; i += SCH_TPB, ++k) {
         const int s = i / G, g = i - s * G;
@@ -1179,7 +1199,7 @@ extern "C" int32_t omgx_goalset_schedule_len(int32_t num_scenes, int32_t num_goa
 }
 
 static int goalset_schedule_impl(const uint32_t* work, const int32_t* active, const int32_t* goal_count, int32_t num_scenes,
-                                 int32_t num_goals, int32_t parts, int32_t slack, int32_t* schedule, void* stream);
+                                 int32_t num_goals, int32_t parts, int32_t slack, int32_t* schedule, void* stream, int32_t order = 0);
 
 extern "C" int omgx_goalset_schedule(const uint32_t* work, const int32_t* active, const int32_t* goal_count, int32_t num_scenes,
                                      int32_t num_goals, int32_t slack, int32_t* schedule, void* stream) {
@@ -1192,9 +1212,16 @@ extern "C" int omgx_goalset_schedule_parts(const uint32_t* work, const int32_t* 
     return goalset_schedule_impl(work, active, goal_count, num_scenes, num_goals, parts, slack, schedule, stream);
 }
 
+extern "C" int omgx_goalset_schedule_ordered(const uint32_t* work, const int32_t* active, const int32_t* goal_count, int32_t num_scenes,
+                                             int32_t num_goals, int32_t parts, int32_t slack, int32_t order, int32_t* schedule, void* stream) {
+    if (parts != 1 && parts != 2 && parts != 4 && parts != 8) return OMGX_ERR_INVALID;
+    if (order != OMGX_SCHEDULE_SCENE_MAJOR && order != OMGX_SCHEDULE_LONGEST_FIRST) return OMGX_ERR_INVALID;
+    return goalset_schedule_impl(work, active, goal_count, num_scenes, num_goals, parts, slack, schedule, stream, order);
+}
+
 // items per scene = goals x parts; everything below counts items
 static int goalset_schedule_impl(const uint32_t* work, const int32_t* active, const int32_t* goal_count, int32_t num_scenes,
-                                 int32_t num_goals_, int32_t parts, int32_t slack, int32_t* schedule, void* stream) {
+                                 int32_t num_goals_, int32_t parts, int32_t slack, int32_t* schedule, void* stream, int32_t order) {
     if (num_scenes <= 0 || num_goals_ <= 0 || slack < 1 || !schedule) return OMGX_ERR_INVALID;
     const int64_t items64 = (int64_t)num_goals_ * parts;
     if (items64 > 65536) return OMGX_ERR_UNSUPPORTED;
@@ -1203,8 +1230,12 @@ static int goalset_schedule_impl(const uint32_t* work, const int32_t* active, co
     if ((int64_t)num_scenes * num_goals > 65536 || num_scenes > OMGX_SCHEDULE_MAX_SCENES) return OMGX_ERR_UNSUPPORTED;
     const int items = num_scenes * num_goals;
     const int staged = (items <= SCH_LDS_ITEMS && num_scenes <= 128) ? 1 : 0;  // keeps the launch below 64 KB of dynamic LDS
-    SchedArgs a{work, active, goal_count, num_scenes, num_goals, slack, omgx_goalset_schedule_len(num_scenes, num_goals, slack) / 8, staged, schedule, parts};
-    const size_t lds = (size_t)num_scenes * (3 * sizeof(unsigned long long) + 3 * sizeof(uint32_t)) + (staged ? (size_t)items * sizeof(uint32_t) : 0);
+    // longest first inside an XCD: O(items^2) comparisons in one workgroup and a byte per item in LDS — for the launches it is meant for
+    // (a round or two of the chip's slots); larger ones keep the scene-major order, which is the better one there anyway
+    const int longest_first = (order == OMGX_SCHEDULE_LONGEST_FIRST && staged && items <= OMGX_SCHEDULE_LONGEST_FIRST_MAX_ITEMS) ? 1 : 0;
+    SchedArgs a{work, active, goal_count, num_scenes, num_goals, slack, omgx_goalset_schedule_len(num_scenes, num_goals, slack) / 8, staged, schedule, parts, longest_first};
+    const size_t lds = (size_t)num_scenes * (3 * sizeof(unsigned long long) + 3 * sizeof(uint32_t)) + (staged ? (size_t)items * sizeof(uint32_t) : 0) +
+                       (longest_first ? (size_t)items : 0);
     hipLaunchKernelGGL(k_goalset_schedule, dim3(1), dim3(SCH_TPB), lds, (hipStream_t)stream, a);
     OMGX_CHECK_LAUNCH("k_goalset_schedule");
     return OMGX_OK;

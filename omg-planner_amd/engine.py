@@ -80,6 +80,12 @@ class ChompEngine:
     # fills it (13 x 128: 0.136 / 0.114 / 0.107 ms per step with 1 / 2 / 3 parts, 25 x 64: 0.134 / 0.120 / 0.108; from 35 x 64
     # on two parts win: 0.142 vs 0.147, 100 x 64: 0.290 vs 0.300).
     PIPELINE_THREE_BELOW = 2048
+    MEASURE_MIN_ITEMS = 256   # (scene, goal, part) items from which the second launch's measured durations order the dispatch schedule
+    # Up to this many items the measured schedule runs an XCD's items LONGEST FIRST across its scenes (omgx_goalset_schedule_ordered):
+    # a launch of a round or two of the chip's 1280 workgroup slots ends with what starts last (13 x 128 in three pipeline parts:
+    # 0.0864 -> 0.080 ms per step with the measured scene-major schedule, -> 0.0785 longest first; 100 x 64 longest first: +16 %,
+    # a scene's volumes leave the L2 — tools/ab_schedule_order.py).  The order changes no result: the goal sums are exact.
+    LONGEST_FIRST_MAX_ITEMS = 2048
 
     @classmethod
     def auto_parts(cls, num_scenes: int, num_goals: int) -> int:
@@ -515,7 +521,7 @@ class ChompEngine:
                 NP = self._np(n_rem)
                 self._parts_last = NP
                 use_sched = self.auto_schedule and (not self._masked or (self._measured and bool(self.reschedule_every)))
-                measure = use_sched and not self._measured and self._gs_launches >= 2 and self.S * self.G * NP >= 2048 and NP == self._parts_max
+                measure = use_sched and not self._measured and self._gs_launches >= 2 and self.S * self.G * NP >= self.MEASURE_MIN_ITEMS and NP == self._parts_max
                 if use_sched and self._masked:
                     if self._sched_age is None or self._sched_age >= self.reschedule_every or self._sched_np != NP:
                         self.schedule = self.build_schedule(active=self._mask(), parts=NP, uniform=(NP != self._parts_max or not self._measured))
@@ -596,7 +602,8 @@ class ChompEngine:
         self._sched_flip ^= 1
         key = (parts, self._sched_flip)
         out = ops.goalset_schedule(None if uniform else self.work[: self.S * self.G * parts], self.S, self.G, active=active, goal_count=self.goal_count,
-                                   slack=self.schedule_slack, out=self._sched_buf.get(key), device=self.device, parts=parts)
+                                   slack=self.schedule_slack, out=self._sched_buf.get(key), device=self.device, parts=parts,
+                                   longest_first=(not uniform) and self.S * self.G * parts <= self.LONGEST_FIRST_MAX_ITEMS)
         self._sched_buf[key] = out
         return out
 
@@ -700,7 +707,7 @@ class ChompEngine:
         if use_sched:
             cfg = self.cfg
             NP = self._np(cfg.timesteps - min(int(((self.t + 1) / cfg.optim_steps) * cfg.timesteps), cfg.timesteps - 1))  # the window of the launch to come
-            if self.schedule is None or self._sched_np != NP or (not self._measured and self._gs_launches >= 1 and self.S * self.G * self._parts_max >= 2048):
+            if self.schedule is None or self._sched_np != NP or (not self._measured and self._gs_launches >= 1 and self.S * self.G * self._parts_max >= self.MEASURE_MIN_ITEMS):
                 return False
         # the prepared calls belong to these very tensor objects (held here, so none of them can be freed and its identity reused)
         key = [getattr(self, k) for k in self._HOT_TENSORS] + [self.scenes.scene_begin]

@@ -355,12 +355,14 @@ def goalset_cost_layer_tiled(robot, P, scenes: DeviceScenes, traj_start, goals, 
 
 
 def goalset_schedule(work, num_scenes: int, num_goals: int, active=None, goal_count=None, slack: int = 2, out=None, device=None,
-                     parts: int = 1):
+                     parts: int = 1, longest_first: bool = False):
     """Dispatch order for goalset_cost_layer (omgx_goalset_schedule): int32 device tensor [omgx_goalset_schedule_len].
     work: int32/uint32 device tensor [S*G] of durations (None: all items weigh the same).  Asynchronous, one small launch.
     The result lives on the device of `out`, else of the first tensor given, else `device`.
     parts > 1 (omgx_goalset_schedule_parts): the items are the S * G * parts (scene, goal, part) workgroups of a launch with
-    split goals; work [S*G*parts]; goal_count still counts goals."""
+    split goals; work [S*G*parts]; goal_count still counts goals.
+    longest_first (omgx_goalset_schedule_ordered): inside an XCD the items run by decreasing work across its scenes — for launches of
+    a round or two of the chip's workgroup slots (falls back to the scene-major order above 8192 items)."""
     l = _lib.lib()
     parts = int(parts)
     n = int(l.omgx_goalset_schedule_len(num_scenes, num_goals * parts, slack))
@@ -375,7 +377,11 @@ def goalset_schedule(work, num_scenes: int, num_goals: int, active=None, goal_co
     _i32n(out, n, "schedule")
     _i32n(work, num_scenes * num_goals * parts, "work")
     with torch.cuda.device(out.device):
-        if parts != 1:
+        if longest_first:
+            check(l.omgx_goalset_schedule_ordered(_ptr(work), _ptr(_active(active, num_scenes)), _ptr(_active(goal_count, num_scenes)),
+                                                  num_scenes, num_goals, parts, slack, _lib.SCHEDULE_LONGEST_FIRST, _ptr(out), _stream()),
+                  "omgx_goalset_schedule_ordered")
+        elif parts != 1:
             check(l.omgx_goalset_schedule_parts(_ptr(work), _ptr(_active(active, num_scenes)), _ptr(_active(goal_count, num_scenes)),
                                                 num_scenes, num_goals, parts, slack, _ptr(out), _stream()), "omgx_goalset_schedule_parts")
         else:

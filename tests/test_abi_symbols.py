@@ -89,6 +89,8 @@ def test_goalset_parts_and_tiled_argument_checks_without_gpu():
     assert parts(sched=d, slen=12) == _lib.OMGX_ERR_INVALID  # a schedule's length is a multiple of 8
     assert lib.omgx_goalset_schedule_parts(None, None, None, 4, 64, 3, 2, d, None) == _lib.OMGX_ERR_INVALID
     assert lib.omgx_goalset_schedule_parts(None, None, None, 4, 64, 2, 2, None, None) == _lib.OMGX_ERR_INVALID
+    assert lib.omgx_goalset_schedule_ordered(None, None, None, 4, 64, 1, 2, 2, d, None) == _lib.OMGX_ERR_INVALID  # no such order
+    assert lib.omgx_goalset_schedule_ordered(None, None, None, 4, 64, 3, 2, 1, d, None) == _lib.OMGX_ERR_INVALID
     assert call(goals=None, traj=None, G=0) == _lib.OMGX_ERR_INVALID
     assert call(goals=None) == _lib.OMGX_ERR_INVALID
     assert call(n_rem=0) == _lib.OMGX_ERR_UNSUPPORTED and call(n_rem=65) == _lib.OMGX_ERR_UNSUPPORTED

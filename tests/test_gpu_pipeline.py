@@ -52,7 +52,7 @@ def test_pipelined_iterations_equal_the_single_stream_engine(dev, parts, ragged)
         one.iterate(t)
         two.iterate(t)
     assert two._parts is not None and len(two._parts) == parts
-    assert all(p._measured for p in two._parts) == (parts == 2)  # parts below 2048 items keep the even split
+    assert all(p._measured for p in two._parts)  # every part above ChompEngine.MEASURE_MIN_ITEMS (256) items has measured its own schedule
     _assert_same(one, two)
     # whole-batch operations join the side streams by themselves
     snap = two.snapshot()

@@ -111,6 +111,49 @@ def test_schedule_matches_the_integer_specification(dev, S, G, ragged, masked, k
             assert abs(load - share) <= wc[kept].max(), (x, load, share)
 
 
+@pytest.mark.parametrize("S,G,ragged,masked,kind,parts", [(13, 128, False, False, "measured", 1), (5, 64, True, True, "ties", 1),
+                                                           (25, 64, True, False, "skewed", 1), (4, 64, False, False, "measured", 4),
+                                                           (1, 64, False, False, "measured", 1)])
+def test_longest_first_inside_an_xcd(dev, S, G, ragged, masked, kind, parts):
+    """omgx_goalset_schedule_ordered(OMGX_SCHEDULE_LONGEST_FIRST): every item on the XCD the scene-major list gives it, an XCD's items
+    by decreasing work (ties: lower item first); above OMGX_SCHEDULE_LONGEST_FIRST_MAX_ITEMS items the scene-major order itself."""
+    from omg_planner_amd import _lib, ops
+    rng = np.random.RandomState(S * 17 + G + parts)
+    Gi = G * parts
+    if kind == "ties":
+        work = rng.randint(0, 3, S * Gi).astype(np.int32)
+    elif kind == "skewed":
+        work = (rng.pareto(1.2, S * Gi) * 2000 + 100).astype(np.int32)
+    else:
+        work = (rng.randint(4000, 30000, S)[:, None] * rng.uniform(0.3, 1.5, (S, Gi))).astype(np.int32).ravel()
+    goal_count = rng.randint(1, G + 1, S).astype(np.int32) if ragged else None
+    active = (rng.uniform(size=S) < 0.6).astype(np.int32) if masked else None
+    if masked:
+        active[0] = 1
+    base, _, kept = schedule_mirror(work, S, Gi, active, None if goal_count is None else goal_count * parts)
+    w = np.maximum(work.astype(np.int64), 1)
+    want = np.full_like(base, -1)
+    for x in range(8):
+        col = base.reshape(-1, 8)[:, x]
+        items = col[col >= 0]
+        items = np.array(sorted(items.tolist(), key=lambda i: (-int(w[i]), i)), np.int64)
+        want.reshape(-1, 8)[: len(items), x] = items
+    t = lambda a: None if a is None else torch.from_numpy(a).to(dev)
+    got = ops.goalset_schedule(t(work), S, G, active=t(active), goal_count=t(goal_count), device=dev, parts=parts, longest_first=True).cpu().numpy()
+    np.testing.assert_array_equal(got, want)
+    assert sorted(got[got >= 0].tolist()) == np.flatnonzero(kept.ravel()).tolist()
+
+
+def test_longest_first_falls_back_to_scene_major_for_large_launches(dev):
+    from omg_planner_amd import _lib, ops
+    S, G = 160, 64  # 10 240 items > OMGX_SCHEDULE_LONGEST_FIRST_MAX_ITEMS
+    assert S * G > _lib.SCHEDULE_LONGEST_FIRST_MAX_ITEMS
+    work = torch.from_numpy(np.random.RandomState(3).randint(1000, 30000, S * G).astype(np.int32)).to(dev)
+    a = ops.goalset_schedule(work, S, G, device=dev).cpu().numpy()
+    b = ops.goalset_schedule(work, S, G, device=dev, longest_first=True).cpu().numpy()
+    np.testing.assert_array_equal(a, b)
+
+
 def test_schedule_rejects_what_it_cannot_hold(dev):
     from omg_planner_amd import _lib, ops
     with pytest.raises(_lib.OmgHipError):

@@ -1,16 +1,10 @@
-#!/usr/bin/env python3
-"""Experiment: what would the pipeline gain if the update launch were LIGHT (workgroups that fit into a goal-set slot)?
-
-The real goal-set launches of k scene ranges on k streams, each followed by stand-ins for the update (tools/light_update_probe.hip:
-workgroups that stay resident for a given time with a given LDS footprint): `heavy` = 2 S workgroups x 35 us with 94 KB (today's
-k_update_optimize_split, to validate the stand-in against the real 285-290 us), `light` = a per-point stage of 3 S workgroups x
-12 us with 12 KB followed by a tail of S workgroups x 25 us with 16 KB.  Trajectories stay fixed (no real update), which does not
-change what a goal-set launch costs.
-    hipcc --offload-arch=gfx950 -O2 -shared -fPIC tools/light_update_probe.hip -o tools/_build/liblight_update_probe.so
-    python tools/ab_light_update.py --parts 2|3|4 --mode heavy|light
-"""
+"""Experiment (round 4): what would an update workgroup of another SHAPE do to the step?  Timing only.
+The two halves of the bench batch iterate on two streams like the pipeline does; the update launch is replaced by 2 S/2 workgroups of
+tools/spin_update.hip that hold (threads, LDS bytes, VGPRs) for `usec` and compute nothing (the trajectories therefore stay where they
+are: compare the stand-in shapes with each other and with `none`, not with `real`).
+    python tools/ab_light_update.py --shape none | real | THREADSxLDSxVGPRSxUSEC  (e.g. 512x96256x151x27, 256x31744x151x40)"""
 import argparse
-import ctypes as C
+import ctypes
 import json
 import sys
 import time
@@ -25,52 +19,54 @@ import bench  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--parts", type=int, default=2)
-    ap.add_argument("--mode", default="light", choices=["heavy", "light", "none"])
-    ap.add_argument("--scenes", type=int, default=100)
+    ap.add_argument("--shape", default="none")
     ap.add_argument("--iters", type=int, default=200)
+    ap.add_argument("--scenes", type=int, default=100)
+    ap.add_argument("--goals", type=int, default=64)
+    ap.add_argument("--parts", type=int, default=2)
+    ap.add_argument("--offset-usec", type=int, default=0, help="part k's stream starts every timed region k x this late (one idle workgroup)")
     a = ap.parse_args()
     from omg_planner_amd.engine import ChompEngine
-    probe = C.CDLL(str(ROOT / "tools" / "_build" / "liblight_update_probe.so"))
-    probe.probe_linger.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     dev = torch.device("cuda:0")
-    cfg, model, batch, start, goals = bench.build_workload(a.scenes, 64, 30, 64, 0, False)
+    spin = ctypes.CDLL(str(ROOT / "tools" / "spin_update.so"))
+    spin.spin_launch.argtypes = [ctypes.c_int] * 5 + [ctypes.c_void_p]
+    cfg, model, batch, start, goals = bench.build_workload(a.scenes, a.goals, 30, 64, 0, False)
     cuts = [a.scenes * k // a.parts for k in range(a.parts + 1)]
-    sink = torch.zeros(4096, dtype=torch.float64, device=dev)
-    parts = []
+    engs, sa = [], []
     for k in range(a.parts):
-        lo, hi = cuts[k], cuts[k + 1]
         st = torch.cuda.Stream(device=dev)
         with torch.cuda.stream(st):
-            e = ChompEngine(model, batch.subset(lo, hi), cfg, start[lo:hi], goals[lo:hi], device=dev, ol_alg="MD")
-            for t in range(4):
-                e.t = 0
-                e.iterate(0)
-        parts.append((e, st))
+            engs.append(ChompEngine(model, batch.subset(cuts[k], cuts[k + 1]), cfg, start[cuts[k]:cuts[k + 1]], goals[cuts[k]:cuts[k + 1]], device=dev, ol_alg="MD"))
+        sa.append(st)
     torch.cuda.synchronize()
+    shape = None if a.shape in ("none", "real") else [int(x) for x in a.shape.split("x")]
 
     def step():
-        for e, st in parts:
-            calls = e._hot[1]
-            e.t = 1
-            prm = e._learner_params()
-            calls.goalset_layer(prm.start_idx, False, e.schedule, None, st.cuda_stream)
-            h = C.c_void_p(st.cuda_stream)
-            if a.mode == "heavy":
-                probe.probe_linger(sink.data_ptr(), 2 * e.S, 35, 94 * 1024, h)
-            elif a.mode == "light":
-                probe.probe_linger(sink.data_ptr(), 3 * e.S, 12, 12 * 1024, h)
-                probe.probe_linger(sink.data_ptr(), e.S, 25, 16 * 1024, h)
+        for e, A in zip(engs, sa):
+            e.t = 0
+            with torch.cuda.stream(A):
+                if a.shape == "real":
+                    e.iterate(0)
+                    continue
+                e.update_goal(defer_update=True, with_layer=True)   # the goal-set + layer launch
+                if shape:
+                    rc = spin.spin_launch(2 * e.S, shape[0], shape[1], shape[2], shape[3], A.cuda_stream)
+                    assert rc == 0, rc
 
     for _ in range(10):
         step()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.iters):
-        step()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    print(json.dumps({"parts": a.parts, "mode": a.mode, "us_per_iteration_of_all_scenes": round(dt / a.iters * 1e6, 1)}))
+    out = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        if a.offset_usec:
+            for k in range(1, a.parts):
+                spin.spin_launch(1, 64, 0, 79, k * a.offset_usec, sa[k].cuda_stream)
+        for _ in range(a.iters):
+            step()
+        torch.cuda.synchronize()
+        out.append((time.perf_counter() - t0) / a.iters * 1e3)
+    print(json.dumps({"shape": a.shape, "scenes": a.scenes, "goals": a.goals, "parts": a.parts, "offset_usec": a.offset_usec, "ms_per_step": [round(x, 4) for x in out]}), flush=True)
 
 
 if __name__ == "__main__":

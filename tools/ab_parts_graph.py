@@ -32,8 +32,11 @@ def main():
     ap.add_argument("--split", default="auto", help="auto | 0 | 1: learner and step in two workgroups")
     ap.add_argument("--goal-parts", type=int, default=1, help="workgroups per goal in the batch layout (ChompEngine(goal_parts=...))")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--measure-min", type=int, default=None, help="ChompEngine.MEASURE_MIN_ITEMS for this run")
     a = ap.parse_args()
     from omg_planner_amd.engine import ChompEngine
+    if a.measure_min is not None:
+        ChompEngine.MEASURE_MIN_ITEMS = a.measure_min
     dev = torch.device("cuda:0")
     cfg, model, batch, start, goals = bench.build_workload(a.scenes, a.goals, 30, 64, 0, False)
     for k in [int(x) for x in a.parts.split(",")]:
@@ -64,7 +67,7 @@ def main():
         torch.cuda.synchronize()
         eager = (time.perf_counter() - t0) / a.iters * 1e3
         if a.no_graph:
-            print(json.dumps({"scenes": a.scenes, "goals": a.goals, "latency_mode": a.latency, "goal_parts": a.goal_parts, "parts": k,
+            print(json.dumps({"scenes": a.scenes, "goals": a.goals, "latency_mode": a.latency, "goal_parts": a.goal_parts, "parts": k, "measure_min": a.measure_min,
                               "ms_per_step_eager": round(eager, 4)}), flush=True)
             del eng
             continue

@@ -46,7 +46,7 @@ lib.omgx_debug_gs_counts(buf, 1)
 c = [buf[i] / (launches * S * G) for i in range(16)]
 names = ["waves", "tiles visited", "tiles entered (a row in reach)", "(tile, object) iterations with a row in reach", "far tests (per link)",
          "far tests with a live lane", "weights computed", "enqueue calls", "issue calls (exact-path batches)", "live lanes enqueued",
-         "(tile, object) iterations", "contributing entries"]
+         "(tile, object) iterations", "contributing entries", "far tests if tiles were 2 waypoints x 2 links", "enqueue calls if tiles were 2 x 2"]
 for n, v in zip(names, c):
     print(f"{n:50s} {v:10.1f} per goal workgroup")
 if json_out:

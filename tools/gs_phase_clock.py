@@ -38,10 +38,11 @@ def main():
     # per-workgroup timeline of the LAST launch: 100 MHz realtime stamps at entry / after the prologue / at exit + hardware id
     import numpy as np
     nwg = ((S + 7) // 8) * 5 * 8 + max(((S + 7) // 8) * G * 8, 0 if eng.schedule is None else int(eng.schedule.numel()))
-    wg = (C.c_ulonglong * (8 * nwg))()
+    base = (S & 1) << 14  # the instrumented kernel keeps the stamps of a launch with an odd number of scenes apart (tools/gs_two_queue_clock.py)
+    wg = (C.c_ulonglong * (8 * (base + nwg)))()
     lib.omgx_debug_gs_wg.argtypes = [C.c_void_p, C.c_int]
-    assert lib.omgx_debug_gs_wg(wg, nwg) == 0
-    w = np.array(list(wg), dtype=np.uint64).reshape(nwg, 8)
+    assert lib.omgx_debug_gs_wg(wg, base + nwg) == 0
+    w = np.frombuffer(wg, dtype=np.uint64).reshape(base + nwg, 8)[base:].copy()
     # stamps of the LAST launch only: blocks that were empty in it may still carry an earlier launch's stamps (other schedule)
     ran = (w[:, 4] > 0) & (w[:, 0] + np.uint64(100000) > w[:, 4].max()) & (w[:, 4] > w[:, 0])
     t0 = w[ran, 0].min()
