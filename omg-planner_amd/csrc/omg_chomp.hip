@@ -255,7 +255,10 @@ __device__ __forceinline__ void apply_ainv(const double* __restrict__ in, double
 template <int MAXIT>  // items (16-lane groups of potentials) per thread the prefetch loops are unrolled for: ceil(n * 160 / CH_TPB) <= MAXIT
 __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* smem, const int s, const uint32_t* wait_goal = nullptr,
                                             const uint32_t ticket = 0) {
-    if (a.active && a.active[s] == 0) return;
+    // The scene's `active` word is REQUESTED here and tested in front of the first barrier, behind the requests of everything else the
+    // workgroup starts from: tested at once it is a trip to memory of its own (~2 us after a launch boundary) ahead of all the others.
+    // Until then nothing is written but LDS.
+    const int scene_active = a.active ? a.active[s] : 1;
     const omgx_chomp_params& prm = a.prm;
     const int n = prm.n_waypoints, P = prm.n_points, c = prm.constraint_num;
     const double dt = prm.time_interval, dt2 = dt * dt;
@@ -263,7 +266,6 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
     const Lds L = carve(smem, n, P, a.pot_in_lds != 0);
     const RobotView rv(a.robot, P);
     const int tid = threadIdx.x;
-    bool wait_failed = false;  // thread 0: the bounded wait for the learner's workgroup ran out
     const int total = n * 10 * P;             // reference flat size of potentials [n][10][P]
     const int nitems = n * 160;               // 16-lane groups: item = (i*10 + l)*16 + p
     const float* pot = a.pot + (size_t)s * total;
@@ -275,16 +277,18 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
 
     // ---------------------------------------------------------------- phase 0: loads + FK
     PHASE_MARK(0);
-    for (int e = tid; e < n * 9; e += blockDim.x) L.xi[e] = traj[e];
-    for (int e = tid; e < 30 * P; e += blockDim.x) L.pts[e] = rv.pts(0, 0)[e];
-    for (int e = tid; e < 60; e += blockDim.x) L.jconst[e] = (e % 6 < 3) ? rv.ax(e / 6)[e % 6] : rv.og(e / 6)[e % 6 - 3];
-    for (int e = tid; e < 256; e += blockDim.x) L.hist[e] = 0;
-    for (int e = tid; e < (nitems + 31) / 32; e += blockDim.x) L.tie[e] = 0;
-    for (int e = tid; e < 246; e += blockDim.x) L.fkc[e] = rv.uvw(0)[e];  // chain constants: LDS reads instead of scalar loads per joint
-    if (tid == 0) { L.iscr[2] = 0; L.red[50] = 0.0; L.red[51] = 0.0; }
+    // Everything the workgroup starts from is REQUESTED before anything is stored: written as copy loops, every loop was a trip to
+    // memory of its own (load, wait, LDS store — six in a row, 8 K of the step's 55 K cycles: tools/phase_timing.py and the ISA).
+    // One element per thread and array (two of the trajectory beyond 56 waypoints).
+    static_assert(CH_TPB >= 480 && 2 * CH_TPB >= OMGX_MAX_WAYPOINTS * 9, "phase 0 keeps one element per thread of the points / constants and two of the trajectory");
+    const double r_xi0 = tid < n * 9 ? traj[tid] : 0.0, r_xi1 = tid + CH_TPB < n * 9 ? traj[tid + CH_TPB] : 0.0;
+    const double r_pts = tid < 30 * P ? rv.pts(0, 0)[tid] : 0.0;
+    const int jc_j = tid < 60 ? tid / 6 : 0, jc_k = tid < 60 ? tid % 6 : 0;
+    const int jc_off = jc_k < 3 ? 3 * jc_j + jc_k : 30 + 3 * jc_j + jc_k - 3;  // ax | og are neighbours in the robot blob: ONE load behind a
+    const double r_jc = rv.ax(0)[jc_off];                                       // selected offset (two loads in a branch wait for each other)
+    const double r_fkc = tid < 246 ? rv.uvw(0)[tid] : 0.0;  // chain constants: LDS reads instead of scalar loads per joint
     // This thread's potentials / collision flags: all loads are issued back to back (one memory latency instead of
-    // one per item) and stay in flight while the FK waves work; first use is after the FK.
-    // Items it = r * CH_TPB + tid, item = (i*10 + l)*16 + p.
+    // one per item); first use is after the FK.  Items it = r * CH_TPB + tid, item = (i*10 + l)*16 + p.
     float pv[MAXIT], cv[MAXIT];
     if (L.potl) {
 #pragma unroll
@@ -296,11 +300,49 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
             cv[r] = col[f];
         }
     }
+    // Poses the caller hands over (omgx_chomp_params: the layer launch's waypoint poses, the tabulated start / end poses) are copied
+    // HERE, with the loads above: one trip to memory for everything.  What is not handed over is computed below: same code either
+    // way, same bits.
+    const int ncfg = n + 2;
+    const double* wp = prm.waypoint_poses ? prm.waypoint_poses + (size_t)s * n * 120 : nullptr;
+    const double* sp = prm.start_poses ? prm.start_poses + (size_t)s * 120 : nullptr;
+    const double* ep = (!wait_goal && prm.end_poses) ? prm.end_poses + (size_t)s * 120 : nullptr;
+    constexpr int PB = 8;  // 8 x 512 doubles = 34 waypoints' poses per round
+    double pvv[PB];
+    if (wp) {
+#pragma unroll
+        for (int r = 0; r < PB; ++r) {
+            const int e = r * CH_TPB + tid;
+            pvv[r] = wp[e < n * 120 ? e : 0];
+        }
+    }
+    const double r_sp = (sp && tid < 120) ? sp[tid] : 0.0, r_ep = (ep && tid < 120) ? ep[tid] : 0.0;
+    PHASE_MARK_T(30, 0);
+    // ---- the stores
+    if (tid < n * 9) L.xi[tid] = r_xi0;
+    PHASE_MARK_T(31, 0);
+    if (tid + CH_TPB < n * 9) L.xi[tid + CH_TPB] = r_xi1;
+    if (tid < 30 * P) L.pts[tid] = r_pts;
+    if (tid < 60) L.jconst[tid] = r_jc;
+    if (tid < 246) L.fkc[tid] = r_fkc;
+    for (int e = tid; e < 256; e += blockDim.x) L.hist[e] = 0;
+    for (int e = tid; e < (nitems + 31) / 32; e += blockDim.x) L.tie[e] = 0;
+    if (tid == 0) { L.iscr[2] = 0; L.red[50] = 0.0; L.red[51] = 0.0; L.red[53] = 0.0; L.red[54] = 0.0; L.red[55] = 0.0; }
+    if (wp) {
+#pragma unroll
+        for (int r = 0; r < PB; ++r) {
+            const int e = r * CH_TPB + tid;
+            if (e < n * 120) L.pose[120 + e] = pvv[r];
+        }
+        for (int e = PB * CH_TPB + tid; e < n * 120; e += CH_TPB) L.pose[120 + e] = wp[e];  // beyond 34 waypoints
+    }
+    if (sp && tid < 120) L.pose[tid] = r_sp;
+    if (ep && tid < 120) L.pose[(size_t)(ncfg - 1) * 120 + tid] = r_ep;
+    if (scene_active == 0) return;  // workgroup-uniform, before any barrier and any global write
     __syncthreads();
     PHASE_MARK_T(16, CH_TPB - 128);
     // FK of start, waypoints, end (cost.py:124-165) in two stages (omg_device.h: fk_chain_row); the (sin, cos) table
     // borrows L.gl, which is first written in phase 2/3.
-    const int ncfg = n + 2;
     double* sc = L.gl;  // [ncfg][7][2]
     auto config_of = [&](int cfg) { return cfg == 0 ? start : (cfg == ncfg - 1 ? end : L.xi + 9 * (cfg - 1)); };
     const RobotView rvl(a.robot, P, L.fkc);
@@ -325,21 +367,13 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
         }
         __syncthreads();
     };
-    // Poses the caller hands over (omgx_chomp_params: the layer launch's waypoint poses, the tabulated start / end poses) are copied,
-    // the rest is computed here: same code either way, same bits.  The end configuration is the goal: later, if it is not known yet.
+    // What was not handed over (copied above, in front of the barrier).  The end configuration is the goal: later, if it is not known yet.
     {
-        const double* wp = prm.waypoint_poses ? prm.waypoint_poses + (size_t)s * n * 120 : nullptr;
-        const double* sp = prm.start_poses ? prm.start_poses + (size_t)s * 120 : nullptr;
-        const double* ep = (!wait_goal && prm.end_poses) ? prm.end_poses + (size_t)s * 120 : nullptr;
-        if (wp) for (int e = tid; e < n * 120; e += blockDim.x) L.pose[120 + e] = wp[e];
-        if (sp) for (int e = tid; e < 120; e += blockDim.x) L.pose[e] = sp[e];
-        if (ep) for (int e = tid; e < 120; e += blockDim.x) L.pose[(size_t)(ncfg - 1) * 120 + e] = ep[e];
         const bool need_end = !wait_goal && !ep;
         if (!wp) fk_configs(sp ? 1 : 0, (need_end ? ncfg : ncfg - 1), sc);  // start (unless given) + waypoints (+ end)
         else {
             if (!sp) fk_configs(0, 1, sc);
             if (need_end) fk_configs(ncfg - 1, ncfg, sc);
-            if (sp && !need_end) __syncthreads();  // the copies
         }
     }
     PHASE_MARK_T(17, CH_TPB - 128);
@@ -667,7 +701,7 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
                 do {
                     __builtin_amdgcn_s_sleep(4);
                     if (wall_clock64() - t0 > 200000000LL) {  // 2 s: the producer is gone; fail loudly instead of hanging the device
-                        wait_failed = true;
+                        L.red[53] = 1.0;  // the wait ran out: the thread that writes `info` reports NaN
                         break;
                     }
                 } while (__hip_atomic_load(wait_goal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ticket);
@@ -807,7 +841,11 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
     double collide = 0.0;
     for (int wv = 0; wv < CH_WAVES; ++wv) collide += L.red[56 + wv];
 
-    if (tid == 0) {
+    // The scalars of `info` (four square roots, a norm, 16 stores: 2.6 K cycles of one thread) are written by a thread of the LAST wave,
+    // which has no element of the [n][9] loops below: the other waves go on to the projected step meanwhile (they used to wait for
+    // thread 0 at the next barrier).  Thread 0's bounded wait reports a failure through L.red[53] (written before the barriers above).
+    if (tid == CH_TPB - 64) {
+        const bool wait_failed = L.red[53] > 0.0;
         double goal_dist = 0.0;
         if (prm.goal_set_proj) {
             const double* gp = goalc;
@@ -850,7 +888,8 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
 
     // ---------------------------------------------------------------- phase 6: covariant (projected) step
     PHASE_MARK(6);
-    __syncthreads();
+    // (no barrier here: L.g is complete since the barrier before the block sums, L.tvs has no reader left, and `info`'s thread reads
+    // L.xi / L.red, which change only behind the barriers below)
     apply_ainv(L.g, L.tvs, n, free_end, dt2);  // Ag = Ainv g
     __syncthreads();
     PHASE_MARK_T(15, 0);
@@ -887,14 +926,25 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
     int cnt = 0;
     for (;;) {
         __syncthreads();
+        int out_of_range = 0;
         for (int e = tid; e < n * 9; e += blockDim.x) {  // compute_traj_v
             const int d = e % 9;
             const double x = L.xi[e];
             const double t = (x < lower[d] ? lower[d] - x : 0.0) + (x > upper[d] ? upper[d] - x : 0.0);
             L.tv[e] = t;
             L.g[e] = t * t;
+            out_of_range |= (t != 0.0) ? 1 : 0;  // (NaN counts: its sum must be formed)
         }
-        const double nrm2 = block_sum(L, L.g, n * 9, 5);
+        // the usual case — every joint inside its limits — needs no sum: all terms are +0.0 and so is their sum, in any order; one
+        // barrier behind a vote instead of block_sum's two barriers around a single wave's walk over the array
+        // (the vote goes through an LDS word per parity of the pass — __syncthreads_or would bring static LDS, and this kernel
+        // asks for all of the CU's as dynamic: thread 0 clears the other parity's word for the next pass behind the barrier)
+        double* const vote = L.red + 54 + (cnt & 1);
+        if (out_of_range) *vote = 1.0;  // benign same-value race
+        __syncthreads();
+        const bool any_out = *vote > 0.0;
+        if (tid == 0) L.red[54 + ((cnt + 1) & 1)] = 0.0;
+        const double nrm2 = any_out ? block_sum(L, L.g, n * 9, 5) : 0.0;
         if (!(sqrt(nrm2) > 1e-2) || cnt >= prm.joint_limit_max_steps) break;
         apply_ainv(L.tv, L.tvs, n, free_end, dt2);
         __syncthreads();
@@ -948,8 +998,9 @@ __global__ __launch_bounds__(CH_TPB) void k_update_optimize_split(omg_learner::L
         if (blockIdx.x == 0 && threadIdx.x == 0) g_chomp_phase[26] = __builtin_readcyclecounter();
 #endif
         double* shl = reinterpret_cast<double*>(smem);
+        int* const sh_idx = reinterpret_cast<int*>(shl + 5 * OMGX_MAX_GOALS + 5 * 128);  // the chosen goal, for the whole workgroup
         omg_learner::learner_scene(la, blockIdx.x, reinterpret_cast<double (*)[OMGX_MAX_GOALS]>(shl),
-                                   reinterpret_cast<double (*)[128]>(shl + 5 * OMGX_MAX_GOALS));
+                                   reinterpret_cast<double (*)[128]>(shl + 5 * OMGX_MAX_GOALS), sh_idx);
         __syncthreads();
         // The kinematics of the chosen end configuration (a 3-lane serial chain, ~7 K cycles) run HERE, where nothing waits for
         // them, instead of in the step's workgroup right after its wait.  The 10 x 12 doubles travel in the scene's `grad`
@@ -959,14 +1010,15 @@ __global__ __launch_bounds__(CH_TPB) void k_update_optimize_split(omg_learner::L
             // Fewer than 14 waypoints: the pose does not travel through the grad rows (the step's workgroup runs the end
             // configuration's kinematics itself), but `end_poses_out` must still follow the goal — the launches of the plan that
             // come after the goal-selecting iterations (k_chomp_optimize) take their end pose from it.
-            const double* src = la.prm.goal_pose_table + ((size_t)blockIdx.x * la.prm.num_goals + la.goal_idx[blockIdx.x]) * 120;
+            const double* src = la.prm.goal_pose_table + ((size_t)blockIdx.x * la.prm.num_goals + *sh_idx) * 120;
             if (threadIdx.x < 120) la.prm.end_poses_out[(size_t)blockIdx.x * 120 + threadIdx.x] = src[threadIdx.x];
         }
         if (end_pose_fits(a.prm.n_waypoints) && scene_on) {
             double* out = a.grad + (size_t)blockIdx.x * a.prm.n_waypoints * 9;
             if (la.prm.goal_pose_table) {
-                // the goals' poses were tabulated for the plan (omgx_pose_table): the chosen goal's 120 doubles are copied
-                const double* src = la.prm.goal_pose_table + ((size_t)blockIdx.x * la.prm.num_goals + la.goal_idx[blockIdx.x]) * 120;
+                // the goals' poses were tabulated for the plan (omgx_pose_table): the chosen goal's 120 doubles are copied (the index
+                // comes through LDS: reading back the word wave 0 has just stored costs a trip to L2 on the iteration's critical path)
+                const double* src = la.prm.goal_pose_table + ((size_t)blockIdx.x * la.prm.num_goals + *sh_idx) * 120;
                 if (threadIdx.x < 120) {
                     const double v = src[threadIdx.x];
                     out[threadIdx.x] = v;
@@ -1119,7 +1171,7 @@ extern "C" int omgx_goal_update_optimize(const omgx_learner_params* h_learner, c
         if (!active) return OMGX_ERR_INVALID;
         a.deactivate = active;
     }
-    const size_t learner_lds = (size_t)(5 * OMGX_MAX_GOALS + 5 * 128) * sizeof(double);
+    const size_t learner_lds = (size_t)(5 * OMGX_MAX_GOALS + 5 * 128 + 2) * sizeof(double);  // + the chosen goal's index (k_update_optimize_split)
     if (lds < learner_lds) lds = learner_lds;
     const bool small = fits_small(a.prm.n_waypoints);
     if (scene_flags) {

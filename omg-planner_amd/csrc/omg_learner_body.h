@@ -178,8 +178,12 @@ __device__ void bregman_projection(const double* x, const double* v, double delt
 
 
 // All threads of the workgroup call this (>= 5 waves for MD); sh_pn [5][OMGX_MAX_GOALS] and sh_tab [5][128] are LDS.
-__device__ __forceinline__ void learner_scene(const LearnerArgs& a, int s, double (*sh_pn)[OMGX_MAX_GOALS], double (*sh_tab)[128]) {
-    if (a.active && a.active[s] == 0) return;  // workgroup-uniform
+// sh_idx (LDS, optional): receives the chosen goal's index — valid for the workgroup after its next barrier (active scenes only).
+__device__ __forceinline__ void learner_scene(const LearnerArgs& a, int s, double (*sh_pn)[OMGX_MAX_GOALS], double (*sh_tab)[128], int* sh_idx = nullptr) {
+    // The scene's `active` word is REQUESTED here and tested where the first write would happen, behind the requests of the cost vector's
+    // inputs (and the experts' distributions): tested at once it is a trip to memory of its own — ~2 us after a launch boundary, on
+    // the critical path of every iteration (goal costs -> learner -> the step's tail) — ahead of all the others.
+    const int scene_active = a.active ? a.active[s] : 1;  // workgroup-uniform
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     LPHASE(0, 4);
     if (a.prm.alg != OMGX_ALG_MD && wave > 0) return;  // no barrier on these paths
@@ -192,8 +196,22 @@ __device__ __forceinline__ void learner_scene(const LearnerArgs& a, int s, doubl
     double* st = a.state + (int64_t)s * (7 * (int64_t)GS + 10);
     double *sum_costs = st, *p = st + GS, *experts_p = st + 2 * GS, *q = st + 7 * GS, *ecost = st + 7 * GS + 5;
     const double* gs = a.goal_set + (int64_t)s * GS * 9;
+    // MD: this wave's expert distribution (last iteration's), requested with everything else (padded lanes: masked at the use)
+    double epw_pre[NPL] = {0, 0, 0, 0};
+    if (prm.alg == OMGX_ALG_MD && wave < 5) {
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) {
+            const int g = lane + 64 * j;
+            if (g < GS) epw_pre[j] = experts_p[(int64_t)wave * GS + g];
+        }
+    }
+    // ... and the mixture's state (wave 0, lanes 0-4: expert k's weight and last cost)
+    const int kk_pre = lane < 5 ? lane : 0;
+    double q_pre = 0.0, ecost_pre = 0.0;
+    if (prm.alg == OMGX_ALG_MD && wave == 0) { q_pre = q[kk_pre]; ecost_pre = ecost[kk_pre]; }
     int idx = 0;
     if (prm.alg == OMGX_ALG_PROJ) {  // :196-206
+        if (scene_active == 0) return;
         const double* last = a.traj + ((int64_t)s * n + n - 1) * 9;
         double best = OMG_ARG_NEUTRAL_MIN;
         int bi = 0x7fffffff;
@@ -236,6 +254,7 @@ __device__ __forceinline__ void learner_scene(const LearnerArgs& a, int s, doubl
             const double nn = sqrt(wsum(part));
             for (int j = 0; j < NPL; ++j) cv[j] /= nn;
         }
+        if (scene_active == 0) return;  // nothing has been written yet (all waves take the same branch: no barrier is skipped by some)
         if (a.cost_vector && wave == 0)
             for (int j = 0; j < NPL; ++j) { const int g = lane + 64 * j; if (g < G) a.cost_vector[(int64_t)s * GS + g] = cv[j]; }
 
@@ -282,7 +301,7 @@ __device__ __forceinline__ void learner_scene(const LearnerArgs& a, int s, doubl
                 for (int j = 0; j < NPL; ++j) {
                     const int g = lane + 64 * j;
                     v[j] = eta * pw[wave] * cv[j];
-                    epw[j] = g < G ? experts_p[(int64_t)wave * GS + g] : 0.0;
+                    epw[j] = g < G ? epw_pre[j] : 0.0;
                 }
                 LPHASE(1, 4);
                 bregman_projection(epw, v, delta, G, lane, pn);
@@ -312,9 +331,9 @@ __device__ __forceinline__ void learner_scene(const LearnerArgs& a, int s, doubl
                 for (int j = 0; j < NPL; ++j) { const int g = lane + 64 * j; ep[i][j] = g < G ? sh_pn[i][g] : 0.0; }
             }
             {
-                const int kk = lane < 5 ? lane : 0;
-                const double e_new = exp(-1.0 * sh_tab[kk][0]), e_old = exp(-1.0 * ecost[kk]);
-                double ql = q[kk];
+                const int kk = kk_pre;
+                const double e_new = exp(-1.0 * sh_tab[kk][0]), e_old = exp(-1.0 * ecost_pre);
+                double ql = q_pre;
                 for (int i = 0; i < 5; ++i) {
                     ql = ql * (kk <= i ? e_new : e_old);
                     double qs = 0.0;
@@ -349,7 +368,7 @@ __device__ __forceinline__ void learner_scene(const LearnerArgs& a, int s, doubl
     }
     LPHASE(5, 0);
     // traj.end / goal rows (online_learner.py:243-245, optimizer.py:93-99)
-    if (lane == 0) a.goal_idx[s] = idx;
+    if (lane == 0) { a.goal_idx[s] = idx; if (sh_idx) *sh_idx = idx; }
     if (lane < 9) {
         const double v = gs[idx * 9 + lane];
         a.end[s * 9 + lane] = v;

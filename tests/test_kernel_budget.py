@@ -62,3 +62,23 @@ def test_goalset_kernel_lds_fits_five_workgroups_per_cu():
     assert n == 8 and total(31, 30, 15, n) <= 31744
     assert total(65, 64, 16, choose(65, 64, 16)) <= 64 * 1024
     assert "__shared__ float" not in src  # no static LDS on top of the dynamic allocation
+
+
+@pytest.mark.skipif(not Path(HIPCC).exists(), reason="hipcc not installed")
+def test_update_kernels_have_no_static_lds(tmp_path):
+    """k_update_optimize_split / k_update_optimize / k_chomp_optimize ask for up to all of a CU's LDS as DYNAMIC memory
+    (hipFuncSetAttribute(..., 160 KB)): any static allocation on top — a `__shared__` variable, or a library helper that brings one,
+    like __syncthreads_or — makes that call fail on the device.  Checked here on the compiled metadata, without a GPU."""
+    out = tmp_path / "omg_chomp.s"
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", f"-I{ROOT / 'include'}",
+             f"-I{ROOT / 'omg-planner_amd' / 'csrc'}", "--cuda-device-only", "-S"]
+    subprocess.run([HIPCC, *flags, str(ROOT / "omg-planner_amd" / "csrc" / "omg_chomp.hip"), "-o", str(out)], check=True,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    text = out.read_text()
+    seen = 0
+    for m in re.finditer(r"\.group_segment_fixed_size: (\d+)[\s\S]*?\.name:\s+(\S+)", text):
+        size, name = int(m.group(1)), m.group(2)
+        if "k_update_optimize" in name or "k_chomp_optimize" in name:
+            seen += 1
+            assert size == 0, f"{name} has {size} B of static LDS"
+    assert seen >= 4, seen  # split, fused and plain kernels in both item-count variants

@@ -22,6 +22,8 @@ from omg_planner_amd.engine import ChompEngine
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 cfg, model, batch, start, goals = bench.build_workload(S, 64, 30, 64, 0, True)
 eng = ChompEngine(model, batch, cfg, start, goals, device="cuda:0", ol_alg="MD")
+if os.environ.get("OMGX_PT_POSES", "1") != "0":  # as inside plan() and bench.py: the launches hand the link poses to each other
+    eng.pose_hand_over(True)
 lib = _lib.lib()
 for it in range(12):
     eng.iterate(it)
@@ -35,6 +37,6 @@ for it in range(12):
     d = np.diff(t[:9])
     print("   phase starts relative to phase 0:", (t[:9] - t[0]).astype(int).tolist())
     print(f"iteration {it}: step workgroup phases 0..7 [shader-clock cycles, ~2.2 GHz]:", d.astype(int).tolist(), "total", int(t[8] - t[0]))
-    print("   extra marks relative to phase 0:", {k: int(t[k] - t[0]) for k in list(range(9, 16)) + list(range(16, 30)) if t[k] > 0 and k not in (26, 27)})
+    print("   extra marks relative to phase 0:", {k: int(t[k] - t[0]) for k in list(range(9, 16)) + list(range(16, 32)) if t[k] > 0 and k not in (26, 27)})
     print("   learner wave 4 [shader-clock cycles, ~2.2 GHz]: cost vector", int(l[1] - l[0]), "projection", int(l[2] - l[1]), "expert cost", int(l[3] - l[2]),
           "| wave 0: mixture", int(l[5] - l[4]), "| whole learner workgroup", int(t[27] - t[26]), "| outer iterations of expert 4:", int(l[8]))
