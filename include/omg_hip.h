@@ -436,10 +436,12 @@ int omgx_goal_update(const omgx_learner_params* h_params, const double* traj, co
  * The two parameter blocks must agree on n_waypoints and constraint_num.
  *   scene_flags  optional [S] int32 device scratch, zeroed once by the caller.  When given, the goal update and the
  *                goal-independent part of the step (FK, top-k, per-point costs, most gradients) run in different
- *                workgroups of the launch and meet through scene_flags[s] == ticket; `ticket` must differ from every
- *                value still stored there (use 1, 2, 3, ... per call).  NULL: one workgroup per scene does both in turn.
- *                In this mode a scene's `grad` rows also carry the end configuration's link poses from the learner's workgroup
- *                to the step's (from 14 waypoints on) before the gradient is written over them: `grad` must not alias anything.
+ *                workgroups of the launch and meet through the scene's word: the learner's workgroup stores
+ *                (ticket << 8) | chosen goal there (ABI 9; one relaxed store, the moment the goal is known), the step's
+ *                workgroup waits for the ticket and reads the goal's configuration, rows and poses from goal_set / reach /
+ *                goal_pose_table itself — `end`, `goal`, `goal_point` are still written, for the launches that follow.  `ticket`
+ *                in [1, 2^24) and different from every ticket still stored there (use 1, 2, 3, ... per call, wrapping long
+ *                before 2^24).  NULL: one workgroup per scene does both in turn.
  *   stop_on_terminate  non-zero: a scene whose info says `terminate` after this step gets active[s] = 0 (active must be
  *                given), i.e. it leaves the planner loop like `if self.info[-1]["terminate"] and t > 0: break`
  *                (omg/planner.py:626) — later launches that take the mask skip it.

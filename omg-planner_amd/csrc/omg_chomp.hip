@@ -77,9 +77,6 @@ struct ChompArgs {
 };
 
 // wrap_joint(l+1) (omg/util.py:213-220): k-th joint index (into the 10-joint tables) of link l; count via njoints().
-// k_update_optimize_split hands the end configuration's 10 x 12 pose doubles from the learner's workgroup to the step's through the
-// scene's grad rows [n][9]: possible from 14 waypoints on
-__device__ __forceinline__ bool end_pose_fits(int n) { return n * 9 >= 120; }
 __device__ __forceinline__ int njoints(int l) { return l < 7 ? l + 1 : (l == 7 ? 7 : 8); }
 __device__ __forceinline__ int joint_of(int l, int k) { return k < 7 ? k : l; /* k==7: finger joint 8 or 9 == link index */ }
 // wrap_index(l+1) (omg/util.py:205-210): trajectory column of slot k of link l.
@@ -254,7 +251,7 @@ __device__ __forceinline__ void apply_ainv(const double* __restrict__ in, double
 // gradients of all but the last waypoint — runs first, then thread 0 waits for *wait_goal == ticket.
 template <int MAXIT>  // items (16-lane groups of potentials) per thread the prefetch loops are unrolled for: ceil(n * 160 / CH_TPB) <= MAXIT
 __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* smem, const int s, const uint32_t* wait_goal = nullptr,
-                                            const uint32_t ticket = 0) {
+                                            const uint32_t ticket = 0, const omg_learner::LearnerArgs* la = nullptr) {
     // The scene's `active` word is REQUESTED here and tested in front of the first barrier, behind the requests of everything else the
     // workgroup starts from: tested at once it is a trip to memory of its own (~2 us after a launch boundary) ahead of all the others.
     // Until then nothing is written but LDS.
@@ -273,7 +270,7 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
     const float* col = a.col + (size_t)s * total;
     double* traj = a.traj + (size_t)s * n * 9;
     const double* start = a.start + 9 * (size_t)s;
-    const double* end = a.end + 9 * (size_t)s;
+    const double* end = a.end + 9 * (size_t)s;  // (with a ticket: re-pointed at the chosen goal's row of the goal set once it is known)
 
     // ---------------------------------------------------------------- phase 0: loads + FK
     PHASE_MARK(0);
@@ -641,8 +638,9 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
     }
     PHASE_MARK_T(9, 0);
     const double* w = prm.link_smooth_weight;
-    auto obstacle_rows = [&](const int e_begin, const int e_end) {  // obstacle gradient [n][9] from the groups' J.g
-        for (int e = e_begin + tid; e < e_end; e += blockDim.x) {
+    // (t0, nt): the calling threads' index and number — the whole workgroup, or a group of its waves beside another group's work
+    auto obstacle_rows = [&](const int e_begin, const int e_end, const int t0, const int nt) {  // obstacle gradient [n][9] from the groups' J.g
+        for (int e = e_begin + t0; e < e_end; e += nt) {
             const int i = e / 9, d = e % 9;
             double sgrad = 0.0;
             for (int l = 0; l < mlinks; ++l) {  // ascending link order = the reference's += order
@@ -654,8 +652,8 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
             L.og[e] = sgrad;
         }
     };
-    auto smooth_terms = [&]() {  // needs the end configuration only for a fixed end (not goal-set mode)
-        for (int e = tid; e < n * 9; e += blockDim.x) {
+    auto smooth_elements = [&](const int t0, const int nt) {  // needs the end configuration only for a fixed end (not goal-set mode)
+        for (int e = t0; e < n * 9; e += nt) {
             const int i = e / 9, d = e % 9;
             // compute_smooth_loss gradient: A xi + D1^T ed (cost.py:447-448)
             const double xc = L.xi[e];
@@ -669,7 +667,7 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
         // lanes — one lane per row walked them in turn: 6 K of the step's 68 K cycles — and parked in L.tv (+ the first row of
         // L.tvs behind it: both are free until phase 5); the row's lane then adds their squares in joint order, as before.
         double* const evs = L.tv;  // [(n + 1)][9]
-        for (int e = tid; e < (n + 1) * 9; e += blockDim.x) {
+        for (int e = t0; e < (n + 1) * 9; e += nt) {
             const int i = e / 9, d = e % 9;
             double vel;
             if (i == 0) vel = L.xi[d] / dt + (-1.0 * start[d] / dt);
@@ -677,7 +675,9 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
             else vel = free_end ? 0.0 : (-L.xi[(n - 1) * 9 + d] / dt + end[d] / dt);
             evs[e] = vel * w[d];
         }
-        __syncthreads();
+    };
+    auto smooth_rows = [&]() {  // behind a barrier after smooth_elements
+        const double* const evs = L.tv;
         for (int i = tid; i <= n; i += blockDim.x) {
             double s2 = 0.0;
             for (int d = 0; d < 9; ++d) {
@@ -688,40 +688,62 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
             L.sml[i] = 0.5 * nrm * nrm;
         }
     };
+    auto smooth_terms = [&]() {
+        smooth_elements(tid, blockDim.x);
+        __syncthreads();
+        smooth_rows();
+    };
     if (wait_goal) {
-        obstacle_rows(0, i_defer * 9);  // everything that does not involve the goal, before waiting for it
-        PHASE_MARK_T(10, 0);
-        if (free_end) smooth_terms();
+        // everything that does not involve the goal, before waiting for it.  The [n][9] loops keep n * 9 / 64 waves busy (5 of 8 at 30
+        // waypoints): the obstacle rows on the first five waves, the smoothness elements on the other three at the same time
+        if (free_end) {
+            constexpr int SPLIT_AT = 5 * 64;
+            if (tid < SPLIT_AT) obstacle_rows(0, i_defer * 9, tid, SPLIT_AT);
+            else smooth_elements(tid - SPLIT_AT, CH_TPB - SPLIT_AT);
+            PHASE_MARK_T(10, 0);
+            __syncthreads();
+            smooth_rows();
+        } else {
+            obstacle_rows(0, i_defer * 9, tid, blockDim.x);
+            PHASE_MARK_T(10, 0);
+        }
         PHASE_MARK_T(11, 0);
         // ------------------------------------------------------------ the goal: wait for the learner's workgroup
         PHASE_MARK_T(23, 0);
+        // The rendezvous word carries the chosen goal: (ticket << 8) | index, stored relaxed by the learner's workgroup the moment
+        // the index is known.  Everything else of the goal — goal point, goal rows, the end configuration and its poses — is read
+        // HERE from the goal set / standoff / pose tables, which no launch in flight writes: no acquire, no cache invalidation, and
+        // the learner's own stores of the goal (for the launches to come) are off the iteration's critical path.
         if (tid == 0) {
-            if (__hip_atomic_load(wait_goal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ticket) {
+            uint32_t word = __hip_atomic_load(wait_goal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((word >> 8) != ticket) {
                 const long long t0 = wall_clock64();  // 100 MHz
                 do {
                     __builtin_amdgcn_s_sleep(4);
                     if (wall_clock64() - t0 > 200000000LL) {  // 2 s: the producer is gone; fail loudly instead of hanging the device
                         L.red[53] = 1.0;  // the wait ran out: the thread that writes `info` reports NaN
+                        word = 0u;        // (goal 0: the arithmetic below stays in bounds)
                         break;
                     }
-                } while (__hip_atomic_load(wait_goal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ticket);
+                    word = __hip_atomic_load(wait_goal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } while ((word >> 8) != ticket);
             }
-            // one acquire for the workgroup: it invalidates this CU's L1 (shared by all its waves) and the stale L2 lines;
-            // the barrier below orders the other threads' reads of the goal after it
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            L.iscr[3] = (int)(word & 0xffu);
         }
         __syncthreads();
         PHASE_MARK_T(24, 0);
-        // everything of the goal the rest of the step reads — the goal point (info["reach"]) and the chosen goal rows (the projected
-        // step) — comes in with the end pose, in ONE round trip to L2 instead of one per use on the critical path
+        const int GS_ = la->prm.num_goals;
+        const int gi = min(L.iscr[3], GS_ - 1);
+        const double* const grow = la->goal_set + ((size_t)s * GS_ + gi) * 9;  // the chosen goal's configuration
+        end = grow;
         if (tid >= 128 && tid < 128 + 9 + c * 9) {
             const int e = tid - 128;
-            goalc[e] = e < 9 ? a.goal_point[9 * (size_t)s + e] : a.goal[(size_t)s * c * 9 + (e - 9)];
+            goalc[e] = e < 9 ? grow[e] : (la->prm.use_standoff ? la->reach[((size_t)s * GS_ + gi) * c * 9 + (e - 9)] : grow[(e - 9) % 9]);
         }
         if (tid >= 256 && tid < 256 + 18) limc[tid - 256] = tid < 265 ? rv.lower()[tid - 256] : rv.upper()[tid - 265];
-        if (end_pose_fits(n)) {  // the learner's workgroup has left the end configuration's poses in this scene's grad rows
-            const double* src = a.grad + (size_t)s * n * 9;
-            for (int e = tid; e < 120; e += blockDim.x) L.pose[(size_t)(ncfg - 1) * 120 + e] = src[e];
+        if (la->prm.goal_pose_table) {  // tabulated for the plan (omgx_pose_table)
+            const double* src = la->prm.goal_pose_table + ((size_t)s * GS_ + gi) * 120;
+            if (tid < 120) L.pose[(size_t)(ncfg - 1) * 120 + tid] = src[tid];
             __syncthreads();
         } else {
             fk_configs(ncfg - 1, ncfg, L.red + 8);  // red[8..21] is free scratch
@@ -745,10 +767,10 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
     }
     if (!wait_goal && tid >= 256 && tid < 256 + 18) limc[tid - 256] = tid < 265 ? rv.lower()[tid - 256] : rv.upper()[tid - 265];
     if (wait_goal) {  // only what the goal-dependent passes above produced is still missing
-        obstacle_rows(i_defer * 9, n * 9);
+        obstacle_rows(i_defer * 9, n * 9, tid, blockDim.x);
         if (!free_end) smooth_terms();
     } else {
-        obstacle_rows(0, n * 9);
+        obstacle_rows(0, n * 9, tid, blockDim.x);
         smooth_terms();
     }
     __syncthreads();
@@ -984,7 +1006,7 @@ __global__ __launch_bounds__(CH_TPB) void k_chomp_optimize(ChompArgs a) {
 }
 
 // The same pair with the goal update in its own workgroup: workgroups [0, S) run the learner of scene b and publish
-// ticket in goal_flags[b]; workgroups [S, 2S) run the optimiser step of scene b - S, whose goal-independent two thirds
+// (ticket << 8) | chosen goal in goal_flags[b]; workgroups [S, 2S) run the optimiser step of scene b - S, whose goal-independent two thirds
 // (FK, top-k, per-point costs, winners' gradients) overlap the learner; they wait for the flag only before the part that
 // uses the goal.  Learner workgroups come first in the grid, so a waiting workgroup's producer has always been
 // dispatched already (no deadlock); the wait is bounded anyway.
@@ -999,60 +1021,24 @@ __global__ __launch_bounds__(CH_TPB) void k_update_optimize_split(omg_learner::L
 #endif
         double* shl = reinterpret_cast<double*>(smem);
         int* const sh_idx = reinterpret_cast<int*>(shl + 5 * OMGX_MAX_GOALS + 5 * 128);  // the chosen goal, for the whole workgroup
+        // learner_scene publishes (ticket << 8) | goal index in the scene's word the moment the index is known: the step's workgroup
+        // needs nothing else from here (it reads the goal's configuration, rows and poses from the tables itself: chomp_scene)
         omg_learner::learner_scene(la, blockIdx.x, reinterpret_cast<double (*)[OMGX_MAX_GOALS]>(shl),
-                                   reinterpret_cast<double (*)[128]>(shl + 5 * OMGX_MAX_GOALS), sh_idx);
-        __syncthreads();
-        // The kinematics of the chosen end configuration (a 3-lane serial chain, ~7 K cycles) run HERE, where nothing waits for
-        // them, instead of in the step's workgroup right after its wait.  The 10 x 12 doubles travel in the scene's `grad`
-        // rows, which the step's workgroup overwrites with the gradient only after it has taken the pose (chomp_scene).
+                                   reinterpret_cast<double (*)[128]>(shl + 5 * OMGX_MAX_GOALS), sh_idx, goal_flags + blockIdx.x, publish);
+        // ... what the launches to come read: `end_poses_out` follows the goal (k_chomp_optimize takes its end pose from it)
         const bool scene_on = !(a.active && a.active[blockIdx.x] == 0);
-        if (!end_pose_fits(a.prm.n_waypoints) && scene_on && la.prm.goal_pose_table && la.prm.end_poses_out) {
-            // Fewer than 14 waypoints: the pose does not travel through the grad rows (the step's workgroup runs the end
-            // configuration's kinematics itself), but `end_poses_out` must still follow the goal — the launches of the plan that
-            // come after the goal-selecting iterations (k_chomp_optimize) take their end pose from it.
+        if (scene_on && la.prm.goal_pose_table && la.prm.end_poses_out) {
+            __syncthreads();
             const double* src = la.prm.goal_pose_table + ((size_t)blockIdx.x * la.prm.num_goals + *sh_idx) * 120;
             if (threadIdx.x < 120) la.prm.end_poses_out[(size_t)blockIdx.x * 120 + threadIdx.x] = src[threadIdx.x];
         }
-        if (end_pose_fits(a.prm.n_waypoints) && scene_on) {
-            double* out = a.grad + (size_t)blockIdx.x * a.prm.n_waypoints * 9;
-            if (la.prm.goal_pose_table) {
-                // the goals' poses were tabulated for the plan (omgx_pose_table): the chosen goal's 120 doubles are copied (the index
-                // comes through LDS: reading back the word wave 0 has just stored costs a trip to L2 on the iteration's critical path)
-                const double* src = la.prm.goal_pose_table + ((size_t)blockIdx.x * la.prm.num_goals + *sh_idx) * 120;
-                if (threadIdx.x < 120) {
-                    const double v = src[threadIdx.x];
-                    out[threadIdx.x] = v;
-                    if (la.prm.end_poses_out) la.prm.end_poses_out[(size_t)blockIdx.x * 120 + threadIdx.x] = v;
-                }
-                __syncthreads();
-            } else {
-            const RobotView rv(a.robot, a.prm.n_points);
-            const double* q = a.end + 9 * (size_t)blockIdx.x;
-            if (threadIdx.x < 7) {
-                double sn, cs;
-                fk_joint_sincos(q[threadIdx.x], sn, cs);
-                shl[2 * threadIdx.x] = sn; shl[2 * threadIdx.x + 1] = cs;
-            }
-            __syncthreads();
-            if (threadIdx.x < 3) {
-                const int r = threadIdx.x;
-                fk_chain_row(rv, r, shl, q[7], q[8], [&](int l, double r0, double r1, double r2, double tr) {
-                    double* dst = out + 12 * l + 3 * r;
-                    dst[0] = r0; dst[1] = r1; dst[2] = r2;
-                    dst[9 - 2 * r] = tr;  // element 9 + r of the pose
-                });
-            }
-            __syncthreads();
-            }
-        }
-        if (threadIdx.x == 0) __hip_atomic_store(goal_flags + blockIdx.x, publish, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef OMGX_PHASE_TIMING
         if (blockIdx.x == 0 && threadIdx.x == 0) g_chomp_phase[27] = __builtin_readcyclecounter();
 #endif
         return;
     }
     const int s = (int)blockIdx.x - S;
-    chomp_scene<MI>(a, smem, s, goal_flags + s, ticket);
+    chomp_scene<MI>(a, smem, s, goal_flags + s, ticket, &la);
 }
 
 // Learner.update_goal followed by Optimizer.optimize for the same scene in one workgroup (planner.py:612-621 calls them
@@ -1175,7 +1161,8 @@ extern "C" int omgx_goal_update_optimize(const omgx_learner_params* h_learner, c
     if (lds < learner_lds) lds = learner_lds;
     const bool small = fits_small(a.prm.n_waypoints);
     if (scene_flags) {
-        const uint32_t publish = g_drop_ticket.load(std::memory_order_relaxed) ? (uint32_t)ticket ^ 0x40000000u : (uint32_t)ticket;
+        if (ticket < 1 || ticket >= (1 << 24)) return OMGX_ERR_INVALID;  // the word is (ticket << 8) | goal index
+        const uint32_t publish = g_drop_ticket.load(std::memory_order_relaxed) ? (uint32_t)ticket ^ 0x400000u : (uint32_t)ticket;
         if (small) {
             if ((rc = allow_big_lds<2>(k_update_optimize_split<MI_SMALL>, "hipFuncSetAttribute(k_update_optimize_split)")) != OMGX_OK) return rc;
             hipLaunchKernelGGL(k_update_optimize_split<MI_SMALL>, dim3(2 * num_scenes), dim3(CH_TPB), lds, (hipStream_t)stream, la, a,

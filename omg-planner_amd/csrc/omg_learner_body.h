@@ -179,7 +179,10 @@ __device__ void bregman_projection(const double* x, const double* v, double delt
 
 // All threads of the workgroup call this (>= 5 waves for MD); sh_pn [5][OMGX_MAX_GOALS] and sh_tab [5][128] are LDS.
 // sh_idx (LDS, optional): receives the chosen goal's index — valid for the workgroup after its next barrier (active scenes only).
-__device__ __forceinline__ void learner_scene(const LearnerArgs& a, int s, double (*sh_pn)[OMGX_MAX_GOALS], double (*sh_tab)[128], int* sh_idx = nullptr) {
+// flag / publish (optional, k_update_optimize_split): the scene's rendezvous word receives (publish << 8) | index the moment the index
+// is known — one relaxed store: whoever waits for it reads nothing but the index and tables that no launch in flight writes.
+__device__ __forceinline__ void learner_scene(const LearnerArgs& a, int s, double (*sh_pn)[OMGX_MAX_GOALS], double (*sh_tab)[128], int* sh_idx = nullptr,
+                                              uint32_t* flag = nullptr, uint32_t publish = 0u) {
     // The scene's `active` word is REQUESTED here and tested where the first write would happen, behind the requests of the cost vector's
     // inputs (and the experts' distributions): tested at once it is a trip to memory of its own — ~2 us after a launch boundary, on
     // the critical path of every iteration (goal costs -> learner -> the step's tail) — ahead of all the others.
@@ -368,7 +371,11 @@ __device__ __forceinline__ void learner_scene(const LearnerArgs& a, int s, doubl
     }
     LPHASE(5, 0);
     // traj.end / goal rows (online_learner.py:243-245, optimizer.py:93-99)
-    if (lane == 0) { a.goal_idx[s] = idx; if (sh_idx) *sh_idx = idx; }
+    if (lane == 0) {
+        if (flag) __hip_atomic_store(flag, (publish << 8) | (uint32_t)idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a.goal_idx[s] = idx;
+        if (sh_idx) *sh_idx = idx;
+    }
     if (lane < 9) {
         const double v = gs[idx * 9 + lane];
         a.end[s * 9 + lane] = v;

@@ -282,9 +282,10 @@ class ChompEngine:
 
     def _next_ticket(self) -> int:
         """The next rendezvous ticket of omgx_goal_update_optimize: monotonically increasing over the engine AND its pipeline
-        parts, never 0 (the flags start at 0), wrapping inside int32 long before any flag could still hold the value."""
+        parts, never 0 (the flags start at 0), wrapping below 2^24 (the scene's word is (ticket << 8) | chosen goal) long before any flag could
+        still hold the value."""
         src = self._ticket_src
-        src[0] = src[0] + 1 if src[0] < 0x7ffffff0 else 1
+        src[0] = src[0] + 1 if src[0] < 0xfffff0 else 1  # the flag word is (ticket << 8) | goal index: tickets stay below 2^24
         return src[0]
 
     def _mask(self):

@@ -53,13 +53,13 @@ def test_bare_iterate_then_pipelined_iterate_draws_fresh_tickets(dev):
     for e in (one, two):
         e.iterate(0)  # bare: one split-update launch over all 70 scenes
     torch.cuda.synchronize()
-    assert int(two._scene_flags.max().item()) == 1 and two._ticket_src[0] == 1
+    assert int((two._scene_flags >> 8).max().item()) == 1 and two._ticket_src[0] == 1  # the word: (ticket << 8) | chosen goal
     two.pipeline = 2
     for t in range(1, 4):
         one.iterate(t); two.iterate(t)
     two.join()
     assert all(p._ticket_src is two._ticket_src for p in two._parts)
-    flags = two._scene_flags.cpu().numpy()
+    flags = two._scene_flags.cpu().numpy() >> 8
     lo, hi = two._parts[0].S, two.S
     assert flags[:lo].max() != flags[lo:hi].max() and two._ticket_src[0] == 1 + 3 * 2  # every launch drew its own ticket
     _assert_same(one, two)
