@@ -46,7 +46,7 @@ using namespace omg;
 // Debug aid (make CXXFLAGS+=-DOMGX_PHASE_TIMING): workgroup 0 stamps the shader clock at the phase boundaries;
 // tools/phase_timing.py reads them through omgx_debug_phase_times.  Not part of the ABI, compiled out by default.
 #ifdef OMGX_PHASE_TIMING
-__device__ unsigned long long g_chomp_phase[32];
+__device__ unsigned long long g_chomp_phase[48];
 #define PHASE_MARK(i) do { if (s == 0 && threadIdx.x == 0) g_chomp_phase[i] = __builtin_readcyclecounter(); } while (0)
 #define PHASE_MARK_T(i, t) do { if (s == 0 && threadIdx.x == (t)) g_chomp_phase[i] = __builtin_readcyclecounter(); } while (0)
 #else
@@ -314,6 +314,9 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
         }
     }
     const double r_sp = (sp && tid < 120) ? sp[tid] : 0.0, r_ep = (ep && tid < 120) ? ep[tid] : 0.0;
+    // With a ticket: the goal the scene HAD (the learner of this launch may be writing the word: either value will do) — its
+    // configuration, rows and poses are fetched SPECULATIVELY below, and kept if the ticket names the same goal (it usually does)
+    const int spec_goal = (wait_goal && la) ? min(max(la->goal_idx[s], 0), la->prm.num_goals - 1) : -1;
     PHASE_MARK_T(30, 0);
     // ---- the stores
     if (tid < n * 9) L.xi[tid] = r_xi0;
@@ -437,12 +440,7 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
                 if (tid < 64) {  // wave 0: locate the bin holding the `want`-th largest key (suffix sums over 256 bins)
                     const uint32_t h0 = L.hist[4 * tid], h1 = L.hist[4 * tid + 1], h2 = L.hist[4 * tid + 2], h3 = L.hist[4 * tid + 3];
                     const int minel = (int)(h0 + h1 + h2 + h3);
-                    int incl = minel;  // inclusive suffix sum over lanes tid..63
-#pragma unroll
-                    for (int off = 1; off < 64; off <<= 1) {
-                        const int v = __shfl_down(incl, off, 64);
-                        if (tid + off < 64) incl += v;
-                    }
+                    const int incl = wave_suffix_sum_i32(minel);  // inclusive suffix sum over lanes tid..63
                     const int above = incl - minel;
                     if (above < want && want <= incl) {  // exactly one lane
                         int acc = above, b = 4 * tid + 3;
@@ -499,6 +497,17 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
     const int i_defer = wait_goal ? n - 1 : n;  // waypoints >= i_defer need the end pose (acceleration): second pass
     double* const goalc = reinterpret_cast<double*>(L.hist);  // [9 + c * 9] goal point | goal rows; the histogram is dead after phase 1 (c <= 8: 81 of its 128 doubles)
     double* const limc = goalc + 96;                          // [18] joint limits (lower | upper): LDS reads in the totals and the limit loop instead of global loads
+    auto fetch_goal = [&](const int gi) {  // goal point | goal rows, joint limits, the end configuration's poses (if tabulated) -> LDS; no barrier inside
+        const int GS_ = la->prm.num_goals;
+        const double* const grow = la->goal_set + ((size_t)s * GS_ + gi) * 9;
+        if (tid >= 128 && tid < 128 + 9 + c * 9) {
+            const int e = tid - 128;
+            goalc[e] = e < 9 ? grow[e] : (la->prm.use_standoff ? la->reach[((size_t)s * GS_ + gi) * c * 9 + (e - 9)] : grow[(e - 9) % 9]);
+        }
+        if (tid >= 256 && tid < 256 + 18) limc[tid - 256] = tid < 265 ? rv.lower()[tid - 256] : rv.upper()[tid - 265];
+        if (la->prm.goal_pose_table && tid < 120) L.pose[(size_t)(ncfg - 1) * 120 + tid] = la->prm.goal_pose_table[((size_t)s * GS_ + gi) * 120 + tid];
+    };
+    if (spec_goal >= 0) fetch_goal(spec_goal);  // (the histogram these words shared is dead; the end pose's slot has no reader before the ticket)
     auto phase2_item = [&](const int it, const bool second_pass) {
         const bool inb = it < nitems;
         const int p = it & 15, grp = it >> 4, l = grp % 10, i = grp / 10;
@@ -642,12 +651,24 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
     auto obstacle_rows = [&](const int e_begin, const int e_end, const int t0, const int nt) {  // obstacle gradient [n][9] from the groups' J.g
         for (int e = e_begin + t0; e < e_end; e += nt) {
             const int i = e / 9, d = e % 9;
-            double sgrad = 0.0;
-            for (int l = 0; l < mlinks; ++l) {  // ascending link order = the reference's += order
+            // all ten reads first, then the additions in ascending link order (= the reference's += order) behind selects: with a branch
+            // per link the loop was read, wait, add ten times over
+            double gv[10];
+#pragma unroll
+            for (int l = 0; l < 10; ++l) {
                 int k = -1;
                 if (d < 7) { if (d < njoints(l)) k = d; }
                 else if (l == d + 1) k = 7;  // column 7 <- link 8, column 8 <- link 9
-                if (k >= 0) sgrad += L.gl[((size_t)i * 10 + l) * 8 + k];
+                gv[l] = L.gl[((size_t)i * 10 + l) * 8 + (k >= 0 ? k : 0)];
+            }
+            double sgrad = 0.0;
+#pragma unroll
+            for (int l = 0; l < 10; ++l) {
+                int k = -1;
+                if (d < 7) { if (d < njoints(l)) k = d; }
+                else if (l == d + 1) k = 7;
+                const double next = sgrad + gv[l];
+                sgrad = (l < mlinks && k >= 0) ? next : sgrad;
             }
             L.og[e] = sgrad;
         }
@@ -734,20 +755,12 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
         PHASE_MARK_T(24, 0);
         const int GS_ = la->prm.num_goals;
         const int gi = min(L.iscr[3], GS_ - 1);
-        const double* const grow = la->goal_set + ((size_t)s * GS_ + gi) * 9;  // the chosen goal's configuration
-        end = grow;
-        if (tid >= 128 && tid < 128 + 9 + c * 9) {
-            const int e = tid - 128;
-            goalc[e] = e < 9 ? grow[e] : (la->prm.use_standoff ? la->reach[((size_t)s * GS_ + gi) * c * 9 + (e - 9)] : grow[(e - 9) % 9]);
+        end = la->goal_set + ((size_t)s * GS_ + gi) * 9;  // the chosen goal's configuration
+        if (gi != spec_goal) {  // (workgroup-uniform) the goal changed in this iteration: fetch again
+            fetch_goal(gi);
+            if (la->prm.goal_pose_table) __syncthreads();
         }
-        if (tid >= 256 && tid < 256 + 18) limc[tid - 256] = tid < 265 ? rv.lower()[tid - 256] : rv.upper()[tid - 265];
-        if (la->prm.goal_pose_table) {  // tabulated for the plan (omgx_pose_table)
-            const double* src = la->prm.goal_pose_table + ((size_t)s * GS_ + gi) * 120;
-            if (tid < 120) L.pose[(size_t)(ncfg - 1) * 120 + tid] = src[tid];
-            __syncthreads();
-        } else {
-            fk_configs(ncfg - 1, ncfg, L.red + 8);  // red[8..21] is free scratch
-        }
+        if (!la->prm.goal_pose_table) fk_configs(ncfg - 1, ncfg, L.red + 8);  // no table: the end configuration's kinematics here (red[8..21] is free scratch)
         PHASE_MARK_T(28, 0);
         if (topk_mode) {
             winners_gradients(i_defer * 10, n * 10);
@@ -759,8 +772,44 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
         PHASE_MARK_T(25, 0);
     }
 
+    // The top-k branch's link sums — each link's cost summed over the waypoints, in waypoint order (cost.py:416): a chain of n dependent
+    // additions on ten lanes, 3.4 K cycles at 30 waypoints — run in THREE pieces on a wave that has no element of the [n][9] loops
+    // (up to 42 waypoints), beside the other waves' deferred rows, weighting and block sums: the whole workgroup used to wait for them
+    // at a barrier.  Same additions in the same order.
+    constexpr int LSW = 6;  // the wave
+    double ls_cl = 0.0;
+    int ls_any = 0;
+    const int ls_piece = n >= 24 ? 8 * (n / 24) : n;  // whole batches of 8 waypoints for the first two pieces (30 waypoints: 8 + 8 + 14)
+    auto link_sum_piece = [&](const int i_begin, const int i_end_) {
+        const int i_end = i_end_ < n ? i_end_ : n;
+        if (!(topk_mode && (tid >> 6) == LSW && (tid & 63) < 10)) return;
+        const int ln = tid & 63;
+        for (int i0 = i_begin; i0 < i_end; i0 += 8) {  // the LDS reads of 8 waypoints at once, then the additions behind selects
+            double gv[8];
+            int gw[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = i0 + j < i_end ? i0 + j : i_end - 1;
+                gv[j] = L.gcost[i * 10 + ln]; gw[j] = L.gwin[i * 10 + ln];
+            }
+            if (i0 + 8 <= i_end) {  // a whole batch: the bare chain of additions
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { ls_cl += gv[j]; ls_any |= gw[j] >= 0 ? 1 : 0; }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const bool in = i0 + j < i_end;
+                    const double next = ls_cl + gv[j];
+                    ls_cl = in ? next : ls_cl;
+                    ls_any |= (in && gw[j] >= 0) ? 1 : 0;
+                }
+            }
+        }
+    };
+
     // ---------------------------------------------------------------- phase 4: obstacle gradient [n][9], smoothness
     PHASE_MARK(4);
+    link_sum_piece(0, ls_piece);
     if (!wait_goal && tid >= 128 && tid < 128 + 9 + c * 9) {  // (with a ticket: loaded right behind it, above)
         const int e = tid - 128;
         goalc[e] = e < 9 ? a.goal_point[9 * (size_t)s + e] : a.goal[(size_t)s * c * 9 + (e - 9)];
@@ -782,6 +831,7 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
 
     // ---------------------------------------------------------------- phase 5: totals (cost.py:464-530)
     PHASE_MARK(5);
+    link_sum_piece(ls_piece, 2 * ls_piece);
     for (int e = tid; e < n * 9; e += blockDim.x) {
         double og = prm.obstacle_weight * L.og[e];
         og = fmin(fmax(og, -prm.clip_grad_scale), prm.clip_grad_scale);
@@ -805,107 +855,102 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
     }
     PHASE_MARK_T(12, 0);
     __syncthreads();
+    PHASE_MARK_T(37, 0);
     // The independent block sums run on different waves at once, each in wave_allsum's fixed order.
     {
         const int wv = tid >> 6, ln = tid & 63;
         const double* arr = wv == 0 ? L.sml : (wv == 1 ? L.og : (wv == 2 ? L.sg : (wv == 3 ? L.tv : L.gcost)));
         const int count = wv == 0 ? n + 1 : (wv <= 3 ? n * 9 : n * 10);
-        if (wv <= 3 || (wv == 4 && !topk_mode)) {
+        if (wv <= 3 || (wv == 4 && !topk_mode)) {  // (wave 4: the clean branch's sum of all group costs)
             double acc = 0.0;
             for (int k = ln; k < count; k += 64) acc += arr[k];
             acc = wave_allsum(acc);
             if (ln == 0) L.red[wv == 4 ? 0 : wv + 1] = acc;  // slots: 1 smooth, 2 |w og|^2, 3 |w sg|^2, 4 |g|^2, 0 obstacle (clean branch)
-        } else if (wv == 4 && ln < 10) {
-            // top-k branch: each link's summed cost is broadcast to every waypoint (cost.py:416)
-            double cl = 0.0;
-            bool any = false;
-            for (int i0 = 0; i0 < n; i0 += 8) {  // the LDS reads of 8 waypoints at once, then the additions in waypoint order
-                double gv[8];
-                int wv[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int i = i0 + j < n ? i0 + j : n - 1;
-                    gv[j] = L.gcost[i * 10 + ln]; wv[j] = L.gwin[i * 10 + ln];
-                }
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    if (i0 + j < n) { cl += gv[j]; any = any || (wv[j] >= 0); }
+        } else if (wv == LSW && topk_mode && ln < 10) {
+            PHASE_MARK_T(38, 384);
+            link_sum_piece(2 * ls_piece, n);
+            L.red[32 + ln] = (ln < mlinks && ls_any) ? ls_cl : 0.0;  // each link's summed cost is broadcast to every waypoint (cost.py:416)
+            PHASE_MARK_T(39, 384);
+        }
+        PHASE_MARK_T(32, 0); PHASE_MARK_T(33, 64); PHASE_MARK_T(34, 128); PHASE_MARK_T(35, 192); PHASE_MARK_T(36, 384);
+    }
+    // What the sums feed — cost_traj, info — is written BEHIND the projected step's `A^-1 g`, which needs none of them (one barrier less
+    // on the way to the new trajectory).
+    auto outputs_of_the_sums = [&]() {  // behind a barrier after the sums
+        double obs_sum;
+        if (topk_mode) {
+            double per_wp = 0.0;
+            for (int l = 0; l < 10; ++l) per_wp += L.red[32 + l];
+            obs_sum = per_wp * (double)n;
+            for (int i = tid; i < n; i += blockDim.x)
+                a.cost_traj[(size_t)s * n + i] = prm.obstacle_weight * per_wp + prm.smoothness_weight * L.sml[i];
+            if (a.aux) {
+                double* oc = a.aux + (size_t)s * (n * 9 + n * 10 + n * 9 + n + 1) + n * 9;
+                for (int e = tid; e < n * 10; e += blockDim.x) oc[e] = L.red[32 + e % 10];
             }
-            L.red[32 + ln] = (ln < mlinks && any) ? cl : 0.0;
+        } else {
+            obs_sum = L.red[0];
+            for (int i = tid; i < n; i += blockDim.x) {
+                double r = 0.0;
+                for (int l = 0; l < 10; ++l) r += L.gcost[i * 10 + l];
+                a.cost_traj[(size_t)s * n + i] = prm.obstacle_weight * r + prm.smoothness_weight * L.sml[i];
+            }
+            if (a.aux) {
+                double* oc = a.aux + (size_t)s * (n * 9 + n * 10 + n * 9 + n + 1) + n * 9;
+                for (int e = tid; e < n * 10; e += blockDim.x) oc[e] = L.gcost[e];
+            }
         }
-    }
-    __syncthreads();
-    PHASE_MARK_T(13, 0);
-    double obs_sum;
-    if (topk_mode) {
-        double per_wp = 0.0;
-        for (int l = 0; l < 10; ++l) per_wp += L.red[32 + l];
-        obs_sum = per_wp * (double)n;
-        for (int i = tid; i < n; i += blockDim.x)
-            a.cost_traj[(size_t)s * n + i] = prm.obstacle_weight * per_wp + prm.smoothness_weight * L.sml[i];
-        if (a.aux) {
-            double* oc = a.aux + (size_t)s * (n * 9 + n * 10 + n * 9 + n + 1) + n * 9;
-            for (int e = tid; e < n * 10; e += blockDim.x) oc[e] = L.red[32 + e % 10];
-        }
-    } else {
-        obs_sum = L.red[0];
-        for (int i = tid; i < n; i += blockDim.x) {
-            double r = 0.0;
-            for (int l = 0; l < 10; ++l) r += L.gcost[i * 10 + l];
-            a.cost_traj[(size_t)s * n + i] = prm.obstacle_weight * r + prm.smoothness_weight * L.sml[i];
-        }
-        if (a.aux) {
-            double* oc = a.aux + (size_t)s * (n * 9 + n * 10 + n * 9 + n + 1) + n * 9;
-            for (int e = tid; e < n * 10; e += blockDim.x) oc[e] = L.gcost[e];
-        }
-    }
-    const double smooth_sum = L.red[1], n_og = L.red[2], n_sg = L.red[3], n_g = L.red[4];
-    double collide = 0.0;
-    for (int wv = 0; wv < CH_WAVES; ++wv) collide += L.red[56 + wv];
+        const double smooth_sum = L.red[1], n_og = L.red[2], n_sg = L.red[3], n_g = L.red[4];
+        double collide = 0.0;
+        for (int wv = 0; wv < CH_WAVES; ++wv) collide += L.red[56 + wv];
 
-    // The scalars of `info` (four square roots, a norm, 16 stores: 2.6 K cycles of one thread) are written by a thread of the LAST wave,
-    // which has no element of the [n][9] loops below: the other waves go on to the projected step meanwhile (they used to wait for
-    // thread 0 at the next barrier).  Thread 0's bounded wait reports a failure through L.red[53] (written before the barriers above).
-    if (tid == CH_TPB - 64) {
-        const bool wait_failed = L.red[53] > 0.0;
-        double goal_dist = 0.0;
-        if (prm.goal_set_proj) {
-            const double* gp = goalc;
-            for (int d = 0; d < 9; ++d) { const double e = L.xi[(n - 1) * 9 + d] - gp[d]; goal_dist += e * e; }
-            goal_dist = sqrt(goal_dist);
+        // The scalars of `info` (four square roots, a norm, 16 stores: 2.6 K cycles of one thread) are written by a thread of the LAST wave,
+        // which has no element of the [n][9] loops below: the other waves go on to the projected step meanwhile (they used to wait for
+        // thread 0 at the next barrier).  Thread 0's bounded wait reports a failure through L.red[53] (written before the barriers above).
+        if (tid == CH_TPB - 64) {
+            const bool wait_failed = L.red[53] > 0.0;
+            double goal_dist = 0.0;
+            if (prm.goal_set_proj) {
+                const double* gp = goalc;
+                for (int d = 0; d < 9; ++d) { const double e = L.xi[(n - 1) * 9 + d] - gp[d]; goal_dist += e * e; }
+                goal_dist = sqrt(goal_dist);
+            }
+            const bool violate = (L.red[50] > 0.0) && (L.red[51] > 0.0);
+            const double w_obs = prm.obstacle_weight * obs_sum, w_sm = prm.smoothness_weight * smooth_sum;
+            bool terminate = (collide <= prm.allow_collision_point) && prm.pre_terminate && (goal_dist < 0.01) &&
+                             (smooth_sum < prm.terminate_smooth_loss);
+            terminate = terminate && !violate;
+            const bool failure = (collide >= prm.allow_collision_point * 10) || (smooth_sum >= prm.terminate_smooth_loss * 2.5);
+            const bool execute = (collide <= prm.allow_collision_point) && (smooth_sum < prm.terminate_smooth_loss);
+            double* info = a.info + (size_t)s * OMGX_INFO_STRIDE;
+            info[OMGX_INFO_COST] = wait_failed ? __builtin_nan("") : w_obs + w_sm;  // a goal that never arrived must not look like a result
+            info[OMGX_INFO_OBS] = obs_sum;
+            info[OMGX_INFO_SMOOTH] = smooth_sum;
+            info[OMGX_INFO_WEIGHTED_OBS] = w_obs;
+            info[OMGX_INFO_WEIGHTED_SMOOTH] = w_sm;
+            info[OMGX_INFO_WEIGHTED_OBS_GRAD] = sqrt(n_og);
+            info[OMGX_INFO_WEIGHTED_SMOOTH_GRAD] = sqrt(n_sg);
+            info[OMGX_INFO_GRAD] = sqrt(n_g);
+            info[OMGX_INFO_COLLIDE] = collide;
+            info[OMGX_INFO_REACH] = goal_dist;
+            info[OMGX_INFO_TERMINATE] = terminate ? 1.0 : 0.0;
+            if (a.deactivate && terminate) a.deactivate[s] = 0;  // read again only by later launches on this stream
+            info[OMGX_INFO_FAILURE_TERMINATE] = failure ? 1.0 : 0.0;
+            info[OMGX_INFO_EXECUTE] = execute ? 1.0 : 0.0;
+            info[OMGX_INFO_STANDOFF_IDX] = prm.use_standoff ? (double)(n - c) : (double)(n - 1);
+            info[OMGX_INFO_VIOLATE_LIMIT] = violate ? 1.0 : 0.0;
+            info[OMGX_INFO_LIMIT_STEPS] = 0.0;
+            L.red[52] = terminate ? 1.0 : 0.0;
         }
-        const bool violate = (L.red[50] > 0.0) && (L.red[51] > 0.0);
-        const double w_obs = prm.obstacle_weight * obs_sum, w_sm = prm.smoothness_weight * smooth_sum;
-        bool terminate = (collide <= prm.allow_collision_point) && prm.pre_terminate && (goal_dist < 0.01) &&
-                         (smooth_sum < prm.terminate_smooth_loss);
-        terminate = terminate && !violate;
-        const bool failure = (collide >= prm.allow_collision_point * 10) || (smooth_sum >= prm.terminate_smooth_loss * 2.5);
-        const bool execute = (collide <= prm.allow_collision_point) && (smooth_sum < prm.terminate_smooth_loss);
-        double* info = a.info + (size_t)s * OMGX_INFO_STRIDE;
-        info[OMGX_INFO_COST] = wait_failed ? __builtin_nan("") : w_obs + w_sm;  // a goal that never arrived must not look like a result
-        info[OMGX_INFO_OBS] = obs_sum;
-        info[OMGX_INFO_SMOOTH] = smooth_sum;
-        info[OMGX_INFO_WEIGHTED_OBS] = w_obs;
-        info[OMGX_INFO_WEIGHTED_SMOOTH] = w_sm;
-        info[OMGX_INFO_WEIGHTED_OBS_GRAD] = sqrt(n_og);
-        info[OMGX_INFO_WEIGHTED_SMOOTH_GRAD] = sqrt(n_sg);
-        info[OMGX_INFO_GRAD] = sqrt(n_g);
-        info[OMGX_INFO_COLLIDE] = collide;
-        info[OMGX_INFO_REACH] = goal_dist;
-        info[OMGX_INFO_TERMINATE] = terminate ? 1.0 : 0.0;
-        if (a.deactivate && terminate) a.deactivate[s] = 0;  // read again only by later launches on this stream
-        info[OMGX_INFO_FAILURE_TERMINATE] = failure ? 1.0 : 0.0;
-        info[OMGX_INFO_EXECUTE] = execute ? 1.0 : 0.0;
-        info[OMGX_INFO_STANDOFF_IDX] = prm.use_standoff ? (double)(n - c) : (double)(n - 1);
-        info[OMGX_INFO_VIOLATE_LIMIT] = violate ? 1.0 : 0.0;
-        info[OMGX_INFO_LIMIT_STEPS] = 0.0;
-        L.red[52] = terminate ? 1.0 : 0.0;
-    }
-    PHASE_MARK_T(14, 0);
-    if (!prm.do_update) return;
-    if (prm.do_update == 2) {  // Optimizer.optimize without force_update: a terminated trajectory is left alone
+    };
+    if (prm.do_update != 1) {  // evaluation only, or a step that depends on `terminate`: the old order
         __syncthreads();
-        if (L.red[52] > 0.0) return;
+        PHASE_MARK_T(13, 0);
+        outputs_of_the_sums();
+        PHASE_MARK_T(14, 0);
+        if (!prm.do_update) return;
+        __syncthreads();
+        if (L.red[52] > 0.0) return;  // Optimizer.optimize without force_update: a terminated trajectory is left alone
     }
 
     // ---------------------------------------------------------------- phase 6: covariant (projected) step
@@ -915,6 +960,7 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
     apply_ainv(L.g, L.tvs, n, free_end, dt2);  // Ag = Ainv g
     __syncthreads();
     PHASE_MARK_T(15, 0);
+    if (prm.do_update == 1) outputs_of_the_sums();  // (their inputs: L.red, L.xi's last row, goalc — all unchanged until the barriers below)
     const double eta = prm.step_size;
     const double* goal = goalc + 9;
     for (int e = tid; e < n * 9; e += blockDim.x) {
@@ -991,7 +1037,7 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
         ++cnt;
     }
     for (int e = tid; e < n * 9; e += blockDim.x) traj[e] = L.xi[e];
-    if (tid == 0) a.info[(size_t)s * OMGX_INFO_STRIDE + OMGX_INFO_LIMIT_STEPS] = (double)cnt;
+    if (tid == CH_TPB - 64) a.info[(size_t)s * OMGX_INFO_STRIDE + OMGX_INFO_LIMIT_STEPS] = (double)cnt;  // the thread that wrote the other scalars (and a 0 here): program order
     PHASE_MARK(8);
 }
 
@@ -1065,7 +1111,7 @@ extern "C" int omgx_debug_learner_phase_times(unsigned long long* h_out, int n) 
     return (int)hipMemcpyFromSymbol(h_out, HIP_SYMBOL(omg_learner::g_learner_phase), sizeof(unsigned long long) * (n < 16 ? n : 16));
 }
 extern "C" int omgx_debug_chomp_phase_times(unsigned long long* h_out, int n) {
-    return (int)hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_chomp_phase), sizeof(unsigned long long) * (n < 32 ? n : 32));
+    return (int)hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_chomp_phase), sizeof(unsigned long long) * (n < 48 ? n : 48));
 }
 #endif
 

@@ -595,6 +595,18 @@ template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v) {
     return __hiloint2double(dpp_i32<CTRL>(__double2hiint(v)), dpp_i32<CTRL>(__double2loint(v)));
 }
+// inclusive SUFFIX sum over the 64 lanes of a wave: lane i receives v[i] + v[i+1] + ... + v[63].  Four row shifts inside the DPP rows
+// of 16 (lanes without a source read 0) and the totals of the higher rows through three lane reads — ~15 instructions where six
+// rounds of __shfl_down (ds_bpermute: a trip through the LDS crossbar each) took ~700 cycles.  Call from all 64 lanes.
+__device__ __forceinline__ int wave_suffix_sum_i32(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x101, 0xf, 0xf, true);  // row_shl:1 — lane i reads lane i + 1 of its row
+    v += __builtin_amdgcn_update_dpp(0, v, 0x102, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x104, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x108, 0xf, 0xf, true);
+    const int t1 = __builtin_amdgcn_readlane(v, 16), t2 = __builtin_amdgcn_readlane(v, 32), t3 = __builtin_amdgcn_readlane(v, 48);
+    const int row = (int)(threadIdx.x & 63) >> 4;
+    return v + (row < 1 ? t1 : 0) + (row < 2 ? t2 : 0) + (row < 3 ? t3 : 0);
+}
 // sum over each aligned group of 16 lanes (a DPP row), result in every lane of the group
 __device__ __forceinline__ double row16_allsum(double v) {
     v += dpp_f64<0xB1>(v);

@@ -28,8 +28,8 @@ lib = _lib.lib()
 for it in range(12):
     eng.iterate(it)
     torch.cuda.synchronize()
-    buf = (C.c_ulonglong * 32)()
-    lib.omgx_debug_chomp_phase_times(buf, 32)
+    buf = (C.c_ulonglong * 48)()
+    lib.omgx_debug_chomp_phase_times(buf, 48)
     t = np.array(list(buf), dtype=np.float64)
     lb = (C.c_ulonglong * 16)()
     lib.omgx_debug_learner_phase_times(lb, 16)
@@ -37,6 +37,6 @@ for it in range(12):
     d = np.diff(t[:9])
     print("   phase starts relative to phase 0:", (t[:9] - t[0]).astype(int).tolist())
     print(f"iteration {it}: step workgroup phases 0..7 [shader-clock cycles, ~2.2 GHz]:", d.astype(int).tolist(), "total", int(t[8] - t[0]))
-    print("   extra marks relative to phase 0:", {k: int(t[k] - t[0]) for k in list(range(9, 16)) + list(range(16, 32)) if t[k] > 0 and k not in (26, 27)})
+    print("   extra marks relative to phase 0:", {k: int(t[k] - t[0]) for k in list(range(9, 16)) + list(range(16, 40)) if t[k] > 0 and k not in (26, 27)})
     print("   learner wave 4 [shader-clock cycles, ~2.2 GHz]: cost vector", int(l[1] - l[0]), "projection", int(l[2] - l[1]), "expert cost", int(l[3] - l[2]),
           "| wave 0: mixture", int(l[5] - l[4]), "| whole learner workgroup", int(t[27] - t[26]), "| outer iterations of expert 4:", int(l[8]))
