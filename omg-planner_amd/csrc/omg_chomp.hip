@@ -716,9 +716,10 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
     };
     if (wait_goal) {
         // everything that does not involve the goal, before waiting for it.  The [n][9] loops keep n * 9 / 64 waves busy (5 of 8 at 30
-        // waypoints): the obstacle rows on the first five waves, the smoothness elements on the other three at the same time
+        // waypoints): here the obstacle rows on three waves and the smoothness elements (two loops with a division or two per element:
+        // the longer half) on the other five at the same time
         if (free_end) {
-            constexpr int SPLIT_AT = 5 * 64;
+            constexpr int SPLIT_AT = 3 * 64;
             if (tid < SPLIT_AT) obstacle_rows(0, i_defer * 9, tid, SPLIT_AT);
             else smooth_elements(tid - SPLIT_AT, CH_TPB - SPLIT_AT);
             PHASE_MARK_T(10, 0);

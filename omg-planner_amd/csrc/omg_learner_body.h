@@ -104,12 +104,17 @@ __device__ void bregman_projection(const double* x, const double* v, double delt
     }
     const double x1 = wmax(vmax);
     const double L0 = (0.0 + x1) / 2.0, s0 = (x1 - 0.0) / 4.0, rx1 = 1.0 / x1;
-    for (int it = 0; it < max_iter; ++it) {
+    // zmax = max_j (alpha_j - v_j) of the pass to come is reduced TOGETHER with the norm that decides whether there is one: two
+    // independent butterflies in one basic block interleave, one after the other they are two dependent chains per pass.
+    double zmax;
+    {
         double zm = -__builtin_inf();
 #pragma unroll
         for (int j = 0; j < NPL; ++j)
             if (lane + 64 * j < G) zm = fmax(zm, alpha[j] - v[j]);
-        const double zmax = wmax(zm);
+        zmax = wmax(zm);
+    }
+    for (int it = 0; it < max_iter; ++it) {
         double partC = 0.0;
 #pragma unroll
         for (int j = 0; j < NPL; ++j)
@@ -162,11 +167,17 @@ __device__ void bregman_projection(const double* x, const double* v, double delt
             nrm += (alpha[j] - ap[j]) * (alpha[j] - ap[j]);
         }
         LCOUNT(8, it + 1);
+        double zm_next = -__builtin_inf();
+#pragma unroll
+        for (int j = 0; j < NPL; ++j)
+            if (lane + 64 * j < G) zm_next = fmax(zm_next, ap[j] - v[j]);
+        const double nrm_all = wsum(nrm), zmax_next = wmax(zm_next);
         // sqrt(x) < 1e-6 (np.linalg.norm(alpha - alpha_prime) < err) <=> x < 0x1.19799812dea10p-40, the smallest double whose
         // correctly rounded root reaches 1e-6 (sqrt is monotone; NaN fails both)
-        if (wsum(nrm) < 0x1.19799812dea10p-40) break;
+        if (nrm_all < 0x1.19799812dea10p-40) break;
 #pragma unroll
         for (int j = 0; j < NPL; ++j) alpha[j] = ap[j];
+        zmax = zmax_next;
     }
     double part = 0.0;
 #pragma unroll
