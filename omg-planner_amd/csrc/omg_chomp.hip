@@ -102,7 +102,7 @@ struct Lds {
     double* pts;     // [10][P][3] centred collision points
     double* red;     // [64] scratch for reductions / scalars
     int* gwin;       // [n][10] winner point of the group or -1
-    uint32_t* hist;  // [256]
+    uint32_t* hist;  // [2][256]
     uint32_t* tie;   // [(n*10*16+31)/32] tie bit mask
     int* iscr;       // [16] int scalars
     int* wlist;      // [n*10] groups that have a winner (phase 3)
@@ -129,7 +129,7 @@ __device__ __forceinline__ Lds carve(unsigned char* base, int n, int P, bool pot
     L.fkc = d; d += 246;
     int* ip = reinterpret_cast<int*>(d);
     L.gwin = ip; ip += n * 10;
-    L.hist = reinterpret_cast<uint32_t*>(ip); ip += 256;
+    L.hist = reinterpret_cast<uint32_t*>(ip); ip += 512;  // two histograms of 256 bins (the radix select's passes take turns)
     L.tie = reinterpret_cast<uint32_t*>(ip); ip += (n * 160 + 31) / 32;
     L.iscr = ip; ip += 16;
     L.wlist = ip; ip += n * 10;
@@ -391,73 +391,73 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
     }
     // ---------------------------------------------------------------- phase 1: top-k threshold (cost.py:392-398)
     PHASE_MARK(1);
-    // Radix select of the K-th largest key over the `total` potentials, 4 passes of 8 bits.
+    // Radix select of the K-th largest key over the `total` potentials, up to 4 passes of 8 bits.
     const int K = prm.top_k;
     const bool topk_mode = K > 0;
     uint32_t tau = 0;      // key of the K-th largest potential; keys > tau are selected outright
     int tie_take = 0;      // how many keys == tau are selected (those with the highest flat index)
     bool tau_is_zero = false;
     if (topk_mode && K < total) {
-        // Most potentials are exactly 0 (points out of every object's reach).  They are the smallest keys and add
-        // nothing to cost or gradient, so count the non-zero ones first: if no more than K of them exist, every
-        // non-zero potential is selected and the radix select is not needed at all (the common case: K = 1000).
+        // Most potentials are exactly 0 (points out of every object's reach).  They are the smallest keys and add nothing to cost or
+        // gradient: only non-zero keys are counted, and if no more than K of them exist every one is selected (the common case with
+        // K = 1000) — known after the FIRST histogram, whose bins add up to their number.
+        // Two histograms take turns: while wave 0 scans the one just filled, the other
+        // waves clear the one the next pass fills — two barriers per pass instead of four, and no counting pass in front.
         const uint32_t key0 = float_key(0.0f);
-        int mine = 0;
-        if (L.potl) {
+        uint32_t* const hbuf[2] = {L.hist /* cleared in phase 0 */, L.hist + 256};
+        uint32_t prefix = 0, mask = 0;
+        int want = K;  // rank (from the top) still to locate inside the current prefix bucket
+        int nz = 0;
+        for (int pass = 0; pass < 4; ++pass) {
+            const int shift = 24 - 8 * pass;
+            uint32_t* const H = hbuf[pass & 1];
+            if (L.potl) {  // the keys are in registers already (padding lanes hold 0.0f = key0: never counted)
 #pragma unroll
-            for (int r = 0; r < MAXIT; ++r) mine += float_key(pv[r]) > key0 ? 1 : 0;
-        } else {
-            for (int f = tid; f < total; f += blockDim.x) mine += float_key(pot[f]) > key0 ? 1 : 0;
+                for (int r = 0; r < MAXIT; ++r) {
+                    const uint32_t key = float_key(pv[r]);
+                    if (key > key0 && (key & mask) == prefix) atomicAdd(&H[(key >> shift) & 255u], 1u);
+                }
+            } else {
+                for (int f = tid; f < total; f += blockDim.x) {
+                    const uint32_t key = float_key(pot[f]);
+                    if (key > key0 && (key & mask) == prefix) atomicAdd(&H[(key >> shift) & 255u], 1u);
+                }
+            }
+            __syncthreads();
+            if (tid < 64) {  // wave 0: locate the bin holding the `want`-th largest key (suffix sums over 256 bins)
+                const uint32_t h0 = H[4 * tid], h1 = H[4 * tid + 1], h2 = H[4 * tid + 2], h3 = H[4 * tid + 3];
+                const int minel = (int)(h0 + h1 + h2 + h3);
+                const int incl = wave_suffix_sum_i32(minel);  // inclusive suffix sum over lanes tid..63
+                if (pass == 0 && tid == 0) L.iscr[2] = incl;  // all non-zero keys
+                const int above = incl - minel;
+                if (above < want && want <= incl) {  // exactly one lane (none when there are fewer than `want` keys: first pass only)
+                    int acc = above, b = 4 * tid + 3;
+                    const uint32_t hh[4] = {h0, h1, h2, h3};
+                    for (; b > 4 * tid; --b) {
+                        if (acc + (int)hh[b - 4 * tid] >= want) break;
+                        acc += (int)hh[b - 4 * tid];
+                    }
+                    L.iscr[0] = b;
+                    L.iscr[1] = want - acc;
+                }
+            } else {
+                uint32_t* const Hn = hbuf[(pass + 1) & 1];
+                for (int e = tid - 64; e < 256; e += blockDim.x - 64) Hn[e] = 0;
+            }
+            __syncthreads();
+            if (pass == 0) {
+                nz = L.iscr[2];
+                if (nz <= K) break;  // workgroup-uniform
+            }
+            prefix |= (uint32_t)L.iscr[0] << shift;
+            mask |= 255u << shift;
+            want = L.iscr[1];
         }
-        if (mine) atomicAdd(&L.iscr[2], mine);  // zeroed before the first barrier
-        __syncthreads();
-        const int nz = L.iscr[2];
         if (nz <= K) {
             tau = key0;
             tau_is_zero = true;
             tie_take = K - nz;
         } else {
-            uint32_t prefix = 0, mask = 0;
-            int want = K;  // rank (from the top) still to locate inside the current prefix bucket
-            for (int pass = 0; pass < 4; ++pass) {
-                const int shift = 24 - 8 * pass;
-                __syncthreads();
-                for (int e = tid; e < 256; e += blockDim.x) L.hist[e] = 0;
-                __syncthreads();
-                if (L.potl) {  // the keys are in registers already (padding lanes hold 0.0f = key0: never counted)
-#pragma unroll
-                    for (int r = 0; r < MAXIT; ++r) {
-                        const uint32_t key = float_key(pv[r]);
-                        if (key > key0 && (key & mask) == prefix) atomicAdd(&L.hist[(key >> shift) & 255u], 1u);
-                    }
-                } else {
-                    for (int f = tid; f < total; f += blockDim.x) {
-                        const uint32_t key = float_key(pot[f]);
-                        if (key > key0 && (key & mask) == prefix) atomicAdd(&L.hist[(key >> shift) & 255u], 1u);
-                    }
-                }
-                __syncthreads();
-                if (tid < 64) {  // wave 0: locate the bin holding the `want`-th largest key (suffix sums over 256 bins)
-                    const uint32_t h0 = L.hist[4 * tid], h1 = L.hist[4 * tid + 1], h2 = L.hist[4 * tid + 2], h3 = L.hist[4 * tid + 3];
-                    const int minel = (int)(h0 + h1 + h2 + h3);
-                    const int incl = wave_suffix_sum_i32(minel);  // inclusive suffix sum over lanes tid..63
-                    const int above = incl - minel;
-                    if (above < want && want <= incl) {  // exactly one lane
-                        int acc = above, b = 4 * tid + 3;
-                        const uint32_t hh[4] = {h0, h1, h2, h3};
-                        for (; b > 4 * tid; --b) {
-                            if (acc + (int)hh[b - 4 * tid] >= want) break;
-                            acc += (int)hh[b - 4 * tid];
-                        }
-                        L.iscr[0] = b;
-                        L.iscr[1] = want - acc;
-                    }
-                }
-                __syncthreads();
-                prefix |= (uint32_t)L.iscr[0] << shift;
-                mask |= 255u << shift;
-                want = L.iscr[1];
-            }
             tau = prefix;
             tie_take = want;  // >= 1
             tau_is_zero = false;
@@ -1119,7 +1119,7 @@ extern "C" int omgx_debug_chomp_phase_times(unsigned long long* h_out, int n) {
 static bool fits_small(int n) { return n * 160 <= MI_SMALL * CH_TPB; }
 static size_t host_lds_bytes(int n, int P) {
     size_t d = (size_t)(n + 2) * 120 + 60 + (size_t)n * 80 + (size_t)n * 10 + (size_t)n * 9 * 6 + (n + 1) + 30 * P + 64 + 246;
-    size_t i = (size_t)n * 10 + 256 + (n * 160 + 31) / 32 + 16 + (size_t)n * 10;
+    size_t i = (size_t)n * 10 + 512 + (n * 160 + 31) / 32 + 16 + (size_t)n * 10;
     return d * 8 + i * 4;
 }
 static const size_t kLdsLimit = 160 * 1024;  // gfx950: 160 KB per workgroup

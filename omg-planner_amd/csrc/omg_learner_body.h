@@ -220,9 +220,13 @@ __device__ __forceinline__ void learner_scene(const LearnerArgs& a, int s, doubl
         }
     }
     // ... and the mixture's state (wave 0, lanes 0-4: expert k's weight and last cost)
+    // The wave that runs the mixture update and everything behind it: NOT one that shares a SIMD with the sharpest expert's wave 4
+    // (waves w and w + 4 do: on wave 0 the mixture's divisions and exponentials slowed that expert's passes by what they hid) — wave 5,
+    // beside expert 1's wave, which finishes early; workgroups of five waves (k_goal_update) keep wave 0.
+    const int mixw = (prm.alg == OMGX_ALG_MD && blockDim.x >= 384) ? 5 : 0;
     const int kk_pre = lane < 5 ? lane : 0;
     double q_pre = 0.0, ecost_pre = 0.0;
-    if (prm.alg == OMGX_ALG_MD && wave == 0) { q_pre = q[kk_pre]; ecost_pre = ecost[kk_pre]; }
+    if (prm.alg == OMGX_ALG_MD && wave == mixw) { q_pre = q[kk_pre]; ecost_pre = ecost[kk_pre]; }
     int idx = 0;
     if (prm.alg == OMGX_ALG_PROJ) {  // :196-206
         if (scene_active == 0) return;
@@ -310,6 +314,12 @@ __device__ __forceinline__ void learner_scene(const LearnerArgs& a, int s, doubl
         } else {  // MD, :219-235
             const double pw[5] = {0.25, 0.5, 1.0, 4.0, 16.0};  // eta * 2**[-2,-1,0,2,4], :82
             const double delta = 1.0 / (4.0 * (double)G + 1.0);
+            // An expert's wave announces its result through a word in LDS (release / acquire at workgroup scope) instead of a
+            // barrier: the mixture update below walks the experts in order and needs expert i only in its pass i, so wave 0 runs
+            // its first four passes — a dependent division each — while the sharpest expert (7-8 projection passes) is still busy.
+            int* const expert_done = reinterpret_cast<int*>(&sh_tab[0][8]);  // [5]
+            if (threadIdx.x < 5) expert_done[threadIdx.x] = 0;
+            __syncthreads();
             if (wave < 5) {  // waves 0..4: Bregman projection of their own expert (reads the OLD experts_p, like the reference)
                 double v[NPL], epw[NPL], pn[NPL];
                 for (int j = 0; j < NPL; ++j) {
@@ -327,12 +337,14 @@ __device__ __forceinline__ void learner_scene(const LearnerArgs& a, int s, doubl
                     if (g < G) { sh_pn[wave][g] = pn[j]; part2 += cv[j] * pn[j] + fabs(pn[j] - epw[j]); }
                 }
                 const double ecw = wsum(part2);
-                if (lane == 0) sh_tab[wave][0] = ecw;
+                if (lane == 0) {
+                    sh_tab[wave][0] = ecw;
+                    __hip_atomic_store(expert_done + wave, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);  // (a wave's LDS stores execute in order)
+                }
             }
             LPHASE(3, 4);
-            __syncthreads();
-            LPHASE(4, 0);
-            if (wave > 0) return;
+            if (wave != mixw) return;
+            LPHASE(4, mixw);
             // The mixture update sits INSIDE the expert loop (:231-235): after expert i, q_k *= exp(-cost_k) for ALL k with
             // the costs as they stand (new for k <= i, last iteration's for k > i), then q is normalised.  All ten
             // exponentials are known up front.  The mixture
@@ -340,15 +352,18 @@ __device__ __forceinline__ void learner_scene(const LearnerArgs& a, int s, doubl
             // Lane k < 5 carries expert k through the loop (its q_k, both of its exponentials), the normalising sum is formed
             // from lane broadcasts in the reference's order: one division per pass instead of five.
             double qv[5], ec[5], ep[5][NPL];
-            for (int i = 0; i < 5; ++i) {
-                ec[i] = sh_tab[i][0];
-                for (int j = 0; j < NPL; ++j) { const int g = lane + 64 * j; ep[i][j] = g < G ? sh_pn[i][g] : 0.0; }
-            }
             {
                 const int kk = kk_pre;
-                const double e_new = exp(-1.0 * sh_tab[kk][0]), e_old = exp(-1.0 * ecost_pre);
+                const double e_old = exp(-1.0 * ecost_pre);
+                double e_new = 0.0;  // lane kk: exp(-cost of expert kk), known from pass kk on
                 double ql = q_pre;
+#pragma unroll
                 for (int i = 0; i < 5; ++i) {
+                    while (__hip_atomic_load(expert_done + i, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(1);
+                    ec[i] = sh_tab[i][0];
+                    for (int j = 0; j < NPL; ++j) { const int g = lane + 64 * j; ep[i][j] = g < G ? sh_pn[i][g] : 0.0; }
+                    const double en = exp(-1.0 * ec[i]);  // the same number in every lane; lane i keeps it
+                    e_new = kk == i ? en : e_new;
                     ql = ql * (kk <= i ? e_new : e_old);
                     double qs = 0.0;
                     for (int k = 0; k < 5; ++k) qs += lane_bcast(ql, k);
@@ -380,7 +395,7 @@ __device__ __forceinline__ void learner_scene(const LearnerArgs& a, int s, doubl
             idx = warg<false>(best, bi);
         }
     }
-    LPHASE(5, 0);
+    LPHASE(5, mixw);
     // traj.end / goal rows (online_learner.py:243-245, optimizer.py:93-99)
     if (lane == 0) {
         if (flag) __hip_atomic_store(flag, (publish << 8) | (uint32_t)idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
