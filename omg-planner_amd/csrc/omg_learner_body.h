@@ -64,15 +64,28 @@ __device__ __forceinline__ double wsum(double v) { return omg::wave_allsum(v); }
 __device__ __forceinline__ double wmax(double v) { return omg::wave_allmax(v); }
 // arg-extreme in numpy's order (first occurrence, NaN wins; omg::np_arg_better).  Lanes start from the neutral element
 // (+-inf, INT_MAX), which loses every tie against a real entry.
+// (value, index) pairs with distinct indices are totally ordered by np_arg_better, so the winner does not depend on the shape of the
+// reduction: four DPP exchanges inside the rows of 16 lanes and the four rows' winners through lane reads — the six rounds of
+// __shfl_xor this replaces were 18 trips through the LDS crossbar on the iteration's critical path.  Call from all 64 lanes.
 template <bool MIN>
 __device__ __forceinline__ int warg(double v, int i) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const double ov = __shfl_xor(v, off, 64);
-        const int oi = __shfl_xor(i, off, 64);
-        if (omg::np_arg_better<MIN>(ov, oi, v, i)) { v = ov; i = oi; }
+#define OMG_WARG_STEP(CTRL)                                                       \
+    {                                                                             \
+        const double ov = omg::dpp_f64<CTRL>(v);                                  \
+        const int oi = omg::dpp_i32<CTRL>(i);                                     \
+        if (omg::np_arg_better<MIN>(ov, oi, v, i)) { v = ov; i = oi; }            \
     }
-    return i;
+    OMG_WARG_STEP(0xB1) OMG_WARG_STEP(0x4E) OMG_WARG_STEP(0x141) OMG_WARG_STEP(0x140)
+#undef OMG_WARG_STEP
+    double bv = omg::readlane_f64(v, 0);
+    int bi = __builtin_amdgcn_readlane(i, 0);
+#pragma unroll
+    for (int r = 16; r < 64; r += 16) {
+        const double ov = omg::readlane_f64(v, r);
+        const int oi = __builtin_amdgcn_readlane(i, r);
+        if (omg::np_arg_better<MIN>(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+    }
+    return bi;
 }
 #define OMG_ARG_NEUTRAL_MIN __builtin_inf()
 #define OMG_ARG_NEUTRAL_MAX (-__builtin_inf())
