@@ -230,13 +230,13 @@ __device__ __forceinline__ void apply_ainv(const double* __restrict__ in, double
         const int i = e / 9, d = e - 9 * i;
         const double* col = in + d;
         double pre = 0.0, suf = 0.0;
-#pragma unroll 4
+#pragma unroll 8
         for (int k = 0; k <= i; ++k) pre += (double)(k + 1) * col[9 * k];
         if (free_end) {
-#pragma unroll 4
+#pragma unroll 8
             for (int k = i + 1; k < n; ++k) suf += col[9 * k];
         } else {
-#pragma unroll 4
+#pragma unroll 8
             for (int k = i + 1; k < n; ++k) suf += (double)(n - k) * col[9 * k];
         }
         out[e] = c * ((free_end ? 1.0 : (double)(n - i)) * pre + (double)(i + 1) * suf);
@@ -327,7 +327,7 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
     if (tid < 246) L.fkc[tid] = r_fkc;
     for (int e = tid; e < 256; e += blockDim.x) L.hist[e] = 0;
     for (int e = tid; e < (nitems + 31) / 32; e += blockDim.x) L.tie[e] = 0;
-    if (tid == 0) { L.iscr[2] = 0; L.red[50] = 0.0; L.red[51] = 0.0; L.red[53] = 0.0; L.red[54] = 0.0; L.red[55] = 0.0; }
+    if (tid == 0) { L.iscr[2] = 0; L.red[7] = 0.0; L.red[50] = 0.0; L.red[51] = 0.0; L.red[53] = 0.0; L.red[54] = 0.0; L.red[55] = 0.0; }
     if (wp) {
 #pragma unroll
         for (int r = 0; r < PB; ++r) {
@@ -964,7 +964,15 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
     if (prm.do_update == 1) outputs_of_the_sums();  // (their inputs: L.red, L.xi's last row, goalc — all unchanged until the barriers below)
     const double eta = prm.step_size;
     const double* goal = goalc + 9;
-    for (int e = tid; e < n * 9; e += blockDim.x) {
+    // The new trajectory stays in REGISTERS (one or two elements per thread): handle_joint_limit's first pass — is any joint out of
+    // range? — runs on them, and in the usual case (none is) they go straight to global memory: no staging copy in LDS and two barriers
+    // less behind the step.  Only a violation brings them into L.xi for the projection loop below.
+    double xnew[2] = {0.0, 0.0};
+    int out_first = 0;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int e = tid + r * CH_TPB;
+        if (e >= n * 9) continue;
         const int i = e / 9, d = e % 9;
         double upd;
         if (!free_end) {
@@ -985,13 +993,29 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
         double xv = L.xi[e];
         if (d < 7 || prm.consider_finger) xv += upd;
         if (d >= 7) xv = fmin(fmax(xv, 0.0), 0.04);
-        L.g[e] = xv;  // new trajectory staged in L.g (L.xi still feeds neighbours' b0 reads)
+        xnew[r] = xv;  // (L.xi still feeds neighbours' b0 reads and info's goal distance)
+        const double t = (xv < lower[d] ? lower[d] - xv : 0.0) + (xv > upper[d] ? upper[d] - xv : 0.0);  // compute_traj_v
+        out_first |= (t != 0.0) ? 1 : 0;  // (NaN counts)
     }
-    __syncthreads();
-    for (int e = tid; e < n * 9; e += blockDim.x) L.xi[e] = L.g[e];
 
     // ---------------------------------------------------------------- phase 7: handle_joint_limit (optimizer.py:148-164)
     PHASE_MARK(7);
+    if (out_first) L.red[7] = 1.0;  // benign same-value race; cleared in phase 0
+    __syncthreads();
+    if (!(L.red[7] > 0.0)) {  // workgroup-uniform: every joint inside its limits — norm 0, no projection step (the usual case)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int e = tid + r * CH_TPB;
+            if (e < n * 9) traj[e] = xnew[r];
+        }
+        PHASE_MARK(8);
+        return;  // (info's LIMIT_STEPS already holds 0)
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int e = tid + r * CH_TPB;
+        if (e < n * 9) L.xi[e] = xnew[r];
+    }
     int cnt = 0;
     for (;;) {
         __syncthreads();
