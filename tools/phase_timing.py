@@ -39,4 +39,4 @@ for it in range(12):
     print(f"iteration {it}: step workgroup phases 0..7 [shader-clock cycles, ~2.2 GHz]:", d.astype(int).tolist(), "total", int(t[8] - t[0]))
     print("   extra marks relative to phase 0:", {k: int(t[k] - t[0]) for k in list(range(9, 16)) + list(range(16, 40)) if t[k] > 0 and k not in (26, 27)})
     print("   learner wave 4 [shader-clock cycles, ~2.2 GHz]: cost vector", int(l[1] - l[0]), "projection", int(l[2] - l[1]), "expert cost", int(l[3] - l[2]),
-          "| wave 0: mixture", int(l[5] - l[4]), "| whole learner workgroup", int(t[27] - t[26]), "| outer iterations of expert 4:", int(l[8]))
+          "| mixture wave (from its expert done to the goal): ", int(l[5] - l[4]), "| whole learner workgroup", int(t[27] - t[26]), "| outer iterations of expert 4:", int(l[8]))
