@@ -54,6 +54,7 @@ def test_bare_iterate_then_pipelined_iterate_draws_fresh_tickets(dev):
         e.iterate(0)  # bare: one split-update launch over all 70 scenes
     torch.cuda.synchronize()
     assert int((two._scene_flags >> 8).max().item()) == 1 and two._ticket_src[0] == 1  # the word: (ticket << 8) | chosen goal
+    assert torch.equal(two._scene_flags & 0xff, two.goal_idx)  # ... and its low byte IS the goal the learner chose (ABI 9)
     two.pipeline = 2
     for t in range(1, 4):
         one.iterate(t); two.iterate(t)
