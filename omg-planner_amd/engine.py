@@ -767,13 +767,17 @@ class ChompEngine:
     def restore(self, snap: dict):
         """Device-to-device copies on the current stream, no host sync."""
         self.join()
+        dst, src = [], []
         for k in self._STATE:
             cur = getattr(self, k)
             if cur.shape != snap[k].shape:  # early_stop used to rebind self.active: keep one tensor
                 setattr(self, k, snap[k].clone())
                 self._refresh_parts()
             else:
-                cur.copy_(snap[k])
+                dst.append(cur)
+                src.append(snap[k])
+        if dst:  # one fused copy per dtype instead of a launch per tensor (17 of them: ~0.15 ms of launches every time a benchmark rewinds its workload)
+            torch._foreach_copy_(dst, src)
         (self.step_count, self.t, self.cfg.obstacle_weight, self.cfg.smoothness_weight, self.cfg.grasp_weight, self.cfg.step_size) = snap["_host"]
         # the mask goes back with the flags it guards: a snapshot taken before any early stop has every scene active, and the
         # launches after the restore run unmasked again (dispatch schedule in use, no mask look-up in the goal-set kernel)
