@@ -364,11 +364,14 @@ def main():
             mx = float(tmax.item())
         return el, mx, allc
 
-    # A region of the driver's size (20 steps of ~0.2 ms) is a few milliseconds: one such interval says little.  When the first
-    # region is shorter than 50 ms, four more of the same --steps are timed and ms_per_step is the MEDIAN region (the spread is
+    # A region of the driver's size (20 steps of ~0.2 ms) is a few milliseconds: one such interval says little — and the first ones
+    # run while the GPU's clocks are still coming up (the goal-set launches of five successive 20-step regions: 179, 174, 173, 168,
+    # 166 us in the median; tools/trace_regions.py).  When the first region is shorter than 50 ms, more regions of the same --steps
+    # are timed — as many as it takes to time ~60 ms, between 5 and 15 — and ms_per_step is the MEDIAN region (the spread is
     # reported beside it); `steps` stays what was asked for.
     first = region()
-    n_regions = args.regions if args.regions > 0 else (5 if first[1] < 0.050 else 1)
+    n_regions = args.regions if args.regions > 0 else (max(5, min(15, int(np.ceil(0.060 / max(first[1], 1e-6))))) if first[1] < 0.050 else 1)
+    # (first[1] is the MAX over the ranks: every rank computes the same number)
     regs = [first] + [region() for _ in range(n_regions - 1)]
     order = sorted(range(len(regs)), key=lambda i: regs[i][1])
     mid = order[len(order) // 2]

@@ -1516,6 +1516,6 @@ def test_bench_two_ranks_on_the_config4_share_shape(tmp_path):
     # the timed regions: `steps` is what was asked for, ms_per_step the median region, the spread beside it
     for line in (j, j1):
         lo, hi = line["ms_per_step_spread"]
-        assert line["regions"] == 5 and lo <= line["ms_per_step"] <= hi and line["steps"] == 6
+        assert 5 <= line["regions"] <= 15 and lo <= line["ms_per_step"] <= hi and line["steps"] == 6
         assert abs(line["value"] - 25 * 6 / (line["ms_per_step"] * 6e-3)) <= 1e-6 * line["value"]
         assert line["setup_ms"]["pack_table_ms"] > 0 and line["setup_ms"]["engine_init_ms"] > 0
