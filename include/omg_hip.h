@@ -229,8 +229,12 @@ int omgx_pose_table(const double* robot, int32_t n_points, const double* configs
  *   potentials [S,G,n_remaining,10,P] float32 out, optional (NULL to skip) — the weighted
  *              potentials batch_obstacle_cost returns
  *   collides   [S,G] float32 out, optional: number of (config, link, point, object) collisions
- *   workspace  device scratch of omgx_goalset_workspace_bytes(S, G, n_remaining, P) bytes (may be NULL since ABI 4: every
- *              workgroup keeps its link poses in LDS; the argument stays for callers written against earlier versions)
+ *   workspace  NULL: every goal workgroup runs the kinematics of its own configurations (one launch).  Non-NULL (ABI 10), device
+ *              scratch of omgx_goalset_workspace_bytes(S, G, n_remaining, P) bytes: the KINEMATICS PRE-PASS — the goals' link
+ *              poses and row masks are computed by a launch of their own (k_goalset_kin: one lane per (goal, configuration),
+ *              no LDS, no barrier) into the workspace ([S*G][10][9][n_remaining+1] doubles, then [S*G][10][n_remaining] uint32),
+ *              and the goal workgroups start from there with one trip to memory.  Same arithmetic, same bits; the workspace
+ *              must not be shared by launches that may run at once (different streams).  Ignored with `potentials`.
  *   active, goal_count  optional [S] int32 (ABI 4), as in omgx_goalset_cost_layer below: scenes with active[s] == 0 and goals
  *              >= goal_count[s] are neither read nor written.  Only without `potentials` (else OMGX_ERR_UNSUPPORTED).
  * ------------------------------------------------------------------------------------------- */
@@ -313,7 +317,8 @@ int omgx_goalset_cost_layer_tiled(const double* robot, int32_t n_points,
                                   float* layer_potentials, float* layer_grads, float* layer_collides,
                                   const int32_t* active, const int32_t* goal_count,
                                   int32_t goal_parts, int32_t layer_link_groups, int32_t layer_config_block,
-                                  int32_t spread, double* layer_poses, void* stream);
+                                  int32_t spread, double* layer_poses, void* workspace /* ABI 10: as in (3), may be NULL */,
+                                  void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * (3d) omgx_goalset_cost_layer_parts — (3b) with a goal's tiles dealt over several workgroups of the BATCH kernel (ABI 8)
@@ -340,7 +345,8 @@ int omgx_goalset_cost_layer_parts(const double* robot, int32_t n_points,
                                   float* layer_potentials, float* layer_grads, float* layer_collides,
                                   const int32_t* active, const int32_t* goal_count,
                                   const int32_t* schedule, int32_t schedule_len, uint32_t* work,
-                                  int32_t goal_parts, double* layer_poses, void* stream);
+                                  int32_t goal_parts, double* layer_poses, void* workspace /* ABI 10: as in (3), may be NULL */,
+                                  void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * (4) omgx_chomp_optimize

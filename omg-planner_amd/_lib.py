@@ -17,7 +17,7 @@ NUM_DOF, INFO_STRIDE = 9, 16
 SCHEDULE_MAX_SCENES = 1792  # OMGX_SCHEDULE_MAX_SCENES
 SCHEDULE_SCENE_MAJOR, SCHEDULE_LONGEST_FIRST = 0, 1  # OMGX_SCHEDULE_*: the order inside an XCD (omgx_goalset_schedule_ordered)
 SCHEDULE_LONGEST_FIRST_MAX_ITEMS = 8192
-ABI_VERSION = 9  # omgx_abi_version() of the library these argtypes describe
+ABI_VERSION = 10  # omgx_abi_version() of the library these argtypes describe
 
 # every symbol include/omg_hip.h declares
 EXPORTS = ["omgx_sdf_loss_forward", "omgx_fk_sdf_workspace_bytes", "omgx_fk_sdf", "omgx_forward_kinematics", "omgx_pose_table",
@@ -83,8 +83,8 @@ def lib() -> C.CDLL:
         l.omgx_goalset_cost_layer.restype = C.c_int
         l.omgx_goalset_parts.argtypes = [i32, i32]
         l.omgx_goalset_parts.restype = i32
-        l.omgx_goalset_cost_layer_tiled.argtypes = [vp, i32, vp, vp, vp, vp, i64, vp, i32, i32, i32, f64, i32, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]
-        l.omgx_goalset_cost_layer_parts.argtypes = [vp, i32, vp, vp, vp, vp, i64, vp, i32, i32, i32, f64, i32, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp]
+        l.omgx_goalset_cost_layer_tiled.argtypes = [vp, i32, vp, vp, vp, vp, i64, vp, i32, i32, i32, f64, i32, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp]
+        l.omgx_goalset_cost_layer_parts.argtypes = [vp, i32, vp, vp, vp, vp, i64, vp, i32, i32, i32, f64, i32, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp]
         l.omgx_goalset_cost_layer_parts.restype = C.c_int
         l.omgx_goalset_schedule_parts.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp]
         l.omgx_goalset_schedule_parts.restype = C.c_int

@@ -37,6 +37,10 @@
 #ifndef GQ_WG_PER_CU
 #define GQ_WG_PER_CU 5   // 32 KB of LDS per workgroup (30 waypoints), <= 96 VGPRs
 #endif
+#ifndef GQ_WAVES
+#define GQ_WAVES 4       // waves per workgroup.  Other values are EXPERIMENT builds (tools/ab_goalset.py): only the
+#endif                   // batch kernel behind the kinematics pre-pass (PRE, no split goals) deals its tiles over GQ_WAVES waves
+#define GQ_NT (64 * GQ_WAVES)
 
 struct GqFar {  // what the far test of one object needs (wave-uniform, SGPRs)
     float T[12], lo[3], rc[3], rh[3], rr2;
@@ -62,7 +66,7 @@ struct GqLayout {
         tbl_off = mask_off + ((10 * MR * 4 + 15) & ~15);
         pts_off = tbl_off + tbl_n * 64;
         stage_off = pts_off + ((10 * P * 3 * 8 + 15) & ~15);
-        total = stage_off + 4 * 64 * 16;
+        total = stage_off + GQ_WAVES * 64 * 16;
         // the (sin, cos) table of the kinematics [PS][7][2] doubles borrows the queues' region (first used in the main loop), so
         // that the records and collision points can be staged while the kinematics run
         const int fk = stage_off + PS * 14 * 8 + 16;  // + the chain waves' progress flags (4 words)
@@ -121,8 +125,11 @@ __device__ __forceinline__ void gq_tbl_store(uint32_t* e, const GqTblRec& r) {
 // SPLIT: the batch kernel with a goal's tiles dealt over a.NP workgroups (omgx_goalset_cost_layer_parts; mid-size batches whose launch
 // is a round or two of the chip's workgroup slots: half as long a workgroup, the kinematics run in every part).  Everything else —
 // scene per XCD, dispatch schedule over (scene, goal, part) items, five workgroups per CU — is the batch kernel's.
-template <int LB, bool STAMP = false, bool LAT = false, bool SPLIT = false>
-__global__ __launch_bounds__(256, LAT ? 2 : GQ_WG_PER_CU) void k_goalset_queue(ChunkArgs a) {  // LAT: a workgroup per CU or two, registers are free
+// PRE: the goals' link poses and row masks come from k_goalset_kin's workspace (omg_goalset_kin.h) — the workgroup's prologue is ONE
+// trip to memory (poses, masks, collision points, records) instead of the kinematics and the culling; everything from the main loop
+// on is the same code on the same LDS contents.
+template <int LB, bool STAMP = false, bool LAT = false, bool SPLIT = false, bool PRE = false>
+__global__ __launch_bounds__(LAT ? 256 : GQ_NT, LAT ? 2 : GQ_WG_PER_CU) void k_goalset_queue(ChunkArgs a) {  // LAT: a workgroup per CU or two, registers are free
     extern __shared__ __attribute__((aligned(16))) double lds_pose[];  // no static LDS: 31744 B is the most a workgroup may use at 5 per CU
     GS_WG_STAMP(0);
     const int xcd = blockIdx.x & 7;
@@ -277,7 +284,45 @@ __global__ __launch_bounds__(256, LAT ? 2 : GQ_WG_PER_CU) void k_goalset_queue(C
     // Only while two waves are free and a link pair's rows fit one pass (CH <= 32): with 50 waypoints a single free wave walked the 10
     // links one pass each and the prologue got LONGER (0.49 instead of 0.41 ms per step at 50 waypoints: measured) — there all four
     // waves cull after the chain as before.  LAT: every wave culls the rows of its own tiles after the chain (below).
-    const bool cull_beside_chain = !LAT && chain_waves <= 2 && CH <= 32;
+    const bool cull_beside_chain = !PRE && !LAT && chain_waves <= 2 && CH <= 32;
+    if constexpr (PRE) {
+        // Everything the main loop starts from, requested before the first LDS store: the goal's poses (workspace layout
+        // [link][component][configuration] -> LDS [link][configuration][9]) and row masks, the robot's collision points, the records.
+        const int ncfg = CH + 1;
+        const int64_t gi = (int64_t)s * a.NG + goal;
+        const double* pw = a.pre_poses + gi * gk_pose_doubles(CH);
+        const uint32_t* mw = a.pre_masks + gi * (int64_t)(10 * CH);
+        const double pv0 = tid < 30 * P ? rv.g[246 + tid] : 0.0, pv1 = tid + GQ_NT < 30 * P ? rv.g[246 + tid + GQ_NT] : 0.0;
+        const bool tbl_lane = tid >= 128 && tid - 128 < a.tbl_n && o_begin + tid - 128 < o_end;
+        GqTblRec trec{};
+        if (tbl_lane) trec = gq_tbl_load(a.objects + o_begin + (tid - 128));
+        if (warming) gq_warm_scalar_cache(a.objects, o_begin, o_end, a.robot + OMGX_ROBOT_POINTS + 30 * P + 306 + 30 * P);
+        const int nm = 10 * CH, ne = 90 * ncfg;
+        uint32_t mv[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) mv[j] = tid + GQ_NT * j < nm ? mw[tid + GQ_NT * j] : 0u;  // 10 x 64 rows at most
+        // element e = tid + 256 j of the goal's poses sits at (lk = e / ncfg, c = e % ncfg): one division per thread, then steps
+        const int dq = GQ_NT / ncfg, dr = GQ_NT - dq * ncfg;
+        int lk = tid / ncfg, c = tid - lk * ncfg;
+        for (int e0 = tid; e0 < ne; e0 += GQ_NT * 12) {
+            double v[12];
+#pragma unroll
+            for (int j = 0; j < 12; ++j) v[j] = e0 + GQ_NT * j < ne ? pw[e0 + GQ_NT * j] : 0.0;
+#pragma unroll
+            for (int j = 0; j < 12; ++j) {
+                const int l = lk / 9, k = lk - 9 * l;
+                if (e0 + GQ_NT * j < ne) lds_pose[((size_t)l * pstride + c) * 9 + k] = v[j];
+                c += dr; lk += dq;
+                if (c >= ncfg) { c -= ncfg; ++lk; }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) if (tid + GQ_NT * j < nm) rowmask[tid + GQ_NT * j] = mv[j];
+        if (tid < 30 * P) pts[tid] = pv0;
+        if (tid + GQ_NT < 30 * P) pts[tid + GQ_NT] = pv1;
+        if (tbl_lane) gq_tbl_store(tbl + (tid - 128) * 16, trec);
+        GS_WG_STAMP(1);
+    } else
     {   // Kinematics of the start + CH interpolated configurations in two stages (omg_device.h: fk_joint_sincos on
         // (configuration, joint) lanes, fk_chain_row on (configuration, pose row) lanes); the (sin, cos) table borrows the
         // region behind the poses, which is first written after the barriers below.
@@ -392,7 +437,9 @@ __global__ __launch_bounds__(256, LAT ? 2 : GQ_WG_PER_CU) void k_goalset_queue(C
     const double* base = lds_pose + 9;
 
     static_assert(LB == 2 || !LAT, "the latency-mode culling maps 8 lanes to a tile of 4 waypoints x 2 links");
-    if (LAT) {
+    if (PRE) {
+        // (the masks came with the poses)
+    } else if (LAT) {
         // A pass over a link's rows costs the latency of its object loop whatever the number of lanes in it (~1 us for a lone wave:
         // beside the chain, 5 links per culling wave were the longest thing in the prologue).  Here every wave culls exactly the rows
         // its own tiles will read — lane -> (tile slot, link of the pair, waypoint of the block), normally one pass — and goes on
@@ -569,7 +616,7 @@ __global__ __launch_bounds__(256, LAT ? 2 : GQ_WG_PER_CU) void k_goalset_queue(C
     GS_COUNT(0);
     constexpr bool PARTS = LAT || SPLIT;  // this workgroup holds one part of a goal's tiles: the wave's q-th tile is lat_tile(q)
 #pragma unroll 1
-    for (int q = 0, t = PARTS ? lat_tile(0) : wave; PARTS ? t >= 0 : t < ntiles; t = PARTS ? lat_tile(++q) : t + 4) {  // every lane stays active: invalid items are flagged, not skipped
+    for (int q = 0, t = PARTS ? lat_tile(0) : wave; PARTS ? t >= 0 : t < ntiles; t = PARTS ? lat_tile(++q) : t + GQ_WAVES) {  // every lane stays active: invalid items are flagged, not skipped
         const int rb = t / (10 / LB), l0 = (t - rb * (10 / LB)) * LB;
         GS_COUNT(1);
         {
@@ -680,15 +727,19 @@ __global__ __launch_bounds__(256, LAT ? 2 : GQ_WG_PER_CU) void k_goalset_queue(C
     {
         const double ws_ = wave_sum(tsum);  // exact (see tsum)
         const float wc_ = wave_sum(tcol);
-        double* red = reinterpret_cast<double*>(lds_bytes + L.tbl_off);  // [4] sums, then [4] float counts: the records are dead once every wave has flushed its queue
-        float* redc = reinterpret_cast<float*>(red + 4);
+        double* red = reinterpret_cast<double*>(lds_bytes + L.tbl_off);  // [GQ_WAVES] sums, then as many float counts: the records are dead once every wave has flushed its queue
+        float* redc = reinterpret_cast<float*>(red + GQ_WAVES);
         __syncthreads();
         if (lane == 0) { red[wave] = ws_; redc[wave] = wc_; }
         __syncthreads();
         if (tid == 0) {
             const int64_t k = (int64_t)s * a.NCH + chunk;
-            if (a.chunk_cost) a.chunk_cost[k] = (float)(((red[0] + red[1]) + red[2]) + red[3]);
-            if (a.chunk_col) a.chunk_col[k] = ((redc[0] + redc[1]) + redc[2]) + redc[3];
+            double rs = ((red[0] + red[1]) + red[2]) + red[3];   // exact: the order does not matter (tsum)
+            float rc = ((redc[0] + redc[1]) + redc[2]) + redc[3];  // integers below 2^24: exact too
+#pragma unroll
+            for (int w = 4; w < GQ_WAVES; ++w) { rs += red[w]; rc += redc[w]; }
+            if (a.chunk_cost) a.chunk_cost[k] = (float)rs;
+            if (a.chunk_col) a.chunk_col[k] = rc;
             if (STAMP) { const unsigned long long dt = wall_clock64() - work_t0; a.work[k] = dt < 1 ? 1u : (dt > 0xffffffffull ? 0xffffffffu : (uint32_t)dt); }
         }
     }

@@ -208,6 +208,10 @@ struct ChunkArgs {
     int layer_parts, layer_lg, layer_nb, layer_cb, spread;
     double* wp_pose_out;       // [S][wp_n][10][12] or null: the layer workgroups of link group 0 leave the waypoints' poses here
     uint32_t* work;
+    // kinematics pre-pass (k_goalset_kin -> k_goalset_queue<..., PRE>; omg_goalset_kin.h): the goals' link poses
+    // [S * NG][10][9][CH + 1] and row masks [S * NG][10][CH] in the caller's workspace, or null: every goal workgroup runs its own
+    double* pre_poses;
+    uint32_t* pre_masks;
 };
 
 // Thread layout: 256 threads = 16 rows x 16 lanes.  Lane = collision point p of a link (P <= 16), row =
@@ -599,6 +603,7 @@ extern "C" int omgx_debug_gs_counts(unsigned long long* h_out, int reset) {
 #endif
 
 
+#include "omg_goalset_kin.h"
 #include "omg_goalset_queue.h"
 
 // =================================================================================================
@@ -668,7 +673,7 @@ static void timing_events(int kind, hipEvent_t* ev0, hipEvent_t* ev1) {
     *ev0 = g_ev[i][0]; *ev1 = g_ev[i][1];
     ++g_timing_n;
 }
-extern "C" int omgx_abi_version(void) { return 9; }  // 9: omgx_goalset_schedule_ordered (longest first inside an XCD); 8: omgx_goalset_cost_layer_parts, omgx_goalset_schedule_parts (a goal's tiles over several workgroups of the batch kernel); 2: `active` masks; 3: ragged goal sets (goal_count, eta); 4: goal schedule + work; 5: 184-byte object records (influence region = rounded box); 6: omgx_goalset_cost_layer_tiled, omgx_learner_params.cost_parts; 7: pose tables (omgx_pose_table, pointer fields at the end of both parameter blocks, layer_poses)
+extern "C" int omgx_abi_version(void) { return 10; }  // 10: kinematics pre-pass (k_goalset_kin) behind the `workspace` argument of omgx_goalset_cost / _cost_layer, new trailing `workspace` of _cost_layer_parts / _cost_layer_tiled; 9: omgx_goalset_schedule_ordered (longest first inside an XCD); 8: omgx_goalset_cost_layer_parts, omgx_goalset_schedule_parts (a goal's tiles over several workgroups of the batch kernel); 2: `active` masks; 3: ragged goal sets (goal_count, eta); 4: goal schedule + work; 5: 184-byte object records (influence region = rounded box); 6: omgx_goalset_cost_layer_tiled, omgx_learner_params.cost_parts; 7: pose tables (omgx_pose_table, pointer fields at the end of both parameter blocks, layer_poses)
 extern "C" int omgx_device_arch(char* h_buf, int32_t h_len) {
     if (!h_buf || h_len <= 0) return OMGX_ERR_INVALID;
     int dev = 0;
@@ -764,9 +769,8 @@ extern "C" int64_t omgx_fk_sdf_workspace_bytes(int32_t num_scenes, int32_t confi
 extern "C" int64_t omgx_goalset_workspace_bytes(int32_t num_scenes, int32_t num_goals, int32_t n_remaining, int32_t n_points) {
     if (num_scenes <= 0 || num_goals <= 0 || n_remaining <= 0 || n_points <= 0) return 0;
     (void)n_points;
-    const int64_t poses = (int64_t)num_scenes * num_goals * 10 * n_remaining * 12 * sizeof(double);
-    const int64_t start = (int64_t)num_scenes * 10 * 12 * sizeof(double);
-    return poses + start;
+    // the kinematics pre-pass (omg_goalset_kin.h): per goal 10 x 9 x (n + 1) pose doubles + 10 x n mask words
+    return gk_workspace_bytes((int64_t)num_scenes * num_goals, n_remaining);
 }
 
 // How a k_goalset_queue launch is cut into workgroups (ChunkArgs: NP, layer_*, spread).  The default is the batch layout.
@@ -776,6 +780,7 @@ struct GsTiling {
     int layer_cb = 0;    // waypoints per layer workgroup; 0: all
     int spread = 0;      // latency mode: workgroups in plain (scene, item) order over all XCDs instead of a scene per XCD
     double* wp_pose_out = nullptr;  // the waypoints' poses for the step that follows (ChunkArgs)
+    void* kin_ws = nullptr;         // omgx_goalset_workspace_bytes of scratch: the goals' kinematics run as a launch of their own (omg_goalset_kin.h)
 };
 
 // Workgroups per goal for a window of n_remaining configurations: the largest power of two <= max_parts that still leaves every
@@ -817,27 +822,34 @@ static int launch_goalset(ChunkArgs& ca, int timing_kind, hipStream_t st, const 
         // the batch layout stays below (61 KB at 64 waypoints x 16 points); the latency-mode kernel adds the chain constants and the
         // layer's per-object contributions (73 KB at 64 waypoints) and opts in
         if (!ca.spread) return OMGX_ERR_UNSUPPORTED;
-        const int rc = allow_big_lds<10>(k_goalset_queue<2, false, true>, "hipFuncSetAttribute(k_goalset_queue)");
+        int rc = allow_big_lds<10>(k_goalset_queue<2, false, true>, "hipFuncSetAttribute(k_goalset_queue)");
         if (rc != OMGX_OK) return rc;
+        rc = allow_big_lds<11>(k_goalset_queue<2, false, true, false, true>, "hipFuncSetAttribute(k_goalset_queue)");
+        if (rc != OMGX_OK) return rc;
+    }
+    const bool pre = tl.kin_ws != nullptr && ca.NG > 0 && ca.traj_start != nullptr;
+    ca.pre_poses = nullptr; ca.pre_masks = nullptr;
+    if (pre) {  // the goals' kinematics and row masks as a launch of their own (omg_goalset_kin.h), one lane per (goal, configuration)
+        const int64_t goals = (int64_t)ca.S * ca.NG;
+        ca.pre_poses = reinterpret_cast<double*>(tl.kin_ws);
+        ca.pre_masks = reinterpret_cast<uint32_t*>(ca.pre_poses + goals * gk_pose_doubles(ca.CH));
+        const int ncfg = ca.CH + 1, gpw = ncfg <= 64 ? 64 / ncfg : 1;
+        const int64_t waves = (int64_t)ca.S * ((ca.NG + gpw - 1) / gpw);
+        hipLaunchKernelGGL(k_goalset_kin, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, ca);
+        OMGX_CHECK_LAUNCH("k_goalset_kin");
     }
     hipEvent_t ev0, ev1;
     timing_events(timing_kind, &ev0, &ev1);
-    if (ca.spread) {
-        if (ev0) hipExtLaunchKernelGGL((k_goalset_queue<2, false, true>), dim3((unsigned)grid), dim3(256), (uint32_t)lds, st, ev0, ev1, 0, ca);
-        else hipLaunchKernelGGL((k_goalset_queue<2, false, true>), dim3((unsigned)grid), dim3(256), lds, st, ca);
-    } else if (split && ca.work) {
-        if (ev0) hipExtLaunchKernelGGL((k_goalset_queue<2, true, false, true>), dim3((unsigned)grid), dim3(256), (uint32_t)lds, st, ev0, ev1, 0, ca);
-        else hipLaunchKernelGGL((k_goalset_queue<2, true, false, true>), dim3((unsigned)grid), dim3(256), lds, st, ca);
-    } else if (split) {
-        if (ev0) hipExtLaunchKernelGGL((k_goalset_queue<2, false, false, true>), dim3((unsigned)grid), dim3(256), (uint32_t)lds, st, ev0, ev1, 0, ca);
-        else hipLaunchKernelGGL((k_goalset_queue<2, false, false, true>), dim3((unsigned)grid), dim3(256), lds, st, ca);
-    } else if (ca.work) {
-        if (ev0) hipExtLaunchKernelGGL((k_goalset_queue<2, true>), dim3((unsigned)grid), dim3(256), (uint32_t)lds, st, ev0, ev1, 0, ca);
-        else hipLaunchKernelGGL((k_goalset_queue<2, true>), dim3((unsigned)grid), dim3(256), lds, st, ca);
-    } else {
-        if (ev0) hipExtLaunchKernelGGL((k_goalset_queue<2, false>), dim3((unsigned)grid), dim3(256), (uint32_t)lds, st, ev0, ev1, 0, ca);
-        else hipLaunchKernelGGL((k_goalset_queue<2, false>), dim3((unsigned)grid), dim3(256), lds, st, ca);
-    }
+    const unsigned g = (unsigned)grid;
+    const uint32_t l32 = (uint32_t)lds;
+#define GQ_GO(STAMP, LAT, SPLIT, PRE) do { if (ev0) hipExtLaunchKernelGGL((k_goalset_queue<2, STAMP, LAT, SPLIT, PRE>), dim3(g), dim3((LAT) ? 256 : GQ_NT), l32, st, ev0, ev1, 0, ca); \
+                                            else hipLaunchKernelGGL((k_goalset_queue<2, STAMP, LAT, SPLIT, PRE>), dim3(g), dim3((LAT) ? 256 : GQ_NT), l32, st, ca); } while (0)
+    if (ca.spread) { if (pre) GQ_GO(false, true, false, true); else GQ_GO(false, true, false, false); }
+    else if (split && ca.work) { if (pre) GQ_GO(true, false, true, true); else GQ_GO(true, false, true, false); }
+    else if (split) { if (pre) GQ_GO(false, false, true, true); else GQ_GO(false, false, true, false); }
+    else if (ca.work) { if (pre) GQ_GO(true, false, false, true); else GQ_GO(true, false, false, false); }
+    else { if (pre) GQ_GO(false, false, false, true); else GQ_GO(false, false, false, false); }
+#undef GQ_GO
     OMGX_CHECK_LAUNCH("k_goalset_queue");
     return OMGX_OK;
 }
@@ -1027,8 +1039,9 @@ static int goalset_cost_impl(const double* robot, int32_t n_points, const omgx_o
     }
     if (schedule && (schedule_len < 8 || schedule_len % 8 != 0)) return OMGX_ERR_INVALID;
     ca.active = active; ca.goal_count = goal_count; ca.schedule = schedule; ca.sched_len = schedule ? schedule_len : 0; ca.work = work;
-    (void)workspace;  // kept in the signature (ABI): no launch of this entry point spills poses to memory any more
-    return potentials ? launch_chunks(ca, st) : launch_goalset(ca, 0, st, tiling);
+    GsTiling tl = tiling;
+    tl.kin_ws = workspace;  // non-null: the goals' kinematics as a launch of their own (ABI 10)
+    return potentials ? launch_chunks(ca, st) : launch_goalset(ca, 0, st, tl);
 }
 
 extern "C" int omgx_goalset_cost(const double* robot, int32_t n_points, const omgx_object* objects,
@@ -1264,13 +1277,13 @@ extern "C" int omgx_goalset_cost_layer_parts(const double* robot, int32_t n_poin
                                              int32_t layer_soften_fingers, float* layer_potentials, float* layer_grads,
                                              float* layer_collides, const int32_t* active, const int32_t* goal_count,
                                              const int32_t* schedule, int32_t schedule_len, uint32_t* work, int32_t goal_parts,
-                                             double* layer_poses, void* stream) {
+                                             double* layer_poses, void* workspace, void* stream) {
     if (!traj) return OMGX_ERR_INVALID;
     GsTiling tl;
     tl.goal_parts = goal_parts;
     tl.wp_pose_out = layer_poses;
     return goalset_cost_impl(robot, n_points, objects, scene_begin, sdf_pool, traj_start, traj_start_stride, goals, num_scenes,
-                             num_goals, n_remaining, time_interval, soften_fingers, goal_cost, nullptr, collides, nullptr, traj,
+                             num_goals, n_remaining, time_interval, soften_fingers, goal_cost, nullptr, collides, workspace, traj,
                              n_waypoints, layer_soften_fingers, layer_potentials, layer_grads, layer_collides, active, goal_count, schedule,
                              schedule_len, work, stream, tl);
 }
@@ -1288,13 +1301,13 @@ extern "C" int omgx_goalset_cost_layer_tiled(const double* robot, int32_t n_poin
                                              float* layer_potentials, float* layer_grads, float* layer_collides,
                                              const int32_t* active, const int32_t* goal_count, int32_t goal_parts,
                                              int32_t layer_link_groups, int32_t layer_config_block, int32_t spread, double* layer_poses,
-                                             void* stream) {
+                                             void* workspace, void* stream) {
     if (!traj && num_goals <= 0) return OMGX_ERR_INVALID;
     GsTiling tl;
     tl.goal_parts = goal_parts; tl.layer_lg = layer_link_groups; tl.layer_cb = layer_config_block; tl.spread = spread;
     tl.wp_pose_out = traj ? layer_poses : nullptr;
     return goalset_cost_impl(robot, n_points, objects, scene_begin, sdf_pool, traj_start, traj_start_stride, goals, num_scenes,
-                             num_goals, num_goals > 0 ? n_remaining : 1, time_interval, soften_fingers, goal_cost, nullptr, collides, nullptr, traj,
+                             num_goals, num_goals > 0 ? n_remaining : 1, time_interval, soften_fingers, goal_cost, nullptr, collides, workspace, traj,
                              n_waypoints, layer_soften_fingers, layer_potentials, layer_grads, layer_collides, active, goal_count, nullptr,
                              0, nullptr, stream, tl);
 }

@@ -151,10 +151,12 @@ class ChompEngine:
     LAT_LAYER_BLOCK = 4   # one link x 4 waypoints per layer workgroup: its four waves take the objects side by side
     LAT_HAND_OVER_POSES = True  # inside plan(), both layouts: link poses handed between the launches (False: every kernel runs its own kinematics; same bits)
 
+    PREPASS_DEFAULT = False
+
     def __init__(self, model: PandaModel, batch: SceneBatch, cfg: Config, start: np.ndarray, goal_set: np.ndarray,
                  reach_grasps: np.ndarray | None = None, traj_init: np.ndarray | None = None, device="cuda:0",
                  ol_alg: str = "FTL", stream: "torch.cuda.Stream | None" = None, goal_counts=None, latency_mode: bool = False,
-                 goal_parts: int = 1):
+                 goal_parts: int = 1, prepass: "bool | None" = None):
         """start [S,9]; goal_set [S,G,9]; reach_grasps [S,G,c,9] (needed when cfg.use_standoff).
         `stream`: run every launch of this engine on that HIP stream (several engines holding disjoint scene
         subsets on different streams overlap each other's latency-bound kernels).
@@ -167,8 +169,16 @@ class ChompEngine:
         sums (goal_cost_total() adds them).  No pipeline, no dispatch schedule in this mode.
         `goal_parts` (1, 2, 4, 8; batch layout only): MID-SIZE batches — a goal's tiles dealt over up to that many workgroups of
         the batch kernel (omgx_goalset_cost_layer_parts), scene per XCD, dispatch schedule and pipeline as usual; goal costs are
-        partial sums as in latency mode.  ChompEngine.layout() names the rule that picks all of this from the shape."""
+        partial sums as in latency mode.  ChompEngine.layout() names the rule that picks all of this from the shape.
+        `prepass`: the goals' kinematics and row culling run as a launch of their own ahead of every goal-set launch
+        (k_goalset_kin, one lane per (goal, configuration), through a workspace in HBM) instead of in every goal workgroup's
+        prologue — the same bits from three launches per iteration instead of two."""
         self.cfg = cfg
+        if prepass is None:  # the class default, or OMGX_PREPASS=0/1 (A/B runs of one command line)
+            import os
+            env = os.environ.get("OMGX_PREPASS", "")
+            prepass = self.PREPASS_DEFAULT if env == "" else env not in ("0", "false", "no")
+        self.prepass = bool(prepass)
         self.latency = bool(latency_mode)
         self.goal_parts = 1 if self.latency else int(goal_parts)
         if self.goal_parts not in (1, 2, 4, 8):
@@ -511,7 +521,7 @@ class ChompEngine:
                     soften_fingers=False, layer_soften_fingers=self.cfg.uncheck_finger_collision == -1, active=self._mask(),
                     goal_count=self.goal_count, goal_parts=self.LAT_GOAL_PARTS, layer_link_groups=self.LAT_LAYER_LINK_GROUPS,
                     layer_config_block=self.LAT_LAYER_BLOCK, spread=True,
-                    layer_poses=self.wp_pose if (self._poses_on and with_layer) else None)
+                    layer_poses=self.wp_pose if (self._poses_on and with_layer) else None, prepass=self.prepass)
             elif with_layer:  # the SDF layer of the current trajectories rides on the goal-set launch
                 # the second launch is the measuring one (the first runs on cold caches and would distort the weights);
                 # until then the items are split evenly by count.  Small batches keep the even split: measuring only pays
@@ -537,7 +547,8 @@ class ChompEngine:
                                        layer_soften_fingers=self.cfg.uncheck_finger_collision == -1,
                                        out=(self.goal_cost, self.goal_col), active=self._mask(), goal_count=self.goal_count,
                                        schedule=self.schedule if use_sched else None, work=self.work[: self.S * self.G * NP] if measure else None,
-                                       goal_parts=self.goal_parts, layer_poses=self.wp_pose if self._poses_on else None)
+                                       goal_parts=self.goal_parts, layer_poses=self.wp_pose if self._poses_on else None,
+                                       prepass=self.prepass)
                 if measure:
                     self._measured = True
                     self.schedule = self.build_schedule(parts=NP)
@@ -545,11 +556,11 @@ class ChompEngine:
                 self._parts_last = ops.goalset_cost_layer_tiled(
                     self.robot, self.P, self.scenes, traj_start, self.cv_goals, n_rem, self.cfg.time_interval, None, None,
                     (self.goal_cost, self.goal_col), soften_fingers=False, active=self._mask(), goal_count=self.goal_count,
-                    goal_parts=self.goal_parts, layer_link_groups=5, layer_config_block=0, spread=False)
+                    goal_parts=self.goal_parts, layer_link_groups=5, layer_config_block=0, spread=False, prepass=self.prepass)
             else:
                 ops.goalset_cost(self.robot, self.P, self.scenes, traj_start, self.cv_goals, n_rem, self.cfg.time_interval,
                                  soften_fingers=False, out=(self.goal_cost, self.goal_col), active=self._mask(),
-                                 goal_count=self.goal_count)
+                                 goal_count=self.goal_count, prepass=self.prepass)
         elif with_layer:
             self._layer()
         if defer_update:
@@ -721,7 +732,7 @@ class ChompEngine:
                                        (self.grad, self.cost_traj, self.info), self.cost_vec, self._active, self.goal_count, self.eta_s,
                                        self._scene_flags, layer_soften_fingers=self.cfg.uncheck_finger_collision == -1,
                                        tiling=self._tiling() if self.latency else None,
-                                       layer_poses=self.wp_pose, goal_parts=self.goal_parts)
+                                       layer_poses=self.wp_pose, goal_parts=self.goal_parts, prepass=self.prepass)
             hot = self._hot = (key, calls, baked)
         calls = hot[1]
         stream = (self.stream if self.stream is not None else torch.cuda.current_stream(self.device)).cuda_stream

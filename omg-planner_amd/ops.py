@@ -39,6 +39,19 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
     return ws
 
 
+def _kin_workspace(prepass, S: int, G: int, n_remaining: int, P: int, device):
+    """Scratch of the kinematics pre-pass (omgx_goalset_workspace_bytes): None without it, the caller's own uint8 tensor, or the
+    per-device cached buffer (one stream at a time: launches on two streams need a workspace each)."""
+    if prepass is None or prepass is False:
+        return None
+    need = _lib.lib().omgx_goalset_workspace_bytes(S, G, int(n_remaining), P)
+    if isinstance(prepass, torch.Tensor):
+        if not prepass.is_cuda or prepass.numel() * prepass.element_size() < need or not prepass.is_contiguous():
+            raise _lib.OmgHipError(f"the pre-pass workspace must be a contiguous device tensor of at least {need} bytes")
+        return prepass
+    return _workspace(need, device)
+
+
 def sdf_loss_forward(pose_init, sdf_grids, sdf_limits, points, epsilons, padding_scales, clearances, disables):
     """omg_cuda.sdf_loss_forward (layers/omg_layers.cpp:24-49): -> [potentials[N], potential_grads[N,3], collides[N]]."""
     for n, t in (("pose_init", pose_init), ("sdf_grids", sdf_grids), ("sdf_limits", sdf_limits), ("points", points),
@@ -207,11 +220,13 @@ def fk_sdf(robot: torch.Tensor, P: int, scenes: DeviceScenes, joints: torch.Tens
 
 
 def goalset_cost(robot, P, scenes: DeviceScenes, traj_start, goals, n_remaining, dt, soften_fingers=False,
-                 want_potentials=False, out=None, active=None, goal_count=None):
+                 want_potentials=False, out=None, active=None, goal_count=None, prepass=False):
     """traj_start [S,9], goals [S,G,9] f64 -> goal_cost [S,G] f32, collides [S,G] f32, potentials [S,G,n,10,P] | None.
     traj_start may be a strided row view such as traj[:, k] of a contiguous [S,n,9] tensor (no copy is made).
     active / goal_count [S] int32 (optional, not with want_potentials): scenes with 0 and the padding goals of a ragged
-    goal set are skipped; their outputs keep their previous contents."""
+    goal set are skipped; their outputs keep their previous contents.
+    prepass: the goals' kinematics and row masks as a launch of their own (k_goalset_kin, ABI 10) through a scratch workspace
+    — same bits, two launches; a torch tensor of omgx_goalset_workspace_bytes is taken as that workspace."""
     if not (traj_start.is_cuda and traj_start.dtype == torch.float64 and traj_start.dim() == 2 and traj_start.shape[1] == 9
             and traj_start.stride(1) == 1 and (traj_start.shape[0] == 1 or traj_start.stride(0) >= 9)):
         raise _lib.OmgHipError("traj_start must be a float64 device tensor [S,9] with unit inner stride")
@@ -227,7 +242,7 @@ def goalset_cost(robot, P, scenes: DeviceScenes, traj_start, goals, n_remaining,
     pots = torch.empty((S, G, n_remaining, 10, P), dtype=torch.float32, device=dev) if want_potentials else None
     l = _lib.lib()
     with torch.cuda.device(dev):
-        ws = _workspace(l.omgx_goalset_workspace_bytes(S, G, n_remaining, P), dev)
+        ws = _kin_workspace(prepass, S, G, n_remaining, P, dev) if not want_potentials else None
         check(l.omgx_goalset_cost(_ptr(robot), P, _ptr(scenes.objects), _ptr(scenes.scene_begin), _ptr(scenes.pool),
                                   _ptr(traj_start), ts_stride, _ptr(goals), S, G, n_remaining, float(dt), int(bool(soften_fingers)),
                                   _ptr(cost), _ptr(pots), _ptr(col), _ptr(ws), _ptr(_active(active, S)), _ptr(_active(goal_count, S)),
@@ -237,13 +252,13 @@ def goalset_cost(robot, P, scenes: DeviceScenes, traj_start, goals, n_remaining,
 
 def goalset_cost_layer(robot, P, scenes: DeviceScenes, traj_start, goals, n_remaining, dt, traj, layer_out, soften_fingers=False,
                        layer_soften_fingers=False, out=None, active=None, goal_count=None, schedule=None, work=None, goal_parts=1,
-                       layer_poses=None):
+                       layer_poses=None, prepass=False):
     """goalset_cost (cost only) + fk_sdf(traj) in one launch (omgx_goalset_cost_layer).  traj [S,n,9] f64;
     layer_out = (potentials [S,n,10,P], grads [S,n,10,P,3], collides [S,n,10,P]) float32, written in place.
     active [S] int32 (optional): scenes with 0 are skipped, their outputs keep their previous contents.
     goal_parts > 1 (omgx_goalset_cost_layer_parts): a goal's tiles dealt over NP = goalset_parts(n_remaining, goal_parts) workgroups
     of the batch kernel; `out` must then hold S * G * NP elements each and receives [S][G][NP] PARTIAL sums, schedule / work count
-    the S * G * NP (scene, goal, part) items.  Returns (cost, collides) as given / allocated."""
+    the S * G * NP (scene, goal, part) items.  prepass: see goalset_cost.  Returns (cost, collides) as given / allocated."""
     if not (traj_start.is_cuda and traj_start.dtype == torch.float64 and traj_start.dim() == 2 and traj_start.shape[1] == 9
             and traj_start.stride(1) == 1 and (traj_start.shape[0] == 1 or traj_start.stride(0) >= 9)):
         raise _lib.OmgHipError("traj_start must be a float64 device tensor [S,9] with unit inner stride")
@@ -282,11 +297,12 @@ def goalset_cost_layer(robot, P, scenes: DeviceScenes, traj_start, goals, n_rema
                                                   int(bool(layer_soften_fingers)), _ptr(lp), _ptr(lg), _ptr(lc), _ptr(_active(active, S)),
                                                   _ptr(_active(goal_count, S)), _ptr(_i32n(schedule, None, "schedule")),
                                                   0 if schedule is None else schedule.numel(), _ptr(_i32n(work, S * G * NP, "work")),
-                                                  int(goal_parts), _ptr(layer_poses), _stream()),
+                                                  int(goal_parts), _ptr(layer_poses), _ptr(_kin_workspace(prepass, S, G, n_remaining, P, dev)),
+                                                  _stream()),
                   "omgx_goalset_cost_layer_parts")
         return cost, col
     with torch.cuda.device(dev):
-        ws = _workspace(l.omgx_goalset_workspace_bytes(S, G, n_remaining, P), dev)
+        ws = _kin_workspace(prepass, S, G, n_remaining, P, dev)
         check(l.omgx_goalset_cost_layer(_ptr(robot), P, _ptr(scenes.objects), _ptr(scenes.scene_begin), _ptr(scenes.pool),
                                         _ptr(traj_start), ts_stride, _ptr(goals), S, G, n_remaining, float(dt),
                                         int(bool(soften_fingers)), _ptr(cost), _ptr(col), _ptr(ws), _ptr(traj), n,
@@ -304,7 +320,7 @@ def goalset_parts(n_remaining: int, goal_parts: int) -> int:
 
 def goalset_cost_layer_tiled(robot, P, scenes: DeviceScenes, traj_start, goals, n_remaining, dt, traj, layer_out, out,
                              soften_fingers=False, layer_soften_fingers=False, active=None, goal_count=None, goal_parts=4,
-                             layer_link_groups=10, layer_config_block=16, spread=True, layer_poses=None):
+                             layer_link_groups=10, layer_config_block=16, spread=True, layer_poses=None, prepass=False):
     """The goal-set batch and / or the trajectory layer cut into many small workgroups (omgx_goalset_cost_layer_tiled: latency
     mode for one or a few scenes).  goals None: only the layer; traj None: only the batch.  out = (cost, collides): float32
     device tensors with at least S * G * goalset_parts(n_remaining, goal_parts) elements, written as [S][G][parts] PARTIAL sums
@@ -349,7 +365,7 @@ def goalset_cost_layer_tiled(robot, P, scenes: DeviceScenes, traj_start, goals, 
             ts_stride, _ptr(goals), S, G, int(n_remaining) if goals is not None else 1, float(dt), int(bool(soften_fingers)), _ptr(cost), _ptr(col),
             _ptr(traj), n, int(bool(layer_soften_fingers)), _ptr(lp), _ptr(lg), _ptr(lc), _ptr(_active(active, S)),
             _ptr(_active(goal_count, S)), int(goal_parts), int(layer_link_groups), int(layer_config_block), int(bool(spread)),
-            _ptr(layer_poses), _stream()),
+            _ptr(layer_poses), _ptr(_kin_workspace(prepass, S, G, n_remaining, P, dev) if goals is not None else None), _stream()),
             "omgx_goalset_cost_layer_tiled")
     return parts
 
@@ -535,7 +551,7 @@ class IterationCalls:
 
     def __init__(self, robot, P, scenes: DeviceScenes, goals, dt, traj, layer_out, goal_out, goal_set, reach, state, goal_idx,
                  start, end, goal_rows, goal_point, step_out, cost_vector, active, goal_count=None, eta=None, scene_flags=None,
-                 layer_soften_fingers=False, tiling=None, layer_poses=None, goal_parts=1):
+                 layer_soften_fingers=False, tiling=None, layer_poses=None, goal_parts=1, prepass=False):
         lp, lg, lc = layer_out
         cost, col = goal_out
         grad, cost_traj, info = step_out
@@ -580,7 +596,12 @@ class IterationCalls:
         self._layer_soft = int(bool(layer_soften_fingers))
         p = _ptr
         self._gs_head = (p(robot), self.P, p(scenes.objects), p(scenes.scene_begin), p(scenes.pool))
-        self._gs_mid = (p(cost), p(col), None, p(traj), n, self._layer_soft, p(lp), p(lg), p(lc))
+        # prepass: the goals' kinematics as a launch of their own (k_goalset_kin) through a workspace this object owns — launches of
+        # different IterationCalls may run at once on different streams
+        self.kin_workspace = (torch.empty(max(16, l.omgx_goalset_workspace_bytes(S, G, n, self.P)), dtype=torch.uint8, device=traj.device)
+                              if prepass else None)
+        self._kin_ws = p(self.kin_workspace)
+        self._gs_mid = (p(cost), p(col), self._kin_ws, p(traj), n, self._layer_soft, p(lp), p(lg), p(lc))
         self._goals, self._active_p, self._goal_count = p(goals), p(active), p(goal_count)
         self._up_a = (p(goal_set), p(reach), p(cost), p(state), p(goal_idx), p(cost_vector), p(robot))
         self._up_b = (p(traj), p(start), p(end), p(goal_rows), p(goal_point), p(lp), p(lg), p(lc), p(active), S, p(grad), p(cost_traj),
@@ -600,7 +621,7 @@ class IterationCalls:
             cost, col, _ws, traj, n, soft, lp, lg, lc = self._gs_mid
             args = (*self._gs_head, C.c_void_p(self._traj_addr + 72 * start_idx), self.n * 9, self._goals, self.S, self.G,
                     self.n - start_idx, self.dt, 0, cost, col, traj, n, soft, lp, lg, lc, self._active_p if masked else None,
-                    self._goal_count, *self._tiling, self._layer_poses if self.use_layer_poses else None, C.c_void_p(stream))
+                    self._goal_count, *self._tiling, self._layer_poses if self.use_layer_poses else None, self._kin_ws, C.c_void_p(stream))
             if self._on_device():
                 check(self._f_gst(*args), "omgx_goalset_cost_layer_tiled")
             else:
@@ -614,7 +635,7 @@ class IterationCalls:
                     self.n - start_idx, self.dt, 0, cost, col, traj, n, soft, lp, lg, lc, self._active_p if masked else None,
                     self._goal_count, _ptr(_i32n(schedule, None, "schedule")), 0 if schedule is None else schedule.numel(),
                     _ptr(_i32n(work, self.S * self.G * NP, "work")), self._goal_parts, self._layer_poses if self.use_layer_poses else None,
-                    C.c_void_p(stream))
+                    self._kin_ws, C.c_void_p(stream))
             if self._on_device():
                 check(self._f_gsp(*args), "omgx_goalset_cost_layer_parts")
             else:

@@ -40,7 +40,9 @@ def test_workspace_and_aux_sizes_without_gpu():
     from omg_planner_amd import _lib
     lib = _lib.lib()
     assert lib.omgx_chomp_aux_doubles(30) == 30 * 9 + 30 * 10 + 30 * 9 + 31
-    assert lib.omgx_goalset_workspace_bytes(100, 64, 30, 15) == (100 * 64 * 10 * 30 * 12 + 100 * 120) * 8
+    # ABI 10: the kinematics pre-pass's scratch — per goal 10 links x 9 doubles x (n + 1) configurations + 10 x n mask words
+    assert lib.omgx_goalset_workspace_bytes(100, 64, 30, 15) == 100 * 64 * (90 * 31 * 8 + 300 * 4)
+    assert lib.omgx_goalset_workspace_bytes(1, 1, 1, 15) == 1488 and lib.omgx_goalset_workspace_bytes(0, 64, 30, 15) == 0
     assert lib.omgx_fk_sdf_workspace_bytes(100, 30, 15) >= 100 * 10 * 32 * 12 * 8
     assert lib.omgx_fk_sdf_workspace_bytes(0, 30, 15) == 0
 
@@ -77,14 +79,14 @@ def test_goalset_parts_and_tiled_argument_checks_without_gpu():
 
     def call(goal_parts=4, lg=10, cb=4, spread=1, goals=d, traj=d, G=64, n_rem=30):
         return lib.omgx_goalset_cost_layer_tiled(d, 15, d, d, d, d, 270, goals, 1, G, n_rem, 0.1, 0, d, d, traj, 30, 0, d, d, d, None, None,
-                                                 goal_parts, lg, cb, spread, None, None)
+                                                 goal_parts, lg, cb, spread, None, None, None)
     assert call(goal_parts=0) == _lib.OMGX_ERR_INVALID and call(goal_parts=9) == _lib.OMGX_ERR_INVALID
     assert call(lg=3) == _lib.OMGX_ERR_INVALID and call(lg=11) == _lib.OMGX_ERR_INVALID and call(cb=-1) == _lib.OMGX_ERR_INVALID
     # (goal_parts > 1 without `spread` is the batch kernel with split goals since ABI 8: omgx_goalset_cost_layer_parts)
 
     def parts(goal_parts=2, traj=d, sched=None, slen=0):
         return lib.omgx_goalset_cost_layer_parts(d, 15, d, d, d, d, 270, d, 1, 64, 30, 0.1, 0, d, d, traj, 30, 0, d, d, d, None, None,
-                                                 sched, slen, None, goal_parts, None, None)
+                                                 sched, slen, None, goal_parts, None, None, None)
     assert parts(traj=None) == _lib.OMGX_ERR_INVALID and parts(goal_parts=0) == _lib.OMGX_ERR_INVALID and parts(goal_parts=16) == _lib.OMGX_ERR_INVALID
     assert parts(sched=d, slen=12) == _lib.OMGX_ERR_INVALID  # a schedule's length is a multiple of 8
     assert lib.omgx_goalset_schedule_parts(None, None, None, 4, 64, 3, 2, d, None) == _lib.OMGX_ERR_INVALID

@@ -149,7 +149,7 @@ def test_tiled_entry_point_rejects_bad_arguments(dev):
     def call(goal_parts=4, lg=10, cb=16, spread=1, goals=eng.cv_goals, traj=eng.traj, G=8):
         return l.omgx_goalset_cost_layer_tiled(p(eng.robot), eng.P, p(eng.scenes.objects), p(eng.scenes.scene_begin), p(eng.scenes.pool),
                                                p(eng.traj), 270, p(goals), 1, G, 30, 0.1, 0, p(cost), p(cost), p(traj), 30, 0,
-                                               p(eng.pot), p(eng.pgrad), p(eng.col), None, None, goal_parts, lg, cb, spread, None, None)
+                                               p(eng.pot), p(eng.pgrad), p(eng.col), None, None, goal_parts, lg, cb, spread, None, None, None)
     assert call() == _lib.OMGX_OK
     assert call(goal_parts=0) == _lib.OMGX_ERR_INVALID and call(goal_parts=9) == _lib.OMGX_ERR_INVALID
     assert call(lg=3) == _lib.OMGX_ERR_INVALID and call(lg=0) == _lib.OMGX_ERR_INVALID and call(cb=-1) == _lib.OMGX_ERR_INVALID

@@ -22,15 +22,15 @@ def test_goalset_kernel_register_and_spill_budget(tmp_path):
     subprocess.run([HIPCC, *flags, str(ROOT / "omg-planner_amd" / "csrc" / "omg_kernels.hip"), "-o", str(out)], check=True,
                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     text = out.read_text()
-    for name in ("_Z15k_goalset_queueILi2ELb0ELb0ELb0EEv9ChunkArgs", "_Z15k_goalset_queueILi2ELb1ELb0ELb0EEv9ChunkArgs",
-                 "_Z15k_goalset_queueILi2ELb0ELb0ELb1EEv9ChunkArgs", "_Z15k_goalset_queueILi2ELb1ELb0ELb1EEv9ChunkArgs",
-                 "_Z15k_goalset_queueILi2ELb0ELb1ELb0EEv9ChunkArgs"):  # batch, measuring, batch with split goals (x2), latency mode
+    variants = [(st, lat, sp, pre) for pre in (0, 1) for (st, lat, sp) in ((0, 0, 0), (1, 0, 0), (0, 0, 1), (1, 0, 1), (0, 1, 0))]
+    for st, lat, sp, pre in variants:  # batch, measuring, batch with split goals (x2), latency mode — each with its own kinematics and behind the pre-pass
+        name = f"_Z15k_goalset_queueILi2ELb{st}ELb{lat}ELb{sp}ELb{pre}EEv9ChunkArgs"  # <LB, STAMP, LAT, SPLIT, PRE>
         start = text.index(name + ":")
         block = text[start: text.index("; Occupancy:", start) + 40]
         vgprs = int(re.search(r"; NumVgprs: (\d+)", block).group(1))
         scratch = int(re.search(r"; ScratchSize: (\d+)", block).group(1))
         occupancy = int(re.search(r"; Occupancy: (\d+)", block).group(1))
-        if "Lb1ELb0EEv9ChunkArgs" not in name:  # the latency-mode variant (LAT = true) runs one or two workgroups per CU
+        if not lat:  # the latency-mode variant (LAT = true) runs one or two workgroups per CU
             assert vgprs <= 96 and occupancy >= 5, (name, vgprs, occupancy)
         assert scratch == 0, f"{name} spills {scratch} bytes per lane: the goal path must stay in registers"
 
