@@ -56,7 +56,9 @@ extern "C" {
  *   D+246+30P AX [10][3]     tip2joint[l][:3,:3] . joint_axis[l]
  *   D+276+30P OG [10][3]     tip2joint[l][:3,3]
  *   D+306+30P RAD [10]       max_p |PTS[l][p]|: bounding-sphere radius of a link's points about its frame origin
- * Total length 528 + 60P + 316 doubles.
+ *   D+316+30P BALL [10][4]   (c_x, c_y, c_z, r): a ball around PTS[l] itself — centre c in the link frame, r >= max_p |PTS[l][p] - c|
+ *                            (ABI 10).  The row-level culling tests it (centre R c + t per configuration) instead of (t, RAD).
+ * Total length 528 + 60P + 356 doubles.
  * ------------------------------------------------------------------------------------------- */
 #define OMGX_ROBOT_POSE0 0
 #define OMGX_ROBOT_TIP2JOINT 160

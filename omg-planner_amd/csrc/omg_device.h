@@ -329,19 +329,20 @@ __device__ __forceinline__ Accum sdf_point(const omgx_object* __restrict__ objs,
 //   D+306+30P RAD [10]      bounding-sphere radius of each link's centred points
 // Latency mode: a workgroup alone on a cold CU takes its scalar-cache misses one after the other — the culling stage's object loop
 // needs two dependent round trips per object (the `disabled` flag, then the record): 5 objects = 7 us of an 8 us stage, measured.
-// gq_warm_scalar_cache requests every 64-byte line of up to 8 object records and of the links' radii through the scalar cache AT ONCE
+// gq_warm_scalar_cache requests every 64-byte line of up to 8 object records and of the links' bounding balls (40 doubles) through the scalar cache AT ONCE
 // and waits for them (one round trip, taken while the workgroup's first vector loads are in flight anyway).  One asm statement:
 // the loads' throw-away targets are clobbers, and nothing of it is in flight when it ends (the compiler neither tracks inline-asm
 // loads nor knows when a scalar load lands).
-__device__ __forceinline__ void gq_warm_scalar_cache(const omgx_object* objects, int o_begin, int o_end, const double* radii) {
+__device__ __forceinline__ void gq_warm_scalar_cache(const omgx_object* objects, int o_begin, int o_end, const double* balls) {
     const omgx_object* ob[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) ob[k] = objects + (o_begin + k < o_end ? o_begin + k : o_end - 1);  // fewer than 8: the last one again (a hit)
 #define OMG_WARM_OBJ(N) "s_load_dword s96, %" #N ", 0x0\n\ts_load_dword s97, %" #N ", 0x40\n\ts_load_dword s98, %" #N ", 0x80\n\ts_load_dword s99, %" #N ", 0xb4\n\t"
     asm volatile(OMG_WARM_OBJ(0) OMG_WARM_OBJ(1) OMG_WARM_OBJ(2) OMG_WARM_OBJ(3) OMG_WARM_OBJ(4) OMG_WARM_OBJ(5) OMG_WARM_OBJ(6) OMG_WARM_OBJ(7)
-                 "s_load_dword s96, %8, 0x0\n\ts_load_dword s97, %8, 0x4c\n\ts_waitcnt lgkmcnt(0)"
+                 "s_load_dword s96, %8, 0x0\n\ts_load_dword s97, %8, 0x40\n\ts_load_dword s98, %8, 0x80\n\ts_load_dword s99, %8, 0xc0\n\t"
+                 "s_load_dword s96, %8, 0x100\n\ts_load_dword s97, %8, 0x13c\n\ts_waitcnt lgkmcnt(0)"
                  :
-                 : "s"(ob[0]), "s"(ob[1]), "s"(ob[2]), "s"(ob[3]), "s"(ob[4]), "s"(ob[5]), "s"(ob[6]), "s"(ob[7]), "s"(radii)
+                 : "s"(ob[0]), "s"(ob[1]), "s"(ob[2]), "s"(ob[3]), "s"(ob[4]), "s"(ob[5]), "s"(ob[6]), "s"(ob[7]), "s"(balls)
                  : "s96", "s97", "s98", "s99", "memory");
 #undef OMG_WARM_OBJ
 }
@@ -368,6 +369,7 @@ struct RobotViewT {
     __device__ __forceinline__ DPtr ax(int l) const { return d + 246 + 30 * P + 3 * l; }
     __device__ __forceinline__ DPtr og(int l) const { return d + 276 + 30 * P + 3 * l; }
     __device__ __forceinline__ double radius(int l) const { return d[306 + 30 * P + l]; }
+    __device__ __forceinline__ DPtr ball(int l) const { return d + 316 + 30 * P + 4 * l; }  // (c_x, c_y, c_z, r) of the link's own points
     __device__ __forceinline__ const double* lower() const { return raw + OMGX_ROBOT_LOWER; }
     __device__ __forceinline__ const double* upper() const { return raw + OMGX_ROBOT_UPPER; }
 };
@@ -569,6 +571,20 @@ __device__ __forceinline__ void pose9_apply(const double* __restrict__ A, const 
     x = (float)(A[0] * p[0] + A[1] * p[1] + A[2] * p[2] + A[6]);
     y = (float)(A[3] * p[0] + A[4] * p[1] + A[5] * p[2] + A[7]);
     z = (float)(r20 * p[0] + r21 * p[1] + r22 * p[2] + A[8]);
+}
+
+// Centre of link l's bounding ball (RobotViewT::ball: centre c in the link frame) in the workspace, for the row-level culling:
+// R c + t, rounded to float32.  Explicit fma, contraction off: every kernel that writes row masks computes the same centre.
+// r0 / r1: rotation rows 0 and 1, t: translation; the third row is r0 x r1 as in pose9_apply.
+template <class BP>
+__device__ __forceinline__ void link_ball_center(const double* r0, const double* r1, const double* t, BP b, float& cx, float& cy, float& cz) {
+#pragma clang fp contract(off)
+    const double c0 = b[0], c1 = b[1], c2 = b[2];
+    const double r20 = __builtin_fma(r0[1], r1[2], -(r0[2] * r1[1])), r21 = __builtin_fma(r0[2], r1[0], -(r0[0] * r1[2])),
+                 r22 = __builtin_fma(r0[0], r1[1], -(r0[1] * r1[0]));
+    cx = (float)(fk_dot3(r0[0], r0[1], r0[2], c0, c1, c2) + t[0]);
+    cy = (float)(fk_dot3(r1[0], r1[1], r1[2], c0, c1, c2) + t[1]);
+    cz = (float)(fk_dot3(r20, r21, r22, c0, c1, c2) + t[2]);
 }
 
 // np.argmin / np.argmax order: does (v, i) beat (bv, bi)?  The first occurrence wins, and a NaN counts as the extreme

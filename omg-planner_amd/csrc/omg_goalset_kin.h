@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void k_goalset_kin(ChunkArgs a) {
         const bool st = owner;
         auto put = [&](int l, int k, double v) { if (st) pw[(int64_t)(l * 9 + k) * ncfg + cfg] = v; };
         double A[3][3] = {{1.0, 0.0, 0.0}, {0.0, 1.0, 0.0}, {0.0, 0.0, 1.0}}, T[3] = {0.0, 0.0, 0.0};
-        float cx[10], cy[10], cz[10];  // the links' origins as the culling reads them (cull_row: (float) of the translation)
+        float cx[10], cy[10], cz[10];  // the centres of the links' bounding balls as the culling reads them (cull_row: link_ball_center)
 #pragma unroll  // unrolled: the link index of every store and of cx / cy / cz is a constant (registers, not scratch)
         for (int i = 0; i < 7; ++i) {
             double sn, cs;
@@ -75,23 +75,26 @@ __global__ __launch_bounds__(256) void k_goalset_kin(ChunkArgs a) {
 #pragma unroll
             for (int r = 0; r < 2; ++r) { put(i, 3 * r, A[r][0]); put(i, 3 * r + 1, A[r][1]); put(i, 3 * r + 2, A[r][2]); }
             put(i, 6, T[0]); put(i, 7, T[1]); put(i, 8, T[2]);
-            cx[i] = (float)T[0]; cy[i] = (float)T[1]; cz[i] = (float)T[2];
+            link_ball_center(A[0], A[1], T, rv.ball(i), cx[i], cy[i], cz[i]);
         }
         const double q7 = joint(7), q8 = joint(8);
+        double tr_[3][2][3], tt_[3][3];  // hand and fingers: [link - 7][row 0 | 1][3], translations [link - 7][3]
 #pragma unroll
         for (int r = 0; r < 3; ++r)
             fk_chain_tail(rv, A[r][0], A[r][1], A[r][2], T[r], q7, q8, [&](int l, double r0, double r1, double r2, double tr) {
-                if (r < 2) { put(l, 3 * r, r0); put(l, 3 * r + 1, r1); put(l, 3 * r + 2, r2); }
+                if (r < 2) { put(l, 3 * r, r0); put(l, 3 * r + 1, r1); put(l, 3 * r + 2, r2); tr_[l - 7][r][0] = r0; tr_[l - 7][r][1] = r1; tr_[l - 7][r][2] = r2; }
                 put(l, 6 + r, tr);
-                (r == 0 ? cx : r == 1 ? cy : cz)[l] = (float)tr;
+                tt_[l - 7][r] = tr;
             });
+#pragma unroll
+        for (int l = 7; l < 10; ++l) link_ball_center(tr_[l - 7][0], tr_[l - 7][1], tt_[l - 7], rv.ball(l), cx[l], cy[l], cz[l]);
         // Row masks: cull_row of omg_goalset_queue.h with the OBJECT in the outer loop — its record comes through the scalar cache
         // once (two dependent trips: `disabled`, then the fields) and serves the ten links; a mask's bits do not depend on the order
         // they are set in.
         uint32_t m[10];
         float rad[10];
 #pragma unroll
-        for (int l = 0; l < 10; ++l) { m[l] = 0u; rad[l] = (float)rv.radius(l) + 1.0e-4f; }
+        for (int l = 0; l < 10; ++l) { m[l] = 0u; rad[l] = (float)rv.ball(l)[3] + 1.0e-4f; }
         for (int o = o_begin; o < o_end; ++o) {
             ObjTablePtr ob = as_const(a.objects) + o;
             if (ob->disabled > 0) continue;

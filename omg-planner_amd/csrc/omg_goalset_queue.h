@@ -237,8 +237,10 @@ __global__ __launch_bounds__(LAT ? 256 : GQ_NT, LAT ? 2 : GQ_WG_PER_CU) void k_g
     // -> bit mask of the objects in reach (objects >= 31 share the last bit).
     auto cull_row = [&](int l, int ci) {
         const double* A = lds_pose + 9 + ((int64_t)l * pstride + ci) * 9;
-        const float cx = (float)A[6], cy = (float)A[7], cz = (float)A[8];
-        const float rad = (float)rv.radius(l) + 1.0e-4f;
+        const auto bl = rv.ball(l);  // the ball around the link's own points (robot blob BALL), not the one about its frame origin
+        float cx, cy, cz;
+        link_ball_center(A, A + 3, A + 6, bl, cx, cy, cz);
+        const float rad = (float)bl[3] + 1.0e-4f;
         uint32_t m = 0;
         for (int o = o_begin; o < o_end; ++o) {
             ObjTablePtr ob = as_const(a.objects) + o;
@@ -296,7 +298,7 @@ __global__ __launch_bounds__(LAT ? 256 : GQ_NT, LAT ? 2 : GQ_WG_PER_CU) void k_g
         const bool tbl_lane = tid >= 128 && tid - 128 < a.tbl_n && o_begin + tid - 128 < o_end;
         GqTblRec trec{};
         if (tbl_lane) trec = gq_tbl_load(a.objects + o_begin + (tid - 128));
-        if (warming) gq_warm_scalar_cache(a.objects, o_begin, o_end, a.robot + OMGX_ROBOT_POINTS + 30 * P + 306 + 30 * P);
+        if (warming) gq_warm_scalar_cache(a.objects, o_begin, o_end, a.robot + OMGX_ROBOT_POINTS + 30 * P + 316 + 30 * P);
         const int nm = 10 * CH, ne = 90 * ncfg;
         uint32_t mv[3];
 #pragma unroll
@@ -341,7 +343,7 @@ __global__ __launch_bounds__(LAT ? 256 : GQ_NT, LAT ? 2 : GQ_WG_PER_CU) void k_g
         const bool tbl_lane = tid >= 128 && tid - 128 < a.tbl_n && o_begin + tid - 128 < o_end;  // lanes of wave 2: idle during the chain stage
         GqTblRec trec{};
         if (LAT && tbl_lane) trec = gq_tbl_load(a.objects + o_begin + (tid - 128));  // LAT: requested here, stored after the barrier
-        if (warming) gq_warm_scalar_cache(a.objects, o_begin, o_end, a.robot + OMGX_ROBOT_POINTS + 30 * P + 306 + 30 * P);
+        if (warming) gq_warm_scalar_cache(a.objects, o_begin, o_end, a.robot + OMGX_ROBOT_POINTS + 30 * P + 316 + 30 * P);
         auto joint = [&](int cfg, int d) { return cfg == 0 ? q0[d] : q0[d] + ((double)cfg * (1.0 / (double)(CH + 1))) * (qg[d] - q0[d]); };
         for (int t = tid; t < ncfg * 7; t += 256) {
             const int cfg = t / 7, i = t - cfg * 7;
@@ -561,7 +563,11 @@ __global__ __launch_bounds__(LAT ? 256 : GQ_NT, LAT ? 2 : GQ_WG_PER_CU) void k_g
         // (axis_of's g > -1e9 && g <= 1e9; at g == -1e9 exactly the index is negative anyway)
         const bool ordered = (__builtin_fabsf(gx) <= 1.0e9f) && (__builtin_fabsf(gy) <= 1.0e9f) && (__builtin_fabsf(gz) <= 1.0e9f);
         const bool in_c = valid && ordered && (uint32_t)ix < (uint32_t)(dx - 1) && (uint32_t)iy < (uint32_t)(dy - 1) && (uint32_t)iz < (uint32_t)(dz - 1);
+#ifdef OMGX_GS_NO_GATHER  // measurement build: every lane reads the grid's first voxels — the exact path's arithmetic without its cache misses
+        const uint32_t b = in_c ? (uint32_t)((ix * dy + iy) * dz + iz) & 1u : 0u;
+#else
         const uint32_t b = in_c ? (uint32_t)((ix * dy + iy) * dz + iz) : 0u;
+#endif
         const char* g0 = reinterpret_cast<const char*>(h_pool) + goffb + (uint64_t)b * 4u;
         const uint32_t syb = (uint32_t)dz * 4u, sxb = (uint32_t)(dy * dz) * 4u;
         f_r00 = *reinterpret_cast<const F2*>(g0);

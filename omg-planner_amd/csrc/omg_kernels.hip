@@ -279,8 +279,10 @@ __global__ __launch_bounds__(TPB) void k_sdf_chunks(ChunkArgs a) {
         uint32_t m = 0;
         if (ci < nvalid) {
             const double* A = base + ((int64_t)l * pstride + ci) * 12;
-            const float cx = (float)A[9], cy = (float)A[10], cz = (float)A[11];
-            const float rad = (float)rv.radius(l) + 1.0e-4f;
+            const auto bl = rv.ball(l);  // the ball around the link's own points (robot blob BALL)
+            float cx, cy, cz;
+            link_ball_center(A, A + 3, A + 9, bl, cx, cy, cz);
+            const float rad = (float)bl[3] + 1.0e-4f;
             for (int o = o_begin; o < o_end; ++o) {
                 ObjTablePtr ob = as_const(a.objects) + o;
                 if (ob->disabled > 0) continue;
@@ -398,7 +400,7 @@ __device__ __forceinline__ void waypoint_layer_block(const ChunkArgs& a, const i
     const double* tr = a.wp_traj + ((int64_t)s * n + c_begin) * 9;
     double* sc = reinterpret_cast<double*>(rowmask);  // [nloc][7][2], dead before the masks are written
     const double fkv = (LAT && threadIdx.x < 246) ? rv.g[threadIdx.x] : 0.0;
-    if (warming) gq_warm_scalar_cache(a.objects, o_begin, o_end, a.robot + OMGX_ROBOT_POINTS + 30 * P + 306 + 30 * P);
+    if (warming) gq_warm_scalar_cache(a.objects, o_begin, o_end, a.robot + OMGX_ROBOT_POINTS + 30 * P + 316 + 30 * P);
     for (int t = threadIdx.x; t < nloc * 7; t += 256) {
         const int cfg = t / 7, i = t - cfg * 7;
         double sn, cs;
@@ -444,8 +446,10 @@ __device__ __forceinline__ void waypoint_layer_block(const ChunkArgs& a, const i
     for (int row = l_begin * nloc + threadIdx.x; row < l_end * nloc; row += 256) {  // row-level culling of this workgroup's links
         const int l = row / nloc, ci = row - l * nloc;
         const double* A = lds_pose + ((int64_t)l * PS + ci) * 9;
-        const float cx = (float)A[6], cy = (float)A[7], cz = (float)A[8];
-        const float rad = (float)rv.radius(l) + 1.0e-4f;
+        const auto bl = rv.ball(l);  // the ball around the link's own points (robot blob BALL)
+        float cx, cy, cz;
+        link_ball_center(A, A + 3, A + 6, bl, cx, cy, cz);
+        const float rad = (float)bl[3] + 1.0e-4f;
         uint32_t m = 0;
         for (int o = o_begin; o < o_end; ++o) {
             ObjTablePtr ob = as_const(a.objects) + o;

@@ -84,10 +84,25 @@ class PandaModel:
         ax = np.einsum("lrc,lc->lr", self.tip2joint[:, :3, :3], self.joint_axis)
         og = self.tip2joint[:, :3, 3]
         radius = np.linalg.norm(pts, axis=-1).max(axis=1)  # bounding-sphere radius of each link's centred points
+        ball = np.stack([bounding_ball(pts[l]) for l in range(NUM_LINKS)])  # [10][4]: a small ball around the points themselves
         out = np.concatenate([np.array(uvw).ravel(), np.array(tp).ravel(), rows(self.pose_0[7]), rows(self.pose_0[8]),
-                              rows(self.pose_0[9]), pts.ravel(), ax.ravel(), og.ravel(), radius.ravel()])
-        assert out.size == 316 + 30 * P
+                              rows(self.pose_0[9]), pts.ravel(), ax.ravel(), og.ravel(), radius.ravel(), ball.ravel()])
+        assert out.size == 356 + 30 * P
         return out
+
+
+def bounding_ball(points: np.ndarray) -> np.ndarray:
+    """(cx, cy, cz, r): a ball that holds every point, centred near the centre of the smallest one (Badoiu-Clarkson steps
+    from the centroid: deterministic, any centre is valid because r is the largest distance to it, rounded up).  The row-level
+    culling tests this ball instead of the one about the link's frame origin (RAD): with the points 2-10 cm off the origin it
+    is about half as large, and a third of the main loop's far tests never start."""
+    p = np.asarray(points, np.float64)
+    c = p.mean(axis=0)
+    for k in range(1, 4001):
+        far = p[np.argmax(((p - c) ** 2).sum(axis=1))]
+        c = c + (far - c) / (k + 1.0)
+    r = float(np.sqrt(((p - c) ** 2).sum(axis=1).max())) * (1.0 + 1e-12) + 1e-15
+    return np.array([c[0], c[1], c[2], r])
 
 
 def synthetic_collision_points(points_per_link: int = 15, seed: int = 0) -> np.ndarray:

@@ -52,7 +52,7 @@ def test_robot_blob_layout():
     m = rb.PandaModel(seed=0)
     b = m.blob()
     P = m.points_per_link
-    assert b.size == 528 + 30 * P + 316 + 30 * P
+    assert b.size == 528 + 30 * P + 356 + 30 * P
     np.testing.assert_array_equal(b[:160].reshape(10, 4, 4), m.pose_0)
     np.testing.assert_array_equal(b[528:528 + 30 * P].reshape(10, P, 3), m.collision_points)
     # derived joint-0 matrices reproduce pose_0[0] @ Rz(q) @ Rx(0)
