@@ -348,6 +348,14 @@ __global__ __launch_bounds__(LAT ? 256 : GQ_NT, LAT ? 2 : GQ_WG_PER_CU) void k_g
         for (int t = tid; t < ncfg * 7; t += 256) {
             const int cfg = t / 7, i = t - cfg * 7;
             double sn, cs;
+#ifdef OMGX_GS_PRO2  // measurement build: the (sin, cos) stage's arithmetic twice — what a prologue instruction costs the step
+            {
+                double qq = joint(cfg, i);
+                asm volatile("" : "+v"(qq));
+                fk_joint_sincos(qq, sn, cs);
+                asm volatile("" : : "v"(sn), "v"(cs));
+            }
+#endif
             fk_joint_sincos(joint(cfg, i), sn, cs);
             sc[2 * t] = sn; sc[2 * t + 1] = cs;
         }

@@ -41,8 +41,13 @@ ROOT = Path(__file__).resolve().parents[1]
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 SIMDS = 256 * 4
 CLOCK_GHZ = 2.4           # data-sheet maximum
-KERNEL = "k_goalset_queue<2, false, false, false>"  # LB = 2, no work stamps, batch layout, whole goals (latency mode: <2, false, true, false>; split goals: <2, false, false, true>)
-KERNEL_OLD = "k_goalset_queue<2, false, false>"     # the same instantiation before round 4 (three template parameters): profiles up to r03h
+KERNEL = "k_goalset_queue<2, false, false, false, false>"  # <LB, STAMP, LAT, SPLIT, PRE>: no work stamps, batch layout, whole goals, own kinematics
+KERNEL_R4 = "k_goalset_queue<2, false, false, false>"      # the same instantiation in round 4 (four template parameters): profiles r04*
+KERNEL_OLD = "k_goalset_queue<2, false, false>"            # ... and before round 4 (three): profiles up to r03h
+
+
+def is_dominant(name: str) -> bool:
+    return KERNEL in name or KERNEL_R4 in name or KERNEL_OLD in name
 CALIBRATION_TAG = "r03d"  # profiles/<tag>_valu_peak.csv
 
 # SQ_INSTS_VALU_* class -> the calibration row that prices it (cheapest member of the class: lower bound of the issue time)
@@ -75,7 +80,7 @@ def _pmc(tag: str, name: str, counter: str, profiles: Path):
     if not f.exists():
         return None
     for r in csv.DictReader(open(f)):
-        if (KERNEL in r["kernel"] or KERNEL_OLD in r["kernel"]) and r["counter"] == counter:
+        if is_dominant(r["kernel"]) and r["counter"] == counter:
             return float(r["mean_per_dispatch"])
     return None
 
@@ -116,7 +121,7 @@ def derive_inputs(tag: str, profiles: Path = ROOT / "profiles") -> dict:
     f = profiles / f"{tag}_kernel_stats.csv"
     if f.exists():
         for r in csv.DictReader(open(f)):
-            if KERNEL in r["Name"] or KERNEL_OLD in r["Name"]:
+            if is_dominant(r["Name"]):
                 stats_ns = float(r["AverageNs"])
     cfg_file = profiles / f"{tag}_workload.json"
     useful_file = profiles / f"{tag}_useful.json"  # tools/gs_block_counts.py (counting build) + the exact-path ablation pass
@@ -124,7 +129,7 @@ def derive_inputs(tag: str, profiles: Path = ROOT / "profiles") -> dict:
     out = {
         "from_profiles_tag": tag,
         "calibration_tag": CALIBRATION_TAG,
-        "kernel": "k_goalset_queue<2, false, false, false> (goal-set batch + trajectory layer: kinematics, culling, SDF lookups, arc-length cost)",
+        "kernel": "k_goalset_queue<2, false, false, false, false> (goal-set batch + trajectory layer: kinematics, culling, SDF lookups, arc-length cost)",
         "workload": json.loads(cfg_file.read_text()) if cfg_file.exists() else None,
         "valu_wave_insts_per_launch": valu,
         "valu_issue_cycles_per_launch": cycles,   # summed over the SIMDs; a lower bound (module docstring)

@@ -3,7 +3,7 @@ bench's timing stride, and as a histogram in 10 us bins.  When the pipeline's ha
 launch that runs alone takes ~115 us instead of ~170 us beside the other half's: the mean drops, the median does not.
     python tools/trace_goalset_durations.py <kernel_trace.csv>"""
 import csv,sys,statistics as st
-rows=[r for r in csv.DictReader(open(sys.argv[1])) if 'k_goalset_queue<2, false, false, false>' in r['Kernel_Name']]
+rows=[r for r in csv.DictReader(open(sys.argv[1])) if 'k_goalset_queue<2, false, false, false' in r['Kernel_Name']]
 rows.sort(key=lambda r:int(r['Start_Timestamp']))
 d=[(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3 for r in rows]
 q=sorted({r['Queue_Id'] for r in rows})

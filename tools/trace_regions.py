@@ -25,7 +25,7 @@ def main():
     if cur:
         regions.append(cur)
     for k, reg in enumerate(regions):
-        gs = [(s, e) for s, e, n in reg if "k_goalset_queue<2, false, false, false>" in n]
+        gs = [(s, e) for s, e, n in reg if "k_goalset_queue<2, false, false, false" in n]
         up = [(s, e) for s, e, n in reg if "k_update_optimize_split" in n]
         if len(gs) < 8:
             continue
