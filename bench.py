@@ -42,9 +42,11 @@ sys.path.insert(0, str(ROOT))
 # the roofline's constants and its one formula live in tools/roofline.py (bound: VALU instruction issue, priced by tools/valu_peak.hip)
 
 
-def build_workload(num_scenes, num_goals, n, grid, seed0, share_grids, num_objects=4, timing=None):
-    """timing: optional dict that receives the host time of scenes.pack_table (object records + SDF pool + the fitted influence
-    regions: the set-up a batch pays once, outside every timed region)."""
+def build_workload(num_scenes, num_goals, n, grid, seed0, share_grids, num_objects=4, timing=None, device=None):
+    """timing: optional dict that receives the time of the scene table's build (object records + SDF pool + the fitted influence
+    regions: the set-up a batch pays once, outside every timed region).  device: build the table ON that device
+    (ops.DeviceScenes.from_scenes: one copy per volume, every region fitted by omgx_fit_influence_regions) and return the
+    DeviceScenes in place of the host SceneBatch; None: scenes.pack_table on the host (the specification)."""
     from omg_planner_amd import robot as rb, scenes as sc
     from omg_planner_amd.config import Config
     cfg = Config(timesteps=n, use_standoff=False)  # omg.core -exp sets use_standoff=False (core.py:873)
@@ -55,7 +57,16 @@ def build_workload(num_scenes, num_goals, n, grid, seed0, share_grids, num_objec
             for ob in scn.objects:
                 ob.sdf = sc.SdfGrid(ob.sdf.data.copy(), ob.sdf.origin, ob.sdf.delta)
     t0 = time.perf_counter()
-    batch = sc.pack_table(scenes, cfg.layer_kwargs(), ragged=True, share_grids=share_grids)
+    if device is not None:
+        import torch
+        from omg_planner_amd import ops
+        parts = {}
+        batch = ops.DeviceScenes.from_scenes(scenes, cfg.layer_kwargs(), device, share_grids=share_grids, timing=parts)
+        torch.cuda.synchronize(device)
+        if timing is not None:
+            timing["scene_table"] = dict(parts, built="on the device: DeviceScenes.from_scenes (records on the host, one copy per volume, omgx_fit_influence_regions)")
+    else:
+        batch = sc.pack_table(scenes, cfg.layer_kwargs(), ragged=True, share_grids=share_grids)
     if timing is not None:
         timing["pack_table_ms"] = (time.perf_counter() - t0) * 1e3
     start = np.tile(rb.HOME_CONFIG, (num_scenes, 1))
@@ -227,6 +238,66 @@ def scene_update_timing(dev, cfg, model, batch, start, goals, ol_alg):
             "same_change_through_the_host_ms": host_ms, "replan_equals_fresh_engine": same}
 
 
+def drop_in_plan_timing(dev, ol_alg="MD", reps=3):
+    """ms per plan through the DROP-IN classes (Trajectory / Cost / Learner / Optimizer) on bench scene 0 — the loop of
+    Planner.plan (omg/planner.py:612-653) as the reference writes it: update_goal, a look at traj.goal_idx, optimize(force_update),
+    a copy of traj.data, a look at info["terminate"]; 50 + 20 iterations (no early exit, like the other plan timings) and the
+    closing info-only call.  Best of `reps`, each on a fresh Trajectory / Learner / Optimizer over a warm Cost."""
+    import types
+    import torch
+    from omg_planner_amd import robot as rb, scenes as sc
+    from omg_planner_amd.config import Config
+    from omg_planner_amd.cost import Cost
+    from omg_planner_amd.online_learner import Learner
+    from omg_planner_amd.optimizer import Optimizer
+    from omg_planner_amd.trajectory import Trajectory
+    n, G = 30, 64
+    model = rb.PandaModel(seed=0)
+    scene = sc.make_tabletop_scene(0, grid=64)
+    sdf, lim = sc.pack_padded(scene.objects)  # Env.combine_sdfs layout (omg/core.py:366-411)
+    goals = sc.make_reach_goals(scene, model, G, 0)
+    robot = types.SimpleNamespace(collision_points=model.collision_points, joint_lower_limit=model.joint_lower_limit,
+                                  joint_upper_limit=model.joint_upper_limit)
+    best, iters, goal_changes = float("inf"), 0, 0
+    cost = None
+    for rep in range(reps + 1):  # the first pass warms everything up (object table, influence regions, buffers)
+        cfg = Config(timesteps=n, use_standoff=False, ol_alg=ol_alg)
+        objs = [types.SimpleNamespace(name=o.name, pose_mat=o.pose_mat, attached=False, reach_grasps=goals[:, None, :]) for o in scene.objects]
+        if cost is None:
+            env = types.SimpleNamespace(robot=robot, objects=objs, target_idx=scene.target_idx, config=cfg,
+                                        sdf_torch=torch.as_tensor(sdf, device=dev), sdf_limits=torch.as_tensor(lim, device=dev))
+            cost = Cost(env)
+        else:
+            env.config, env.objects, cost.cfg = cfg, objs, cfg
+            cost.target_obj = objs[scene.target_idx]
+        traj = Trajectory(cfg=cfg)
+        traj.start, traj.goal_set, traj.end = rb.HOME_CONFIG.copy(), goals, goals[0].copy()
+        traj.interpolate_waypoints()
+        learner = Learner(env, traj, cost)
+        optim = Optimizer(types.SimpleNamespace(config=cfg, robot=robot), cost)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        infos, history, selected = [], [np.copy(traj.data)], []
+        for t in range(cfg.optim_steps + cfg.extra_smooth_steps):
+            if cfg.goal_set_proj and ol_alg not in ("Baseline", "Proj") and t < cfg.optim_steps:
+                learner.update_goal()
+                selected.append(traj.goal_idx)
+            infos.append(optim.optimize(traj, force_update=True))
+            history.append(np.copy(traj.data))
+            _ = infos[-1]["terminate"] and t > 0
+        infos.append(optim.optimize(traj, info_only=True))
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) * 1e3
+        if rep > 0:
+            best = min(best, ms)
+        iters = len(history) - 1
+        sel = [int(g) for g in selected]
+        goal_changes = int(sum(1 for a, b in zip(sel[:-1], sel[1:]) if a != b))
+    return {"ms_per_plan_drop_in_classes": best, "iterations": iters, "goal_changes": goal_changes, "final_cost": float(infos[-1]["cost"]),
+            "what": "Planner.plan's loop (omg/planner.py:612-653) written with the drop-in Trajectory / Cost / Learner / Optimizer on bench scene 0 "
+                    f"(64 goals, {ol_alg}), {iters} iterations + the closing info-only call, best of {reps} on a warm Cost"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -240,6 +311,7 @@ def main():
     ap.add_argument("--objects", type=int, default=4, help="obstacles per scene besides the table (BASELINE config 5's clutter: 12 with --waypoints 50)")
     ap.add_argument("--share-grids", action="store_true", help="store identical SDF volumes once (model library)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-pack", action="store_true", help="build the scene table with scenes.pack_table on the host (round 1-4) instead of on the device")
     ap.add_argument("--pipeline", type=int, default=0, help="parts of the engine's software pipeline (0: ChompEngine.layout's choice)")
     ap.add_argument("--layout-scenes", type=int, default=0, help="scene count ChompEngine.layout is evaluated for (0: the largest shard, ceil(total / world)); "
                     "a single-process run given a multi-rank job's number computes the same bits as that job")
@@ -286,7 +358,26 @@ def main():
     else:
         S, seed0, total_scenes = args.scenes, rank * args.scenes, world * args.scenes
     setup = {}
-    cfg, model, batch, start, goals = build_workload(S, G, n, args.grid, seed0=seed0, share_grids=args.share_grids, num_objects=args.objects, timing=setup)
+    # the HIP runtime's own first-use costs (context, the staging buffers of the first pageable copy, loading the library's code
+    # objects) are not the scene table's: paid here, reported beside it
+    t_w = time.perf_counter()
+    torch.from_numpy(np.zeros(1 << 18, np.float32)).to(dev)
+    ops_warm = torch.zeros((2, 3), dtype=torch.float64, device=dev)
+    from omg_planner_amd import ops as _ops
+    _ops.point_cloud_sdf(ops_warm, 0.5, 0.1)
+    torch.cuda.synchronize()
+    setup["runtime_warmup_ms"] = (time.perf_counter() - t_w) * 1e3
+    cfg, model, batch, start, goals = build_workload(S, G, n, args.grid, seed0=seed0, share_grids=args.share_grids, num_objects=args.objects, timing=setup,
+                                                     device=None if args.host_pack else dev)
+    scenes_dev = None if args.host_pack else batch
+    _host = [batch if args.host_pack else None]
+
+    def host_batch():  # the oracle's legs (cpu_baseline, parity_sample) and the one-scene engines read the table from the host
+        if _host[0] is None:
+            from omg_planner_amd import scenes as sc_
+            hb = scenes_dev.host_batch()
+            _host[0] = sc_.SceneBatch(hb.objects, hb.scene_begin, hb.pool)
+        return _host[0]
     # The layout — latency mode, split goals, pipeline parts — follows ONE rule of the shape (ChompEngine.layout), evaluated on every
     # rank for the same scene count (the largest shard), so that all shards of a job compute comparable bits
     S_max = len(shard_range(args.total_scenes, 0, world)) if strong else S
@@ -415,13 +506,14 @@ def main():
         # region repeats (same pinned window), trajectories / final costs / chosen goals
         from oracle.check import engine_vs_oracle
         eng.restore(snap)
-        parity = engine_vs_oracle(eng, batch, sorted({0, S // 2, S - 1}), steps=3, pin_window=True)
+        parity = engine_vs_oracle(eng, host_batch(), sorted({0, S // 2, S - 1}), steps=3, pin_window=True)
 
     ms_per_plan = ms_plan_early = ms_single = ms_single_batch_layout = terminated = ms_graph_early = ms_graph_single = None
-    share4 = scene_upd = None
+    share4 = scene_upd = drop_in = None
     if not args.no_plan and rank == 0 and world == 1:
         share4 = rank_share_config4(dev, args.ol_alg)
-        scene_upd = scene_update_timing(dev, cfg, model, batch, start, goals, args.ol_alg)
+        scene_upd = scene_update_timing(dev, cfg, model, host_batch(), start, goals, args.ol_alg)
+        drop_in = drop_in_plan_timing(dev, args.ol_alg)
     if not args.no_plan and rank == 0:
         ms_per_plan = float("inf")
         for _ in range(2):  # best of 2: the first plan pays one-off costs (code-object load of the 30 window sizes)
@@ -442,7 +534,7 @@ def main():
         ms_plan_early = (time.perf_counter() - tp) * 1e3
         terminated = int((eng3.active == 0).sum().item())
         del eng3
-        one = batch.subset(0, 1)  # BASELINE configs[0]/[1] shape: ONE scene, 64 goals — latency of a whole plan
+        one = host_batch().subset(0, 1)  # BASELINE configs[0]/[1] shape: ONE scene, 64 goals — latency of a whole plan
         # latency mode (ChompEngine(latency_mode=True): the launches cut into many small workgroups over the whole chip) and, for
         # comparison, the batch layout a 100-scene run uses (one workgroup per goal on the scene's XCD)
         ms_single, ms_single_batch_layout = float("inf"), float("inf")
@@ -511,13 +603,17 @@ def main():
         }
         if parity is not None:
             out["parity_sample"] = parity
-        out["setup_ms"] = dict(setup, what="host: scenes.pack_table (records, pool, fitted influence regions) / engine_init: uploads + allocations; once per batch, outside the timed regions")
+        out["setup_ms"] = dict(setup, what=("pack_table_ms: the scene table (records, SDF pool, fitted influence regions) — " + ("scenes.pack_table on the host" if args.host_pack else "built on the device, see scene_table") +
+                                            "; engine_init_ms: uploads + allocations; once per batch, outside the timed regions"))
         if share4 is not None:
             out["ms_per_step_rank_share_config4"] = share4[0]  # 13 scenes x 128 goals on this GPU: one rank's share of BASELINE config 4 on 8 GPUs
             out["rank_share_config4_layout"] = share4[1]
         if scene_upd is not None:
             out["scene_update_ms"] = scene_upd["scene_update_ms"]
             out["scene_update"] = scene_upd
+        if drop_in is not None:
+            out["ms_per_plan_drop_in_classes"] = drop_in["ms_per_plan_drop_in_classes"]  # the reference's own call surface: Learner.update_goal + Optimizer.optimize per iteration
+            out["drop_in_plan"] = drop_in
         if ms_per_plan is not None:
             out["plan_timing_version"] = 2  # since round 3: single-scene plans on a WARM engine restored from a snapshot, best of 3 (round 1-2: first plan of a fresh batch-layout engine); round 4: the batch's engines laid out by ChompEngine.layout
             out["ms_per_plan"] = ms_per_plan  # Planner.plan for all scenes of rank 0: initial goal pick + 50 + 20 iterations + final info
@@ -529,7 +625,7 @@ def main():
             out["ms_per_plan_early_stop_graph"] = ms_graph_early  # the early-stop plan replayed as one HIP graph (capture_plan)
             out["ms_per_plan_single_scene_graph"] = ms_graph_single
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, model, batch, start, goals, n)
+            out["cpu_baseline"] = cpu_baseline(cfg, model, host_batch(), start, goals, n)
         print(json.dumps(out))
     if dist_on:
         import torch.distributed as dist

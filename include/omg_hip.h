@@ -540,6 +540,26 @@ int omgx_object_set_grid(omgx_object* object, const float* h_lo, const float* h_
 int omgx_fit_influence_region(omgx_object* object, const float* grid, const int32_t* h_dims, const float* h_lo, const float* h_hi,
                               float epsilon, float clearance, void* scratch, void* stream);
 
+/* ABI 10: the same fit for a whole object table in seven launches (first build of a batch without a host pass over the voxels,
+ * omg/core.py:366-411 Env.combine_sdfs).  The records must already hold their grid fields (lo, hi, dim, grid_offset, epsilon,
+ * clearance: what omgx_object_set_grid / scenes.pack_table write) and the pool their volumes.
+ *   fit_list      [n_fit] int32 (device): one object index per DISTINCT (volume, thresholds) to fit; only records the kernels cull
+ *                 for (epsilon < 1, clearance <= 1, positive extents, dims >= 2) belong here
+ *   need_offsets  [n_fit] int64 (device): byte offset of each entry's window flags inside the scratch's flag area — a running sum
+ *                 of dx*dy*dz over the list; need_bytes = its total
+ *   max_voxels    the largest dx*dy*dz in the list (sizes the launches)
+ *   copy_src      [num_objects] int32 (device) or NULL: object o takes the region of object copy_src[o] (-1: keeps its own) — the
+ *                 records that share a fitted entry's volume and thresholds
+ *   scratch       omgx_regions_scratch_bytes(n_fit, need_bytes) bytes
+ * Every fitted record equals what omgx_fit_influence_region writes for it (= scenes.tighten_far_boxes), field for field. */
+int64_t omgx_regions_scratch_bytes(int32_t n_fit, int64_t need_bytes);
+/* hashes [num_objects][2] uint64 (device) <- a 128-bit content hash of every object's volume (dims x float bits): equal volumes
+ * give equal hashes, so a caller can fit volumes that occur several times once (DeviceScenes.fit_all). */
+int omgx_volume_hashes(const omgx_object* objects, int32_t num_objects, const float* pool, uint64_t* hashes, void* stream);
+int omgx_fit_influence_regions(omgx_object* objects, int32_t num_objects, const float* pool, const int32_t* fit_list,
+                               const int64_t* need_offsets, int32_t n_fit, int64_t max_voxels, const int32_t* copy_src,
+                               void* scratch, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Diagnostics
  * ------------------------------------------------------------------------------------------- */
@@ -559,6 +579,7 @@ int omgx_timing_enable(int32_t on);
 int omgx_timing_collect(float* h_ms, int32_t* h_kind, int32_t cap);
 int omgx_abi_version(void);        /* bumps when a signature or struct layout changes              */
 int omgx_device_arch(char* h_buf, int32_t h_len); /* writes gcnArchName of the current device      */
+int32_t omgx_device_cu_count(void);               /* compute units of the current device (< 0: error)  */
 
 #ifdef __cplusplus
 }

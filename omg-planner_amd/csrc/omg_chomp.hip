@@ -750,6 +750,7 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
                     word = __hip_atomic_load(wait_goal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 } while ((word >> 8) != ticket);
             }
+            static_assert(OMGX_MAX_GOALS <= 256, "the rendezvous word is (ticket << 8) | goal index: the index must fit 8 bits");
             L.iscr[3] = (int)(word & 0xffu);
         }
         __syncthreads();

@@ -485,10 +485,15 @@ __global__ __launch_bounds__(LAT ? 256 : GQ_NT, LAT ? 2 : GQ_WG_PER_CU) void k_g
     uint32_t f_meta = 0u;  // object index | soft << 16 | in_c << 30 | valid << 31
     bool inflight = false;
     // A goal's cost is the sum of pot * weight (a float32 product, as before) over its pairs — accumulated EXACTLY: every term is
-    // rounded to the grid 2^-36 (far below the float32 resolution of any cost that matters: |term| < 2^15) and added in float64,
-    // where sums of grid multiples below 2^16 are exact.  The sum therefore does not depend on the order of its terms: whatever
-    // the queue order, the tile assignment, the number of workgroups a goal is split over or the dispatch schedule, the workgroup's
-    // sum is the same number, rounded to float32 once at the end (the oracle's bar: 1e-5 relative).
+    // rounded to a multiple of 2^-36 ((x + C) - C with C = 1.5 * 2^16: the grid is 2^-36 for |x| < 2^15 and a coarser power of two
+    // — still multiples of 2^-36 — beyond) and added in float64, where sums of such multiples are exact while their magnitude stays
+    // below 2^17 (53 - 36 bits).  In that range the sum does not depend on the order of its terms: whatever the queue order, the
+    // tile assignment, the number of workgroups a goal is split over or the dispatch schedule, the workgroup's sum is the same
+    // number, rounded to float32 once at the end (the oracle's bar: 1e-5 relative).  RANGE: a goal cost of 131072 or more (table-top
+    // scenes: < 10^3; it takes potentials of metres times speeds of km/s) leaves it — the float64 additions then round at 2^-53
+    // relative, the sum depends on the order again at that level, and the float32 result can differ in its last bit between two
+    // launch layouts about once in 10^9 goals; nothing else changes (tests/test_gpu_prepass.py::test_huge_goal_costs_...).
+    // Terms below 2^-37 are dropped: 7e-12 absolute against costs whose float32 resolution is >= 6e-8 relative.
     double tsum = 0.0;
     float tcol = 0.0f;
     auto add_term = [&](float term) { const double C = 98304.0; /* 1.5 * 2^16: (x + C) - C rounds x to a multiple of 2^-36 */ tsum += ((double)term + C) - C; };

@@ -678,6 +678,12 @@ static void timing_events(int kind, hipEvent_t* ev0, hipEvent_t* ev1) {
     ++g_timing_n;
 }
 extern "C" int omgx_abi_version(void) { return 10; }  // 10: kinematics pre-pass (k_goalset_kin) behind the `workspace` argument of omgx_goalset_cost / _cost_layer, new trailing `workspace` of _cost_layer_parts / _cost_layer_tiled; 9: omgx_goalset_schedule_ordered (longest first inside an XCD); 8: omgx_goalset_cost_layer_parts, omgx_goalset_schedule_parts (a goal's tiles over several workgroups of the batch kernel); 2: `active` masks; 3: ragged goal sets (goal_count, eta); 4: goal schedule + work; 5: 184-byte object records (influence region = rounded box); 6: omgx_goalset_cost_layer_tiled, omgx_learner_params.cost_parts; 7: pose tables (omgx_pose_table, pointer fields at the end of both parameter blocks, layer_poses)
+extern "C" int32_t omgx_device_cu_count(void) {  // compute units of the current device (a plain attribute query: no property table)
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return -1;
+    return n;
+}
 extern "C" int omgx_device_arch(char* h_buf, int32_t h_len) {
     if (!h_buf || h_len <= 0) return OMGX_ERR_INVALID;
     int dev = 0;

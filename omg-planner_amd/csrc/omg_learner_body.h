@@ -411,6 +411,7 @@ __device__ __forceinline__ void learner_scene(const LearnerArgs& a, int s, doubl
     LPHASE(5, mixw);
     // traj.end / goal rows (online_learner.py:243-245, optimizer.py:93-99)
     if (lane == 0) {
+        static_assert(OMGX_MAX_GOALS <= 256, "the rendezvous word is (ticket << 8) | goal index: the index must fit 8 bits");
         if (flag) __hip_atomic_store(flag, (publish << 8) | (uint32_t)idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         a.goal_idx[s] = idx;
         if (sh_idx) *sh_idx = idx;

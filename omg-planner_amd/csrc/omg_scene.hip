@@ -42,7 +42,7 @@ struct RegionArgs {
     omgx_object* rec;
 };
 
-__global__ void k_region_init(RegionStats* st) {
+__device__ __forceinline__ void rg_init(RegionStats* st) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     st->maxabs_bits = 0u;
     for (int k = 0; k < 3; ++k) { st->nmin[k] = 0x7fffffff; st->nmax[k] = -1; st->qmin[k] = 0x7fffffff; st->qmax[k] = -1; }
@@ -51,7 +51,7 @@ __global__ void k_region_init(RegionStats* st) {
     for (int c = 0; c < RG_CANDS; ++c) st->r2bits[c] = 0ull;
 }
 
-__global__ __launch_bounds__(256) void k_region_maxabs(const float* __restrict__ g, int64_t N, RegionStats* st) {
+__device__ __forceinline__ void rg_maxabs(const float* __restrict__ g, int64_t N, RegionStats* st) {
     float m = 0.0f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
         const float a = __builtin_fabsf(g[i]);
@@ -84,7 +84,7 @@ __device__ __forceinline__ double rg_margin(const RegionStats* st) {
 }
 
 // one thread per window w (shape = grid dims): window w is the trilinear polynomial of voxels w - 1 .. w per axis
-__global__ __launch_bounds__(256) void k_region_need(RegionArgs a) {
+__device__ __forceinline__ void rg_need(const RegionArgs& a) {
     const int64_t N = (int64_t)a.X * a.Y * a.Z;
     const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const double margin = rg_margin(a.st);
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void k_region_need(RegionArgs a) {
 }
 
 // the family of candidate inner boxes (scenes.influence_rbox): one thread
-__global__ void k_region_cands(RegionArgs a) {
+__device__ __forceinline__ void rg_cands(const RegionArgs& a) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     RegionStats* st = a.st;
     if (st->count == 0ull) return;
@@ -169,8 +169,7 @@ __global__ void k_region_cands(RegionArgs a) {
 // maximum beyond the layer next to the boundary, which scenes.influence_rbox lists: a deeper window lies between two listed
 // boxes along every axis, so none of its corners is an extreme point).  Every lane keeps, per candidate, the largest squared
 // distance from the candidate's inner box to the far corner of a box it has seen.
-__global__ __launch_bounds__(256) void k_region_boxes(RegionArgs a) {
-    __shared__ double sc[RG_CANDS][3], sh[RG_CANDS][3];
+__device__ __forceinline__ void rg_boxes(const RegionArgs& a, double (*sc)[3], double (*sh)[3]) {
     RegionStats* st = a.st;
     const int ncand = st->ncand;
     if (ncand == 0) return;
@@ -284,7 +283,7 @@ __device__ __forceinline__ float rg_next_up(float v) {  // np.nextafter(v, +inf)
 }
 
 // the smallest rounded box among the candidates -> the record (scenes.tighten_far_boxes): one thread
-__global__ void k_region_pick(RegionArgs a) {
+__device__ __forceinline__ void rg_pick(const RegionArgs& a) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     RegionStats* st = a.st;
     omgx_object* r = a.rec;
@@ -312,6 +311,66 @@ __global__ void k_region_pick(RegionArgs a) {
     const float rr = rg_next_up((float)R);
     r->rb_r = rr;
     r->rb_r2 = rg_next_up((float)((double)rr * (double)rr));
+}
+
+// ---- one object (omgx_fit_influence_region) ---------------------------------------------------------------------------------
+__global__ void k_region_init(RegionStats* st) { rg_init(st); }
+__global__ __launch_bounds__(256) void k_region_maxabs(const float* __restrict__ g, int64_t N, RegionStats* st) { rg_maxabs(g, N, st); }
+__global__ __launch_bounds__(256) void k_region_need(RegionArgs a) { rg_need(a); }
+__global__ void k_region_cands(RegionArgs a) { rg_cands(a); }
+__global__ __launch_bounds__(256) void k_region_boxes(RegionArgs a) {
+    __shared__ double sc[RG_CANDS][3], sh[RG_CANDS][3];
+    rg_boxes(a, sc, sh);
+}
+__global__ void k_region_pick(RegionArgs a) { rg_pick(a); }
+
+// ---- a whole table (omgx_fit_influence_regions, ABI 10): blockIdx.y = entry of the fit list; every launch reads what it needs —
+// dims, limits, thresholds, the volume's place in the pool — from the object's record ON THE DEVICE.  Same bodies, same bits.
+struct RegionBatch {
+    omgx_object* objects;
+    const float* pool;
+    const int32_t* fit_list;   // [n_fit] object indices: one per distinct (volume, epsilon, clearance)
+    const int64_t* need_off;   // [n_fit] byte offset of the entry's window flags in `need`
+    RegionStats* stats;        // [n_fit]
+    unsigned char* need;
+    int n_fit;
+};
+__device__ __forceinline__ RegionArgs rg_entry(const RegionBatch& b, int f) {
+    omgx_object* r = b.objects + b.fit_list[f];
+    RegionArgs a;
+    a.g = b.pool + r->grid_offset;
+    a.X = r->dim[0]; a.Y = r->dim[1]; a.Z = r->dim[2];
+    a.eps = (double)r->epsilon; a.clr = (double)r->clearance;
+    for (int k = 0; k < 3; ++k) a.vox[k] = (double)((r->hi[k] - r->lo[k]) / (float)r->dim[k]);
+    a.st = b.stats + f;
+    a.need = b.need + b.need_off[f];
+    a.rec = r;
+    return a;
+}
+__global__ void k_regions_init(RegionBatch b) { rg_init(b.stats + blockIdx.y); }
+__global__ __launch_bounds__(256) void k_regions_maxabs(RegionBatch b) {
+    const RegionArgs a = rg_entry(b, blockIdx.y);
+    rg_maxabs(a.g, (int64_t)a.X * a.Y * a.Z, a.st);
+}
+__global__ __launch_bounds__(256) void k_regions_need(RegionBatch b) {
+    const RegionArgs a = rg_entry(b, blockIdx.y);
+    if ((int64_t)blockIdx.x * blockDim.x >= (int64_t)a.X * a.Y * a.Z) return;  // the grid is sized for the largest volume
+    rg_need(a);
+}
+__global__ void k_regions_cands(RegionBatch b) { rg_cands(rg_entry(b, blockIdx.y)); }
+__global__ __launch_bounds__(256) void k_regions_boxes(RegionBatch b) {
+    __shared__ double sc[RG_CANDS][3], sh[RG_CANDS][3];
+    rg_boxes(rg_entry(b, blockIdx.y), sc, sh);
+}
+__global__ void k_regions_pick(RegionBatch b) { rg_pick(rg_entry(b, blockIdx.y)); }
+// the records that share a fitted entry's volume and thresholds take its region: copy_src[o] = the fitted object, or -1
+__global__ __launch_bounds__(256) void k_regions_copy(omgx_object* objects, const int32_t* copy_src, int n) {
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= n) return;
+    const int s = copy_src[o];
+    if (s < 0 || s == o) return;
+    for (int k = 0; k < 3; ++k) { objects[o].rb_c[k] = objects[s].rb_c[k]; objects[o].rb_h[k] = objects[s].rb_h[k]; }
+    objects[o].rb_r = objects[s].rb_r; objects[o].rb_r2 = objects[s].rb_r2;
 }
 
 // the grid fields of a record and everything derived from them (scenes.pack_table + finish_records): one thread
@@ -392,5 +451,71 @@ extern "C" int omgx_fit_influence_region(omgx_object* object, const float* grid,
     hipLaunchKernelGGL(k_region_boxes, dim3(wblocks < 2048 ? wblocks : 2048), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_region_pick, dim3(1), dim3(64), 0, st, a);
     OMGX_CHECK_LAUNCH("omgx_fit_influence_region");
+    return OMGX_OK;
+}
+
+
+// Content hash of every object's volume: two independent 64-bit sums of mixed (float bits, position) words — commutative, so the
+// lanes add in any order; equal for equal volumes, different otherwise with probability 1 - 2^-128.  DeviceScenes.fit_all fits
+// volumes that occur several times (private copies of one model in many scenes) once.
+__device__ __forceinline__ unsigned long long rg_mix(unsigned long long z) {  // splitmix64 finaliser
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+__global__ __launch_bounds__(256) void k_volume_hashes(const omgx_object* objects, const float* pool, unsigned long long* out) {
+    const omgx_object* r = objects + blockIdx.y;
+    const int64_t N = (int64_t)r->dim[0] * r->dim[1] * r->dim[2];
+    const uint32_t* g = reinterpret_cast<const uint32_t*>(pool + r->grid_offset);
+    unsigned long long h0 = 0ull, h1 = 0ull;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned long long w = ((unsigned long long)g[i] << 32) ^ (unsigned long long)i;
+        h0 += rg_mix(w + 0x9e3779b97f4a7c15ull);
+        h1 += rg_mix(w ^ 0xd1b54a32d192ed03ull);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { h0 += __shfl_xor(h0, off, 64); h1 += __shfl_xor(h1, off, 64); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(out + 2 * blockIdx.y, h0); atomicAdd(out + 2 * blockIdx.y + 1, h1); }
+}
+
+extern "C" int omgx_volume_hashes(const omgx_object* objects, int32_t num_objects, const float* pool, uint64_t* hashes, void* stream) {
+    if (num_objects < 0) return OMGX_ERR_INVALID;
+    if (num_objects == 0) return OMGX_OK;
+    if (!objects || !pool || !hashes) return OMGX_ERR_INVALID;
+    if (num_objects > 65535) return OMGX_ERR_UNSUPPORTED;
+    hipError_t e = hipMemsetAsync(hashes, 0, (size_t)num_objects * 16, (hipStream_t)stream);
+    if (e != hipSuccess) return omgx_set_error("hipMemsetAsync", e);
+    hipLaunchKernelGGL(k_volume_hashes, dim3(16, (unsigned)num_objects), dim3(256), 0, (hipStream_t)stream, objects, pool,
+                       reinterpret_cast<unsigned long long*>(hashes));
+    OMGX_CHECK_LAUNCH("k_volume_hashes");
+    return OMGX_OK;
+}
+
+extern "C" int64_t omgx_regions_scratch_bytes(int32_t n_fit, int64_t need_bytes) {
+    if (n_fit < 0 || need_bytes < 0) return 0;
+    return (int64_t)n_fit * (int64_t)sizeof(RegionStats) + 256 + need_bytes;
+}
+
+extern "C" int omgx_fit_influence_regions(omgx_object* objects, int32_t num_objects, const float* pool, const int32_t* fit_list,
+                                          const int64_t* need_offsets, int32_t n_fit, int64_t max_voxels, const int32_t* copy_src,
+                                          void* scratch, void* stream) {
+    if (n_fit < 0 || num_objects < 0 || max_voxels < 0) return OMGX_ERR_INVALID;
+    if (n_fit == 0) return OMGX_OK;
+    if (!objects || !pool || !fit_list || !need_offsets || !scratch || max_voxels < 1) return OMGX_ERR_INVALID;
+    if (max_voxels > (int64_t)1 << 31 || n_fit > 65535) return OMGX_ERR_UNSUPPORTED;
+    RegionBatch b;
+    b.objects = objects; b.pool = pool; b.fit_list = fit_list; b.need_off = need_offsets; b.n_fit = n_fit;
+    b.stats = reinterpret_cast<RegionStats*>(scratch);
+    b.need = reinterpret_cast<unsigned char*>(scratch) + (((size_t)n_fit * sizeof(RegionStats) + 255) & ~(size_t)255);
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned blocks = (unsigned)((max_voxels + 255) / 256), ny = (unsigned)n_fit;
+    hipLaunchKernelGGL(k_regions_init, dim3(1, ny), dim3(64), 0, st, b);
+    hipLaunchKernelGGL(k_regions_maxabs, dim3(blocks < 64 ? blocks : 64, ny), dim3(256), 0, st, b);
+    hipLaunchKernelGGL(k_regions_need, dim3(blocks, ny), dim3(256), 0, st, b);
+    hipLaunchKernelGGL(k_regions_cands, dim3(1, ny), dim3(64), 0, st, b);
+    hipLaunchKernelGGL(k_regions_boxes, dim3(blocks < 256 ? blocks : 256, ny), dim3(256), 0, st, b);
+    hipLaunchKernelGGL(k_regions_pick, dim3(1, ny), dim3(64), 0, st, b);
+    if (copy_src) hipLaunchKernelGGL(k_regions_copy, dim3((unsigned)((num_objects + 255) / 256)), dim3(256), 0, st, objects, copy_src, (int)num_objects);
+    OMGX_CHECK_LAUNCH("omgx_fit_influence_regions");
     return OMGX_OK;
 }

@@ -197,6 +197,8 @@ class ChompEngine:
         f64 = dict(dtype=torch.float64, device=dev)
         self.robot = ops.robot_blob(model, dev)
         self.scenes = batch if isinstance(batch, ops.DeviceScenes) else ops.DeviceScenes(batch, dev)  # a DeviceScenes: shared, and changeable between plans (set_object_pose, replace_grid)
+        if torch.device(self.scenes.device) != dev and not (self.scenes.device.type == dev.type == "cuda" and (self.scenes.device.index or 0) == (dev.index or 0)):
+            raise ValueError(f"the DeviceScenes live on {self.scenes.device}, the engine was asked for {dev}")
         self.start = torch.as_tensor(start, **f64).contiguous()
         self.goal_set = torch.as_tensor(goal_set, **f64).contiguous()
         self.use_standoff = bool(cfg.use_standoff)
@@ -209,7 +211,11 @@ class ChompEngine:
         else:
             self.reach = None
             self.cv_goals = self.goal_set
-        self.goal_idx = torch.zeros(self.S, dtype=torch.int32, device=dev)
+        # (Set-up builds its tensors on the HOST and uploads them: the first use of a torch kernel — fill, strided copy,
+        # index_select, where — loads another piece of torch's code objects, 20-120 ms each on a cold process, where a copy is DMA.)
+        def dzeros(shape, dtype):
+            return torch.from_numpy(np.zeros(shape, dtype)).to(dev)
+        self.goal_idx = dzeros(self.S, np.int32)
         self.goal_count = self.eta_s = None
         if goal_counts is not None:
             gc = np.asarray(goal_counts, np.int64).reshape(-1)
@@ -222,10 +228,13 @@ class ChompEngine:
         if traj_init is None:
             from .scenes import cubic_init
             traj_init = np.stack([cubic_init(start[s], goal_set[s, 0], n) for s in range(S)])
-        self.traj = torch.as_tensor(traj_init, **f64).contiguous().clone()
-        self.end = self.goal_set[:, 0].contiguous().clone()
-        self.goal_rows = torch.empty((S, self.c, 9), **f64)
-        self.goal_point = torch.empty((S, 9), **f64)
+        self.traj = torch.from_numpy(np.ascontiguousarray(traj_init, np.float64).copy()).to(dev)
+        gs_h = np.ascontiguousarray(goal_set, np.float64)
+        self.end = torch.from_numpy(gs_h[:, 0].copy()).to(dev)
+        # the goal the plan starts from is goal 0 (goal_idx = 0): traj.end / chosen rows / goal point (online_learner.py:243-245, optimizer.py:93-99)
+        self.goal_point = torch.from_numpy(gs_h[:, 0].copy()).to(dev)
+        rows_h = np.ascontiguousarray(reach_grasps, np.float64)[:, 0] if self.use_standoff else gs_h[:, 0][:, None, :]
+        self.goal_rows = torch.from_numpy(np.ascontiguousarray(rows_h).copy()).to(dev)
         # preallocated outputs: nothing is allocated inside an iteration
         f32 = dict(dtype=torch.float32, device=dev)
         self.pot = torch.empty((S, n, 10, P), **f32)
@@ -233,7 +242,7 @@ class ChompEngine:
         self.col = torch.empty((S, n, 10, P), **f32)
         self.grad = torch.empty((S, n, 9), **f64)
         self.cost_traj = torch.empty((S, n), **f64)
-        self.info = torch.zeros((S, _lib.INFO_STRIDE), **f64)
+        self.info = dzeros((S, _lib.INFO_STRIDE), np.float64)
         # latency mode: [S][G][parts] partial sums, parts = ceil(window / LAT_GOAL_PARTS) shrinking with the window (flat buffer)
         self._parts_max = ops.goalset_parts(n, self.LAT_GOAL_PARTS) if self.latency else (ops.goalset_parts(n, self.goal_parts) if self.goal_parts > 1 else 1)
         self._parts_last = 1
@@ -242,24 +251,24 @@ class ChompEngine:
         self._poses_on = False
         self.wp_pose = torch.empty((S, n, 10, 12), **f64)
         self.start_pose = torch.empty((S, 10, 12), **f64)
-        self.end_pose = torch.zeros((S, 10, 12), **f64)
+        self.end_pose = dzeros((S, 10, 12), np.float64)
         self.goal_pose_tab = torch.empty((S, G, 10, 12), **f64)
-        self.goal_cost = torch.zeros((S, G * self._parts_max), **f32)
-        self.goal_col = torch.zeros((S, G * self._parts_max), **f32)
+        self.goal_cost = dzeros((S, G * self._parts_max), np.float32)
+        self.goal_col = dzeros((S, G * self._parts_max), np.float32)
         self.learner_state = ops.learner_state(S, G, dev, goal_counts)  # sum_costs | p | experts_p | q | experts_costs
-        self.cost_vec = torch.zeros((S, G), **f64)
+        self.cost_vec = dzeros((S, G), np.float64)
         self.eta = float(np.sqrt(np.log(G + 1) / cfg.optim_steps))  # online_learner.py:80
-        self._active = torch.ones(S, dtype=torch.int32, device=dev)
+        self._active = torch.from_numpy(np.ones(S, np.int32)).to(dev)
         self._masked = False  # becomes True with the first early_stop iteration or when `active` is assigned: launches then take the mask
         self.step_count = 0  # Optimizer.step
         self.t = 0           # Learner.t
-        self._scene_flags = torch.zeros(S, dtype=torch.int32, device=dev)  # omgx_goal_update_optimize's rendezvous
+        self._scene_flags = dzeros(S, np.int32)  # omgx_goal_update_optimize's rendezvous
         # Dispatch order of the goal-set launch.  The first launch of a plan runs in scene-major order and records every goal
         # workgroup's duration in `work`; build_schedule() turns that — on the device, no host sync — into the order of all
         # later launches: scenes dealt to the 8 XCDs by weight (heaviest first, serpentine), each scene's goals longest first.
         # A scene keeps all its workgroups on one XCD (its SDF volumes stay in that XCD's L2: without this affinity the
         # launch takes 1.7x as long).  Results do not depend on the order.
-        self.work = torch.zeros(S * G * (1 if self.latency else self._parts_max), dtype=torch.int32, device=dev)  # one counter per (scene, goal, part) workgroup
+        self.work = dzeros(S * G * (1 if self.latency else self._parts_max), np.int32)  # one counter per (scene, goal, part) workgroup
         self.auto_schedule = True
         self.schedule = None
         self._sched_np = 1  # parts per goal the current schedule's items count
@@ -271,12 +280,14 @@ class ChompEngine:
         # a ticket must differ from every value still stored in the flags it is compared with (include/omg_hip.h), whoever
         # launched last — the whole engine, a part, parts of an earlier split.  A one-element list, shared by reference.
         self._ticket_src = [0]
-        self._num_cus = torch.cuda.get_device_properties(dev).multi_processor_count
+        with torch.cuda.device(dev):
+            self._num_cus = int(_lib.lib().omgx_device_cu_count())  # (torch.cuda.get_device_properties costs 110 ms on its first call)
+        if self._num_cus <= 0:
+            self._num_cus = torch.cuda.get_device_properties(dev).multi_processor_count
         self._parts, self._forked, self._in_plan = None, False, False
         self._hot = None
         self._capturing = False
         self._scratch_state = self._cubic_h = self._cubic_tmp = self._cubic_diff = None
-        self._gather_goal()
 
     @property
     def active(self) -> torch.Tensor:
@@ -788,7 +799,11 @@ class ChompEngine:
                 dst.append(cur)
                 src.append(snap[k])
         if dst:  # one fused copy per dtype instead of a launch per tensor (17 of them: ~0.15 ms of launches every time a benchmark rewinds its workload)
-            torch._foreach_copy_(dst, src)
+            if hasattr(torch, "_foreach_copy_"):
+                torch._foreach_copy_(dst, src)
+            else:  # older torch builds: one copy per tensor
+                for d_, s_ in zip(dst, src):
+                    d_.copy_(s_)
         (self.step_count, self.t, self.cfg.obstacle_weight, self.cfg.smoothness_weight, self.cfg.grasp_weight, self.cfg.step_size) = snap["_host"]
         # the mask goes back with the flags it guards: a snapshot taken before any early stop has every scene active, and the
         # launches after the restore run unmasked again (dispatch schedule in use, no mask look-up in the goal-set kernel)

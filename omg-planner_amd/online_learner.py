@@ -17,24 +17,47 @@ import torch
 from . import _lib, ops
 
 
+def _host_value(name):
+    """A learner attribute whose truth lives on the device between calls (p, sum_costs, experts_p, q, experts_costs): reading it
+    applies a deferred update_goal() and pulls the state if the device is ahead."""
+    def get(self):
+        loop = self.__dict__.get("_loop")
+        if loop is not None:
+            if loop._pending is not None:
+                loop.flush()
+            if loop.state_dirty:
+                self._pull_state()
+        return self.__dict__["_hv"][name]
+
+    def put(self, value):
+        self.__dict__.setdefault("_hv", {})[name] = value
+    return property(get, put)
+
+
 class Learner(object):
+    p, sum_costs, experts_p, q, experts_costs = (_host_value(k) for k in ("p", "sum_costs", "experts_p", "q", "experts_costs"))
+    # Learner.update_goal() defers its device work to the Optimizer.optimize() that follows (device_loop.DeviceLoop): one fused pair
+    # of launches and one download per planner iteration.  False: every call does its own work at once (round-2 behaviour).
+    DEFER_UPDATE = True
+
     def __init__(self, env, traj, cost):
         cfg, n = env.config, len(traj.goal_set)
         eta = np.sqrt(np.log(n + 1) / cfg.optim_steps)
         etas = [eta * 2.0 ** k for k in (-2, -1, 0, 2, 4)]
         # The reference's attribute surface (omg/online_learner.py:67-92): planner and user code read these names, so names and
         # initial values are the interface.  The numerical state among them (p, sum_costs, experts_p, q, experts_costs) is the
-        # host view of the device state and is refreshed after every update.
+        # host view of the device state and is refreshed when it is read after an update.
+        self._loop = None
         vars(self).update(
             cfg=cfg, env=env, traj=traj, cost=cost, alg_name=cfg.ol_alg, N=n, T=cfg.optim_steps, t=0.0, last_leader=0,
-            Ti=np.zeros(n), Tis=[], weights=np.ones(n), p=np.full(n, 1.0) / n, sum_costs=np.zeros(n),
+            Ti=np.zeros(n), Tis=[], weights=np.ones(n),
             eta=eta, etas=etas, num_experts=len(etas), delta=np.ones(n) / (4 * n + 1),
-            experts_p=[np.ones(n) / n for _ in etas], experts_costs=np.zeros(len(etas)), q=np.ones(len(etas)) / len(etas),
         )
+        self.p, self.sum_costs = np.full(n, 1.0) / n, np.zeros(n)
+        self.experts_p, self.experts_costs, self.q = [np.ones(n) / n for _ in etas], np.zeros(len(etas)), np.ones(len(etas)) / len(etas)
         if self.alg_name not in _lib.ALG:
             raise ValueError(f"cfg.ol_alg = {self.alg_name!r}: the learner knows {sorted(_lib.ALG)}")
         self._dev = cost.device
-        self._state = None  # device copy of (sum_costs | p | experts_p | q | experts_costs), created with the goal tensors
         self._goals_key = None
         if self.alg_name != "Proj" and len(self.env.objects[self.env.target_idx].reach_grasps) > 0:  # online_learner.py:96-102
             costs = self.cost_vector()
@@ -44,69 +67,57 @@ class Learner(object):
 
     # ---- device side -------------------------------------------------------------------------------
     def _tensors(self):
-        """Goal set / standoff tails / learner state on the device; rebuilt when the goal arrays are replaced."""
-        goal_set = np.asarray(self.traj.goal_set, np.float64)
+        """The device loop of this (learner, trajectory) pair — goal set / standoff tails / learner state / trajectory on the
+        device; rebuilt when the goal arrays are replaced (the learner's state is kept while the goal count stays)."""
+        from .device_loop import DeviceLoop
         reach = self.env.objects[self.env.target_idx].reach_grasps
-        key = (id(self.traj.goal_set), goal_set.shape, id(reach), bool(self.cfg.use_standoff))
-        if self._goals_key != key:
-            f64 = dict(dtype=torch.float64, device=self._dev)
-            self._goal_set = torch.as_tensor(goal_set[None], **f64).contiguous()
-            self._reach = None
-            self._cv_goals = self._goal_set
-            if self.cfg.use_standoff:
-                r = np.asarray(reach, np.float64)
-                if r.ndim != 3 or r.shape[0] != goal_set.shape[0]:
-                    raise _lib.OmgHipError("cfg.use_standoff needs target_obj.reach_grasps [G,c,9]")
-                self._reach = torch.as_tensor(r[None], **f64).contiguous()
-                self._cv_goals = self._reach[:, :, -1, :].contiguous()  # online_learner.py:121-125
-            G, c = goal_set.shape[0], (self._reach.shape[2] if self._reach is not None else 1)
-            if self._state is None or self._state.shape[1] != 7 * G + 10:
-                self._state = ops.learner_state(1, G, self._dev)
-            self._idx = torch.zeros(1, dtype=torch.int32, device=self._dev)
-            self._end = torch.zeros((1, 9), **f64)
-            self._rows = torch.zeros((1, c, 9), **f64)
-            self._gp = torch.zeros((1, 9), **f64)
-            self._cv = torch.zeros((1, G), **f64)
-            self._gcost = torch.zeros((1, G), dtype=torch.float32, device=self._dev)
-            self._gcol = torch.zeros((1, G), dtype=torch.float32, device=self._dev)
+        key = (id(self.traj.goal_set), np.asarray(self.traj.goal_set).shape, id(reach), bool(self.cfg.use_standoff), int(self.cfg.timesteps))
+        loop = self._loop
+        if loop is None or self._goals_key != key or self.cost._robot_model()[1] is not loop.robot:
+            old = loop
+            if old is not None and old._pending is not None:
+                old.flush()
+            loop = DeviceLoop(self.cost, self)
+            if old is not None and old.state.shape == loop.state.shape:
+                loop.state.copy_(old.state)
+            self._loop = self.cost._loop = loop
             self._goals_key = key
-        return self._goal_set, self._reach, self._cv_goals
+        elif self.cost.__dict__.get("_loop") is not loop:
+            self.cost._loop = loop  # several learners may share a Cost: the optimiser follows the one that spoke last
+        return loop
 
-    def _params(self, alg: str) -> _lib.LearnerParams:
+    def _params(self, alg: str, tiled: bool = False) -> _lib.LearnerParams:
         cfg = self.cfg
         p = _lib.LearnerParams()
         p.alg = _lib.ALG[alg]
         p.num_goals, p.n_waypoints = self.N, int(cfg.timesteps)
         p.start_idx = min(int((self.t / cfg.optim_steps) * cfg.timesteps), cfg.timesteps - 1)  # online_learner.py:109-110
         p.use_standoff = int(bool(cfg.use_standoff))
-        p.constraint_num = int(self._rows.shape[1])
+        p.constraint_num = int(self._loop.c)
         p.normalize_cost = int(bool(cfg.normalize_cost))
         p.base_obstacle_weight = float(cfg.base_obstacle_weight)
         p.smooth_weight = float(cfg.smoothness_base_weight * cfg.dist_eps)
         p.eta = float(self.eta)
+        if tiled:  # the goal costs come from the latency-mode launch as [G][parts] partial sums
+            p.cost_parts = ops.goalset_parts(p.n_waypoints - p.start_idx, self._loop.LAT_TILING[0])
         return p
-
-    def _run(self, alg: str, state: torch.Tensor):
-        """cost_vector's device work + one update of `state` with rule `alg`; returns the learner parameters used."""
-        goal_set, reach, cv_goals = self._tensors()
-        prm = self._params(alg)
-        model, robot = self.cost._robot_model()
-        traj = torch.as_tensor(np.ascontiguousarray(self.traj.data, np.float64)[None], dtype=torch.float64).to(self._dev)
-        if traj.shape[1] != prm.n_waypoints:
-            raise _lib.OmgHipError(f"trajectory has {traj.shape[1]} waypoints, cfg.timesteps is {prm.n_waypoints}")
-        if alg != "Proj":
-            ops.goalset_cost(robot, model.points_per_link, self.cost._scenes(), traj[:, prm.start_idx], cv_goals,
-                             prm.n_waypoints - prm.start_idx, float(self.cfg.time_interval), soften_fingers=False,
-                             out=(self._gcost, self._gcol))
-        ops.goal_update(prm, traj, goal_set, reach, self._gcost, state, self._idx, self._end, self._rows, self._gp, self._cv)
-        return prm
 
     def _pull_state(self):
         G = self.N
-        s = self._state[0].cpu().numpy()
+        s = self._loop.pull_state()
         self.sum_costs, self.p = s[:G].copy(), s[G:2 * G].copy()
         self.experts_p = [s[2 * G + i * G: 3 * G + i * G].copy() for i in range(5)]
         self.q, self.experts_costs = s[7 * G:7 * G + 5].copy(), s[7 * G + 5:7 * G + 10].copy()
+        if self.alg_name == "Proj":  # online_learner.py:200-210: one-hot on the goal closest to the trajectory's end
+            self.p = np.zeros(self.N)
+            self.p[int(self._loop._m_idx)] = 1
+
+    def _goal_taken(self, idx: int):
+        """Host bookkeeping of an update whose goal index has just become known (online_learner.py:243-248)."""
+        if self.alg_name in ("FTL", "FTC"):
+            self.last_leader = idx
+        self.Ti[idx] += 1
+        self.Tis.append(self.Ti)
 
     # ---- the reference's methods -------------------------------------------------------------------
     def cost_vector(self):
@@ -115,27 +126,42 @@ class Learner(object):
         reach = self.env.objects[self.env.target_idx].reach_grasps
         if getattr(cfg, "traj_init", "grasp") == "grasp" and (len(reach) == 0 or (cfg.use_standoff and len(np.array(reach).shape) == 2)):
             return np.zeros(1)
-        self._tensors()
-        self._run("FTC", self._state.clone())  # FTC keeps no state: only the cost vector is of interest
-        return self._cv[0].cpu().numpy()
+        loop = self._tensors()
+        if loop._pending is not None:
+            loop.flush()
+        loop.sync_inputs(self.traj)
+        prm = self._params("FTC")  # FTC keeps no state: only the cost vector is of interest
+        model = self.cost._robot_model()[0]
+        traj = loop.d("traj")
+        G = self.N
+        gcost, gcol = loop.gcost.view(-1)[:G].view(1, G), loop.gcol.view(-1)[:G].view(1, G)
+        ops.goalset_cost(loop.robot, model.points_per_link, self.cost._scenes(), traj[:, prm.start_idx], loop.cv_goals,
+                         prm.n_waypoints - prm.start_idx, float(cfg.time_interval), soften_fingers=False, out=(gcost, gcol))
+        ops.goal_update(prm, traj, loop.goal_set, loop.reach, gcost, loop.state.clone(), loop.s_idx, loop.s_end, loop.s_rows, loop.s_gp, loop.cv)
+        return loop.cv[0].cpu().numpy()
 
     def update_goal_dist(self):
-        """One step of the configured rule on the goal distribution (online_learner.py:162-234)."""
-        self._tensors()
-        self._run(self.alg_name, self._state)
-        self._pull_state()
+        """One step of the configured rule on the goal distribution (online_learner.py:162-234), at once."""
+        loop = self._tensors()
+        idx = loop.update_now(self._params(self.alg_name, tiled=True))
         if self.alg_name in ("FTL", "FTC"):
-            self.last_leader = int(self._idx[0])
-        if self.alg_name == "Proj":  # online_learner.py:200-210: one-hot on the goal closest to the trajectory's end
-            self.p = np.zeros(self.N)
-            self.p[int(self._idx[0])] = 1
+            self.last_leader = idx
+        return idx
 
     def update_goal(self):
-        """Take the arg-max of the goal distribution (online_learner.py:237-249); True when the goal changed."""
+        """Take the arg-max of the goal distribution (online_learner.py:237-249); True when the goal changed.  With
+        DEFER_UPDATE the device work waits for the Optimizer.optimize() that follows (or for whoever looks at the result
+        first): traj.goal_idx / traj.end / the return value are promises that turn into int / array / bool on use."""
         self.t += 1
-        self.update_goal_dist()
+        loop = self._tensors()
+        if self.DEFER_UPDATE:
+            from .device_loop import _LazyEnd
+            idx, changed = loop.defer_update(self._params(self.alg_name, tiled=True))
+            self.traj.goal_idx = idx
+            self.traj.end = _LazyEnd(loop, idx)
+            return changed
         goal_idx_old = self.traj.goal_idx
-        self.traj.goal_idx = int(self._idx[0])  # np.argmax(self.p) with numpy's NaN / tie rules, taken on the device
+        self.traj.goal_idx = self.update_goal_dist()  # np.argmax(self.p) with numpy's NaN / tie rules, taken on the device
         self.traj.end = self.traj.goal_set[self.traj.goal_idx]
         self.Ti[self.traj.goal_idx] += 1
         self.Tis.append(self.Ti)

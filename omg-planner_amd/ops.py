@@ -96,7 +96,118 @@ class DeviceScenes:
         self.pool_used = used
         sizes = self.host_objects["dim"].astype(np.int64).prod(axis=1)
         self._slot_cap = {i: int(sizes[i]) for i in range(len(sizes))}  # elements object i may use at its grid_offset
+        # scenes.pack_table(share_grids=True) and scene_io store identical volumes once: several records then point at one offset.
+        # A slot that is shared is never written in place (copy-on-write: the object that changes gets space of its own).
+        from collections import Counter
+        self._refs = Counter(int(o) for o in self.host_objects["grid_offset"])
+        self._free = []       # [(offset, capacity)] slots no record points at any more: reused before the reserve is touched
+        self._pending = {}    # object -> (offset, capacity) handed out by grid_slot, not yet committed by replace_grid
         self._scratch = None
+
+    @classmethod
+    def from_scenes(cls, scenes, cfg_kwargs=None, device="cuda:0", share_grids: bool = True, reserve_voxels: int = 0,
+                    timing: "dict | None" = None) -> "DeviceScenes":
+        """First build of a batch WITHOUT a host pass over the voxels (Env.combine_sdfs, omg/core.py:366-411; scenes.pack_table is
+        the host-side specification): the records are written on the host from the scenes' poses / limits / thresholds (a few
+        hundred bytes per object), every distinct volume goes to the pool with one copy, and ALL influence regions are fitted on
+        the device in seven launches (omgx_fit_influence_regions) — volumes and thresholds that occur several times are fitted
+        once.  share_grids: a volume referenced by several objects (the same ndarray) is stored once.  The device records equal
+        scenes.pack_table(scenes, cfg_kwargs, ragged=True, share_grids=share_grids) field for field; the host mirror's region
+        fields are the loose ones until sync_host()."""
+        import time as _time
+        from . import scenes as _sc
+        t0 = _time.perf_counter()
+        cfg_kwargs = cfg_kwargs or {}
+        dev = torch.device(device)
+        n_obj = sum(len(s.objects) for s in scenes)
+        rec = np.zeros(n_obj, _sc.OBJECT_DTYPE)
+        begins, chunks, seen, offset, k = [0], [], {}, 0, 0
+        for s in scenes:
+            poses, eps, pad, clr, dis = _sc.layer_params(s, **cfg_kwargs)
+            m = len(s.objects)
+            rec["pose_inv"][k: k + m] = poses[:, :3, :4].reshape(m, 12)
+            rec["epsilon"][k: k + m], rec["padding_scale"][k: k + m], rec["clearance"][k: k + m] = eps, pad, clr
+            rec["disabled"][k: k + m] = dis > 0
+            for i, ob in enumerate(s.objects):
+                mn, mxc = ob.sdf.min_coords, ob.sdf.max_coords
+                rec["lo"][k + i] = mn.astype(np.float32)
+                rec["hi"][k + i] = np.array([mn[a] + (mxc[a] - mn[a]) * 1.0 for a in range(3)], np.float32)  # scenes.pack_table (ragged)
+                rec["dim"][k + i] = ob.sdf.data.shape
+                rec["delta"][k + i] = ob.sdf.delta
+                key = id(ob.sdf.data)
+                if share_grids and key in seen:
+                    rec["grid_offset"][k + i] = seen[key]
+                else:
+                    rec["grid_offset"][k + i] = offset
+                    seen[key] = offset
+                    chunks.append((offset, ob.sdf.data))
+                    offset += int(ob.sdf.data.size)
+            k += m
+            begins.append(k)
+        _sc.finish_records(rec)  # derived constants + the loose region
+        t1 = _time.perf_counter()
+        self = cls.__new__(cls)
+        self.device = dev
+        self.num_scenes = len(scenes)
+        self.host_objects = rec
+        self.host_scene_begin = np.array(begins, np.int32)
+        with torch.cuda.device(dev):
+            self.pool = torch.empty(offset + int(reserve_voxels), dtype=torch.float32, device=dev)
+            for off, data in chunks:
+                src = torch.from_numpy(np.ascontiguousarray(data, np.float32).reshape(-1))
+                self.pool[off: off + src.numel()].copy_(src, non_blocking=True)
+            self.objects = torch.from_numpy(rec.view(np.uint8).copy()).to(dev)
+            self.scene_begin = torch.from_numpy(self.host_scene_begin).to(dev)
+        self.pool_used = offset
+        sizes = rec["dim"].astype(np.int64).prod(axis=1)
+        self._slot_cap = {i: int(sizes[i]) for i in range(n_obj)}
+        from collections import Counter
+        self._refs = Counter(int(o) for o in rec["grid_offset"])
+        self._free, self._pending, self._scratch = [], {}, None
+        t2 = _time.perf_counter()
+        self.fit_all()
+        if timing is not None:
+            torch.cuda.synchronize(dev)
+            t3 = _time.perf_counter()
+            timing.update(records_ms=(t1 - t0) * 1e3, upload_ms=(t2 - t1) * 1e3, fit_ms=(t3 - t2) * 1e3, total_ms=(t3 - t0) * 1e3)
+        return self
+
+    def fit_all(self) -> int:
+        """Fit the influence region of every record the kernels cull for, on the device, in seven launches
+        (omgx_fit_influence_regions); records with the same volume CONTENT (omgx_volume_hashes: private copies of one model in many
+        scenes count as one), dims, voxel size and thresholds are fitted once.  Returns the number of distinct fits."""
+        rec = self.host_objects
+        w = (rec["hi"].astype(np.float32) - rec["lo"].astype(np.float32)).astype(np.float32)
+        ok = (w > 0).all(axis=1) & (rec["dim"] > 1).all(axis=1) & (rec["epsilon"] < 1.0) & (rec["clearance"] <= 1.0)  # scenes.tighten_far_boxes
+        l = _lib.lib()
+        with torch.cuda.device(self.device):  # 128-bit content hashes of all volumes: one launch, one small download
+            d_hash = torch.empty((len(rec), 2), dtype=torch.int64, device=self.device)
+            check(l.omgx_volume_hashes(_ptr(self.objects), len(rec), _ptr(self.pool), _ptr(d_hash), _stream()), "omgx_volume_hashes")
+            hashes = d_hash.cpu().numpy()
+        copy_src = np.full(len(rec), -1, np.int32)
+        leaders, first = [], {}
+        for o in np.nonzero(ok)[0]:
+            r = rec[o]
+            key = (hashes[o].tobytes(), r["dim"].tobytes(), w[o].tobytes(), float(r["epsilon"]), float(r["clearance"]))
+            lead = first.setdefault(key, int(o))
+            copy_src[o] = lead
+            if lead == o:
+                leaders.append(int(o))
+        if not leaders:
+            return 0
+        fit_list = np.array(leaders, np.int32)
+        nvox = rec["dim"][fit_list].astype(np.int64).prod(axis=1)
+        need_off = np.concatenate([[0], np.cumsum(nvox)[:-1]]).astype(np.int64)
+        nbytes = int(l.omgx_regions_scratch_bytes(len(fit_list), int(nvox.sum())))
+        with torch.cuda.device(self.device):
+            scratch = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            d_fit = torch.from_numpy(fit_list).to(self.device)
+            d_off = torch.from_numpy(need_off).to(self.device)
+            d_src = torch.from_numpy(copy_src).to(self.device)
+            check(l.omgx_fit_influence_regions(_ptr(self.objects), len(rec), _ptr(self.pool), _ptr(d_fit), _ptr(d_off), len(fit_list),
+                                               int(nvox.max()), _ptr(d_src), _ptr(scratch), _stream()), "omgx_fit_influence_regions")
+            scratch.record_stream(torch.cuda.current_stream(self.device))
+        return len(fit_list)
 
     def _index(self, scene: int, obj: int) -> int:
         lo, hi = int(self.host_scene_begin[scene]), int(self.host_scene_begin[scene + 1])
@@ -127,19 +238,43 @@ class DeviceScenes:
 
     def grid_slot(self, scene: int, obj: int, shape) -> torch.Tensor:
         """A float32 [X,Y,Z] view into the pool where the object's NEXT volume can be written in place (e.g. by
-        point_cloud_sdf(out=...)): the object's own slot if the shape fits, else fresh space from the reserve.  Pass it to
-        replace_grid afterwards."""
+        point_cloud_sdf(out=...)): the object's own slot if the shape fits and no other object shares it, else a slot nobody
+        uses any more, else fresh space from the reserve.  Nothing about the object changes until replace_grid is given the view:
+        a slot handed out and never used goes back to the free list with the next grid_slot call for the same object.
+        Sizing the reserve: one extra volume per object whose cloud extents grow from frame to frame (a slot that is outgrown
+        is reused by the next volume that fits it), plus one per object that shares its volume and will be changed."""
         idx = self._index(scene, obj)
         n = int(np.prod(shape))
-        off = int(self.host_objects[idx]["grid_offset"])
-        if n > self._slot_cap[idx]:
-            if self.pool_used + n > self.pool.numel():
-                raise _lib.OmgHipError(f"the SDF pool has no room for {n} more voxels: build DeviceScenes with reserve_voxels")
-            off = self.pool_used
-            self.pool_used += n
-            self._slot_cap[idx] = n
-            self.host_objects[idx]["grid_offset"] = off
+        old = self._pending.pop(idx, None)
+        if old is not None and old[0] != int(self.host_objects[idx]["grid_offset"]):
+            self._free.append(old)  # handed out earlier, never committed
+        off, cap = int(self.host_objects[idx]["grid_offset"]), self._slot_cap[idx]
+        if n > cap or self._refs[off] > 1:
+            for k, (fo, fc) in enumerate(self._free):
+                if fc >= n:
+                    off, cap = self._free.pop(k)
+                    break
+            else:
+                if self.pool_used + n > self.pool.numel():
+                    raise _lib.OmgHipError(f"the SDF pool has no room for {n} more voxels: build DeviceScenes with reserve_voxels")
+                off, cap = self.pool_used, n
+                self.pool_used += n
+        self._pending[idx] = (off, cap)
         return self.pool[off: off + n].view(tuple(int(d) for d in shape))
+
+    def _commit_slot(self, idx: int, n: int):
+        """replace_grid: the object moves into the slot grid_slot handed out; a slot it leaves behind is free once no record uses it."""
+        off, cap = self._pending.pop(idx)
+        old = int(self.host_objects[idx]["grid_offset"])
+        if off != old:
+            self._refs[old] -= 1
+            if self._refs[old] <= 0:
+                del self._refs[old]
+                self._free.append((old, self._slot_cap[idx]))
+            self._refs[off] += 1
+            self._slot_cap[idx] = cap
+            self.host_objects[idx]["grid_offset"] = off
+        return off
 
     def replace_grid(self, scene: int, obj: int, grid: torch.Tensor, origin, delta: float, fit: str = "device") -> None:
         """Give an object a new volume that is already on the device: grid [X,Y,Z] float32 (a view from grid_slot: used in place;
@@ -154,9 +289,14 @@ class DeviceScenes:
             raise _lib.OmgHipError("grid must be [X,Y,Z]")
         idx = self._index(scene, obj)
         shape = tuple(int(d) for d in grid.shape)
-        slot = self.grid_slot(scene, obj, shape)
-        if slot.data_ptr() != grid.data_ptr():
+        n = int(np.prod(shape))
+        pend = self._pending.get(idx)
+        if pend is not None and n <= pend[1] and grid.data_ptr() == self.pool.data_ptr() + 4 * pend[0]:
+            slot = grid  # the view grid_slot handed out, filled in place
+        else:
+            slot = self.grid_slot(scene, obj, shape)
             slot.copy_(grid)
+        self._commit_slot(idx, n)
         rec = self.host_objects[idx]
         mn = np.asarray(origin, np.float64)
         mxc = mn + float(delta) * np.array(shape)
@@ -463,15 +603,15 @@ def learner_state(S: int, G: int, device, goal_count=None) -> torch.Tensor:
     """Initial Learner state [S, 7G+10] f64: sum_costs 0 | p 1/G | experts_p 1/G | q 1/5 | experts_costs 0
     (Learner.__init__, omg/online_learner.py:66-95).  goal_count [S] (ragged goal sets padded to G): scene s holds
     1 / goal_count[s] in its first goal_count[s] entries and 0 in the padding."""
-    st = torch.zeros((S, 7 * G + 10), dtype=torch.float64, device=device)
+    st = np.zeros((S, 7 * G + 10), np.float64)  # built on the host: one upload instead of four first-use torch kernels
     if goal_count is None:
         st[:, G:7 * G] = 1.0 / G
     else:
-        cnt = torch.as_tensor(np.asarray(goal_count), dtype=torch.float64, device=device).reshape(S, 1)
-        row = torch.where(torch.arange(G, device=device)[None, :] < cnt, 1.0 / cnt, torch.zeros((), dtype=torch.float64, device=device))
-        st[:, G:7 * G] = row.repeat(1, 6)
+        cnt = np.asarray(goal_count, np.float64).reshape(S, 1)
+        row = np.where(np.arange(G)[None, :] < cnt, 1.0 / cnt, 0.0)
+        st[:, G:7 * G] = np.tile(row, (1, 6))
     st[:, 7 * G:7 * G + 5] = 0.2
-    return st
+    return torch.from_numpy(st).to(device)
 
 
 def _eta(eta, S):
@@ -651,6 +791,38 @@ class IterationCalls:
         else:
             with torch.cuda.device(self.device):
                 check(self._f_gs(*args), "omgx_goalset_cost_layer")
+
+    def _call(self, fn, args, what):
+        if self._on_device():
+            check(fn(*args), what)
+        else:
+            with torch.cuda.device(self.device):
+                check(fn(*args), what)
+
+    def layer_only(self, stream):
+        """The SDF layer of the current trajectories alone (omgx_goalset_cost_layer_tiled with num_goals = 0): what omgx_fk_sdf
+        computes for the step, with this object's tiling (latency mode) or five workgroups per scene (batch layout)."""
+        cost, col, _ws, traj, n, soft, lp, lg, lc = self._gs_mid
+        tl = self._tiling if self._tiling is not None else (1, 5, 0, 0)
+        args = (*self._gs_head, None, 9, None, self.S, 0, 1, self.dt, 0, None, None, traj, n, soft, lp, lg, lc, None, None, *tl,
+                self._layer_poses if self.use_layer_poses else None, None, C.c_void_p(stream))
+        self._call(self._f_gst, args, "omgx_goalset_cost_layer_tiled")
+
+    def step(self, params: ChompParams, stop_on_terminate: bool, stream):
+        """omgx_chomp_optimize on the layer outputs this object's launches write."""
+        robot = self._gs_head[0]
+        traj, start, end, goal_rows, goal_point, lp, lg, lc, active, S, grad, cost_traj, info, _aux = self._up_b
+        args = (robot, C.byref(params), traj, start, end, goal_rows, goal_point, lp, lg, lc, active, S, grad, cost_traj, info, None,
+                int(bool(stop_on_terminate)), C.c_void_p(stream))
+        self._call(_lib.lib().omgx_chomp_optimize, args, "omgx_chomp_optimize")
+
+    def goal_update(self, lparams: LearnerParams, stream):
+        """omgx_goal_update alone (the learner without the step) on the goal costs the last goalset_layer() left."""
+        goal_set, reach, cost, state, goal_idx, cost_vector, _robot = self._up_a
+        traj, _start, end, goal_rows, goal_point = self._up_b[:5]
+        args = (C.byref(lparams), traj, goal_set, reach, cost, state, self.S, goal_idx, end, goal_rows, goal_point, cost_vector,
+                None, self._goal_count, self._eta, C.c_void_p(stream))
+        self._call(_lib.lib().omgx_goal_update, args, "omgx_goal_update")
 
     def update(self, lparams: LearnerParams, params: ChompParams, split: bool, ticket: int, stop_on_terminate: bool, stream):
         """omgx_goal_update_optimize."""

@@ -64,17 +64,34 @@ class Optimizer(object):
         self.update()
         cost, cfg = self.cost, self.cfg
         n = traj.data.shape[0]
-        if cfg.goal_set_proj:
+
+        def chosen_rows(idx):  # optimizer.py:93-99
             if cfg.use_standoff:
-                chosen = np.asarray(cost.target_obj.reach_grasps[int(traj.goal_idx)], np.float64)
+                return np.asarray(cost.target_obj.reach_grasps[idx], np.float64)
+            return np.asarray(traj.goal_set[idx], np.float64)[None]
+        do_update = 0 if info_only else (1 if force_update else 2)
+        loop = getattr(cost, "_loop", None)
+        if loop is not None and loop.matches(traj):
+            # the planner loop's fast path (device_loop.DeviceLoop): trajectory, goal set and learner state stay on the device; a
+            # deferred Learner.update_goal() rides on this call's launches; one download
+            if cfg.goal_set_proj:
+                rows = lambda: chosen_rows(int(traj.goal_idx))
+                point = lambda: np.asarray(traj.goal_set[int(traj.goal_idx)], np.float64)
             else:
-                chosen = np.asarray(traj.goal_set[int(traj.goal_idx)], np.float64)[None]
-            goal_point = np.asarray(traj.goal_set[int(traj.goal_idx)], np.float64)
+                rows = lambda: np.tile(np.asarray(traj.end, np.float64), (cost._params(n, 0).constraint_num, 1))
+                point = lambda: np.asarray(traj.end, np.float64)
+            st = loop.optimize(traj, cost._params(n, do_update), rows, point)
+            collision_pts = cost._collision_pts_recompute(traj.data)
         else:
-            chosen = np.tile(np.asarray(traj.end, np.float64), (cost._params(n, 0).constraint_num, 1))
-            goal_point = np.asarray(traj.end, np.float64)
-        # one upload, two launches, one download (cost._Staging); results are host views valid until the next call
-        st = cost._run_step(traj.data, traj.start, traj.end, chosen, goal_point, 0 if info_only else (1 if force_update else 2), False)
+            if cfg.goal_set_proj:
+                chosen = chosen_rows(int(traj.goal_idx))
+                goal_point = np.asarray(traj.goal_set[int(traj.goal_idx)], np.float64)
+            else:
+                chosen = np.tile(np.asarray(traj.end, np.float64), (cost._params(n, 0).constraint_num, 1))
+                goal_point = np.asarray(traj.end, np.float64)
+            # one upload, two launches, one download (cost._Staging); results are host views valid until the next call
+            st = cost._run_step(traj.data, traj.start, traj.end, chosen, goal_point, do_update, False)
+            collision_pts = cost._collision_pts_builder(traj.data, st)
         i = st.h("info")[0].copy()
         info = {
             "obs": i[1], "smooth": i[2], "grasp": 0, "weighted_obs": i[3], "weighted_smooth": i[4],
@@ -84,7 +101,7 @@ class Optimizer(object):
             "execute": bool(i[12]), "cost_traj": st.h("cost_traj")[0].copy(), "violate_limit": bool(i[14]),
         }
         from .cost import LazyInfo
-        info = LazyInfo(info, collision_pts=cost._collision_pts_builder(traj.data, st))  # built on first access (viewer only)
+        info = LazyInfo(info, collision_pts=collision_pts)  # built on first access (viewer only)
         info["text"] = self.report(np.asarray(traj.data), info)
         if (info["terminate"] and not force_update) or info_only:
             return info

@@ -84,23 +84,54 @@ class PandaModel:
         ax = np.einsum("lrc,lc->lr", self.tip2joint[:, :3, :3], self.joint_axis)
         og = self.tip2joint[:, :3, 3]
         radius = np.linalg.norm(pts, axis=-1).max(axis=1)  # bounding-sphere radius of each link's centred points
-        ball = np.stack([bounding_ball(pts[l]) for l in range(NUM_LINKS)])  # [10][4]: a small ball around the points themselves
+        key = pts.tobytes()
+        if key not in _BALL_CACHE:
+            if len(_BALL_CACHE) > 64:
+                _BALL_CACHE.clear()
+            _BALL_CACHE[key] = np.stack([bounding_ball(pts[l]) for l in range(NUM_LINKS)])
+        ball = _BALL_CACHE[key]  # [10][4]: a small ball around the points themselves
         out = np.concatenate([np.array(uvw).ravel(), np.array(tp).ravel(), rows(self.pose_0[7]), rows(self.pose_0[8]),
                               rows(self.pose_0[9]), pts.ravel(), ax.ravel(), og.ravel(), radius.ravel(), ball.ravel()])
         assert out.size == 356 + 30 * P
         return out
 
 
+_BALL_CACHE: dict = {}
+
+
 def bounding_ball(points: np.ndarray) -> np.ndarray:
-    """(cx, cy, cz, r): a ball that holds every point, centred near the centre of the smallest one (Badoiu-Clarkson steps
-    from the centroid: deterministic, any centre is valid because r is the largest distance to it, rounded up).  The row-level
-    culling tests this ball instead of the one about the link's frame origin (RAD): with the points 2-10 cm off the origin it
-    is about half as large, and a third of the main loop's far tests never start."""
+    """(cx, cy, cz, r): the smallest ball that holds every point (Welzl's algorithm on the at most 16 points of a link:
+    deterministic — the points are taken in their given order), r rounded up.  The row-level culling tests this ball instead of
+    the one about the link's frame origin (RAD): with the points 2-10 cm off the origin it is about half as large, and a third
+    of the main loop's far tests never start.  Any centre is valid: r is recomputed as the largest
+    distance to it."""
     p = np.asarray(points, np.float64)
-    c = p.mean(axis=0)
-    for k in range(1, 4001):
-        far = p[np.argmax(((p - c) ** 2).sum(axis=1))]
-        c = c + (far - c) / (k + 1.0)
+
+    def ball_of(sup):
+        if len(sup) == 0:
+            return np.zeros(3), -1.0
+        if len(sup) == 1:
+            return sup[0].copy(), 0.0
+        q0 = sup[0]
+        A = np.array([q - q0 for q in sup[1:]])            # the centre lies in q0 + span(A) and is equidistant from the support
+        b = 0.5 * (A * A).sum(axis=1)
+        lam = np.linalg.lstsq(A @ A.T, b, rcond=None)[0]
+        c = q0 + A.T @ lam
+        return c, float(np.sqrt(((sup[0] - c) ** 2).sum()))
+
+    def inside(q, c, r):
+        return r >= 0.0 and ((q - c) ** 2).sum() <= r * r * (1.0 + 1e-12) + 1e-30
+
+    def welzl(n, sup):
+        c, r = ball_of(sup)
+        if len(sup) == 4:
+            return c, r
+        for i in range(n):
+            if not inside(p[i], c, r):
+                c, r = welzl(i, sup + [p[i]])
+        return c, r
+
+    c, _ = welzl(len(p), [])
     r = float(np.sqrt(((p - c) ** 2).sum(axis=1).max())) * (1.0 + 1e-12) + 1e-15
     return np.array([c[0], c[1], c[2], r])
 

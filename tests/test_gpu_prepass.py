@@ -174,3 +174,31 @@ def test_prepass_workspace_is_checked(dev):
     T = ops.pose_table(eng.robot, eng.P, torch.as_tensor(cfgs, device=dev)).cpu().numpy().reshape(31, 10, 12)
     np.testing.assert_allclose(w[0, 3, :, 0:6, :].transpose(2, 0, 1), T[:, :, 0:6], rtol=0, atol=1e-12)
     np.testing.assert_allclose(w[0, 3, :, 6:9, :].transpose(2, 0, 1), T[:, :, 9:12], rtol=0, atol=1e-12)
+
+
+def test_huge_goal_costs_stay_within_the_oracles_bar(dev):
+    """The exact (order-independent) goal sum holds while a goal's cost stays below 2^17 (omg_goalset_queue.h: tsum).  A scene whose
+    volumes hold potentials of thousands pushes the sums far beyond: the batch kernel, the split launch and the oracle must still
+    agree at the tolerances of every other test (the additions then round at 2^-53 relative)."""
+    import bench
+    from omg_planner_amd import ops, scenes as sc
+    from omg_planner_amd.engine import ChompEngine
+    from oracle import oracle as orc
+    cfg, model, batch, start, goals = bench.build_workload(2, 12, 30, 32, 0, False)
+    pool = np.array(batch.pool, np.float32)
+    pool[pool < 0.05] -= 4000.0  # inside / near every object: potentials of ~4e3, goal costs of ~1e6-1e7
+    big = sc.SceneBatch(batch.objects, batch.scene_begin, pool)
+    eng = ChompEngine(model, big, copy.deepcopy(cfg), start, goals, device=dev, ol_alg="MD")
+    ts = eng.traj[:, 0]
+    lay = _nan_like(eng.pot, eng.pgrad, eng.col)
+    c1, _ = ops.goalset_cost_layer(eng.robot, eng.P, eng.scenes, ts, eng.cv_goals, 30, eng.cfg.time_interval, eng.traj, lay)
+    pc = torch.zeros((2, 12 * 4), dtype=torch.float32, device=dev)
+    ops.goalset_cost_layer(eng.robot, eng.P, eng.scenes, ts, eng.cv_goals, 30, eng.cfg.time_interval, eng.traj, lay, out=(pc, torch.zeros_like(pc)), goal_parts=4)
+    torch.cuda.synchronize()
+    tot = pc.reshape(2, 12, 4).sum(-1).cpu().numpy()
+    a = c1.cpu().numpy()
+    assert a.max() > 2.0 ** 17
+    np.testing.assert_allclose(tot, a, rtol=2e-6)
+    for s in range(2):
+        gc, _ = orc.goalset_cost(eng.model.blob(), eng.P, big.subset(s, s + 1), ts[s:s + 1].cpu().numpy(), eng.cv_goals[s:s + 1].cpu().numpy(), 30, eng.cfg.time_interval)
+        np.testing.assert_allclose(a[s], np.asarray(gc).reshape(-1), rtol=1e-5)

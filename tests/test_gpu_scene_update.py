@@ -157,3 +157,117 @@ def test_pool_reserve_and_argument_errors(dev):
     assert l.omgx_region_scratch_bytes(0, 4, 4) == 0 and l.omgx_region_scratch_bytes(4, 4, 4) >= 64
     assert l.omgx_fit_influence_region(None, None, None, None, None, 0.1, 0.0, None, None) == _lib.OMGX_ERR_INVALID
     assert l.omgx_object_set_grid(None, None, None, None, 0.1, 0, None) == _lib.OMGX_ERR_INVALID
+
+
+def test_replacing_a_shared_volume_leaves_the_other_scenes_alone(dev):
+    """scenes.pack_table(share_grids=True) stores identical volumes once: several records point at one grid_offset.  Replacing ONE
+    object's volume must not write into that slot (copy-on-write: the object gets space of its own), must leave every other
+    record and every other scene's costs untouched, and hand a slot nobody uses any more to the next volume that fits it."""
+    import bench
+    from omg_planner_amd import ops, scenes as sc
+    from omg_planner_amd.engine import ChompEngine
+    S, G = 4, 8
+    cfg, model, batch, start, goals = bench.build_workload(S, G, 30, 32, 0, True)  # share_grids=True
+    offs = batch.objects["grid_offset"]
+    shared = [int(o) for o in np.unique(offs) if (offs == o).sum() > 1]
+    assert shared, "the workload must share at least one volume between scenes"
+    ds = ops.DeviceScenes(batch, dev, reserve_voxels=3 * 40 ** 3)
+    eng = ChompEngine(model, ds, copy.deepcopy(cfg), start, goals, device=dev, ol_alg="MD")
+    fresh = eng.snapshot()
+
+    def goal_costs():
+        eng.restore(fresh)
+        eng.t = 0
+        eng.iterate(0)
+        torch.cuda.synchronize()
+        return eng.goal_cost_total().cpu().numpy().copy(), eng.pot.cpu().numpy().copy()
+    before, pot_before = goal_costs()
+    # the object of scene 1 that shares its volume with other scenes gets a new (different) volume of the same shape
+    lo1, hi1 = int(batch.scene_begin[1]), int(batch.scene_begin[2])
+    o = next(k for k in range(lo1, hi1) if int(offs[k]) in shared)
+    users = [k for k in range(len(offs)) if int(offs[k]) == int(offs[o]) and k != o]
+    pool_before = ds.pool[: ds.pool_used].clone()
+    recs_before = ds.sync_host().copy()
+    shape = tuple(int(d) for d in batch.objects["dim"][o])
+    vol = sc.sphere_sdf(0.04, shape, float(batch.objects["delta"][o]))
+    slot = ds.grid_slot(1, o - lo1, shape)
+    assert slot.data_ptr() != ds.pool.data_ptr() + 4 * int(offs[o])   # not the shared slot
+    assert int(ds.host_objects[o]["grid_offset"]) == int(offs[o])        # nothing changes before replace_grid
+    slot.copy_(torch.from_numpy(np.ascontiguousarray(vol.data, np.float32)))
+    ds.replace_grid(1, o - lo1, slot, batch.objects["lo"][o].astype(np.float64), float(batch.objects["delta"][o]))
+    torch.cuda.synchronize()
+    assert torch.equal(ds.pool[: pool_before.numel()], pool_before)      # no byte of the old pool was written
+    recs = ds.sync_host()
+    for k in range(len(recs)):
+        if k != o:
+            assert recs[k].tobytes() == recs_before[k].tobytes(), k      # every other record as it was
+    assert int(recs[o]["grid_offset"]) >= pool_before.numel() and all(int(recs[k]["grid_offset"]) == int(offs[o]) for k in users)
+    after, pot_after = goal_costs()
+    for s in (0, 2, 3):
+        assert np.array_equal(after[s], before[s]) and np.array_equal(pot_after[s], pot_before[s]), s
+    assert not np.array_equal(after[1], before[1])
+    # ... and like an engine packed afresh from what the device holds now
+    hb = ds.host_batch()
+    eng2 = ChompEngine(model, sc.SceneBatch(hb.objects, hb.scene_begin, hb.pool), copy.deepcopy(cfg), start, goals, device=dev, ol_alg="MD")
+    eng2.t = 0
+    eng2.iterate(0)
+    torch.cuda.synchronize()
+    assert np.array_equal(eng2.goal_cost_total().cpu().numpy(), after)
+    # the object's own slot is reused in place from now on; a slot that is outgrown goes to the free list and is taken by the next fit
+    used = ds.pool_used
+    assert ds.grid_slot(1, o - lo1, shape).data_ptr() == slot.data_ptr() and ds.pool_used == used
+    big = tuple(d + 4 for d in shape)
+    s2 = ds.grid_slot(1, o - lo1, big)
+    assert ds.pool_used == used + int(np.prod(big))
+    s2.fill_(0.5)
+    ds.replace_grid(1, o - lo1, s2, np.zeros(3), 0.02, fit="loose")
+    other = next(k for k in range(int(batch.scene_begin[2]), int(batch.scene_begin[3])) if int(offs[k]) in shared)
+    s3 = ds.grid_slot(2, other - int(batch.scene_begin[2]), tuple(int(d) for d in batch.objects["dim"][other]))
+    if int(np.prod(batch.objects["dim"][other])) <= int(np.prod(shape)):
+        assert s3.data_ptr() == slot.data_ptr() and ds.pool_used == used + int(np.prod(big))  # the freed slot, not the reserve
+    # a slot handed out and never committed returns to the free list
+    s4 = ds.grid_slot(2, other - int(batch.scene_begin[2]), tuple(int(d) for d in batch.objects["dim"][other]))
+    assert s4.data_ptr() == s3.data_ptr()
+
+
+@pytest.mark.parametrize("S,share", [(100, False), (12, True)])
+def test_first_build_on_the_device_is_the_host_pack_table(dev, S, share):
+    """DeviceScenes.from_scenes (records on the host, one copy per volume, ALL influence regions fitted by
+    omgx_fit_influence_regions in seven launches) against scenes.pack_table — the specification — at the bench's size: every
+    record field for field, the pool byte for byte; an engine built that way plans like one built from the host table and like
+    the oracle."""
+    from omg_planner_amd import ops, robot as rb, scenes as sc
+    from omg_planner_amd.config import Config
+    from omg_planner_amd.engine import ChompEngine
+    from oracle.check import engine_vs_oracle
+    cfg = Config(timesteps=30, use_standoff=False)
+    scenes = [sc.make_tabletop_scene(s, num_objects=4, grid=64 if S > 50 else 32) for s in range(S)]
+    if not share:
+        for scn in scenes:
+            for ob in scn.objects:
+                ob.sdf = sc.SdfGrid(ob.sdf.data.copy(), ob.sdf.origin, ob.sdf.delta)
+    want = sc.pack_table(scenes, cfg.layer_kwargs(), ragged=True, share_grids=share)
+    tm = {}
+    ds = ops.DeviceScenes.from_scenes(scenes, cfg.layer_kwargs(), dev, share_grids=share, timing=tm)
+    got = ds.sync_host()
+    assert got.shape == want.objects.shape and np.array_equal(ds.host_scene_begin, want.scene_begin)
+    for name in want.objects.dtype.names:
+        assert np.array_equal(got[name], want.objects[name], equal_nan=True), name
+    assert np.array_equal(ds.pool[: ds.pool_used].cpu().numpy(), want.pool)
+    assert tm["total_ms"] > 0 and set(tm) >= {"records_ms", "upload_ms", "fit_ms"}
+    if S > 50:
+        return
+    model = rb.PandaModel(seed=0)
+    start = np.tile(rb.HOME_CONFIG, (S, 1))
+    goals = np.stack([sc.make_reach_goals(scenes[s], model, 8, s) for s in range(S)])
+    a = ChompEngine(model, ds, copy.deepcopy(cfg), start, goals, device=dev, ol_alg="MD")
+    b = ChompEngine(model, want, copy.deepcopy(cfg), start, goals, device=dev, ol_alg="MD")
+    for e in (a, b):
+        e.plan(early_stop=True)
+    torch.cuda.synchronize()
+    for k in ("traj", "info", "goal_idx", "learner_state"):
+        assert torch.equal(getattr(a, k), getattr(b, k)), k
+    c = ChompEngine(model, ds, copy.deepcopy(cfg), start, goals, device=dev, ol_alg="MD")
+    c.select_initial_goal()
+    r = engine_vs_oracle(c, want, [0, S // 2, S - 1], steps=6, pin_window=False)
+    assert r["goal_idx_equal"] and r["max_traj_err"] <= 1e-9 and r["max_cost_rel_err"] <= 1e-5, r
