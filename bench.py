@@ -158,13 +158,19 @@ def cpu_baseline(cfg, model, batch, start, goals, n, budget_s=10.0):
                                 "box; timed in the build container by tools/time_reference_cpu.py: BASELINE.md section 3.1"}
 
 
-def rank_share_config4(dev, ol_alg, steps=100, regions=3):
-    """ms per step of ONE GPU's share of BASELINE config 4 on 8 GPUs (100 scenes x 128 goals -> 13 scenes x 128 goals), laid out
-    by ChompEngine.layout like any rank of that job would be: what the 8-GPU strong-scaling ceiling hangs on (DESIGN.md section 6)."""
+def shape_step_timing(dev, ol_alg, scenes, goals_n, n=30, objects=4, layout_scenes=None, steps=100, regions=3):
+    """ms per step of ANOTHER shape on this GPU, laid out by ChompEngine.layout like a rank that owns it would be, with the roofline
+    block of its own goal-set launches (HIP events on the dispatch, per-launch counts from the profiled workload of that shape:
+    tools/roofline.py).  -> (ms_per_step, layout, roofline block)."""
+    import ctypes as C
     import torch
+    from omg_planner_amd import _lib
     from omg_planner_amd.engine import ChompEngine
-    cfg, model, batch, start, goals = build_workload(13, 128, 30, 64, seed0=0, share_grids=False)
-    eng = ChompEngine.auto(model, batch, copy.deepcopy(cfg), start, goals, layout_scenes=13, device=dev, ol_alg=ol_alg)
+    from tools.roofline import roofline_block
+    cfg, model, batch, start, goals = build_workload(scenes, goals_n, n, 64, seed0=0, share_grids=False, num_objects=objects, device=dev)
+    eng = ChompEngine.auto(model, batch, copy.deepcopy(cfg), start, goals, layout_scenes=scenes if layout_scenes is None else layout_scenes,
+                           device=dev, ol_alg=ol_alg)
+    eng.pose_hand_over(True)
     snap = eng.snapshot()
     count = [0]
 
@@ -177,6 +183,9 @@ def rank_share_config4(dev, ol_alg, steps=100, regions=3):
 
     for _ in range(20):
         step()
+    lib = _lib.lib()
+    parts = 1 if eng.latency else max(1, int(eng.pipeline or 1))
+    lib.omgx_timing_enable(5 if steps * parts >= 25 else 1)
     out = []
     for _ in range(regions):
         eng.join()
@@ -187,7 +196,30 @@ def rank_share_config4(dev, ol_alg, steps=100, regions=3):
         eng.join()
         torch.cuda.synchronize()
         out.append((time.perf_counter() - t0) / steps * 1e3)
-    return sorted(out)[len(out) // 2], dict(eng.layout_used)
+    buf, kinds = (C.c_float * 4096)(), (C.c_int32 * 4096)()
+    nrec = lib.omgx_timing_collect(buf, kinds, 4096)
+    lib.omgx_timing_enable(0)
+    goal_ms = np.array([buf[i] for i in range(nrec) if kinds[i] == 0], dtype=np.float64)
+    ms = sorted(out)[len(out) // 2]
+    P = model.points_per_link
+    alg_bytes = (scenes * goals_n * n * 10 * P + scenes * n * 10 * P) / parts * (32 + 128 * (objects + 1))
+    roof = roofline_block(ROOT / "profiles" / "roofline_inputs.json", float(goal_ms.mean()) if len(goal_ms) else ms, int(len(goal_ms)),
+                          5 if steps * parts >= 25 else 1, alg_bytes,
+                          {"scenes": scenes, "goals": goals_n, "waypoints": n, "points_per_link": P, "grid": 64, "pipeline": parts, "objects": objects + 1},
+                          launches_per_step=parts, ms_per_step=ms)
+    roof.pop("note", None)
+    return ms, dict(eng.layout_used, pipeline=parts), roof
+
+
+def rank_share_config4(dev, ol_alg, steps=100, regions=3):
+    """ms per step of ONE GPU's share of BASELINE config 4 on 8 GPUs (100 scenes x 128 goals -> 13 scenes x 128 goals), laid out
+    by ChompEngine.layout like any rank of that job would be: what the 8-GPU strong-scaling ceiling hangs on (DESIGN.md section 6)."""
+    return shape_step_timing(dev, ol_alg, 13, 128, layout_scenes=13, steps=steps, regions=regions)
+
+
+def config5_shape(dev, ol_alg, steps=100, regions=3):
+    """BASELINE config 5's shape on one GPU: 16 cluttered scenes (12 obstacles + the table), 50 waypoints, 64 goals."""
+    return shape_step_timing(dev, ol_alg, 16, 64, n=50, objects=12, steps=steps, regions=regions)
 
 
 def scene_update_timing(dev, cfg, model, batch, start, goals, ol_alg):
@@ -490,7 +522,7 @@ def main():
     alg_bytes = pts_per_launch * (32 + 128 * O_active)
     from tools.roofline import roofline_block
     roof = roofline_block(ROOT / "profiles" / "roofline_inputs.json", avg_ms, int(len(goal_ms)), stride, alg_bytes,
-                          {"scenes": S, "goals": G, "waypoints": n, "points_per_link": P, "grid": args.grid, "pipeline": parts},
+                          {"scenes": S, "goals": G, "waypoints": n, "points_per_link": P, "grid": args.grid, "pipeline": parts, "objects": O_active},
                           launches_per_step=parts, ms_per_step=elapsed_local / args.steps * 1e3)
     per_rank = None
     if dist_on:
@@ -509,9 +541,10 @@ def main():
         parity = engine_vs_oracle(eng, host_batch(), sorted({0, S // 2, S - 1}), steps=3, pin_window=True)
 
     ms_per_plan = ms_plan_early = ms_single = ms_single_batch_layout = terminated = ms_graph_early = ms_graph_single = None
-    share4 = scene_upd = drop_in = None
+    share4 = scene_upd = drop_in = cfg5 = None
     if not args.no_plan and rank == 0 and world == 1:
         share4 = rank_share_config4(dev, args.ol_alg)
+        cfg5 = config5_shape(dev, args.ol_alg)
         scene_upd = scene_update_timing(dev, cfg, model, host_batch(), start, goals, args.ol_alg)
         drop_in = drop_in_plan_timing(dev, args.ol_alg)
     if not args.no_plan and rank == 0:
@@ -608,6 +641,11 @@ def main():
         if share4 is not None:
             out["ms_per_step_rank_share_config4"] = share4[0]  # 13 scenes x 128 goals on this GPU: one rank's share of BASELINE config 4 on 8 GPUs
             out["rank_share_config4_layout"] = share4[1]
+            out["roofline_rank_share_config4"] = share4[2]  # the same block as `roofline`, for that shape's own goal-set launches
+        if cfg5 is not None:
+            out["ms_per_step_config5_shape"] = cfg5[0]  # 16 scenes x 64 goals, 50 waypoints, 12 obstacles + table (BASELINE config 5's shape)
+            out["config5_shape_layout"] = cfg5[1]
+            out["roofline_config5_shape"] = cfg5[2]
         if scene_upd is not None:
             out["scene_update_ms"] = scene_upd["scene_update_ms"]
             out["scene_update"] = scene_upd

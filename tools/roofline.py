@@ -147,6 +147,38 @@ def derive_inputs(tag: str, profiles: Path = ROOT / "profiles") -> dict:
     return out
 
 
+SHAPE_KEYS = ("goals", "waypoints", "points_per_link", "grid", "objects")  # what a goal workgroup's work depends on
+DEFAULT_OBJECTS = 5  # profiles collected before round 5 do not name it: 4 obstacles + the table
+
+
+def _entries(inp: dict):
+    """All profiled workloads of an inputs file: the primary one (top level) and inp["others"]."""
+    out = [inp] if inp.get("workload") else []
+    return out + list(inp.get("others") or [])
+
+
+def match_inputs(inp: dict, workload: dict):
+    """-> (entry, scale) for the launch `workload` describes, or (None, None).  An entry fits when a goal workgroup does the same
+    work in it — goals per scene, window, points per link, grid, objects per scene — and its per-launch counts are then scaled by
+    the number of scenes a launch handles (scenes / pipeline parts): the counters are sums over workgroups, and a scene's
+    workgroups do not know how many other scenes the launch holds.  scale == 1.0 for the profiled launch itself."""
+    def shape(w):
+        return tuple(w.get(k, DEFAULT_OBJECTS if k == "objects" else None) for k in SHAPE_KEYS)
+
+    def per_launch(w):
+        return float(w.get("scenes", 0)) / max(1, int(w.get("pipeline", 1)))
+    want, n = shape(workload), per_launch(workload)
+    best = None
+    for e in _entries(inp):
+        w = e.get("workload") or {}
+        if shape(w) != want or per_launch(w) <= 0 or n <= 0:
+            continue
+        d = abs(per_launch(w) - n)
+        if best is None or d < best[0]:
+            best = (d, e, n / per_launch(w))
+    return (None, None) if best is None else (best[1], best[2])
+
+
 def roofline_block(inputs_file, avg_launch_ms: float, launches: int, timing_stride: int, algorithmic_bytes: float, workload: dict,
                    launches_per_step: int = 1, ms_per_step: float | None = None) -> dict:
     """The `roofline` object of bench.py's JSON line.
@@ -158,12 +190,18 @@ def roofline_block(inputs_file, avg_launch_ms: float, launches: int, timing_stri
     the kernel's instructions take over the whole timed region, update launches and gaps included.
 
     peak = 1024 SIMDs x 2.4 GHz / (mean issue cycles of THIS kernel's instructions), so that frac = achieved / peak =
-    (issue cycles the instructions occupy) / (SIMD cycles that passed)."""
-    inp = json.loads(Path(inputs_file).read_text()) if Path(inputs_file).exists() else {}
-    same = inp.get("workload") is not None and all(inp["workload"].get(k) == v for k, v in workload.items())
-    valu = inp.get("valu_wave_insts_per_launch") if same else None
-    cycles = inp.get("valu_issue_cycles_per_launch") if same else None
-    hbm = inp.get("hbm_bytes_per_launch") if same else None
+    (issue cycles the instructions occupy) / (SIMD cycles that passed).
+
+    The per-launch COUNTS come from the profiled workload of profiles/roofline_inputs.json that matches (match_inputs): the same
+    work per goal workgroup, scaled to this launch's number of scenes (`counts_scaled`: 1.0 for the profiled launch itself)."""
+    whole = json.loads(Path(inputs_file).read_text()) if Path(inputs_file).exists() else {}
+    inp, scale = match_inputs(whole, workload)
+    same = inp is not None
+    inp = inp or {}
+    k_ = (lambda v: None if v is None else v * scale) if same else (lambda v: None)
+    valu = k_(inp.get("valu_wave_insts_per_launch"))
+    cycles = k_(inp.get("valu_issue_cycles_per_launch"))
+    hbm = k_(inp.get("hbm_bytes_per_launch"))
     useful = inp.get("useful") if same else None
     sec = avg_launch_ms * 1e-3
     chip = launches_per_step > 1
@@ -177,7 +215,7 @@ def roofline_block(inputs_file, avg_launch_ms: float, launches: int, timing_stri
     frac = None if (achieved is None or peak is None) else achieved / peak
     block = {
         "bound": "valu-issue",
-        "kernel": inp.get("kernel", KERNEL),
+        "kernel": whole.get("kernel", KERNEL),
         "achieved": achieved, "peak": peak, "unit": "G wave-instr/s",
         "frac": frac,
         "mean_issue_cycles_per_instr": mean_cycles,
@@ -199,12 +237,14 @@ def roofline_block(inputs_file, avg_launch_ms: float, launches: int, timing_stri
         "algorithmic_equiv_GBs": algorithmic_bytes / sec_eff / 1e9,
         "algorithmic_bytes_per_launch": algorithmic_bytes,
         "from_profiles_tag": inp.get("from_profiles_tag") if same else None,
-        "calibration_tag": inp.get("calibration_tag") if same else None,
+        "counts_scaled": scale if same else None,  # scenes per launch here / in the profiled launch (counts are sums over a scene's workgroups)
+        "profiled_workload": inp.get("workload") if same else None,
+        "calibration_tag": whole.get("calibration_tag") if same else None,
         "note": "bound = VALU instruction issue: peak = 1024 SIMDs x 2.4 GHz / the mean issue cycles of this kernel's own instruction mix "
                 "(SQ_INSTS_VALU_* classes priced by tools/valu_peak.hip: 2 cycles full rate, 4 for f64 / conversions / int64, 8 transcendental; "
                 "uncategorised and int32 at 2: a lower bound, frac errs low); counts per launch from profiles/<from_profiles_tag>_pmc_*.csv via "
                 "tools/roofline.py, durations measured in this run; algorithmic_equiv_GBs (SURVEY 8d: 32 + 128 O bytes per point) is not a "
-                "fraction of anything: the kernel proves most pairs zero in registers" + ("" if same else "; profiles/roofline_inputs.json is for another workload: counts omitted"),
+                "fraction of anything: the kernel proves most pairs zero in registers" + ("" if same else "; profiles/roofline_inputs.json holds no workload with this shape: counts omitted"),
     }
     return block
 
@@ -214,6 +254,7 @@ def main():
     ap.add_argument("--tag", required=True)
     ap.add_argument("--bench", default=None, help="a bench.py JSON line to recompute (default: profiles/<tag>_bench.json)")
     ap.add_argument("--no-write", action="store_true")
+    ap.add_argument("--other", action="store_true", help="add the tag's workload beside the primary one (another shape bench.py times: rank share, config 5, 128 goals)")
     args = ap.parse_args()
     prof = ROOT / "profiles"
     inp = derive_inputs(args.tag, prof)
@@ -221,7 +262,23 @@ def main():
     inputs_path = prof / "roofline_inputs.json"
     if args.no_write:  # recompute an older tag's bench line from that tag's own CSVs without touching the tracked inputs
         inputs_path = Path(tempfile.mkdtemp()) / "roofline_inputs.json"
-    inputs_path.write_text(json.dumps(inp, indent=1) + "\n")
+        inputs_path.write_text(json.dumps(inp, indent=1) + "\n")
+    else:
+        # the tracked file holds ONE primary workload (the bench default: top level) and any number of others (inp["others"]): a tag
+        # replaces the entry with its own workload, wherever that is
+        cur = json.loads(inputs_path.read_text()) if inputs_path.exists() else {}
+        others = [e for e in (cur.get("others") or []) if e.get("workload") != inp.get("workload")]
+        top = {k: v for k, v in cur.items() if k != "others"}
+        if args.other:
+            if top.get("workload") == inp.get("workload"):
+                raise SystemExit("this workload is the primary entry: collect it without --other")
+            others.append(inp)
+            top["others"] = others
+            inputs_path.write_text(json.dumps(top, indent=1) + "\n")
+        else:
+            inp2 = dict(inp)
+            inp2["others"] = others
+            inputs_path.write_text(json.dumps(inp2, indent=1) + "\n")
     print(json.dumps(inp, indent=1))
     bench = Path(args.bench) if args.bench else prof / f"{args.tag}_bench.json"
     if bench.exists():
