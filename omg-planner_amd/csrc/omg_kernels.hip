@@ -562,7 +562,7 @@ __device__ __forceinline__ void waypoint_layer_block(const ChunkArgs& a, const i
 // its first / last wave leaves the main loop, exit — and its hardware id.  Never part of the shipped library.
 #ifdef OMGX_GS_CLOCK
 __device__ unsigned long long g_gs_wg[1 << 16][8];
-// two launches that run at once (tools/gs_two_queue_clock.py) keep their stamps apart when one has an odd number of scenes
+// two launches that run at once (tools/experiments/gs_two_queue_clock.py) keep their stamps apart when one has an odd number of scenes
 #define GS_WG_IDX ((blockIdx.x + (((unsigned)a.S & 1u) << 14)) & 0xffffu)
 #define GS_WG_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < (1u << 16)) { g_gs_wg[GS_WG_IDX][k] = wall_clock64(); if (k == 0) { g_gs_wg[GS_WG_IDX][5] = ~0ull; g_gs_wg[GS_WG_IDX][6] = 0ull; unsigned hw, xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); g_gs_wg[GS_WG_IDX][7] = ((unsigned long long)xcc << 32) | hw; } } } while (0)
 __device__ unsigned long long g_gs_wave[1 << 16][8];  // per wave: [w] when wave w finished its part of the chain / culling stage; [4 + w] when it entered it
@@ -1192,7 +1192,7 @@ __global__ __launch_bounds__(SCH_TPB) void k_goalset_schedule(SchedArgs a) {
     if (a.longest_first) {
         // The XCD of every item as above (whole scenes per XCD, equal work); its place inside the XCD by weight alone — longest first
         // across the XCD's scenes, ties by index.  For launches of a round or two of the chip's workgroup slots, whose span is set by
-        // what starts last (tools/ab_schedule_order.py; with many rounds the scene-major order keeps a scene's volumes in L2 and wins).
+        // what starts last (tools/experiments/ab_schedule_order.py; with many rounds the scene-major order keeps a scene's volumes in L2 and wins).
         for (int i = tid; i < S * G; i += SCH_TPB) {
             const uint32_t w = wl[i];
             if (!w) continue;

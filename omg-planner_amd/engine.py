@@ -64,13 +64,13 @@ class ChompEngine:
     separate_launches = False
     # Under early stop: iterations between rebuilds of the schedule without the terminated scenes (omgx_goalset_schedule, one
     # ~10 us launch); 0: scene-major order once scenes drop out (the kernel then deals the remaining scenes to the XCDs itself).
-    # Measured equal within 1 % for 100 and 13 scenes x 64 goals (tools/ab_plan.py: 12.5 / 6.3 ms per early-stop plan either way), so
+    # Measured equal within 1 % for 100 and 13 scenes x 64 goals (tools/experiments/ab_plan.py: 12.5 / 6.3 ms per early-stop plan either way), so
     # the simpler policy is the default.
     reschedule_every = 0
     schedule_slack = 2  # goal workgroup slots per XCD in units of the even share (see build_schedule)
     # Software pipeline over scene sub-ranges (see _iterate_pipelined): an integer k runs every iterate() as k parts on k HIP
     # streams (1: never); None: plan() pipelines two parts from PIPELINE_MIN_ITEMS (scene, goal) items on — below, the host's
-    # four launches per iteration (~95 us) take longer than the GPU needs (tools/ab_pipeline.py: 8 x 64: 90 -> 96 us,
+    # four launches per iteration (~95 us) take longer than the GPU needs (tools/experiments/ab_pipeline.py: 8 x 64: 90 -> 96 us,
     # 16 x 64: 109 -> 95, 13 x 128: 139 -> 112, 50 x 64: 191 -> 172, 100 x 64: 312 -> 285) — a bare iterate() does not: its
     # caller owns the synchronisation (join()).
     pipeline = None
@@ -84,7 +84,7 @@ class ChompEngine:
     # Up to this many items the measured schedule runs an XCD's items LONGEST FIRST across its scenes (omgx_goalset_schedule_ordered):
     # a launch of a round or two of the chip's 1280 workgroup slots ends with what starts last (13 x 128 in three pipeline parts:
     # 0.0864 -> 0.080 ms per step with the measured scene-major schedule, -> 0.0785 longest first; 100 x 64 longest first: +16 %,
-    # a scene's volumes leave the L2 — tools/ab_schedule_order.py).  The order changes no result: the goal sums are exact.
+    # a scene's volumes leave the L2 — tools/experiments/ab_schedule_order.py).  The order changes no result: the goal sums are exact.
     LONGEST_FIRST_MAX_ITEMS = 2048
 
     @classmethod
@@ -97,7 +97,7 @@ class ChompEngine:
     # ---------------------------------------------------------------------------------------------
     # The size-aware layout: ONE documented rule, a pure function of the shape, so that every rank of a job picks the same one
     # (a goal's cost is a float32 sum whose order depends on goal_parts / latency mode: shards computed under different layouts
-    # would not be bit-comparable).  Measured on MI355X (tools/ab_parts_graph.py, profiles/r04a_layout_sweep.json), ms per step
+    # would not be bit-comparable).  Measured on MI355X (tools/experiments/ab_parts_graph.py, profiles/r04a_layout_sweep.json), ms per step
     # of bench.py's step, best (goal_parts, pipeline parts) against the plain batch layout:
     #   1 x 64   latency mode 0.050          plain 0.065      |   6 x 64   (2, 3) 0.067   plain 0.073
     #   2 x 64   (4, 1) 0.059                plain 0.068      |  10 x 64   (2, 2) 0.070   plain 0.075
@@ -425,7 +425,7 @@ class ChompEngine:
     # into parts (contiguous scene ranges) whose iterations are enqueued alternately on different streams with no dependency
     # between them.  The parts mostly run in step — their goal-set launches at once, ramp-ups and tails overlapping, then their
     # update launches at once (DESIGN.md section 4 item 8 has the kernel trace) — which packs the same work into less time (measured:
-    # 312 -> 285-290 us per iteration of 100 scenes; tools/ab_pipeline.py).  A part is a ChompEngine whose per-scene tensors are
+    # 312 -> 285-290 us per iteration of 100 scenes; tools/experiments/ab_pipeline.py).  A part is a ChompEngine whose per-scene tensors are
     # row views of this engine's — same code, same results bit for bit; its dispatch schedule, work counters and flags are its own.
     def _make_part(self, lo: int, hi: int, stream):
         import copy

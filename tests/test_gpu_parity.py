@@ -1510,8 +1510,12 @@ def test_bench_two_ranks_on_the_config4_share_shape(tmp_path):
     assert [r["rank"] for r in pr] == [0, 1] and [r["scenes"] for r in pr] == [13, 12]
     for r in pr:
         assert set(r) >= {"rank", "scenes", "ms_per_step", "avg_launch_ms", "launches", "achieved", "frac", "hbm_GBs", "algorithmic_equiv_GBs"}
-        # (achieved / frac need the instruction counts of profiles/roofline_inputs.json, which are for the 100 x 64 workload: None here)
         assert r["launches"] > 0 and r["avg_launch_ms"] > 0 and r["ms_per_step"] > 0 and r["algorithmic_equiv_GBs"] > 0
+        # since round 5 profiles/roofline_inputs.json holds the counts of this shape too (13 x 128, three pipeline parts; the shard
+        # of 12 scenes takes them scaled by 12 / 13): every rank's achieved rate and fraction is a number
+        assert r["achieved"] is not None and 0.0 < r["frac"] <= 1.0, r
+    assert j["roofline"]["profiled_workload"]["goals"] == 128 and j["roofline"]["profiled_workload"]["scenes"] == 13
+    assert j["roofline"]["counts_scaled"] == pytest.approx(1.0) and j1["roofline"]["frac"] is not None
     assert "cpu_baseline" not in j  # an N = 1 field
     # the timed regions: `steps` is what was asked for, ms_per_step the median region, the spread beside it
     for line in (j, j1):

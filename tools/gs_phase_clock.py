@@ -38,7 +38,7 @@ def main():
     # per-workgroup timeline of the LAST launch: 100 MHz realtime stamps at entry / after the prologue / at exit + hardware id
     import numpy as np
     nwg = ((S + 7) // 8) * 5 * 8 + max(((S + 7) // 8) * G * 8, 0 if eng.schedule is None else int(eng.schedule.numel()))
-    base = (S & 1) << 14  # the instrumented kernel keeps the stamps of a launch with an odd number of scenes apart (tools/gs_two_queue_clock.py)
+    base = (S & 1) << 14  # the instrumented kernel keeps the stamps of a launch with an odd number of scenes apart (tools/experiments/gs_two_queue_clock.py)
     wg = (C.c_ulonglong * (8 * (base + nwg)))()
     lib.omgx_debug_gs_wg.argtypes = [C.c_void_p, C.c_int]
     assert lib.omgx_debug_gs_wg(wg, base + nwg) == 0

@@ -19,8 +19,13 @@ lines = [l.rstrip() for l in open(log, errors="replace") if l.strip()]
 summary = next((l for l in reversed(lines) if "trials agree" in l), lines[-1] if lines else "")
 m = re.search(r"(\d+)/(\d+) trials agree", summary)
 fails = [l for l in lines if "FAIL" in l]
+classes = {}
+for l in lines:  # "class <name>: <n> trial(s) <json>": trials that agree under a class of their own (diverged in both, free-running feedback)
+    mc = re.match(r"class (\w+): (\d+) trial\(s\) (.*)$", l)
+    if mc:
+        classes[mc.group(1)] = {"trials": int(mc.group(2)), "first": json.loads(mc.group(3))}
 print(json.dumps({"tool": "tests/fuzz/" + tool + ".py", "seed": int(seed), "trials": int(trials), "agree": int(m.group(1)) if m else None,
-                  "failures": len(fails), "first_failures": fails[:3], "summary": summary, "exit_code": int(rc), "seconds": int(secs)}))
+                  "failures": len(fails), "first_failures": fails[:3], "classes": classes, "summary": summary, "exit_code": int(rc), "seconds": int(secs)}))
 PY
   cat $O/${TAG}_$1_seed${SEED}.json
 }
