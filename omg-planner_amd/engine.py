@@ -75,11 +75,13 @@ class ChompEngine:
     # caller owns the synchronisation (join()).
     pipeline = None
     PIPELINE_MIN_ITEMS = 768
-    # Between PIPELINE_MIN_ITEMS and this many items three parts beat two: a part is then a single partial round of workgroups,
-    # the step is bound by the latency of a part's launch chain rather than by the GPU's capacity, and a third chain in flight
-    # fills it (13 x 128: 0.136 / 0.114 / 0.107 ms per step with 1 / 2 / 3 parts, 25 x 64: 0.134 / 0.120 / 0.108; from 35 x 64
-    # on two parts win: 0.142 vs 0.147, 100 x 64: 0.290 vs 0.300).
-    PIPELINE_THREE_BELOW = 2048
+    # Between PIPELINE_MIN_ITEMS and this many items three parts beat two: while one part's update launch (two latency-bound
+    # workgroups per scene) runs, the other TWO parts' goal-set launches keep the chip busy instead of one.  Round 5, after the
+    # goal-set kernel got 8 % shorter and the update's share of a step grew (bench.py --pipeline 2 / 3, ms per step): 35 x 64
+    # 0.1004 / 0.0981, 50 x 64 0.1291 / 0.1228, 100 x 64 0.1945 / 0.1898, 200 x 64 0.3987 / 0.3873, 100 x 128 0.3309 / 0.3324,
+    # 400 x 64 0.8274 / 0.8412 (two parts win again: three launches of 133 scenes lose more to their tails than the idle update
+    # phases cost); four parts at 100 x 64: 0.214.  (Rounds 2-4: three parts only below 2048 items.)
+    PIPELINE_THREE_BELOW = 16384
     MEASURE_MIN_ITEMS = 256   # (scene, goal, part) items from which the second launch's measured durations order the dispatch schedule
     # Up to this many items the measured schedule runs an XCD's items LONGEST FIRST across its scenes (omgx_goalset_schedule_ordered):
     # a launch of a round or two of the chip's 1280 workgroup slots ends with what starts last (13 x 128 in three pipeline parts:
@@ -118,7 +120,7 @@ class ChompEngine:
             gp, pipe = 4, 2
         elif load <= 896:
             gp, pipe = 2, 2
-        elif load < 2048:
+        elif load < cls.PIPELINE_THREE_BELOW:
             gp, pipe = 1, 3
         else:
             gp, pipe = 1, 2

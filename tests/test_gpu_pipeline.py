@@ -67,7 +67,7 @@ def test_pipelined_plan_with_early_stop_equals_the_single_stream_plan(dev):
     make, _ = _engines(dev, 64, 64)
     one, two = make(), make()
     one.pipeline = 1
-    assert two.pipeline is None and two.auto_parts(64, 64) == 2 and two.auto_parts(13, 128) == 3 and two.auto_parts(8, 64) == 1  # plan() decides
+    assert two.pipeline is None and two.auto_parts(64, 64) == 3 and two.auto_parts(400, 64) == 2 and two.auto_parts(13, 128) == 3 and two.auto_parts(8, 64) == 1  # plan() decides
     i1 = one.plan(early_stop=True).cpu().numpy()
     i2 = two.plan(early_stop=True).cpu().numpy()
     assert two._parts is not None and len(two._parts) == 2 and one._parts is None

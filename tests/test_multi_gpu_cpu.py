@@ -106,12 +106,13 @@ def test_gather_costs_rejects_a_shard_of_the_wrong_size():
 
 
 def test_pipeline_parts_by_batch_size():
-    """ChompEngine.auto_parts (host logic, no GPU): no pipeline below 768 (scene, goal) items, three parts up to 2048, two beyond —
+    """ChompEngine.auto_parts (host logic, no GPU): no pipeline below 768 (scene, goal) items, three parts up to 16384, two beyond —
     never more parts than scenes."""
     from omg_planner_amd.engine import ChompEngine
     assert ChompEngine.auto_parts(1, 64) == 1 and ChompEngine.auto_parts(8, 64) == 1 and ChompEngine.auto_parts(11, 64) == 1
     assert ChompEngine.auto_parts(12, 64) == 3 and ChompEngine.auto_parts(13, 128) == 3 and ChompEngine.auto_parts(25, 64) == 3
-    assert ChompEngine.auto_parts(32, 64) == 2 and ChompEngine.auto_parts(100, 64) == 2 and ChompEngine.auto_parts(100, 128) == 2
+    assert ChompEngine.auto_parts(32, 64) == 3 and ChompEngine.auto_parts(100, 64) == 3 and ChompEngine.auto_parts(100, 128) == 3
+    assert ChompEngine.auto_parts(256, 64) == 2 and ChompEngine.auto_parts(400, 64) == 2
     assert ChompEngine.auto_parts(2, 512) == 2 and ChompEngine.auto_parts(1, 1024) == 1  # bounded by the number of scenes
 
 
@@ -126,7 +127,7 @@ def test_layout_rule_is_a_pure_function_of_the_shape():
     assert L(6, 64)["goal_parts"] == 2 and L(14, 64)["goal_parts"] == 2 and L(6, 128)["goal_parts"] == 2
     for shape in ((13, 128), (25, 64), (16, 64), (50, 64), (100, 64), (100, 128), (400, 64)):
         assert L(*shape)["goal_parts"] == 1 and not L(*shape)["latency_mode"], shape
-    assert L(13, 128)["pipeline"] == 3 and L(25, 64)["pipeline"] == 3 and L(100, 64)["pipeline"] == 2 and L(2, 64)["pipeline"] == 2
+    assert L(13, 128)["pipeline"] == 3 and L(25, 64)["pipeline"] == 3 and L(100, 64)["pipeline"] == 3 and L(400, 64)["pipeline"] == 2 and L(2, 64)["pipeline"] == 2
     assert L(16, 12, 50)["goal_parts"] == 4 and L(16, 64, 50)["goal_parts"] == 1  # the load grows with the window
     assert all(L(s, g)["pipeline"] <= s for s in (1, 2, 3) for g in (8, 64, 512))
     assert L(13, 128) == L(13, 128)  # no hidden state
