@@ -70,7 +70,7 @@ def test_pipelined_plan_with_early_stop_equals_the_single_stream_plan(dev):
     assert two.pipeline is None and two.auto_parts(64, 64) == 3 and two.auto_parts(400, 64) == 2 and two.auto_parts(13, 128) == 3 and two.auto_parts(8, 64) == 1  # plan() decides
     i1 = one.plan(early_stop=True).cpu().numpy()
     i2 = two.plan(early_stop=True).cpu().numpy()
-    assert two._parts is not None and len(two._parts) == 2 and one._parts is None
+    assert two._parts is not None and len(two._parts) == 3 and one._parts is None
     assert np.array_equal(i1, i2, equal_nan=True)
     _assert_same(one, two)
     assert int((two.active == 0).sum().item()) > 0, "the workload should let some scenes terminate"
@@ -85,13 +85,15 @@ def test_small_batches_and_bare_iterate_are_not_pipelined(dev):
 
 
 def test_pipelined_bench_workload_matches_oracle(dev):
-    """bench.py's configuration run the way bench.py runs it (two parts) against the oracle on scenes of both parts."""
+    """bench.py's configuration run the way bench.py runs it (three parts since round 5) against the oracle on scenes of every part."""
     from oracle.check import engine_vs_oracle
+    from omg_planner_amd.engine import ChompEngine
     make, batch = _engines(dev, 100, 64, grid=64)
     eng = make()
-    eng.pipeline = 2
+    eng.pipeline = ChompEngine.layout(100, 64)["pipeline"]
+    assert eng.pipeline == 3
     for phase in range(2):
-        r = engine_vs_oracle(eng, batch, [0, 49, 50, 99], steps=3, pin_window=True)
+        r = engine_vs_oracle(eng, batch, [0, 32, 33, 49, 66, 99], steps=3, pin_window=True)
         assert r["goal_idx_equal"], r
         assert r["max_traj_err"] <= 1e-6 and r["max_cost_rel_err"] <= 1e-5, r
 
