@@ -104,6 +104,8 @@ def one_trial(rng, trial, dev, dry=False):
         pipe = int(min(S, r2.choice([2, 2, 3])))
         STATS["pipelined"] = STATS.get("pipelined", 0) + 1
     lat = pipe is None and r2.rand() < 0.33
+    if os.environ.get("OMGX_FUZZ_NO_LATENCY"):  # experiment builds that only carry the batch kernel (tools/experiments/f32kin_check.py)
+        lat = False
     if lat:
         STATS["latency"] = STATS.get("latency", 0) + 1
     # round 4: split goals in the batch layout (goal_parts 2 / 4 / 8, pipelined or not) in a third of the trials that are not in
