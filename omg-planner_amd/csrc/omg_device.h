@@ -587,70 +587,6 @@ __device__ __forceinline__ void link_ball_center(const double* r0, const double*
     cz = (float)(fk_dot3(r20, r21, r22, c0, c1, c2) + t[2]);
 }
 
-// -------------------------------------------------------------------------------------------------
-// EXPERIMENT (make EXTRA=-DOMGX_GS_F32KIN=1; never the shipped build): the goal workgroups' kinematics in
-// float32 — (sin, cos), joint matrices, rotation rows of the chain, the points — with the chain's TRANSLATIONS accumulated in
-// float64 (the one place where float32 loses: a metre-sized sum of centimetre-sized steps).  A pose keeps its 72-byte slot:
-// floats [0, 9) hold the joint matrix and then rotation rows 0 and 1 (6 floats), bytes [48, 72) the translation as 3 doubles.
-// The reference computes these in float64 and narrows the POINTS to float32 (omg/cost.py:218); here the points differ by an
-// ulp or two, so goal costs are no longer the oracle's bits.
-// -------------------------------------------------------------------------------------------------
-template <class RV>
-__device__ __forceinline__ void fk_joint_matrix_f32(const RV& rv, int i, float s, float c, float* __restrict__ B) {
-    const auto uvw = rv.uvw(i);
-#pragma unroll
-    for (int k = 0; k < 9; ++k) B[k] = __builtin_fmaf(s, (float)uvw[9 + k], c * (float)uvw[k]) + (float)uvw[18 + k];
-}
-__device__ __forceinline__ float fk_dot3f(float a0, float a1, float a2, float b0, float b1, float b2) {
-    return __builtin_fmaf(a2, b2, __builtin_fmaf(a1, b1, a0 * b0));
-}
-// the chain for pose row r over the tabulated float matrices (one pose slot = 18 floats apart per link: bstride in floats);
-// f(l, r0, r1, r2, t): rotation row r (floats) and translation entry r (double)
-template <class RV, class F>
-__device__ __forceinline__ void fk_chain_row_B_f32(const RV& rv, int r, const float* Bt, double q7, double q8, F&& f, int bstride) {
-    float a0 = r == 0 ? 1.0f : 0.0f, a1 = r == 1 ? 1.0f : 0.0f, a2 = r == 2 ? 1.0f : 0.0f;
-    double at = 0.0;
-#pragma unroll 1
-    for (int i = 0; i < 7; ++i) {
-        const float* B = Bt + (size_t)bstride * i;
-        const auto tp = rv.tp(i);
-        const float n0 = fk_dot3f(a0, a1, a2, B[0], B[3], B[6]);
-        const float n1 = fk_dot3f(a0, a1, a2, B[1], B[4], B[7]);
-        const float n2 = fk_dot3f(a0, a1, a2, B[2], B[5], B[8]);
-        at = fk_dot3((double)a0, (double)a1, (double)a2, tp[0], tp[1], tp[2]) + at;
-        a0 = n0; a1 = n1; a2 = n2;
-        f(i, a0, a1, a2, at);
-    }
-    const auto H = rv.hand();
-    const float h0 = fk_dot3f(a0, a1, a2, (float)H[0], (float)H[4], (float)H[8]), h1 = fk_dot3f(a0, a1, a2, (float)H[1], (float)H[5], (float)H[9]),
-                h2 = fk_dot3f(a0, a1, a2, (float)H[2], (float)H[6], (float)H[10]);
-    const double ht = fk_dot3((double)a0, (double)a1, (double)a2, H[3], H[7], H[11]) + at;
-    f(7, h0, h1, h2, ht);
-    const auto Lf = rv.lf();
-    f(8, fk_dot3f(h0, h1, h2, (float)Lf[0], (float)Lf[4], (float)Lf[8]), fk_dot3f(h0, h1, h2, (float)Lf[1], (float)Lf[5], (float)Lf[9]),
-      fk_dot3f(h0, h1, h2, (float)Lf[2], (float)Lf[6], (float)Lf[10]),
-      fk_dot3((double)h0, (double)h1, (double)h2, Lf[3], Lf[7] + deg_round_trip(q7), Lf[11]) + ht);
-    const auto Rf = rv.rf();
-    f(9, fk_dot3f(h0, h1, h2, (float)Rf[0], (float)Rf[4], (float)Rf[8]), fk_dot3f(h0, h1, h2, (float)Rf[1], (float)Rf[5], (float)Rf[9]),
-      fk_dot3f(h0, h1, h2, (float)Rf[2], (float)Rf[6], (float)Rf[10]),
-      fk_dot3((double)h0, (double)h1, (double)h2, Rf[3], Rf[7] - deg_round_trip(q8), Rf[11]) + ht);
-}
-// x = R p + t from a float32 pose slot (rows 0, 1 as floats, third row their cross product, translation as doubles): the rotation
-// part in float32, the sum with the translation in float64, rounded once
-__device__ __forceinline__ void pose9f_apply(const double* slot, const float* __restrict__ p, float& x, float& y, float& z) {
-    const float* A = reinterpret_cast<const float*>(slot);
-    const double* t = slot + 6;
-    const float r20 = __builtin_fmaf(A[1], A[5], -(A[2] * A[4])), r21 = __builtin_fmaf(A[2], A[3], -(A[0] * A[5])), r22 = __builtin_fmaf(A[0], A[4], -(A[1] * A[3]));
-    x = (float)((double)fk_dot3f(A[0], A[1], A[2], p[0], p[1], p[2]) + t[0]);
-    y = (float)((double)fk_dot3f(A[3], A[4], A[5], p[0], p[1], p[2]) + t[1]);
-    z = (float)((double)fk_dot3f(r20, r21, r22, p[0], p[1], p[2]) + t[2]);
-}
-template <class BP>
-__device__ __forceinline__ void link_ball_center_f32(const double* slot, BP b, float& cx, float& cy, float& cz) {
-    const float c[3] = {(float)b[0], (float)b[1], (float)b[2]};
-    pose9f_apply(slot, c, cx, cy, cz);
-}
-
 // np.argmin / np.argmax order: does (v, i) beat (bv, bi)?  The first occurrence wins, and a NaN counts as the extreme
 // for BOTH (numpy propagates NaN: np.argmax([1, nan, 3]) == np.argmin([1, nan, 0]) == 1) — a degenerate cost vector
 // (0/0 after normalisation) therefore selects index 0 like the reference instead of leaving the index undefined.

@@ -239,11 +239,7 @@ __global__ __launch_bounds__(LAT ? 256 : GQ_NT, LAT ? 2 : GQ_WG_PER_CU) void k_g
         const double* A = lds_pose + 9 + ((int64_t)l * pstride + ci) * 9;
         const auto bl = rv.ball(l);  // the ball around the link's own points (robot blob BALL), not the one about its frame origin
         float cx, cy, cz;
-#ifdef OMGX_GS_F32KIN
-        link_ball_center_f32(A, bl, cx, cy, cz);
-#else
         link_ball_center(A, A + 3, A + 6, bl, cx, cy, cz);
-#endif
         const float rad = (float)bl[3] + 1.0e-4f;
         uint32_t m = 0;
         for (int o = o_begin; o < o_end; ++o) {
@@ -360,27 +356,14 @@ __global__ __launch_bounds__(LAT ? 256 : GQ_NT, LAT ? 2 : GQ_WG_PER_CU) void k_g
                 asm volatile("" : : "v"(sn), "v"(cs));
             }
 #endif
-#ifdef OMGX_GS_F32KIN
-            {
-                float sf, cf;
-                __sincosf((float)deg_round_trip(joint(cfg, i)), &sf, &cf);
-                sn = (double)sf; cs = (double)cf;
-            }
-#else
             fk_joint_sincos(joint(cfg, i), sn, cs);
-#endif
             sc[2 * t] = sn; sc[2 * t + 1] = cs;
         }
         if (LAT && tid < 246) fkc[tid] = fkv;
         __syncthreads();
         GS_WG_STAMP(1);
-#ifdef OMGX_GS_F32KIN
-        if (tid < 30 * P) reinterpret_cast<float*>(pts)[tid] = (float)pv0;
-        if (tid + 256 < 30 * P) reinterpret_cast<float*>(pts)[tid + 256] = (float)pv1;
-#else
         if (tid < 30 * P) pts[tid] = pv0;
         if (tid + 256 < 30 * P) pts[tid + 256] = pv1;
-#endif
         // ---- exact-path records of the scene's first a.tbl_n objects -> LDS, by lanes of wave 2 (idle during the chain stage)
         if (tbl_lane) {
             if (!LAT) trec = gq_tbl_load(a.objects + o_begin + (tid - 128));
@@ -415,27 +398,6 @@ __global__ __launch_bounds__(LAT ? 256 : GQ_NT, LAT ? 2 : GQ_WG_PER_CU) void k_g
                 });
             }
         } else if constexpr (BTAB) {
-#ifdef OMGX_GS_F32KIN
-            for (int j = wave; j < 7; j += 4)
-                for (int cfg = lane; cfg < ncfg; cfg += 64)
-                    fk_joint_matrix_f32(rv, j, (float)sc[2 * (cfg * 7 + j)], (float)sc[2 * (cfg * 7 + j) + 1],
-                                        reinterpret_cast<float*>(lds_pose + ((size_t)j * pstride + cfg) * 9));
-            __syncthreads();
-            GS_WAVE_STAMP(4 + wave);
-            if (wave < chain_waves && lane < 63) {
-                const int cfg = 21 * wave + lane / 3, rr = lane - 3 * (lane / 3);
-                if (cfg < ncfg)
-                    fk_chain_row_B_f32(rv, rr, reinterpret_cast<const float*>(lds_pose + (size_t)cfg * 9), joint(cfg, 7), joint(cfg, 8),
-                                       [&](int l, float r0, float r1, float r2, double tr) {
-                        double* dst = lds_pose + ((size_t)l * pstride + cfg) * 9;
-                        float* rf = reinterpret_cast<float*>(dst);
-                        if (rr < 2) { rf[3 * rr] = r0; rf[3 * rr + 1] = r1; rf[3 * rr + 2] = r2; }
-                        dst[6 + rr] = tr;
-                        if (lane == 0) __hip_atomic_store(progress + wave, l + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }, pstride * 18);
-                GS_WAVE_STAMP(6 + wave);
-            }
-#else
             for (int j = wave; j < 7; j += 4)  // wave-uniform joint: U, V, W of the joint are scalar operands
                 for (int cfg = lane; cfg < ncfg; cfg += 64)
                     fk_joint_matrix(rv, j, sc[2 * (cfg * 7 + j)], sc[2 * (cfg * 7 + j) + 1], lds_pose + ((size_t)j * pstride + cfg) * 9);
@@ -452,7 +414,6 @@ __global__ __launch_bounds__(LAT ? 256 : GQ_NT, LAT ? 2 : GQ_WG_PER_CU) void k_g
                     }, pstride * 9);
                 GS_WAVE_STAMP(6 + wave);  // (instrumented build: when this chain wave finished the chain; overwrites the entry stamps of waves 2, 3)
             }
-#endif
         } else run_chain(rv);                                          // constants through the scalar cache (warm in a batch)
         if (cull_beside_chain) {
             // The rows of a link PAIR fit one wave (CH <= 32: lanes 0-31 link l, lanes 32-63 link l + 1).  The five pairs are claimed
@@ -699,11 +660,7 @@ __global__ __launch_bounds__(LAT ? 256 : GQ_NT, LAT ? 2 : GQ_WG_PER_CU) void k_g
             for (int k = 0; k < LB; ++k) {
                 px[k] = py[k] = pz[k] = 0.0f;
                 if (__any(msk[k] != 0))  // a link none of whose four rows reaches anything needs no points (its far tests are skipped too)
-#ifdef OMGX_GS_F32KIN
-                    pose9f_apply((base + (l0 + k) * h_ps * 9) + cic9, (reinterpret_cast<const float*>(pts) + 3 * (l0 + k) * h_P) + pc3, px[k], py[k], pz[k]);
-#else
                     pose9_apply((base + (l0 + k) * h_ps * 9) + cic9, (pts + 3 * (l0 + k) * h_P) + pc3, px[k], py[k], pz[k]);
-#endif
             }
             for (int o = h_ob; o < h_oe; ++o) {
                 const int oo = o - h_ob;
@@ -750,11 +707,7 @@ __global__ __launch_bounds__(LAT ? 256 : GQ_NT, LAT ? 2 : GQ_WG_PER_CU) void k_g
                         const int l = l0 + k;
                         float qx, qy, qz;
                         // the previous configuration's pose: cfg ci - 1 of the same link, i.e. one 72-byte record back (ci = 0: the start, record 0)
-#ifdef OMGX_GS_F32KIN
-                        pose9f_apply((lds_pose + l * h_ps * 9) + cic9, (reinterpret_cast<const float*>(pts) + 3 * l * h_P) + pc3, qx, qy, qz);
-#else
                         pose9_apply((lds_pose + l * h_ps * 9) + cic9, (pts + 3 * l * h_P) + pc3, qx, qy, qz);
-#endif
                         const float vx = (px[k] - qx) * h_idt, vy = (py[k] - qy) * h_idt, vz = (pz[k] - qz) * h_idt;
                         w[k] = sqrtf(vx * vx + vy * vy + vz * vz);
                         wdone[k] = true;
