@@ -270,7 +270,7 @@ def scene_update_timing(dev, cfg, model, batch, start, goals, ol_alg):
             "same_change_through_the_host_ms": host_ms, "replan_equals_fresh_engine": same}
 
 
-def drop_in_plan_timing(dev, ol_alg="MD", reps=3):
+def drop_in_plan_timing(dev, ol_alg="MD", reps=5):
     """ms per plan through the DROP-IN classes (Trajectory / Cost / Learner / Optimizer) on bench scene 0 — the loop of
     Planner.plan (omg/planner.py:612-653) as the reference writes it: update_goal, a look at traj.goal_idx, optimize(force_update),
     a copy of traj.data, a look at info["terminate"]; 50 + 20 iterations (no early exit, like the other plan timings) and the
@@ -307,6 +307,8 @@ def drop_in_plan_timing(dev, ol_alg="MD", reps=3):
         traj.interpolate_waypoints()
         learner = Learner(env, traj, cost)
         optim = Optimizer(types.SimpleNamespace(config=cfg, robot=robot), cost)
+        import gc
+        gc.collect()  # (the previous pass's garbage is not this pass's time)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         infos, history, selected = [], [np.copy(traj.data)], []

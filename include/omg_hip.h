@@ -580,6 +580,9 @@ int omgx_timing_collect(float* h_ms, int32_t* h_kind, int32_t cap);
 int omgx_abi_version(void);        /* bumps when a signature or struct layout changes              */
 int omgx_device_arch(char* h_buf, int32_t h_len); /* writes gcnArchName of the current device      */
 int32_t omgx_device_cu_count(void);               /* compute units of the current device (< 0: error)  */
+/* h_dst (pinned host memory) <- nbytes from device memory `src`, ordered behind everything enqueued on `stream`, and wait for it:
+ * hipMemcpyAsync + hipStreamSynchronize in one call (the closing step of a planner iteration through the drop-in classes). */
+int omgx_download_sync(void* h_dst, const void* src, int64_t nbytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -22,7 +22,7 @@ ABI_VERSION = 10  # omgx_abi_version() of the library these argtypes describe
 # every symbol include/omg_hip.h declares
 EXPORTS = ["omgx_sdf_loss_forward", "omgx_fk_sdf_workspace_bytes", "omgx_fk_sdf", "omgx_forward_kinematics", "omgx_pose_table",
            "omgx_goalset_workspace_bytes", "omgx_goalset_cost", "omgx_goalset_cost_layer", "omgx_goalset_parts", "omgx_goalset_cost_layer_tiled", "omgx_goalset_cost_layer_parts", "omgx_goalset_schedule_len", "omgx_goalset_schedule", "omgx_goalset_schedule_parts", "omgx_goalset_schedule_ordered", "omgx_region_scratch_bytes", "omgx_object_set_grid", "omgx_fit_influence_region", "omgx_regions_scratch_bytes", "omgx_fit_influence_regions", "omgx_volume_hashes", "omgx_chomp_aux_doubles", "omgx_chomp_optimize",
-           "omgx_learner_state_doubles", "omgx_goal_update", "omgx_goal_update_optimize", "omgx_point_cloud_sdf", "omgx_last_error", "omgx_abi_version", "omgx_device_arch", "omgx_device_cu_count",
+           "omgx_learner_state_doubles", "omgx_goal_update", "omgx_goal_update_optimize", "omgx_point_cloud_sdf", "omgx_last_error", "omgx_abi_version", "omgx_device_arch", "omgx_device_cu_count", "omgx_download_sync",
            "omgx_timing_enable", "omgx_timing_collect"]
 
 
@@ -122,6 +122,8 @@ def lib() -> C.CDLL:
         l.omgx_last_error.restype = C.c_char_p
         l.omgx_device_arch.argtypes = [C.c_char_p, i32]
         l.omgx_device_cu_count.restype = i32
+        l.omgx_download_sync.argtypes = [vp, vp, i64, vp]
+        l.omgx_download_sync.restype = C.c_int
         l.omgx_timing_enable.argtypes = [i32]
         l.omgx_timing_collect.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_int32), i32]
         for name in ("omgx_sdf_loss_forward", "omgx_fk_sdf", "omgx_forward_kinematics", "omgx_pose_table", "omgx_goalset_cost", "omgx_chomp_optimize",

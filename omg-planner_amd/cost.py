@@ -236,13 +236,13 @@ class Cost(object):
         self._scenes_cache = (key, weakref.ref(env.sdf_torch), ds, weakref.ref(lim_t))
         return ds
 
-    def _params(self, n: int, do_update: int) -> _lib.ChompParams:
+    def _params(self, n: int, do_update: int, P: "int | None" = None) -> _lib.ChompParams:
         """omgx_chomp_params of the moment.  The fields that change from call to call (the optimiser's schedule, do_update) are
         written every time; everything else is kept while cfg says the same (a tuple comparison instead of ~40 attribute
         writes through ctypes: 10 us of a 90 us planner iteration)."""
         cfg = self.cfg
         lsw = cfg.link_smooth_weight
-        key = (n, self._robot_model()[0].points_per_link, cfg.top_k_collision, cfg.consider_finger, cfg.goal_set_proj, cfg.use_standoff,
+        key = (n, self._robot_model()[0].points_per_link if P is None else P, cfg.top_k_collision, cfg.consider_finger, cfg.goal_set_proj, cfg.use_standoff,
                cfg.reach_tail_length, cfg.uncheck_finger_collision, cfg.joint_limit_max_steps, cfg.allow_collision_point, cfg.pre_terminate,
                cfg.time_interval, cfg.clip_grad_scale, cfg.terminate_smooth_loss, lsw if isinstance(lsw, (int, float)) else tuple(np.ravel(lsw)))
         cached = self.__dict__.get("_params_cache")

@@ -678,6 +678,18 @@ static void timing_events(int kind, hipEvent_t* ev0, hipEvent_t* ev1) {
     ++g_timing_n;
 }
 extern "C" int omgx_abi_version(void) { return 10; }  // 10: kinematics pre-pass (k_goalset_kin) behind the `workspace` argument of omgx_goalset_cost / _cost_layer, new trailing `workspace` of _cost_layer_parts / _cost_layer_tiled; 9: omgx_goalset_schedule_ordered (longest first inside an XCD); 8: omgx_goalset_cost_layer_parts, omgx_goalset_schedule_parts (a goal's tiles over several workgroups of the batch kernel); 2: `active` masks; 3: ragged goal sets (goal_count, eta); 4: goal schedule + work; 5: 184-byte object records (influence region = rounded box); 6: omgx_goalset_cost_layer_tiled, omgx_learner_params.cost_parts; 7: pose tables (omgx_pose_table, pointer fields at the end of both parameter blocks, layer_poses)
+// One call for "copy these bytes back and wait": hipMemcpyAsync (device -> pinned host) + hipStreamSynchronize on the caller's stream
+// — the last step of a planner iteration through the drop-in classes (device_loop.DeviceLoop), where two framework calls cost the
+// host more than the copy itself.
+extern "C" int omgx_download_sync(void* h_dst, const void* src, int64_t nbytes, void* stream) {
+    if (nbytes < 0 || (nbytes > 0 && (!h_dst || !src))) return OMGX_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = nbytes > 0 ? hipMemcpyAsync(h_dst, src, (size_t)nbytes, hipMemcpyDeviceToHost, st) : hipSuccess;
+    if (e != hipSuccess) return omgx_set_error("hipMemcpyAsync", e);
+    e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return omgx_set_error("hipStreamSynchronize", e);
+    return OMGX_OK;
+}
 extern "C" int32_t omgx_device_cu_count(void) {  // compute units of the current device (a plain attribute query: no property table)
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess) return -1;

@@ -208,7 +208,7 @@ class DeviceLoop:
             self._h[name] = hnp[o: o + nb].view(ndt).reshape(shape)
         self._out_lo = self._slots["traj"][0]
         self._goal_lo = self._slots["end"][0]
-        self._xfer = {lo: (self.host[lo:], self.dev[lo:]) for lo in (self._out_lo, self._goal_lo)}  # the two downloads' views, made once
+        self._h_ptr, self._d_ptr, self._dl = self.host.data_ptr(), self.dev.data_ptr(), _lib.lib().omgx_download_sync
         self.state = ops.learner_state(1, G, dev)
         parts_max = ops.goalset_parts(n, self.LAT_TILING[0])
         self.gcost = torch.zeros((1, G * parts_max), dtype=torch.float32, device=dev)
@@ -304,9 +304,7 @@ class DeviceLoop:
                 setattr(self, attr, b)
 
     def _download(self, lo):
-        h, d = self._xfer[lo]
-        h.copy_(d, non_blocking=True)
-        torch.cuda.current_stream(self.device).synchronize()
+        _lib.check(self._dl(self._h_ptr + lo, self._d_ptr + lo, self.nbytes - lo, self._stream()), "omgx_download_sync")
 
     def _take_goal(self):
         """After a download that covers the goal block: the mirrors follow what the learner wrote on the device."""

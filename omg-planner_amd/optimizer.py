@@ -80,7 +80,7 @@ class Optimizer(object):
             else:
                 rows = lambda: np.tile(np.asarray(traj.end, np.float64), (cost._params(n, 0).constraint_num, 1))
                 point = lambda: np.asarray(traj.end, np.float64)
-            st = loop.optimize(traj, cost._params(n, do_update), rows, point)
+            st = loop.optimize(traj, cost._params(n, do_update, loop.P), rows, point)  # (loop.matches has just checked the robot's points)
             collision_pts = cost._collision_pts_recompute(traj.data)
         else:
             if cfg.goal_set_proj:
