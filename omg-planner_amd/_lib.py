@@ -67,6 +67,12 @@ def lib() -> C.CDLL:
         if not LIB_PATH.exists():
             raise OmgHipError(f"{LIB_PATH} is missing: build it with `make -C {_CSRC}` "
                               "(or __graft_entry__.build()); there is no CPU fallback")
+        try:
+            # torch first: its HIP runtime must be the one in the process before this library binds to it (loaded the other way
+            # round — build() followed by smoke() in one process — the two runtimes disagree and no device is found)
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         l = C.CDLL(str(LIB_PATH))
         vp, i32, i64, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_double
         l.omgx_sdf_loss_forward.argtypes = [vp] * 8 + [i64, i32] + [vp] * 3 + [vp]
