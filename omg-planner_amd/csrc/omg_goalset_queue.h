@@ -45,8 +45,13 @@
 struct GqFar {  // what the far test of one object needs (wave-uniform, SGPRs)
     float T[12], lo[3], rc[3], rh[3], rr2;
     bool cullable;
+    int disabled;
 };
 
+// EVERY field in one trip through the scalar cache: the loads are issued back to back and nothing is looked at before all of them
+// have landed (the empty asm ties them together).  Written naturally — `disabled` first, then `eps < 1 && clr <= 1`, then the rest —
+// the compiler makes three to four DEPENDENT trips of it per (tile, object) iteration, ~100 cycles each on the main loop's critical
+// path; a disabled object is rare and its record costs nothing.
 __device__ __forceinline__ GqFar gq_load_far(ObjTablePtr ob) {
     GqFar f;
 #pragma unroll
@@ -54,16 +59,21 @@ __device__ __forceinline__ GqFar gq_load_far(ObjTablePtr ob) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) { f.lo[k] = ob->lo[k]; f.rc[k] = ob->rb_c[k]; f.rh[k] = ob->rb_h[k]; }
     f.rr2 = ob->rb_r2;
-    f.cullable = ob->epsilon < 1.0f && ob->clearance <= 1.0f;  // else an out-of-range lookup (value 1.0) still adds something
+    float eps = ob->epsilon, clr = ob->clearance;
+    int dis = ob->disabled;
+    asm volatile("" : "+s"(dis), "+s"(eps), "+s"(clr) : "s"(f.T[0]), "s"(f.T[4]), "s"(f.T[8]), "s"(f.lo[0]), "s"(f.rc[0]), "s"(f.rh[0]), "s"(f.rr2));
+    f.cullable = (eps < 1.0f) & (clr <= 1.0f);  // else an out-of-range lookup (value 1.0) still adds something
+    f.disabled = dis;
     return f;
 }
 
 // dynamic LDS behind the poses (bytes, all 16-byte aligned): row masks | exact-path records | collision points | staging
 struct GqLayout {
-    int mask_off, tbl_off, pts_off, stage_off, fkc_off, objc_off, btab_off, total;
+    int mask_off, tile_off, tbl_off, pts_off, stage_off, fkc_off, objc_off, btab_off, total;
     __host__ __device__ GqLayout(int PS, int MR, int P, int tbl_n, bool with_fkc = false) {
         mask_off = PS * 90 * 8;
-        tbl_off = mask_off + ((10 * MR * 4 + 15) & ~15);
+        tile_off = mask_off + 10 * MR * 4;  // 3 words behind the row masks: bit (block * 5 + link pair) = the tile has a row in reach of something
+        tbl_off = mask_off + ((10 * MR * 4 + 16 + 15) & ~15);
         pts_off = tbl_off + tbl_n * 64;
         stage_off = pts_off + ((10 * P * 3 * 8 + 15) & ~15);
         total = stage_off + GQ_WAVES * 64 * 16;
@@ -213,6 +223,7 @@ __global__ __launch_bounds__(LAT ? 256 : GQ_NT, LAT ? 2 : GQ_WG_PER_CU) void k_g
     const GqLayout L(pstride, MR, P, a.tbl_n, LAT);
     char* const lds_bytes = reinterpret_cast<char*>(lds_pose);
     uint32_t* const rowmask = reinterpret_cast<uint32_t*>(lds_bytes + L.mask_off);
+    uint32_t* const tilebits = reinterpret_cast<uint32_t*>(lds_bytes + L.tile_off);  // goal workgroups: which tiles have anything in reach
     if (is_layer) {
         const int lgi = a.layer_nb > 1 ? layer_part / a.layer_nb : layer_part, cbi = layer_part - lgi * a.layer_nb;
         const int lpg = 10 / a.layer_lg, c_begin = cbi * a.layer_cb;
@@ -256,7 +267,15 @@ __global__ __launch_bounds__(LAT ? 256 : GQ_NT, LAT ? 2 : GQ_WG_PER_CU) void k_g
             if (near || !cullable) m |= bit;
         }
         rowmask[l * CH + ci] = m;
+        return m;
     };
+    // TILE BITS (round 5): 28 of a goal's 40 tiles have no row in reach of anything, and finding that out in the main loop costs two
+    // mask reads, an OR and a vote per tile.  The culling leaves one bit per tile instead — bit 4 * block + (pair & 3) of word pair >> 2,
+    // behind the masks — and an empty tile is a scalar bit test.  Only where the tiles are dealt plainly and a link pair's rows fit one
+    // pass (batch kernel, whole goals, own kinematics, window <= 32: eight blocks); elsewhere every bit is set.
+    constexpr bool TILEBITS = !LAT && !SPLIT && !PRE && LB == 2;
+    const bool tb_on = TILEBITS && CH <= 32;
+    if (tid < 4) tilebits[tid] = tb_on ? 0u : 0xffffffffu;  // (ordered before the culling by the barrier behind the (sin, cos) stage)
     // The chain stage of the kinematics keeps ceil(3 (CH + 1) / 64) waves busy (one lane per (configuration, pose row)) and
     // produces the links' poses in order; the other waves cull the rows of a link as soon as every chain wave has published
     // it (a progress word per chain wave in LDS, release / acquire at workgroup scope): the culling stage disappears behind
@@ -437,7 +456,15 @@ __global__ __launch_bounds__(LAT ? 256 : GQ_NT, LAT ? 2 : GQ_WG_PER_CU) void k_g
                     if (done > need) break;
                     __builtin_amdgcn_s_sleep(4);
                 }
-                if ((lane & 31) < CH) cull_row(l + (lane >> 5), lane & 31);
+                uint32_t m = 0u;
+                if ((lane & 31) < CH) m = cull_row(l + (lane >> 5), lane & 31);
+                if constexpr (TILEBITS) {  // (cull_beside_chain implies CH <= 32: tb_on)
+                    const unsigned long long bal = __ballot(m != 0u);
+                    unsigned long long x = (unsigned long long)((uint32_t)bal | (uint32_t)(bal >> 32)) << blk_shift;  // per configuration, either link; blocks of 4 from bit 0
+                    x |= x >> 1; x |= x >> 2; x &= 0x111111111ull;  // bit 4 b: block b has a row in reach
+                    const uint32_t w = (uint32_t)x << (pr & 3);
+                    if (lane == 0 && w) __hip_atomic_fetch_or(tilebits + (pr >> 2), w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
             }
         }
         GS_WAVE_STAMP(wave);
@@ -460,7 +487,12 @@ __global__ __launch_bounds__(LAT ? 256 : GQ_NT, LAT ? 2 : GQ_WG_PER_CU) void k_g
             if (t >= 0 && ci >= 0 && ci < CH) cull_row(l, ci);
         }
     } else if (!cull_beside_chain) {
-        for (int row = tid; row < 10 * CH; row += 256) cull_row(row / CH, row - (row / CH) * CH);
+        for (int row = tid; row < 10 * CH; row += 256) {
+            const int l = row / CH, ci = row - l * CH;
+            const uint32_t m = cull_row(l, ci);
+            if (tb_on && m != 0u)  // (chain on more than two waves with a short window)
+                __hip_atomic_fetch_or(tilebits + (l >> 3), 1u << (4 * ((ci + blk_shift) >> 2) + ((l >> 1) & 3)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
         __syncthreads();
     }
     GS_WG_STAMP(3);
@@ -634,9 +666,18 @@ __global__ __launch_bounds__(LAT ? 256 : GQ_NT, LAT ? 2 : GQ_WG_PER_CU) void k_g
     const int pc3 = 3 * (p < h_P ? p : 0);  // lane part of a collision-point address (doubles)
     GS_COUNT(0);
     constexpr bool PARTS = LAT || SPLIT;  // this workgroup holds one part of a goal's tiles: the wave's q-th tile is lat_tile(q)
+    uint32_t tb0 = 0xffffffffu, tb1 = 0xffffffffu;
+    if constexpr (TILEBITS) {
+        tb0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)tilebits[0]);
+        tb1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)tilebits[1]);
+    }
 #pragma unroll 1
     for (int q = 0, t = PARTS ? lat_tile(0) : wave; PARTS ? t >= 0 : t < ntiles; t = PARTS ? lat_tile(++q) : t + GQ_WAVES) {  // every lane stays active: invalid items are flagged, not skipped
         const int rb = t / (10 / LB), l0 = (t - rb * (10 / LB)) * LB;
+        if constexpr (TILEBITS) {  // nothing in reach of any row of this tile: a scalar test (bits all set when the window is longer than 32)
+            const int pr = l0 >> 1;
+            if (!(((pr < 4 ? tb0 : tb1) >> ((4 * rb + (pr & 3)) & 31)) & 1u)) continue;
+        }
         GS_COUNT(1);
         {
             const int ci = rb * 4 + (lane >> 4) - blk_shift;
@@ -668,9 +709,9 @@ __global__ __launch_bounds__(LAT ? 256 : GQ_NT, LAT ? 2 : GQ_WG_PER_CU) void k_g
                 GS_COUNT(10);
                 if (!__any((many & bit) != 0)) continue;
                 ObjTablePtr ob = as_const(h_objects) + o;
-                if (ob->disabled > 0) continue;  // .cu:115-116
-                GS_COUNT(3);
                 const GqFar fp = gq_load_far(ob);
+                if (fp.disabled > 0) continue;  // .cu:115-116
+                GS_COUNT(3);
                 const bool queued = oo < h_tbl;  // objects beyond the LDS records (rare) are evaluated on the spot
 #ifdef OMGX_GS_COUNT  // what tiles of 2 waypoints x 2 links would do here (verdict round 3, item 2 i): far tests and enqueue calls per half wave
                 if (LB == 2) {
@@ -717,7 +758,10 @@ __global__ __launch_bounds__(LAT ? 256 : GQ_NT, LAT ? 2 : GQ_WG_PER_CU) void k_g
                         GS_COUNT(7);
                         enqueue(live, tx, ty, tz, w[k], (uint32_t)oo | (soft << 16));
                     } else if (live) {
-                        const ObjParams op = load_object(ob);
+                        ObjParams op = load_object(ob);
+                        // (an object beyond the LDS records is rare: keep what only this branch needs — 0.5 * (double)eps of the hinge —
+                        // from being hoisted into every (tile, object) iteration: two half-rate instructions each)
+                        asm volatile("" : "+s"(op.eps));
                         Accum one{0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
                         pair_exact<false>(op, h_pool + ob->grid_offset, tx, ty, tz, one);
                         if (soft) { one.pot *= 0.1f; one.col = 0.0f; }

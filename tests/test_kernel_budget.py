@@ -46,7 +46,7 @@ def test_goalset_kernel_lds_fits_five_workgroups_per_cu():
 
     def total(PS, MR, P, n):
         mask_off = PS * 90 * 8
-        tbl_off = mask_off + ((10 * MR * 4 + 15) & ~15)
+        tbl_off = mask_off + ((10 * MR * 4 + 16 + 15) & ~15)  # row masks + the tile bits
         pts_off = tbl_off + n * 64
         stage_off = pts_off + ((10 * P * 3 * 8 + 15) & ~15)
         return max(stage_off + 4 * 64 * 16, PS * 90 * 8 + PS * 14 * 8)
