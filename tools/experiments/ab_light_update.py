@@ -28,7 +28,7 @@ def main():
     a = ap.parse_args()
     from omg_planner_amd.engine import ChompEngine
     dev = torch.device("cuda:0")
-    spin = ctypes.CDLL(str(ROOT / "tools" / "spin_update.so"))
+    spin = ctypes.CDLL(str(ROOT / "tools" / "experiments" / "spin_update.so"))
     spin.spin_launch.argtypes = [ctypes.c_int] * 5 + [ctypes.c_void_p]
     cfg, model, batch, start, goals = bench.build_workload(a.scenes, a.goals, 30, 64, 0, False)
     cuts = [a.scenes * k // a.parts for k in range(a.parts + 1)]
