@@ -961,6 +961,62 @@ def test_drop_in_classes_reproduce_reference_planner_loop(dev, case):
     assert abs(learner.p.sum() - 1.0) < 1e-7 and learner.t == min(len(history), cfg.optim_steps)  # Exp normalises with safe_div (+1e-8)
 
 
+@pytest.mark.parametrize("case", ["md_switch_70", "exp_standoff_41"])
+def test_drop_in_loop_gives_the_same_bits_however_it_is_driven(dev, case, monkeypatch):
+    """device_loop.DeviceLoop (round 5): the planner loop through the drop-in classes (a) as omg/planner.py drives it — the goal index
+    stored unread, the learner's update riding on optimize()'s fused launches —, (b) with the goal index READ right after
+    update_goal() — the update then runs on its own and optimize() only steps —, (c) with Learner.DEFER_UPDATE = False, and (d) with
+    host-side edits between the calls (traj.data replaced by an equal copy, the learner's distribution read every iteration): the
+    same goals, the same trajectories bit for bit, the same info records; the learner's host attributes agree at the end."""
+    from omg_planner_amd.config import Config
+    from omg_planner_amd.cost import Cost
+    from omg_planner_amd.device_loop import LazyIndex
+    from omg_planner_amd.online_learner import Learner
+    from omg_planner_amd.optimizer import Optimizer
+    from omg_planner_amd.trajectory import Trajectory
+    import types
+    fx = H.load(f"plan_{case}.npz")
+    standoff = bool(int(fx["cfg_use_standoff"]))
+    iters = int(fx["iterations"])
+    runs = {}
+    for mode in ("planner", "read_at_once", "no_defer", "edits"):
+        monkeypatch.setattr(Learner, "DEFER_UPDATE", mode != "no_defer")
+        cfg = Config(timesteps=30, use_standoff=standoff, ol_alg=str(fx["alg"]))
+        env = _env_from(fx, dev, cfg)
+        env.objects[env.target_idx].reach_grasps = fx["reach_grasps"]
+        traj = Trajectory(cfg=cfg)
+        traj.start, traj.goal_set, traj.end = fx["start"].copy(), fx["goal_set"], fx["goal_set"][0].copy()
+        traj.interpolate_waypoints()
+        cost = Cost(env)
+        learner = Learner(env, traj, cost)
+        optim = Optimizer(types.SimpleNamespace(config=cfg, robot=env.robot), cost)
+        goals, history, infos, lazy = [], [], [], 0
+        for t in range(iters):
+            if t < cfg.optim_steps:
+                changed = learner.update_goal()
+                lazy += isinstance(traj.goal_idx, LazyIndex) and not traj.goal_idx.resolved()
+                if mode == "read_at_once":
+                    assert int(traj.goal_idx) == int(fx["selected_goals"][t]) and isinstance(bool(changed), bool)
+                if mode == "edits":
+                    assert abs(float(np.sum(learner.p)) - 1.0) < 1e-6  # reading the distribution applies the update
+                    traj.data = np.array(traj.data)                    # an equal copy: noticed, nothing to upload
+                goals.append(traj.goal_idx)
+            infos.append(optim.optimize(traj, force_update=True))
+            history.append(np.copy(traj.data))
+        infos.append(optim.optimize(traj, info_only=True))
+        assert (lazy == min(iters, cfg.optim_steps)) == (mode in ("planner", "read_at_once", "edits")), (mode, lazy)
+        runs[mode] = ([int(g) for g in goals], np.stack(history), np.array([[i["cost"], i["obs"], i["smooth"], i["grad"], float(i["terminate"])] for i in infos]),
+                      np.array(learner.p), np.array(traj.end, np.float64))
+    ref = runs["planner"]
+    assert ref[0] == [int(g) for g in fx["selected_goals"][: len(ref[0])]]
+    np.testing.assert_allclose(ref[1], fx["history"][:iters], rtol=0, atol=1e-6)
+    for mode in ("read_at_once", "no_defer", "edits"):
+        got = runs[mode]
+        assert got[0] == ref[0], mode
+        for a, b in zip(got[1:], ref[1:]):
+            assert np.array_equal(a, b), mode
+
+
 @pytest.mark.parametrize("mode", ["fused", "serial"])
 def test_inactive_scenes_are_left_alone(dev, mode, monkeypatch):
     """Once a scene terminates the reference leaves its loop (omg/planner.py:626): no goal-set batch, no goal update, no
