@@ -255,16 +255,19 @@ __global__ __launch_bounds__(LAT ? 256 : GQ_NT, LAT ? 2 : GQ_WG_PER_CU) void k_g
         uint32_t m = 0;
         for (int o = o_begin; o < o_end; ++o) {
             ObjTablePtr ob = as_const(a.objects) + o;
-            if (ob->disabled > 0) continue;
+            // the record in ONE trip through the scalar cache (gq_load_far: written field by field the compiler waits for `disabled`,
+            // then for epsilon / clearance, then for the rest — two to three dependent trips per object and pass on the prologue's tail)
+            const GqFar f = gq_load_far(ob);
+            float rbr = ob->rb_r;
+            asm volatile("" : "+s"(rbr) : "s"(f.rr2));
+            if (f.disabled > 0) continue;
             const int oo = o - o_begin;
             const uint32_t bit = 1u << (oo < 31 ? oo : 31);
-            const float ux = __builtin_fmaf(ob->pose_inv[2], cz, __builtin_fmaf(ob->pose_inv[1], cy, __builtin_fmaf(ob->pose_inv[0], cx, ob->pose_inv[3]))) - ob->lo[0];
-            const float uy = __builtin_fmaf(ob->pose_inv[6], cz, __builtin_fmaf(ob->pose_inv[5], cy, __builtin_fmaf(ob->pose_inv[4], cx, ob->pose_inv[7]))) - ob->lo[1];
-            const float uz = __builtin_fmaf(ob->pose_inv[10], cz, __builtin_fmaf(ob->pose_inv[9], cy, __builtin_fmaf(ob->pose_inv[8], cx, ob->pose_inv[11]))) - ob->lo[2];
-            const float rbc[3] = {ob->rb_c[0], ob->rb_c[1], ob->rb_c[2]}, rbh[3] = {ob->rb_h[0], ob->rb_h[1], ob->rb_h[2]};
-            const bool near = rbox_near(ux, uy, uz, rad, rbc, rbh, ob->rb_r);
-            const bool cullable = ob->epsilon < 1.0f && ob->clearance <= 1.0f;
-            if (near || !cullable) m |= bit;
+            const float ux = __builtin_fmaf(f.T[2], cz, __builtin_fmaf(f.T[1], cy, __builtin_fmaf(f.T[0], cx, f.T[3]))) - f.lo[0];
+            const float uy = __builtin_fmaf(f.T[6], cz, __builtin_fmaf(f.T[5], cy, __builtin_fmaf(f.T[4], cx, f.T[7]))) - f.lo[1];
+            const float uz = __builtin_fmaf(f.T[10], cz, __builtin_fmaf(f.T[9], cy, __builtin_fmaf(f.T[8], cx, f.T[11]))) - f.lo[2];
+            const bool near = rbox_near(ux, uy, uz, rad, f.rc, f.rh, rbr);
+            if (near || !f.cullable) m |= bit;
         }
         rowmask[l * CH + ci] = m;
         return m;
