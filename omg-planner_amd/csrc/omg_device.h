@@ -281,6 +281,10 @@ __device__ __forceinline__ void sdf_pair(const ObjParams& o, const float* __rest
 #define OMG_CONST_AS __attribute__((address_space(4)))
 typedef const OMG_CONST_AS omgx_object* ObjTablePtr;
 typedef const OMG_CONST_AS int32_t* IntTablePtr;
+#define OMG_GLOBAL_AS __attribute__((address_space(1)))
+typedef const OMG_GLOBAL_AS char* GlobalBytes;  // a pointer the compiler must treat as global memory (global_load, vmcnt only), whatever it went through
+typedef float F2v __attribute__((ext_vector_type(2), aligned(4)));
+__device__ __forceinline__ F2 global_f2(GlobalBytes p) { const F2v v = *(const OMG_GLOBAL_AS F2v*)p; return F2{v.x, v.y}; }
 __device__ __forceinline__ ObjTablePtr as_const(const omgx_object* p) { return (ObjTablePtr)(uintptr_t)p; }
 __device__ __forceinline__ IntTablePtr as_const(const int32_t* p) { return (IntTablePtr)(uintptr_t)p; }
 

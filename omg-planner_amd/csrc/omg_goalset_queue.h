@@ -43,29 +43,58 @@
 #define GQ_NT (64 * GQ_WAVES)
 
 struct GqFar {  // what the far test of one object needs (wave-uniform, SGPRs)
-    float T[12], lo[3], rc[3], rh[3], rr2;
+    float T[12], lo[3], rc[3], rh[3], rr2, rb_r;
     bool cullable;
     int disabled;
 };
 
-// EVERY field in one trip through the scalar cache: the loads are issued back to back and nothing is looked at before all of them
-// have landed (the empty asm ties them together).  Written naturally — `disabled` first, then `eps < 1 && clr <= 1`, then the rest —
-// the compiler makes three to four DEPENDENT trips of it per (tile, object) iteration, ~100 cycles each on the main loop's critical
-// path; a disabled object is rare and its record costs nothing.
+// EVERY field in ONE trip through the scalar cache, by three wide loads (the record's dwords 0-15, 22-25, 34-41) and one wait.
+// Written field by field the compiler issues nine loads and — whatever ties them together in the source — waits two or three
+// times for them (it sinks the fields the `disabled` test does not need behind that test): 50-140 cycles per trip on the
+// critical path of every (tile, object) iteration, and the scalar unit's issue slots are as scarce as the vector unit's in this
+// kernel (tools/issue_probe.hip: a scalar instruction occupies its SIMD for 4.4 cycles, a float32 VALU instruction for 2).
+// `cullable` — epsilon < 1 and clearance <= 1, else a lookup outside the volume (value 1.0) still adds something — is decided on
+// the bit patterns: for floats that are not NaN the signed integer order of the patterns is the float order on one side of zero,
+// and a negative value (sign bit) is below 1.0 either way; a NaN with its sign bit set would read "cullable", where the hinge
+// terms are NaN-free zeros anyway.  No vector compare, no wait for a VALU result on the scalar unit.
+typedef uint32_t GqU16 __attribute__((ext_vector_type(16)));
+typedef uint32_t GqU8 __attribute__((ext_vector_type(8)));
+typedef uint32_t GqU4 __attribute__((ext_vector_type(4)));
+static_assert(offsetof(omgx_object, pose_inv) == 0 && offsetof(omgx_object, lo) == 0x30 && offsetof(omgx_object, epsilon) == 0x58 &&
+              offsetof(omgx_object, clearance) == 0x60 && offsetof(omgx_object, disabled) == 0x64 && offsetof(omgx_object, rb_c) == 0x88 &&
+              offsetof(omgx_object, rb_h) == 0x94 && offsetof(omgx_object, rb_r) == 0xa0 && offsetof(omgx_object, rb_r2) == 0xa4 &&
+              sizeof(omgx_object) >= 0xa8, "gq_load_far reads the record by byte offsets");
 __device__ __forceinline__ GqFar gq_load_far(ObjTablePtr ob) {
+    GqU16 a;
+    GqU4 b;
+    GqU8 c;
+    asm volatile("s_load_dwordx16 %0, %3, 0x0\n\ts_load_dwordx4 %1, %3, 0x58\n\ts_load_dwordx8 %2, %3, 0x88\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(a), "=&s"(b), "=&s"(c) : "s"((uint64_t)(uintptr_t)ob));
     GqFar f;
 #pragma unroll
-    for (int k = 0; k < 12; ++k) f.T[k] = ob->pose_inv[k];
+    for (int k = 0; k < 12; ++k) f.T[k] = __uint_as_float(a[k]);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { f.lo[k] = ob->lo[k]; f.rc[k] = ob->rb_c[k]; f.rh[k] = ob->rb_h[k]; }
-    f.rr2 = ob->rb_r2;
-    float eps = ob->epsilon, clr = ob->clearance;
-    int dis = ob->disabled;
-    asm volatile("" : "+s"(dis), "+s"(eps), "+s"(clr) : "s"(f.T[0]), "s"(f.T[4]), "s"(f.T[8]), "s"(f.lo[0]), "s"(f.rc[0]), "s"(f.rh[0]), "s"(f.rr2));
-    f.cullable = (eps < 1.0f) & (clr <= 1.0f);  // else an out-of-range lookup (value 1.0) still adds something
-    f.disabled = dis;
+    for (int k = 0; k < 3; ++k) { f.lo[k] = __uint_as_float(a[12 + k]); f.rc[k] = __uint_as_float(c[k]); f.rh[k] = __uint_as_float(c[3 + k]); }
+    f.rb_r = __uint_as_float(c[6]);
+    f.rr2 = __uint_as_float(c[7]);
+    f.cullable = ((int32_t)b[0] < 0x3f800000) & ((int32_t)b[2] <= 0x3f800000);
+    f.disabled = (int32_t)b[3];
     return f;
 }
+// u = T (x, y, z, 1) with the rows of T in SGPRs (SE3(pose) * point, .cu:125-133: fma(T2, z, fma(T1, y, fma(T0, x, T3))) per row) as
+// nine v_fma_f32 in ONE asm statement, the three rows' chains interleaved.  Left to itself the compiler packs two rows into
+// v_pk_fma_f32 and pays two s_mov per packed operand to bring their coefficients side by side — six scalar instructions per far test,
+// and a scalar instruction occupies the SIMD for longer than a float32 multiply-add (tools/issue_probe.hip).
+__device__ __forceinline__ void se3_apply_s(const float* T, float x, float y, float z, float& ux, float& uy, float& uz) {
+    ux = T[3]; uy = T[7]; uz = T[11];
+    asm("v_fma_f32 %0, %3, %12, %0\n\tv_fma_f32 %1, %6, %12, %1\n\tv_fma_f32 %2, %9, %12, %2\n\t"
+        "v_fma_f32 %0, %4, %13, %0\n\tv_fma_f32 %1, %7, %13, %1\n\tv_fma_f32 %2, %10, %13, %2\n\t"
+        "v_fma_f32 %0, %5, %14, %0\n\tv_fma_f32 %1, %8, %14, %1\n\tv_fma_f32 %2, %11, %14, %2"
+        : "+v"(ux), "+v"(uy), "+v"(uz)
+        : "s"(T[0]), "s"(T[1]), "s"(T[2]), "s"(T[4]), "s"(T[5]), "s"(T[6]), "s"(T[8]), "s"(T[9]), "s"(T[10]), "v"(x), "v"(y), "v"(z));
+}
+// votes as scalar tests of the lane mask itself (HIP's __any goes through an int per lane: a select and a second compare)
+__device__ __forceinline__ unsigned long long wave_ballot(bool b) { return __builtin_amdgcn_ballot_w64(b); }
 
 // dynamic LDS behind the poses (bytes, all 16-byte aligned): row masks | exact-path records | collision points | staging
 struct GqLayout {
@@ -142,6 +171,9 @@ template <int LB, bool STAMP = false, bool LAT = false, bool SPLIT = false, bool
 __global__ __launch_bounds__(LAT ? 256 : GQ_NT, LAT ? 2 : GQ_WG_PER_CU) void k_goalset_queue(ChunkArgs a) {  // LAT: a workgroup per CU or two, registers are free
     extern __shared__ __attribute__((aligned(16))) double lds_pose[];  // no static LDS: 31744 B is the most a workgroup may use at 5 per CU
     GS_WG_STAMP(0);
+#ifdef OMGX_GS_PRIO
+    __builtin_amdgcn_s_setprio(OMGX_GS_PRIO);
+#endif
     const int xcd = blockIdx.x & 7;
     // with a trajectory layer, a.layer_parts workgroups per scene compute it (a.layer_lg link groups x a.layer_nb blocks of a.layer_cb
     // configurations: 5 x 1 in a batch, finer in latency mode); those lead the grid
@@ -258,15 +290,12 @@ __global__ __launch_bounds__(LAT ? 256 : GQ_NT, LAT ? 2 : GQ_WG_PER_CU) void k_g
             // the record in ONE trip through the scalar cache (gq_load_far: written field by field the compiler waits for `disabled`,
             // then for epsilon / clearance, then for the rest — two to three dependent trips per object and pass on the prologue's tail)
             const GqFar f = gq_load_far(ob);
-            float rbr = ob->rb_r;
-            asm volatile("" : "+s"(rbr) : "s"(f.rr2));
             if (f.disabled > 0) continue;
             const int oo = o - o_begin;
             const uint32_t bit = 1u << (oo < 31 ? oo : 31);
-            const float ux = __builtin_fmaf(f.T[2], cz, __builtin_fmaf(f.T[1], cy, __builtin_fmaf(f.T[0], cx, f.T[3]))) - f.lo[0];
-            const float uy = __builtin_fmaf(f.T[6], cz, __builtin_fmaf(f.T[5], cy, __builtin_fmaf(f.T[4], cx, f.T[7]))) - f.lo[1];
-            const float uz = __builtin_fmaf(f.T[10], cz, __builtin_fmaf(f.T[9], cy, __builtin_fmaf(f.T[8], cx, f.T[11]))) - f.lo[2];
-            const bool near = rbox_near(ux, uy, uz, rad, f.rc, f.rh, rbr);
+            float ux, uy, uz;
+            se3_apply_s(f.T, cx, cy, cz, ux, uy, uz);
+            const bool near = rbox_near(ux - f.lo[0], uy - f.lo[1], uz - f.lo[2], rad, f.rc, f.rh, f.rb_r);
             if (near || !f.cullable) m |= bit;
         }
         rowmask[l * CH + ci] = m;
@@ -278,7 +307,7 @@ __global__ __launch_bounds__(LAT ? 256 : GQ_NT, LAT ? 2 : GQ_WG_PER_CU) void k_g
     // pass (batch kernel, whole goals, own kinematics, window <= 32: eight blocks); elsewhere every bit is set.
     constexpr bool TILEBITS = !LAT && !SPLIT && !PRE && LB == 2;
     const bool tb_on = TILEBITS && CH <= 32;
-    if (tid < 4) tilebits[tid] = tb_on ? 0u : 0xffffffffu;  // (ordered before the culling by the barrier behind the (sin, cos) stage)
+    if (tid < 4) tilebits[tid] = (tb_on || tid >= 2) ? 0u : 0xffffffffu;  // (ordered before the culling by the barrier behind the (sin, cos) stage; word 2: the main loop's tile counter)
     // The chain stage of the kinematics keeps ceil(3 (CH + 1) / 64) waves busy (one lane per (configuration, pose row)) and
     // produces the links' poses in order; the other waves cull the rows of a link as soon as every chain wave has published
     // it (a progress word per chain wave in LDS, release / acquire at workgroup scope): the culling stage disappears behind
@@ -499,6 +528,9 @@ __global__ __launch_bounds__(LAT ? 256 : GQ_NT, LAT ? 2 : GQ_WG_PER_CU) void k_g
         __syncthreads();
     }
     GS_WG_STAMP(3);
+#ifdef OMGX_GS_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
 
     // The main loop's wave-uniform inputs as copies of their own (an empty asm the compiler cannot see through): the kernel's
     // arguments arrive as 4- and 8-dword tuples of neighbouring fields, and a tuple that stays live for ONE field is spilled and
@@ -616,12 +648,15 @@ __global__ __launch_bounds__(LAT ? 256 : GQ_NT, LAT ? 2 : GQ_WG_PER_CU) void k_g
 #else
         const uint32_t b = in_c ? (uint32_t)((ix * dy + iy) * dz + iz) : 0u;
 #endif
-        const char* g0 = reinterpret_cast<const char*>(h_pool) + goffb + (uint64_t)b * 4u;
+        // GLOBAL address space, said out loud: h_pool went through an asm copy, behind which the compiler no longer knows where it
+        // points and falls back to flat_load — which counts on lgkmcnt as well as vmcnt, so the next far test's wait for its scalar
+        // loads (or any LDS read) would wait for these gathers too and the queue would hide nothing
+        const GlobalBytes g0 = (GlobalBytes)(uintptr_t)h_pool + goffb + (uint64_t)b * 4u;
         const uint32_t syb = (uint32_t)dz * 4u, sxb = (uint32_t)(dy * dz) * 4u;
-        f_r00 = *reinterpret_cast<const F2*>(g0);
-        f_r01 = *reinterpret_cast<const F2*>(g0 + syb);
-        f_r10 = *reinterpret_cast<const F2*>(g0 + sxb);
-        f_r11 = *reinterpret_cast<const F2*>(g0 + sxb + syb);
+        f_r00 = global_f2(g0);
+        f_r01 = global_f2(g0 + syb);
+        f_r10 = global_f2(g0 + sxb);
+        f_r11 = global_f2(g0 + sxb + syb);
         f_fx = fx; f_fy = fy; f_fz = fz;
         f_w = valid ? q_w : 0.0f;
         f_meta = (q_meta & 0x1ffffu) | (in_c ? 1u << 30 : 0u) | ((valid && !(q_meta & 0x10000u)) ? 1u << 31 : 0u);
@@ -635,8 +670,7 @@ __global__ __launch_bounds__(LAT ? 256 : GQ_NT, LAT ? 2 : GQ_WG_PER_CU) void k_g
     // ones, a write and nothing else — a wave's LDS operations execute in program order, so the ISSUE that reads the slots
     // needs no round trip through registers.  A full ring is issued (after the batch in flight has been consumed) and the
     // entries that did not fit start the next one.
-    auto enqueue = [&](bool live, float tx, float ty, float tz, float w, uint32_t oo_soft) {
-        const unsigned long long bal = __ballot(live);
+    auto enqueue = [&](bool live, unsigned long long bal, float tx, float ty, float tz, float w, uint32_t oo_soft) {  // bal = wave_ballot(live)
         const int n = __popcll(bal);
         const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
         const int room = 64 - pending;
@@ -669,18 +703,52 @@ __global__ __launch_bounds__(LAT ? 256 : GQ_NT, LAT ? 2 : GQ_WG_PER_CU) void k_g
     const int pc3 = 3 * (p < h_P ? p : 0);  // lane part of a collision-point address (doubles)
     GS_COUNT(0);
     constexpr bool PARTS = LAT || SPLIT;  // this workgroup holds one part of a goal's tiles: the wave's q-th tile is lat_tile(q)
-    uint32_t tb0 = 0xffffffffu, tb1 = 0xffffffffu;
-    if constexpr (TILEBITS) {
-        tb0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)tilebits[0]);
-        tb1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)tilebits[1]);
+    // WHO TAKES WHICH TILE (round 5, batch kernel with whole goals): the waves draw from ONE list — the goal's non-empty tiles, goal
+    // end and hand links first — through a counter in LDS.  Dealt statically ((block, pair) -> wave (5 block + pair) % 4) the first
+    // wave left the main loop 10.1 us after the prologue and the last 14.7 us (tools/gs_phase_clock.py): a third of the loop's span
+    // was three waves waiting for the fourth, with the workgroup's LDS and registers held.  The exact path's work per tile cannot be
+    // predicted from the masks (measured: a split by mask hits was 7 % worse than round-robin), so the waves balance themselves.
+    // Nothing depends on who computes what: the goal's sum is exact (tsum), the counts are integers.
+    // The list: lane i of EVERY wave holds the i-th tile of the order (each wave builds its own copy in its ring, which the queue
+    // does not use before the first enqueue; a wave's LDS operations run in program order), a draw is one LDS atomic.
+    constexpr bool DYN = !PARTS;
+    int my_tile = -1, n_list = 0;
+    uint32_t* const tile_counter = tilebits + 2;
+    if constexpr (DYN) {
+        if (ntiles <= 64) {
+            const int t = ntiles - 1 - lane;
+            bool ne = t >= 0;
+            if constexpr (TILEBITS) {  // bits all set when the window is longer than 32
+                const int rb = (t < 0 ? 0 : t) / (10 / LB), pr = (t < 0 ? 0 : t) - rb * (10 / LB);
+                const uint32_t wsel = tilebits[pr >> 2];
+                ne = ne && ((wsel >> ((4 * rb + (pr & 3)) & 31)) & 1u);
+            }
+            const unsigned long long bal = wave_ballot(ne);
+            const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+            int* const lst = reinterpret_cast<int*>(stage);
+            if (ne) lst[rank] = t;
+            n_list = __popcll(bal);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            my_tile = lane < n_list ? lst[lane] : -1;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();  // the list has been read: the ring is the queue's from here on
+        } else n_list = ntiles;
     }
+    int q_static = 0;
+    auto next_tile = [&]() -> int {
+        if constexpr (DYN) {
+            int q = 0;
+            if (lane == 0) q = (int)__hip_atomic_fetch_add(tile_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            q = __builtin_amdgcn_readfirstlane(q);
+            if (q >= n_list) return -1;
+            return ntiles <= 64 ? __builtin_amdgcn_readlane(my_tile, q) : ntiles - 1 - q;
+        } else return lat_tile(q_static++);
+    };
 #pragma unroll 1
-    for (int q = 0, t = PARTS ? lat_tile(0) : wave; PARTS ? t >= 0 : t < ntiles; t = PARTS ? lat_tile(++q) : t + GQ_WAVES) {  // every lane stays active: invalid items are flagged, not skipped
+    for (int t = next_tile(); t >= 0; t = next_tile()) {  // every lane stays active: invalid items are flagged, not skipped
         const int rb = t / (10 / LB), l0 = (t - rb * (10 / LB)) * LB;
-        if constexpr (TILEBITS) {  // nothing in reach of any row of this tile: a scalar test (bits all set when the window is longer than 32)
-            const int pr = l0 >> 1;
-            if (!(((pr < 4 ? tb0 : tb1) >> ((4 * rb + (pr & 3)) & 31)) & 1u)) continue;
-        }
         GS_COUNT(1);
         {
             const int ci = rb * 4 + (lane >> 4) - blk_shift;
@@ -688,29 +756,36 @@ __global__ __launch_bounds__(LAT ? 256 : GQ_NT, LAT ? 2 : GQ_WG_PER_CU) void k_g
             const int cic = valid ? ci : 0;
             const int cic9 = cic * 9;  // lane part of a pose address (doubles); base = configuration 1, lds_pose = configuration 0
             float px[LB], py[LB], pz[LB], w[LB];
-            uint32_t msk[LB];
+            uint32_t msk[LB], sm[LB];
             bool wdone[LB];
-            uint32_t many = 0;
+            uint32_t s_any = 0;
+            // sm[k]: the OR of the four rows' masks of link k as a SCALAR (the rows sit in lanes 0, 16, 32, 48; lanes without a row hold
+            // 0), so that "does any row of this tile / of this link reach object o" is a scalar bit test.  As votes (`__any((msk & bit)
+            // != 0)`) these tests cost a v_cmp, a trip of its result to the scalar unit and a branch on it — 37 cycles of the wave's
+            // time each (tools/issue_probe.hip), three per (tile, object) iteration — and visited every object of the scene.
 #pragma unroll
             for (int k = 0; k < LB; ++k) {
                 msk[k] = valid ? (rowmask + (l0 + k) * h_CH)[cic] : 0u;  // uniform part of every address on the scalar unit
-                many |= msk[k];
+                sm[k] = (uint32_t)__builtin_amdgcn_readlane((int)msk[k], 0) | (uint32_t)__builtin_amdgcn_readlane((int)msk[k], 16) |
+                        (uint32_t)__builtin_amdgcn_readlane((int)msk[k], 32) | (uint32_t)__builtin_amdgcn_readlane((int)msk[k], 48);
+                s_any |= sm[k];
                 wdone[k] = false;
                 w[k] = 0.0f;
             }
-            if (!__any(many != 0)) continue;  // nothing in reach of any row of this tile
+            if (s_any == 0) continue;  // nothing in reach of any row of this tile
             GS_COUNT(2);
 #pragma unroll
             for (int k = 0; k < LB; ++k) {
                 px[k] = py[k] = pz[k] = 0.0f;
-                if (__any(msk[k] != 0))  // a link none of whose four rows reaches anything needs no points (its far tests are skipped too)
+                if (sm[k] != 0)  // a link none of whose four rows reaches anything needs no points (its far tests are skipped too)
                     pose9_apply((base + (l0 + k) * h_ps * 9) + cic9, (pts + 3 * (l0 + k) * h_P) + pc3, px[k], py[k], pz[k]);
             }
             for (int o = h_ob; o < h_oe; ++o) {
                 const int oo = o - h_ob;
-                const uint32_t bit = 1u << (oo < 31 ? oo : 31);
+                const int sh = oo < 31 ? oo : 31;
+                const uint32_t bit = 1u << sh;
                 GS_COUNT(10);
-                if (!__any((many & bit) != 0)) continue;
+                if (!((s_any >> sh) & 1u)) continue;
                 ObjTablePtr ob = as_const(h_objects) + o;
                 const GqFar fp = gq_load_far(ob);
                 if (fp.disabled > 0) continue;  // .cu:115-116
@@ -734,18 +809,39 @@ __global__ __launch_bounds__(LAT ? 256 : GQ_NT, LAT ? 2 : GQ_WG_PER_CU) void k_g
 #endif
 #pragma unroll
                 for (int k = 0; k < LB; ++k) {
-                    if (!__any((msk[k] & bit) != 0)) continue;  // none of this link's four rows reaches the object
+                    if (!((sm[k] >> sh) & 1u)) continue;  // none of this link's four rows reaches the object
                     // SE3(pose) * point (.cu:125-133) and the far test of pair_prepare
-                    const float ux = __builtin_fmaf(fp.T[2], pz[k], __builtin_fmaf(fp.T[1], py[k], __builtin_fmaf(fp.T[0], px[k], fp.T[3])));
-                    const float uy = __builtin_fmaf(fp.T[6], pz[k], __builtin_fmaf(fp.T[5], py[k], __builtin_fmaf(fp.T[4], px[k], fp.T[7])));
-                    const float uz = __builtin_fmaf(fp.T[10], pz[k], __builtin_fmaf(fp.T[9], py[k], __builtin_fmaf(fp.T[8], px[k], fp.T[11])));
+#if defined(OMGX_GS_ADD_S)  // measurement builds (DESIGN appendix A): what ONE more instruction of a class costs the launch, in situ
+                    { uint32_t d0 = (uint32_t)oo, d1 = (uint32_t)k; asm volatile("s_add_u32 %0, %0, 3\n\ts_add_u32 %1, %1, 5\n\ts_add_u32 %0, %0, 3\n\ts_add_u32 %1, %1, 5\n\ts_add_u32 %0, %0, 3\n\ts_add_u32 %1, %1, 5\n\ts_add_u32 %0, %0, 3\n\ts_add_u32 %1, %1, 5\n\t"
+                                   "s_add_u32 %0, %0, 3\n\ts_add_u32 %1, %1, 5\n\ts_add_u32 %0, %0, 3\n\ts_add_u32 %1, %1, 5\n\ts_add_u32 %0, %0, 3\n\ts_add_u32 %1, %1, 5\n\ts_add_u32 %0, %0, 3\n\ts_add_u32 %1, %1, 5" : "+s"(d0), "+s"(d1) : : "scc"); }
+#elif defined(OMGX_GS_ADD_V)
+                    { float d0 = px[k], d1 = py[k], d2 = pz[k], d3 = w[k]; asm volatile("v_fma_f32 %0, %0, %0, %0\n\tv_fma_f32 %1, %1, %1, %1\n\tv_fma_f32 %2, %2, %2, %2\n\tv_fma_f32 %3, %3, %3, %3\n\t"
+                                   "v_fma_f32 %0, %0, %0, %0\n\tv_fma_f32 %1, %1, %1, %1\n\tv_fma_f32 %2, %2, %2, %2\n\tv_fma_f32 %3, %3, %3, %3\n\t"
+                                   "v_fma_f32 %0, %0, %0, %0\n\tv_fma_f32 %1, %1, %1, %1\n\tv_fma_f32 %2, %2, %2, %2\n\tv_fma_f32 %3, %3, %3, %3\n\t"
+                                   "v_fma_f32 %0, %0, %0, %0\n\tv_fma_f32 %1, %1, %1, %1\n\tv_fma_f32 %2, %2, %2, %2\n\tv_fma_f32 %3, %3, %3, %3" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3)); }
+#elif defined(OMGX_GS_ADD_V64)
+                    { double d0 = px[k], d1 = py[k], d2 = pz[k], d3 = w[k]; asm volatile("v_fma_f64 %0, %0, %0, %0\n\tv_fma_f64 %1, %1, %1, %1\n\tv_fma_f64 %2, %2, %2, %2\n\tv_fma_f64 %3, %3, %3, %3\n\t"
+                                   "v_fma_f64 %0, %0, %0, %0\n\tv_fma_f64 %1, %1, %1, %1\n\tv_fma_f64 %2, %2, %2, %2\n\tv_fma_f64 %3, %3, %3, %3\n\t"
+                                   "v_fma_f64 %0, %0, %0, %0\n\tv_fma_f64 %1, %1, %1, %1\n\tv_fma_f64 %2, %2, %2, %2\n\tv_fma_f64 %3, %3, %3, %3\n\t"
+                                   "v_fma_f64 %0, %0, %0, %0\n\tv_fma_f64 %1, %1, %1, %1\n\tv_fma_f64 %2, %2, %2, %2\n\tv_fma_f64 %3, %3, %3, %3" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3)); }
+#elif defined(OMGX_GS_ADD_B)
+                    asm volatile("s_branch 1f\n\ts_nop 0\n\t1:\n\ts_branch 2f\n\ts_nop 0\n\t2:\n\ts_branch 3f\n\ts_nop 0\n\t3:\n\ts_branch 4f\n\ts_nop 0\n\t4:\n\t"
+                                 "s_branch 5f\n\ts_nop 0\n\t5:\n\ts_branch 6f\n\ts_nop 0\n\t6:\n\ts_branch 7f\n\ts_nop 0\n\t7:\n\ts_branch 8f\n\ts_nop 0\n\t8:");
+#elif defined(OMGX_GS_ADD_N)
+                    asm volatile("s_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0");
+#endif
+                    float ux, uy, uz;
+                    se3_apply_s(fp.T, px[k], py[k], pz[k], ux, uy, uz);
                     const float tx = ux - fp.lo[0], ty = uy - fp.lo[1], tz = uz - fp.lo[2];
-                    const bool inside = rbox_inside(tx, ty, tz, fp.rc, fp.rh, fp.rr2);
-                    const bool live = (msk[k] & bit) && (inside || !fp.cullable);
+                    const bool reach = (msk[k] & bit) != 0, inside = rbox_inside(tx, ty, tz, fp.rc, fp.rh, fp.rr2);
+                    const bool live = reach && (inside || !fp.cullable);
+                    // the same as a lane mask, from the two compares' own masks (a ballot of the combined bool goes through a select and a
+                    // second compare per lane)
+                    const unsigned long long live_mask = wave_ballot(reach) & (wave_ballot(inside) | (fp.cullable ? 0ull : ~0ull));
                     GS_COUNT(4);
-                    if (!__any(live)) continue;
+                    if (live_mask == 0) continue;
                     GS_COUNT(5);
-                    GS_COUNT_N(9, __popcll(__ballot(live)));
+                    GS_COUNT_N(9, __popcll(live_mask));
                     if (!wdone[k]) {
                         GS_COUNT(6);  // ||(x_i - x_{i-1}) / dt|| in float32 (config.py:162-187, cost.py:260-275), once per (row, link)
                         const int l = l0 + k;
@@ -759,12 +855,12 @@ __global__ __launch_bounds__(LAT ? 256 : GQ_NT, LAT ? 2 : GQ_WG_PER_CU) void k_g
                     const uint32_t soft = (h_soft && l0 + k >= 8) ? 1u : 0u;
                     if (queued) {
                         GS_COUNT(7);
-                        enqueue(live, tx, ty, tz, w[k], (uint32_t)oo | (soft << 16));
+                        enqueue(live, live_mask, tx, ty, tz, w[k], (uint32_t)oo | (soft << 16));
                     } else if (live) {
                         ObjParams op = load_object(ob);
                         // (an object beyond the LDS records is rare: keep what only this branch needs — 0.5 * (double)eps of the hinge —
                         // from being hoisted into every (tile, object) iteration: two half-rate instructions each)
-                        asm volatile("" : "+s"(op.eps));
+                        asm volatile("" : "+s"(op.eps), "+s"(op.clr));
                         Accum one{0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
                         pair_exact<false>(op, h_pool + ob->grid_offset, tx, ty, tz, one);
                         if (soft) { one.pot *= 0.1f; one.col = 0.0f; }

@@ -863,7 +863,10 @@ static int launch_goalset(ChunkArgs& ca, int timing_kind, hipStream_t st, const 
     hipEvent_t ev0, ev1;
     timing_events(timing_kind, &ev0, &ev1);
     const unsigned g = (unsigned)grid;
-    const uint32_t l32 = (uint32_t)lds;
+    uint32_t l32 = (uint32_t)lds;
+#ifdef OMGX_GS_CLOCK  // measurement build only (tools/gs_phase_clock.py): fewer workgroups per CU by asking for more LDS than the layout needs
+    if (const char* e = getenv("OMGX_GS_LDS_MIN")) { const uint32_t v = (uint32_t)atoi(e); if (v > l32 && v <= 64 * 1024) l32 = v; }
+#endif
 #define GQ_GO(STAMP, LAT, SPLIT, PRE) do { if (ev0) hipExtLaunchKernelGGL((k_goalset_queue<2, STAMP, LAT, SPLIT, PRE>), dim3(g), dim3((LAT) ? 256 : GQ_NT), l32, st, ev0, ev1, 0, ca); \
                                             else hipLaunchKernelGGL((k_goalset_queue<2, STAMP, LAT, SPLIT, PRE>), dim3(g), dim3((LAT) ? 256 : GQ_NT), l32, st, ca); } while (0)
     if (ca.spread) { if (pre) GQ_GO(false, true, false, true); else GQ_GO(false, true, false, false); }
