@@ -692,18 +692,14 @@ __global__ __launch_bounds__(LAT ? 256 : GQ_NT, LAT ? 2 : GQ_WG_PER_CU) void k_g
         }
     };
 
-    // The wave's work: TILES of 4 consecutive waypoints x LB links, dealt over the 4 waves as tile (block rb, link batch lp)
-    // -> wave (rb * (10 / LB) + lp) % 4.  The pairs that survive the culling are concentrated at the goal end of the path and
-    // on the links near the hand (tests/fuzz/pair_density.py: the last waypoints carry ~20x the work of the first), so with
-    // whole blocks of waypoints per wave the busiest wave had 1.4x the mean load; dealt like this the last wave leaves the
-    // main loop 1.07x after the mean (tools/gs_phase_clock.py).  Measured and rejected: single waypoints dealt to the waves
-    // (the rows of a tile then see different objects: +2 %), a split of the tile sequence by the number of row-mask hits
-    // (a poor predictor of the exact-path work: +7 %), one link per tile (+5 %).
+    // The waves' work: TILES of 4 consecutive waypoints x LB links.  The pairs that survive the culling are concentrated at the goal
+    // end of the path and on the links near the hand (tests/fuzz/pair_density.py: the last waypoints carry ~20x the work of the
+    // first).  Measured and rejected as tile shapes: single waypoints (the rows of a tile then see different objects: +2 %), one
+    // link per tile (+5 %).
     const int ntiles = ((h_CH + 3) >> 2) * (10 / LB);
     const int pc3 = 3 * (p < h_P ? p : 0);  // lane part of a collision-point address (doubles)
     GS_COUNT(0);
-    constexpr bool PARTS = LAT || SPLIT;  // this workgroup holds one part of a goal's tiles: the wave's q-th tile is lat_tile(q)
-    // WHO TAKES WHICH TILE (round 5, batch kernel with whole goals): the waves draw from ONE list — the goal's non-empty tiles, goal
+    // WHO TAKES WHICH TILE (round 5; not in latency mode, where the wave's q-th tile is lat_tile(q)): the waves draw from ONE list — the goal's non-empty tiles, goal
     // end and hand links first — through a counter in LDS.  Dealt statically ((block, pair) -> wave (5 block + pair) % 4) the first
     // wave left the main loop 10.1 us after the prologue and the last 14.7 us (tools/gs_phase_clock.py): a third of the loop's span
     // was three waves waiting for the fourth, with the workgroup's LDS and registers held.  The exact path's work per tile cannot be
@@ -711,12 +707,15 @@ __global__ __launch_bounds__(LAT ? 256 : GQ_NT, LAT ? 2 : GQ_WG_PER_CU) void k_g
     // Nothing depends on who computes what: the goal's sum is exact (tsum), the counts are integers.
     // The list: lane i of EVERY wave holds the i-th tile of the order (each wave builds its own copy in its ring, which the queue
     // does not use before the first enqueue; a wave's LDS operations run in program order), a draw is one LDS atomic.
-    constexpr bool DYN = !PARTS;
+    constexpr bool DYN = !LAT;  // (latency mode: every wave has culled the rows of ITS tiles only)
+    // the tiles this workgroup holds, heaviest first: all of the goal's, or — SPLIT — the tiles part, part + NP, ... of it
+    const int ncand = SPLIT ? (ntiles > part ? (ntiles - part + NP - 1) / NP : 0) : ntiles;
+    auto cand = [&](int j) { return SPLIT ? part + NP * (ncand - 1 - j) : ntiles - 1 - j; };
     int my_tile = -1, n_list = 0;
     uint32_t* const tile_counter = tilebits + 2;
     if constexpr (DYN) {
-        if (ntiles <= 64) {
-            const int t = ntiles - 1 - lane;
+        if (ncand <= 64) {
+            const int t = lane < ncand ? cand(lane) : -1;
             bool ne = t >= 0;
             if constexpr (TILEBITS) {  // bits all set when the window is longer than 32
                 const int rb = (t < 0 ? 0 : t) / (10 / LB), pr = (t < 0 ? 0 : t) - rb * (10 / LB);
@@ -734,7 +733,7 @@ __global__ __launch_bounds__(LAT ? 256 : GQ_NT, LAT ? 2 : GQ_WG_PER_CU) void k_g
             my_tile = lane < n_list ? lst[lane] : -1;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();  // the list has been read: the ring is the queue's from here on
-        } else n_list = ntiles;
+        } else n_list = ncand;
     }
     int q_static = 0;
     auto next_tile = [&]() -> int {
@@ -743,7 +742,9 @@ __global__ __launch_bounds__(LAT ? 256 : GQ_NT, LAT ? 2 : GQ_WG_PER_CU) void k_g
             if (lane == 0) q = (int)__hip_atomic_fetch_add(tile_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             q = __builtin_amdgcn_readfirstlane(q);
             if (q >= n_list) return -1;
-            return ntiles <= 64 ? __builtin_amdgcn_readlane(my_tile, q) : ntiles - 1 - q;
+            // (a draw requested one tile ahead, to hide the atomic's trip behind the previous tile, was measured: every wave then holds
+            // two of the dozen tiles from the start and the balance is the static deal's again — first / last wave out 10.8 / 15.1 us)
+            return ncand <= 64 ? __builtin_amdgcn_readlane(my_tile, q) : cand(q);
         } else return lat_tile(q_static++);
     };
 #pragma unroll 1
