@@ -649,8 +649,8 @@ __global__ __launch_bounds__(LAT ? 256 : GQ_NT, LAT ? 2 : GQ_WG_PER_CU) void k_g
         const uint32_t b = in_c ? (uint32_t)((ix * dy + iy) * dz + iz) : 0u;
 #endif
         // GLOBAL address space, said out loud: h_pool went through an asm copy, behind which the compiler no longer knows where it
-        // points and falls back to flat_load — which counts on lgkmcnt as well as vmcnt, so the next far test's wait for its scalar
-        // loads (or any LDS read) would wait for these gathers too and the queue would hide nothing
+        // points and falls back to flat_load, which counts on lgkmcnt as well as vmcnt (measured: no difference for this kernel —
+        // the waits that follow an issue are about as long as the gathers — but there is no reason to keep the coupling)
         const GlobalBytes g0 = (GlobalBytes)(uintptr_t)h_pool + goffb + (uint64_t)b * 4u;
         const uint32_t syb = (uint32_t)dz * 4u, sxb = (uint32_t)(dy * dz) * 4u;
         f_r00 = global_f2(g0);
