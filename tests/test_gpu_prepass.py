@@ -202,3 +202,40 @@ def test_huge_goal_costs_stay_within_the_oracles_bar(dev):
     for s in range(2):
         gc, _ = orc.goalset_cost(eng.model.blob(), eng.P, big.subset(s, s + 1), ts[s:s + 1].cpu().numpy(), eng.cv_goals[s:s + 1].cpu().numpy(), 30, eng.cfg.time_interval)
         np.testing.assert_allclose(a[s], np.asarray(gc).reshape(-1), rtol=1e-5)
+
+
+@pytest.mark.parametrize("goal_parts", [1, 2])
+def test_goal_costs_do_not_depend_on_who_draws_which_tile(dev, goal_parts):
+    """Since round 5 the waves of a goal workgroup DRAW their tiles from an LDS counter: which wave computes which pair depends
+    on timing.  The goal's cost is an exact sum and the counts are integers, so a launch
+    repeated under different loads — alone, beside a second stream that keeps the chip busy — must leave the same bits, and they
+    must be the bits of a goal split over several workgroups' draws added up by the learner's rule (one float32 rounding per
+    part: compared here part by part between repetitions only)."""
+    from omg_planner_amd import ops
+    S, G = 24, 64
+    eng, _ = _make(dev, S, G, grid=32)
+    NP = ops.goalset_parts(30, goal_parts) if goal_parts > 1 else 1
+    ts = eng.traj[:, 0]
+
+    def launch():
+        lay = _nan_like(eng.pot, eng.pgrad, eng.col)
+        pc = torch.full((S, G * NP), float("nan"), dtype=torch.float32, device=dev)
+        pl = torch.full_like(pc, float("nan"))
+        ops.goalset_cost_layer(eng.robot, eng.P, eng.scenes, ts, eng.cv_goals, 30, eng.cfg.time_interval, eng.traj, lay, out=(pc, pl),
+                               goal_parts=goal_parts)
+        return (pc, pl) + lay
+
+    first = launch()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(device=dev)
+    noise_a = torch.randn(4096, 4096, device=dev)
+    for rep in range(4):
+        if rep % 2:  # something else on the chip while the launch runs: other waves win other draws
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    noise_a = torch.tanh(noise_a @ noise_a * 1e-3)
+        again = launch()
+        torch.cuda.synchronize()
+        for x, y in zip(first, again):
+            assert _eq(x, y), rep
+    assert torch.isfinite(first[0]).all() and float(first[0].abs().sum()) > 0.0
