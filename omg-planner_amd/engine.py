@@ -60,6 +60,7 @@ class ChompEngine:
     # learner and step of a scene in different workgroups of omgx_goal_update_optimize (None: whenever both sets are resident
     # at once, 2 S <= CUs — beyond that the single-workgroup kernel is a little faster; True / False force it)
     split_update = None
+    HOT_FIXED_GOAL = True  # fixed-goal iterations through the prepared calls (_iterate_hot_fixed); False: the general path (A/B, tests)
     # True: iterate() goes through iterate_separate(), the five separate entry points (cross-checks)
     separate_launches = False
     # Under early stop: iterations between rebuilds of the schedule without the terminated scenes (omgx_goalset_schedule, one
@@ -688,6 +689,12 @@ class ChompEngine:
                 self._masked = True
             if self._iterate_hot(bool(early_stop and t > 0)):
                 return None
+        elif self.HOT_FIXED_GOAL and not self.separate_launches and not self._forked and not (cfg.goal_set_proj and t < cfg.optim_steps):
+            # the goal is fixed (the plan's last cfg.extra_smooth_steps iterations): layer launch + step through the prepared calls
+            if early_stop:
+                self._masked = True
+            self._iterate_hot_fixed(bool(early_stop and t > 0))
+            return None
         if self.stream is not None and torch.cuda.current_stream(self.device) != self.stream:
             with torch.cuda.stream(self.stream):
                 return self._iterate_general(t, early_stop)
@@ -734,6 +741,20 @@ class ChompEngine:
             NP = self._np(cfg.timesteps - min(int(((self.t + 1) / cfg.optim_steps) * cfg.timesteps), cfg.timesteps - 1))  # the window of the launch to come
             if self.schedule is None or self._sched_np != NP or (not self._measured and self._gs_launches >= 1 and self.S * self.G * self._parts_max >= self.MEASURE_MIN_ITEMS):
                 return False
+        calls = self._hot_calls()
+        stream = (self.stream if self.stream is not None else torch.cuda.current_stream(self.device)).cuda_stream
+        self.t += 1
+        prm = self._learner_params()
+        self._gs_launches += 1
+        self._parts_last = max(1, int(prm.cost_parts))
+        calls.use_layer_poses = self._poses_on
+        calls.goalset_layer(prm.start_idx, self._masked, self.schedule if use_sched else None, None, stream)
+        self._schedule()
+        split = 2 * self.S <= self._num_cus if self.split_update is None else bool(self.split_update)
+        calls.update(prm, self._params(True), split, self._next_ticket(), stop, stream)
+        return True
+
+    def _hot_calls(self) -> "ops.IterationCalls":
         # the prepared calls belong to these very tensor objects (held here, so none of them can be freed and its identity reused)
         key = [getattr(self, k) for k in self._HOT_TENSORS] + [self.scenes.scene_begin]
         baked = (float(self.cfg.time_interval), self.cfg.uncheck_finger_collision == -1)  # the scalars the calls carry
@@ -747,18 +768,20 @@ class ChompEngine:
                                        tiling=self._tiling() if self.latency else None,
                                        layer_poses=self.wp_pose, goal_parts=self.goal_parts, prepass=self.prepass)
             hot = self._hot = (key, calls, baked)
-        calls = hot[1]
+        return hot[1]
+
+    def _iterate_hot_fixed(self, stop: bool):
+        """An iteration with the goal fixed — the layer launch and the step (`_layer()` + `_step()` of the general path: the same two
+        entry points on the same tensors) — through ops.IterationCalls, on this engine's stream without switching torch's current
+        stream.  The general path costs ~50 us of host time per part and iteration (argument checks, stream context), more than
+        the two launches need on the device: the last 20 iterations of a pipelined plan were bound by the host (kernel trace of a
+        100-scene plan: a part's period 150 us against 58 us of kernels)."""
+        calls = self._hot_calls()
         stream = (self.stream if self.stream is not None else torch.cuda.current_stream(self.device)).cuda_stream
-        self.t += 1
-        prm = self._learner_params()
-        self._gs_launches += 1
-        self._parts_last = max(1, int(prm.cost_parts))
         calls.use_layer_poses = self._poses_on
-        calls.goalset_layer(prm.start_idx, self._masked, self.schedule if use_sched else None, None, stream)
+        calls.layer_only(stream)
         self._schedule()
-        split = 2 * self.S <= self._num_cus if self.split_update is None else bool(self.split_update)
-        calls.update(prm, self._params(True), split, self._next_ticket(), stop, stream)
-        return True
+        calls.step(self._params(True), stop, stream)
 
     def iterate_separate(self, t: int, early_stop: bool = False):
         """The same iteration composed from the separate entry points the drop-in classes use — omgx_goalset_cost,
