@@ -812,25 +812,7 @@ __global__ __launch_bounds__(LAT ? 256 : GQ_NT, LAT ? 2 : GQ_WG_PER_CU) void k_g
                 for (int k = 0; k < LB; ++k) {
                     if (!((sm[k] >> sh) & 1u)) continue;  // none of this link's four rows reaches the object
                     // SE3(pose) * point (.cu:125-133) and the far test of pair_prepare
-#if defined(OMGX_GS_ADD_S)  // measurement builds (DESIGN appendix A): what ONE more instruction of a class costs the launch, in situ
-                    { uint32_t d0 = (uint32_t)oo, d1 = (uint32_t)k; asm volatile("s_add_u32 %0, %0, 3\n\ts_add_u32 %1, %1, 5\n\ts_add_u32 %0, %0, 3\n\ts_add_u32 %1, %1, 5\n\ts_add_u32 %0, %0, 3\n\ts_add_u32 %1, %1, 5\n\ts_add_u32 %0, %0, 3\n\ts_add_u32 %1, %1, 5\n\t"
-                                   "s_add_u32 %0, %0, 3\n\ts_add_u32 %1, %1, 5\n\ts_add_u32 %0, %0, 3\n\ts_add_u32 %1, %1, 5\n\ts_add_u32 %0, %0, 3\n\ts_add_u32 %1, %1, 5\n\ts_add_u32 %0, %0, 3\n\ts_add_u32 %1, %1, 5" : "+s"(d0), "+s"(d1) : : "scc"); }
-#elif defined(OMGX_GS_ADD_V)
-                    { float d0 = px[k], d1 = py[k], d2 = pz[k], d3 = w[k]; asm volatile("v_fma_f32 %0, %0, %0, %0\n\tv_fma_f32 %1, %1, %1, %1\n\tv_fma_f32 %2, %2, %2, %2\n\tv_fma_f32 %3, %3, %3, %3\n\t"
-                                   "v_fma_f32 %0, %0, %0, %0\n\tv_fma_f32 %1, %1, %1, %1\n\tv_fma_f32 %2, %2, %2, %2\n\tv_fma_f32 %3, %3, %3, %3\n\t"
-                                   "v_fma_f32 %0, %0, %0, %0\n\tv_fma_f32 %1, %1, %1, %1\n\tv_fma_f32 %2, %2, %2, %2\n\tv_fma_f32 %3, %3, %3, %3\n\t"
-                                   "v_fma_f32 %0, %0, %0, %0\n\tv_fma_f32 %1, %1, %1, %1\n\tv_fma_f32 %2, %2, %2, %2\n\tv_fma_f32 %3, %3, %3, %3" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3)); }
-#elif defined(OMGX_GS_ADD_V64)
-                    { double d0 = px[k], d1 = py[k], d2 = pz[k], d3 = w[k]; asm volatile("v_fma_f64 %0, %0, %0, %0\n\tv_fma_f64 %1, %1, %1, %1\n\tv_fma_f64 %2, %2, %2, %2\n\tv_fma_f64 %3, %3, %3, %3\n\t"
-                                   "v_fma_f64 %0, %0, %0, %0\n\tv_fma_f64 %1, %1, %1, %1\n\tv_fma_f64 %2, %2, %2, %2\n\tv_fma_f64 %3, %3, %3, %3\n\t"
-                                   "v_fma_f64 %0, %0, %0, %0\n\tv_fma_f64 %1, %1, %1, %1\n\tv_fma_f64 %2, %2, %2, %2\n\tv_fma_f64 %3, %3, %3, %3\n\t"
-                                   "v_fma_f64 %0, %0, %0, %0\n\tv_fma_f64 %1, %1, %1, %1\n\tv_fma_f64 %2, %2, %2, %2\n\tv_fma_f64 %3, %3, %3, %3" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3)); }
-#elif defined(OMGX_GS_ADD_B)
-                    asm volatile("s_branch 1f\n\ts_nop 0\n\t1:\n\ts_branch 2f\n\ts_nop 0\n\t2:\n\ts_branch 3f\n\ts_nop 0\n\t3:\n\ts_branch 4f\n\ts_nop 0\n\t4:\n\t"
-                                 "s_branch 5f\n\ts_nop 0\n\t5:\n\ts_branch 6f\n\ts_nop 0\n\t6:\n\ts_branch 7f\n\ts_nop 0\n\t7:\n\ts_branch 8f\n\ts_nop 0\n\t8:");
-#elif defined(OMGX_GS_ADD_N)
-                    asm volatile("s_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0");
-#endif
+                    GS_MARGINAL_COST_PROBE(px[k], py[k], pz[k], w[k], oo, k);  // (measurement builds only)
                     float ux, uy, uz;
                     se3_apply_s(fp.T, px[k], py[k], pz[k], ux, uy, uz);
                     const float tx = ux - fp.lo[0], ty = uy - fp.lo[1], tz = uz - fp.lo[2];

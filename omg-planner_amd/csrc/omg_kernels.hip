@@ -590,6 +590,23 @@ extern "C" int omgx_debug_gs_wg(unsigned long long* h_out, int n_wg) {
 #define GS_FREQ_END()
 #endif
 
+// Measurement aid (EXTRA=-DOMGX_GS_ADD_{S,V,V64,B,N}=1): 16 more instructions of ONE class per far test of
+// k_goalset_queue — scalar adds, float32 / float64 multiply-adds on four chains, eight taken branches, s_nops — to read off what an
+// instruction of that class costs the launch where it runs.  Never part of the shipped library.
+#if defined(OMGX_GS_ADD_S)
+#define GS_MARGINAL_COST_PROBE(a_, b_, c_, d_, i_, j_) do { { uint32_t d0 = (uint32_t)(i_), d1 = (uint32_t)(j_); asm volatile("s_add_u32 %0, %0, 3\n\ts_add_u32 %1, %1, 5\n\ts_add_u32 %0, %0, 3\n\ts_add_u32 %1, %1, 5\n\ts_add_u32 %0, %0, 3\n\ts_add_u32 %1, %1, 5\n\ts_add_u32 %0, %0, 3\n\ts_add_u32 %1, %1, 5\n\t" "s_add_u32 %0, %0, 3\n\ts_add_u32 %1, %1, 5\n\ts_add_u32 %0, %0, 3\n\ts_add_u32 %1, %1, 5\n\ts_add_u32 %0, %0, 3\n\ts_add_u32 %1, %1, 5\n\ts_add_u32 %0, %0, 3\n\ts_add_u32 %1, %1, 5" : "+s"(d0), "+s"(d1) : : "scc"); } } while (0)
+#elif defined(OMGX_GS_ADD_V)
+#define GS_MARGINAL_COST_PROBE(a_, b_, c_, d_, i_, j_) do { { float d0 = (a_), d1 = (b_), d2 = (c_), d3 = (d_); asm volatile("v_fma_f32 %0, %0, %0, %0\n\tv_fma_f32 %1, %1, %1, %1\n\tv_fma_f32 %2, %2, %2, %2\n\tv_fma_f32 %3, %3, %3, %3\n\t" "v_fma_f32 %0, %0, %0, %0\n\tv_fma_f32 %1, %1, %1, %1\n\tv_fma_f32 %2, %2, %2, %2\n\tv_fma_f32 %3, %3, %3, %3\n\t" "v_fma_f32 %0, %0, %0, %0\n\tv_fma_f32 %1, %1, %1, %1\n\tv_fma_f32 %2, %2, %2, %2\n\tv_fma_f32 %3, %3, %3, %3\n\t" "v_fma_f32 %0, %0, %0, %0\n\tv_fma_f32 %1, %1, %1, %1\n\tv_fma_f32 %2, %2, %2, %2\n\tv_fma_f32 %3, %3, %3, %3" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3)); } } while (0)
+#elif defined(OMGX_GS_ADD_V64)
+#define GS_MARGINAL_COST_PROBE(a_, b_, c_, d_, i_, j_) do { { double d0 = (a_), d1 = (b_), d2 = (c_), d3 = (d_); asm volatile("v_fma_f64 %0, %0, %0, %0\n\tv_fma_f64 %1, %1, %1, %1\n\tv_fma_f64 %2, %2, %2, %2\n\tv_fma_f64 %3, %3, %3, %3\n\t" "v_fma_f64 %0, %0, %0, %0\n\tv_fma_f64 %1, %1, %1, %1\n\tv_fma_f64 %2, %2, %2, %2\n\tv_fma_f64 %3, %3, %3, %3\n\t" "v_fma_f64 %0, %0, %0, %0\n\tv_fma_f64 %1, %1, %1, %1\n\tv_fma_f64 %2, %2, %2, %2\n\tv_fma_f64 %3, %3, %3, %3\n\t" "v_fma_f64 %0, %0, %0, %0\n\tv_fma_f64 %1, %1, %1, %1\n\tv_fma_f64 %2, %2, %2, %2\n\tv_fma_f64 %3, %3, %3, %3" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3)); } } while (0)
+#elif defined(OMGX_GS_ADD_B)
+#define GS_MARGINAL_COST_PROBE(a_, b_, c_, d_, i_, j_) do { asm volatile("s_branch 1f\n\ts_nop 0\n\t1:\n\ts_branch 2f\n\ts_nop 0\n\t2:\n\ts_branch 3f\n\ts_nop 0\n\t3:\n\ts_branch 4f\n\ts_nop 0\n\t4:\n\t" "s_branch 5f\n\ts_nop 0\n\t5:\n\ts_branch 6f\n\ts_nop 0\n\t6:\n\ts_branch 7f\n\ts_nop 0\n\t7:\n\ts_branch 8f\n\ts_nop 0\n\t8:"); } while (0)
+#elif defined(OMGX_GS_ADD_N)
+#define GS_MARGINAL_COST_PROBE(a_, b_, c_, d_, i_, j_) do { asm volatile("s_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0"); } while (0)
+#else
+#define GS_MARGINAL_COST_PROBE(a_, b_, c_, d_, i_, j_) do { } while (0)
+#endif
+
 // Debug aid (EXTRA=-DOMGX_GS_COUNT=1; tools/gs_block_counts.py): how often each block of k_goalset_queue's main loop runs,
 // counted per wave.  Never part of the shipped library.
 #ifdef OMGX_GS_COUNT
