@@ -24,8 +24,6 @@ sum of its parts' sums); there is no CPU path here either
 """
 from __future__ import annotations
 
-import ctypes as C
-
 import numpy as np
 import torch
 

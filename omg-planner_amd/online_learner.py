@@ -12,7 +12,6 @@ device and fuses the update with the optimiser step.
 from __future__ import annotations
 
 import numpy as np
-import torch
 
 from . import _lib, ops
 

@@ -12,9 +12,6 @@ from __future__ import annotations
 import time
 
 import numpy as np
-import torch
-
-from . import _lib, ops
 
 
 class Optimizer(object):
