@@ -173,3 +173,24 @@ def test_whole_plan_at_bench_size_follows_the_oracle(dev):
     r = engine_vs_oracle(eng, batch, [3, 96], steps=eng.cfg.optim_steps + eng.cfg.extra_smooth_steps, pin_window=False)
     assert r["goal_idx_equal"], r
     assert r["max_traj_err"] <= 1e-4 and r["max_cost_rel_err"] <= 1e-4, r
+
+
+@pytest.mark.parametrize("S,early,alg", [(48, True, "MD"), (3, False, "MD"), (6, True, "Proj")])
+def test_fixed_goal_iterations_through_the_prepared_calls_leave_the_same_bits(dev, S, early, alg):
+    """The plan's last cfg.extra_smooth_steps iterations (goal fixed: layer launch + step) run through ops.IterationCalls
+    (ChompEngine._iterate_hot_fixed) instead of the general path's checked calls: same entry points, same tensors, same bits —
+    pipelined and not, with and without the early stop, and for a rule that never selects a goal."""
+    import bench
+    from omg_planner_amd.engine import ChompEngine
+    cfg, model, batch, start, goals = bench.build_workload(S, 64, 30, 32, 0, False)
+    out = []
+    try:
+        for hot in (True, False):
+            ChompEngine.HOT_FIXED_GOAL = hot
+            e = ChompEngine.auto(model, batch, copy.deepcopy(cfg), start, goals, device=dev, ol_alg=alg)
+            e.plan(early_stop=early)
+            torch.cuda.synchronize()
+            out.append(e)
+    finally:
+        ChompEngine.HOT_FIXED_GOAL = True
+    _assert_same(out[0], out[1])
