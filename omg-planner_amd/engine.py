@@ -684,13 +684,16 @@ class ChompEngine:
         if k > 1:
             return self._iterate_pipelined(t, early_stop, k)
         cfg = self.cfg
-        if not self.separate_launches and cfg.goal_set_proj and t < cfg.optim_steps and not self._forked:
+        # planner.py:609-618: the learner runs only for the online-learning rules and only for the first optim_steps iterations
+        select = cfg.goal_set_proj and t < cfg.optim_steps and self.ol_alg not in ("Baseline", "Proj")
+        if not self.separate_launches and select and not self._forked:
             if early_stop:
                 self._masked = True
             if self._iterate_hot(bool(early_stop and t > 0)):
                 return None
-        elif self.HOT_FIXED_GOAL and not self.separate_launches and not self._forked and not (cfg.goal_set_proj and t < cfg.optim_steps):
-            # the goal is fixed (the plan's last cfg.extra_smooth_steps iterations): layer launch + step through the prepared calls
+        elif self.HOT_FIXED_GOAL and not self.separate_launches and not self._forked and not select:
+            # the goal is fixed (the plan's last cfg.extra_smooth_steps iterations; "Proj" / "Baseline" throughout): layer launch + step
+            # through the prepared calls
             if early_stop:
                 self._masked = True
             self._iterate_hot_fixed(bool(early_stop and t > 0))
