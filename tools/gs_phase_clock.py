@@ -26,7 +26,8 @@ from omg_planner_amd.engine import ChompEngine  # noqa: E402
 def main():
     S = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     G = int(sys.argv[2]) if len(sys.argv) > 2 else 64
-    cfg, model, batch, start, goals = bench.build_workload(S, G, 30, 64, 0, False)
+    NW = int(sys.argv[3]) if len(sys.argv) > 3 else 30  # waypoints (the goal-set window at t = 0)
+    cfg, model, batch, start, goals = bench.build_workload(S, G, NW, 64, 0, False)
     eng = ChompEngine(model, batch, cfg, start, goals, device="cuda:0", ol_alg="MD")
     lib = _lib.lib()
     iters = 10
