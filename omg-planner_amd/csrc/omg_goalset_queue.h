@@ -38,7 +38,7 @@
 #define GQ_WG_PER_CU 5   // 32 KB of LDS per workgroup (30 waypoints), <= 96 VGPRs
 #endif
 #ifndef GQ_WAVES
-#define GQ_WAVES 4       // waves per workgroup.  Other values are EXPERIMENT builds (tools/ab_goalset.py): only the
+#define GQ_WAVES 4       // waves per workgroup.  Other values are EXPERIMENT builds (tools/ab_goalset.py; DESIGN_HISTORY.md appendix A): only the
 #endif                   // batch kernel behind the kinematics pre-pass (PRE, no split goals) deals its tiles over GQ_WAVES waves
 #define GQ_NT (64 * GQ_WAVES)
 
@@ -598,7 +598,7 @@ __global__ __launch_bounds__(LAT ? 256 : GQ_NT, LAT ? 2 : GQ_WG_PER_CU) void k_g
         return;
 #endif
         const bool valid = lane < count;
-#ifdef OMGX_GS_SORT  // experiment (verdict item 3, DESIGN appendix A): the ring's entries grouped by object before the gathers
+#ifdef OMGX_GS_SORT  // experiment (verdict item 3, DESIGN_HISTORY.md appendix A): the ring's entries grouped by object before the gathers
         int src = lane;
         uint32_t q_meta_s = q_meta;
         {

@@ -590,7 +590,7 @@ extern "C" int omgx_debug_gs_wg(unsigned long long* h_out, int n_wg) {
 #define GS_FREQ_END()
 #endif
 
-// Measurement aid (EXTRA=-DOMGX_GS_ADD_{S,V,V64,B,N}=1): 16 more instructions of ONE class per far test of
+// Measurement aid (EXTRA=-DOMGX_GS_ADD_{S,V,V64,B,N}=1; DESIGN_HISTORY.md appendix A): 16 more instructions of ONE class per far test of
 // k_goalset_queue — scalar adds, float32 / float64 multiply-adds on four chains, eight taken branches, s_nops — to read off what an
 // instruction of that class costs the launch where it runs.  Never part of the shipped library.
 #if defined(OMGX_GS_ADD_S)
