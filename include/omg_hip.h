@@ -481,18 +481,22 @@ int omgx_point_cloud_sdf(const double* points, int32_t num_points, const double*
  * (7) omgx_goalset_schedule — dispatch order for omgx_goalset_cost_layer from the durations it recorded in `work` (ABI 4)
  * No counterpart in the reference (it plans one scene at a time); this is the engine's load balancing across the 8 XCDs.
  * The kept (scene, goal) items — scene active, goal < goal_count[scene] — are laid out scene by scene, scenes by decreasing
- * total work, each scene's goals longest first, and this list is cut into 8 contiguous pieces of equal (clamped) work;
+ * total work, each scene's goals longest first, and this list is cut into 8 contiguous pieces of equal work;
  * piece x becomes the workgroups k = 8 r + x, r = 0, 1, ... of the launch.  A scene's workgroups thus stay on one XCD (two
- * where a cut falls inside it: its SDF volumes stay in those L2s), every XCD gets the same work.  Weights are clamped to
- * [L, slack L], L = mean / 1.4, so that no piece needs more than slack times the even share of slots.
+ * where a cut falls inside it: its SDF volumes stay in those L2s), every XCD gets the same work.  The cut uses the weights
+ * as measured whenever every piece then fits its slots (slack times the even share); otherwise weights clamped to
+ * [L, slack L], L = mean / 1.4, with which no piece can need more.
  *   work      [S*G] uint32 (0 counts as 1), or NULL: all items weigh the same
  *   active, goal_count   optional [S] int32 as above
  *   schedule  [omgx_goalset_schedule_len(S, G, slack)] int32 out (unused slots: -1)
  * Exact (integer) definition, restated in tests/test_gpu_schedule.py: w = work, 0 -> 1; T = sum of w over the kept items, N their
  * number; L = max(1, 10 T / (14 N)), wc = min(max(w, L), slack L); scenes ordered by decreasing sum of w (ties: lower index
  * first), a scene's goals by decreasing w (ties: lower goal first); an item with c = the wc of all items before it in that
- * list belongs to piece x = min(7, 8 (2 c + wc) / (2 Tc)), Tc = sum of wc; with p its position in the list and first(x) the
- * lowest position of piece x:  schedule[8 (p - first(x)) + x] = scene * G + goal.
+ * list belongs to piece x = min(7, 8 (2 c + wc) / (2 Tc)), Tc = sum of wc — and, with cr = the w of all items before it, to piece
+ * xr = min(7, 8 (2 cr + w) / (2 T)) of the raw cut, which replaces x for ALL items if no piece of the raw cut holds more than
+ * omgx_goalset_schedule_len / 8 items (ABI 10, second half of round 5: the clamp counts light scenes for more and heavy ones for less
+ * than they are); with p its position in the list and first(x) the lowest position of piece x:
+ * schedule[8 (p - first(x)) + x] = scene * G + goal.
  * One workgroup; S * G <= 65536 and S <= OMGX_SCHEDULE_MAX_SCENES (1792: its per-scene arrays stay below 64 KB of LDS), else
  * OMGX_ERR_UNSUPPORTED.
  * ------------------------------------------------------------------------------------------- */

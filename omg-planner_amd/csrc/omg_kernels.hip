@@ -1128,7 +1128,9 @@ __global__ __launch_bounds__(SCH_TPB) void k_goalset_schedule(SchedArgs a) {
     unsigned char* xs = reinterpret_cast<unsigned char*>(wl + S * G);   // [S*G] the item's XCD, 255 = left out (a.longest_first)
     __shared__ unsigned long long tot[2];                               // total weight, total clamped weight
     __shared__ uint32_t cnt_all;
-    __shared__ uint32_t first[8];
+    __shared__ uint32_t first[8];    // lowest list position of every piece, clamped cut
+    __shared__ uint32_t first_r[8];  // ... cut by the weights as measured
+    __shared__ uint32_t cnt_r[8];    // items of every piece under that cut
     // weight of item (s, g), 0 if it is left out: from LDS when staged (the loops below read every weight O(G) times)
     auto item_w = [&](int s, int g) -> uint32_t {
         if (a.staged) return wl[s * G + g];
@@ -1137,7 +1139,7 @@ __global__ __launch_bounds__(SCH_TPB) void k_goalset_schedule(SchedArgs a) {
         return w ? w : 1u;
     };
     if (tid == 0) { tot[0] = tot[1] = 0ull; cnt_all = 0u; }
-    if (tid < 8) first[tid] = 0xffffffffu;
+    if (tid < 8) { first[tid] = 0xffffffffu; first_r[tid] = 0xffffffffu; cnt_r[tid] = 0u; }
     for (int i = tid; i < a.slots * 8; i += SCH_TPB) a.sched[i] = -1;
     if (a.staged)
         for (int i = tid; i < S * G; i += SCH_TPB) {
@@ -1182,45 +1184,60 @@ __global__ __launch_bounds__(SCH_TPB) void k_goalset_schedule(SchedArgs a) {
         srank[s] = r;
     }
     __syncthreads();
-    for (int s = tid; s < S; s += SCH_TPB) {  // what the scenes ranked before this one hold
-        unsigned long long w = 0;
+    unsigned long long offr_reg[2] = {0ull, 0ull};  // (S <= OMGX_SCHEDULE_MAX_SCENES = 1792: at most two scenes per thread)
+    for (int s = tid, k = 0; s < S; s += SCH_TPB, ++k) {  // what the scenes ranked before this one hold
+        unsigned long long w = 0, wr = 0;
         uint32_t n = 0;
         for (int q = 0; q < S; ++q)
-            if (srank[q] < srank[s]) { w += Wc[q]; n += nval[q]; }
+            if (srank[q] < srank[s]) { w += Wc[q]; wr += Ws[q]; n += nval[q]; }
         offw[s] = w; offp[s] = n;
+        offr_reg[k & 1] = wr;
     }
     __syncthreads();
-    const unsigned long long total_c = tot[1] ? tot[1] : 1ull;
-    auto place = [&](int s, int g, uint32_t w, uint32_t& pos, int& x) {
+    unsigned long long* const offr = Wc;  // the scenes' clamped weights have been summed: their array holds the raw prefix from here on
+    for (int s = tid, k = 0; s < S; s += SCH_TPB, ++k) offr[s] = offr_reg[k & 1];
+    __syncthreads();
+    const unsigned long long total_c = tot[1] ? tot[1] : 1ull, total_r = tot[0] ? tot[0] : 1ull;
+    // x: the item's piece when the list is cut by CLAMPED work (a piece then never needs more than its slots); xr: when it is cut by
+    // the work as measured — used when every piece fits (the usual case: the clamp's bias, light scenes counted for more than they
+    // are and heavy ones for less, left the XCD with the heaviest scenes finishing 10-25 % after the one with the lightest)
+    auto place = [&](int s, int g, uint32_t w, uint32_t& pos, int& x, int& xr) {
         uint32_t r = 0;
-        unsigned long long before = 0;
+        unsigned long long before = 0, before_r = 0;
 #pragma unroll 4
         for (int q = 0; q < G; ++q) {
             const uint32_t wq = item_w(s, q);
             const bool ahead = wq > w || (wq == w && q < g);  // wq = 0 (left out) never ranks before a kept item
             r += ahead ? 1u : 0u;
             before += ahead ? wclamp(wq) : 0u;
+            before_r += ahead ? wq : 0u;
         }
         pos = offp[s] + r;
         const unsigned long long c2 = 2ull * (offw[s] + before) + wclamp(w);
         const unsigned long long xx = (8ull * c2) / (2ull * total_c);
         x = xx > 7 ? 7 : (int)xx;
+        const unsigned long long r2 = 2ull * (offr[s] + before_r) + w;
+        const unsigned long long xq = (8ull * r2) / (2ull * total_r);
+        xr = xq > 7 ? 7 : (int)xq;
     };
     // an item's place is computed once and kept in registers for the second pass (up to 4 items per thread: 4096 items;
     // beyond that the second pass computes it again)
     uint32_t kpos[4];
-    int kx[4];
+    int kx[4], kxr[4];
     int kept_n = 0;
     for (int i = tid; i < S * G; i += SCH_TPB) {  // first position of every piece
         const int s = i / G, g = i - s * G;
         const uint32_t w = item_w(s, g);
-        uint32_t pos = 0; int x = -1;
-        if (w) { place(s, g, w, pos, x); atomicMin(&first[x], pos); }
-        if (kept_n < 4) { kpos[kept_n] = pos; kx[kept_n] = x; }
+        uint32_t pos = 0; int x = -1, xr = -1;
+        if (w) { place(s, g, w, pos, x, xr); atomicMin(&first[x], pos); atomicMin(&first_r[xr], pos); atomicAdd(&cnt_r[xr], 1u); }
+        if (kept_n < 4) { kpos[kept_n] = pos; kx[kept_n] = x; kxr[kept_n] = xr; }
         ++kept_n;
-        if (a.longest_first) xs[i] = (unsigned char)(w ? x : 255);
+        if (a.longest_first) xs[i] = (unsigned char)(w ? (x | (xr << 4)) : 255);
     }
     __syncthreads();
+    bool use_raw = true;  // every piece of the raw cut fits its slots
+#pragma unroll
+    for (int x = 0; x < 8; ++x) use_raw = use_raw && cnt_r[x] <= (uint32_t)a.slots;
     if (a.longest_first) {
         // The XCD of every item as above (whole scenes per XCD, equal work); its place inside the XCD by weight alone — longest first
         // across the XCD's scenes, ties by index.  For launches of a round or two of the chip's workgroup slots, whose span is set by
@@ -1228,10 +1245,11 @@ __global__ __launch_bounds__(SCH_TPB) void k_goalset_schedule(SchedArgs a) {
         for (int i = tid; i < S * G; i += SCH_TPB) {
             const uint32_t w = wl[i];
             if (!w) continue;
-            const unsigned char x = xs[i];
+            const int sh = use_raw ? 4 : 0;
+            const unsigned char x = (xs[i] >> sh) & 7;
             uint32_t r = 0;
 #pragma unroll 4
-            for (int j = 0; j < S * G; ++j) r += (xs[j] == x && (wl[j] > w || (wl[j] == w && j < i))) ? 1u : 0u;
+            for (int j = 0; j < S * G; ++j) r += (wl[j] != 0u && ((xs[j] >> sh) & 7) == x && (wl[j] > w || (wl[j] == w && j < i))) ? 1u : 0u;
             if ((int)r < a.slots) a.sched[(size_t)r * 8 + x] = i;
         }
         return;
@@ -1239,11 +1257,12 @@ __global__ __launch_bounds__(SCH_TPB) void k_goalset_schedule(SchedArgs a) {
     int k = 0;
     for (int i = tid; i < S * G; i += SCH_TPB, ++k) {
         const int s = i / G, g = i - s * G;
-        uint32_t pos; int x;
-        if (k < 4) { pos = kpos[k]; x = kx[k]; if (x < 0) continue; }
-        else { const uint32_t w = item_w(s, g); if (!w) continue; place(s, g, w, pos, x); }
-        const uint32_t r = pos - first[x];
-        if ((int)r < a.slots) a.sched[(size_t)r * 8 + x] = i;  // always true: the clamp bounds a piece's count (include/omg_hip.h)
+        uint32_t pos; int x, xr;
+        if (k < 4) { pos = kpos[k]; x = kx[k]; xr = kxr[k]; if (x < 0) continue; }
+        else { const uint32_t w = item_w(s, g); if (!w) continue; place(s, g, w, pos, x, xr); }
+        if (use_raw) x = xr;
+        const uint32_t r = pos - (use_raw ? first_r[x] : first[x]);
+        if ((int)r < a.slots) a.sched[(size_t)r * 8 + x] = i;  // always true: checked for the raw cut, bounded by the clamp otherwise (include/omg_hip.h)
     }
 }
 

@@ -1,7 +1,7 @@
 """omgx_goalset_schedule (include/omg_hip.h section 7) against a numpy restatement of its integer specification, and the
 properties the goal-set launch relies on: every kept (scene, goal) item appears exactly once, an XCD's column holds a
-contiguous run of the scene-major list, the pieces carry equal (clamped) work, and the result of the launch does not depend
-on the order.
+contiguous run of the scene-major list, the pieces carry equal work (as measured; clamped when a piece would not fit its slots
+otherwise), and the result of the launch does not depend on the order.
 
 The schedule is dispatch policy of THIS implementation (the reference has no counterpart: omg/online_learner.py:128-148
 evaluates the goal set as one batch); what the reference fixes is the launch's result, which test_gpu_parity.py checks under
@@ -42,26 +42,35 @@ def schedule_mirror(work, S, G, active=None, goal_count=None, slack=2):
     Ws = [int(w[s][kept[s]].sum()) for s in range(S)]
     Wc = [int(wc[s][kept[s]].sum()) for s in range(S)]
     order = sorted(range(S), key=lambda s: (-Ws[s], s))
-    total_c = max(sum(Wc), 1)
-    pos, cum, items = 0, 0, []
+    total_c, total_r = max(sum(Wc), 1), max(total, 1)
+    pos, cum, cum_r, items = 0, 0, 0, []
     for s in order:
         goals = sorted((g for g in range(G) if kept[s, g]), key=lambda g: (-int(w[s, g]), g))
         for g in goals:
-            x = min(7, (8 * (2 * cum + int(wc[s, g]))) // (2 * total_c))
-            items.append((pos, x, s * G + g))
+            x = min(7, (8 * (2 * cum + int(wc[s, g]))) // (2 * total_c))          # the list cut by clamped work
+            xr = min(7, (8 * (2 * cum_r + int(w[s, g]))) // (2 * total_r))        # ... by the work as measured
+            items.append((pos, x, xr, s * G + g))
             pos += 1
             cum += int(wc[s, g])
+            cum_r += int(w[s, g])
+    # the raw cut when every piece fits its slots, the clamped one (whose pieces always do) otherwise
+    counts = np.bincount([xr for _, _, xr, _ in items], minlength=8) if items else np.zeros(8, int)
+    raw = bool((counts <= n_slots).all())
     first = {}
-    for p, x, _ in items:
-        first.setdefault(x, p)
-    for p, x, it in items:
-        sched[(p - first[x]) * 8 + x] = it
-    return sched, wc, kept
+    for p, x, xr, _ in items:
+        first.setdefault(xr if raw else x, p)
+    for p, x, xr, it in items:
+        xx = xr if raw else x
+        sched[(p - first[xx]) * 8 + xx] = it
+    schedule_mirror.last_cut_was_raw = raw
+    return sched, (w if raw else wc), kept
 
 
 CASES = [
     # S, G, ragged, masked, work
     (100, 64, False, False, "measured"),
+    (100, 64, False, False, "narrow"),   # scene weights within a factor of two, like measured durations: the raw cut fits
+    (33, 64, True, True, "narrow"),
     (100, 64, False, True, "measured"),
     (13, 64, True, False, "measured"),
     (12, 64, False, False, "uniform"),
@@ -84,6 +93,8 @@ def test_schedule_matches_the_integer_specification(dev, S, G, ragged, masked, k
         work = rng.randint(0, 3, S * G).astype(np.int32)  # zeros count as 1; many equal weights: index order decides
     elif kind == "skewed":
         work = (rng.pareto(1.2, S * G) * 2000 + 100).astype(np.int32)  # heavy tail: the clamp band is what bounds a piece
+    elif kind == "narrow":
+        work = (rng.randint(20000, 36000, S)[:, None] * rng.uniform(0.6, 1.6, (S, G))).astype(np.int32).ravel()
     else:
         base = rng.randint(4000, 30000, S)[:, None]
         work = (base * rng.uniform(0.3, 1.5, (S, G))).astype(np.int32).ravel()
@@ -109,6 +120,19 @@ def test_schedule_matches_the_integer_specification(dev, S, G, ragged, masked, k
         if k:
             load = wc.ravel()[col[:k]].sum()
             assert abs(load - share) <= wc[kept].max(), (x, load, share)
+
+
+def test_both_cuts_are_exercised(dev):
+    """The measured-work cut is the usual one; a heavy-tailed weight distribution overflows a piece's slots and falls back to the
+    clamped cut.  Both must occur among the cases above (the device result is compared with the mirror there)."""
+    rng = np.random.RandomState(40 * 131 + 100)
+    skew = (rng.pareto(1.2, 40 * 100) * 2000 + 100).astype(np.int32)
+    schedule_mirror(skew, 40, 100)
+    assert schedule_mirror.last_cut_was_raw is False
+    rng = np.random.RandomState(100 * 131 + 64)
+    meas = (rng.randint(20000, 36000, 100)[:, None] * rng.uniform(0.6, 1.6, (100, 64))).astype(np.int32).ravel()
+    schedule_mirror(meas, 100, 64)
+    assert schedule_mirror.last_cut_was_raw is True
 
 
 @pytest.mark.parametrize("S,G,ragged,masked,kind,parts", [(13, 128, False, False, "measured", 1), (5, 64, True, True, "ties", 1),
