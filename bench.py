@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — CHOMP iterations/sec over batched scenes on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W        (N > 1: starts its N ranks itself, as a child torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -361,12 +361,27 @@ def main():
     ap.add_argument("--dump-costs", default=None, help="rank 0 writes the gathered final per-scene costs to this .npy file (tests)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` typed plainly: start the N ranks as a CHILD process group (torch.distributed.run, one rank per
+        # GPU) before this process has imported torch or touched the GPU — never os.exec*: replacing a process that has initialised
+        # HIP takes the machine down on this pool — relay its output (rank 0 prints the JSON line) and leave with its exit code.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+        raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and args.gpus > 1 and world == 1:
-        raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+    if args.gpus != world and args.gpus > 1:
+        raise SystemExit(f"--gpus {args.gpus} under a launcher with WORLD_SIZE = {world}: one rank per GPU")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
     # one rank per GPU; OMGX_BENCH_BACKEND=gloo lets several ranks share one GPU for a functional test of this path

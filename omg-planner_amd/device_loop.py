@@ -86,6 +86,20 @@ class LazyIndex(_Promise):
     def __rsub__(self, other):
         return other - int(self)
 
+    def __mul__(self, other):
+        return int(self) * other
+
+    __rmul__ = __mul__
+
+    def __floordiv__(self, other):
+        return int(self) // other
+
+    def __mod__(self, other):
+        return int(self) % other
+
+    def __bool__(self):
+        return int(self) != 0
+
     def __repr__(self):
         return repr(int(self))
 
@@ -186,7 +200,8 @@ class DeviceLoop:
             self.cv_goals = self.reach[:, :, -1, :].contiguous()  # online_learner.py:121-125
         self.c = int(self.reach.shape[2]) if self.reach is not None else 1
         c = self.c
-        self._goal_set_host, self._reach_host = goal_set, (np.asarray(reach, np.float64) if self.reach is not None else None)
+        # private copies: an in-place edit of traj.goal_set / reach_grasps on the host is found by comparing bytes (matches())
+        self._goal_set_host, self._reach_host = goal_set.copy(), (np.array(reach, np.float64) if self.reach is not None else None)
         # ---- one device buffer, one pinned mirror: [start | traj | grad | cost_traj | info | end | goal rows | goal point | goal index]
         slots = [("start", (1, 9)), ("traj", (1, n, 9)), ("grad", (1, n, 9)), ("cost_traj", (1, n)), ("info", (1, _lib.INFO_STRIDE)),
                  ("end", (1, 9)), ("rows", (1, c, 9)), ("gp", (1, 9)), ("idx", (2,))]
@@ -242,8 +257,12 @@ class DeviceLoop:
         if traj is not self.traj_obj or int(self.cfg.timesteps) != self.n or self.cost._robot_model()[1] is not self.robot:
             return False
         gs = traj.goal_set
-        if gs is not None and (len(gs) != self.G or (gs is not self._goal_set_host and not np.array_equal(np.asarray(gs, np.float64), self._goal_set_host))):
+        if gs is not None and (len(gs) != self.G or not np.array_equal(np.asarray(gs, np.float64), self._goal_set_host)):
             return False
+        if self._reach_host is not None:
+            r = np.asarray(self.learner.env.objects[self.learner.env.target_idx].reach_grasps, np.float64)
+            if r.shape != self._reach_host.shape or not np.array_equal(r, self._reach_host):
+                return False
         return True
 
     # ---- launches ------------------------------------------------------------------------------------------------------------
@@ -257,6 +276,7 @@ class DeviceLoop:
                                              (self.d("grad"), self.d("cost_traj"), self.d("info")), self.cv, None, None, None, self.flags,
                                              layer_soften_fingers=self.cfg.uncheck_finger_collision == -1, tiling=self.LAT_TILING)
             self._calls_key, self._scenes_ref = key, scenes
+            self._layer_valid = False  # pot / pgrad / col on the device were computed against the OLD table
         return self._calls
 
     def _stream(self):
@@ -326,6 +346,12 @@ class DeviceLoop:
         idx._value = new
         changed._value = bool(new != int(old))
         self.learner._goal_taken(new)
+        # the trajectory keeps plain values once they are known (deepcopy / pickle / isinstance checks of a stored history)
+        t = self.traj_obj
+        if getattr(t, "goal_idx", None) is idx:
+            t.goal_idx = new
+        if isinstance(getattr(t, "end", None), _LazyEnd) and t.end._promise is idx:
+            t.end = t.end._get()
 
     def force(self, promise):
         """A promise is needed before optimize() ran: do the learner's update on its own."""

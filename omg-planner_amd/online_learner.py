@@ -79,6 +79,14 @@ class Learner(object):
             loop = DeviceLoop(self.cost, self)
             if old is not None and old.state.shape == loop.state.shape:
                 loop.state.copy_(old.state)
+            elif self.__dict__.pop("_push_state", False):  # reset(): the host attributes are the truth, the device follows
+                import torch
+                hv, G = self.__dict__["_hv"], self.N
+                vec = np.concatenate([np.asarray(hv["sum_costs"], np.float64), np.asarray(hv["p"], np.float64),
+                                      np.concatenate([np.asarray(e, np.float64) for e in hv["experts_p"]]),
+                                      np.asarray(hv["q"], np.float64), np.asarray(hv["experts_costs"], np.float64)])
+                if vec.shape[0] == 7 * G + 10:
+                    loop.state.copy_(torch.from_numpy(vec[None]))
             self._loop = self.cost._loop = loop
             self._goals_key = key
         elif self.cost.__dict__.get("_loop") is not loop:
@@ -146,6 +154,36 @@ class Learner(object):
         if self.alg_name in ("FTL", "FTC"):
             self.last_leader = idx
         return idx
+
+    def reset(self, traj):
+        """Reset the online learner for a new trajectory (omg/online_learner.py:251-263): alg_name, N, T, weights, t, traj, p,
+        sum_costs and last_leader start again; the experts' distributions, their costs, the mixture weights q and the Ti / Tis
+        counters stay what they are, as in the reference.  (A goal set of another SIZE leaves the reference's experts_p at the
+        old length, which its MD update cannot use; here the experts then start from uniform like in __init__.)"""
+        old = self._loop
+        if old is not None:
+            if old._pending is not None:
+                old.flush()
+            if old.state_dirty:
+                self._pull_state()  # experts_p / q / experts_costs of the device are the ones that stay
+        n_old = self.N
+        self.alg_name = self.cfg.ol_alg
+        if self.alg_name not in _lib.ALG:
+            raise ValueError(f"cfg.ol_alg = {self.alg_name!r}: the learner knows {sorted(_lib.ALG)}")
+        self.N = n = len(traj.goal_set)
+        self.T = self.cfg.optim_steps
+        self.weights = np.ones(n)
+        self.t = 0.0
+        self.traj = traj
+        self.p, self.sum_costs = np.ones(n) / n, np.zeros(n)
+        self.last_leader = 0
+        if n != n_old:
+            self.experts_p = [np.ones(n) / n for _ in self.etas]
+        # the device loop belongs to a (learner, trajectory) pair: the next use builds one for `traj` and uploads this state
+        self._loop, self._goals_key = None, None
+        if self.cost.__dict__.get("_loop") is old:
+            self.cost._loop = None
+        self.__dict__["_push_state"] = True
 
     def update_goal(self):
         """Take the arg-max of the goal distribution (online_learner.py:237-249); True when the goal changed.  With

@@ -525,7 +525,7 @@ def main(out_dir=OUT, script=None):
         print(f"batch_{name}.npz  goal_cost {out['goal_cost'][:4]}")
 
     # ---- (f-1) Learner.update_goal: cost_vector + FTL / FTC / Exp / MD (omg/online_learner.py) ----------
-    def run_learner_case(alg, scene_seed, G, steps, use_standoff, spread=0.12, tag="", cfg_over=None):
+    def run_learner_case(alg, scene_seed, G, steps, use_standoff, spread=0.12, tag="", cfg_over=None, reset_at=None):
         reset_cfg(cfg, timesteps=30, ol_alg=alg, use_standoff=use_standoff, **(cfg_over or {}))
         scene = small_scene(sc, scene_seed)
         env, sdf, lim = make_env(cfg, kin, model, scene)
@@ -544,8 +544,15 @@ def main(out_dir=OUT, script=None):
                    dist_eps=np.float64(cfg.dist_eps), cfg_normalize_cost=np.int64(cfg.normalize_cost),
                    cfg_base_obstacle_weight=np.float64(cfg.base_obstacle_weight),
                    cfg_smoothness_base_weight=np.float64(cfg.smoothness_base_weight))
-        cvs, ps, idxs, qs, trajs = [], [], [], [], []
+        cvs, ps, idxs, qs, trajs, ts = [], [], [], [], [], []
         for k in range(steps):
+            if reset_at is not None and k == reset_at:
+                # Learner.reset(traj) (omg/online_learner.py:251-263) for a NEW trajectory object over the same goal set: t, p, sum_costs,
+                # last_leader start again, the experts' distributions and the mixture weights stay
+                gi = int(traj.goal_idx)
+                traj = Traj(cfg, sc.cubic_init(start, goals[gi], 30), start, goals[gi], goal_set=goals, goal_idx=gi)
+                traj.interpolate_waypoints = lambda *a, **k: None
+                learner.reset(traj)
             # move the trajectory between calls (as the optimiser would) so the cost vectors change
             traj.data = traj.data + r.normal(0, 0.06, size=(1, 9)) * np.array([1] * 7 + [0, 0]) * np.linspace(0.2, 1.0, 30)[:, None]
             trajs.append(np.array(traj.data).copy())
@@ -553,10 +560,12 @@ def main(out_dir=OUT, script=None):
             cv = learner.cost_vector()
             learner.t -= 1
             learner.update_goal()
+            ts.append(float(learner.t))
             cvs.append(cv.copy()); ps.append(np.array(learner.p, dtype=np.float64).copy()); idxs.append(int(traj.goal_idx))
             qs.append(np.array(learner.q).copy())
         rec.update(trajs=np.stack(trajs), cost_vectors=np.stack(cvs), p=np.stack(ps), goal_idx=np.array(idxs), q=np.stack(qs), sum_costs=np.array(learner.sum_costs),
-                   experts_p=np.stack(learner.experts_p), final_t=np.float64(learner.t))
+                   experts_p=np.stack(learner.experts_p), final_t=np.float64(learner.t), t_of_step=np.array(ts),
+                   reset_at=np.int64(-1 if reset_at is None else reset_at))
         rec.update(scene_arrays(scene, sdf, lim))
         np.savez_compressed(out_dir / f"learner_{alg}_{int(use_standoff)}{tag}.npz", **rec)
         print(f"learner_{alg}_{int(use_standoff)}{tag}.npz  goal_idx {idxs}")
@@ -620,6 +629,10 @@ def main(out_dir=OUT, script=None):
         run_learner_case("FTC", 33, 8, 8, False, spread=0.015, tag="_close")
     if fixed:
         run_learner_case("MD", 34, 8, 8, False, spread=0.015, tag="_close")
+    if fixed:
+        run_learner_case("MD", 35, 8, 8, False, tag="_reset", reset_at=4)   # Learner.reset(traj) after four updates (round 6)
+    if fixed:
+        run_learner_case("Exp", 36, 8, 7, False, tag="_reset", reset_at=3)
 
     if fixed:
         run_batch_case("arc_g6_n30", 21, 6, 30, True, 0)

@@ -589,7 +589,7 @@ def test_goal_update_matches_reference_learner_fixture(dev, case):
             np.testing.assert_allclose(state[0, 7 * G:7 * G + 5].cpu().numpy(), fx["q"][k], rtol=1e-4, atol=1e-7)
 
 
-@pytest.mark.parametrize("case", ["FTL_0", "FTC_0", "Exp_0", "MD_0", "MD_1", "FTC_0_close", "MD_0_close"])
+@pytest.mark.parametrize("case", ["FTL_0", "FTC_0", "Exp_0", "MD_0", "MD_1", "FTC_0_close", "MD_0_close", "MD_0_reset", "Exp_0_reset"])
 def test_learner_class_matches_reference_learner_fixture(dev, case):
     """The mirror class online_learner.Learner driven like the reference's (constructor picks the initial goal; then
     update_goal per step on the trajectories the fixture recorded): goal indices and the public attributes p, q, sum_costs,
@@ -609,7 +609,15 @@ def test_learner_class_matches_reference_learner_fixture(dev, case):
     learner = Learner(env, traj, Cost(env))
     assert int(traj.goal_idx) == int(fx["init_goal_idx"]) and abs(learner.eta - float(fx["eta"])) < 1e-15
     np.testing.assert_array_equal(traj.end, fx["goal_set"][int(fx["init_goal_idx"])])
+    reset_at = int(fx["reset_at"]) if "reset_at" in fx else -1
     for k in range(fx["trajs"].shape[0]):
+        if k == reset_at:  # Learner.reset(traj) for a new trajectory object over the same goal set (omg/online_learner.py:251-263)
+            gi = int(traj.goal_idx)
+            traj = _Traj(fx["trajs"][k], fx["start"], fx["goal_set"][gi], fx["goal_set"], gi)
+            traj.interpolate_waypoints = lambda *a, **k: None
+            learner.reset(traj)
+            assert learner.t == 0.0 and learner.traj is traj and learner.last_leader == 0
+            np.testing.assert_array_equal(learner.p, np.ones(len(fx["goal_set"])) / len(fx["goal_set"]))
         traj.data = fx["trajs"][k]
         learner.t += 1
         cv = learner.cost_vector()

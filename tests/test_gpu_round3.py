@@ -302,3 +302,16 @@ def test_bench_collective_path_runs_over_rccl_with_one_rank(tmp_path):
     assert len(pr) == 1 and pr[0]["rank"] == 0 and pr[0]["scenes"] == 6 and pr[0]["avg_launch_ms"] > 0
     j1 = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][-1])
     assert "per_rank" not in j1["roofline"]
+
+
+@pytest.mark.gpu
+def test_bench_launches_its_own_ranks_when_typed_plainly(tmp_path):
+    """`python bench.py --gpus 2` with no launcher around it (what a driver types): bench.py starts torch.distributed.run as a child
+    before it touches the GPU, rank 0's JSON line comes back on stdout, exit code 0.  Both ranks share the one GPU over gloo."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["OMGX_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--total-scenes", "5", "--goals", "8", "--grid", "24", "--steps", "3",
+                        "--warmup", "1", "--no-plan", "--no-cpu-baseline", "--no-parity"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and len(j["roofline"]["per_rank"]) == 2

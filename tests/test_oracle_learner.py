@@ -6,7 +6,7 @@ import pytest
 from oracle import oracle as orc
 from tests import helpers as H
 
-CASES = ["FTL_0", "FTC_0", "Exp_0", "MD_0", "MD_1", "FTC_0_close", "MD_0_close"]
+CASES = ["FTL_0", "FTC_0", "Exp_0", "MD_0", "MD_1", "FTC_0_close", "MD_0_close", "MD_0_reset", "Exp_0_reset"]  # _reset: Learner.reset(traj) on the way
 
 
 def learner_params(fx, t):
@@ -32,8 +32,12 @@ def run_oracle_sequence(fx, goal_cost_fn):
     # Learner.__init__ runs one cost_vector at t = 0 for the initial goal (online_learner.py:97-102); it does not
     # touch the learner state, so the replay starts from the initial state
     out = []
+    reset_at = int(fx["reset_at"]) if "reset_at" in fx else -1
     for k in range(fx["trajs"].shape[0]):
-        prm = learner_params(fx, k + 1)
+        if k == reset_at:  # Learner.reset (omg/online_learner.py:251-263): p, sum_costs and t start again, experts / q stay
+            state[0, :G] = 0.0
+            state[0, G:2 * G] = 1.0 / G
+        prm = learner_params(fx, float(fx["t_of_step"][k]) if "t_of_step" in fx else k + 1)
         gc = goal_cost_fn(k, prm)
         idx, end, rows, gp, cv = orc.goal_update(prm, fx["trajs"][k][None], fx["goal_set"][None], fx["reach_grasps"][None], gc, state)
         out.append((idx[0], cv[0].copy(), state[0, G:2 * G].copy(), state[0, 7 * G:7 * G + 5].copy(), end[0], rows[0], gp[0]))
