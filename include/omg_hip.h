@@ -565,6 +565,53 @@ int omgx_fit_influence_regions(omgx_object* objects, int32_t num_objects, const 
                                void* scratch, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * (9) omgx_plan_persistent — K iterations of the planner loop for all scenes in ONE launch (ABI 11)
+ * Replaces the loop body of Planner.plan (omg/planner.py:612-630) — Learner.update_goal (omg/online_learner.py:237-249) followed by
+ * Optimizer.optimize(traj, force_update=True) (omg/optimizer.py:115-135), num_iters times — for S independent scenes: what
+ * num_iters x (omgx_goalset_cost_layer + omgx_goal_update_optimize) compute, bit for bit, scheduled by the one dependency the
+ * algorithm has (iteration t + 1 of scene s needs iteration t of scene s; omg/core.py:869-885 plans scenes independently)
+ * instead of by launch boundaries.  Resident workgroups claim work items — a goal of the goal-set batch, a piece of a scene's
+ * trajectory layer — the last item of a scene's iteration to finish runs the scene's learner and step and activates its next
+ * iteration (csrc/omg_persist.h).  Batch layout (whole goals), poses handed over: omgx_chomp_params.start_poses / end_poses,
+ * omgx_learner_params.goal_pose_table / end_poses_out and layer_poses are REQUIRED.
+ *   iteration k   omgx_plan_iter: mode 1 = goal-selecting (goal-set batch over the window that starts at start_idx + layer, then
+ *                 learner + step), 0 = goal fixed (layer + step: the plan's last cfg.extra_smooth_steps iterations);
+ *                 obstacle_weight / smoothness_weight / step_size = Optimizer.update's schedule for that iteration
+ *                 (omg/optimizer.py:59-80); stop_on_terminate: a scene whose step reports info["terminate"] leaves the loop
+ *                 (planner.py:626; active[s] <- 0); do_update as in omgx_chomp_params.
+ *   h_iters       [num_iters] host (checked here), d_iters: the same bytes in device memory (read by the kernel)
+ *   active        [S] int32 or NULL: scenes with 0 are not planned
+ *   workspace     omgx_plan_persistent_workspace_bytes(S, n) bytes of device memory: queue state (re-initialised by every call) and
+ *                 the step's scratch; one workspace per launch in flight
+ *   max_workgroups  0: five per compute unit (what is resident at 30 waypoints); tests pass small numbers
+ * Everything else as in omgx_goalset_cost_layer_parts (goal_parts = 1) and omgx_goal_update_optimize.  Asynchronous; errors inside
+ * the launch (a bounded wait that ran out) are reported by omgx_plan_persistent_status after the stream has been synchronised:
+ * h_status[0] != 0.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct omgx_plan_iter {
+    int32_t mode;              /* 1: Learner.update_goal + Optimizer.optimize, 0: Optimizer.optimize with the goal fixed */
+    int32_t start_idx;         /* Learner's window start of this iteration (online_learner.py:109-110); mode 0: ignored    */
+    int32_t stop_on_terminate; /* planner.py:626                                                                           */
+    int32_t do_update;         /* omgx_chomp_params.do_update of this iteration                                            */
+    double obstacle_weight, smoothness_weight, step_size; /* cfg.* after Optimizer.update for this iteration              */
+} omgx_plan_iter;
+int64_t omgx_plan_persistent_workspace_bytes(int32_t num_scenes, int32_t n_waypoints);
+int omgx_plan_persistent(const double* robot, int32_t n_points, const omgx_object* objects, const int32_t* scene_begin,
+                         const float* sdf_pool, const double* goals, int32_t num_scenes, int32_t num_goals,
+                         double time_interval, int32_t soften_fingers, float* goal_cost, float* collides, double* traj,
+                         int32_t n_waypoints, int32_t layer_soften_fingers, float* layer_potentials, float* layer_grads,
+                         float* layer_collides, double* layer_poses, int32_t* active, const int32_t* goal_count,
+                         const omgx_learner_params* h_learner, const double* goal_set, const double* reach,
+                         double* learner_state, int32_t* goal_idx, double* cost_vector, const double* eta,
+                         const omgx_chomp_params* h_params, const double* start, double* end, double* goal,
+                         double* goal_point, double* grad, double* cost_traj, double* info,
+                         const omgx_plan_iter* h_iters, const omgx_plan_iter* d_iters, int32_t num_iters,
+                         void* workspace, int64_t workspace_bytes, int32_t max_workgroups, void* stream);
+/* h_status[4] <- {failure code (0 = none), scenes finished, scenes planned, activations made} of the last launch on this workspace;
+ * synchronises `stream`. */
+int omgx_plan_persistent_status(const void* workspace, int32_t num_scenes, int32_t* h_status, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Diagnostics
  * ------------------------------------------------------------------------------------------- */
 const char* omgx_last_error(void); /* thread-local text of the last OMGX_ERR_LAUNCH               */

@@ -17,13 +17,13 @@ NUM_DOF, INFO_STRIDE = 9, 16
 SCHEDULE_MAX_SCENES = 1792  # OMGX_SCHEDULE_MAX_SCENES
 SCHEDULE_SCENE_MAJOR, SCHEDULE_LONGEST_FIRST = 0, 1  # OMGX_SCHEDULE_*: the order inside an XCD (omgx_goalset_schedule_ordered)
 SCHEDULE_LONGEST_FIRST_MAX_ITEMS = 8192
-ABI_VERSION = 10  # omgx_abi_version() of the library these argtypes describe
+ABI_VERSION = 11  # omgx_abi_version() of the library these argtypes describe
 
 # every symbol include/omg_hip.h declares
 EXPORTS = ["omgx_sdf_loss_forward", "omgx_fk_sdf_workspace_bytes", "omgx_fk_sdf", "omgx_forward_kinematics", "omgx_pose_table",
            "omgx_goalset_workspace_bytes", "omgx_goalset_cost", "omgx_goalset_cost_layer", "omgx_goalset_parts", "omgx_goalset_cost_layer_tiled", "omgx_goalset_cost_layer_parts", "omgx_goalset_schedule_len", "omgx_goalset_schedule", "omgx_goalset_schedule_parts", "omgx_goalset_schedule_ordered", "omgx_region_scratch_bytes", "omgx_object_set_grid", "omgx_fit_influence_region", "omgx_regions_scratch_bytes", "omgx_fit_influence_regions", "omgx_volume_hashes", "omgx_chomp_aux_doubles", "omgx_chomp_optimize",
            "omgx_learner_state_doubles", "omgx_goal_update", "omgx_goal_update_optimize", "omgx_point_cloud_sdf", "omgx_last_error", "omgx_abi_version", "omgx_device_arch", "omgx_device_cu_count", "omgx_download_sync",
-           "omgx_timing_enable", "omgx_timing_collect"]
+           "omgx_timing_enable", "omgx_timing_collect", "omgx_plan_persistent_workspace_bytes", "omgx_plan_persistent", "omgx_plan_persistent_status"]
 
 
 class OmgHipError(RuntimeError):
@@ -46,6 +46,12 @@ class LearnerParams(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("alg", "num_goals", "n_waypoints", "start_idx", "constraint_num", "use_standoff",
                                           "normalize_cost", "cost_parts")] + [(n, C.c_double) for n in (
         "base_obstacle_weight", "smooth_weight", "eta")] + [(n, C.c_void_p) for n in ("goal_pose_table", "end_poses_out")]
+
+
+class PlanIter(C.Structure):
+    """Mirror of `omgx_plan_iter` (include/omg_hip.h): one iteration of omgx_plan_persistent."""
+    _fields_ = [(n, C.c_int32) for n in ("mode", "start_idx", "stop_on_terminate", "do_update")] + [(n, C.c_double) for n in (
+        "obstacle_weight", "smoothness_weight", "step_size")]
 
 
 ALG = {"FTL": 0, "FTC": 1, "Exp": 2, "MD": 3, "Proj": 4}
@@ -132,6 +138,15 @@ def lib() -> C.CDLL:
         l.omgx_download_sync.restype = C.c_int
         l.omgx_timing_enable.argtypes = [i32]
         l.omgx_timing_collect.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_int32), i32]
+        l.omgx_plan_persistent_workspace_bytes.argtypes = [i32, i32]
+        l.omgx_plan_persistent_workspace_bytes.restype = i64
+        l.omgx_plan_persistent.argtypes = ([vp, i32, vp, vp, vp, vp, i32, i32, f64, i32, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp] +       # goal-set batch + layer
+                                           [C.POINTER(LearnerParams), vp, vp, vp, vp, vp, vp] +                                       # learner
+                                           [C.POINTER(ChompParams), vp, vp, vp, vp, vp, vp, vp] +                                     # step
+                                           [C.POINTER(PlanIter), vp, i32, vp, i64, i32, vp])                                          # the plan
+        l.omgx_plan_persistent.restype = C.c_int
+        l.omgx_plan_persistent_status.argtypes = [vp, i32, C.POINTER(i32), vp]
+        l.omgx_plan_persistent_status.restype = C.c_int
         for name in ("omgx_sdf_loss_forward", "omgx_fk_sdf", "omgx_forward_kinematics", "omgx_pose_table", "omgx_goalset_cost", "omgx_chomp_optimize",
                      "omgx_abi_version", "omgx_device_arch", "omgx_timing_enable", "omgx_timing_collect"):
             getattr(l, name).restype = C.c_int

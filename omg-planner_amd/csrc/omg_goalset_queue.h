@@ -167,73 +167,25 @@ __device__ __forceinline__ void gq_tbl_store(uint32_t* e, const GqTblRec& r) {
 // PRE: the goals' link poses and row masks come from k_goalset_kin's workspace (omg_goalset_kin.h) — the workgroup's prologue is ONE
 // trip to memory (poses, masks, collision points, records) instead of the kinematics and the culling; everything from the main loop
 // on is the same code on the same LDS contents.
-template <int LB, bool STAMP = false, bool LAT = false, bool SPLIT = false, bool PRE = false>
-__global__ __launch_bounds__(LAT ? 256 : GQ_NT, LAT ? 2 : GQ_WG_PER_CU) void k_goalset_queue(ChunkArgs a) {  // LAT: a workgroup per CU or two, registers are free
-    extern __shared__ __attribute__((aligned(16))) double lds_pose[];  // no static LDS: 31744 B is the most a workgroup may use at 5 per CU
-    GS_WG_STAMP(0);
-#ifdef OMGX_GS_PRIO
-    __builtin_amdgcn_s_setprio(OMGX_GS_PRIO);
-#endif
-    const int xcd = blockIdx.x & 7;
-    // with a trajectory layer, a.layer_parts workgroups per scene compute it (a.layer_lg link groups x a.layer_nb blocks of a.layer_cb
-    // configurations: 5 x 1 in a batch, finer in latency mode); those lead the grid
-    // (at the end of the grid, as fillers of the launch's tail, they cost 3 %: measured)
-    const int LPARTS = a.layer_parts;
-    const bool spread = LAT;
-    static_assert(!(LAT && SPLIT), "latency mode has its parts already");
-    const int NP = (LAT || SPLIT) ? a.NP : 1;
-    bool is_layer;
-    int s, chunk, layer_part;
-    bool scheduled = false;
-    if (spread) {
-        // latency mode (a handful of scenes): workgroup b -> (scene, item) in plain order, the scene's workgroups spread over all XCDs
-        const int nl = a.wp_traj ? a.S * LPARTS : 0;
-        is_layer = (int)blockIdx.x < nl;
-        const int j = (int)blockIdx.x - nl;
-        s = is_layer ? (int)blockIdx.x / LPARTS : j / a.NCH;
-        layer_part = (int)blockIdx.x - s * LPARTS;
-        chunk = is_layer ? 0 : j - s * a.NCH;
-    } else {
-        const int nlayer = a.wp_traj ? ((a.S + 7) >> 3) * LPARTS : 0;
-        is_layer = (int)(blockIdx.x >> 3) < nlayer;
-        const int j = (int)(blockIdx.x >> 3) - nlayer;
-        const int sgrp = is_layer ? (int)(blockIdx.x >> 3) / LPARTS : j / a.NCH;
-        layer_part = (int)(blockIdx.x >> 3) - sgrp * LPARTS;
-        s = sgrp * 8 + xcd;
-        chunk = is_layer ? 0 : j - sgrp * a.NCH;
-        scheduled = a.schedule && !is_layer;
-        if (scheduled) {  // goal workgroup b of the launch works on item schedule[b] (ChunkArgs)
-            const int item = as_const(a.schedule)[(int)blockIdx.x - nlayer * 8];
-            if (item < 0 || item >= a.S * a.NCH) return;
-            s = item / a.NCH;
-            chunk = item - s * a.NCH;
-            if (a.active && as_const(a.active)[s] == 0) { if (STAMP && threadIdx.x == 0) a.work[item] = 0u; return; }
-        }
-    }
-    if (s >= a.S) return;
-    if (a.active && !scheduled && !spread) {
-        // Scenes the planner has left (planner.py:626) get no workgroups, and the remaining ones are dealt out again so that
-        // every XCD keeps an equal share: slot k = sgrp * 8 + xcd works on the k-th ACTIVE scene (ascending).  Every wave
-        // finds it by itself with ballots over the mask (S / 64 steps, wave-uniform): no barrier, no extra launch, same
-        // result in all waves.  With all scenes active this is the identity.
-        const int k = s, ln = threadIdx.x & 63;
-        int seen = 0;
-        s = -1;
-        for (int base = 0; base < a.S; base += 64) {
-            const int i = base + ln;
-            const unsigned long long bal = __ballot(i < a.S && a.active[i] != 0);
-            const int cnt = __popcll(bal);
-            if (k < seen + cnt) {
-                unsigned long long m = bal;
-                for (int q = k - seen; q > 0; --q) m &= m - 1;  // drop the k - seen lowest set bits
-                s = base + __builtin_ctzll(m);
-                break;
-            }
-            seen += cnt;
-        }
-    }
-    if (s < 0) return;  // fewer active scenes than slots
-    if (spread && a.active && as_const(a.active)[s] == 0) return;
+// PERSIST (omg_persist.h: the persistent planner kernel calls this once per work item): what OTHER workgroups of the same launch wrote or
+// will read goes through agent-scope accesses — the trajectory is read with sc1 loads (the step's workgroup stored it with sc1 stores), the
+// goal's cost and collision count are stored with sc1 stores (their reader is the scene's last workgroup to arrive); everything else is the
+// same code.  (MI355X_MICROARCH.md, inter-workgroup visibility: 8-byte agent-scope atomics on both sides need no fence.)
+template <bool PERSIST>
+__device__ __forceinline__ double gq_ld_traj(const double* p) {
+    if constexpr (PERSIST) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *p;
+}
+template <bool PERSIST>
+__device__ __forceinline__ void gq_st_out(float* p, float v) {
+    if constexpr (PERSIST) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+
+// One work item of k_goalset_queue — a goal (or one part of it) or one piece of a scene's trajectory layer — by a whole workgroup.
+// ROLE (omg_persist.h compiles the two kinds of item as functions of their own): 0 = either, 1 = a trajectory-layer piece, 2 = a goal.
+template <int LB, bool STAMP, bool LAT, bool SPLIT, bool PRE, bool PERSIST = false, int ROLE = 0>
+__device__ __forceinline__ void gq_item(const ChunkArgs& a, double* const lds_pose, const int s, const bool is_layer, const int layer_part, const int chunk, const int NP) {
     const int o_begin = as_const(a.scene_begin)[s], o_end = as_const(a.scene_begin)[s + 1];
     const int P = a.P;
     // LAT: the scene's object records and the links' radii into the scalar cache, asynchronously (consumed after the (sin, cos) stage)
@@ -256,11 +208,11 @@ __global__ __launch_bounds__(LAT ? 256 : GQ_NT, LAT ? 2 : GQ_WG_PER_CU) void k_g
     char* const lds_bytes = reinterpret_cast<char*>(lds_pose);
     uint32_t* const rowmask = reinterpret_cast<uint32_t*>(lds_bytes + L.mask_off);
     uint32_t* const tilebits = reinterpret_cast<uint32_t*>(lds_bytes + L.tile_off);  // goal workgroups: which tiles have anything in reach
-    if (is_layer) {
+    if (ROLE == 1 || (ROLE == 0 && is_layer)) {
         const int lgi = a.layer_nb > 1 ? layer_part / a.layer_nb : layer_part, cbi = layer_part - lgi * a.layer_nb;
         const int lpg = 10 / a.layer_lg, c_begin = cbi * a.layer_cb;
         const int c_end = c_begin + a.layer_cb < a.wp_n ? c_begin + a.layer_cb : a.wp_n;
-        waypoint_layer_block<LAT>(a, s, lgi * lpg, (lgi + 1) * lpg, c_begin, c_end, lds_pose, rowmask, o_begin, o_end, rv,
+        waypoint_layer_block<LAT, PERSIST>(a, s, lgi * lpg, (lgi + 1) * lpg, c_begin, c_end, lds_pose, rowmask, o_begin, o_end, rv,
                                   reinterpret_cast<double*>(lds_bytes + L.fkc_off), warming,
                                   reinterpret_cast<float*>(lds_bytes + L.objc_off), reinterpret_cast<double*>(lds_bytes + L.btab_off));
         GS_WG_STAMP(4);
@@ -395,7 +347,7 @@ __global__ __launch_bounds__(LAT ? 256 : GQ_NT, LAT ? 2 : GQ_WG_PER_CU) void k_g
         GqTblRec trec{};
         if (LAT && tbl_lane) trec = gq_tbl_load(a.objects + o_begin + (tid - 128));  // LAT: requested here, stored after the barrier
         if (warming) gq_warm_scalar_cache(a.objects, o_begin, o_end, a.robot + OMGX_ROBOT_POINTS + 30 * P + 316 + 30 * P);
-        auto joint = [&](int cfg, int d) { return cfg == 0 ? q0[d] : q0[d] + ((double)cfg * (1.0 / (double)(CH + 1))) * (qg[d] - q0[d]); };
+        auto joint = [&](int cfg, int d) { const double q0d = gq_ld_traj<PERSIST>(q0 + d); return cfg == 0 ? q0d : q0d + ((double)cfg * (1.0 / (double)(CH + 1))) * (qg[d] - q0d); };
         for (int t = tid; t < ncfg * 7; t += 256) {
             const int cfg = t / 7, i = t - cfg * 7;
             double sn, cs;
@@ -883,11 +835,81 @@ __global__ __launch_bounds__(LAT ? 256 : GQ_NT, LAT ? 2 : GQ_WG_PER_CU) void k_g
             float rc = ((redc[0] + redc[1]) + redc[2]) + redc[3];  // integers below 2^24: exact too
 #pragma unroll
             for (int w = 4; w < GQ_WAVES; ++w) { rs += red[w]; rc += redc[w]; }
-            if (a.chunk_cost) a.chunk_cost[k] = (float)rs;
-            if (a.chunk_col) a.chunk_col[k] = rc;
+            if (a.chunk_cost) gq_st_out<PERSIST>(a.chunk_cost + k, (float)rs);
+            if (a.chunk_col) gq_st_out<PERSIST>(a.chunk_col + k, rc);
             if (STAMP) { const unsigned long long dt = wall_clock64() - work_t0; a.work[k] = dt < 1 ? 1u : (dt > 0xffffffffull ? 0xffffffffu : (uint32_t)dt); }
         }
     }
     GS_FREQ_END();
     GS_WG_STAMP(4);
+}
+
+template <int LB, bool STAMP = false, bool LAT = false, bool SPLIT = false, bool PRE = false>
+__global__ __launch_bounds__(LAT ? 256 : GQ_NT, LAT ? 2 : GQ_WG_PER_CU) void k_goalset_queue(ChunkArgs a) {  // LAT: a workgroup per CU or two, registers are free
+    extern __shared__ __attribute__((aligned(16))) double lds_pose[];  // no static LDS: 31744 B is the most a workgroup may use at 5 per CU
+    GS_WG_STAMP(0);
+#ifdef OMGX_GS_PRIO
+    __builtin_amdgcn_s_setprio(OMGX_GS_PRIO);
+#endif
+    const int xcd = blockIdx.x & 7;
+    // with a trajectory layer, a.layer_parts workgroups per scene compute it (a.layer_lg link groups x a.layer_nb blocks of a.layer_cb
+    // configurations: 5 x 1 in a batch, finer in latency mode); those lead the grid
+    // (at the end of the grid, as fillers of the launch's tail, they cost 3 %: measured)
+    const int LPARTS = a.layer_parts;
+    const bool spread = LAT;
+    static_assert(!(LAT && SPLIT), "latency mode has its parts already");
+    const int NP = (LAT || SPLIT) ? a.NP : 1;
+    bool is_layer;
+    int s, chunk, layer_part;
+    bool scheduled = false;
+    if (spread) {
+        // latency mode (a handful of scenes): workgroup b -> (scene, item) in plain order, the scene's workgroups spread over all XCDs
+        const int nl = a.wp_traj ? a.S * LPARTS : 0;
+        is_layer = (int)blockIdx.x < nl;
+        const int j = (int)blockIdx.x - nl;
+        s = is_layer ? (int)blockIdx.x / LPARTS : j / a.NCH;
+        layer_part = (int)blockIdx.x - s * LPARTS;
+        chunk = is_layer ? 0 : j - s * a.NCH;
+    } else {
+        const int nlayer = a.wp_traj ? ((a.S + 7) >> 3) * LPARTS : 0;
+        is_layer = (int)(blockIdx.x >> 3) < nlayer;
+        const int j = (int)(blockIdx.x >> 3) - nlayer;
+        const int sgrp = is_layer ? (int)(blockIdx.x >> 3) / LPARTS : j / a.NCH;
+        layer_part = (int)(blockIdx.x >> 3) - sgrp * LPARTS;
+        s = sgrp * 8 + xcd;
+        chunk = is_layer ? 0 : j - sgrp * a.NCH;
+        scheduled = a.schedule && !is_layer;
+        if (scheduled) {  // goal workgroup b of the launch works on item schedule[b] (ChunkArgs)
+            const int item = as_const(a.schedule)[(int)blockIdx.x - nlayer * 8];
+            if (item < 0 || item >= a.S * a.NCH) return;
+            s = item / a.NCH;
+            chunk = item - s * a.NCH;
+            if (a.active && as_const(a.active)[s] == 0) { if (STAMP && threadIdx.x == 0) a.work[item] = 0u; return; }
+        }
+    }
+    if (s >= a.S) return;
+    if (a.active && !scheduled && !spread) {
+        // Scenes the planner has left (planner.py:626) get no workgroups, and the remaining ones are dealt out again so that
+        // every XCD keeps an equal share: slot k = sgrp * 8 + xcd works on the k-th ACTIVE scene (ascending).  Every wave
+        // finds it by itself with ballots over the mask (S / 64 steps, wave-uniform): no barrier, no extra launch, same
+        // result in all waves.  With all scenes active this is the identity.
+        const int k = s, ln = threadIdx.x & 63;
+        int seen = 0;
+        s = -1;
+        for (int base = 0; base < a.S; base += 64) {
+            const int i = base + ln;
+            const unsigned long long bal = __ballot(i < a.S && a.active[i] != 0);
+            const int cnt = __popcll(bal);
+            if (k < seen + cnt) {
+                unsigned long long m = bal;
+                for (int q = k - seen; q > 0; --q) m &= m - 1;  // drop the k - seen lowest set bits
+                s = base + __builtin_ctzll(m);
+                break;
+            }
+            seen += cnt;
+        }
+    }
+    if (s < 0) return;  // fewer active scenes than slots
+    if (spread && a.active && as_const(a.active)[s] == 0) return;
+    gq_item<LB, STAMP, LAT, SPLIT, PRE>(a, lds_pose, s, is_layer, layer_part, chunk, NP);
 }

@@ -388,7 +388,8 @@ __global__ __launch_bounds__(TPB) void k_sdf_chunks(ChunkArgs a) {
 // extra workgroups per scene (ChunkArgs::layer_parts) of k_goalset_queue (omg_goalset_queue.h).  The optimiser step that follows on
 // the same stream then depends on a single kernel: no side stream, no events.  Arithmetic is that of k_sdf_chunks<true>
 // (same sdf_pair calls on the same float32 points); kinematics in two stages like the goal workgroups.
-template <bool LAT>  // the chain's constants from LDS (fkc, filled here) instead of through the scalar cache: see k_goalset_queue
+// PERSIST: the trajectory is read with agent-scope (sc1) loads — another workgroup of the same launch stored it (omg_persist.h)
+template <bool LAT, bool PERSIST = false>  // LAT: the chain's constants from LDS (fkc, filled here) instead of through the scalar cache: see k_goalset_queue
 __device__ __forceinline__ void waypoint_layer_block(const ChunkArgs& a, const int s, const int l_begin, const int l_end,
                                                      const int c_begin, const int c_end, double* lds_pose, uint32_t* rowmask,
                                                      const int o_begin, const int o_end, const RobotViewS& rv, double* fkc,
@@ -399,12 +400,16 @@ __device__ __forceinline__ void waypoint_layer_block(const ChunkArgs& a, const i
     const int nloc = c_end - c_begin;
     const double* tr = a.wp_traj + ((int64_t)s * n + c_begin) * 9;
     double* sc = reinterpret_cast<double*>(rowmask);  // [nloc][7][2], dead before the masks are written
+    auto ldtr = [&](int k) -> double {
+        if constexpr (PERSIST) return __hip_atomic_load(tr + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else return tr[k];
+    };
     const double fkv = (LAT && threadIdx.x < 246) ? rv.g[threadIdx.x] : 0.0;
     if (warming) gq_warm_scalar_cache(a.objects, o_begin, o_end, a.robot + OMGX_ROBOT_POINTS + 30 * P + 316 + 30 * P);
     for (int t = threadIdx.x; t < nloc * 7; t += 256) {
         const int cfg = t / 7, i = t - cfg * 7;
         double sn, cs;
-        fk_joint_sincos(tr[cfg * 9 + i], sn, cs);
+        fk_joint_sincos(ldtr(cfg * 9 + i), sn, cs);
         sc[2 * t] = sn; sc[2 * t + 1] = cs;
     }
     if (LAT && threadIdx.x < 246) fkc[threadIdx.x] = fkv;
@@ -414,7 +419,7 @@ __device__ __forceinline__ void waypoint_layer_block(const ChunkArgs& a, const i
     auto run_chain = [&](const auto& view) {
         for (int t = threadIdx.x; t < nloc * 3; t += 256) {
             const int cfg = t / 3, r = t - cfg * 3;
-            fk_chain_row(view, r, sc + 14 * cfg, tr[cfg * 9 + 7], tr[cfg * 9 + 8], [&](int l, double r0, double r1, double r2, double tt) {
+            fk_chain_row(view, r, sc + 14 * cfg, ldtr(cfg * 9 + 7), ldtr(cfg * 9 + 8), [&](int l, double r0, double r1, double r2, double tt) {
                 double* dst = lds_pose + ((size_t)l * PS + cfg) * 9;
                 if (r < 2) { dst[3 * r] = r0; dst[3 * r + 1] = r1; dst[3 * r + 2] = r2; }
                 dst[6 + r] = tt;
@@ -431,7 +436,7 @@ __device__ __forceinline__ void waypoint_layer_block(const ChunkArgs& a, const i
         __syncthreads();
         for (int t = threadIdx.x; t < nloc * 3; t += 256) {
             const int cfg = t / 3, r = t - cfg * 3;
-            fk_chain_row_B(rvl, r, btab + 63 * cfg, tr[cfg * 9 + 7], tr[cfg * 9 + 8], [&](int l, double r0, double r1, double r2, double tt) {
+            fk_chain_row_B(rvl, r, btab + 63 * cfg, ldtr(cfg * 9 + 7), ldtr(cfg * 9 + 8), [&](int l, double r0, double r1, double r2, double tt) {
                 double* dst = lds_pose + ((size_t)l * PS + cfg) * 9;
                 if (r < 2) { dst[3 * r] = r0; dst[3 * r + 1] = r1; dst[3 * r + 2] = r2; }
                 dst[6 + r] = tt;
@@ -694,7 +699,7 @@ static void timing_events(int kind, hipEvent_t* ev0, hipEvent_t* ev1) {
     *ev0 = g_ev[i][0]; *ev1 = g_ev[i][1];
     ++g_timing_n;
 }
-extern "C" int omgx_abi_version(void) { return 10; }  // 10: kinematics pre-pass (k_goalset_kin) behind the `workspace` argument of omgx_goalset_cost / _cost_layer, new trailing `workspace` of _cost_layer_parts / _cost_layer_tiled; 9: omgx_goalset_schedule_ordered (longest first inside an XCD); 8: omgx_goalset_cost_layer_parts, omgx_goalset_schedule_parts (a goal's tiles over several workgroups of the batch kernel); 2: `active` masks; 3: ragged goal sets (goal_count, eta); 4: goal schedule + work; 5: 184-byte object records (influence region = rounded box); 6: omgx_goalset_cost_layer_tiled, omgx_learner_params.cost_parts; 7: pose tables (omgx_pose_table, pointer fields at the end of both parameter blocks, layer_poses)
+extern "C" int omgx_abi_version(void) { return 11; }  // 11: omgx_plan_persistent (K iterations of all scenes in one launch); 10: kinematics pre-pass (k_goalset_kin) behind the `workspace` argument of omgx_goalset_cost / _cost_layer, new trailing `workspace` of _cost_layer_parts / _cost_layer_tiled; 9: omgx_goalset_schedule_ordered (longest first inside an XCD); 8: omgx_goalset_cost_layer_parts, omgx_goalset_schedule_parts (a goal's tiles over several workgroups of the batch kernel); 2: `active` masks; 3: ragged goal sets (goal_count, eta); 4: goal schedule + work; 5: 184-byte object records (influence region = rounded box); 6: omgx_goalset_cost_layer_tiled, omgx_learner_params.cost_parts; 7: pose tables (omgx_pose_table, pointer fields at the end of both parameter blocks, layer_poses)
 // One call for "copy these bytes back and wait": hipMemcpyAsync (device -> pinned host) + hipStreamSynchronize on the caller's stream
 // — the last step of a planner iteration through the drop-in classes (device_loop.DeviceLoop), where two framework calls cost the
 // host more than the copy itself.
@@ -1371,4 +1376,127 @@ extern "C" int omgx_goalset_cost_layer_tiled(const double* robot, int32_t n_poin
                              num_goals, num_goals > 0 ? n_remaining : 1, time_interval, soften_fingers, goal_cost, nullptr, collides, workspace, traj,
                              n_waypoints, layer_soften_fingers, layer_potentials, layer_grads, layer_collides, active, goal_count, nullptr,
                              0, nullptr, stream, tl);
+}
+
+// =================================================================================================
+// (9) omgx_plan_persistent — K planner iterations for all scenes in one launch (omg_persist.h)
+// =================================================================================================
+#include "omg_chomp_body.h"   // float64 code, contract(fast) from here on: nothing float32 may follow but what was parsed above
+#include "omg_persist.h"
+#pragma clang fp contract(off)
+
+static inline int64_t persist_ring_cap(int32_t S) { return ((int64_t)S + 63) & ~63ll; }
+
+extern "C" int64_t omgx_plan_persistent_workspace_bytes(int32_t num_scenes, int32_t n_waypoints) {
+    if (num_scenes <= 0 || n_waypoints <= 0) return 0;
+    // ring [cap] u64 | claim words [8] u64 | control [8] u32 | arrivals [S] u32 (padded to 8 bytes) | gradient rows [S][n][10][8] f64
+    return persist_ring_cap(num_scenes) * 8 + 64 + 32 + (((int64_t)num_scenes * 4 + 7) & ~7ll) + (int64_t)num_scenes * n_waypoints * 80 * 8;
+}
+
+extern "C" int omgx_plan_persistent_status(const void* workspace, int32_t num_scenes, int32_t* h_status /* [4]: failure code, scenes finished, scenes planned, activations made */, void* stream) {
+    if (!workspace || !h_status || num_scenes <= 0) return OMGX_ERR_INVALID;
+    const char* base = reinterpret_cast<const char*>(workspace) + persist_ring_cap(num_scenes) * 8 + 64;
+    uint32_t ctl[8];
+    hipError_t e = hipMemcpyAsync(ctl, base, sizeof(ctl), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) return omgx_set_error("omgx_plan_persistent_status", e);
+    h_status[0] = (int32_t)ctl[3]; h_status[1] = (int32_t)ctl[2]; h_status[2] = (int32_t)ctl[4]; h_status[3] = (int32_t)ctl[0];
+    return OMGX_OK;
+}
+
+extern "C" int omgx_plan_persistent(const double* robot, int32_t n_points, const omgx_object* objects, const int32_t* scene_begin,
+                                    const float* sdf_pool, const double* goals, int32_t num_scenes, int32_t num_goals,
+                                    double time_interval, int32_t soften_fingers, float* goal_cost, float* collides, double* traj,
+                                    int32_t n_waypoints, int32_t layer_soften_fingers, float* layer_potentials, float* layer_grads,
+                                    float* layer_collides, double* layer_poses, int32_t* active, const int32_t* goal_count,
+                                    const omgx_learner_params* h_learner, const double* goal_set, const double* reach,
+                                    double* learner_state, int32_t* goal_idx, double* cost_vector, const double* eta,
+                                    const omgx_chomp_params* h_params, const double* start, double* end, double* goal,
+                                    double* goal_point, double* grad, double* cost_traj, double* info,
+                                    const omgx_plan_iter* h_iters, const omgx_plan_iter* d_iters, int32_t num_iters,
+                                    void* workspace, int64_t workspace_bytes, int32_t max_workgroups, void* stream) {
+    using namespace omg_persist;
+    if (num_scenes < 0 || num_iters < 0 || !h_learner || !h_params || !h_iters || !d_iters) return OMGX_ERR_INVALID;
+    if (num_scenes == 0 || num_iters == 0) return OMGX_OK;
+    if (!robot || !objects || !scene_begin || !traj || !layer_potentials || !layer_grads || !layer_collides || !layer_poses || !start ||
+        !end || !goal || !goal_point || !grad || !cost_traj || !info || !workspace)
+        return OMGX_ERR_INVALID;
+    if (num_scenes > 65535 || num_iters > 65535) return OMGX_ERR_UNSUPPORTED;  // an activation word holds 16 bits of each
+    if (n_points < 1 || n_points > OMGX_MAX_POINTS || n_waypoints < 1 || n_waypoints > OMGX_MAX_WAYPOINTS) return OMGX_ERR_UNSUPPORTED;
+    if (!(time_interval > 0.0)) return OMGX_ERR_INVALID;
+    if (workspace_bytes < omgx_plan_persistent_workspace_bytes(num_scenes, n_waypoints)) return OMGX_ERR_INVALID;
+    const omgx_chomp_params& cp = *h_params;
+    if (cp.n_waypoints != n_waypoints || cp.n_points != n_points || cp.constraint_num < 1 || cp.constraint_num > OMGX_MAX_CONSTRAINTS ||
+        cp.constraint_num > cp.n_waypoints || cp.top_k < 0)
+        return OMGX_ERR_INVALID;
+    // the step runs inside a goal workgroup's footprint: every pose it needs is handed over (omgx_chomp_params / omgx_learner_params, ABI 7)
+    if (!cp.start_poses || !cp.end_poses) return OMGX_ERR_INVALID;
+    bool any_select = false;
+    int min_start = n_waypoints;
+    for (int k = 0; k < num_iters; ++k) {
+        const omgx_plan_iter& r = h_iters[k];
+        if (r.mode < 0 || r.mode > 1 || r.start_idx < 0 || r.start_idx >= n_waypoints || r.do_update < 0 || r.do_update > 2) return OMGX_ERR_INVALID;
+        if (r.mode) { any_select = true; if (r.start_idx < min_start) min_start = r.start_idx; }
+    }
+    omg_learner::LearnerArgs la{};
+    if (any_select) {
+        if (num_goals < 1 || !goals || !goal_cost || !goal_set || !learner_state || !goal_idx) return OMGX_ERR_INVALID;
+        if (h_learner->alg == OMGX_ALG_PROJ) return OMGX_ERR_UNSUPPORTED;  // no goal-set batch to ride on: the per-iteration launches serve it
+        if (!h_learner->goal_pose_table || !h_learner->end_poses_out) return OMGX_ERR_INVALID;
+        if (h_learner->cost_parts > 1 || h_learner->n_waypoints != n_waypoints || h_learner->constraint_num != cp.constraint_num) return OMGX_ERR_INVALID;
+        const int rc = omg_learner::make_args(h_learner, traj, goal_set, reach, goal_cost, learner_state, num_scenes, goal_idx, end, goal,
+                                              goal_point, cost_vector, nullptr, goal_count, eta, la);
+        if (rc != OMGX_OK) return rc;
+        if (h_learner->num_goals != num_goals) return OMGX_ERR_INVALID;
+    }
+    PersistArgs pa{};
+    ChunkArgs& ca = pa.ca;
+    ca.robot = robot; ca.objects = objects; ca.scene_begin = scene_begin; ca.pool = sdf_pool;
+    ca.S = num_scenes; ca.NCH = num_goals; ca.NG = num_goals; ca.NP = 1; ca.P = n_points; ca.soften = soften_fingers != 0;
+    ca.arc = 1; ca.inv_dt = (float)(1.0 / time_interval);
+    ca.chunk_cost = goal_cost; ca.chunk_col = collides;
+    ca.ts_stride = (int64_t)n_waypoints * 9; ca.goals = goals;
+    ca.wp_traj = traj; ca.wp_n = n_waypoints; ca.wp_soften = layer_soften_fingers != 0;
+    ca.wp_pot = layer_potentials; ca.wp_grad = layer_grads; ca.wp_col = layer_collides; ca.wp_pose_out = layer_poses;
+    ca.goal_count = goal_count; ca.LPW = 10;
+    ca.layer_lg = 5; ca.layer_nb = 1; ca.layer_cb = n_waypoints; ca.layer_parts = 5;
+    pa.la = la;
+    ChompArgs& ch = pa.ch;
+    ch.robot = robot; ch.prm = cp; ch.traj = traj; ch.start = start; ch.end = end; ch.goal = goal; ch.goal_point = goal_point;
+    ch.pot = layer_potentials; ch.pgrad = layer_grads; ch.col = layer_collides; ch.grad = grad; ch.cost_traj = cost_traj; ch.info = info;
+    ch.prm.waypoint_poses = layer_poses;  // the layer items of this launch leave them there
+    pa.iters = d_iters; pa.num_iters = num_iters; pa.G = num_goals; pa.active = active;
+    char* w = reinterpret_cast<char*>(workspace);
+    pa.cap = (int)persist_ring_cap(num_scenes);
+    pa.ring = reinterpret_cast<unsigned long long*>(w); w += (size_t)pa.cap * 8;
+    pa.xw = reinterpret_cast<unsigned long long*>(w); w += 64;
+    pa.ctl = reinterpret_cast<uint32_t*>(w); w += 32;
+    pa.arrive = reinterpret_cast<uint32_t*>(w); w += ((size_t)num_scenes * 4 + 7) & ~(size_t)7;
+    ch.light_scratch = reinterpret_cast<double*>(w);
+    // dynamic LDS: the goal workgroup's layout for the longest window of the plan, or what the learner / the light step carve from the same block
+    const int CHmax = any_select ? n_waypoints - min_start : 1;
+    const int PS = CHmax + 1 > n_waypoints ? CHmax + 1 : n_waypoints, MR = CHmax > n_waypoints ? CHmax : n_waypoints;
+    size_t lds = (size_t)GqLayout(PS, MR, n_points, gq_choose_tbl_n(PS, MR, n_points)).total;
+    const size_t light = chomp_light_lds_bytes(n_waypoints, n_points), learner = (size_t)(5 * OMGX_MAX_GOALS + 5 * 128 + 2) * sizeof(double);
+    if (lds < light) lds = light;
+    if (lds < learner) lds = learner;
+    lds = (lds + 15) & ~(size_t)15;
+    if (lds > 64 * 1024) return OMGX_ERR_UNSUPPORTED;
+    pa.lds_bytes = (uint32_t)lds;
+    int cus = omgx_device_cu_count();
+    if (cus <= 0) cus = 256;
+    int64_t grid = (int64_t)cus * GQ_WG_PER_CU;
+    const int64_t items = (int64_t)num_scenes * (5 + (any_select ? num_goals : 0));
+    if (grid > items) grid = items;
+    if (max_workgroups > 0 && grid > max_workgroups) grid = max_workgroups;
+    grid = (grid + 7) & ~7ll;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_persist_init, dim3(1), dim3(256), 0, st, pa);
+    OMGX_CHECK_LAUNCH("k_persist_init");
+    hipEvent_t ev0, ev1;
+    timing_events(2, &ev0, &ev1);
+    if (ev0) hipExtLaunchKernelGGL((k_plan_persistent<2>), dim3((unsigned)grid), dim3(GQ_NT), (uint32_t)lds, st, ev0, ev1, 0, pa);
+    else hipLaunchKernelGGL((k_plan_persistent<2>), dim3((unsigned)grid), dim3(GQ_NT), (uint32_t)lds, st, pa);
+    OMGX_CHECK_LAUNCH("k_plan_persistent");
+    return OMGX_OK;
 }

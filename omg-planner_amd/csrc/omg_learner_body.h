@@ -205,6 +205,10 @@ __device__ void bregman_projection(const double* x, const double* v, double delt
 // sh_idx (LDS, optional): receives the chosen goal's index — valid for the workgroup after its next barrier (active scenes only).
 // flag / publish (optional, k_update_optimize_split): the scene's rendezvous word receives (publish << 8) | index the moment the index
 // is known — one relaxed store: whoever waits for it reads nothing but the index and tables that no launch in flight writes.
+// FOUR: a workgroup of FOUR waves (the persistent planner kernel, omg_persist.h).  MD's five experts then share four waves — wave 0 the
+// sharpest expert 4 (7-8 projection passes), wave 1 expert 3, wave 2 experts 2 and 0, wave 3 expert 1 and then the mixture — every
+// expert's projection is still one wave's work from the same inputs: same bits.
+template <bool FOUR = false>
 __device__ __forceinline__ void learner_scene(const LearnerArgs& a, int s, double (*sh_pn)[OMGX_MAX_GOALS], double (*sh_tab)[128], int* sh_idx = nullptr,
                                               uint32_t* flag = nullptr, uint32_t publish = 0u) {
     // The scene's `active` word is REQUESTED here and tested where the first write would happen, behind the requests of the cost vector's
@@ -224,19 +228,24 @@ __device__ __forceinline__ void learner_scene(const LearnerArgs& a, int s, doubl
     double *sum_costs = st, *p = st + GS, *experts_p = st + 2 * GS, *q = st + 7 * GS, *ecost = st + 7 * GS + 5;
     const double* gs = a.goal_set + (int64_t)s * GS * 9;
     // MD: this wave's expert distribution (last iteration's), requested with everything else (padded lanes: masked at the use)
+    // (FOUR: the wave's experts ex0 [, ex1]; else expert = wave)
+    const int ex0 = FOUR ? (wave == 0 ? 4 : (wave == 1 ? 3 : (wave == 2 ? 2 : 1))) : (wave < 5 ? wave : -1);
+    const int ex1 = (FOUR && wave == 2) ? 0 : -1;
     double epw_pre[NPL] = {0, 0, 0, 0};
-    if (prm.alg == OMGX_ALG_MD && wave < 5) {
+    double epw_pre1[FOUR ? NPL : 1] = {};
+    if (prm.alg == OMGX_ALG_MD && ex0 >= 0) {
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {
             const int g = lane + 64 * j;
-            if (g < GS) epw_pre[j] = experts_p[(int64_t)wave * GS + g];
+            if (g < GS) epw_pre[j] = experts_p[(int64_t)ex0 * GS + g];
+            if constexpr (FOUR) if (ex1 >= 0 && g < GS) epw_pre1[j] = experts_p[(int64_t)ex1 * GS + g];
         }
     }
     // ... and the mixture's state (wave 0, lanes 0-4: expert k's weight and last cost)
     // The wave that runs the mixture update and everything behind it: NOT one that shares a SIMD with the sharpest expert's wave 4
     // (waves w and w + 4 do: on wave 0 the mixture's divisions and exponentials slowed that expert's passes by what they hid) — wave 5,
     // beside expert 1's wave, which finishes early; workgroups of five waves (k_goal_update) keep wave 0.
-    const int mixw = (prm.alg == OMGX_ALG_MD && blockDim.x >= 384) ? 5 : 0;
+    const int mixw = FOUR ? (prm.alg == OMGX_ALG_MD ? 3 : 0) : ((prm.alg == OMGX_ALG_MD && blockDim.x >= 384) ? 5 : 0);
     const int kk_pre = lane < 5 ? lane : 0;
     double q_pre = 0.0, ecost_pre = 0.0;
     if (prm.alg == OMGX_ALG_MD && wave == mixw) { q_pre = q[kk_pre]; ecost_pre = ecost[kk_pre]; }
@@ -333,12 +342,15 @@ __device__ __forceinline__ void learner_scene(const LearnerArgs& a, int s, doubl
             int* const expert_done = reinterpret_cast<int*>(&sh_tab[0][8]);  // [5]
             if (threadIdx.x < 5) expert_done[threadIdx.x] = 0;
             __syncthreads();
-            if (wave < 5) {  // waves 0..4: Bregman projection of their own expert (reads the OLD experts_p, like the reference)
+            for (int q = 0; q < (FOUR ? 2 : 1); ++q) {  // waves 0..4: Bregman projection of their own expert (reads the OLD experts_p, like the reference)
+                const int ex = q == 0 ? ex0 : ex1;
+                if (ex < 0) break;
                 double v[NPL], epw[NPL], pn[NPL];
                 for (int j = 0; j < NPL; ++j) {
                     const int g = lane + 64 * j;
-                    v[j] = eta * pw[wave] * cv[j];
-                    epw[j] = g < G ? epw_pre[j] : 0.0;
+                    v[j] = eta * pw[ex] * cv[j];
+                    if constexpr (FOUR) epw[j] = g < G ? (q == 0 ? epw_pre[j] : epw_pre1[j]) : 0.0;
+                    else epw[j] = g < G ? epw_pre[j] : 0.0;
                 }
                 LPHASE(1, 4);
                 bregman_projection(epw, v, delta, G, lane, pn);
@@ -347,12 +359,12 @@ __device__ __forceinline__ void learner_scene(const LearnerArgs& a, int s, doubl
                 double part2 = 0.0;
                 for (int j = 0; j < NPL; ++j) {
                     const int g = lane + 64 * j;
-                    if (g < G) { sh_pn[wave][g] = pn[j]; part2 += cv[j] * pn[j] + fabs(pn[j] - epw[j]); }
+                    if (g < G) { sh_pn[ex][g] = pn[j]; part2 += cv[j] * pn[j] + fabs(pn[j] - epw[j]); }
                 }
                 const double ecw = wsum(part2);
                 if (lane == 0) {
-                    sh_tab[wave][0] = ecw;
-                    __hip_atomic_store(expert_done + wave, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);  // (a wave's LDS stores execute in order)
+                    sh_tab[ex][0] = ecw;
+                    __hip_atomic_store(expert_done + ex, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);  // (a wave's LDS stores execute in order)
                 }
             }
             LPHASE(3, 4);

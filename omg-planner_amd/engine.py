@@ -802,6 +802,75 @@ class ChompEngine:
         self._step(True, None, stop_on_terminate=stop)
 
     # ---------------------------------------------------------------------------------------------
+    # The persistent planner launch (omgx_plan_persistent, csrc/omg_persist.h): K iterations of iterate() for all scenes in ONE
+    # launch, scheduled by the per-scene dependency instead of by launch boundaries.  Bit for bit what K calls of iterate() compute.
+    PERSISTENT_ALGS = ("FTL", "FTC", "Exp", "MD")
+
+    def persistent_ok(self) -> bool:
+        """Can run_persistent() serve this engine?  Batch layout with whole goals, an online-learning rule with a goal-set batch
+        (or fixed-goal iterations only), the pose hand-over available."""
+        return (not self.latency and self.goal_parts == 1 and not self.separate_launches and self.stream is None and self.S <= 65535)
+
+    def _iter_table(self, ts, early_stop: bool, pin_window: bool):
+        """The omgx_plan_iter records of iterate(t) for t in ts — and, like the calls it replaces, the host-side counters advance:
+        Learner.t, Optimizer.update's schedule (omg/optimizer.py:59-80)."""
+        cfg = self.cfg
+        recs = (_lib.PlanIter * len(ts))()
+        for k, t in enumerate(ts):
+            select = bool(cfg.goal_set_proj and t < cfg.optim_steps and self.ol_alg not in ("Baseline", "Proj"))
+            r = recs[k]
+            if select:
+                if pin_window:
+                    self.t = 0
+                self.t += 1
+                r.start_idx = min(int((self.t / cfg.optim_steps) * cfg.timesteps), cfg.timesteps - 1)  # online_learner.py:109-110
+            r.mode = int(select)
+            self._schedule()
+            r.obstacle_weight, r.smoothness_weight, r.step_size = float(cfg.obstacle_weight), float(cfg.smoothness_weight), float(cfg.step_size)
+            r.do_update = 1
+            r.stop_on_terminate = int(bool(early_stop and t > 0))
+        return recs
+
+    def run_persistent(self, ts, early_stop: bool = False, pin_window: bool = False, max_workgroups: int = 0):
+        """iterate(t, early_stop) for every t of `ts`, in order, as ONE launch on the current stream (no host sync).  pin_window: the
+        learner's window stays at its first-iteration size (bench.py's step: Learner.t = 0 before every iteration)."""
+        if not self.persistent_ok():
+            raise ValueError("run_persistent: batch layout with whole goals on the current stream only")
+        ts = [int(t) for t in ts]
+        if not ts:
+            return
+        self.join()
+        if any(self.cfg.goal_set_proj and t < self.cfg.optim_steps for t in ts) and self.ol_alg not in self.PERSISTENT_ALGS and self.ol_alg not in ("Baseline", "Proj"):
+            raise ValueError(f"run_persistent: ol_alg {self.ol_alg!r}")
+        if not self._poses_on:
+            self._refresh_pose_tables()
+            self._poses_on = True
+        if early_stop:
+            self._masked = True
+        recs = self._iter_table(ts, early_stop, pin_window)
+        raw = bytes(recs)
+        cache = self.__dict__.setdefault("_persist_tables", {})
+        d_iters = cache.get(raw)
+        if d_iters is None:
+            if len(cache) > 64:
+                cache.clear()
+            d_iters = cache[raw] = torch.from_numpy(np.frombuffer(raw, np.uint8).copy()).to(self.device)
+        ws = self.__dict__.get("_persist_ws")
+        if ws is None:
+            ws = self._persist_ws = torch.zeros(int(_lib.lib().omgx_plan_persistent_workspace_bytes(self.S, self.n)), dtype=torch.uint8, device=self.device)
+        lprm = self._learner_params()
+        lprm.cost_parts = 0
+        self._parts_last = 1
+        ops.plan_persistent(self.robot, self.P, self.scenes, self.cv_goals, self.cfg.time_interval, self.traj, (self.pot, self.pgrad, self.col),
+                            self.wp_pose, (self.goal_cost, self.goal_col), lprm, self.goal_set, self.reach, self.learner_state, self.goal_idx,
+                            self.cost_vec, self._params(True), self.start, self.end, self.goal_rows, self.goal_point,
+                            (self.grad, self.cost_traj, self.info), recs, d_iters, ws, active=self._mask(), goal_count=self.goal_count, eta=self.eta_s,
+                            soften_fingers=False, layer_soften_fingers=self.cfg.uncheck_finger_collision == -1, max_workgroups=max_workgroups)
+
+    def persistent_status(self) -> dict:
+        return ops.plan_persistent_status(self._persist_ws, self.S)
+
+    # ---------------------------------------------------------------------------------------------
     _STATE = ("traj", "end", "goal_rows", "goal_point", "goal_idx", "learner_state", "info", "active", "goal_cost", "goal_col",
               "cost_vec", "grad", "cost_traj", "pot", "pgrad", "col", "end_pose")
 

@@ -835,6 +835,60 @@ class IterationCalls:
                 check(self._f_up(*args), "omgx_goal_update_optimize")
 
 
+def plan_persistent(robot, P, scenes: DeviceScenes, goals, dt, traj, layer_out, layer_poses, goal_out, lparams: LearnerParams, goal_set, reach,
+                    state, goal_idx, cost_vector, params: ChompParams, start, end, goal_rows, goal_point, step_out, iters, d_iters, workspace,
+                    active=None, goal_count=None, eta=None, soften_fingers=False, layer_soften_fingers=False, max_workgroups=0):
+    """omgx_plan_persistent: len(iters) iterations of the planner loop (omg/planner.py:612-630) for every scene in ONE launch
+    (csrc/omg_persist.h) on the current stream.  iters: a ctypes array of _lib.PlanIter (host); d_iters: a uint8 device tensor holding the
+    same bytes; workspace: uint8 device tensor of omgx_plan_persistent_workspace_bytes(S, n).  The same tensors as
+    goalset_cost_layer() + goal_update_optimize(); the pose hand-over (params.start_poses / end_poses, lparams.goal_pose_table /
+    end_poses_out, layer_poses) is required."""
+    lp, lg, lc = layer_out
+    cost, col = goal_out
+    grad, cost_traj, info = step_out
+    for n_, t in (("goals", goals), ("traj", traj), ("goal_set", goal_set), ("state", state), ("start", start), ("end", end),
+                  ("goal", goal_rows), ("goal_point", goal_point), ("grad", grad), ("cost_traj", cost_traj), ("info", info),
+                  ("layer_poses", layer_poses)):
+        _need(t, torch.float64, n_)
+    if reach is not None:
+        _need(reach, torch.float64, "reach")
+    if cost_vector is not None:
+        _need(cost_vector, torch.float64, "cost_vector")
+    for n_, t in (("layer potentials", lp), ("layer grads", lg), ("layer collides", lc), ("goal_cost", cost), ("goal collides", col)):
+        _need(t, torch.float32, n_)
+    S, G, n = goals.shape[0], goals.shape[1], traj.shape[1]
+    if traj.shape[0] != S or lp.numel() != S * n * 10 * P or lg.numel() != 3 * lp.numel() or lc.numel() != lp.numel() or layer_poses.numel() != S * n * 120:
+        raise _lib.OmgHipError("layer outputs must be [S,n,10,P], [S,n,10,P,3], [S,n,10,P], layer_poses [S,n,10,12]")
+    if cost.numel() < S * G or col.numel() < S * G:
+        raise _lib.OmgHipError("goal_cost / collides must hold S * G elements")
+    if goal_idx.dtype != torch.int32 or not goal_idx.is_cuda or goal_idx.numel() != S:
+        raise _lib.OmgHipError("goal_idx must be an int32 device tensor [S]")
+    _active(active, S); _active(goal_count, S); _eta(eta, S)
+    K = len(iters)
+    if not (d_iters.is_cuda and d_iters.dtype == torch.uint8 and d_iters.numel() >= K * C.sizeof(_lib.PlanIter)):
+        raise _lib.OmgHipError("d_iters must be a uint8 device tensor holding the iteration table")
+    l = _lib.lib()
+    need = l.omgx_plan_persistent_workspace_bytes(S, n)
+    if not (workspace.is_cuda and workspace.dtype == torch.uint8 and workspace.numel() >= need):
+        raise _lib.OmgHipError(f"workspace must be a uint8 device tensor of {need} bytes")
+    with torch.cuda.device(traj.device):
+        check(l.omgx_plan_persistent(_ptr(robot), int(P), _ptr(scenes.objects), _ptr(scenes.scene_begin), _ptr(scenes.pool), _ptr(goals), S, G,
+                                     float(dt), int(bool(soften_fingers)), _ptr(cost), _ptr(col), _ptr(traj), n, int(bool(layer_soften_fingers)),
+                                     _ptr(lp), _ptr(lg), _ptr(lc), _ptr(layer_poses), _ptr(active), _ptr(goal_count),
+                                     C.byref(lparams), _ptr(goal_set), _ptr(reach), _ptr(state), _ptr(goal_idx), _ptr(cost_vector), _ptr(eta),
+                                     C.byref(params), _ptr(start), _ptr(end), _ptr(goal_rows), _ptr(goal_point), _ptr(grad), _ptr(cost_traj), _ptr(info),
+                                     iters, _ptr(d_iters), K, _ptr(workspace), workspace.numel(), int(max_workgroups), _stream()),
+              "omgx_plan_persistent")
+
+
+def plan_persistent_status(workspace, num_scenes: int) -> dict:
+    """{"failure", "scenes_finished", "scenes_planned", "activations"} of the last omgx_plan_persistent on `workspace` (synchronises)."""
+    st = (C.c_int32 * 4)()
+    with torch.cuda.device(workspace.device):
+        check(_lib.lib().omgx_plan_persistent_status(_ptr(workspace), int(num_scenes), st, _stream()), "omgx_plan_persistent_status")
+    return {"failure": int(st[0]), "scenes_finished": int(st[1]), "scenes_planned": int(st[2]), "activations": int(st[3])}
+
+
 def point_cloud_sdf(points: torch.Tensor, grid_resolution: float = 0.02, margin: float = 0.24, out: "torch.Tensor | None" = None):
     """PointEnv.compute_sdf_from_points (omg/core.py:426-457) on the device: points [N,3] f64 (robot base frame) ->
     (grid float32 [X,Y,Z] of nearest-point distances, origin [3] float64 numpy, resolution).  The workspace bounds

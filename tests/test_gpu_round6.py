@@ -50,3 +50,112 @@ def test_more_objects_than_mask_bits(dev, latency):
     eng2 = ChompEngine(model, batch, copy.deepcopy(cfg), start, goals, device=dev, ol_alg="MD", latency_mode=latency)
     out = engine_vs_oracle(eng2, batch, [0, 1], steps=3, pin_window=False)
     assert out["ok"] and out["max_traj_err"] < 1e-6, out
+
+
+# ------------------------------------------------------------------------------------------------
+# omgx_plan_persistent: K iterations of every scene in one launch == K x (omgx_goalset_cost_layer + omgx_goal_update_optimize)
+# ------------------------------------------------------------------------------------------------
+_CMP = ("traj", "info", "learner_state", "goal_idx", "grad", "cost_traj", "pot", "pgrad", "col", "goal_cost", "goal_col", "end", "goal_rows",
+        "goal_point", "cost_vec", "end_pose", "wp_pose")
+
+
+def _pair(dev, S, G, n, alg, objects=4, grid=24, standoff=False, goal_counts=None, cfg_over=None):
+    import bench
+    from omg_planner_amd import scenes as sc
+    from omg_planner_amd.engine import ChompEngine
+    cfg, model, batch, start, goals = bench.build_workload(S, G, n, grid, 3, False, num_objects=objects)
+    for k, v in (cfg_over or {}).items():
+        setattr(cfg, k, v)
+    reach = None
+    if standoff:
+        cfg.use_standoff = True
+        c = cfg.reach_tail_length
+        reach = np.stack([[np.concatenate([sc.linear_init(g - np.array([0.1, -0.05, 0.1, 0.15, 0, -0.1, 0.1, 0, 0]), g, c - 1), g[None]], 0) for g in goals[s]]
+                          for s in range(S)])
+    mk = lambda: ChompEngine(model, batch, copy.deepcopy(cfg), start, goals, reach_grasps=reach, device=dev, ol_alg=alg, goal_counts=goal_counts)
+    return mk(), mk()
+
+
+def _same(a, b, what=""):
+    torch.cuda.synchronize()
+    for k in _CMP:
+        x, y = getattr(a, k), getattr(b, k)
+        assert torch.equal(x, y), (what, k, float((x.double() - y.double()).abs().max()))
+    assert a.t == b.t and a.step_count == b.step_count
+
+
+@pytest.mark.parametrize("alg,S,G,max_wg", [("MD", 6, 16, 0), ("FTL", 3, 9, 0), ("Exp", 9, 5, 24), ("FTC", 2, 33, 8), ("MD", 17, 12, 40)])
+def test_persistent_launch_equals_the_iterations_it_replaces(dev, alg, S, G, max_wg):
+    """run_persistent(range(K)) against K calls of iterate(): every tensor the iterations leave, bit for bit — with all of the
+    chip's slots and with a handful of workgroups (long queues, every scene migrating between XCDs)."""
+    a, b = _pair(dev, S, G, 30, alg)
+    for e in (a, b):
+        e.select_initial_goal()
+        e.pose_hand_over(True)
+    K = 12
+    for t in range(K):
+        a.iterate(t)
+    b.run_persistent(range(K), max_workgroups=max_wg)
+    _same(a, b, "first launch")
+    st = b.persistent_status()
+    assert st["failure"] == 0 and st["scenes_finished"] == S == st["scenes_planned"] and st["activations"] == S * K, st
+    # a second launch from where the first one ended (the queue is re-initialised by every call)
+    for t in range(K, K + 5):
+        a.iterate(t)
+    b.run_persistent(range(K, K + 5), max_workgroups=max_wg)
+    _same(a, b, "second launch")
+
+
+def test_persistent_launch_fixed_goal_iterations_and_early_stop(dev):
+    """A whole plan's iteration sequence: cfg.optim_steps goal-selecting iterations, then fixed-goal ones (layer + step only), with
+    early stop (planner.py:626: a scene that terminates leaves the loop; active[s] <- 0)."""
+    a, b = _pair(dev, 7, 8, 30, "MD", cfg_over={"optim_steps": 9, "extra_smooth_steps": 6})
+    for e in (a, b):
+        e.select_initial_goal()
+        e.pose_hand_over(True)
+    ts = list(range(15))
+    for t in ts:
+        a.iterate(t, early_stop=True)
+    b.run_persistent(ts, early_stop=True)
+    _same(a, b)
+    assert torch.equal(a.active, b.active)
+
+
+def test_persistent_launch_ragged_goal_sets_and_standoff(dev):
+    a, b = _pair(dev, 5, 12, 30, "MD", standoff=True, goal_counts=[12, 3, 7, 1, 12])
+    for e in (a, b):
+        e.select_initial_goal()
+        e.pose_hand_over(True)
+    for t in range(8):
+        a.iterate(t)
+    b.run_persistent(range(8))
+    _same(a, b)
+
+
+def test_persistent_launch_fifty_waypoints_a_dozen_objects(dev):
+    """BASELINE config 5's shape: 50 waypoints (a goal workgroup's LDS no longer admits five per CU), 12 obstacles + table."""
+    a, b = _pair(dev, 3, 16, 50, "MD", objects=12, grid=32)
+    for e in (a, b):
+        e.select_initial_goal()
+        e.pose_hand_over(True)
+    for t in range(6):
+        a.iterate(t)
+    b.run_persistent(range(6))
+    _same(a, b)
+
+
+def test_persistent_launch_whole_plan_against_the_oracle(dev):
+    """70 iterations in one launch against the oracle-driven loop (no early stop): the persistent path on its own, not only against
+    the launches it replaces."""
+    from omg_planner_amd.engine import ChompEngine
+    from oracle.check import engine_vs_oracle
+    import bench
+    cfg, model, batch, start, goals = bench.build_workload(3, 16, 30, 24, 11, False)
+
+    class Persistent(ChompEngine):
+        def iterate(self, t, early_stop=False):
+            self.run_persistent([t], early_stop)
+    eng = Persistent(model, batch, copy.deepcopy(cfg), start, goals, device=dev, ol_alg="MD")
+    eng.select_initial_goal()
+    out = engine_vs_oracle(eng, batch, [0, 1, 2], steps=20, pin_window=False)
+    assert out["ok"] and out["max_traj_err"] < 1e-6, out
