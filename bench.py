@@ -560,6 +560,12 @@ def main():
         from oracle.check import engine_vs_oracle
         eng.restore(snap)
         parity = engine_vs_oracle(eng, host_batch(), sorted({0, S // 2, S - 1}), steps=3, pin_window=True)
+        # the same sample against the oracle in SOPHUS MODE (the reference kernel's quaternion round trip, which the product path does
+        # not restate): the one knowing deviation as a number on the timed workload; the bar is north_star's 1e-4
+        eng.restore(snap)
+        sm = engine_vs_oracle(eng, host_batch(), sorted({0, S // 2, S - 1}), steps=3, pin_window=True, sophus=True)
+        parity["sophus_mode"] = {k: sm[k] for k in ("max_traj_err", "max_cost_rel_err", "goal_idx_equal", "ok")}
+        parity["ok"] = bool(parity["ok"] and sm["ok"])
 
     ms_per_plan = ms_plan_early = ms_single = ms_single_batch_layout = terminated = ms_graph_early = ms_graph_single = None
     share4 = scene_upd = drop_in = cfg5 = None

@@ -928,8 +928,11 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
             double per_wp = 0.0;
             for (int l = 0; l < 10; ++l) per_wp += L.red[32 + l];
             obs_sum = per_wp * (double)n;
+            // (the weighted obstacle term rounded on its own, then ONE fused multiply-add: written out, because which of the two products
+            // of `a b + c d` the compiler fuses depends on the code around it — the four-wave build chose the other one, 1 ulp)
+            const double w_obs_wp = prm.obstacle_weight * per_wp;
             for (int i = tid; i < n; i += blockDim.x)
-                a.cost_traj[(size_t)s * n + i] = prm.obstacle_weight * per_wp + prm.smoothness_weight * L.sml[i];
+                a.cost_traj[(size_t)s * n + i] = __builtin_fma(prm.smoothness_weight, L.sml[i], w_obs_wp);
             if (a.aux) {
                 double* oc = a.aux + (size_t)s * (n * 9 + n * 10 + n * 9 + n + 1) + n * 9;
                 for (int e = tid; e < n * 10; e += blockDim.x) oc[e] = L.red[32 + e % 10];
@@ -939,7 +942,8 @@ __device__ __forceinline__ void chomp_scene(const ChompArgs& a, unsigned char* s
             for (int i = tid; i < n; i += blockDim.x) {
                 double r = 0.0;
                 for (int l = 0; l < 10; ++l) r += L.gcost[i * 10 + l];
-                a.cost_traj[(size_t)s * n + i] = prm.obstacle_weight * r + prm.smoothness_weight * L.sml[i];
+                const double w_obs_r = prm.obstacle_weight * r;
+                a.cost_traj[(size_t)s * n + i] = __builtin_fma(prm.smoothness_weight, L.sml[i], w_obs_r);
             }
             if (a.aux) {
                 double* oc = a.aux + (size_t)s * (n * 9 + n * 10 + n * 9 + n + 1) + n * 9;

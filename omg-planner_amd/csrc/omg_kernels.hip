@@ -1389,19 +1389,28 @@ static inline int64_t persist_ring_cap(int32_t S) { return ((int64_t)S + 63) & ~
 
 extern "C" int64_t omgx_plan_persistent_workspace_bytes(int32_t num_scenes, int32_t n_waypoints) {
     if (num_scenes <= 0 || n_waypoints <= 0) return 0;
-    // ring [cap] u64 | claim words [8] u64 | control [8] u32 | arrivals [S] u32 (padded to 8 bytes) | gradient rows [S][n][10][8] f64
-    return persist_ring_cap(num_scenes) * 8 + 64 + 32 + (((int64_t)num_scenes * 4 + 7) & ~7ll) + (int64_t)num_scenes * n_waypoints * 80 * 8;
+    // ring [cap] u64 | claim words: 8 x PQ_SLOTS lines of 128 bytes | control: a line | statistics: a line | arrivals [S] u32 (padded to 128 bytes) |
+    // gradient rows [S][n][10][8] f64
+    return persist_ring_cap(num_scenes) * 8 + 8 * PQ_SLOTS * 128 + 128 + 128 + (((int64_t)num_scenes * 4 + 127) & ~127ll) + (int64_t)num_scenes * n_waypoints * 80 * 8;
 }
 
 extern "C" int omgx_plan_persistent_status(const void* workspace, int32_t num_scenes, int32_t* h_status /* [4]: failure code, scenes finished, scenes planned, activations made */, void* stream) {
     if (!workspace || !h_status || num_scenes <= 0) return OMGX_ERR_INVALID;
-    const char* base = reinterpret_cast<const char*>(workspace) + persist_ring_cap(num_scenes) * 8 + 64;
+    const char* base = reinterpret_cast<const char*>(workspace) + persist_ring_cap(num_scenes) * 8 + 8 * PQ_SLOTS * 128;
     uint32_t ctl[8];
     hipError_t e = hipMemcpyAsync(ctl, base, sizeof(ctl), hipMemcpyDeviceToHost, (hipStream_t)stream);
     if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
     if (e != hipSuccess) return omgx_set_error("omgx_plan_persistent_status", e);
     h_status[0] = (int32_t)ctl[3]; h_status[1] = (int32_t)ctl[2]; h_status[2] = (int32_t)ctl[4]; h_status[3] = (int32_t)ctl[0];
     return OMGX_OK;
+}
+// Measurement builds (-DOMGX_PERSIST_STATS; tools/experiments/persist_stats.py): h_stats[8] <- claim spins, item ticks, update ticks, items,
+// updates, claim ticks (ticks of 10 ns, summed over workgroups).  Not part of the ABI.
+extern "C" int omgx_debug_persist_stats(const void* workspace, int32_t num_scenes, unsigned long long* h_stats, void* stream) {
+    const char* base = reinterpret_cast<const char*>(workspace) + persist_ring_cap(num_scenes) * 8 + 8 * PQ_SLOTS * 128 + 128;
+    hipError_t e = hipMemcpyAsync(h_stats, base, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    return e == hipSuccess ? OMGX_OK : omgx_set_error("omgx_debug_persist_stats", e);
 }
 
 extern "C" int omgx_plan_persistent(const double* robot, int32_t n_points, const omgx_object* objects, const int32_t* scene_begin,
@@ -1469,9 +1478,10 @@ extern "C" int omgx_plan_persistent(const double* robot, int32_t n_points, const
     char* w = reinterpret_cast<char*>(workspace);
     pa.cap = (int)persist_ring_cap(num_scenes);
     pa.ring = reinterpret_cast<unsigned long long*>(w); w += (size_t)pa.cap * 8;
-    pa.xw = reinterpret_cast<unsigned long long*>(w); w += 64;
-    pa.ctl = reinterpret_cast<uint32_t*>(w); w += 32;
-    pa.arrive = reinterpret_cast<uint32_t*>(w); w += ((size_t)num_scenes * 4 + 7) & ~(size_t)7;
+    pa.xw = reinterpret_cast<unsigned long long*>(w); w += 8 * PQ_SLOTS * 128;
+    pa.ctl = reinterpret_cast<uint32_t*>(w); w += 128;
+    pa.stats = reinterpret_cast<unsigned long long*>(w); w += 128;
+    pa.arrive = reinterpret_cast<uint32_t*>(w); w += ((size_t)num_scenes * 4 + 127) & ~(size_t)127;
     ch.light_scratch = reinterpret_cast<double*>(w);
     // dynamic LDS: the goal workgroup's layout for the longest window of the plan, or what the learner / the light step carve from the same block
     const int CHmax = any_select ? n_waypoints - min_start : 1;

@@ -100,15 +100,16 @@ __device__ __forceinline__ int warg(double v, int i) {
 // the reference stays finite near the root, a factored exp(L) * sum exp(z_j) would be inf * 0).  exp(L + zmax) at the
 // end is (target / C) exp(d) with |d| <~ 1e-6 (third-order series; the full exp only if the bisection did not converge).
 // Decisions can differ from the reference's floating-point f only when |f| is within ~1e-15 of 0 or of err.
+template <int NPLT = NPL>  // goals per lane: NPLT serves G <= 256; a build for fewer goals holds fewer registers (same bits: padded lanes add exact zeros)
 __device__ void bregman_projection(const double* x, const double* v, double delta, int G, int lane, double* y) {
     const int max_iter = 100;
     const double err = 1e-6;
-    double alpha[NPL] = {0, 0, 0, 0}, shiftx[NPL], lds[NPL], ezs[NPL];
+    double alpha[NPLT] = {}, shiftx[NPLT], lds[NPLT], ezs[NPLT];
     const double target = 1.0 + delta * (double)G;
     const double dlo = log1p(-err / target), dhi = log1p(err / target), ltarget = log(target);
     double vmax = -__builtin_inf();
 #pragma unroll
-    for (int j = 0; j < NPL; ++j) {
+    for (int j = 0; j < NPLT; ++j) {
         const bool ok = lane + 64 * j < G;
         shiftx[j] = x[j] + delta;
         lds[j] = ok ? log(delta / shiftx[j]) : 0.0;
@@ -123,14 +124,14 @@ __device__ void bregman_projection(const double* x, const double* v, double delt
     {
         double zm = -__builtin_inf();
 #pragma unroll
-        for (int j = 0; j < NPL; ++j)
+        for (int j = 0; j < NPLT; ++j)
             if (lane + 64 * j < G) zm = fmax(zm, alpha[j] - v[j]);
         zmax = wmax(zm);
     }
     for (int it = 0; it < max_iter; ++it) {
         double partC = 0.0;
 #pragma unroll
-        for (int j = 0; j < NPL; ++j)
+        for (int j = 0; j < NPLT; ++j)
             if (lane + 64 * j < G) { ezs[j] = exp((alpha[j] - v[j]) - zmax); partC += shiftx[j] * ezs[j]; }
         const double Csum = wsum(partC);
         const double lstar = ltarget - log(Csum);  // L + zmax at the root
@@ -171,9 +172,9 @@ __device__ void bregman_projection(const double* x, const double* v, double delt
         // exp(L + zmax) = exp(lstar) exp(d) = (target / Csum) exp(d)
         const double ed = converged ? 1.0 + d * (1.0 + d * (0.5 + d * (1.0 / 6.0))) : exp(d);
         const double EL = (target / Csum) * ed;
-        double nrm = 0.0, ap[NPL];
+        double nrm = 0.0, ap[NPLT];
 #pragma unroll
-        for (int j = 0; j < NPL; ++j) {
+        for (int j = 0; j < NPLT; ++j) {
             const bool ok = lane + 64 * j < G;
             y[j] = ok ? shiftx[j] * (EL * ezs[j]) - delta : 0.0;  // shiftx exp(L + alpha - v) - delta
             ap[j] = ok ? fmax(0.0, v[j] - L + lds[j]) : 0.0;
@@ -182,22 +183,22 @@ __device__ void bregman_projection(const double* x, const double* v, double delt
         LCOUNT(8, it + 1);
         double zm_next = -__builtin_inf();
 #pragma unroll
-        for (int j = 0; j < NPL; ++j)
+        for (int j = 0; j < NPLT; ++j)
             if (lane + 64 * j < G) zm_next = fmax(zm_next, ap[j] - v[j]);
         const double nrm_all = wsum(nrm), zmax_next = wmax(zm_next);
         // sqrt(x) < 1e-6 (np.linalg.norm(alpha - alpha_prime) < err) <=> x < 0x1.19799812dea10p-40, the smallest double whose
         // correctly rounded root reaches 1e-6 (sqrt is monotone; NaN fails both)
         if (nrm_all < 0x1.19799812dea10p-40) break;
 #pragma unroll
-        for (int j = 0; j < NPL; ++j) alpha[j] = ap[j];
+        for (int j = 0; j < NPLT; ++j) alpha[j] = ap[j];
         zmax = zmax_next;
     }
     double part = 0.0;
 #pragma unroll
-    for (int j = 0; j < NPL; ++j) { y[j] = fmax(y[j], 0.0); part += y[j]; }
+    for (int j = 0; j < NPLT; ++j) { y[j] = fmax(y[j], 0.0); part += y[j]; }
     const double sy = wsum(part);
 #pragma unroll
-    for (int j = 0; j < NPL; ++j) y[j] /= sy;
+    for (int j = 0; j < NPLT; ++j) y[j] /= sy;
 }
 
 
@@ -208,7 +209,7 @@ __device__ void bregman_projection(const double* x, const double* v, double delt
 // FOUR: a workgroup of FOUR waves (the persistent planner kernel, omg_persist.h).  MD's five experts then share four waves — wave 0 the
 // sharpest expert 4 (7-8 projection passes), wave 1 expert 3, wave 2 experts 2 and 0, wave 3 expert 1 and then the mixture — every
 // expert's projection is still one wave's work from the same inputs: same bits.
-template <bool FOUR = false>
+template <bool FOUR = false, int NPLT = NPL>  // NPLT: goals per lane this instantiation serves (G <= 64 NPLT)
 __device__ __forceinline__ void learner_scene(const LearnerArgs& a, int s, double (*sh_pn)[OMGX_MAX_GOALS], double (*sh_tab)[128], int* sh_idx = nullptr,
                                               uint32_t* flag = nullptr, uint32_t publish = 0u) {
     // The scene's `active` word is REQUESTED here and tested where the first write would happen, behind the requests of the cost vector's
@@ -223,7 +224,14 @@ __device__ __forceinline__ void learner_scene(const LearnerArgs& a, int s, doubl
     // in a ragged batch computes exactly what it would compute alone (padded lanes contribute exact zeros)
     const int GS = prm.num_goals, n = prm.n_waypoints, c = prm.constraint_num;
     const int G = a.goal_count ? min(max(a.goal_count[s], 1), GS) : GS;
-    const double eta = a.eta ? a.eta[s] : prm.eta;
+    // (not `a.eta ? a.eta[s] : prm.eta`: the compiler makes that a select between two ADDRESSES — one of them a stack copy of prm.eta
+    // read through the flat aperture; the empty asm keeps the loaded value a value)
+    double eta = prm.eta;
+    if (a.eta) {
+        double es = a.eta[s];
+        asm volatile("" : "+v"(es));
+        eta = es;
+    }
     double* st = a.state + (int64_t)s * (7 * (int64_t)GS + 10);
     double *sum_costs = st, *p = st + GS, *experts_p = st + 2 * GS, *q = st + 7 * GS, *ecost = st + 7 * GS + 5;
     const double* gs = a.goal_set + (int64_t)s * GS * 9;
@@ -231,11 +239,11 @@ __device__ __forceinline__ void learner_scene(const LearnerArgs& a, int s, doubl
     // (FOUR: the wave's experts ex0 [, ex1]; else expert = wave)
     const int ex0 = FOUR ? (wave == 0 ? 4 : (wave == 1 ? 3 : (wave == 2 ? 2 : 1))) : (wave < 5 ? wave : -1);
     const int ex1 = (FOUR && wave == 2) ? 0 : -1;
-    double epw_pre[NPL] = {0, 0, 0, 0};
-    double epw_pre1[FOUR ? NPL : 1] = {};
+    double epw_pre[NPLT] = {};
+    double epw_pre1[FOUR ? NPLT : 1] = {};
     if (prm.alg == OMGX_ALG_MD && ex0 >= 0) {
 #pragma unroll
-        for (int j = 0; j < NPL; ++j) {
+        for (int j = 0; j < NPLT; ++j) {
             const int g = lane + 64 * j;
             if (g < GS) epw_pre[j] = experts_p[(int64_t)ex0 * GS + g];
             if constexpr (FOUR) if (ex1 >= 0 && g < GS) epw_pre1[j] = experts_p[(int64_t)ex1 * GS + g];
@@ -255,7 +263,7 @@ __device__ __forceinline__ void learner_scene(const LearnerArgs& a, int s, doubl
         const double* last = a.traj + ((int64_t)s * n + n - 1) * 9;
         double best = OMG_ARG_NEUTRAL_MIN;
         int bi = 0x7fffffff;
-        for (int j = 0; j < NPL; ++j) {
+        for (int j = 0; j < NPLT; ++j) {
             const int g = lane + 64 * j;
             if (g < G) {
                 double d2 = 0.0;
@@ -265,12 +273,12 @@ __device__ __forceinline__ void learner_scene(const LearnerArgs& a, int s, doubl
             }
         }
         idx = warg<true>(best, bi);
-        for (int j = 0; j < NPL; ++j) { const int g = lane + 64 * j; if (g < G) p[g] = (g == idx) ? 1.0 : 0.0; }
+        for (int j = 0; j < NPLT; ++j) { const int g = lane + 64 * j; if (g < G) p[g] = (g == idx) ? 1.0 : 0.0; }
     } else {
         const double* ts = a.traj + ((int64_t)s * n + prm.start_idx) * 9;
-        double cv[NPL];
+        double cv[NPLT];
         double part = 0.0;
-        for (int j = 0; j < NPL; ++j) {
+        for (int j = 0; j < NPLT; ++j) {
             const int g = lane + 64 * j;
             cv[j] = 0.0;
             if (g < G) {
@@ -292,16 +300,16 @@ __device__ __forceinline__ void learner_scene(const LearnerArgs& a, int s, doubl
         }
         if (prm.normalize_cost) {
             const double nn = sqrt(wsum(part));
-            for (int j = 0; j < NPL; ++j) cv[j] /= nn;
+            for (int j = 0; j < NPLT; ++j) cv[j] /= nn;
         }
         if (scene_active == 0) return;  // nothing has been written yet (all waves take the same branch: no barrier is skipped by some)
         if (a.cost_vector && wave == 0)
-            for (int j = 0; j < NPL; ++j) { const int g = lane + 64 * j; if (g < G) a.cost_vector[(int64_t)s * GS + g] = cv[j]; }
+            for (int j = 0; j < NPLT; ++j) { const int g = lane + 64 * j; if (g < G) a.cost_vector[(int64_t)s * GS + g] = cv[j]; }
 
         if (prm.alg == OMGX_ALG_FTL || prm.alg == OMGX_ALG_FTC) {  // :175-189
             double best = OMG_ARG_NEUTRAL_MIN;
             int bi = 0x7fffffff;
-            for (int j = 0; j < NPL; ++j) {
+            for (int j = 0; j < NPLT; ++j) {
                 const int g = lane + 64 * j;
                 if (g < G) {
                     double key = cv[j];
@@ -310,17 +318,17 @@ __device__ __forceinline__ void learner_scene(const LearnerArgs& a, int s, doubl
                 }
             }
             idx = warg<true>(best, bi);
-            for (int j = 0; j < NPL; ++j) { const int g = lane + 64 * j; if (g < G) p[g] = (g == idx) ? 1.0 : 0.0; }
+            for (int j = 0; j < NPLT; ++j) { const int g = lane + 64 * j; if (g < G) p[g] = (g == idx) ? 1.0 : 0.0; }
         } else if (prm.alg == OMGX_ALG_EXP) {  // :208-217
-            double sc[NPL], pn[NPL], tot = 0.0;
-            for (int j = 0; j < NPL; ++j) {
+            double sc[NPLT], pn[NPLT], tot = 0.0;
+            for (int j = 0; j < NPLT; ++j) {
                 const int g = lane + 64 * j;
                 sc[j] = 0.0;
                 if (g < G) { sc[j] = sum_costs[g] + cv[j]; sum_costs[g] = sc[j]; tot += sc[j]; }
             }
             tot = wsum(tot);
             double ps = 0.0;
-            for (int j = 0; j < NPL; ++j) {
+            for (int j = 0; j < NPLT; ++j) {
                 const int g = lane + 64 * j;
                 pn[j] = 0.0;
                 if (g < G) { pn[j] = exp(-eta * cv[j]) * p[g] * 0.999 + (sc[j] / (tot + 1e-8)) * 0.001; ps += pn[j]; }
@@ -328,7 +336,7 @@ __device__ __forceinline__ void learner_scene(const LearnerArgs& a, int s, doubl
             ps = wsum(ps);
             double best = OMG_ARG_NEUTRAL_MAX;
             int bi = 0x7fffffff;
-            for (int j = 0; j < NPL; ++j) {
+            for (int j = 0; j < NPLT; ++j) {
                 const int g = lane + 64 * j;
                 if (g < G) { const double v = pn[j] / (ps + 1e-8); p[g] = v; if (omg::np_arg_better<false>(v, g, best, bi)) { best = v; bi = g; } }
             }
@@ -345,19 +353,19 @@ __device__ __forceinline__ void learner_scene(const LearnerArgs& a, int s, doubl
             for (int q = 0; q < (FOUR ? 2 : 1); ++q) {  // waves 0..4: Bregman projection of their own expert (reads the OLD experts_p, like the reference)
                 const int ex = q == 0 ? ex0 : ex1;
                 if (ex < 0) break;
-                double v[NPL], epw[NPL], pn[NPL];
-                for (int j = 0; j < NPL; ++j) {
+                double v[NPLT], epw[NPLT], pn[NPLT];
+                for (int j = 0; j < NPLT; ++j) {
                     const int g = lane + 64 * j;
                     v[j] = eta * pw[ex] * cv[j];
                     if constexpr (FOUR) epw[j] = g < G ? (q == 0 ? epw_pre[j] : epw_pre1[j]) : 0.0;
                     else epw[j] = g < G ? epw_pre[j] : 0.0;
                 }
                 LPHASE(1, 4);
-                bregman_projection(epw, v, delta, G, lane, pn);
+                bregman_projection<NPLT>(epw, v, delta, G, lane, pn);
                 LPHASE(2, 4);
                 // this expert's cost (:229-230) on its own wave: sum_g cv pn + |pn - old p|; the step table is dead by now
                 double part2 = 0.0;
-                for (int j = 0; j < NPL; ++j) {
+                for (int j = 0; j < NPLT; ++j) {
                     const int g = lane + 64 * j;
                     if (g < G) { sh_pn[ex][g] = pn[j]; part2 += cv[j] * pn[j] + fabs(pn[j] - epw[j]); }
                 }
@@ -376,7 +384,7 @@ __device__ __forceinline__ void learner_scene(const LearnerArgs& a, int s, doubl
             // p = sum_k q_k p_k is overwritten in every pass of the reference loop, so only the last one is formed.
             // Lane k < 5 carries expert k through the loop (its q_k, both of its exponentials), the normalising sum is formed
             // from lane broadcasts in the reference's order: one division per pass instead of five.
-            double qv[5], ec[5], ep[5][NPL];
+            double qv[5], ec[5], ep[5][NPLT];
             {
                 const int kk = kk_pre;
                 const double e_old = exp(-1.0 * ecost_pre);
@@ -386,7 +394,7 @@ __device__ __forceinline__ void learner_scene(const LearnerArgs& a, int s, doubl
                 for (int i = 0; i < 5; ++i) {
                     while (__hip_atomic_load(expert_done + i, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(1);
                     ec[i] = sh_tab[i][0];
-                    for (int j = 0; j < NPL; ++j) { const int g = lane + 64 * j; ep[i][j] = g < G ? sh_pn[i][g] : 0.0; }
+                    for (int j = 0; j < NPLT; ++j) { const int g = lane + 64 * j; ep[i][j] = g < G ? sh_pn[i][g] : 0.0; }
                     const double en = exp(-1.0 * ec[i]);  // the same number in every lane; lane i keeps it
                     e_new = kk == i ? en : e_new;
                     ql = ql * (kk <= i ? e_new : e_old);
@@ -396,18 +404,18 @@ __device__ __forceinline__ void learner_scene(const LearnerArgs& a, int s, doubl
                 }
                 for (int k = 0; k < 5; ++k) qv[k] = lane_bcast(ql, k);
             }
-            double pm[NPL], ps = 0.0;
-            for (int j = 0; j < NPL; ++j) {
+            double pm[NPLT], ps = 0.0;
+            for (int j = 0; j < NPLT; ++j) {
                 double m = 0.0;
                 for (int k = 0; k < 5; ++k) m += ep[k][j] * qv[k];
                 pm[j] = (lane + 64 * j < G) ? m : 0.0;
                 ps += pm[j];
             }
             ps = wsum(ps);
-            for (int j = 0; j < NPL; ++j) pm[j] /= ps;
+            for (int j = 0; j < NPLT; ++j) pm[j] /= ps;
             double best = OMG_ARG_NEUTRAL_MAX;
             int bi = 0x7fffffff;
-            for (int j = 0; j < NPL; ++j) {
+            for (int j = 0; j < NPLT; ++j) {
                 const int g = lane + 64 * j;
                 if (g < G) {
                     p[g] = pm[j];

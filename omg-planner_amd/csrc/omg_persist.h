@@ -38,8 +38,17 @@ __device__ __forceinline__ IterTablePtr as_const(const omgx_plan_iter* p) { retu
 
 namespace omg_persist {
 
-#define PQ_LOCK 0x80000000u
+#ifdef OMGX_PERSIST_STATS
+#define PQ_STAT(i, v) __hip_atomic_fetch_add(pa.stats + (i), (unsigned long long)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#else
+#define PQ_STAT(i, v) do { } while (0)
+#endif
+// claim word: [63:48] scene | [47:32] iteration | [31] LOCK | [30] VALID | [29:24] install count | [23:0] next item
+#define PQ_LOCK 0x80000000ull
+#define PQ_VALID 0x40000000ull
+#define PQ_KMASK 0xffffffull
 #define PQ_DONE 0xffffffffffffffffull
+#define PQ_SLOTS 3  // claim words per XCD
 
 struct PersistArgs {
     ChunkArgs ca;                     // a goal-set + layer launch in the batch layout; CH / PS / MR / tbl_n / traj_start follow the iteration
@@ -50,8 +59,9 @@ struct PersistArgs {
     int G;                            // goals per scene (padded)
     int32_t* active;                  // [S] or null: scenes with 0 are not planned; a scene that terminates under stop_on_terminate gets 0
     unsigned long long* ring;         // [cap] activations
-    unsigned long long* xw;           // [8] per-XCD claim words
-    uint32_t* ctl;                    // [0] ring tail, [1] ring head, [2] scenes finished, [3] failure code, [4] scenes in the plan
+    unsigned long long* xw;           // [8][PQ_SLOTS][16] claim words, one 128-byte line each (word 0 of the line)
+    uint32_t* ctl;                    // [32] (a line of its own) [8..9] the ring's {tail | head} as one 64-bit word, [0] activations made, [1] -, [2] scenes finished, [3] failure code, [4] scenes in the plan
+    unsigned long long* stats;        // [16] (a line of its own; -DOMGX_PERSIST_STATS) [0] claim spins, [1] item ticks, [2] update ticks, [3] items, [4] updates, [5] claim ticks
     uint32_t* arrive;                 // [S] items of the scene's current iteration that have finished
     int cap;
     uint32_t lds_bytes;               // dynamic LDS of the launch
@@ -59,17 +69,22 @@ struct PersistArgs {
 
 __device__ __forceinline__ uint32_t ld_u32(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ unsigned long long ld_u64(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// a read as a read-modify-write atomic: performed where the word lives, whatever this XCD's L2 still holds of the line
+__device__ __forceinline__ uint32_t rmw_u32(uint32_t* p) { return __hip_atomic_fetch_add(p, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long rmw_u64(unsigned long long* p) { return __hip_atomic_fetch_add(p, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // (Re-)initialise the queue for a launch: every active scene activated for iteration 0, in scene order; one workgroup.
 __global__ __launch_bounds__(256) void k_persist_init(PersistArgs pa) {
     for (int i = threadIdx.x; i < pa.ca.S; i += 256) pa.arrive[i] = 0u;
-    if (threadIdx.x < 8) pa.xw[threadIdx.x] = 0ull;
+    if (threadIdx.x < 8 * PQ_SLOTS) pa.xw[16 * threadIdx.x] = 0ull;
+    if (threadIdx.x < 16) pa.stats[threadIdx.x] = 0ull;
     __syncthreads();
     if (threadIdx.x == 0) {  // (serial: the order of the ring is the scenes' order; S <= 65535)
         uint32_t n = 0;
         for (int s = 0; s < pa.ca.S; ++s)
             if (!pa.active || pa.active[s] != 0) { pa.ring[n] = ((unsigned long long)(n + 1) << 32) | (unsigned long long)(uint32_t)s; ++n; }
         pa.ctl[0] = n; pa.ctl[1] = 0u; pa.ctl[2] = 0u; pa.ctl[3] = 0u; pa.ctl[4] = n;
+        *reinterpret_cast<unsigned long long*>(pa.ctl + 8) = (unsigned long long)n << 32;  // {tail | head} of the ring
     }
 }
 
@@ -78,13 +93,20 @@ struct Item { int s, t, k, nitems, mode; };
 
 typedef __attribute__((address_space(3))) unsigned char* LdsBytes;
 
+// a value every lane holds, as a scalar (function arguments arrive in vector registers)
+__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+
 // a kernel argument block (or a part of it) read through the constant address space: scalar loads, field by field
 template <class T>
 __device__ __forceinline__ T load_const(unsigned long long addr) {
     static_assert(sizeof(T) % 4 == 0, "dwords");
     T out;
-    const OMG_CONST_AS uint32_t* src = (const OMG_CONST_AS uint32_t*)(uintptr_t)addr;
-    uint32_t* dst = reinterpret_cast<uint32_t*>(&out);
+    typedef uint32_t __attribute__((may_alias)) u32_any;  // (the dwords ARE the object's fields, of whatever type: no type-based reordering)
+    const OMG_CONST_AS u32_any* src = (const OMG_CONST_AS u32_any*)(uintptr_t)addr;
+    u32_any* dst = reinterpret_cast<u32_any*>(&out);
 #pragma unroll
     for (size_t i = 0; i < sizeof(T) / 4; ++i) dst[i] = src[i];
     return out;
@@ -94,7 +116,8 @@ __device__ __forceinline__ T load_const(unsigned long long addr) {
 // whatever the kernel around it keeps alive.  k < 5: piece k of the scene's trajectory layer, else goal k - 5; start_idx: the learner's
 // window of the scene's iteration.
 template <int LB, int ROLE>  // ROLE 1: a trajectory-layer piece, 2: a goal — two functions, two register allocations
-__device__ __attribute__((noinline)) void persist_item(const unsigned long long pa_addr, LdsBytes lds, const int s_in, const int k_in, const int start_in) {
+__device__ __attribute__((noinline)) void persist_item(const unsigned long long pa_addr_in, LdsBytes lds, const int s_in, const int k_in, const int start_in) {
+    const unsigned long long pa_addr = uniform_u64(pa_addr_in);
     const int s = __builtin_amdgcn_readfirstlane(s_in), k = __builtin_amdgcn_readfirstlane(k_in), start_idx = __builtin_amdgcn_readfirstlane(start_in);
     ChunkArgs ca = load_const<ChunkArgs>(pa_addr + offsetof(PersistArgs, ca));
     const uint32_t lds_bytes = load_const<uint32_t>(pa_addr + offsetof(PersistArgs, lds_bytes));
@@ -115,66 +138,98 @@ __device__ __attribute__((noinline)) void persist_item(const unsigned long long 
     gq_item<LB, false, false, false, false, true, ROLE>(ca, lds_pose, s, is_layer, is_layer ? k : 0, is_layer ? 0 : k - 5, 1);
 }
 
-// Learner.update_goal + Optimizer.optimize of scene s at iteration t, then the scene's next activation (or its end); called by the whole
-// workgroup that finished the scene's last item.  pa_addr: the kernel's argument block; lds: the workgroup's dynamic LDS.
-__device__ __attribute__((noinline)) void persist_update(const unsigned long long pa_addr, LdsBytes lds, const int s_in, const int t_in) {
-    const int tid = (int)threadIdx.x;
-    Item it{__builtin_amdgcn_readfirstlane(s_in), __builtin_amdgcn_readfirstlane(t_in), 0, 0, 0};
-    const PersistArgs pa = load_const<PersistArgs>(pa_addr);
+// The scene's update behind CALLS too, in two functions with their own register allocations: the learner (its arrays hold NPLT goals per
+// lane: a build per goal count class instead of one for 256 goals) and the step.  Both start from the workgroup's dynamic LDS.
+__device__ __forceinline__ omgx_plan_iter load_iter(const PersistArgs& pa, int t) {
     omgx_plan_iter rec;
-    {
-        IterTablePtr r = as_const(pa.iters) + it.t;
-        rec.mode = r->mode; rec.start_idx = r->start_idx; rec.stop_on_terminate = r->stop_on_terminate; rec.do_update = r->do_update;
-        rec.obstacle_weight = r->obstacle_weight; rec.smoothness_weight = r->smoothness_weight; rec.step_size = r->step_size;
+    IterTablePtr r = as_const(pa.iters) + t;
+    rec.mode = r->mode; rec.start_idx = r->start_idx; rec.stop_on_terminate = r->stop_on_terminate; rec.do_update = r->do_update;
+    rec.obstacle_weight = r->obstacle_weight; rec.smoothness_weight = r->smoothness_weight; rec.step_size = r->step_size;
+    return rec;
+}
+
+// Learner.update_goal for scene s (iteration t's window); leaves the chosen goal's index in the LDS word behind the learner's tables
+// and its link poses in end_poses_out.
+template <int NPLT>
+__device__ __attribute__((noinline)) void persist_learner(const unsigned long long pa_addr_in, LdsBytes lds, const int s_in, const int t_in) {
+    const unsigned long long pa_addr = uniform_u64(pa_addr_in);
+    const int s = __builtin_amdgcn_readfirstlane(s_in), t = __builtin_amdgcn_readfirstlane(t_in);
+    omg_learner::LearnerArgs la = load_const<omg_learner::LearnerArgs>(pa_addr + offsetof(PersistArgs, la));
+    const omgx_plan_iter* iters = load_const<const omgx_plan_iter*>(pa_addr + offsetof(PersistArgs, iters));
+    la.prm.start_idx = (as_const(iters) + t)->start_idx;
+    la.active = nullptr;  // only scenes in the loop are ever activated
+    double* shl = reinterpret_cast<double*>((unsigned char*)lds);
+    int* const sh_idx = reinterpret_cast<int*>(shl + 5 * OMGX_MAX_GOALS + 5 * 128);
+    omg_learner::learner_scene<true, NPLT>(la, s, reinterpret_cast<double (*)[OMGX_MAX_GOALS]>(shl), reinterpret_cast<double (*)[128]>(shl + 5 * OMGX_MAX_GOALS), sh_idx);
+    __syncthreads();  // the goal (global memory, this CU) and its index (LDS) are the workgroup's
+    const int gi = *sh_idx;
+    const double* src = la.prm.goal_pose_table + ((size_t)s * la.prm.num_goals + gi) * 120;
+    if (threadIdx.x < 120) la.prm.end_poses_out[(size_t)s * 120 + threadIdx.x] = src[threadIdx.x];  // (for the fixed-goal iterations and later launches)
+}
+
+// Optimizer.optimize for scene s with iteration t's schedule; gi >= 0: the goal the learner has just chosen (its poses come from the
+// goal pose table), else the scene's current end pose.
+__device__ __attribute__((noinline)) void persist_step(const unsigned long long pa_addr_in, LdsBytes lds, const int s_in, const int t_in, const int gi_in) {
+    const unsigned long long pa_addr = uniform_u64(pa_addr_in);
+    const int s = __builtin_amdgcn_readfirstlane(s_in), t = __builtin_amdgcn_readfirstlane(t_in), gi = __builtin_amdgcn_readfirstlane(gi_in);
+    ChompArgs ch = load_const<ChompArgs>(pa_addr + offsetof(PersistArgs, ch));
+    const omgx_plan_iter* iters = load_const<const omgx_plan_iter*>(pa_addr + offsetof(PersistArgs, iters));
+    int32_t* const active = load_const<int32_t*>(pa_addr + offsetof(PersistArgs, active));
+    IterTablePtr r = as_const(iters) + t;
+    ch.prm.obstacle_weight = r->obstacle_weight; ch.prm.smoothness_weight = r->smoothness_weight; ch.prm.step_size = r->step_size;
+    ch.prm.do_update = r->do_update;
+    ch.active = nullptr;
+    ch.deactivate = (r->stop_on_terminate && active) ? active : nullptr;
+    const double* end_pose = ch.prm.end_poses + (size_t)s * 120;
+    if (gi >= 0) {
+        const double* table = load_const<const double*>(pa_addr + offsetof(PersistArgs, la) + offsetof(omg_learner::LearnerArgs, prm) + offsetof(omgx_learner_params, goal_pose_table));
+        const int G = load_const<int>(pa_addr + offsetof(PersistArgs, G));
+        end_pose = table + ((size_t)s * G + gi) * 120;
     }
-    it.mode = rec.mode;
-    double* const lds_pose = reinterpret_cast<double*>((unsigned char*)lds);
-    {
-        if (tid == 0) {
-            __hip_atomic_store(pa.arrive + it.s, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // nobody touches it before the next activation
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // this CU's L1 forgets what other workgroups have rewritten
-        }
-        __syncthreads();
-        unsigned char* const smem = reinterpret_cast<unsigned char*>(lds_pose);
-        const double* end_pose = pa.ch.prm.end_poses + (size_t)it.s * 120;
-        if (it.mode) {
-            omg_learner::LearnerArgs la = pa.la;
-            la.prm.start_idx = rec.start_idx;
-            la.active = nullptr;  // only scenes in the loop are ever activated
-            double* shl = reinterpret_cast<double*>(smem);
-            int* const sh_idx = reinterpret_cast<int*>(shl + 5 * OMGX_MAX_GOALS + 5 * 128);
-            omg_learner::learner_scene<true>(la, it.s, reinterpret_cast<double (*)[OMGX_MAX_GOALS]>(shl), reinterpret_cast<double (*)[128]>(shl + 5 * OMGX_MAX_GOALS), sh_idx);
-            __syncthreads();  // the goal (global memory, this CU) and its index (LDS) are the workgroup's
-            const int gi = *sh_idx;
-            const double* src = la.prm.goal_pose_table + ((size_t)it.s * la.prm.num_goals + gi) * 120;
-            if (tid < 120) la.prm.end_poses_out[(size_t)it.s * 120 + tid] = src[tid];  // (for the fixed-goal iterations and later launches)
-            end_pose = src;
-            __syncthreads();  // chomp_scene reuses the learner's LDS
-        }
-        {
-            ChompArgs ch = pa.ch;
-            ch.prm.obstacle_weight = rec.obstacle_weight; ch.prm.smoothness_weight = rec.smoothness_weight; ch.prm.step_size = rec.step_size;
-            ch.prm.do_update = rec.do_update;
-            ch.active = nullptr;
-            ch.deactivate = (rec.stop_on_terminate && pa.active) ? pa.active : nullptr;
-            chomp_scene<1, GQ_NT, true>(ch, smem, it.s, nullptr, 0u, nullptr, end_pose);
-        }
-        // ---- everything the step left is visible at agent scope, then the scene goes on (or has finished)
+    chomp_scene<1, GQ_NT, true>(ch, (unsigned char*)lds, s, nullptr, 0u, nullptr, end_pose);
+}
+
+// Learner.update_goal + Optimizer.optimize of scene s at iteration t, then the scene's next activation (or its end); called by the whole
+// workgroup that finished the scene's last item.
+__device__ __forceinline__ void persist_update(const PersistArgs& pa, const unsigned long long ka, LdsBytes lds, const int s, const int t) {
+    const int tid = (int)threadIdx.x;
+    IterTablePtr rec = as_const(pa.iters) + t;
+    const int mode = rec->mode, stop = rec->stop_on_terminate;
+    if (tid == 0) {
+        __hip_atomic_store(pa.arrive + s, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // nobody touches it before the next activation
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // this CU's L1 forgets what other workgroups have rewritten
+    }
+    __syncthreads();
+    int gi = -1;
+    if (mode) {
+#ifdef OMGX_PERSIST_NPL4  // experiment build: one learner for every goal count
+        persist_learner<4>(ka, lds, s, t);
+#else
+        if (pa.G <= 64) persist_learner<1>(ka, lds, s, t);
+        else if (pa.G <= 128) persist_learner<2>(ka, lds, s, t);
+        else persist_learner<4>(ka, lds, s, t);
+#endif
+        gi = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(reinterpret_cast<const double*>((unsigned char*)lds) + 5 * OMGX_MAX_GOALS + 5 * 128));
+        __syncthreads();  // chomp_scene reuses the learner's LDS
+    }
+    persist_step(ka, lds, s, t, gi);
+    // ---- everything the step left is visible at agent scope, then the scene goes on (or has finished)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            bool more = it.t + 1 < pa.num_iters;
-            if (more && rec.stop_on_terminate && pa.active) more = __hip_atomic_load(pa.active + it.s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-            if (more) {
-                const uint32_t p = __hip_atomic_fetch_add(pa.ctl + 0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(pa.ring + p % (uint32_t)pa.cap, ((unsigned long long)(p + 1u) << 32) | ((unsigned long long)(uint32_t)(it.t + 1) << 16) | (unsigned long long)(uint32_t)it.s,
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else __hip_atomic_fetch_add(pa.ctl + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __syncthreads();
+        bool more = t + 1 < pa.num_iters;
+        if (more && stop && pa.active) more = __hip_atomic_load(pa.active + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+        if (more) {
+            // the slot's word first, then the tail: whoever sees the tail moved finds the word (the tag is checked anyway)
+            __hip_atomic_fetch_add(pa.ctl + 0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (activations made, for the status)
+            const uint32_t p = (uint32_t)(__hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(pa.ctl + 8), 1ull << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32);
+            __hip_atomic_store(pa.ring + p % (uint32_t)pa.cap, ((unsigned long long)(p + 1u) << 32) | ((unsigned long long)(uint32_t)(t + 1) << 16) | (unsigned long long)(uint32_t)s,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else __hip_atomic_fetch_add(pa.ctl + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    __syncthreads();
 }
 
 
@@ -183,75 +238,115 @@ __global__ __launch_bounds__(GQ_NT, GQ_WG_PER_CU) void k_plan_persistent(Persist
     extern __shared__ __attribute__((aligned(16))) double lds_pose[];
     const int tid = (int)threadIdx.x;
     const int xcd = (int)(blockIdx.x & 7u);  // observed placement (block b on XCD b % 8): used for cache affinity only, never for correctness
-    unsigned long long* const xw = pa.xw + xcd;
+    unsigned long long* const xw0 = pa.xw + 16 * PQ_SLOTS * xcd;  // this XCD's claim words, one 128-byte line each
+    int my_slot = (int)((blockIdx.x >> 3) % PQ_SLOTS);                  // where this workgroup looks first (tid 0 only)
     int* const bc = reinterpret_cast<int*>(lds_pose);  // [8] broadcast words at the front of the LDS (dead between items)
     const int LP = 5;                                   // layer pieces per scene (2 links each)
 
     for (;;) {
         // ------------------------------------------------------------------------------------------------ claim an item (one lane)
+        // A claim word says WHICH activation it hands out — {scene | iteration | LOCK | VALID | install count | next item} — so a claim is
+        // one returning atomic add and needs nothing else from memory.  (The ring slot of an activation that has been taken off the ring
+        // may be rewritten while its items are still being claimed: only the installer reads the ring.)  An XCD has PQ_SLOTS such words:
+        // while one is being refilled — four dependent round trips to words the whole chip shares — its workgroups claim from the
+        // others.  Everything another workgroup may have written is read with a read-modify-write atomic (performed where the word
+        // lives, never served from a stale cache line).
         if (tid == 0) {
             int got_s = -1, got_t = 0, got_k = 0, got_n = 0, got_mode = 0;
             const long long t_begin = wall_clock64();
-            for (;;) {
-                unsigned long long w = ld_u64(xw);
-                if (w == PQ_DONE) break;
-                const uint32_t pos1 = (uint32_t)(w >> 32), kk = (uint32_t)w;
-                bool exhausted = pos1 == 0u;
-                if (pos1 != 0u && !(kk & PQ_LOCK)) {
+            unsigned spins = 0; (void)spins;
+            int nap = 1;
+            auto items_of = [&](int s, int t, int& mode) {
+                mode = (as_const(pa.iters) + t)->mode;
+                const int gs = pa.ca.goal_count ? as_const(pa.ca.goal_count)[s] : pa.G;
+                return mode ? LP + gs : LP;
+            };
+            bool done = false;
+            while (!done && got_s < 0) {
+                ++spins;
+                int free_slot = -1;
+                unsigned long long free_word = 0ull;
+                for (int a = 0; a < PQ_SLOTS && got_s < 0 && !done; ++a) {
+                    const int sl = (my_slot + a) % PQ_SLOTS;
+                    unsigned long long* const xw = xw0 + 16 * sl;
+                    unsigned long long w = ld_u64(xw);
+                    if ((spins & 31u) == 0u) w = rmw_u64(xw);  // (a stale line must not keep a workgroup asleep)
+                    if (w == PQ_DONE) { done = true; break; }
+                    if (w & PQ_LOCK) continue;  // its installer is at work
+                    int mode;
+                    if (!(w & PQ_VALID) || (int)(w & PQ_KMASK) >= items_of((int)(w >> 48), (int)((w >> 32) & 0xffffu), mode)) {
+                        if (free_slot < 0) { free_slot = sl; free_word = w; }
+                        continue;
+                    }
                     const unsigned long long old = __hip_atomic_fetch_add(xw, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (old == PQ_DONE) { __hip_atomic_store(xw, PQ_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-                    const uint32_t opos1 = (uint32_t)(old >> 32), ok = (uint32_t)old;
-                    if (opos1 != 0u && !(ok & PQ_LOCK)) {
-                        const unsigned long long e = ld_u64(pa.ring + (opos1 - 1u) % (uint32_t)pa.cap);  // installed => published
-                        const int s = (int)(e & 0xffffu), t = (int)((e >> 16) & 0xffffu);
-                        const int mode = as_const(pa.iters)[t].mode;
-                        const int gs = pa.ca.goal_count ? as_const(pa.ca.goal_count)[s] : pa.G;
-                        const int n = mode ? LP + gs : LP;
-                        if ((int)ok < n) { got_s = s; got_t = t; got_k = (int)ok; got_n = n; got_mode = mode; break; }
-                        exhausted = true;
-                        w = old + 1ull;
-                    } else { __builtin_amdgcn_s_sleep(8); continue; }  // locked (an installer is at work) or emptied meanwhile
-                } else if (pos1 != 0u) { __builtin_amdgcn_s_sleep(8); continue; }  // locked: its installer is looking for the next activation
-                if (exhausted) {
-                    // become the installer: lock the word (whatever its item counter has reached), unless somebody else did
-                    unsigned long long cur = ld_u64(xw);
-                    if (cur == PQ_DONE) break;
-                    if ((uint32_t)(cur >> 32) != (uint32_t)(w >> 32) || ((uint32_t)cur & PQ_LOCK)) { __builtin_amdgcn_s_sleep(4); continue; }
-                    const unsigned long long locked = (cur & 0xffffffff00000000ull) | PQ_LOCK;
-                    if (!__hip_atomic_compare_exchange_strong(xw, &cur, locked, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) continue;
-                    // ---- take the next activation off the ring (or find the plan finished)
-                    uint32_t pos = 0u;
-                    bool finished = false;
-                    for (;;) {
-                        uint32_t h = ld_u32(pa.ctl + 1);
-                        const uint32_t tl = ld_u32(pa.ctl + 0);
-                        if ((int32_t)(tl - h) > 0) {
-                            if (__hip_atomic_compare_exchange_strong(pa.ctl + 1, &h, h + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { pos = h; break; }
-                            continue;
-                        }
-                        if (ld_u32(pa.ctl + 2) >= ld_u32(pa.ctl + 4) || ld_u32(pa.ctl + 3) != 0u) { finished = true; break; }
-                        __builtin_amdgcn_s_sleep(16);
-                        if (wall_clock64() - t_begin > 200000000LL) { __hip_atomic_store(pa.ctl + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); finished = true; break; }
+                    if (old == PQ_DONE) { __hip_atomic_store(xw, PQ_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); done = true; break; }
+                    if ((old & PQ_VALID) && !(old & PQ_LOCK)) {
+                        const int s = (int)(old >> 48), t = (int)((old >> 32) & 0xffffu), k = (int)(old & PQ_KMASK);
+                        const int n2 = items_of(s, t, mode);
+                        if (k < n2) { got_s = s; got_t = t; got_k = k; got_n = n2; got_mode = mode; my_slot = sl; }
                     }
-                    if (finished) { __hip_atomic_store(xw, PQ_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-                    unsigned long long e;
-                    for (;;) {  // the producer took the slot (tail) before it wrote the word: wait for the tag
-                        e = ld_u64(pa.ring + pos % (uint32_t)pa.cap);
-                        if ((uint32_t)(e >> 32) == pos + 1u) break;
-                        __builtin_amdgcn_s_sleep(2);
-                        if (wall_clock64() - t_begin > 200000000LL) { __hip_atomic_store(pa.ctl + 3, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                }
+                if (done || got_s >= 0) break;
+                if (free_slot < 0) {  // every word is being refilled: back off (a look every 0.05 .. 2 us)
+                    for (int z = 0; z < nap; ++z) __builtin_amdgcn_s_sleep(2);
+                    nap = nap < 32 ? nap * 2 : 32;
+                    continue;
+                }
+                // ---- an exhausted (or never filled) word: become its installer — lock it, unless somebody else has
+                unsigned long long* const xw = xw0 + 16 * free_slot;
+                unsigned long long cur = free_word;
+                if (!__hip_atomic_compare_exchange_strong(xw, &cur, cur | PQ_LOCK, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    if (cur == PQ_DONE) { done = true; break; }
+                    // the counter moved on, or somebody locked it: if it is still the same exhausted activation and unlocked, once more
+                    if ((cur >> 24) != (free_word >> 24) || (cur & PQ_LOCK)) continue;
+                    if (!__hip_atomic_compare_exchange_strong(xw, &cur, cur | PQ_LOCK, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) continue;
+                }
+                // ---- take the next activation off the ring (or find the plan finished): ctl64 = {tail | head}
+                unsigned long long* const ht = reinterpret_cast<unsigned long long*>(pa.ctl + 8);
+                uint32_t pos = 0u;
+                bool have = false, finished = false;
+                unsigned long long q = rmw_u64(ht);
+                for (int idle = 1; !have && !finished;) {
+                    const uint32_t h = (uint32_t)q, tl = (uint32_t)(q >> 32);
+                    if ((int32_t)(tl - h) > 0) {
+                        if (__hip_atomic_compare_exchange_strong(ht, &q, q + 1ull, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { pos = h; have = true; }
+                        continue;  // (a failed exchange left the word's current value in q)
                     }
-                    if ((uint32_t)(e >> 32) != pos + 1u) { __hip_atomic_store(xw, PQ_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-                    const int s = (int)(e & 0xffffu), t = (int)((e >> 16) & 0xffffu);
-                    const int mode = as_const(pa.iters)[t].mode;
-                    const int gs = pa.ca.goal_count ? as_const(pa.ca.goal_count)[s] : pa.G;
-                    // installed with item 0 taken by this workgroup
-                    __hip_atomic_store(xw, ((unsigned long long)(pos + 1u) << 32) | 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    got_s = s; got_t = t; got_k = 0; got_n = mode ? LP + gs : LP; got_mode = mode;
+                    if (rmw_u32(pa.ctl + 2) >= rmw_u32(pa.ctl + 4) || rmw_u32(pa.ctl + 3) != 0u) { finished = true; break; }
+                    // nothing to take right now: give the word back (another slot of this XCD may still hold items) after a short wait
+                    for (int z = 0; z < idle; ++z) __builtin_amdgcn_s_sleep(2);
+                    idle = idle < 16 ? idle * 2 : 16;
+                    if (wall_clock64() - t_begin > 200000000LL) { __hip_atomic_store(pa.ctl + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); finished = true; break; }
+                    q = rmw_u64(ht);
+                }
+                if (finished) {
+                    for (int a = 0; a < PQ_SLOTS; ++a) __hip_atomic_store(xw0 + 16 * a, PQ_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    done = true;
                     break;
                 }
+                unsigned long long e;
+                for (;;) {  // the producer took the slot (tail) before it wrote the word: wait for the tag
+                    e = rmw_u64(pa.ring + pos % (uint32_t)pa.cap);
+                    if ((uint32_t)(e >> 32) == pos + 1u) break;
+                    __builtin_amdgcn_s_sleep(2);
+                    if (wall_clock64() - t_begin > 200000000LL) { __hip_atomic_store(pa.ctl + 3, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                }
+                if ((uint32_t)(e >> 32) != pos + 1u) {
+                    for (int a = 0; a < PQ_SLOTS; ++a) __hip_atomic_store(xw0 + 16 * a, PQ_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    done = true;
+                    break;
+                }
+                const int s = (int)(e & 0xffffu), t = (int)((e >> 16) & 0xffffu);
+                int mode;
+                const int n = items_of(s, t, mode);
+                // installed with item 0 taken by this workgroup; the install count tells this activation from the one before it
+                const unsigned long long seq = ((cur >> 24) + 1ull) & 0x3full;
+                __hip_atomic_store(xw, ((unsigned long long)(uint32_t)s << 48) | ((unsigned long long)(uint32_t)t << 32) | PQ_VALID | (seq << 24) | 1ull,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                got_s = s; got_t = t; got_k = 0; got_n = n; got_mode = mode; my_slot = free_slot;
             }
             bc[0] = got_s; bc[1] = got_t; bc[2] = got_k; bc[3] = got_n; bc[4] = got_mode;
+            PQ_STAT(0, spins); PQ_STAT(5, wall_clock64() - t_begin);
         }
         __syncthreads();
         Item it{bc[0], bc[1], bc[2], bc[3], bc[4]};
@@ -265,8 +360,14 @@ __global__ __launch_bounds__(GQ_NT, GQ_WG_PER_CU) void k_plan_persistent(Persist
         {
             const bool is_layer = it.k < LP;
             const unsigned long long ka = reinterpret_cast<unsigned long long>(__builtin_amdgcn_kernarg_segment_ptr());
+#ifdef OMGX_PERSIST_STATS
+            const long long t_item = wall_clock64();
+#endif
             if (is_layer) persist_item<LB, 1>(ka, (LdsBytes)(__attribute__((address_space(3))) void*)lds_pose, it.s, it.k, start_idx);
             else persist_item<LB, 2>(ka, (LdsBytes)(__attribute__((address_space(3))) void*)lds_pose, it.s, it.k, start_idx);
+#ifdef OMGX_PERSIST_STATS
+            if (tid == 0) { PQ_STAT(1, wall_clock64() - t_item); PQ_STAT(3, 1); }
+#endif
             // ---- arrival: what this item wrote is visible at agent scope before the counter moves
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -288,8 +389,13 @@ __global__ __launch_bounds__(GQ_NT, GQ_WG_PER_CU) void k_plan_persistent(Persist
         // A CALL, not inlined: the learner and the step need more registers than a goal item has (they spill to scratch at this
         // kernel's 96), and inlined they drag the item's main loop into the same allocation — scratch traffic inside the hot loop.
         // Behind a call the item's code is allocated as in k_goalset_queue, and only the update pays for its own spills.
-        persist_update(reinterpret_cast<unsigned long long>(__builtin_amdgcn_kernarg_segment_ptr()),
-                       (LdsBytes)(__attribute__((address_space(3))) void*)lds_pose, it.s, it.t);
+#ifdef OMGX_PERSIST_STATS
+        const long long t_upd = wall_clock64();
+#endif
+        persist_update(pa, reinterpret_cast<unsigned long long>(__builtin_amdgcn_kernarg_segment_ptr()), (LdsBytes)(__attribute__((address_space(3))) void*)lds_pose, it.s, it.t);
+#ifdef OMGX_PERSIST_STATS
+        if (tid == 0) { PQ_STAT(2, wall_clock64() - t_upd); PQ_STAT(4, 1); }
+#endif
         __syncthreads();
     }
 }

@@ -20,7 +20,19 @@ def _copy_struct(dst, src):
     return dst
 
 
-def engine_vs_oracle(eng, batch, scene_ids, steps: int = 3, pin_window: bool = True) -> dict:
+def engine_vs_oracle(eng, batch, scene_ids, steps: int = 3, pin_window: bool = True, sophus: bool = False) -> dict:
+    """(see _engine_vs_oracle)  sophus: the oracle's SDF pairs go through Sophus' quaternion round trip like the reference's kernel
+    (omg_oracle.c, SOPHUS MODE) — the one place where the product path knowingly differs from the reference's arithmetic."""
+    if not sophus:
+        return _engine_vs_oracle(eng, batch, scene_ids, steps, pin_window)
+    orc.set_sophus_mode(True)
+    try:
+        return dict(_engine_vs_oracle(eng, batch, scene_ids, steps, pin_window), sophus_mode=True)
+    finally:
+        orc.set_sophus_mode(False)
+
+
+def _engine_vs_oracle(eng, batch, scene_ids, steps: int = 3, pin_window: bool = True) -> dict:
     """eng: ChompEngine (no early stop, no ragged goal sets); batch: the host SceneBatch it was built from.
     pin_window: keep Learner.t at 0 before every iteration like bench.py's step (goal-set window = all waypoints)."""
     import torch

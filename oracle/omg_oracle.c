@@ -80,14 +80,74 @@ void orc_gradient_interpolated(float gx, float gy, float gz, int dx, int dy, int
     out3[2] = (float)(0.5 * (double)(fpz - fmz) / (double)delta);
 }
 
+/* SOPHUS MODE (round 6; off by default).  The reference builds `Sophus::SE3<float>(Matrix4f)` (.cu:125-126): the rotation becomes a unit
+ * quaternion (Eigen's matrix -> quaternion assignment, Eigen/src/Geometry/Quaternion.h: quaternionbase_assign_impl<.., 3, 3>), the
+ * point is rotated with the quaternion (QuaternionBase::_transformVector: uv = 2 q.vec x p; p + w uv + q.vec x uv) and translated
+ * (.cu:133), and the gradient is rotated back with the matrix REGENERATED from the quaternion (so3().matrix() = toRotationMatrix,
+ * .cu:126,176).  Sophus is an empty submodule of the reference tree and Eigen is not in this image, so this is a restatement of the
+ * PUBLISHED algorithms (Eigen 3.3 / Sophus 1.0 as the reference's submodule pins them), all in float32 without contraction; the default
+ * mode multiplies by the float32 matrix, which is what the HIP kernels do.  bench.py's parity_sample runs the engine against the
+ * oracle in BOTH modes and reports the difference. */
+static int g_sophus_mode = 0;
+void orc_set_sophus_mode(int on) { g_sophus_mode = on ? 1 : 0; }
+int orc_get_sophus_mode(void) { return g_sophus_mode; }
+
+static void orc_quat_from_rows(const float* T, float* q /* x y z w */) {
+#define M(r, c) T[4 * (r) + (c)]
+    float t = M(0, 0) + M(1, 1) + M(2, 2);
+    if (t > 0.0f) {
+        t = sqrtf(t + 1.0f);
+        q[3] = 0.5f * t;
+        t = 0.5f / t;
+        q[0] = (M(2, 1) - M(1, 2)) * t;
+        q[1] = (M(0, 2) - M(2, 0)) * t;
+        q[2] = (M(1, 0) - M(0, 1)) * t;
+    } else {
+        int i = 0;
+        if (M(1, 1) > M(0, 0)) i = 1;
+        if (M(2, 2) > M(i, i)) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = sqrtf(M(i, i) - M(j, j) - M(k, k) + 1.0f);
+        q[i] = 0.5f * t;
+        t = 0.5f / t;
+        q[3] = (M(k, j) - M(j, k)) * t;
+        q[j] = (M(j, i) + M(i, j)) * t;
+        q[k] = (M(k, i) + M(i, k)) * t;
+    }
+#undef M
+}
+static void orc_cross(const float* a, const float* b, float* o) {
+    o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
+}
+static void orc_quat_matrix(const float* q, float* m /* [9] row-major */) {  /* QuaternionBase::toRotationMatrix */
+    const float x = q[0], y = q[1], z = q[2], w = q[3];
+    const float tx = 2.0f * x, ty = 2.0f * y, tz = 2.0f * z;
+    const float twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    m[0] = 1.0f - (tyy + tzz); m[1] = txy - twz; m[2] = txz + twy;
+    m[3] = txy + twz; m[4] = 1.0f - (txx + tzz); m[5] = tyz - twx;
+    m[6] = txz - twy; m[7] = tyz + twx; m[8] = 1.0f - (txx + tyy);
+}
+
 /* One (point, object) pair: the body of SDFdistanceForward, .cu:111-180.  Adds into pot/grad/col. */
 static void orc_sdf_pair(const float* T /*[3][4] rows of the inverse pose*/, const float* lo, const float* hi,
                          const int* dim, float delta, float eps, float pad, float clr, const float* grid,
                          const float* p, float* pot, float* grad, float* col) {
-    /* SE3(pose) * point, .cu:125-133 (Sophus; restated as R p + t) */
-    const float ux = fmaf(T[2], p[2], fmaf(T[1], p[1], fmaf(T[0], p[0], T[3])));
-    const float uy = fmaf(T[6], p[2], fmaf(T[5], p[1], fmaf(T[4], p[0], T[7])));
-    const float uz = fmaf(T[10], p[2], fmaf(T[9], p[1], fmaf(T[8], p[0], T[11])));
+    /* SE3(pose) * point, .cu:125-133 (Sophus; restated as R p + t — or, in Sophus mode, through the quaternion) */
+    float ux, uy, uz, Rq[9], qd[4];
+    if (g_sophus_mode) {
+        float uv[3], c2[3];
+        orc_quat_from_rows(T, qd);
+        orc_cross(qd, p, uv);
+        uv[0] += uv[0]; uv[1] += uv[1]; uv[2] += uv[2];
+        orc_cross(qd, uv, c2);
+        ux = ((p[0] + qd[3] * uv[0]) + c2[0]) + T[3];
+        uy = ((p[1] + qd[3] * uv[1]) + c2[1]) + T[7];
+        uz = ((p[2] + qd[3] * uv[2]) + c2[2]) + T[11];
+    } else {
+        ux = fmaf(T[2], p[2], fmaf(T[1], p[1], fmaf(T[0], p[0], T[3])));
+        uy = fmaf(T[6], p[2], fmaf(T[5], p[1], fmaf(T[4], p[0], T[7])));
+        uz = fmaf(T[10], p[2], fmaf(T[9], p[1], fmaf(T[8], p[0], T[11])));
+    }
     /* grid coordinates, .cu:137-142 */
     const int d0 = dim[0], d1 = dim[1], d2 = dim[2];
     const float gx = (ux - lo[0]) / (hi[0] - lo[0]) * (float)d0;
@@ -117,6 +177,13 @@ static void orc_sdf_pair(const float* T /*[3][4] rows of the inverse pose*/, con
         v0 = ie * g0 * d * pad; v1 = ie * g1 * d * pad; v2 = ie * g2 * d * pad;
     }
     /* rotationMatrix.transpose() * vgrad, .cu:176-179 */
+    if (g_sophus_mode) {  /* the matrix regenerated from the quaternion; Eigen's product: a plain sum of three products per row */
+        orc_quat_matrix(qd, Rq);
+        grad[0] += (Rq[0] * v0 + Rq[3] * v1) + Rq[6] * v2;
+        grad[1] += (Rq[1] * v0 + Rq[4] * v1) + Rq[7] * v2;
+        grad[2] += (Rq[2] * v0 + Rq[5] * v1) + Rq[8] * v2;
+        return;
+    }
     grad[0] += fmaf(T[8], v2, fmaf(T[4], v1, T[0] * v0));
     grad[1] += fmaf(T[9], v2, fmaf(T[5], v1, T[1] * v0));
     grad[2] += fmaf(T[10], v2, fmaf(T[6], v1, T[2] * v0));

@@ -83,6 +83,16 @@ def set_threads(n: int) -> None:
     omp.omp_set_num_threads(int(n))
 
 
+def set_sophus_mode(on: bool) -> None:
+    """SDF pairs through Sophus' quaternion round trip (layers/sdf_matching_loss_kernel.cu:125-133,176) instead of the float32
+    matrix product — see omg_oracle.c (SOPHUS MODE).  A process-wide switch of the checker; off by default."""
+    lib().orc_set_sophus_mode(int(bool(on)))
+
+
+def sophus_mode() -> bool:
+    return bool(lib().orc_get_sophus_mode())
+
+
 def _p(a, ctype):
     return None if a is None else a.ctypes.data_as(C.POINTER(ctype))
 

@@ -144,3 +144,41 @@ def test_top_k_ties_differ_from_numpy_only_inside_the_tie_at_the_cut():
             idx = np.flatnonzero(flat == cut)
             assert sorted(i for i in ours if flat[i] == cut) == idx[-taken:].tolist()
     assert found, "no k puts the cut inside a tie group: the test scene lost its ties"
+
+
+def test_oracle_sophus_mode_is_the_numpy_restatement():
+    """The oracle's second mode (oracle/omg_oracle.c, SOPHUS MODE: quaternion from the float32 matrix, quaternion rotation, gradient
+    rotated back with the regenerated matrix) against the float32 numpy restatement above: same coordinates, hence the same
+    potentials and collision flags bit for bit; gradients up to the association of a three-term float32 sum."""
+    rng = np.random.RandomState(5)
+    assert not orc.sophus_mode()
+    for trial in range(6):
+        A = np.linalg.qr(rng.normal(size=(3, 3)))[0]
+        A *= np.sign(np.linalg.det(A))
+        if trial == 4:  # a rotation by ~pi: the trace is negative, Eigen's conversion takes its other branch
+            A = np.diag([1.0, -1.0, -1.0]) @ np.linalg.qr(np.eye(3) + 0.01 * rng.normal(size=(3, 3)))[0]
+            A *= np.sign(np.linalg.det(A))
+        pose = np.eye(4)
+        pose[:3, :3], pose[:3, 3] = A, rng.uniform(-0.8, 0.8, 3)
+        inv = sc.se3_inverse(pose).astype(F)
+        grid = sc.sphere_sdf(0.08, (24, 24, 24), 0.5 / 24) if trial % 2 else sc.box_sdf((0.06, 0.09, 0.05), (24, 20, 28), 0.02)
+        sdf, lim = sc.pack_padded([sc.SceneObject("o", pose, grid)])
+        local = rng.uniform(grid.min_coords - 0.03, grid.min_coords + np.array(grid.data.shape) * grid.delta + 0.03, (3000, 3))
+        pts = (local @ A.T + pose[:3, 3]).astype(F)
+        eps, pad, clr, dis = (np.array([v], F) for v in (0.2, 1.0, 0.01, 0.0))
+        q = _eigen_quaternion_from_matrix(inv[:3, :3])
+        if trial == 4:
+            assert float(inv[0, 0] + inv[1, 1] + inv[2, 2]) <= 0
+        u_b = np.stack([_sophus_rotate(q, p) + inv[:3, 3] for p in pts]).astype(F)
+        pot_b, grad_o, col_b = orc.sdf_loss_forward(np.eye(4, dtype=F)[None], sdf, lim, u_b, eps, pad, clr, dis)
+        grad_b = (grad_o.astype(np.float64) @ _quaternion_matrix(q).astype(np.float64))
+        try:
+            orc.set_sophus_mode(True)
+            pot_s, grad_s, col_s = orc.sdf_loss_forward(inv[None], sdf, lim, pts, eps, pad, clr, dis)
+        finally:
+            orc.set_sophus_mode(False)
+        assert (pot_s != 0).mean() > 0.05
+        np.testing.assert_array_equal(pot_s, pot_b)
+        np.testing.assert_array_equal(col_s, col_b)
+        np.testing.assert_allclose(grad_s, grad_b, rtol=0, atol=2e-6)
+    assert not orc.sophus_mode()
