@@ -584,6 +584,9 @@ int omgx_fit_influence_regions(omgx_object* objects, int32_t num_objects, const 
  *   workspace     omgx_plan_persistent_workspace_bytes(S, n) bytes of device memory: queue state (re-initialised by every call) and
  *                 the step's scratch; one workspace per launch in flight
  *   max_workgroups  0: five per compute unit (what is resident at 30 waypoints); tests pass small numbers
+ *   update_cus    compute units per XCD whose workgroups take no items and serve the scenes' updates instead (the update is the
+ *                 scene's critical path and latency-bound: beside four goal workgroups it runs three times as long); < 0: the library's
+ *                 rule (2 when the launch fills the chip and holds >= 32 scenes, else 0), 0: every update runs where the scene's last item ran
  * Everything else as in omgx_goalset_cost_layer_parts (goal_parts = 1) and omgx_goal_update_optimize.  Asynchronous; errors inside
  * the launch (a bounded wait that ran out) are reported by omgx_plan_persistent_status after the stream has been synchronised:
  * h_status[0] != 0.
@@ -606,7 +609,7 @@ int omgx_plan_persistent(const double* robot, int32_t n_points, const omgx_objec
                          const omgx_chomp_params* h_params, const double* start, double* end, double* goal,
                          double* goal_point, double* grad, double* cost_traj, double* info,
                          const omgx_plan_iter* h_iters, const omgx_plan_iter* d_iters, int32_t num_iters,
-                         void* workspace, int64_t workspace_bytes, int32_t max_workgroups, void* stream);
+                         void* workspace, int64_t workspace_bytes, int32_t max_workgroups, int32_t update_cus, void* stream);
 /* h_status[4] <- {failure code (0 = none), scenes finished, scenes planned, activations made} of the last launch on this workspace;
  * synchronises `stream`. */
 int omgx_plan_persistent_status(const void* workspace, int32_t num_scenes, int32_t* h_status, void* stream);

@@ -143,7 +143,7 @@ def lib() -> C.CDLL:
         l.omgx_plan_persistent.argtypes = ([vp, i32, vp, vp, vp, vp, i32, i32, f64, i32, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp] +       # goal-set batch + layer
                                            [C.POINTER(LearnerParams), vp, vp, vp, vp, vp, vp] +                                       # learner
                                            [C.POINTER(ChompParams), vp, vp, vp, vp, vp, vp, vp] +                                     # step
-                                           [C.POINTER(PlanIter), vp, i32, vp, i64, i32, vp])                                          # the plan
+                                           [C.POINTER(PlanIter), vp, i32, vp, i64, i32, i32, vp])                                          # the plan
         l.omgx_plan_persistent.restype = C.c_int
         l.omgx_plan_persistent_status.argtypes = [vp, i32, C.POINTER(i32), vp]
         l.omgx_plan_persistent_status.restype = C.c_int

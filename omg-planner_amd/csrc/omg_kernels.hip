@@ -1390,8 +1390,9 @@ static inline int64_t persist_ring_cap(int32_t S) { return ((int64_t)S + 63) & ~
 extern "C" int64_t omgx_plan_persistent_workspace_bytes(int32_t num_scenes, int32_t n_waypoints) {
     if (num_scenes <= 0 || n_waypoints <= 0) return 0;
     // ring [cap] u64 | claim words: 8 x PQ_SLOTS lines of 128 bytes | control: a line | statistics: a line | arrivals [S] u32 (padded to 128 bytes) |
-    // gradient rows [S][n][10][8] f64
-    return persist_ring_cap(num_scenes) * 8 + 8 * PQ_SLOTS * 128 + 128 + 128 + (((int64_t)num_scenes * 4 + 127) & ~127ll) + (int64_t)num_scenes * n_waypoints * 80 * 8;
+    // CU roles [4096] u32 | per-XCD counters: 8 lines | update rings [8][cap] u64 | their {tail | head}: 8 lines | gradient rows [S][n][10][8] f64
+    return persist_ring_cap(num_scenes) * 8 + 8 * PQ_SLOTS * 128 + 128 + 128 + (((int64_t)num_scenes * 4 + 127) & ~127ll) + 4096 * 4 + 8 * 128 +
+           8 * persist_ring_cap(num_scenes) * 8 + 8 * 128 + (int64_t)num_scenes * n_waypoints * 80 * 8;
 }
 
 extern "C" int omgx_plan_persistent_status(const void* workspace, int32_t num_scenes, int32_t* h_status /* [4]: failure code, scenes finished, scenes planned, activations made */, void* stream) {
@@ -1423,7 +1424,7 @@ extern "C" int omgx_plan_persistent(const double* robot, int32_t n_points, const
                                     const omgx_chomp_params* h_params, const double* start, double* end, double* goal,
                                     double* goal_point, double* grad, double* cost_traj, double* info,
                                     const omgx_plan_iter* h_iters, const omgx_plan_iter* d_iters, int32_t num_iters,
-                                    void* workspace, int64_t workspace_bytes, int32_t max_workgroups, void* stream) {
+                                    void* workspace, int64_t workspace_bytes, int32_t max_workgroups, int32_t update_cus, void* stream) {
     using namespace omg_persist;
     if (num_scenes < 0 || num_iters < 0 || !h_learner || !h_params || !h_iters || !d_iters) return OMGX_ERR_INVALID;
     if (num_scenes == 0 || num_iters == 0) return OMGX_OK;
@@ -1482,6 +1483,10 @@ extern "C" int omgx_plan_persistent(const double* robot, int32_t n_points, const
     pa.ctl = reinterpret_cast<uint32_t*>(w); w += 128;
     pa.stats = reinterpret_cast<unsigned long long*>(w); w += 128;
     pa.arrive = reinterpret_cast<uint32_t*>(w); w += ((size_t)num_scenes * 4 + 127) & ~(size_t)127;
+    pa.cu_role = reinterpret_cast<uint32_t*>(w); w += 4096 * 4;
+    pa.xcd_cus = reinterpret_cast<uint32_t*>(w); w += 8 * 128;
+    pa.uq = reinterpret_cast<unsigned long long*>(w); w += (size_t)8 * pa.cap * 8;
+    pa.uq_ht = reinterpret_cast<unsigned long long*>(w); w += 8 * 128;
     ch.light_scratch = reinterpret_cast<double*>(w);
     // dynamic LDS: the goal workgroup's layout for the longest window of the plan, or what the learner / the light step carve from the same block
     const int CHmax = any_select ? n_waypoints - min_start : 1;
@@ -1500,6 +1505,10 @@ extern "C" int omgx_plan_persistent(const double* robot, int32_t n_points, const
     if (grid > items) grid = items;
     if (max_workgroups > 0 && grid > max_workgroups) grid = max_workgroups;
     grid = (grid + 7) & ~7ll;
+    // dedicated update CUs per XCD (omg_persist.h): only when the launch fills the chip (every CU then holds workgroups of this launch) and
+    // there are scenes enough to keep them busy; < 0: this rule, else the caller's number (0: updates run where the scene's last item ran)
+    pa.update_cus = update_cus >= 0 ? (update_cus > 8 ? 8 : update_cus) : ((grid >= (int64_t)cus * GQ_WG_PER_CU && num_scenes >= 32 && any_select) ? 2 : 0);
+    if (grid < (int64_t)cus * GQ_WG_PER_CU) pa.update_cus = update_cus > 0 ? pa.update_cus : 0;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_persist_init, dim3(1), dim3(256), 0, st, pa);
     OMGX_CHECK_LAUNCH("k_persist_init");

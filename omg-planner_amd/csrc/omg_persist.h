@@ -65,6 +65,12 @@ struct PersistArgs {
     uint32_t* arrive;                 // [S] items of the scene's current iteration that have finished
     int cap;
     uint32_t lds_bytes;               // dynamic LDS of the launch
+    // dedicated update CUs (update_cus per XCD; 0: the scene's last item runs its update in place)
+    int update_cus;
+    uint32_t* cu_role;                // [4096] by hardware CU key: 0 unknown, 3 being decided, 1 item CU, 2 update CU
+    uint32_t* xcd_cus;                // [8][32] (a line each) [0] CUs registered on the XCD, [1] update workgroups registered
+    unsigned long long* uq;           // [8][cap] update requests per XCD: {tag = position + 1 | iteration | scene}
+    unsigned long long* uq_ht;        // [8][16] (a line each) {tail | head} of the XCD's update ring
 };
 
 __device__ __forceinline__ uint32_t ld_u32(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -78,6 +84,14 @@ __global__ __launch_bounds__(256) void k_persist_init(PersistArgs pa) {
     for (int i = threadIdx.x; i < pa.ca.S; i += 256) pa.arrive[i] = 0u;
     if (threadIdx.x < 8 * PQ_SLOTS) pa.xw[16 * threadIdx.x] = 0ull;
     if (threadIdx.x < 16) pa.stats[threadIdx.x] = 0ull;
+    for (int i = threadIdx.x; i < 4096; i += 256) pa.cu_role[i] = 0u;
+    for (int i = threadIdx.x; i < 8 * 32; i += 256) pa.xcd_cus[i] = 0u;
+    if (threadIdx.x < 8) pa.uq_ht[16 * threadIdx.x] = 0ull;
+    // every polled word starts from zero in EVERY launch: a ring slot still holding last launch's word would pass for this launch's (the
+    // tags count positions from the same start), in the window between a producer's ticket and its store
+    for (int i = threadIdx.x; i < pa.cap; i += 256) pa.ring[i] = 0ull;
+    for (int i = threadIdx.x; i < 8 * pa.cap; i += 256) pa.uq[i] = 0ull;
+    __syncthreads();
     __syncthreads();
     if (threadIdx.x == 0) {  // (serial: the order of the ring is the scenes' order; S <= 65535)
         uint32_t n = 0;
@@ -115,8 +129,8 @@ __device__ __forceinline__ T load_const(unsigned long long addr) {
 // One work item (omg_goalset_queue.h: gq_item) behind a CALL: the item's code gets the register allocation it has in k_goalset_queue,
 // whatever the kernel around it keeps alive.  k < 5: piece k of the scene's trajectory layer, else goal k - 5; start_idx: the learner's
 // window of the scene's iteration.
-template <int LB, int ROLE>  // ROLE 1: a trajectory-layer piece, 2: a goal — two functions, two register allocations
-__device__ __attribute__((noinline)) void persist_item(const unsigned long long pa_addr_in, LdsBytes lds, const int s_in, const int k_in, const int start_in) {
+template <int LB, int ROLE>  // ROLE 1: a trajectory-layer piece, 2: a goal
+__device__ __forceinline__ void persist_item_impl(const unsigned long long pa_addr_in, LdsBytes lds, const int s_in, const int k_in, const int start_in) {
     const unsigned long long pa_addr = uniform_u64(pa_addr_in);
     const int s = __builtin_amdgcn_readfirstlane(s_in), k = __builtin_amdgcn_readfirstlane(k_in), start_idx = __builtin_amdgcn_readfirstlane(start_in);
     ChunkArgs ca = load_const<ChunkArgs>(pa_addr + offsetof(PersistArgs, ca));
@@ -136,6 +150,18 @@ __device__ __attribute__((noinline)) void persist_item(const unsigned long long 
     const bool is_layer = k < 5;
     double* const lds_pose = reinterpret_cast<double*>((unsigned char*)lds);
     gq_item<LB, false, false, false, false, true, ROLE>(ca, lds_pose, s, is_layer, is_layer ? k : 0, is_layer ? 0 : k - 5, 1);
+}
+
+#ifndef OMGX_PERSIST_GOAL_ATTR
+#define OMGX_PERSIST_GOAL_ATTR __attribute__((noinline))
+#endif
+template <int LB>
+__device__ OMGX_PERSIST_GOAL_ATTR void persist_goal_item(const unsigned long long pa_addr, LdsBytes lds, const int s, const int k, const int start_idx) {
+    persist_item_impl<LB, 2>(pa_addr, lds, s, k, start_idx);
+}
+template <int LB>
+__device__ __attribute__((noinline)) void persist_layer_item(const unsigned long long pa_addr, LdsBytes lds, const int s, const int k, const int start_idx) {
+    persist_item_impl<LB, 1>(pa_addr, lds, s, k, start_idx);
 }
 
 // The scene's update behind CALLS too, in two functions with their own register allocations: the learner (its arrays hold NPLT goals per
@@ -195,6 +221,13 @@ __device__ __forceinline__ void persist_update(const PersistArgs& pa, const unsi
     const int tid = (int)threadIdx.x;
     IterTablePtr rec = as_const(pa.iters) + t;
     const int mode = rec->mode, stop = rec->stop_on_terminate;
+    // The update is the scene's critical path (its next iteration waits for it) and latency-bound (chains of dependent float64
+    // instructions, barriers): beside four goal workgroups on its CU, served oldest-first, it took 190 us against 55 us alone, and
+    // with every scene spending most of its cycle here the chip ran out of items (measured, 100 x 64).  Its waves go first.
+#ifndef OMGX_PERSIST_UPDATE_PRIO
+#define OMGX_PERSIST_UPDATE_PRIO 3
+#endif
+    __builtin_amdgcn_s_setprio(OMGX_PERSIST_UPDATE_PRIO);
     if (tid == 0) {
         __hip_atomic_store(pa.arrive + s, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // nobody touches it before the next activation
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // this CU's L1 forgets what other workgroups have rewritten
@@ -229,6 +262,7 @@ __device__ __forceinline__ void persist_update(const PersistArgs& pa, const unsi
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else __hip_atomic_fetch_add(pa.ctl + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    __builtin_amdgcn_s_setprio(0);
     __syncthreads();
 }
 
@@ -237,11 +271,83 @@ template <int LB>
 __global__ __launch_bounds__(GQ_NT, GQ_WG_PER_CU) void k_plan_persistent(PersistArgs pa) {
     extern __shared__ __attribute__((aligned(16))) double lds_pose[];
     const int tid = (int)threadIdx.x;
-    const int xcd = (int)(blockIdx.x & 7u);  // observed placement (block b on XCD b % 8): used for cache affinity only, never for correctness
+    // where this workgroup runs: XCC_ID (hardware register 20) and the CU's coordinates inside it (HW_ID bits 8-15: CU, SH, SE) —
+    // used for cache affinity and for the roles below, never for correctness
+    const int xcd = (int)(__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 7u);
+    const uint32_t cu_key = ((uint32_t)xcd << 8) | ((__builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 4) >> 8) & 0xffu);
     unsigned long long* const xw0 = pa.xw + 16 * PQ_SLOTS * xcd;  // this XCD's claim words, one 128-byte line each
     int my_slot = (int)((blockIdx.x >> 3) % PQ_SLOTS);                  // where this workgroup looks first (tid 0 only)
     int* const bc = reinterpret_cast<int*>(lds_pose);  // [8] broadcast words at the front of the LDS (dead between items)
     const int LP = 5;                                   // layer pieces per scene (2 links each)
+    const unsigned long long ka = reinterpret_cast<unsigned long long>(__builtin_amdgcn_kernarg_segment_ptr());
+    unsigned long long* const uht = pa.uq_ht + 16 * xcd;
+
+    // ---------------------------------------------------------------------------------------------------- roles
+    // DEDICATED UPDATE CUs.  The update (learner + step) is the scene's critical path and latency-bound; on a CU it shares with four
+    // goal workgroups it took 157-190 us against 55 us alone, every scene spent most of its cycle in it, and the chip ran out of items
+    // (workgroups idle a third of their time: measured, 100 x 64).  So the first pa.update_cus CUs of every XCD to report take no
+    // items: their workgroups serve the XCD's update requests, which the scenes' last items post.  Elected at run time from the hardware's
+    // own CU numbers (no assumption about which CUs exist or where the dispatcher puts a workgroup).
+    int role = 1;
+    if (pa.update_cus > 0) {
+        if (tid == 0) {
+            uint32_t r = rmw_u32(pa.cu_role + cu_key);
+            if (r == 0u) {
+                uint32_t expect = 0u;
+                if (__hip_atomic_compare_exchange_strong(pa.cu_role + cu_key, &expect, 3u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    const uint32_t idx = __hip_atomic_fetch_add(pa.xcd_cus + 32 * xcd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    r = idx < (uint32_t)pa.update_cus ? 2u : 1u;
+                    __hip_atomic_store(pa.cu_role + cu_key, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else r = expect;
+            }
+            for (int spin = 0; r == 3u && spin < 100000; ++spin) { __builtin_amdgcn_s_sleep(1); r = rmw_u32(pa.cu_role + cu_key); }
+            if (r != 2u) r = 1u;
+            if (r == 2u) __hip_atomic_fetch_add(pa.xcd_cus + 32 * xcd + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bc[0] = (int)r;
+        }
+        __syncthreads();
+        role = __builtin_amdgcn_readfirstlane(bc[0]);
+        __syncthreads();
+    }
+    if (role == 2) {
+        // ---- an update workgroup: serve this XCD's update requests until the plan is finished
+        for (;;) {
+            if (tid == 0) {
+                int got_s = -1, got_t = 0;
+                const long long t_begin = wall_clock64();
+                unsigned long long q = rmw_u64(uht);
+                for (int idle = 1;;) {
+                    const uint32_t h = (uint32_t)q, tl = (uint32_t)(q >> 32);
+                    if ((int32_t)(tl - h) > 0) {
+                        if (!__hip_atomic_compare_exchange_strong(uht, &q, q + 1ull, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) continue;
+                        unsigned long long e = rmw_u64(pa.uq + (size_t)xcd * pa.cap + h % (uint32_t)pa.cap);
+                        while ((uint32_t)(e >> 32) != h + 1u && wall_clock64() - t_begin < 200000000LL) { __builtin_amdgcn_s_sleep(1); e = rmw_u64(pa.uq + (size_t)xcd * pa.cap + h % (uint32_t)pa.cap); }
+                        if ((uint32_t)(e >> 32) != h + 1u) { __hip_atomic_store(pa.ctl + 3, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                        got_s = (int)(e & 0xffffu); got_t = (int)((e >> 16) & 0xffffu);
+                        break;
+                    }
+                    if (rmw_u32(pa.ctl + 2) >= rmw_u32(pa.ctl + 4) || rmw_u32(pa.ctl + 3) != 0u) break;
+                    for (int z = 0; z < idle; ++z) __builtin_amdgcn_s_sleep(2);
+                    idle = idle < 8 ? idle * 2 : 8;
+                    if (wall_clock64() - t_begin > 200000000LL) { __hip_atomic_store(pa.ctl + 3, 5u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                    q = rmw_u64(uht);
+                }
+                bc[0] = got_s; bc[1] = got_t;
+            }
+            __syncthreads();
+            const int us = __builtin_amdgcn_readfirstlane(bc[0]), ut = __builtin_amdgcn_readfirstlane(bc[1]);
+            __syncthreads();
+            if (us < 0) return;
+#ifdef OMGX_PERSIST_STATS
+            const long long t_upd = wall_clock64();
+#endif
+            persist_update(pa, ka, (LdsBytes)(__attribute__((address_space(3))) void*)lds_pose, us, ut);
+#ifdef OMGX_PERSIST_STATS
+            if (tid == 0) { PQ_STAT(2, wall_clock64() - t_upd); PQ_STAT(4, 1); }
+#endif
+            __syncthreads();
+        }
+    }
 
     for (;;) {
         // ------------------------------------------------------------------------------------------------ claim an item (one lane)
@@ -359,12 +465,11 @@ __global__ __launch_bounds__(GQ_NT, GQ_WG_PER_CU) void k_plan_persistent(Persist
         // ------------------------------------------------------------------------------------------------ the item
         {
             const bool is_layer = it.k < LP;
-            const unsigned long long ka = reinterpret_cast<unsigned long long>(__builtin_amdgcn_kernarg_segment_ptr());
 #ifdef OMGX_PERSIST_STATS
             const long long t_item = wall_clock64();
 #endif
-            if (is_layer) persist_item<LB, 1>(ka, (LdsBytes)(__attribute__((address_space(3))) void*)lds_pose, it.s, it.k, start_idx);
-            else persist_item<LB, 2>(ka, (LdsBytes)(__attribute__((address_space(3))) void*)lds_pose, it.s, it.k, start_idx);
+            if (is_layer) persist_layer_item<LB>(ka, (LdsBytes)(__attribute__((address_space(3))) void*)lds_pose, it.s, it.k, start_idx);
+            else persist_goal_item<LB>(ka, (LdsBytes)(__attribute__((address_space(3))) void*)lds_pose, it.s, it.k, start_idx);
 #ifdef OMGX_PERSIST_STATS
             if (tid == 0) { PQ_STAT(1, wall_clock64() - t_item); PQ_STAT(3, 1); }
 #endif
@@ -377,7 +482,15 @@ __global__ __launch_bounds__(GQ_NT, GQ_WG_PER_CU) void k_plan_persistent(Persist
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the compiler may drop the wait behind buffer_wbl2: guideline 16, pitfall 12)
                 }
                 const uint32_t old = __hip_atomic_fetch_add(pa.arrive + it.s, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                bc[0] = (old + 1u == (uint32_t)it.nitems) ? 1 : 0;
+                int last_one = (old + 1u == (uint32_t)it.nitems) ? 1 : 0;
+                if (last_one && pa.update_cus > 0 && rmw_u32(pa.xcd_cus + 32 * xcd + 1) > 0u) {
+                    // the scene's update goes to this XCD's update workgroups (what the items wrote is visible: every item released before it arrived)
+                    const uint32_t p = (uint32_t)(__hip_atomic_fetch_add(uht, 1ull << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32);
+                    __hip_atomic_store(pa.uq + (size_t)xcd * pa.cap + p % (uint32_t)pa.cap,
+                                       ((unsigned long long)(p + 1u) << 32) | ((unsigned long long)(uint32_t)it.t << 16) | (unsigned long long)(uint32_t)it.s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    last_one = 0;
+                }
+                bc[0] = last_one;
             }
             __syncthreads();
         }
@@ -392,7 +505,7 @@ __global__ __launch_bounds__(GQ_NT, GQ_WG_PER_CU) void k_plan_persistent(Persist
 #ifdef OMGX_PERSIST_STATS
         const long long t_upd = wall_clock64();
 #endif
-        persist_update(pa, reinterpret_cast<unsigned long long>(__builtin_amdgcn_kernarg_segment_ptr()), (LdsBytes)(__attribute__((address_space(3))) void*)lds_pose, it.s, it.t);
+        persist_update(pa, ka, (LdsBytes)(__attribute__((address_space(3))) void*)lds_pose, it.s, it.t);
 #ifdef OMGX_PERSIST_STATS
         if (tid == 0) { PQ_STAT(2, wall_clock64() - t_upd); PQ_STAT(4, 1); }
 #endif

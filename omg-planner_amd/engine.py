@@ -831,7 +831,7 @@ class ChompEngine:
             r.stop_on_terminate = int(bool(early_stop and t > 0))
         return recs
 
-    def run_persistent(self, ts, early_stop: bool = False, pin_window: bool = False, max_workgroups: int = 0):
+    def run_persistent(self, ts, early_stop: bool = False, pin_window: bool = False, max_workgroups: int = 0, update_cus: int = -1):
         """iterate(t, early_stop) for every t of `ts`, in order, as ONE launch on the current stream (no host sync).  pin_window: the
         learner's window stays at its first-iteration size (bench.py's step: Learner.t = 0 before every iteration)."""
         if not self.persistent_ok():
@@ -865,7 +865,7 @@ class ChompEngine:
                             self.wp_pose, (self.goal_cost, self.goal_col), lprm, self.goal_set, self.reach, self.learner_state, self.goal_idx,
                             self.cost_vec, self._params(True), self.start, self.end, self.goal_rows, self.goal_point,
                             (self.grad, self.cost_traj, self.info), recs, d_iters, ws, active=self._mask(), goal_count=self.goal_count, eta=self.eta_s,
-                            soften_fingers=False, layer_soften_fingers=self.cfg.uncheck_finger_collision == -1, max_workgroups=max_workgroups)
+                            soften_fingers=False, layer_soften_fingers=self.cfg.uncheck_finger_collision == -1, max_workgroups=max_workgroups, update_cus=update_cus)
 
     def persistent_status(self) -> dict:
         return ops.plan_persistent_status(self._persist_ws, self.S)

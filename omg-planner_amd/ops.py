@@ -837,7 +837,7 @@ class IterationCalls:
 
 def plan_persistent(robot, P, scenes: DeviceScenes, goals, dt, traj, layer_out, layer_poses, goal_out, lparams: LearnerParams, goal_set, reach,
                     state, goal_idx, cost_vector, params: ChompParams, start, end, goal_rows, goal_point, step_out, iters, d_iters, workspace,
-                    active=None, goal_count=None, eta=None, soften_fingers=False, layer_soften_fingers=False, max_workgroups=0):
+                    active=None, goal_count=None, eta=None, soften_fingers=False, layer_soften_fingers=False, max_workgroups=0, update_cus=-1):
     """omgx_plan_persistent: len(iters) iterations of the planner loop (omg/planner.py:612-630) for every scene in ONE launch
     (csrc/omg_persist.h) on the current stream.  iters: a ctypes array of _lib.PlanIter (host); d_iters: a uint8 device tensor holding the
     same bytes; workspace: uint8 device tensor of omgx_plan_persistent_workspace_bytes(S, n).  The same tensors as
@@ -877,7 +877,7 @@ def plan_persistent(robot, P, scenes: DeviceScenes, goals, dt, traj, layer_out, 
                                      _ptr(lp), _ptr(lg), _ptr(lc), _ptr(layer_poses), _ptr(active), _ptr(goal_count),
                                      C.byref(lparams), _ptr(goal_set), _ptr(reach), _ptr(state), _ptr(goal_idx), _ptr(cost_vector), _ptr(eta),
                                      C.byref(params), _ptr(start), _ptr(end), _ptr(goal_rows), _ptr(goal_point), _ptr(grad), _ptr(cost_traj), _ptr(info),
-                                     iters, _ptr(d_iters), K, _ptr(workspace), workspace.numel(), int(max_workgroups), _stream()),
+                                     iters, _ptr(d_iters), K, _ptr(workspace), workspace.numel(), int(max_workgroups), int(update_cus), _stream()),
               "omgx_plan_persistent")
 
 

@@ -159,3 +159,19 @@ def test_persistent_launch_whole_plan_against_the_oracle(dev):
     eng.select_initial_goal()
     out = engine_vs_oracle(eng, batch, [0, 1, 2], steps=20, pin_window=False)
     assert out["ok"] and out["max_traj_err"] < 1e-6, out
+
+
+@pytest.mark.parametrize("update_cus", [1, 3])
+def test_persistent_launch_with_dedicated_update_cus(dev, update_cus):
+    """A launch that fills the chip, with the scenes' updates served by the workgroups of dedicated CUs (omg_persist.h: roles): the
+    same bits as the launched iterations — who runs an update changes nothing."""
+    a, b = _pair(dev, 24, 64, 30, "MD", grid=32)
+    for e in (a, b):
+        e.select_initial_goal()
+        e.pose_hand_over(True)
+    for t in range(8):
+        a.iterate(t)
+    b.run_persistent(range(8), update_cus=update_cus)
+    _same(a, b)
+    st = b.persistent_status()
+    assert st["failure"] == 0 and st["scenes_finished"] == 24, st

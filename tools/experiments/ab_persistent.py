@@ -12,6 +12,12 @@ sys.path.insert(0, str(ROOT))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+import os  # noqa: E402
+
+from omg_planner_amd import _lib  # noqa: E402
+
+if os.environ.get("OMGX_LIB"):  # a variant build of the library (omg-planner_amd/csrc/<name>)
+    _lib.LIB_PATH = ROOT / "omg-planner_amd" / "csrc" / os.environ["OMGX_LIB"]
 import bench  # noqa: E402
 from omg_planner_amd.engine import ChompEngine  # noqa: E402
 
@@ -27,10 +33,11 @@ def main():
     ap.add_argument("--regions", type=int, default=6)
     ap.add_argument("--alg", default="MD")
     ap.add_argument("--max-wg", type=int, default=0)
+    ap.add_argument("--update-cus", type=int, default=-1)
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     cfg, model, batch, start, goals = bench.build_workload(args.scenes, args.goals, args.waypoints, args.grid, 0, False, num_objects=args.objects, device=dev)
-    out = {"shape": [args.scenes, args.goals, args.waypoints, args.objects], "steps": args.steps}
+    out = {"shape": [args.scenes, args.goals, args.waypoints, args.objects], "steps": args.steps, "lib": Path(_lib.LIB_PATH).name, "update_cus": args.update_cus}
     engs = {}
     for mode in ("launches", "persistent"):
         eng = ChompEngine.auto(model, batch, copy.deepcopy(cfg), start, goals, device=dev, ol_alg=args.alg)
@@ -49,7 +56,7 @@ def main():
                 eng.iterate(0)
             eng.join()
         else:
-            eng.run_persistent([0] * args.steps, pin_window=True, max_workgroups=args.max_wg)
+            eng.run_persistent([0] * args.steps, pin_window=True, max_workgroups=args.max_wg, update_cus=args.update_cus)
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / args.steps * 1e3
 

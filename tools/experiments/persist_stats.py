@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--objects", type=int, default=4)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--max-wg", type=int, default=0)
+    ap.add_argument("--update-cus", type=int, default=-1)
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     cfg, model, batch, start, goals = bench.build_workload(args.scenes, args.goals, args.waypoints, 64, 0, False, num_objects=args.objects, device=dev)
@@ -41,7 +42,7 @@ def main():
         eng.restore(snap)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        eng.run_persistent([0] * args.steps, pin_window=True, max_workgroups=args.max_wg)
+        eng.run_persistent([0] * args.steps, pin_window=True, max_workgroups=args.max_wg, update_cus=args.update_cus)
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) * 1e3
         st = (C.c_ulonglong * 8)()
