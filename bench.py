@@ -75,6 +75,29 @@ def build_workload(num_scenes, num_goals, n, grid, seed0, share_grids, num_objec
     return cfg, model, batch, start, goals
 
 
+class _stdout_to_stderr:
+    """While RCCL comes up: its version banner goes to the C library's stdout (and is flushed whenever that buffer is) — the driver reads
+    ONE JSON line from this process's stdout.  File descriptor 1 points at stderr for the duration; the C buffers are flushed before it
+    comes back."""
+
+    def __enter__(self):
+        import ctypes
+        sys.stdout.flush()
+        self._libc = ctypes.CDLL(None)
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        try:
+            self._libc.fflush(None)
+        finally:
+            sys.stdout.flush()
+            os.dup2(self._saved, 1)
+            os.close(self._saved)
+        return False
+
+
 def cpu_quota():
     """CPUs' worth of time the container may use (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited."""
     try:
@@ -220,6 +243,100 @@ def rank_share_config4(dev, ol_alg, steps=100, regions=3):
 def config5_shape(dev, ol_alg, steps=100, regions=3):
     """BASELINE config 5's shape on one GPU: 16 cluttered scenes (12 obstacles + the table), 50 waypoints, 64 goals."""
     return shape_step_timing(dev, ol_alg, 16, 64, n=50, objects=12, steps=steps, regions=regions)
+
+
+def strong_scaling_estimate(dev, ol_alg, share8=None, steps=60, regions=3):
+    """BASELINE config 4 (100 scenes x 128 goals) on 1 / 2 / 4 / 8 GPUs, ESTIMATED from this one GPU: a rank of an N-GPU job owns
+    ceil(100 / N) whole scenes and exchanges nothing per iteration (engine.shard_range), so the job's step is the
+    step of its largest shard — timed here shard by shard (100, 50, 25, 13 scenes x 128 goals), each laid out by ChompEngine.layout like
+    the rank that would own it, each with its roofline block.  speedup = ms(100 scenes) / ms(shard): what N GPUs could give at best
+    (the collective and the ranks' skew come on top: `collective`).  An estimate from 1-GPU runs, NOT a measured scaling curve."""
+    out = {}
+    for n_gpus, scenes in ((1, 100), (2, 50), (4, 25), (8, 13)):
+        ms, lay, roof = share8 if (n_gpus == 8 and share8 is not None) else shape_step_timing(dev, ol_alg, scenes, 128, layout_scenes=scenes, steps=steps, regions=regions)
+        out[str(n_gpus)] = {"scenes_per_gpu": scenes, "ms_per_step": ms, "layout": lay, "frac": roof.get("frac"), "avg_launch_ms": roof.get("avg_launch_ms")}
+    base = out["1"]["ms_per_step"]
+    for k, v in out.items():
+        v["speedup"] = base / v["ms_per_step"]
+        v["efficiency"] = v["speedup"] / int(k)
+    out["what"] = "estimate: step of the largest shard of 100 scenes x 128 goals, timed on ONE GPU; no N-GPU node has run this"
+    return out
+
+
+def collective_cost(dev, num_scenes, reps=50):
+    """What the job's ONE collective costs per call: the all-gather of the final per-scene costs (engine.gather_costs) over RCCL with
+    one rank — the floor of its latency on this box (kernel launch + RCCL's own bookkeeping; over xGMI with N ranks the ring adds
+    N - 1 hops of a few microseconds for these <= 51 KB).  Weak scaling exchanges nothing else: this cost is paid once per timed
+    region / plan, not per step."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    if dist.is_initialized():
+        return None
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    try:
+        from omg_planner_amd.engine import gather_costs_equal
+        x = torch.zeros(num_scenes, dtype=torch.float64, device=dev)
+        with _stdout_to_stderr():
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+            for _ in range(5):
+                gather_costs_equal(x, 1)
+            torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            gather_costs_equal(x, 1)
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) * 1e6)
+        ts.sort()
+        return {"all_gather_us_one_rank": ts[len(ts) // 2], "min_us": ts[0], "bytes": num_scenes * 8, "backend": "nccl (RCCL), world_size 1",
+                "per": "timed region / plan (one call closes the job), not per step"}
+    except Exception as e:  # a box without RCCL support for a one-rank group: say so instead of failing the bench
+        return {"error": repr(e)[:200]}
+    finally:
+        with _stdout_to_stderr():
+            if dist.is_initialized():
+                dist.destroy_process_group()
+
+
+def persistent_launch_timing(dev, cfg, model, batch, start, goals, ol_alg, steps=50, regions=4):
+    """The same step as ONE persistent launch per block of iterations (ChompEngine.run_persistent, omgx_plan_persistent: workgroups
+    claim items, a scene's last item runs its learner and step and activates the scene's next iteration — DESIGN.md section 4.7)
+    against the launches per iteration of the timed region, same engine layout rule, same pinned window: ms per step of both and whether
+    every bit agrees.  Measured here so that the comparison is the bench line's, not a side script's."""
+    import torch
+    from omg_planner_amd.engine import ChompEngine
+    eng = ChompEngine(model, batch, copy.deepcopy(cfg), start, goals, device=dev, ol_alg=ol_alg)
+    if not eng.persistent_ok() or ol_alg not in ChompEngine.PERSISTENT_ALGS:
+        return None
+    eng.pose_hand_over(True)
+    snap = eng.snapshot()
+    ref = ChompEngine.auto(model, batch, copy.deepcopy(cfg), start, goals, device=dev, ol_alg=ol_alg)
+    ref.pose_hand_over(True)
+    rsnap = ref.snapshot()
+
+    def run(persistent):
+        e, sn = (eng, snap) if persistent else (ref, rsnap)
+        e.restore(sn)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if persistent:
+            e.run_persistent([0] * steps, pin_window=True)
+        else:
+            for _ in range(steps):
+                e.t = 0
+                e.iterate(0)
+            e.join()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps * 1e3
+    run(True), run(False)
+    a = sorted(run(True) for _ in range(regions))
+    b = sorted(run(False) for _ in range(regions))
+    same = all(bool(torch.equal(getattr(eng, k), getattr(ref, k))) for k in ("traj", "info", "goal_idx", "learner_state", "goal_cost", "cost_traj"))
+    return {"ms_per_step_persistent": a[len(a) // 2], "ms_per_step_launches": b[len(b) // 2], "steps_per_launch": steps, "bits_equal": same,
+            "status": eng.persistent_status(), "note": "one launch for `steps_per_launch` iterations of all scenes; not the path the timed region uses"}
 
 
 def scene_update_timing(dev, cfg, model, batch, start, goals, ol_alg):
@@ -395,10 +512,13 @@ def main():
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        with _stdout_to_stderr():
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+                dist.barrier()  # the communicator (and RCCL's banner) comes up HERE, not inside the first timed collective
+                torch.cuda.synchronize()
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
 
     from omg_planner_amd import _lib
     from omg_planner_amd.engine import ChompEngine, gather_costs, gather_costs_equal, shard_range
@@ -568,10 +688,12 @@ def main():
         parity["ok"] = bool(parity["ok"] and sm["ok"])
 
     ms_per_plan = ms_plan_early = ms_single = ms_single_batch_layout = terminated = ms_graph_early = ms_graph_single = None
-    share4 = scene_upd = drop_in = cfg5 = None
+    share4 = scene_upd = drop_in = cfg5 = scaling = coll = persist = None
     if not args.no_plan and rank == 0 and world == 1:
         share4 = rank_share_config4(dev, args.ol_alg)
         cfg5 = config5_shape(dev, args.ol_alg)
+        scaling = strong_scaling_estimate(dev, args.ol_alg, share8=share4)
+        persist = persistent_launch_timing(dev, cfg, model, batch, start, goals, args.ol_alg)
         scene_upd = scene_update_timing(dev, cfg, model, host_batch(), start, goals, args.ol_alg)
         drop_in = drop_in_plan_timing(dev, args.ol_alg)
     if not args.no_plan and rank == 0:
@@ -669,6 +791,10 @@ def main():
             out["ms_per_step_rank_share_config4"] = share4[0]  # 13 scenes x 128 goals on this GPU: one rank's share of BASELINE config 4 on 8 GPUs
             out["rank_share_config4_layout"] = share4[1]
             out["roofline_rank_share_config4"] = share4[2]  # the same block as `roofline`, for that shape's own goal-set launches
+        if scaling is not None:
+            out["strong_scaling_estimate"] = scaling  # BASELINE config 4 on 1 / 2 / 4 / 8 GPUs from 1-GPU runs of the shards: ms_per_step, speed-up, frac per N
+        if persist is not None:
+            out["persistent_launch"] = persist
         if cfg5 is not None:
             out["ms_per_step_config5_shape"] = cfg5[0]  # 16 scenes x 64 goals, 50 waypoints, 12 obstacles + table (BASELINE config 5's shape)
             out["config5_shape_layout"] = cfg5[1]
@@ -691,10 +817,16 @@ def main():
             out["ms_per_plan_single_scene_graph"] = ms_graph_single
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, model, host_batch(), start, goals, n)
+        if world == 1 and not dist_on and not args.no_plan:
+            coll = collective_cost(dev, S)
+            if coll is not None:
+                out["collective"] = coll  # the job's one collective (final costs): what weak scaling pays on top of the ranks' own steps
         print(json.dumps(out))
     if dist_on:
         import torch.distributed as dist
-        dist.destroy_process_group()
+        sys.stdout.flush()
+        with _stdout_to_stderr():
+            dist.destroy_process_group()
     if parity is not None and not parity["ok"]:
         raise SystemExit(f"parity_sample failed: {parity}")
 

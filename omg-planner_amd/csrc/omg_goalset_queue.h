@@ -257,8 +257,16 @@ __device__ __forceinline__ void gq_item(const ChunkArgs& a, double* const lds_po
     // mask reads, an OR and a vote per tile.  The culling leaves one bit per tile instead — bit 4 * block + (pair & 3) of word pair >> 2,
     // behind the masks — and an empty tile is a scalar bit test.  Only where the tiles are dealt plainly and a link pair's rows fit one
     // pass (batch kernel, whole goals, own kinematics, window <= 32: eight blocks); elsewhere every bit is set.
+    // Round 6: windows of 33 .. 64 waypoints (BASELINE config 5 plans with 50) have up to 16 blocks: bit 4 (block & 7) + pair of word
+    // block >> 3 for the pairs 0-3, bit `block` of word 3 for pair 4 (word 2 stays the tile counter) — and their up to 80 tiles get the
+    // drawn list too (two entries per lane).  They used to visit all 65 tiles, one LDS atomic each, votes and mask reads included.
     constexpr bool TILEBITS = !LAT && !SPLIT && !PRE && LB == 2;
-    const bool tb_on = TILEBITS && CH <= 32;
+    const bool tb_on = TILEBITS;
+    const bool tb_wide = CH > 32;  // which of the two bit layouts
+    auto tile_bit_set = [&](int rb, int pr) -> bool {  // after the culling (LDS reads)
+        if (!tb_wide) return (tilebits[pr >> 2] >> ((4 * rb + (pr & 3)) & 31)) & 1u;
+        return pr < 4 ? ((tilebits[rb >> 3] >> (4 * (rb & 7) + pr)) & 1u) : ((tilebits[3] >> rb) & 1u);
+    };
     if (tid < 4) tilebits[tid] = (tb_on || tid >= 2) ? 0u : 0xffffffffu;  // (ordered before the culling by the barrier behind the (sin, cos) stage; word 2: the main loop's tile counter)
     // The chain stage of the kinematics keeps ceil(3 (CH + 1) / 64) waves busy (one lane per (configuration, pose row)) and
     // produces the links' poses in order; the other waves cull the rows of a link as soon as every chain wave has published
@@ -474,8 +482,11 @@ __device__ __forceinline__ void gq_item(const ChunkArgs& a, double* const lds_po
         for (int row = tid; row < 10 * CH; row += 256) {
             const int l = row / CH, ci = row - l * CH;
             const uint32_t m = cull_row(l, ci);
-            if (tb_on && m != 0u)  // (chain on more than two waves with a short window)
-                __hip_atomic_fetch_or(tilebits + (l >> 3), 1u << (4 * ((ci + blk_shift) >> 2) + ((l >> 1) & 3)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (tb_on && m != 0u) {  // (chain on more than two waves, or a window beyond 32 waypoints)
+                const int rb = (ci + blk_shift) >> 2, pr = l >> 1;
+                if (!tb_wide) __hip_atomic_fetch_or(tilebits + (l >> 3), 1u << (4 * rb + (pr & 3)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                else __hip_atomic_fetch_or(tilebits + (pr < 4 ? (rb >> 3) : 3), 1u << (pr < 4 ? 4 * (rb & 7) + pr : rb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
         }
         __syncthreads();
     }
@@ -663,26 +674,32 @@ __device__ __forceinline__ void gq_item(const ChunkArgs& a, double* const lds_po
     // the tiles this workgroup holds, heaviest first: all of the goal's, or — SPLIT — the tiles part, part + NP, ... of it
     const int ncand = SPLIT ? (ntiles > part ? (ntiles - part + NP - 1) / NP : 0) : ntiles;
     auto cand = [&](int j) { return SPLIT ? part + NP * (ncand - 1 - j) : ntiles - 1 - j; };
-    int my_tile = -1, n_list = 0;
+    int my_tile = -1, my_tile2 = -1, n_list = 0;  // the list: entry i in lane i of my_tile, entry 64 + i in lane i of my_tile2
     uint32_t* const tile_counter = tilebits + 2;
+    constexpr int LIST_MAX = TILEBITS ? 128 : 64;  // (80 tiles at 64 waypoints)
     if constexpr (DYN) {
-        if (ncand <= 64) {
-            const int t = lane < ncand ? cand(lane) : -1;
-            bool ne = t >= 0;
-            if constexpr (TILEBITS) {  // bits all set when the window is longer than 32
-                const int rb = (t < 0 ? 0 : t) / (10 / LB), pr = (t < 0 ? 0 : t) - rb * (10 / LB);
-                const uint32_t wsel = tilebits[pr >> 2];
-                ne = ne && ((wsel >> ((4 * rb + (pr & 3)) & 31)) & 1u);
-            }
-            const unsigned long long bal = wave_ballot(ne);
-            const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+        if (ncand <= LIST_MAX) {
             int* const lst = reinterpret_cast<int*>(stage);
-            if (ne) lst[rank] = t;
-            n_list = __popcll(bal);
+            int base = 0;
+            for (int j0 = 0; j0 < ncand; j0 += 64) {  // (one round up to 64 candidates)
+                const int j = j0 + lane;
+                const int t = j < ncand ? cand(j) : -1;
+                bool ne = t >= 0;
+                if constexpr (TILEBITS) {
+                    const int rb = (t < 0 ? 0 : t) / (10 / LB), pr = (t < 0 ? 0 : t) - rb * (10 / LB);
+                    ne = ne && tile_bit_set(rb, pr);
+                }
+                const unsigned long long bal = wave_ballot(ne);
+                const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+                if (ne) lst[base + rank] = t;
+                base += __popcll(bal);
+            }
+            n_list = base;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             my_tile = lane < n_list ? lst[lane] : -1;
+            if constexpr (TILEBITS) my_tile2 = 64 + lane < n_list ? lst[64 + lane] : -1;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();  // the list has been read: the ring is the queue's from here on
         } else n_list = ncand;
@@ -696,7 +713,9 @@ __device__ __forceinline__ void gq_item(const ChunkArgs& a, double* const lds_po
             if (q >= n_list) return -1;
             // (a draw requested one tile ahead, to hide the atomic's trip behind the previous tile, was measured: every wave then holds
             // two of the dozen tiles from the start and the balance is the static deal's again — first / last wave out 10.8 / 15.1 us)
-            return ncand <= 64 ? __builtin_amdgcn_readlane(my_tile, q) : cand(q);
+            if (ncand > LIST_MAX) return cand(q);
+            if constexpr (TILEBITS) { if (q >= 64) return __builtin_amdgcn_readlane(my_tile2, q - 64); }
+            return __builtin_amdgcn_readlane(my_tile, q);
         } else return lat_tile(q_static++);
     };
 #pragma unroll 1

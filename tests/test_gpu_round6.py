@@ -145,8 +145,8 @@ def test_persistent_launch_fifty_waypoints_a_dozen_objects(dev):
 
 
 def test_persistent_launch_whole_plan_against_the_oracle(dev):
-    """70 iterations in one launch against the oracle-driven loop (no early stop): the persistent path on its own, not only against
-    the launches it replaces."""
+    """Twenty planner iterations, each a persistent launch, against the oracle-driven loop: the persistent path on its own, not only
+    against the launches it replaces."""
     from omg_planner_amd.engine import ChompEngine
     from oracle.check import engine_vs_oracle
     import bench
@@ -175,3 +175,24 @@ def test_persistent_launch_with_dedicated_update_cus(dev, update_cus):
     _same(a, b)
     st = b.persistent_status()
     assert st["failure"] == 0 and st["scenes_finished"] == 24, st
+
+
+@pytest.mark.parametrize("G", [128, 200])
+def test_persistent_launch_many_goals(dev, G):
+    """More than 64 goals: the persistent launch's learner holds two (G <= 128) or four goals per lane — other instantiations of the
+    same float64 code than the update kernels', whose fused multiply-adds the compiler may place differently: the learner's state agrees
+    to the last bits (1e-15), everything downstream of the chosen goal bit for bit."""
+    a, b = _pair(dev, 3, G, 30, "MD", grid=24)
+    for e in (a, b):
+        e.select_initial_goal()
+        e.pose_hand_over(True)
+    for t in range(6):
+        a.iterate(t)
+    b.run_persistent(range(6))
+    torch.cuda.synchronize()
+    for k in _CMP:
+        x, y = getattr(a, k), getattr(b, k)
+        if k == "learner_state":
+            np.testing.assert_allclose(y.cpu().numpy(), x.cpu().numpy(), rtol=1e-12, atol=1e-15)
+        else:
+            assert torch.equal(x, y), (k, float((x.double() - y.double()).abs().max()))
