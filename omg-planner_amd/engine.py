@@ -117,6 +117,13 @@ class ChompEngine:
         load = num_scenes * num_goals * max(n_waypoints, 1) / 30.0
         if num_scenes == 1:
             return {"latency_mode": True, "goal_parts": 1, "pipeline": 1}
+        if n_waypoints > 40 and 320 < load < 2560:
+            # Long windows (round 6; BASELINE config 5 plans with 50 waypoints): a goal workgroup's poses alone are 37 KB, three
+            # workgroups per CU instead of five, and its 65 tiles make a long life — two workgroups per goal pay up to twice the size the
+            # 30-waypoint sweep found (bench.py --waypoints 50 --objects 12, ms per step, (goal_parts, pipeline)): 4 x 64 (2, 2) 0.091
+            # against (1, 3) 0.126; 8 x 64 (2, 2) 0.125, (2, 3) 0.120 against 0.170; 16 x 64 (2, 2) 0.165 against 0.189 — (1, 1) 0.183,
+            # (2, 3) 0.193; 32 x 64 and 16 x 128: whole goals again ((1, 3) 0.275 / 0.256 against (2, 2) 0.297 / 0.261)
+            return {"latency_mode": False, "goal_parts": 2, "pipeline": max(1, min(2, num_scenes))}
         if load <= 320:
             gp, pipe = 4, 2
         elif load <= 896:

@@ -121,6 +121,16 @@ def one_trial(rng, trial, dev, dry=False):
     if r2.rand() < 0.5:
         eng.pose_hand_over(True)
         STATS["pose_hand_over"] = STATS.get("pose_hand_over", 0) + 1
+    # round 6: every iteration as a persistent launch (omgx_plan_persistent: workgroups claim items, the scene's last item runs its
+    # update) in a third of the trials the batch layout with whole goals serves — its own random stream, with a handful of
+    # workgroups in half of them (long queues, scenes migrating between XCDs) and dedicated update CUs in a few
+    r3 = np.random.RandomState(104729 * trial + 7)
+    persistent = (pipe is None and not lat and gparts == 1 and (alg in ChompEngine.PERSISTENT_ALGS or not cfg.goal_set_proj) and r3.rand() < 0.33
+                  and not os.environ.get("OMGX_FUZZ_NO_PERSISTENT"))
+    p_wg = int(r3.choice([0, 0, 8, 16, 40])) if persistent else 0
+    p_ucu = int(r3.choice([-1, -1, -1, 1])) if persistent and p_wg == 0 else (0 if persistent else -1)
+    if persistent:
+        STATS["persistent"] = STATS.get("persistent", 0) + 1
     traj = eng.traj.cpu().numpy().copy()
     state = orc.learner_state_init(S, G)
     states_r = None if counts is None else [orc.learner_state_init(1, int(k_)) for k_ in counts]
@@ -137,7 +147,10 @@ def one_trial(rng, trial, dev, dry=False):
         eng.join()
         prev = {k_: getattr(eng, k_).clone() for k_ in ("traj", "learner_state", "goal_idx", "end", "goal_rows", "goal_point", "info")}
         prev["active"] = eng.active.clone()
-        eng.iterate(t, early_stop=early)
+        if persistent:
+            eng.run_persistent([t], early_stop=early, max_workgroups=p_wg, update_cus=p_ucu)
+        else:
+            eng.iterate(t, early_stop=early)
         eng.join()
         if os.environ.get("OMGX_FUZZ_DEBUG"):
             torch.cuda.synchronize()
@@ -287,7 +300,7 @@ def main(trials=None, seed=None):
         print(f"class {name}: {len(items)} trial(s) " + json.dumps({str(k_): v_ for k_, v_ in list(items.items())[:8]}), flush=True)
     print(f"{trials - bad}/{trials} trials agree; worst trajectory difference {worst_all:.2e}; joint-limit projection steps "
           f"{STATS['limit_steps']}, limit-violation flags {STATS['violations']}, scene-iterations skipped after termination {STATS['stopped']}, "
-          f"{STATS.get('ragged', 0)} trials with ragged goal sets, {STATS.get('pipelined', 0)} with a pipelined engine, {STATS.get('latency', 0)} in latency mode, {STATS.get('split_goals', 0)} with split goals, {STATS.get('pose_hand_over', 0)} with the pose hand-over; {time.time() - t0:.0f} s")
+          f"{STATS.get('ragged', 0)} trials with ragged goal sets, {STATS.get('pipelined', 0)} with a pipelined engine, {STATS.get('latency', 0)} in latency mode, {STATS.get('split_goals', 0)} with split goals, {STATS.get('pose_hand_over', 0)} with the pose hand-over, {STATS.get('persistent', 0)} through the persistent launch; {time.time() - t0:.0f} s")
     return 1 if bad else 0
 
 

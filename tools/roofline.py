@@ -46,8 +46,11 @@ KERNEL_R4 = "k_goalset_queue<2, false, false, false>"      # the same instantiat
 KERNEL_OLD = "k_goalset_queue<2, false, false>"            # ... and before round 4 (three): profiles up to r03h
 
 
+KERNEL_SPLIT = "k_goalset_queue<2, false, false, true, false>"  # the batch kernel with a goal's tiles over two or more workgroups (long windows, small batches)
+
+
 def is_dominant(name: str) -> bool:
-    return KERNEL in name or KERNEL_R4 in name or KERNEL_OLD in name
+    return KERNEL in name or KERNEL_SPLIT in name or KERNEL_R4 in name or KERNEL_OLD in name
 CALIBRATION_TAG = "r03d"  # profiles/<tag>_valu_peak.csv
 
 # SQ_INSTS_VALU_* class -> the calibration row that prices it (cheapest member of the class: lower bound of the issue time)
