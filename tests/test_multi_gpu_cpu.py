@@ -128,7 +128,10 @@ def test_layout_rule_is_a_pure_function_of_the_shape():
     for shape in ((13, 128), (25, 64), (16, 64), (50, 64), (100, 64), (100, 128), (400, 64)):
         assert L(*shape)["goal_parts"] == 1 and not L(*shape)["latency_mode"], shape
     assert L(13, 128)["pipeline"] == 3 and L(25, 64)["pipeline"] == 3 and L(100, 64)["pipeline"] == 3 and L(400, 64)["pipeline"] == 2 and L(2, 64)["pipeline"] == 2
-    assert L(16, 12, 50)["goal_parts"] == 4 and L(16, 64, 50)["goal_parts"] == 1  # the load grows with the window
+    assert L(16, 12, 50)["goal_parts"] == 4  # the load grows with the window
+    # round 6: beyond 40 waypoints two workgroups per goal pay up to load 2560 (BASELINE config 5's shape), whole goals beyond
+    assert L(16, 64, 50) == {"latency_mode": False, "goal_parts": 2, "pipeline": 2} and L(8, 64, 50)["goal_parts"] == 2
+    assert L(32, 64, 50)["goal_parts"] == 1 and L(16, 128, 50)["goal_parts"] == 1 and L(16, 64, 40)["goal_parts"] == 1
     assert all(L(s, g)["pipeline"] <= s for s in (1, 2, 3) for g in (8, 64, 512))
     assert L(13, 128) == L(13, 128)  # no hidden state
     # BASELINE config 4 on 8 ranks: shards of 13 and 12 scenes, one layout
