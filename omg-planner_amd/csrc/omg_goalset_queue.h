@@ -301,6 +301,8 @@ __device__ __forceinline__ void gq_item(const ChunkArgs& a, double* const lds_po
     if constexpr (PRE) {
         // Everything the main loop starts from, requested before the first LDS store: the goal's poses (workspace layout
         // [link][component][configuration] -> LDS [link][configuration][9]) and row masks, the robot's collision points, the records.
+        static_assert(30 * OMGX_MAX_POINTS <= 2 * GQ_NT && 10 * OMGX_MAX_WAYPOINTS <= 3 * GQ_NT && GQ_WAVES >= 4,
+                      "the prologue loads the collision points in two passes and the row masks in three, and the final reduction reads four waves' sums");
         const int ncfg = CH + 1;
         const int64_t gi = (int64_t)s * a.NG + goal;
         const double* pw = a.pre_poses + gi * gk_pose_doubles(CH);

@@ -41,7 +41,7 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
 
 def _kin_workspace(prepass, S: int, G: int, n_remaining: int, P: int, device):
     """Scratch of the kinematics pre-pass (omgx_goalset_workspace_bytes): None without it, the caller's own uint8 tensor, or the
-    per-device cached buffer (one stream at a time: launches on two streams need a workspace each)."""
+    cached buffer of this (device, current stream) pair (`_workspace`: launches on different streams get different buffers)."""
     if prepass is None or prepass is False:
         return None
     need = _lib.lib().omgx_goalset_workspace_bytes(S, G, int(n_remaining), P)
