@@ -52,6 +52,9 @@ template <int MI>
 __global__ __launch_bounds__(CH_TPB) void k_update_optimize_split(omg_learner::LearnerArgs la, ChompArgs a, uint32_t* goal_flags,
                                                                   uint32_t ticket, uint32_t publish /* == ticket (test hook: see omgx_debug_drop_ticket) */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#ifdef OMGX_UPD_PRIO
+    __builtin_amdgcn_s_setprio(OMGX_UPD_PRIO);  // experiment build (DESIGN_HISTORY appendix A): the update's waves ahead of the goal workgroups that share their CU
+#endif
     const int S = la.S;
     if ((int)blockIdx.x < S) {
 #ifdef OMGX_PHASE_TIMING
