@@ -99,13 +99,13 @@ __device__ __forceinline__ unsigned long long wave_ballot(bool b) { return __bui
 // dynamic LDS behind the poses (bytes, all 16-byte aligned): row masks | exact-path records | collision points | staging
 struct GqLayout {
     int mask_off, tile_off, tbl_off, pts_off, stage_off, fkc_off, objc_off, btab_off, total;
-    __host__ __device__ GqLayout(int PS, int MR, int P, int tbl_n, bool with_fkc = false) {
+    __host__ __device__ GqLayout(int PS, int MR, int P, int tbl_n, bool with_fkc = false, int waves = GQ_WAVES) {
         mask_off = PS * 90 * 8;
         tile_off = mask_off + 10 * MR * 4;  // 3 words behind the row masks: bit (block * 5 + link pair) = the tile has a row in reach of something
         tbl_off = mask_off + ((10 * MR * 4 + 16 + 15) & ~15);
         pts_off = tbl_off + tbl_n * 64;
         stage_off = pts_off + ((10 * P * 3 * 8 + 15) & ~15);
-        total = stage_off + GQ_WAVES * 64 * 16;
+        total = stage_off + waves * 64 * 16;  // a 1 KB ring per wave
         // the (sin, cos) table of the kinematics [PS][7][2] doubles borrows the queues' region (first used in the main loop), so
         // that the records and collision points can be staged while the kinematics run
         const int fk = stage_off + PS * 14 * 8 + 16;  // + the chain waves' progress flags (4 words)
@@ -123,9 +123,9 @@ struct GqLayout {
 // How many exact-path records to stage: as many as still fit the LDS of the occupancy step the launch is on anyway.  The steps
 // are what a CU admits (tools/lds_occupancy_probe.hip: 6 workgroups up to 26 624 B, 5 up to 31 744 B, 4 up to 40 960 B — at
 // 32 768 B the occupancy API still says 5 but only 4 become resident).
-static inline int gq_choose_tbl_n(int PS, int MR, int P, bool with_fkc = false) {
+static inline int gq_choose_tbl_n(int PS, int MR, int P, bool with_fkc = false, int waves = GQ_WAVES) {
     static const int step[] = {26624, 31744, 40960, 53248, 80896, 163840};
-    const int base = GqLayout(PS, MR, P, 0, with_fkc).total;
+    const int base = GqLayout(PS, MR, P, 0, with_fkc, waves).total;
     for (int k = 0; k < 6; ++k)
         if (base + 4 * 64 <= step[k]) {  // at least 4 records
             const int n = (step[k] - base) / 64;
@@ -184,7 +184,10 @@ __device__ __forceinline__ void gq_st_out(float* p, float v) {
 
 // One work item of k_goalset_queue — a goal (or one part of it) or one piece of a scene's trajectory layer — by a whole workgroup.
 // ROLE (omg_persist.h compiles the two kinds of item as functions of their own): 0 = either, 1 = a trajectory-layer piece, 2 = a goal.
-template <int LB, bool STAMP, bool LAT, bool SPLIT, bool PRE, bool PERSIST = false, int ROLE = 0>
+// W (round 6): waves per workgroup.  4 everywhere but in the WIDE instantiations of the batch kernel (whole goals, own kinematics), which
+// mid-size launches use: a launch whose workgroups all start at once lasts as long as its heaviest goal, and a goal's tiles are drawn by
+// however many waves there are.  Same masks, same tiles, same exact sum: same bits.
+template <int LB, bool STAMP, bool LAT, bool SPLIT, bool PRE, bool PERSIST = false, int ROLE = 0, int W = GQ_WAVES>
 __device__ __forceinline__ void gq_item(const ChunkArgs& a, double* const lds_pose, const int s, const bool is_layer, const int layer_part, const int chunk, const int NP) {
     const int o_begin = as_const(a.scene_begin)[s], o_end = as_const(a.scene_begin)[s + 1];
     const int P = a.P;
@@ -204,7 +207,9 @@ __device__ __forceinline__ void gq_item(const ChunkArgs& a, double* const lds_po
     const int tid = (int)threadIdx.x;
     const RobotViewS rv(a.robot, P);
     const int pstride = a.PS, MR = a.MR;
-    const GqLayout L(pstride, MR, P, a.tbl_n, LAT);
+    static_assert(W == GQ_WAVES || (!LAT && !SPLIT && !PRE && !PERSIST && W >= 4), "wide workgroups: the batch kernel with whole goals and its own kinematics");
+    constexpr int NT = 64 * W;  // threads of the workgroup
+    const GqLayout L(pstride, MR, P, a.tbl_n, LAT, W);
     char* const lds_bytes = reinterpret_cast<char*>(lds_pose);
     uint32_t* const rowmask = reinterpret_cast<uint32_t*>(lds_bytes + L.mask_off);
     uint32_t* const tilebits = reinterpret_cast<uint32_t*>(lds_bytes + L.tile_off);  // goal workgroups: which tiles have anything in reach
@@ -350,7 +355,7 @@ __device__ __forceinline__ void gq_item(const ChunkArgs& a, double* const lds_po
         int* const progress = reinterpret_cast<int*>(lds_bytes + L.stage_off + pstride * 14 * 8);  // [4] links a chain wave has published
         if (tid < 4) progress[tid] = (tid < chain_waves || (cull_beside_chain && tid == 3)) ? 0 : 99;  // [3]: the culling's pair counter when two waves are free
         // the robot's collision points -> LDS: the loads are issued here and land while the (sin, cos) stage runs
-        const double pv0 = tid < 30 * P ? rv.g[246 + tid] : 0.0, pv1 = tid + 256 < 30 * P ? rv.g[246 + tid + 256] : 0.0;
+        const double pv0 = tid < 30 * P ? rv.g[246 + tid] : 0.0, pv1 = (tid < 256 && tid + 256 < 30 * P) ? rv.g[246 + tid + 256] : 0.0;  // (30 P <= 480)
         double* const fkc = reinterpret_cast<double*>(lds_bytes + L.fkc_off);  // LAT: the chain's constants, one coalesced load
         const double fkv = (LAT && tid < 246) ? rv.g[tid] : 0.0;
         const bool tbl_lane = tid >= 128 && tid - 128 < a.tbl_n && o_begin + tid - 128 < o_end;  // lanes of wave 2: idle during the chain stage
@@ -358,7 +363,7 @@ __device__ __forceinline__ void gq_item(const ChunkArgs& a, double* const lds_po
         if (LAT && tbl_lane) trec = gq_tbl_load(a.objects + o_begin + (tid - 128));  // LAT: requested here, stored after the barrier
         if (warming) gq_warm_scalar_cache(a.objects, o_begin, o_end, a.robot + OMGX_ROBOT_POINTS + 30 * P + 316 + 30 * P);
         auto joint = [&](int cfg, int d) { const double q0d = gq_ld_traj<PERSIST>(q0 + d); return cfg == 0 ? q0d : q0d + ((double)cfg * (1.0 / (double)(CH + 1))) * (qg[d] - q0d); };
-        for (int t = tid; t < ncfg * 7; t += 256) {
+        for (int t = tid; t < ncfg * 7; t += NT) {
             const int cfg = t / 7, i = t - cfg * 7;
             double sn, cs;
 #ifdef OMGX_GS_PRO2  // measurement build: the (sin, cos) stage's arithmetic twice — what a prologue instruction costs the step
@@ -376,14 +381,14 @@ __device__ __forceinline__ void gq_item(const ChunkArgs& a, double* const lds_po
         __syncthreads();
         GS_WG_STAMP(1);
         if (tid < 30 * P) pts[tid] = pv0;
-        if (tid + 256 < 30 * P) pts[tid + 256] = pv1;
+        if (tid < 256 && tid + 256 < 30 * P) pts[tid + 256] = pv1;
         // ---- exact-path records of the scene's first a.tbl_n objects -> LDS, by lanes of wave 2 (idle during the chain stage)
         if (tbl_lane) {
             if (!LAT) trec = gq_tbl_load(a.objects + o_begin + (tid - 128));
             gq_tbl_store(tbl + (tid - 128) * 16, trec);
         }
         auto run_chain = [&](const auto& view) {
-            for (int t = tid; t < ncfg * 3; t += 256) {
+            for (int t = tid; t < ncfg * 3; t += NT) {
                 const int cfg = t / 3, rr = t - cfg * 3;
                 fk_chain_row(view, rr, sc + 14 * cfg, joint(cfg, 7), joint(cfg, 8), [&](int l, double r0, double r1, double r2, double tr) {
                     double* dst = lds_pose + ((size_t)l * pstride + cfg) * 9;  // rows 0 and 1 of R, then t
@@ -411,7 +416,7 @@ __device__ __forceinline__ void gq_item(const ChunkArgs& a, double* const lds_po
                 });
             }
         } else if constexpr (BTAB) {
-            for (int j = wave; j < 7; j += 4)  // wave-uniform joint: U, V, W of the joint are scalar operands
+            for (int j = wave; j < 7; j += W)  // wave-uniform joint: U, V, W of the joint are scalar operands
                 for (int cfg = lane; cfg < ncfg; cfg += 64)
                     fk_joint_matrix(rv, j, sc[2 * (cfg * 7 + j)], sc[2 * (cfg * 7 + j) + 1], lds_pose + ((size_t)j * pstride + cfg) * 9);
             __syncthreads();
@@ -481,7 +486,7 @@ __device__ __forceinline__ void gq_item(const ChunkArgs& a, double* const lds_po
             if (t >= 0 && ci >= 0 && ci < CH) cull_row(l, ci);
         }
     } else if (!cull_beside_chain) {
-        for (int row = tid; row < 10 * CH; row += 256) {
+        for (int row = tid; row < 10 * CH; row += NT) {
             const int l = row / CH, ci = row - l * CH;
             const uint32_t m = cull_row(l, ci);
             if (tb_on && m != 0u) {  // (chain on more than two waves, or a window beyond 32 waypoints)
@@ -845,8 +850,8 @@ __device__ __forceinline__ void gq_item(const ChunkArgs& a, double* const lds_po
     {
         const double ws_ = wave_sum(tsum);  // exact (see tsum)
         const float wc_ = wave_sum(tcol);
-        double* red = reinterpret_cast<double*>(lds_bytes + L.tbl_off);  // [GQ_WAVES] sums, then as many float counts: the records are dead once every wave has flushed its queue
-        float* redc = reinterpret_cast<float*>(red + GQ_WAVES);
+        double* red = reinterpret_cast<double*>(lds_bytes + L.tbl_off);  // [W] sums, then as many float counts: the records are dead once every wave has flushed its queue
+        float* redc = reinterpret_cast<float*>(red + W);
         __syncthreads();
         if (lane == 0) { red[wave] = ws_; redc[wave] = wc_; }
         __syncthreads();
@@ -855,7 +860,7 @@ __device__ __forceinline__ void gq_item(const ChunkArgs& a, double* const lds_po
             double rs = ((red[0] + red[1]) + red[2]) + red[3];   // exact: the order does not matter (tsum)
             float rc = ((redc[0] + redc[1]) + redc[2]) + redc[3];  // integers below 2^24: exact too
 #pragma unroll
-            for (int w = 4; w < GQ_WAVES; ++w) { rs += red[w]; rc += redc[w]; }
+            for (int w = 4; w < W; ++w) { rs += red[w]; rc += redc[w]; }
             if (a.chunk_cost) gq_st_out<PERSIST>(a.chunk_cost + k, (float)rs);
             if (a.chunk_col) gq_st_out<PERSIST>(a.chunk_col + k, rc);
             if (STAMP) { const unsigned long long dt = wall_clock64() - work_t0; a.work[k] = dt < 1 ? 1u : (dt > 0xffffffffull ? 0xffffffffu : (uint32_t)dt); }
@@ -865,8 +870,11 @@ __device__ __forceinline__ void gq_item(const ChunkArgs& a, double* const lds_po
     GS_WG_STAMP(4);
 }
 
-template <int LB, bool STAMP = false, bool LAT = false, bool SPLIT = false, bool PRE = false>
-__global__ __launch_bounds__(LAT ? 256 : GQ_NT, LAT ? 2 : GQ_WG_PER_CU) void k_goalset_queue(ChunkArgs a) {  // LAT: a workgroup per CU or two, registers are free
+// Workgroups per CU the WIDE instantiations are compiled for: six waves x 3 = 18 waves (96 VGPRs like the 4 x 5 of the plain kernel), eight
+// waves x 2 = 16 (128 VGPRs).
+template <int W> struct GqWide { static constexpr int wg_per_cu = W == GQ_WAVES ? GQ_WG_PER_CU : (W <= 6 ? 3 : 2); };
+template <int LB, bool STAMP = false, bool LAT = false, bool SPLIT = false, bool PRE = false, int W = GQ_WAVES>
+__global__ __launch_bounds__(LAT ? 256 : 64 * W, LAT ? 2 : GqWide<W>::wg_per_cu) void k_goalset_queue(ChunkArgs a) {  // LAT: a workgroup per CU or two, registers are free
     extern __shared__ __attribute__((aligned(16))) double lds_pose[];  // no static LDS: 31744 B is the most a workgroup may use at 5 per CU
     GS_WG_STAMP(0);
 #ifdef OMGX_GS_PRIO
@@ -932,5 +940,9 @@ __global__ __launch_bounds__(LAT ? 256 : GQ_NT, LAT ? 2 : GQ_WG_PER_CU) void k_g
     }
     if (s < 0) return;  // fewer active scenes than slots
     if (spread && a.active && as_const(a.active)[s] == 0) return;
-    gq_item<LB, STAMP, LAT, SPLIT, PRE>(a, lds_pose, s, is_layer, layer_part, chunk, NP);
+    if constexpr (W != GQ_WAVES) {
+        // a trajectory-layer piece is written for four waves: the others leave (a finished wave no longer counts at the workgroup's barriers)
+        if (is_layer && threadIdx.x >= 64 * GQ_WAVES) return;
+    }
+    gq_item<LB, STAMP, LAT, SPLIT, PRE, false, 0, W>(a, lds_pose, s, is_layer, layer_part, chunk, NP);
 }

@@ -571,7 +571,7 @@ __device__ unsigned long long g_gs_wg[1 << 16][8];
 #define GS_WG_IDX ((blockIdx.x + (((unsigned)a.S & 1u) << 14)) & 0xffffu)
 #define GS_WG_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < (1u << 16)) { g_gs_wg[GS_WG_IDX][k] = wall_clock64(); if (k == 0) { g_gs_wg[GS_WG_IDX][5] = ~0ull; g_gs_wg[GS_WG_IDX][6] = 0ull; unsigned hw, xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); g_gs_wg[GS_WG_IDX][7] = ((unsigned long long)xcc << 32) | hw; } } } while (0)
 __device__ unsigned long long g_gs_wave[1 << 16][8];  // per wave: [w] when wave w finished its part of the chain / culling stage; [4 + w] when it entered it
-#define GS_WAVE_STAMP(k) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < (1u << 16)) g_gs_wave[blockIdx.x][k] = wall_clock64(); } while (0)
+#define GS_WAVE_STAMP(k) do { if ((threadIdx.x & 63) == 0 && (k) < 8 && blockIdx.x < (1u << 16)) g_gs_wave[blockIdx.x][k] = wall_clock64(); } while (0)  // (wide workgroups: waves 4.. have no slot)
 extern "C" int omgx_debug_gs_wave(unsigned long long* h_out, int n_wg) {
     if (n_wg > (1 << 16)) n_wg = 1 << 16;
     return hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_gs_wave), sizeof(unsigned long long) * 8 * n_wg) == hipSuccess ? 0 : -2;
@@ -817,6 +817,15 @@ extern "C" int64_t omgx_goalset_workspace_bytes(int32_t num_scenes, int32_t num_
     return gk_workspace_bytes((int64_t)num_scenes * num_goals, n_remaining);
 }
 
+#ifndef GS_WIDE8_MAX_ITEMS
+#define GS_WIDE8_MAX_ITEMS 0    // (set by measurement: DESIGN.md section 4.5)
+#endif
+#ifndef GS_WIDE6_MAX_ITEMS
+#define GS_WIDE6_MAX_ITEMS 0
+#endif
+#ifndef GS_WIDE6_LONG_MAX_ITEMS
+#define GS_WIDE6_LONG_MAX_ITEMS 0  // windows beyond 32 waypoints
+#endif
 // How a k_goalset_queue launch is cut into workgroups (ChunkArgs: NP, layer_*, spread).  The default is the batch layout.
 struct GsTiling {
     int goal_parts = 1;  // workgroups per goal (1, 2, 4 or 8) at most: omgx_goalset_parts picks the count for a window
@@ -834,6 +843,47 @@ static inline int gs_parts(int n_remaining, int max_parts) {
     int np = 1;
     while (np * 2 <= max_parts && ntiles / (np * 2) >= 4) np *= 2;
     return np;
+}
+
+// Waves per goal workgroup of a batch launch with `items` whole goals and a window of n_remaining configurations: GQ_WAVES, or 6 / 8 for the
+// WIDE instantiations (three / two workgroups per CU).  EXPERIMENT knobs (read once): OMGX_GS_WIDE=0 never wide; OMGX_GS_WIDE8_MAX /
+// OMGX_GS_WIDE6_MAX = the largest launch (goal workgroups) that runs on eight / six waves.
+static int g_wide_on = -1;  // -1: not read yet
+static int64_t g_wide_max8 = GS_WIDE8_MAX_ITEMS, g_wide_max6 = GS_WIDE6_MAX_ITEMS, g_wide_long6 = GS_WIDE6_LONG_MAX_ITEMS;
+// Waves per goal workgroup of a batch launch of `items` whole goals with a window of n_remaining configurations (PS / MR / P: the launch's
+// LDS layout).  The rule (round 6, measured: DESIGN.md section 4.5):
+//   * a window whose four-wave layout needs more than 53 248 B of LDS — 57 .. 64 waypoints — admits TWO workgroups per CU whatever their
+//     waves: eight waves each (16 per CU instead of 8; 50 / 100 scenes x 64 goals x 64 waypoints: 0.287 -> 0.240 / 0.500 -> 0.399 ms per step);
+//   * everything else on four: up to 56 waypoints the wide workgroups cost a workgroup per CU (three of six waves do not fit the SIMDs'
+//     wave slots beside each other: 52 / 56 waypoints +6 .. +10 %), and at 30 waypoints they pay only in launches of a few hundred goals
+//     under a layout rule of their own (2 - 8 scenes x 64 goals -4 .. -5 %, 13 x 128 +13 %): thresholds 0, kept as EXPERIMENT knobs —
+//     OMGX_GS_WIDE=0 never wide; OMGX_GS_WIDE8_MAX / OMGX_GS_WIDE6_MAX / OMGX_GS_WIDE6_LONG_MAX = the largest launch (goal workgroups) on
+//     eight / six waves (windows up to 32 waypoints) / six waves (longer windows), read once; omgx_debug_set_wide.
+static inline int gs_wide_waves(int64_t items, int n_remaining, int PS, int MR, int P) {
+    if (g_wide_on < 0) {
+        const char* e = getenv("OMGX_GS_WIDE");
+        const char* e8 = getenv("OMGX_GS_WIDE8_MAX");
+        const char* e6 = getenv("OMGX_GS_WIDE6_MAX");
+        const char* el = getenv("OMGX_GS_WIDE6_LONG_MAX");
+        if (el) g_wide_long6 = (int64_t)atoll(el);
+        if (e8) g_wide_max8 = (int64_t)atoll(e8);
+        if (e6) g_wide_max6 = (int64_t)atoll(e6);
+        g_wide_on = e ? (atoi(e) != 0) : 1;
+    }
+    if (!g_wide_on || GQ_WAVES != 4) return GQ_WAVES;
+    if (GqLayout(PS, MR, P, 4, false, GQ_WAVES).total > 53248 && GqLayout(PS, MR, P, 4, false, 8).total <= 64 * 1024) return 8;
+    if (n_remaining > 32) return items <= g_wide_long6 ? 6 : GQ_WAVES;
+    if (items <= g_wide_max8) return 8;
+    if (items <= g_wide_max6) return 6;
+    return GQ_WAVES;
+}
+// test / experiment hook (tests/test_gpu_round6.py, tools/experiments/ab_wide.py; not part of the ABI): the rule's two thresholds; negative = keep
+extern "C" void omgx_debug_set_wide(int on, long long max8, long long max6, long long long6) {
+    (void)gs_wide_waves(0, 1, 2, 1, 1);  // the environment first, so that it does not overwrite what is set here
+    g_wide_on = on != 0;
+    if (max8 >= 0) g_wide_max8 = max8; else if (max8 < -1) g_wide_max8 = GS_WIDE8_MAX_ITEMS;  // (-1: keep, below: the built-in rule)
+    if (max6 >= 0) g_wide_max6 = max6; else if (max6 < -1) g_wide_max6 = GS_WIDE6_MAX_ITEMS;
+    if (long6 >= 0) g_wide_long6 = long6; else if (long6 < -1) g_wide_long6 = GS_WIDE6_LONG_MAX_ITEMS;
 }
 
 // dynamic LDS and grid of a k_goalset_queue launch (goal workgroups and / or trajectory-layer workgroups)
@@ -860,8 +910,12 @@ static int launch_goalset(ChunkArgs& ca, int timing_kind, hipStream_t st, const 
                                          (layer ? (int64_t)scene_groups * ca.layer_parts * 8 : 0);
     if (grid > 0x7fffffff) return OMGX_ERR_UNSUPPORTED;
     if (grid == 0) return OMGX_OK;
-    ca.tbl_n = gq_choose_tbl_n(ca.PS, ca.MR, ca.P, ca.spread);
-    const size_t lds = (size_t)GqLayout(ca.PS, ca.MR, ca.P, ca.tbl_n, ca.spread).total;
+    const bool pre = tl.kin_ws != nullptr && ca.NG > 0 && ca.traj_start != nullptr;
+    // WIDE workgroups (round 6; omg_goalset_queue.h, template parameter W): a launch of few enough goal workgroups to be resident all at
+    // once lasts as long as its heaviest goal — more waves draw that goal's tiles.  Whole goals with their own kinematics only.
+    const int wide = (!ca.spread && !split && !pre && ca.NG > 0) ? gs_wide_waves((int64_t)ca.S * ca.NG, ca.CH, ca.PS, ca.MR, ca.P) : GQ_WAVES;
+    ca.tbl_n = gq_choose_tbl_n(ca.PS, ca.MR, ca.P, ca.spread, wide);
+    const size_t lds = (size_t)GqLayout(ca.PS, ca.MR, ca.P, ca.tbl_n, ca.spread, wide).total;
     if (lds > 64 * 1024) {
         // the batch layout stays below (61 KB at 64 waypoints x 16 points); the latency-mode kernel adds the chain constants and the
         // layer's per-object contributions (73 KB at 64 waypoints) and opts in
@@ -871,7 +925,6 @@ static int launch_goalset(ChunkArgs& ca, int timing_kind, hipStream_t st, const 
         rc = allow_big_lds<11>(k_goalset_queue<2, false, true, false, true>, "hipFuncSetAttribute(k_goalset_queue)");
         if (rc != OMGX_OK) return rc;
     }
-    const bool pre = tl.kin_ws != nullptr && ca.NG > 0 && ca.traj_start != nullptr;
     ca.pre_poses = nullptr; ca.pre_masks = nullptr;
     if (pre) {  // the goals' kinematics and row masks as a launch of their own (omg_goalset_kin.h), one lane per (goal, configuration)
         const int64_t goals = (int64_t)ca.S * ca.NG;
@@ -891,12 +944,18 @@ static int launch_goalset(ChunkArgs& ca, int timing_kind, hipStream_t st, const 
 #endif
 #define GQ_GO(STAMP, LAT, SPLIT, PRE) do { if (ev0) hipExtLaunchKernelGGL((k_goalset_queue<2, STAMP, LAT, SPLIT, PRE>), dim3(g), dim3((LAT) ? 256 : GQ_NT), l32, st, ev0, ev1, 0, ca); \
                                             else hipLaunchKernelGGL((k_goalset_queue<2, STAMP, LAT, SPLIT, PRE>), dim3(g), dim3((LAT) ? 256 : GQ_NT), l32, st, ca); } while (0)
+#define GQ_GO_W(STAMP, WW) do { if (ev0) hipExtLaunchKernelGGL((k_goalset_queue<2, STAMP, false, false, false, WW>), dim3(g), dim3(64 * WW), l32, st, ev0, ev1, 0, ca); \
+                                 else hipLaunchKernelGGL((k_goalset_queue<2, STAMP, false, false, false, WW>), dim3(g), dim3(64 * WW), l32, st, ca); } while (0)
+    if (wide == 6) { if (ca.work) GQ_GO_W(true, 6); else GQ_GO_W(false, 6); }
+    else if (wide == 8) { if (ca.work) GQ_GO_W(true, 8); else GQ_GO_W(false, 8); }
+    else
     if (ca.spread) { if (pre) GQ_GO(false, true, false, true); else GQ_GO(false, true, false, false); }
     else if (split && ca.work) { if (pre) GQ_GO(true, false, true, true); else GQ_GO(true, false, true, false); }
     else if (split) { if (pre) GQ_GO(false, false, true, true); else GQ_GO(false, false, true, false); }
     else if (ca.work) { if (pre) GQ_GO(true, false, false, true); else GQ_GO(true, false, false, false); }
     else { if (pre) GQ_GO(false, false, false, true); else GQ_GO(false, false, false, false); }
 #undef GQ_GO
+#undef GQ_GO_W
     OMGX_CHECK_LAUNCH("k_goalset_queue");
     return OMGX_OK;
 }
@@ -1508,7 +1567,11 @@ extern "C" int omgx_plan_persistent(const double* robot, int32_t n_points, const
     // dedicated update CUs per XCD (omg_persist.h): only when the launch fills the chip (every CU then holds workgroups of this launch) and
     // there are scenes enough to keep them busy; < 0: this rule, else the caller's number (0: updates run where the scene's last item ran)
     pa.update_cus = update_cus >= 0 ? (update_cus > 8 ? 8 : update_cus) : ((grid >= (int64_t)cus * GQ_WG_PER_CU && num_scenes >= 32 && any_select) ? 2 : 0);
-    if (grid < (int64_t)cus * GQ_WG_PER_CU) pa.update_cus = update_cus > 0 ? pa.update_cus : 0;
+    // NEVER in a launch that does not fill the chip, whatever the caller asks for: the first CUs of an XCD to report become update CUs, and
+    // with a workgroup or two per XCD those are ALL of its CUs — nobody would run an item (fuzz campaign r06final: one scene with one to
+    // five goals and update_cus = 1 waited 2 s for requests that could not come, failure code 5).  And never more than a quarter of an XCD.
+    if (grid < (int64_t)cus * GQ_WG_PER_CU) pa.update_cus = 0;
+    if (pa.update_cus > cus / 32) pa.update_cus = cus / 32;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_persist_init, dim3(1), dim3(256), 0, st, pa);
     OMGX_CHECK_LAUNCH("k_persist_init");

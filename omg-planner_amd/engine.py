@@ -485,6 +485,13 @@ class ChompEngine:
             for part in self._parts[1:]:
                 cur.wait_stream(part.stream)
             self._forked = False
+        if self.__dict__.get("_persist_unchecked"):
+            # a persistent launch reports what went wrong inside it (a bounded wait that ran out) through its control block only: look at it
+            # before anything else is done with the engine's tensors (one small download per persistent launch)
+            self._persist_unchecked = False
+            st = self.persistent_status()
+            if st["failure"]:
+                raise _lib.OmgHipError(f"omgx_plan_persistent: failure code {st['failure']} inside the launch ({st}); the engine's tensors are not valid")
 
     _CFG_SCHEDULE = ("obstacle_weight", "smoothness_weight", "grasp_weight", "step_size")
 
@@ -873,6 +880,7 @@ class ChompEngine:
                             self.cost_vec, self._params(True), self.start, self.end, self.goal_rows, self.goal_point,
                             (self.grad, self.cost_traj, self.info), recs, d_iters, ws, active=self._mask(), goal_count=self.goal_count, eta=self.eta_s,
                             soften_fingers=False, layer_soften_fingers=self.cfg.uncheck_finger_collision == -1, max_workgroups=max_workgroups, update_cus=update_cus)
+        self._persist_unchecked = True  # join() reads the launch's status
 
     def persistent_status(self) -> dict:
         return ops.plan_persistent_status(self._persist_ws, self.S)

@@ -131,6 +131,9 @@ def one_trial(rng, trial, dev, dry=False):
     p_ucu = int(r3.choice([-1, -1, -1, 1])) if persistent and p_wg == 0 else (0 if persistent else -1)
     if persistent:
         STATS["persistent"] = STATS.get("persistent", 0) + 1
+    if os.environ.get("OMGX_FUZZ_DEBUG"):
+        print(f"    layout: pipeline={pipe} latency={lat} goal_parts={gparts} pose_hand_over={eng._poses_on} persistent={persistent} (workgroups {p_wg}, update CUs {p_ucu}) "
+              f"ragged={None if counts is None else counts.tolist()} early_stop={early}", flush=True)
     traj = eng.traj.cpu().numpy().copy()
     state = orc.learner_state_init(S, G)
     states_r = None if counts is None else [orc.learner_state_init(1, int(k_)) for k_ in counts]

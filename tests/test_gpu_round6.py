@@ -196,3 +196,67 @@ def test_persistent_launch_many_goals(dev, G):
             np.testing.assert_allclose(y.cpu().numpy(), x.cpu().numpy(), rtol=1e-12, atol=1e-15)
         else:
             assert torch.equal(x, y), (k, float((x.double() - y.double()).abs().max()))
+
+
+def _set_wide(on, max8=-1, max6=-1, long6=-1):
+    import ctypes as C
+    from omg_planner_amd import _lib
+    f = _lib.lib().omgx_debug_set_wide
+    f.argtypes = [C.c_int, C.c_longlong, C.c_longlong, C.c_longlong]
+    f.restype = None
+    f(on, max8, max6, long6)
+
+
+@pytest.mark.parametrize("waves,alg,S,G,n,kw", [
+    (8, "MD", 5, 24, 30, {}), (6, "MD", 5, 24, 30, {}), (8, "FTL", 3, 70, 30, {"standoff": True}), (6, "Exp", 9, 16, 17, {}),
+    (8, "MD", 4, 12, 30, {"goal_counts": [12, 5, 1, 9]}), (6, "MD", 2, 40, 32, {"objects": 9}), (8, "FTC", 3, 8, 5, {}),
+    (6, "MD", 3, 10, 50, {"objects": 12}), (6, "FTL", 2, 7, 64, {}), (6, "Exp", 2, 9, 41, {"standoff": True})])
+def test_wide_workgroups_change_no_bit(dev, waves, alg, S, G, n, kw):
+    """The WIDE instantiations of the batch kernel (six / eight waves per goal workgroup, chosen for launches small enough to be resident
+    at once; omg_kernels.hip gs_wide_waves): masks, tiles and the exact sum are those of four waves — every tensor the iterations
+    leave is bit for bit the same, through the dispatch-schedule measurement and the scheduled launches too."""
+    try:
+        _set_wide(0)
+        a, b = _pair(dev, S, G, n, alg, **kw)
+        for e in (a, b):
+            e.select_initial_goal()
+            e.pose_hand_over(True)
+        for t in range(8):
+            a.iterate(t)
+        torch.cuda.synchronize()
+        _set_wide(1, 1 << 40 if waves == 8 else 0, 1 << 40 if waves == 6 else 0, 1 << 40)
+        for t in range(8):
+            b.iterate(t)
+        _same(a, b, f"{waves} waves")
+        # the stand-alone goal-set entry point (Cost.batch_obstacle_cost's numbers) as well
+        ca, cb = a.goal_cost.clone(), b.goal_cost.clone()
+        assert torch.equal(ca, cb)
+    finally:
+        _set_wide(1, -2, -2, -2)  # back to the built-in rule
+
+
+@pytest.mark.parametrize("S,G,n,alg,proj,update_cus", [(1, 1, 12, "FTL", False, 1), (1, 5, 20, "Exp", False, 1), (1, 2, 41, "FTL", True, 2), (2, 2, 12, "MD", True, 2),
+                                                      (3, 1, 12, "FTL", False, 8), (1, 8, 30, "MD", True, 2)])
+def test_persistent_launch_of_a_tiny_plan_ignores_dedicated_update_cus(dev, S, G, n, alg, proj, update_cus):
+    """Fuzz campaign r06final (seed 12011, 7 of 6000): a launch of a handful of workgroups with `update_cus` > 0 made every workgroup an
+    update workgroup — the first CUs of an XCD to report ARE all its CUs then — and nobody ran an item (2 s of waiting, failure code 5,
+    tensors never written).  Dedicated update CUs exist only in launches that fill the chip; and a failure inside a launch raises at the
+    engine's next join()."""
+    import bench
+    from omg_planner_amd.engine import ChompEngine
+    cfg, model, batch, start, goals = bench.build_workload(S, G, n, 20, 3, False, num_objects=3)
+    cfg.goal_set_proj = proj
+    mk = lambda: ChompEngine(model, batch, copy.deepcopy(cfg), start, goals, device=dev, ol_alg=alg)
+    a, b = mk(), mk()
+    for e in (a, b):
+        e.select_initial_goal()
+        e.pose_hand_over(True)
+    for t0 in (0, 1, 2, 4):
+        ts = [t0] if t0 < 2 else [t0, t0 + 1]
+        for t in ts:
+            a.iterate(t)
+        b.run_persistent(ts, update_cus=update_cus)
+        b.join()  # raises on a failure code
+        _same(a, b, f"iterations {ts}")
+        st = b.persistent_status()
+        assert st["failure"] == 0 and st["scenes_finished"] == S, st

@@ -22,9 +22,10 @@ def test_goalset_kernel_register_and_spill_budget(tmp_path):
     subprocess.run([HIPCC, *flags, str(ROOT / "omg-planner_amd" / "csrc" / "omg_kernels.hip"), "-o", str(out)], check=True,
                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     text = out.read_text()
-    variants = [(st, lat, sp, pre) for pre in (0, 1) for (st, lat, sp) in ((0, 0, 0), (1, 0, 0), (0, 0, 1), (1, 0, 1), (0, 1, 0))]
-    for st, lat, sp, pre in variants:  # batch, measuring, batch with split goals (x2), latency mode — each with its own kinematics and behind the pre-pass
-        name = f"_Z15k_goalset_queueILi2ELb{st}ELb{lat}ELb{sp}ELb{pre}EEv9ChunkArgs"  # <LB, STAMP, LAT, SPLIT, PRE>
+    variants = [(st, lat, sp, pre, 4) for pre in (0, 1) for (st, lat, sp) in ((0, 0, 0), (1, 0, 0), (0, 0, 1), (1, 0, 1), (0, 1, 0))]
+    variants += [(st, 0, 0, 0, w) for w in (6, 8) for st in (0, 1)]  # round 6: the WIDE instantiations (six / eight waves: 3 / 2 workgroups per CU)
+    for st, lat, sp, pre, w in variants:  # batch, measuring, batch with split goals (x2), latency mode — each with its own kinematics and behind the pre-pass
+        name = f"_Z15k_goalset_queueILi2ELb{st}ELb{lat}ELb{sp}ELb{pre}ELi{w}EEv9ChunkArgs"  # <LB, STAMP, LAT, SPLIT, PRE, W>
         start = text.index(name + ":")
         block = text[start: text.index("; Occupancy:", start) + 40]
         vgprs = int(re.search(r"; NumVgprs: (\d+)", block).group(1))
