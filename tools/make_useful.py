@@ -17,7 +17,7 @@ d = Path(sys.argv[2]) if len(sys.argv) > 2 else Path(__file__).resolve().parents
 
 def valu(name):
     for r in csv.DictReader(open(d / f"{tag}_pmc_{name}.csv")):
-        if any(k in r["kernel"] for k in ("k_goalset_queue<2, false, false, false, false>", "k_goalset_queue<2, false, false, true, false>", "k_goalset_queue<2, false, false, false>", "k_goalset_queue<2, false, false>")) and r["counter"] == "SQ_INSTS_VALU":
+        if any(k in r["kernel"] for k in ("k_goalset_queue<2, false, false, false, false, 4>", "k_goalset_queue<2, false, false, false, false, 8>", "k_goalset_queue<2, false, false, true, false, 4>", "k_goalset_queue<2, false, false, false, false>", "k_goalset_queue<2, false, false, true, false>", "k_goalset_queue<2, false, false, false>", "k_goalset_queue<2, false, false>")) and r["counter"] == "SQ_INSTS_VALU":
             return float(r["mean_per_dispatch"])
     return None
 

@@ -41,16 +41,18 @@ ROOT = Path(__file__).resolve().parents[1]
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 SIMDS = 256 * 4
 CLOCK_GHZ = 2.4           # data-sheet maximum
-KERNEL = "k_goalset_queue<2, false, false, false, false>"  # <LB, STAMP, LAT, SPLIT, PRE>: no work stamps, batch layout, whole goals, own kinematics
+KERNEL = "k_goalset_queue<2, false, false, false, false, 4>"  # <LB, STAMP, LAT, SPLIT, PRE, W>: no work stamps, batch layout, whole goals, own kinematics, four waves
+KERNEL_WIDE = "k_goalset_queue<2, false, false, false, false, 8>"  # ... on eight waves (windows of 57-64 waypoints)
+KERNEL_R5 = "k_goalset_queue<2, false, false, false, false>"  # the same instantiation before the sixth template parameter (round 6's wide workgroups): profiles r05*, r06a*
 KERNEL_R4 = "k_goalset_queue<2, false, false, false>"      # the same instantiation in round 4 (four template parameters): profiles r04*
 KERNEL_OLD = "k_goalset_queue<2, false, false>"            # ... and before round 4 (three): profiles up to r03h
 
 
-KERNEL_SPLIT = "k_goalset_queue<2, false, false, true, false>"  # the batch kernel with a goal's tiles over two or more workgroups (long windows, small batches)
+KERNEL_SPLIT = "k_goalset_queue<2, false, false, true, false"  # the batch kernel with a goal's tiles over two or more workgroups (long windows, small batches); with or without W
 
 
 def is_dominant(name: str) -> bool:
-    return KERNEL in name or KERNEL_SPLIT in name or KERNEL_R4 in name or KERNEL_OLD in name
+    return any(k in name for k in (KERNEL, KERNEL_WIDE, KERNEL_R5, KERNEL_SPLIT, KERNEL_R4, KERNEL_OLD))
 CALIBRATION_TAG = "r03d"  # profiles/<tag>_valu_peak.csv
 
 # SQ_INSTS_VALU_* class -> the calibration row that prices it (cheapest member of the class: lower bound of the issue time)
@@ -132,7 +134,7 @@ def derive_inputs(tag: str, profiles: Path = ROOT / "profiles") -> dict:
     out = {
         "from_profiles_tag": tag,
         "calibration_tag": CALIBRATION_TAG,
-        "kernel": "k_goalset_queue<2, false, false, false, false> (goal-set batch + trajectory layer: kinematics, culling, SDF lookups, arc-length cost)",
+        "kernel": "k_goalset_queue<2, false, false, false, false, 4> (goal-set batch + trajectory layer: kinematics, culling, SDF lookups, arc-length cost)",
         "workload": json.loads(cfg_file.read_text()) if cfg_file.exists() else None,
         "valu_wave_insts_per_launch": valu,
         "valu_issue_cycles_per_launch": cycles,   # summed over the SIMDs; a lower bound (module docstring)
