@@ -187,7 +187,14 @@ __device__ __forceinline__ void gq_st_out(float* p, float v) {
 // W (round 6): waves per workgroup.  4 everywhere but in the WIDE instantiations of the batch kernel (whole goals, own kinematics), which
 // mid-size launches use: a launch whose workgroups all start at once lasts as long as its heaviest goal, and a goal's tiles are drawn by
 // however many waves there are.  Same masks, same tiles, same exact sum: same bits.
-template <int LB, bool STAMP, bool LAT, bool SPLIT, bool PRE, bool PERSIST = false, int ROLE = 0, int W = GQ_WAVES>
+// RANGE (round 6; with SPLIT, NP = 2): the two parts of a goal are RANGES of its window — part 0 the waypoints 1 .. a.range_h, part 1 the
+// rest — instead of tiles dealt round-robin: each part runs the kinematics of ITS configurations only (+ the one before them, which the
+// first waypoint's arc-length weight needs) and holds only their poses.  For long windows that is the difference between three
+// workgroups per CU and five (50 waypoints: 50 KB of LDS against 29 KB), and no kinematics run twice.  A part is a goal workgroup of a
+// shorter window whose configurations are numbered from cfg_off on: everything behind the kinematics is the whole-goal code, tile bits and
+// drawn tile list included.  Rows, masks and terms are those of the whole goal; the two partial sums are exact, their float32 roundings
+// are added by the learner like the tile parts' (omgx_learner_params.cost_parts).
+template <int LB, bool STAMP, bool LAT, bool SPLIT, bool PRE, bool PERSIST = false, int ROLE = 0, int W = GQ_WAVES, bool RANGE = false>
 __device__ __forceinline__ void gq_item(const ChunkArgs& a, double* const lds_pose, const int s, const bool is_layer, const int layer_part, const int chunk, const int NP) {
     const int o_begin = as_const(a.scene_begin)[s], o_end = as_const(a.scene_begin)[s + 1];
     const int P = a.P;
@@ -198,7 +205,10 @@ __device__ __forceinline__ void gq_item(const ChunkArgs& a, double* const lds_po
     // evenly — and runs the kinematics of all configurations itself (the chain's latency does not depend on their number).
     const int goal = NP > 1 ? chunk / NP : chunk;
     const int part = NP > 1 ? chunk - goal * NP : 0;
-    const int CH = a.CH;
+    static_assert(!RANGE || (SPLIT && !LAT && !PRE && !PERSIST && W == GQ_WAVES), "waypoint ranges: the batch kernel with two parts per goal and their own kinematics");
+    const int CHg = a.CH;                                     // the goal's whole window
+    const int cfg_off = (RANGE && part > 0) ? a.range_h : 0;  // configuration 0 of this workgroup in the window's numbering
+    const int CH = RANGE ? (part > 0 ? CHg - a.range_h : a.range_h) : CHg;
     // The blocks of 4 waypoints are aligned with the END of the window: when CH is no multiple of 4 the short block is the first one
     // (far from the goal, mostly culled as a whole) instead of the last one — the heaviest tiles, which then ran at half their lanes.
     const int blk_shift = (4 - (CH & 3)) & 3;
@@ -265,7 +275,7 @@ __device__ __forceinline__ void gq_item(const ChunkArgs& a, double* const lds_po
     // Round 6: windows of 33 .. 64 waypoints (BASELINE config 5 plans with 50) have up to 16 blocks: bit 4 (block & 7) + pair of word
     // block >> 3 for the pairs 0-3, bit `block` of word 3 for pair 4 (word 2 stays the tile counter) — and their up to 80 tiles get the
     // drawn list too (two entries per lane).  They used to visit all 65 tiles, one LDS atomic each, votes and mask reads included.
-    constexpr bool TILEBITS = !LAT && !SPLIT && !PRE && LB == 2;
+    constexpr bool TILEBITS = !LAT && (!SPLIT || RANGE) && !PRE && LB == 2;
     const bool tb_on = TILEBITS;
     const bool tb_wide = CH > 32;  // which of the two bit layouts
     auto tile_bit_set = [&](int rb, int pr) -> bool {  // after the culling (LDS reads)
@@ -362,7 +372,11 @@ __device__ __forceinline__ void gq_item(const ChunkArgs& a, double* const lds_po
         GqTblRec trec{};
         if (LAT && tbl_lane) trec = gq_tbl_load(a.objects + o_begin + (tid - 128));  // LAT: requested here, stored after the barrier
         if (warming) gq_warm_scalar_cache(a.objects, o_begin, o_end, a.robot + OMGX_ROBOT_POINTS + 30 * P + 316 + 30 * P);
-        auto joint = [&](int cfg, int d) { const double q0d = gq_ld_traj<PERSIST>(q0 + d); return cfg == 0 ? q0d : q0d + ((double)cfg * (1.0 / (double)(CH + 1))) * (qg[d] - q0d); };
+        auto joint = [&](int cfg_local, int d) {  // (RANGE: this workgroup's configuration cfg_local is the window's cfg_off + cfg_local)
+            const int cfg = cfg_local + cfg_off;
+            const double q0d = gq_ld_traj<PERSIST>(q0 + d);
+            return cfg == 0 ? q0d : q0d + ((double)cfg * (1.0 / (double)(CHg + 1))) * (qg[d] - q0d);
+        };
         for (int t = tid; t < ncfg * 7; t += NT) {
             const int cfg = t / 7, i = t - cfg * 7;
             double sn, cs;
@@ -679,8 +693,9 @@ __device__ __forceinline__ void gq_item(const ChunkArgs& a, double* const lds_po
     // does not use before the first enqueue; a wave's LDS operations run in program order), a draw is one LDS atomic.
     constexpr bool DYN = !LAT;  // (latency mode: every wave has culled the rows of ITS tiles only)
     // the tiles this workgroup holds, heaviest first: all of the goal's, or — SPLIT — the tiles part, part + NP, ... of it
-    const int ncand = SPLIT ? (ntiles > part ? (ntiles - part + NP - 1) / NP : 0) : ntiles;
-    auto cand = [&](int j) { return SPLIT ? part + NP * (ncand - 1 - j) : ntiles - 1 - j; };
+    constexpr bool DEALT = SPLIT && !RANGE;  // the goal's tiles dealt over the parts (a RANGE part holds all the tiles of its own window)
+    const int ncand = DEALT ? (ntiles > part ? (ntiles - part + NP - 1) / NP : 0) : ntiles;
+    auto cand = [&](int j) { return DEALT ? part + NP * (ncand - 1 - j) : ntiles - 1 - j; };
     int my_tile = -1, my_tile2 = -1, n_list = 0;  // the list: entry i in lane i of my_tile, entry 64 + i in lane i of my_tile2
     uint32_t* const tile_counter = tilebits + 2;
     constexpr int LIST_MAX = TILEBITS ? 128 : 64;  // (80 tiles at 64 waypoints)
@@ -873,9 +888,10 @@ __device__ __forceinline__ void gq_item(const ChunkArgs& a, double* const lds_po
 // Workgroups per CU the WIDE instantiations are compiled for: six waves x 3 = 18 waves (96 VGPRs like the 4 x 5 of the plain kernel), eight
 // waves x 2 = 16 (128 VGPRs).
 template <int W> struct GqWide { static constexpr int wg_per_cu = W == GQ_WAVES ? GQ_WG_PER_CU : (W <= 6 ? 3 : 2); };
-template <int LB, bool STAMP = false, bool LAT = false, bool SPLIT = false, bool PRE = false, int W = GQ_WAVES>
-__global__ __launch_bounds__(LAT ? 256 : 64 * W, LAT ? 2 : GqWide<W>::wg_per_cu) void k_goalset_queue(ChunkArgs a) {  // LAT: a workgroup per CU or two, registers are free
-    extern __shared__ __attribute__((aligned(16))) double lds_pose[];  // no static LDS: 31744 B is the most a workgroup may use at 5 per CU
+// What a workgroup of the launch does: find its item (scene, trajectory-layer piece | goal [, part]) and run it.  Two kernels share it:
+// k_goalset_queue and k_goalset_range (RANGE).
+template <int LB, bool STAMP, bool LAT, bool SPLIT, bool PRE, int W, bool RANGE>
+__device__ __forceinline__ void goalset_queue_body(const ChunkArgs& a, double* const lds_pose) {
     GS_WG_STAMP(0);
 #ifdef OMGX_GS_PRIO
     __builtin_amdgcn_s_setprio(OMGX_GS_PRIO);
@@ -944,5 +960,18 @@ __global__ __launch_bounds__(LAT ? 256 : 64 * W, LAT ? 2 : GqWide<W>::wg_per_cu)
         // a trajectory-layer piece is written for four waves: the others leave (a finished wave no longer counts at the workgroup's barriers)
         if (is_layer && threadIdx.x >= 64 * GQ_WAVES) return;
     }
-    gq_item<LB, STAMP, LAT, SPLIT, PRE, false, 0, W>(a, lds_pose, s, is_layer, layer_part, chunk, NP);
+    gq_item<LB, STAMP, LAT, SPLIT, PRE, false, 0, W, RANGE>(a, lds_pose, s, is_layer, layer_part, chunk, NP);
+}
+
+template <int LB, bool STAMP = false, bool LAT = false, bool SPLIT = false, bool PRE = false, int W = GQ_WAVES>
+__global__ __launch_bounds__(LAT ? 256 : 64 * W, LAT ? 2 : GqWide<W>::wg_per_cu) void k_goalset_queue(ChunkArgs a) {  // LAT: a workgroup per CU or two, registers are free
+    extern __shared__ __attribute__((aligned(16))) double lds_pose[];  // no static LDS: 31744 B is the most a workgroup may use at 5 per CU
+    goalset_queue_body<LB, STAMP, LAT, SPLIT, PRE, W, false>(a, lds_pose);
+}
+
+// The batch kernel with a goal's window cut into two waypoint RANGES (gq_item: RANGE), a kernel name of its own.
+template <int LB, bool STAMP = false>
+__global__ __launch_bounds__(GQ_NT, GQ_WG_PER_CU) void k_goalset_range(ChunkArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double lds_pose[];
+    goalset_queue_body<LB, STAMP, false, true, false, GQ_WAVES, true>(a, lds_pose);
 }

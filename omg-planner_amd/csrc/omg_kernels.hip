@@ -205,6 +205,7 @@ struct ChunkArgs {
     // NP workgroups (chunk = goal * NP + part; NCH = NG * NP chunks per scene), layer_lg x layer_nb layer workgroups per scene
     // (10 / layer_lg links x layer_cb waypoints), workgroups in plain order over all XCDs (spread).
     int NG, NP;
+    int range_h;  // k_goalset_range: a goal's window cut into two RANGES of waypoints — part 0 the first range_h, part 1 the rest (omg_goalset_queue.h: RANGE)
     int layer_parts, layer_lg, layer_nb, layer_cb, spread;
     double* wp_pose_out;       // [S][wp_n][10][12] or null: the layer workgroups of link group 0 leave the waypoints' poses here
     uint32_t* work;
@@ -817,6 +818,12 @@ extern "C" int64_t omgx_goalset_workspace_bytes(int32_t num_scenes, int32_t num_
     return gk_workspace_bytes((int64_t)num_scenes * num_goals, n_remaining);
 }
 
+#ifndef GS_RANGE_MIN_WINDOW
+#define GS_RANGE_MIN_WINDOW (1 << 20)  // windows beyond this many configurations: two parts of a goal are waypoint ranges — never, by default (launch_goalset)
+#endif
+static int g_range_min = -1;  // -1: not read yet (OMGX_GS_RANGE_MIN, omgx_debug_set_range)
+// test / experiment hook (tests/test_gpu_parts.py, tools/experiments/ab_range.sh; not part of the ABI); negative: the built-in rule
+extern "C" void omgx_debug_set_range(int min_window) { g_range_min = min_window >= 0 ? min_window : GS_RANGE_MIN_WINDOW; }
 #ifndef GS_WIDE8_MAX_ITEMS
 #define GS_WIDE8_MAX_ITEMS 0    // (set by measurement: DESIGN.md section 4.5)
 #endif
@@ -899,10 +906,23 @@ static int launch_goalset(ChunkArgs& ca, int timing_kind, hipStream_t st, const 
     if (ca.spread && (ca.schedule || ca.work)) return OMGX_ERR_UNSUPPORTED;  // a dispatch schedule belongs to the batch layout: a scene per XCD
     ca.wp_pose_out = layer ? tl.wp_pose_out : nullptr;
     ca.layer_lg = tl.layer_lg;
-    ca.layer_cb = layer ? ((tl.layer_cb > 0 && tl.layer_cb < ca.wp_n) ? tl.layer_cb : ca.wp_n) : 1;
+    // RANGES (round 6; omg_goalset_queue.h: RANGE, k_goalset_range): two parts of a LONG window are waypoint ranges, not dealt tiles — each
+    // holds only its own configurations' poses (50 waypoints: 29 KB of LDS instead of 50, five workgroups per CU instead of three) and
+    // no kinematics run twice.  The second range — the goal's end, where the objects are — is the shorter one and a multiple of four
+    // waypoints (its blocks then hold four rows each).  The trajectory layer's pieces are cut in two as well, or their poses would
+    // set the launch's LDS.  MEASURED AND LEFT OFF (DESIGN_HISTORY.md appendix A, round 6): a part pays a workgroup's whole latency L0 for half a
+    // goal's work — 100 x 64 x 50 waypoints 0.306 against 0.317 ms per step with whole goals, config 5's shape 0.185 against 0.164 with
+    // dealt tiles (the goal's end is the heavy range).  OMGX_GS_RANGE_MIN=<n> / omgx_debug_set_range(n): ranges for windows beyond n.
+    if (g_range_min < 0) { const char* e = getenv("OMGX_GS_RANGE_MIN"); g_range_min = e ? atoi(e) : GS_RANGE_MIN_WINDOW; }
+    const bool range = split && ca.NP == 2 && ca.CH > g_range_min && tl.kin_ws == nullptr && ca.traj_start != nullptr;
+    ca.range_h = range ? ca.CH - 4 * (ca.CH / 8) : 0;
+    int layer_cb_req = tl.layer_cb;
+    if (range && layer && layer_cb_req == 0) layer_cb_req = (ca.wp_n + 1) / 2;
+    ca.layer_cb = layer ? ((layer_cb_req > 0 && layer_cb_req < ca.wp_n) ? layer_cb_req : ca.wp_n) : 1;
     ca.layer_nb = layer ? (ca.wp_n + ca.layer_cb - 1) / ca.layer_cb : 1;
     ca.layer_parts = ca.layer_lg * ca.layer_nb;
     ca.PS = ca.CH + 1; ca.MR = ca.CH; ca.LPW = 10;
+    if (range) { ca.PS = ca.range_h + 1; ca.MR = ca.range_h; }  // (range_h >= CH - range_h)
     if (layer) { if (ca.layer_cb > ca.PS) ca.PS = ca.layer_cb; if (ca.layer_cb > ca.MR) ca.MR = ca.layer_cb; }
     const int64_t per_scene = (int64_t)ca.NCH + (layer ? ca.layer_parts : 0);
     const int64_t grid = ca.spread ? (int64_t)ca.S * per_scene
@@ -946,6 +966,10 @@ static int launch_goalset(ChunkArgs& ca, int timing_kind, hipStream_t st, const 
                                             else hipLaunchKernelGGL((k_goalset_queue<2, STAMP, LAT, SPLIT, PRE>), dim3(g), dim3((LAT) ? 256 : GQ_NT), l32, st, ca); } while (0)
 #define GQ_GO_W(STAMP, WW) do { if (ev0) hipExtLaunchKernelGGL((k_goalset_queue<2, STAMP, false, false, false, WW>), dim3(g), dim3(64 * WW), l32, st, ev0, ev1, 0, ca); \
                                  else hipLaunchKernelGGL((k_goalset_queue<2, STAMP, false, false, false, WW>), dim3(g), dim3(64 * WW), l32, st, ca); } while (0)
+    if (range) {
+        if (ca.work) { if (ev0) hipExtLaunchKernelGGL((k_goalset_range<2, true>), dim3(g), dim3(GQ_NT), l32, st, ev0, ev1, 0, ca); else hipLaunchKernelGGL((k_goalset_range<2, true>), dim3(g), dim3(GQ_NT), l32, st, ca); }
+        else { if (ev0) hipExtLaunchKernelGGL((k_goalset_range<2, false>), dim3(g), dim3(GQ_NT), l32, st, ev0, ev1, 0, ca); else hipLaunchKernelGGL((k_goalset_range<2, false>), dim3(g), dim3(GQ_NT), l32, st, ca); }
+    } else
     if (wide == 6) { if (ca.work) GQ_GO_W(true, 6); else GQ_GO_W(false, 6); }
     else if (wide == 8) { if (ca.work) GQ_GO_W(true, 8); else GQ_GO_W(false, 8); }
     else

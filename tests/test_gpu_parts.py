@@ -217,3 +217,116 @@ def test_a_goals_cost_does_not_depend_on_the_order_of_its_terms(dev, n_rem):
         torch.cuda.synchronize()
         tot = qc.reshape(2, 24, NP).double().sum(-1)
         np.testing.assert_allclose(tot.cpu().numpy(), cost.double().cpu().numpy(), rtol=NP * 6e-8, atol=1e-9)
+
+
+@pytest.fixture
+def ranges_on():
+    """Waypoint ranges are built, tested and OFF by default (measured: no faster than dealt tiles / whole goals): switched on through the
+    library's experiment hook for the tests that hold them to the parts' contract."""
+    import ctypes as C
+    from omg_planner_amd import _lib
+    f = _lib.lib().omgx_debug_set_range
+    f.argtypes, f.restype = [C.c_int], None
+    f(40)
+    yield f
+    f(-1)
+
+
+@pytest.mark.parametrize("n,n_rem", [(50, 50), (50, 43), (64, 64), (41, 41), (64, 57)])
+def test_long_windows_split_into_waypoint_ranges(dev, ranges_on, n, n_rem):
+    """Round 6 (k_goalset_range): beyond 40 configurations the two parts of a goal are RANGES of its window — each with the kinematics
+    and the poses of its own configurations only — not dealt tiles.  Same contract as the dealt parts: partial sums that add up to the
+    whole goal's cost within float32 summation rounding, collision counts that add up exactly, layer outputs and handed-over poses bit
+    for bit (the layer's pieces are cut in two as well), any dispatch schedule the same bits, padding never written, the oracle's bar."""
+    from omg_planner_amd import ops
+    from oracle import oracle as orc
+    S, G = 3, 20
+    counts = np.array([20, 9, 14])
+    eng, batch = _make(dev, S, G, 1, counts, grid=24, n=n)
+    ts = eng.traj[:, n - n_rem]
+    lay = tuple(torch.full_like(t, float("nan")) for t in (eng.pot, eng.pgrad, eng.col))
+    cost, col = ops.goalset_cost_layer(eng.robot, eng.P, eng.scenes, ts, eng.cv_goals, n_rem, eng.cfg.time_interval, eng.traj, lay,
+                                       goal_count=eng.goal_count)
+    NP = ops.goalset_parts(n_rem, 2)
+    assert NP == 2
+    pc = torch.full((S, G * NP), float("nan"), dtype=torch.float32, device=dev)
+    pl = torch.full_like(pc, float("nan"))
+    lay2 = tuple(torch.full_like(t, float("nan")) for t in lay)
+    poses = torch.full((S, n, 10, 12), float("nan"), dtype=torch.float64, device=dev)
+    ops.goalset_cost_layer(eng.robot, eng.P, eng.scenes, ts, eng.cv_goals, n_rem, eng.cfg.time_interval, eng.traj, lay2, out=(pc, pl),
+                           goal_count=eng.goal_count, goal_parts=2, layer_poses=poses)
+    torch.cuda.synchronize()
+    for a, b in zip(lay, lay2):
+        assert torch.equal(a, b)
+    np.testing.assert_array_equal(poses.cpu().numpy(), ops.pose_table(eng.robot, eng.P, eng.traj).cpu().numpy())
+    tot, tcol = _total(pc, S, G, NP).cpu().numpy(), _total(pl, S, G, NP).cpu().numpy()
+    parts = pc.reshape(S, G, NP).cpu().numpy()
+    for s in range(S):
+        k = counts[s]
+        np.testing.assert_allclose(tot[s, :k], cost[s, :k].cpu().numpy(), rtol=2e-6, atol=1e-7)
+        assert np.array_equal(tcol[s, :k], col[s, :k].cpu().numpy())
+        assert np.isnan(parts[s, k:]).all()
+        gc, _ = orc.goalset_cost(eng.model.blob(), eng.P, batch.subset(s, s + 1), ts[s:s + 1].cpu().numpy(), eng.cv_goals[s:s + 1, :k].cpu().numpy(),
+                                 n_rem, eng.cfg.time_interval)
+        np.testing.assert_allclose(tot[s, :k], np.asarray(gc).reshape(-1), rtol=1e-5, atol=1e-6)
+    # ... and these ARE ranges: the dealt tiles of the default build split the same totals differently
+    ranges_on(-1)
+    pct, plt = torch.full_like(pc, float("nan")), torch.full_like(pl, float("nan"))
+    ops.goalset_cost_layer(eng.robot, eng.P, eng.scenes, ts, eng.cv_goals, n_rem, eng.cfg.time_interval, eng.traj, lay2, out=(pct, plt),
+                           goal_count=eng.goal_count, goal_parts=2)
+    torch.cuda.synchronize()
+    ranges_on(40)
+    tt = _total(pct, S, G, NP).cpu().numpy()
+    for s in range(S):
+        np.testing.assert_allclose(tt[s, :counts[s]], tot[s, :counts[s]], rtol=2e-6, atol=1e-7)
+    assert not np.array_equal(pct.cpu().numpy(), pc.cpu().numpy(), equal_nan=True)
+    h = n_rem - 4 * (n_rem // 8)
+    work = torch.zeros(S * G * NP, dtype=torch.int32, device=dev)
+    sched = ops.goalset_schedule(None, S, G, goal_count=eng.goal_count, parts=NP, device=dev)
+    pc2, pl2 = torch.full_like(pc, float("nan")), torch.full_like(pl, float("nan"))
+    ops.goalset_cost_layer(eng.robot, eng.P, eng.scenes, ts, eng.cv_goals, n_rem, eng.cfg.time_interval, eng.traj, lay2, out=(pc2, pl2),
+                           goal_count=eng.goal_count, goal_parts=2, schedule=sched, work=work)
+    sched2 = ops.goalset_schedule(work, S, G, goal_count=eng.goal_count, parts=NP)
+    pc3, pl3 = torch.full_like(pc, float("nan")), torch.full_like(pl, float("nan"))
+    ops.goalset_cost_layer(eng.robot, eng.P, eng.scenes, ts, eng.cv_goals, n_rem, eng.cfg.time_interval, eng.traj, lay2, out=(pc3, pl3),
+                           goal_count=eng.goal_count, goal_parts=2, schedule=sched2)
+    torch.cuda.synchronize()
+    for x in (pc2, pc3):
+        assert np.array_equal(x.cpu().numpy(), pc.cpu().numpy(), equal_nan=True)
+    for x in (pl2, pl3):
+        assert np.array_equal(x.cpu().numpy(), pl.cpu().numpy(), equal_nan=True)
+    w = work.cpu().numpy().reshape(S, G, NP)
+    for s in range(S):
+        assert (w[s, :counts[s]] > 0).all() and (w[s, counts[s]:] == 0).all()
+    assert h >= n_rem - h and (n_rem - h) % 4 == 0
+
+
+def test_range_split_engine_follows_the_unsplit_engine_and_the_oracle(dev, ranges_on):
+    """A 50-waypoint plan (BASELINE config 5's window) with two workgroups per goal: while the window is longer than 40 configurations
+    the parts are waypoint ranges, then dealt tiles — the same goals as the unsplit engine, trajectories at 1e-9, layer outputs bit for
+    bit; pipelined equals unpipelined bit for bit; and the oracle's bars over the first iterations."""
+    from oracle.check import engine_vs_oracle
+    counts = np.array([12, 7, 10, 12])
+    a, _ = _make(dev, 4, 12, 1, counts, grid=24, n=50)
+    b, _ = _make(dev, 4, 12, 2, counts, grid=24, n=50)
+    c, _ = _make(dev, 4, 12, 2, counts, grid=24, n=50)
+    c.pipeline = 2
+    for e in (a, b, c):
+        e.select_initial_goal()
+        e.pose_hand_over(True)
+    for t in range(0, 40):
+        for e in (a, b, c):
+            e.iterate(t, early_stop=t > 3)
+        if t in (0, 1, 5, 9, 10, 11, 20, 39):
+            c.join()
+            torch.cuda.synchronize()
+            for k in ("pot", "pgrad", "col"):
+                assert torch.equal(getattr(a, k), getattr(b, k)), (t, k)
+            assert torch.equal(a.goal_idx, b.goal_idx), t
+            np.testing.assert_allclose(b.traj.cpu().numpy(), a.traj.cpu().numpy(), rtol=0, atol=1e-9)
+            for k in ("traj", "goal_idx", "learner_state", "info", "pot", "col", "goal_cost"):
+                assert np.array_equal(getattr(b, k).cpu().numpy(), getattr(c, k).cpu().numpy(), equal_nan=True), (t, k)
+    d, batch = _make(dev, 2, 10, 2, grid=24, n=50)
+    d.select_initial_goal()
+    r = engine_vs_oracle(d, batch, [0, 1], steps=12, pin_window=False)
+    assert r["goal_idx_equal"] and r["max_traj_err"] <= 1e-6 and r["max_cost_rel_err"] <= 1e-5, r
