@@ -859,7 +859,7 @@ static int g_wide_on = -1;  // -1: not read yet
 static int64_t g_wide_max8 = GS_WIDE8_MAX_ITEMS, g_wide_max6 = GS_WIDE6_MAX_ITEMS, g_wide_long6 = GS_WIDE6_LONG_MAX_ITEMS;
 // Waves per goal workgroup of a batch launch of `items` whole goals with a window of n_remaining configurations (PS / MR / P: the launch's
 // LDS layout).  The rule (round 6, measured: DESIGN.md section 4.5):
-//   * a window whose four-wave layout needs more than 53 248 B of LDS — 57 .. 64 waypoints — admits TWO workgroups per CU whatever their
+//   * a window whose four-wave layout needs more than 53 248 B of LDS — 59 .. 64 configurations (15-16 points per link) — admits TWO workgroups per CU whatever their
 //     waves: eight waves each (16 per CU instead of 8; 50 / 100 scenes x 64 goals x 64 waypoints: 0.287 -> 0.240 / 0.500 -> 0.399 ms per step);
 //   * everything else on four: up to 56 waypoints the wide workgroups cost a workgroup per CU (three of six waves do not fit the SIMDs'
 //     wave slots beside each other: 52 / 56 waypoints +6 .. +10 %), and at 30 waypoints they pay only in launches of a few hundred goals
