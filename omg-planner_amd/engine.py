@@ -452,6 +452,7 @@ class ChompEngine:
         part.__dict__.update(self.__dict__)
         part.cfg = copy.copy(self.cfg)  # the weight schedule's fields are set per iteration (_iterate_pipelined)
         part.S, part.stream, part._lo = hi - lo, stream, lo
+        part._batch_scenes = self.S  # the scenes of the whole batch: what the chip holds while this part's launches run
         part._parts, part._forked, part.pipeline = None, False, 1
         part._hot = None
         sc = object.__new__(ops.DeviceScenes)
@@ -793,6 +794,7 @@ class ChompEngine:
                                        self._scene_flags, layer_soften_fingers=self.cfg.uncheck_finger_collision == -1,
                                        tiling=self._tiling() if self.latency else None,
                                        layer_poses=self.wp_pose, goal_parts=self.goal_parts, prepass=self.prepass)
+            calls.batch_scenes = int(self.__dict__.get("_batch_scenes", self.S))  # (a pipeline part: the whole engine's count)
             hot = self._hot = (key, calls, baked)
         return hot[1]
 

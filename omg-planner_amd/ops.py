@@ -2,6 +2,7 @@
 libomg_hip.so.  Every function enqueues on torch's current stream and returns without syncing."""
 from __future__ import annotations
 
+import os
 import ctypes as C
 
 import numpy as np
@@ -799,11 +800,23 @@ class IterationCalls:
             with torch.cuda.device(self.device):
                 check(fn(*args), what)
 
+    # (goal_parts, layer_link_groups, layer_config_block, spread) of a layer-ONLY launch in the batch layout (the smoothing iterations of a
+    # plan): any split gives the same bits (every element is computed on its own).  Five workgroups per scene (2 links x all waypoints)
+    # take 38 us on a chip they fill to a third; TEN (one link each) shorten the launch: plan of 100 scenes 9.06 -> 8.73 ms, with early
+    # stop 7.88 -> 7.62 (round 6, tools/experiments/ab_layer_tiling.sh; config blocks on top: nothing; 13 x 128 and 16 x 64: within the noise
+    # either way).  OMGX_LAYER_ONLY_TILING="1,5,0,0" (experiments) overrides.
+    LAYER_ONLY_TILING = tuple(int(x) for x in os.environ["OMGX_LAYER_ONLY_TILING"].split(",")) if os.environ.get("OMGX_LAYER_ONLY_TILING") else None
+
+    def _layer_only_tiling(self):
+        if self.LAYER_ONLY_TILING is not None:
+            return self.LAYER_ONLY_TILING
+        return (1, 10, 0, 0) if getattr(self, "batch_scenes", self.S) >= 32 else (1, 5, 0, 0)  # batch_scenes: set by the engine (a pipeline part's calls know the batch)
+
     def layer_only(self, stream):
         """The SDF layer of the current trajectories alone (omgx_goalset_cost_layer_tiled with num_goals = 0): what omgx_fk_sdf
         computes for the step, with this object's tiling (latency mode) or five workgroups per scene (batch layout)."""
         cost, col, _ws, traj, n, soft, lp, lg, lc = self._gs_mid
-        tl = self._tiling if self._tiling is not None else (1, 5, 0, 0)
+        tl = self._tiling if self._tiling is not None else self._layer_only_tiling()
         args = (*self._gs_head, None, 9, None, self.S, 0, 1, self.dt, 0, None, None, traj, n, soft, lp, lg, lc, None, None, *tl,
                 self._layer_poses if self.use_layer_poses else None, None, C.c_void_p(stream))
         self._call(self._f_gst, args, "omgx_goalset_cost_layer_tiled")
