@@ -861,8 +861,8 @@ static int64_t g_wide_max8 = GS_WIDE8_MAX_ITEMS, g_wide_max6 = GS_WIDE6_MAX_ITEM
 // LDS layout).  The rule (round 6, measured: DESIGN.md section 4.5):
 //   * a window whose four-wave layout needs more than 53 248 B of LDS — 59 .. 64 configurations (15-16 points per link) — admits TWO workgroups per CU whatever their
 //     waves: eight waves each (16 per CU instead of 8; 50 / 100 scenes x 64 goals x 64 waypoints: 0.287 -> 0.240 / 0.500 -> 0.399 ms per step);
-//   * everything else on four: up to 56 waypoints the wide workgroups cost a workgroup per CU (three of six waves do not fit the SIMDs'
-//     wave slots beside each other: 52 / 56 waypoints +6 .. +10 %), and at 30 waypoints they pay only in launches of a few hundred goals
+//   * everything else on four: up to 56 waypoints the wide workgroups cost a workgroup per CU (stamps: 2.0 six-wave workgroups resident per CU
+//     against 2.85 four-wave ones at 50 waypoints: 52 / 56 waypoints +6 .. +10 %), and at 30 waypoints they pay only in launches of a few hundred goals
 //     under a layout rule of their own (2 - 8 scenes x 64 goals -4 .. -5 %, 13 x 128 +13 %): thresholds 0, kept as EXPERIMENT knobs —
 //     OMGX_GS_WIDE=0 never wide; OMGX_GS_WIDE8_MAX / OMGX_GS_WIDE6_MAX / OMGX_GS_WIDE6_LONG_MAX = the largest launch (goal workgroups) on
 //     eight / six waves (windows up to 32 waypoints) / six waves (longer windows), read once; omgx_debug_set_wide.
