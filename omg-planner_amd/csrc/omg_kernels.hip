@@ -879,7 +879,10 @@ static inline int gs_wide_waves(int64_t items, int n_remaining, int PS, int MR, 
     }
     if (!g_wide_on || GQ_WAVES != 4) return GQ_WAVES;
     if (GqLayout(PS, MR, P, 4, false, GQ_WAVES).total > 53248 && GqLayout(PS, MR, P, 4, false, 8).total <= 64 * 1024) return 8;
-    if (n_remaining > 32) return items <= g_wide_long6 ? 6 : GQ_WAVES;
+    if (n_remaining > 32) {  // (EXPERIMENT: OMGX_GS_WIDE_LONG_W = 6 | 8 waves for the long windows the knob admits)
+        static const int lw = [] { const char* e = getenv("OMGX_GS_WIDE_LONG_W"); return (e && atoi(e) == 8) ? 8 : 6; }();
+        return items <= g_wide_long6 ? lw : GQ_WAVES;
+    }
     if (items <= g_wide_max8) return 8;
     if (items <= g_wide_max6) return 6;
     return GQ_WAVES;
