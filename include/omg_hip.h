@@ -269,7 +269,7 @@ int omgx_goalset_cost(const double* robot, int32_t n_points,
  *           omgx_goalset_schedule (section 7) derives an order from `work` that gives every XCD the same measured
  *           work, heaviest scenes first (ABI 4).
  *   work    optional [S*num_goals] uint32: receives how long each goal's workgroup ran, in 10 ns ticks (0 = skipped).
- * How many waves a goal's workgroup has is the library's business (four; eight for windows of 59 - 64 configurations, where the LDS admits
+ * How many waves a goal's workgroup has is the library's business (four; eight for plans of 57 - 64 waypoints, where the LDS admits
  * two workgroups per CU either way — round 6): a goal's sum is exact and its tiles are drawn from one list, the results do not depend on it.
  * ------------------------------------------------------------------------------------------- */
 int omgx_goalset_cost_layer(const double* robot, int32_t n_points,

@@ -859,7 +859,7 @@ static int g_wide_on = -1;  // -1: not read yet
 static int64_t g_wide_max8 = GS_WIDE8_MAX_ITEMS, g_wide_max6 = GS_WIDE6_MAX_ITEMS, g_wide_long6 = GS_WIDE6_LONG_MAX_ITEMS;
 // Waves per goal workgroup of a batch launch of `items` whole goals with a window of n_remaining configurations (PS / MR / P: the launch's
 // LDS layout).  The rule (round 6, measured: DESIGN.md section 4.5):
-//   * a window whose four-wave layout needs more than 53 248 B of LDS — 59 .. 64 configurations (15-16 points per link) — admits TWO workgroups per CU whatever their
+//   * a window whose four-wave layout needs more than 53 248 B of LDS — plans of 57 .. 64 waypoints (15-16 points per link; the launch's poses are the trajectory layer's: all n) — admits TWO workgroups per CU whatever their
 //     waves: eight waves each (16 per CU instead of 8; 50 / 100 scenes x 64 goals x 64 waypoints: 0.287 -> 0.240 / 0.500 -> 0.399 ms per step);
 //   * everything else on four: up to 56 waypoints the wide workgroups cost a workgroup per CU (stamps: 2.0 six-wave workgroups resident per CU
 //     against 2.85 four-wave ones at 50 waypoints: 52 / 56 waypoints +6 .. +10 %), and at 30 waypoints they pay only in launches of a few hundred goals
@@ -887,6 +887,10 @@ static inline int gs_wide_waves(int64_t items, int n_remaining, int PS, int MR, 
     if (items <= g_wide_max6) return 6;
     return GQ_WAVES;
 }
+// which instantiation the calling thread's process launched last (test hook: the rules above are the library's business, a test can still hold
+// them): waves per goal workgroup | 0x100 waypoint ranges | 0x200 split goals | 0x400 latency mode | 0x800 behind the kinematics pre-pass
+static int g_last_goalset_variant = 0;
+extern "C" int omgx_debug_last_goalset_variant(void) { return g_last_goalset_variant; }
 // test / experiment hook (tests/test_gpu_round6.py, tools/experiments/ab_wide.py; not part of the ABI): the rule's two thresholds; negative = keep
 extern "C" void omgx_debug_set_wide(int on, long long max8, long long max6, long long long6) {
     (void)gs_wide_waves(0, 1, 2, 1, 1);  // the environment first, so that it does not overwrite what is set here
@@ -983,6 +987,7 @@ static int launch_goalset(ChunkArgs& ca, int timing_kind, hipStream_t st, const 
     else { if (pre) GQ_GO(false, false, false, true); else GQ_GO(false, false, false, false); }
 #undef GQ_GO
 #undef GQ_GO_W
+    g_last_goalset_variant = (range ? 0x100 : 0) | (split ? 0x200 : 0) | (ca.spread ? 0x400 : 0) | (pre ? 0x800 : 0) | (range ? GQ_WAVES : wide);
     OMGX_CHECK_LAUNCH("k_goalset_queue");
     return OMGX_OK;
 }

@@ -110,7 +110,7 @@ class ChompEngine:
     # A goal workgroup's life is a latency-bound prologue (kinematics of the window) + its tiles; splitting a goal shortens the
     # launch only while the chip has idle workgroup slots — every part repeats the prologue — i.e. below about 0.7 rounds of the
     # 1280 slots.  Beyond that the batch is bound by the chip's capacity and the plain layout wins.
-    WIDE_WINDOW_FROM = 60  # cfg.timesteps from which the first window of a plan (n - 1 configurations) needs more than 53 248 B of LDS per four-wave goal workgroup (15-16 points per link: from 59 configurations on): eight waves
+    WIDE_WINDOW_FROM = 57  # cfg.timesteps from which a plan's goal-set launches (their LDS follows the trajectory layer: all n waypoints) need more than 53 248 B per four-wave goal workgroup (15-16 points per link): eight waves
 
     @classmethod
     def layout(cls, num_scenes: int, num_goals: int, n_waypoints: int = 30) -> dict:
@@ -120,11 +120,11 @@ class ChompEngine:
         if num_scenes == 1:
             return {"latency_mode": True, "goal_parts": 1, "pipeline": 1}
         if n_waypoints >= cls.WIDE_WINDOW_FROM and num_scenes * num_goals <= 4096:
-            # Plans of 60-64 waypoints (round 6; first windows of 59-63 configurations): the library runs their whole goals on EIGHT-wave workgroups (two per CU by LDS either way:
+            # Plans of 57-64 waypoints (round 6): the library runs their whole goals on EIGHT-wave workgroups (two per CU by LDS either way:
             # omg_kernels.hip gs_wide_waves) and those beat split goals wherever the rule below would split — bench.py --waypoints 64, ms per
             # step, rule / whole goals on (1, 2, 3) pipeline parts: 4 x 64 0.0815 / 0.0795, 0.0807, 0.0842; 8 x 64 0.106 / 0.096, 0.104, 0.110;
             # 16 x 64 0.159 / 0.123, 0.115, 0.116; 32 x 64 0.179 / 0.184, 0.173, 0.179; 16 x 64 x 60 waypoints x 13 objects 0.231 / 0.209,
-            # 0.211, 0.211.  (A whole PLAN does not care — 16 x 64 x 64: 9.40 against 9.38 ms — its window is below 59 configurations after a few iterations.)
+            # 0.211, 0.211.  (A whole PLAN does not care — 16 x 64 x 64: 9.40 against 9.38 ms — its late windows are short either way.)
             return {"latency_mode": False, "goal_parts": 1, "pipeline": 1 if num_scenes * num_goals <= 512 else max(1, min(2, num_scenes))}
         if n_waypoints > 40 and 320 < load < 2560:
             # Long windows (round 6; BASELINE config 5 plans with 50 waypoints): a goal workgroup's poses alone are 37 KB, three

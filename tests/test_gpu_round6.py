@@ -260,3 +260,34 @@ def test_persistent_launch_of_a_tiny_plan_ignores_dedicated_update_cus(dev, S, G
         _same(a, b, f"iterations {ts}")
         st = b.persistent_status()
         assert st["failure"] == 0 and st["scenes_finished"] == S, st
+
+
+def test_the_library_picks_the_goal_workgroups_width_by_the_window(dev, request):
+    """omg_kernels.hip gs_wide_waves / launch_goalset: four waves per goal workgroup, EIGHT in plans of 57 .. 64 waypoints (the launch's LDS
+    follows the trajectory layer's n configurations: two workgroups per CU either way), split goals and latency mode never wide, waypoint ranges only behind their hook — read
+    back through the library's test probe after real launches of the engine."""
+    import ctypes as C
+    import bench
+    from omg_planner_amd import _lib
+    from omg_planner_amd.engine import ChompEngine
+    probe = _lib.lib().omgx_debug_last_goalset_variant
+    probe.restype = C.c_int
+
+    def variant(S, G, n, **kw):
+        cfg, model, batch, start, goals = bench.build_workload(S, G, n, 16, 1, False)
+        e = ChompEngine(model, batch, cfg, start, goals, device=dev, ol_alg="MD", **kw)
+        e.iterate(0)
+        torch.cuda.synchronize()
+        return probe()
+
+    assert variant(3, 8, 30) == 4 and variant(3, 8, 50) == 4 and variant(2, 8, 56) == 4
+    assert variant(2, 8, 64) == 8 and variant(2, 8, 60) == 8 and variant(2, 8, 57) == 8
+    assert variant(2, 8, 64, goal_parts=2) == 0x200 | 4 and variant(2, 8, 50, goal_parts=2) == 0x200 | 4
+    assert variant(1, 8, 64, latency_mode=True) & 0x400
+    f = _lib.lib().omgx_debug_set_range
+    f.argtypes, f.restype = [C.c_int], None
+    try:
+        f(40)
+        assert variant(2, 8, 50, goal_parts=2) == 0x300 | 4 and variant(2, 8, 30, goal_parts=2) == 0x200 | 4
+    finally:
+        f(-1)

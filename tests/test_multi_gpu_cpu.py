@@ -132,6 +132,10 @@ def test_layout_rule_is_a_pure_function_of_the_shape():
     # round 6: beyond 40 waypoints two workgroups per goal pay up to load 2560 (BASELINE config 5's shape), whole goals beyond
     assert L(16, 64, 50) == {"latency_mode": False, "goal_parts": 2, "pipeline": 2} and L(8, 64, 50)["goal_parts"] == 2
     assert L(32, 64, 50)["goal_parts"] == 1 and L(16, 128, 50)["goal_parts"] == 1 and L(16, 64, 40)["goal_parts"] == 1
+    # round 6: plans of 57-64 waypoints run whole goals (the library gives them eight-wave workgroups): one pipeline part up to 512 goals, two beyond
+    assert L(16, 64, 64) == {"latency_mode": False, "goal_parts": 1, "pipeline": 2} and L(8, 64, 64) == {"latency_mode": False, "goal_parts": 1, "pipeline": 1}
+    assert L(4, 64, 60)["goal_parts"] == 1 and L(4, 64, 60)["pipeline"] == 1 and L(16, 64, 56)["goal_parts"] == 2 and L(16, 64, 57)["goal_parts"] == 1 and L(1, 64, 64)["latency_mode"]
+    assert L(100, 64, 64)["goal_parts"] == 1 and L(100, 64, 64)["pipeline"] == 3  # (beyond 4096 goals: the general rule)
     assert all(L(s, g)["pipeline"] <= s for s in (1, 2, 3) for g in (8, 64, 512))
     assert L(13, 128) == L(13, 128)  # no hidden state
     # BASELINE config 4 on 8 ranks: shards of 13 and 12 scenes, one layout
