@@ -818,6 +818,9 @@ extern "C" int64_t omgx_goalset_workspace_bytes(int32_t num_scenes, int32_t num_
     return gk_workspace_bytes((int64_t)num_scenes * num_goals, n_remaining);
 }
 
+#ifndef GS_LAYER_FOLLOW_MIN
+#define GS_LAYER_FOLLOW_MIN 16  // waypoints per trajectory-layer piece at least, when the pieces follow the goal window (launch_goalset)
+#endif
 #ifndef GS_RANGE_MIN_WINDOW
 #define GS_RANGE_MIN_WINDOW (1 << 20)  // windows beyond this many configurations: two parts of a goal are waypoint ranges — never, by default (launch_goalset)
 #endif
@@ -925,6 +928,18 @@ static int launch_goalset(ChunkArgs& ca, int timing_kind, hipStream_t st, const 
     ca.range_h = range ? ca.CH - 4 * (ca.CH / 8) : 0;
     int layer_cb_req = tl.layer_cb;
     if (range && layer && layer_cb_req == 0) layer_cb_req = (ca.wp_n + 1) / 2;
+    {   // The trajectory layer's pieces cut to the goal WINDOW's size (round 6): a piece holds the poses of all its waypoints, so five pieces of
+        // all n waypoints set the launch's LDS by the plan's LENGTH — in a 50-waypoint plan every goal-set launch asked for 47-50 KB, three
+        // workgroups per CU, however short its window had become.  Cut to max(window + 1, 16) waypoints the launch's LDS follows the window and
+        // the later launches hold four or five: plan of 100 x 64 x 50 waypoints 14.35 -> 12.64 ms, config 5's shape 10.91 -> 10.23, 50 x 64 x 64
+        // 12.18 -> 11.02, 100 x 64 x 41 11.58 -> 11.18 (tools/experiments/ab_layer_follow.sh).  Any split of the layer gives the same bits.
+        // Plans up to 32 waypoints hold five workgroups per CU anyway.  OMGX_GS_LAYER_FOLLOW=0 (experiments): the five whole pieces.
+        static const int follow = [] { const char* e = getenv("OMGX_GS_LAYER_FOLLOW"); return e ? atoi(e) : GS_LAYER_FOLLOW_MIN; }();
+        if (follow > 0 && layer && layer_cb_req == 0 && !ca.spread && ca.NG > 0 && !range && ca.wp_n > 32) {
+            const int want = ca.CH + 1 > follow ? ca.CH + 1 : follow;
+            if (want < ca.wp_n) layer_cb_req = want;
+        }
+    }
     ca.layer_cb = layer ? ((layer_cb_req > 0 && layer_cb_req < ca.wp_n) ? layer_cb_req : ca.wp_n) : 1;
     ca.layer_nb = layer ? (ca.wp_n + ca.layer_cb - 1) / ca.layer_cb : 1;
     ca.layer_parts = ca.layer_lg * ca.layer_nb;
