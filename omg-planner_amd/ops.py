@@ -810,7 +810,14 @@ class IterationCalls:
     def _layer_only_tiling(self):
         if self.LAYER_ONLY_TILING is not None:
             return self.LAYER_ONLY_TILING
-        return (1, 10, 0, 0) if getattr(self, "batch_scenes", self.S) >= 32 else (1, 5, 0, 0)  # batch_scenes: set by the engine (a pipeline part's calls know the batch)
+        S = getattr(self, "batch_scenes", self.S)  # set by the engine (a pipeline part's calls know the batch)
+        if self.n > 32:
+            # Long plans (50 waypoints, a dozen objects): a piece of 2 links x all waypoints is 70 us of work and a batch of 16 scenes has 80 of
+            # them on 1 280 slots.  About 1 100 pieces in all, ten link groups x blocks of waypoints: plan of 16 x 64 x 50 x 13 objects 9.94 ->
+            # 8.85 ms, 8 x 64 x 50 7.92 -> 6.86, 32 x 64 x 50 13.41 -> 12.22, 100 x 64 x 50 13.23 -> 12.79 (tools/experiments/ab_layer_tiling_long.sh)
+            blocks = max(1, min(7, round(110.0 / max(S, 1))))
+            return (1, 10, 0 if blocks == 1 else -(-self.n // blocks), 0)
+        return (1, 10, 0, 0) if S >= 32 else (1, 5, 0, 0)
 
     def layer_only(self, stream):
         """The SDF layer of the current trajectories alone (omgx_goalset_cost_layer_tiled with num_goals = 0): what omgx_fk_sdf
