@@ -23,6 +23,7 @@ closes the job (``gather_costs``).
 from __future__ import annotations
 
 import operator
+import os
 
 import numpy as np
 import torch
@@ -110,6 +111,11 @@ class ChompEngine:
     # A goal workgroup's life is a latency-bound prologue (kinematics of the window) + its tiles; splitting a goal shortens the
     # launch only while the chip has idle workgroup slots — every part repeats the prologue — i.e. below about 0.7 rounds of the
     # 1280 slots.  Beyond that the batch is bound by the chip's capacity and the plain layout wins.
+    # Fixed-goal iterations (the plan's smoothing phase: a layer-only launch + a step launch) of a batch below this many scenes run as ONE
+    # pipeline part: their kernels are short chains on an almost empty chip, and three parts cost the host three times the launches — with the
+    # layer in 40 pieces per scene (ops.IterationCalls._layer_only_tiling) a plan of 13 x 128 goes 4.72 -> 4.26 ms, 16 x 64 4.84 -> 4.24, 25 x 64
+    # 4.97 -> 4.64 (tools/experiments/ab_smooth_small.sh).  Larger batches keep their parts (100 scenes: 8.80-8.86 as one part against 8.72-8.74).
+    SMOOTH_SINGLE_PART_BELOW = int(os.environ.get("OMGX_SMOOTH_SINGLE_PART_BELOW", 32))
     WIDE_WINDOW_FROM = 57  # cfg.timesteps from which a plan's goal-set launches (their LDS follows the trajectory layer: all n waypoints) need more than 53 248 B per four-wave goal workgroup (15-16 points per link): eight waves
 
     @classmethod
@@ -705,9 +711,13 @@ class ChompEngine:
         (Learner.update_goal + Optimizer.optimize); once the goal is fixed (t >= optim_steps, "Proj", "Baseline") the layer
         launch and the step."""
         k = self._pipeline_parts()
+        cfg = self.cfg
+        if k > 1 and self.SMOOTH_SINGLE_PART_BELOW > self.S and not (cfg.goal_set_proj and t < cfg.optim_steps and self.ol_alg not in ("Baseline", "Proj")) \
+                and self.HOT_FIXED_GOAL and not self.separate_launches and self.stream is None:
+            self.join()  # (the side streams are joined once, at the phase's first iteration; scenes are independent: the same bits)
+            k = 1
         if k > 1:
             return self._iterate_pipelined(t, early_stop, k)
-        cfg = self.cfg
         # planner.py:609-618: the learner runs only for the online-learning rules and only for the first optim_steps iterations
         select = cfg.goal_set_proj and t < cfg.optim_steps and self.ol_alg not in ("Baseline", "Proj")
         if not self.separate_launches and select and not self._forked:
