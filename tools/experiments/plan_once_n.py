@@ -10,6 +10,9 @@ S, G, n, obj = (int(x) for x in sys.argv[1:5])
 early = bool(int(sys.argv[5])) if len(sys.argv) > 5 else False
 cfg, model, batch, start, goals = bench.build_workload(S, G, n, 64, 0, False, num_objects=obj)
 eng = ChompEngine.auto(model, batch, copy.deepcopy(cfg), start, goals, layout_scenes=S, device=torch.device("cuda:0"), ol_alg="MD")
+import os
+if os.environ.get("OMGX_PLAN_PIPELINE"):
+    eng.pipeline = int(os.environ["OMGX_PLAN_PIPELINE"])
 snap = eng.snapshot()
 for rep in range(4):
     eng.restore(snap); torch.cuda.synchronize()
