@@ -939,6 +939,16 @@ static int launch_goalset(ChunkArgs& ca, int timing_kind, hipStream_t st, const 
             const int want = ca.CH + 1 > follow ? ca.CH + 1 : follow;
             if (want < ca.wp_n) layer_cb_req = want;
         }
+        // SMALL launches (up to 1 024 goal workgroups: everything is resident at once and the launch lasts as long as its longest workgroup —
+        // late in a plan that is a layer piece of 2 links x all waypoints, 26 us, beside goals of 13): ten link groups x blocks of max(window
+        // + 1, 16) waypoints.  Plan of 13 x 128 4.53 -> 4.18 ms, 16 x 64 4.25 -> 4.04, 25 x 64 4.65 -> 4.19, 8 x 64 4.06 -> 3.62; the pinned step of
+        // 16 x 64 0.0698 -> 0.0679, 13 x 128 unchanged (tools/experiments/ab_layer_small.sh).  OMGX_GS_LAYER_SMALL=0 (experiments): five whole pieces.
+        static const int small = [] { const char* e = getenv("OMGX_GS_LAYER_SMALL"); return e ? atoi(e) : GS_LAYER_FOLLOW_MIN; }();
+        if (small > 0 && layer && layer_cb_req == 0 && !ca.spread && ca.NG > 0 && !range && tl.layer_lg == 5 && (int64_t)ca.S * ca.NCH <= 1024) {
+            ca.layer_lg = 10;
+            const int want = ca.CH + 1 > small ? ca.CH + 1 : small;
+            if (want < ca.wp_n) layer_cb_req = want;
+        }
     }
     ca.layer_cb = layer ? ((layer_cb_req > 0 && layer_cb_req < ca.wp_n) ? layer_cb_req : ca.wp_n) : 1;
     ca.layer_nb = layer ? (ca.wp_n + ca.layer_cb - 1) / ca.layer_cb : 1;
