@@ -16,11 +16,13 @@ ap.add_argument("--iters", type=int, default=200)
 ap.add_argument("--scenes", type=int, default=13)
 ap.add_argument("--goals", type=int, default=128)
 ap.add_argument("--parts", type=int, default=0)
+ap.add_argument("--waypoints", type=int, default=30)
+ap.add_argument("--objects", type=int, default=4)
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 spin = ctypes.CDLL(str(ROOT / "tools" / "experiments" / "spin_update.so"))
 spin.spin_launch.argtypes = [ctypes.c_int] * 5 + [ctypes.c_void_p]
-cfg, model, batch, start, goals = bench.build_workload(a.scenes, a.goals, 30, 64, 0, False)
+cfg, model, batch, start, goals = bench.build_workload(a.scenes, a.goals, a.waypoints, 64, 0, False, num_objects=a.objects)
 eng = ChompEngine.auto(model, batch, copy.deepcopy(cfg), start, goals, layout_scenes=a.scenes, device=dev, ol_alg="MD")
 if a.parts:
     eng.pipeline = a.parts
