@@ -234,6 +234,27 @@ def shape_step_timing(dev, ol_alg, scenes, goals_n, n=30, objects=4, layout_scen
     return ms, dict(eng.layout_used, pipeline=parts), roof
 
 
+def shape_plan_timing(dev, ol_alg, scenes, goals_n, n=30, objects=4, reps=5):
+    """ms per whole plan (cfg.optim_steps goal-selecting + cfg.extra_smooth_steps fixed-goal iterations, no early stop) of ANOTHER shape on
+    this GPU, laid out by ChompEngine.layout; best of `reps` from the same fresh state (device-to-device restore outside the timing)."""
+    import torch
+    from omg_planner_amd.engine import ChompEngine
+    cfg, model, batch, start, goals = build_workload(scenes, goals_n, n, 64, seed0=0, share_grids=False, num_objects=objects, device=dev)
+    eng = ChompEngine.auto(model, batch, copy.deepcopy(cfg), start, goals, layout_scenes=scenes, device=dev, ol_alg=ol_alg)
+    snap = eng.snapshot()
+    best = float("inf")
+    for _ in range(reps + 1):  # (the first pass warms the schedule measurement and the prepared calls)
+        eng.restore(snap)
+        eng.join()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.plan(early_stop=False)
+        eng.join()
+        torch.cuda.synchronize()
+        best = min(best, (time.perf_counter() - t0) * 1e3)
+    return best
+
+
 def rank_share_config4(dev, ol_alg, steps=100, regions=3):
     """ms per step of ONE GPU's share of BASELINE config 4 on 8 GPUs (100 scenes x 128 goals -> 13 scenes x 128 goals), laid out
     by ChompEngine.layout like any rank of that job would be: what the 8-GPU strong-scaling ceiling hangs on."""
@@ -688,10 +709,11 @@ def main():
         parity["ok"] = bool(parity["ok"] and sm["ok"])
 
     ms_per_plan = ms_plan_early = ms_single = ms_single_batch_layout = terminated = ms_graph_early = ms_graph_single = None
-    share4 = scene_upd = drop_in = cfg5 = scaling = coll = persist = None
+    share4 = scene_upd = drop_in = cfg5 = scaling = coll = persist = plans_other = None
     if not args.no_plan and rank == 0 and world == 1:
         share4 = rank_share_config4(dev, args.ol_alg)
         cfg5 = config5_shape(dev, args.ol_alg)
+        plans_other = (shape_plan_timing(dev, args.ol_alg, 13, 128), shape_plan_timing(dev, args.ol_alg, 16, 64, n=50, objects=12))
         scaling = strong_scaling_estimate(dev, args.ol_alg, share8=share4)
         persist = persistent_launch_timing(dev, cfg, model, batch, start, goals, args.ol_alg)
         scene_upd = scene_update_timing(dev, cfg, model, host_batch(), start, goals, args.ol_alg)
@@ -795,6 +817,8 @@ def main():
             out["strong_scaling_estimate"] = scaling  # BASELINE config 4 on 1 / 2 / 4 / 8 GPUs from 1-GPU runs of the shards: ms_per_step, speed-up, frac per N
         if persist is not None:
             out["persistent_launch"] = persist
+        if plans_other is not None:
+            out["ms_per_plan_rank_share_config4"], out["ms_per_plan_config5_shape"] = plans_other  # whole plans of the two other BASELINE shapes (13 x 128; 16 x 64 x 50 waypoints x 13 objects), best of 5
         if cfg5 is not None:
             out["ms_per_step_config5_shape"] = cfg5[0]  # 16 scenes x 64 goals, 50 waypoints, 12 obstacles + table (BASELINE config 5's shape)
             out["config5_shape_layout"] = cfg5[1]
