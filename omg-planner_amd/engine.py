@@ -119,11 +119,15 @@ class ChompEngine:
     WIDE_WINDOW_FROM = 57  # cfg.timesteps from which a plan's goal-set launches (their LDS follows the trajectory layer: all n waypoints) need more than 53 248 B per four-wave goal workgroup (15-16 points per link): eight waves
 
     @classmethod
-    def layout(cls, num_scenes: int, num_goals: int, n_waypoints: int = 30) -> dict:
+    def layout(cls, num_scenes: int, num_goals: int, n_waypoints: int = 30, for_plan: bool = False) -> dict:
         """-> {"latency_mode", "goal_parts", "pipeline"} for a rank that plans num_scenes x num_goals goals over n_waypoints.
-        The work of a goal workgroup grows with the window, so the thresholds count (scene, goal) items scaled by n / 30."""
+        The work of a goal workgroup grows with the window, so the thresholds count (scene, goal) items scaled by n / 30.
+        for_plan: the engine will run WHOLE plans (shrinking windows), not the pinned first-iteration step the rule was fitted to — two to four
+        scenes then plan in latency mode like one (round 6, tools/experiments/plan_once_n.py with OMGX_PLAN_LATENCY: plan of 2 / 3 / 4 x 64 x 30
+        waypoints 3.63 / 3.66 / 3.71 -> 2.89 / 2.99 / 3.30 ms, 2 / 3 x 64 x 50 x 13 objects 5.20 / 5.19 -> 4.69 / 4.91; their pinned step is SLOWER in
+        latency mode — 0.0455 / 0.0444 / 0.0456 -> 0.0497 / 0.0547 / 0.0664 ms — so the default stays what it was)."""
         load = num_scenes * num_goals * max(n_waypoints, 1) / 30.0
-        if num_scenes == 1:
+        if num_scenes == 1 or (for_plan and num_scenes <= (4 if n_waypoints <= 32 else 3)):
             return {"latency_mode": True, "goal_parts": 1, "pipeline": 1}
         if n_waypoints >= cls.WIDE_WINDOW_FROM and num_scenes * num_goals <= 4096:
             # Plans of 57-64 waypoints (round 6): the library runs their whole goals on EIGHT-wave workgroups (two per CU by LDS either way:
@@ -150,12 +154,12 @@ class ChompEngine:
         return {"latency_mode": False, "goal_parts": gp, "pipeline": max(1, min(pipe, num_scenes))}
 
     @classmethod
-    def auto(cls, model, batch, cfg, start, goal_set, layout_scenes: "int | None" = None, **kw) -> "ChompEngine":
+    def auto(cls, model, batch, cfg, start, goal_set, layout_scenes: "int | None" = None, for_plan: bool = False, **kw) -> "ChompEngine":
         """An engine laid out by ChompEngine.layout for its shape.  `layout_scenes`: the scene count the RULE is evaluated for —
         in a multi-rank job every rank passes the same number (the largest shard, ceil(total / world)), so that shards of 13 and
         12 scenes run the same layout and stay bit-comparable with each other and with a single-process run given that number."""
         S, G = goal_set.shape[0], goal_set.shape[1]
-        lay = cls.layout(S if layout_scenes is None else int(layout_scenes), G, cfg.timesteps)
+        lay = cls.layout(S if layout_scenes is None else int(layout_scenes), G, cfg.timesteps, for_plan=for_plan)
         if lay["latency_mode"] and S > 4:  # the latency-mode kernel runs two workgroups per CU: a rule evaluated for another size must not force it on a batch
             lay = dict(lay, latency_mode=False, goal_parts=4)
         eng = cls(model, batch, cfg, start, goal_set, latency_mode=lay["latency_mode"], goal_parts=lay["goal_parts"], **kw)

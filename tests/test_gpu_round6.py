@@ -291,3 +291,24 @@ def test_the_library_picks_the_goal_workgroups_width_by_the_window(dev, request)
         assert variant(2, 8, 50, goal_parts=2) == 0x300 | 4 and variant(2, 8, 30, goal_parts=2) == 0x200 | 4
     finally:
         f(-1)
+
+
+def test_an_engine_laid_out_for_plans_agrees_with_the_default_one(dev):
+    """ChompEngine.auto(for_plan=True): two to four scenes plan in latency mode (round 6: whole plans are faster there, the pinned step is
+    not).  Same goals, trajectories at 1e-9 (a goal's cost is summed in another number of parts), the oracle's bars."""
+    import bench
+    from omg_planner_amd.engine import ChompEngine
+    from oracle.check import engine_vs_oracle
+    cfg, model, batch, start, goals = bench.build_workload(3, 16, 30, 24, 5, False)
+    a = ChompEngine.auto(model, batch, copy.deepcopy(cfg), start, goals, device=dev, ol_alg="MD")
+    b = ChompEngine.auto(model, batch, copy.deepcopy(cfg), start, goals, device=dev, ol_alg="MD", for_plan=True)
+    assert b.latency and not a.latency and b.layout_used["latency_mode"]
+    a.plan(early_stop=False)
+    b.plan(early_stop=False)
+    torch.cuda.synchronize()
+    assert torch.equal(a.goal_idx, b.goal_idx)
+    np.testing.assert_allclose(b.traj.cpu().numpy(), a.traj.cpu().numpy(), rtol=0, atol=1e-9)
+    c = ChompEngine.auto(model, batch, copy.deepcopy(cfg), start, goals, device=dev, ol_alg="MD", for_plan=True)
+    c.select_initial_goal()
+    r = engine_vs_oracle(c, batch, [0, 1, 2], steps=12, pin_window=False)
+    assert r["goal_idx_equal"] and r["max_traj_err"] <= 1e-6 and r["max_cost_rel_err"] <= 1e-5, r

@@ -9,8 +9,12 @@ from omg_planner_amd.engine import ChompEngine
 S, G, n, obj = (int(x) for x in sys.argv[1:5])
 early = bool(int(sys.argv[5])) if len(sys.argv) > 5 else False
 cfg, model, batch, start, goals = bench.build_workload(S, G, n, 64, 0, False, num_objects=obj)
-eng = ChompEngine.auto(model, batch, copy.deepcopy(cfg), start, goals, layout_scenes=S, device=torch.device("cuda:0"), ol_alg="MD")
 import os
+if os.environ.get("OMGX_PLAN_LATENCY"):
+    eng = ChompEngine(model, batch, copy.deepcopy(cfg), start, goals, device=torch.device("cuda:0"), ol_alg="MD", latency_mode=True)
+    eng.layout_used = {"latency_mode": True}
+else:
+    eng = ChompEngine.auto(model, batch, copy.deepcopy(cfg), start, goals, layout_scenes=S, device=torch.device("cuda:0"), ol_alg="MD")
 if os.environ.get("OMGX_PLAN_PIPELINE"):
     eng.pipeline = int(os.environ["OMGX_PLAN_PIPELINE"])
 snap = eng.snapshot()
