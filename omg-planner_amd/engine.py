@@ -143,6 +143,11 @@ class ChompEngine:
             # against (1, 3) 0.126; 8 x 64 (2, 2) 0.125, (2, 3) 0.120 against 0.170; 16 x 64 (2, 2) 0.165 against 0.189 — (1, 1) 0.183,
             # (2, 3) 0.193; 32 x 64 and 16 x 128: whole goals again ((1, 3) 0.275 / 0.256 against (2, 2) 0.297 / 0.261)
             return {"latency_mode": False, "goal_parts": 2, "pipeline": max(1, min(2, num_scenes))}
+        if for_plan and n_waypoints <= 40 and load <= 896:
+            # whole plans of small batches: split goals repeat the prologue in every part, and late in a plan the prologue is most of a goal —
+            # plan of 5 / 6 / 8 / 12 x 64 and 6 x 128: 3.62 / 3.50 / 3.49 / 3.74 / 3.68 ms by the rule below, 3.44 / 3.43 / 3.46 / 3.58 / 3.51 with whole goals
+            # on two pipeline parts (profiles/r06i_ab_plan_layout.log; three parts: 4.0-4.7)
+            return {"latency_mode": False, "goal_parts": 1, "pipeline": max(1, min(2, num_scenes))}
         if load <= 320:
             gp, pipe = 4, 2
         elif load <= 896:

@@ -139,7 +139,7 @@ def test_layout_rule_is_a_pure_function_of_the_shape():
     # round 6: an engine built for whole plans runs two to four scenes in latency mode (three beyond 32 waypoints); the default is unchanged
     assert L(2, 64, for_plan=True)["latency_mode"] and L(4, 64, for_plan=True)["latency_mode"] and not L(5, 64, for_plan=True)["latency_mode"]
     assert L(3, 64, 50, for_plan=True)["latency_mode"] and not L(4, 64, 50, for_plan=True)["latency_mode"] and not L(2, 64)["latency_mode"]
-    assert L(13, 128, for_plan=True) == L(13, 128)
+    assert L(13, 128, for_plan=True) == L(13, 128) and L(8, 64, for_plan=True) == {"latency_mode": False, "goal_parts": 1, "pipeline": 2} and L(8, 64, 50, for_plan=True) == L(8, 64, 50)
     assert all(L(s, g)["pipeline"] <= s for s in (1, 2, 3) for g in (8, 64, 512))
     assert L(13, 128) == L(13, 128)  # no hidden state
     # BASELINE config 4 on 8 ranks: shards of 13 and 12 scenes, one layout

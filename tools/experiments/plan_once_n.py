@@ -13,6 +13,9 @@ import os
 if os.environ.get("OMGX_PLAN_LATENCY"):
     eng = ChompEngine(model, batch, copy.deepcopy(cfg), start, goals, device=torch.device("cuda:0"), ol_alg="MD", latency_mode=True)
     eng.layout_used = {"latency_mode": True}
+elif os.environ.get("OMGX_PLAN_GOAL_PARTS"):
+    eng = ChompEngine(model, batch, copy.deepcopy(cfg), start, goals, device=torch.device("cuda:0"), ol_alg="MD", goal_parts=int(os.environ["OMGX_PLAN_GOAL_PARTS"]))
+    eng.layout_used = {"goal_parts": int(os.environ["OMGX_PLAN_GOAL_PARTS"])}
 else:
     eng = ChompEngine.auto(model, batch, copy.deepcopy(cfg), start, goals, layout_scenes=S, device=torch.device("cuda:0"), ol_alg="MD")
 if os.environ.get("OMGX_PLAN_PIPELINE"):
